@@ -1,0 +1,319 @@
+// Field arithmetic in GF(2^255-19) for the MI355X Ed25519 engine.
+//
+// Replaces (functionally) /root/reference src/group/edwards25519/fe.rs — fe_mul (fe.rs:299-535),
+// fe_square (fe.rs:544-688), fe_invert (fe.rs:857-944), fe_pow22523 (fe.rs:946-1035),
+// fe_from_bytes / fe_to_bytes (fe.rs:67-122,147-238) — but is NOT a transcription of it:
+//
+//  * limbs are UNSIGNED, radix 2^25.5 (26,25,26,25,... bits) in ten 32-bit VGPRs; products are
+//    accumulated with v_mad_u64_u32 (32x32+64->64), the only wide integer multiply gfx950 has.
+//    A "51-bit limb" (north_star wording) is one even/odd limb pair; gfx950 has no 64x64 multiplier,
+//    so the pair is kept as two VGPRs and one 51x51 product is four v_mad_u64_u32.
+//  * columns are evaluated serially and the carry of column k is the 64-bit addend of the first
+//    multiply-add of column k+1, so carry propagation costs 3 VALU ops per limb instead of 8.
+//  * subtraction adds a limb-wise multiple of p (no signed limbs, no rounding carries).
+//
+// Bounds notation: T_i = 2^26 (even i) / 2^25 (odd i).  "kT" means limb_i <= k*T_i for every i.
+//   tight   : <= 1.01T   (output of fe_mul / fe_sq / fe_reduce_weak)
+//   fe_mul(h, f, g): f <= 6T, g <= 3.3T   (19*g_i and 2*f_odd must fit 32 bits, column sums 64 bits)
+//   fe_sq(h, f)    : f <= 3.3T
+// The same source is compiled by g++ for tests/ (KYB_HOST_TEST) where every multiply is shadowed by a
+// 128-bit overflow check; that host build is test infrastructure, never a product code path.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define KYB_HD __host__ __device__ __forceinline__
+#define KYB_UNROLL _Pragma("unroll")
+#else
+#define KYB_HD inline
+#define KYB_UNROLL
+#endif
+
+#include "consts.inc"
+
+namespace kyb {
+
+struct fe {
+  uint32_t v[10];
+};
+
+#define KYB_BITS(i) (((i) & 1) ? 25 : 26)
+#define KYB_MASK(i) (((i) & 1) ? 0x1ffffffu : 0x3ffffffu)
+
+#if defined(KYB_HOST_TEST)
+// overflow shadow check for the host-compiled test build
+extern "C" void kyb_host_overflow(const char* what);
+static inline uint64_t kyb_mad(uint32_t a, uint32_t b, uint64_t c) {
+  unsigned __int128 w = (unsigned __int128)a * b + c;
+  if (w >> 64) kyb_host_overflow("mad64");
+  return (uint64_t)w;
+}
+static inline uint32_t kyb_mul32(uint32_t a, uint32_t b, const char* what) {
+  uint64_t w = (uint64_t)a * b;
+  if (w >> 32) kyb_host_overflow(what);
+  return (uint32_t)w;
+}
+static inline uint32_t kyb_sub32(uint32_t a, uint32_t b, const char* what) {
+  if (b > a) kyb_host_overflow(what);
+  return a - b;
+}
+static inline uint32_t kyb_add32(uint32_t a, uint32_t b, const char* what) {
+  uint64_t w = (uint64_t)a + b;
+  if (w >> 32) kyb_host_overflow(what);
+  return (uint32_t)w;
+}
+#else
+KYB_HD uint64_t kyb_mad(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+KYB_HD uint32_t kyb_mul32(uint32_t a, uint32_t b, const char*) { return a * b; }
+KYB_HD uint32_t kyb_sub32(uint32_t a, uint32_t b, const char*) { return a - b; }
+KYB_HD uint32_t kyb_add32(uint32_t a, uint32_t b, const char*) { return a + b; }
+#endif
+
+KYB_HD uint32_t kyb_x19(uint32_t a) { return kyb_mul32(a, 19u, "x19"); }
+
+KYB_HD void fe_zero(fe& h) {
+  KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = 0;
+}
+KYB_HD void fe_one(fe& h) {
+  h.v[0] = 1;
+  KYB_UNROLL for (int i = 1; i < 10; ++i) h.v[i] = 0;
+}
+KYB_HD void fe_copy(fe& h, const fe& f) {
+  KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = f.v[i];
+}
+// h = f + g, no carry: bound(h) = bound(f) + bound(g)
+KYB_HD void fe_add(fe& h, const fe& f, const fe& g) {
+  KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = kyb_add32(f.v[i], g.v[i], "fe_add");
+}
+// h = f - g computed as f + 2p - g; requires g <= 1.99T; bound(h) = bound(f) + 2T
+KYB_HD void fe_sub(fe& h, const fe& f, const fe& g) {
+  const uint32_t p2[10] = KYB_FE_2P;
+  KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = kyb_add32(f.v[i], kyb_sub32(p2[i], g.v[i], "fe_sub"), "fe_sub+");
+}
+// h = f - g computed as f + 4p - g; requires g <= 3.99T; bound(h) = bound(f) + 4T
+KYB_HD void fe_sub4(fe& h, const fe& f, const fe& g) {
+  const uint32_t p4[10] = KYB_FE_4P;
+  KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = kyb_add32(f.v[i], kyb_sub32(p4[i], g.v[i], "fe_sub4"), "fe_sub4+");
+}
+// h = -f = 2p - f; requires f <= 1.99T; h <= 2T
+KYB_HD void fe_neg(fe& h, const fe& f) {
+  const uint32_t p2[10] = KYB_FE_2P;
+  KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = kyb_sub32(p2[i], f.v[i], "fe_neg");
+}
+// h = c ? g : f  (lowered to v_cndmask_b32; c is 0/1)
+KYB_HD void fe_select(fe& h, const fe& f, const fe& g, uint32_t c) {
+  KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = c ? g.v[i] : f.v[i];
+}
+KYB_HD void fe_cmov(fe& h, const fe& g, uint32_t c) {
+  KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = c ? g.v[i] : h.v[i];
+}
+KYB_HD void fe_cswap(fe& f, fe& g, uint32_t c) {
+  KYB_UNROLL for (int i = 0; i < 10; ++i) {
+    uint32_t a = f.v[i], b = g.v[i];
+    f.v[i] = c ? b : a;
+    g.v[i] = c ? a : b;
+  }
+}
+
+// One parallel carry pass: any 32-bit limbs in, tight (<= 1.01T) out.  30 VALU ops.
+KYB_HD void fe_reduce_weak(fe& h, const fe& f) {
+  uint32_t c[10];
+  KYB_UNROLL for (int i = 0; i < 10; ++i) c[i] = f.v[i] >> KYB_BITS(i);
+  h.v[0] = (f.v[0] & KYB_MASK(0)) + 19u * c[9];  // c[9] <= 2^7
+  KYB_UNROLL for (int i = 1; i < 10; ++i) h.v[i] = (f.v[i] & KYB_MASK(i)) + c[i - 1];
+}
+
+// h = f*g.  f <= 6T, g <= 3.3T.  100 v_mad_u64_u32 + ~50 VALU.  Output tight.
+KYB_HD void fe_mul(fe& h, const fe& f, const fe& g) {
+  uint32_t g19[10], f2[10];
+  KYB_UNROLL for (int i = 1; i < 10; ++i) g19[i] = kyb_x19(g.v[i]);
+  KYB_UNROLL for (int i = 1; i < 10; i += 2) f2[i] = kyb_add32(f.v[i], f.v[i], "f2");
+  g19[0] = 0; f2[0] = f2[2] = f2[4] = f2[6] = f2[8] = 0;
+  uint64_t acc = 0;
+  uint32_t r[10];
+  KYB_UNROLL for (int k = 0; k < 10; ++k) {
+    KYB_UNROLL for (int i = 0; i < 10; ++i) {
+      const int j = (k - i + 10) % 10;
+      const bool wrap = i > k;
+      const uint32_t fi = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
+      const uint32_t gj = wrap ? g19[j] : g.v[j];
+      acc = kyb_mad(fi, gj, acc);
+    }
+    r[k] = (uint32_t)acc & KYB_MASK(k);
+    acc >>= KYB_BITS(k);
+  }
+  // acc < 2^39: fold 19*acc into limb 0 and ripple once into limb 1
+  uint64_t t = (uint64_t)r[0] + acc * 19u;
+  h.v[0] = (uint32_t)t & KYB_MASK(0);
+  h.v[1] = r[1] + (uint32_t)(t >> 26);
+  KYB_UNROLL for (int i = 2; i < 10; ++i) h.v[i] = r[i];
+}
+
+// h = f^2.  f <= 3.3T.  55 v_mad_u64_u32.  Output tight.
+KYB_HD void fe_sq(fe& h, const fe& f) {
+  uint32_t f2[10], f19[10], f38[10];
+  KYB_UNROLL for (int i = 0; i < 10; ++i) f2[i] = kyb_add32(f.v[i], f.v[i], "sq f2");
+  KYB_UNROLL for (int i = 0; i < 10; ++i) { f19[i] = 0; f38[i] = 0; }
+  KYB_UNROLL for (int i = 5; i < 10; ++i) f19[i] = kyb_x19(f.v[i]);
+  KYB_UNROLL for (int i = 5; i < 10; i += 2) f38[i] = kyb_add32(f19[i], f19[i], "sq f38");
+  uint64_t acc = 0;
+  uint32_t r[10];
+  KYB_UNROLL for (int k = 0; k < 10; ++k) {
+    KYB_UNROLL for (int i = 0; i < 10; ++i) {
+      const int j = (k - i + 10) % 10;
+      if (i > j) continue;                    // each unordered pair once
+      const bool wrap = (i + j) >= 10;
+      const bool cross = (i != j);
+      const bool oo = (i & 1) && (j & 1);
+      // multiplier = (cross?2:1) * (oo?2:1) * (wrap?19:1), split between the two operands
+      uint32_t a, b;
+      if (!wrap) { a = cross ? f2[i] : f.v[i]; b = oo ? f2[j] : f.v[j]; }
+      else       { a = cross ? f2[i] : f.v[i]; b = oo ? f38[j] : f19[j]; }
+      acc = kyb_mad(a, b, acc);
+    }
+    r[k] = (uint32_t)acc & KYB_MASK(k);
+    acc >>= KYB_BITS(k);
+  }
+  uint64_t t = (uint64_t)r[0] + acc * 19u;
+  h.v[0] = (uint32_t)t & KYB_MASK(0);
+  h.v[1] = r[1] + (uint32_t)(t >> 26);
+  KYB_UNROLL for (int i = 2; i < 10; ++i) h.v[i] = r[i];
+}
+
+// h = f^(2^n), n >= 1 (rolled loop: one copy of the squaring body per call site)
+KYB_HD void fe_sqn(fe& h, const fe& f, int n) {
+  fe_sq(h, f);
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+  for (int i = 1; i < n; ++i) fe_sq(h, h);
+}
+
+// z^(2^250-1) and z^11, the shared prefix of both exponentiations
+KYB_HD void fe_pow_250_1(fe& z250, fe& z11, const fe& z) {
+  fe z2, z9, t, z5, z10, z20, z50, z100;
+  fe_sq(z2, z);               // 2
+  fe_sqn(t, z2, 2);           // 8
+  fe_mul(z9, t, z);           // 9
+  fe_mul(z11, z9, z2);        // 11
+  fe_sq(t, z11);              // 22
+  fe_mul(z5, t, z9);          // 2^5-1
+  fe_sqn(t, z5, 5);
+  fe_mul(z10, t, z5);         // 2^10-1
+  fe_sqn(t, z10, 10);
+  fe_mul(z20, t, z10);        // 2^20-1
+  fe_sqn(t, z20, 20);
+  fe_mul(t, t, z20);          // 2^40-1
+  fe_sqn(t, t, 10);
+  fe_mul(z50, t, z10);        // 2^50-1
+  fe_sqn(t, z50, 50);
+  fe_mul(z100, t, z50);       // 2^100-1
+  fe_sqn(t, z100, 100);
+  fe_mul(t, t, z100);         // 2^200-1
+  fe_sqn(t, t, 50);
+  fe_mul(z250, t, z50);       // 2^250-1
+}
+// h = z^(p-2) = z^(2^255-21): 254 squarings + 11 multiplications (same count as fe.rs:857-944)
+KYB_HD void fe_invert(fe& h, const fe& z) {
+  fe z250, z11;
+  fe_pow_250_1(z250, z11, z);
+  fe_sqn(z250, z250, 5);
+  fe_mul(h, z250, z11);
+}
+// h = z^((p-5)/8) = z^(2^252-3)  (fe.rs:946-1035)
+KYB_HD void fe_pow22523(fe& h, const fe& z) {
+  fe z250, z11;
+  fe_pow_250_1(z250, z11, z);
+  fe_sqn(z250, z250, 2);
+  fe_mul(h, z250, z);
+}
+
+// Canonical limbs (value in [0,p), limb_i < 2^bits_i).  Input: any limbs <= 2^31.
+KYB_HD void fe_canon(fe& h, const fe& f) {
+  uint32_t v[10];
+  KYB_UNROLL for (int i = 0; i < 10; ++i) v[i] = f.v[i];
+  // two sequential carry passes -> every limb within its mask, value < 2^255
+  KYB_UNROLL for (int pass = 0; pass < 2; ++pass) {
+    uint32_t c = 0;
+    KYB_UNROLL for (int i = 0; i < 10; ++i) {
+      v[i] += c;
+      c = v[i] >> KYB_BITS(i);
+      v[i] &= KYB_MASK(i);
+    }
+    v[0] += 19u * c;
+  }
+  // q = 1 iff value >= p  (value + 19 >= 2^255)
+  uint32_t q = (v[0] + 19u) >> 26;
+  KYB_UNROLL for (int i = 1; i < 10; ++i) q = (v[i] + q) >> KYB_BITS(i);
+  uint32_t c = 19u * q;
+  KYB_UNROLL for (int i = 0; i < 10; ++i) {
+    v[i] += c;
+    c = v[i] >> KYB_BITS(i);
+    v[i] &= KYB_MASK(i);
+  }
+  KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = v[i];
+}
+
+// 8 little-endian 32-bit words of the canonical value (fe_to_bytes, fe.rs:147-238)
+KYB_HD void fe_to_words(uint32_t w[8], const fe& f) {
+  fe c;
+  fe_canon(c, f);
+  const uint32_t* v = c.v;
+  // bit offsets 0,26,51,77,102,128,153,179,204,230
+  w[0] = v[0] | (v[1] << 26);
+  w[1] = (v[1] >> 6) | (v[2] << 19);
+  w[2] = (v[2] >> 13) | (v[3] << 13);
+  w[3] = (v[3] >> 19) | (v[4] << 6);
+  w[4] = v[5] | (v[6] << 25);
+  w[5] = (v[6] >> 7) | (v[7] << 19);
+  w[6] = (v[7] >> 13) | (v[8] << 12);
+  w[7] = (v[8] >> 20) | (v[9] << 6);
+}
+
+// limbs from 8 LE words; bit 255 ignored, values >= p accepted as-is (fe_from_bytes, fe.rs:67-122:
+// "ignores bit 255 and does not reject y >= p").  Output limbs within masks (tight).
+KYB_HD void fe_from_words(fe& h, const uint32_t w[8]) {
+  h.v[0] = w[0] & 0x3ffffffu;
+  h.v[1] = ((w[0] >> 26) | (w[1] << 6)) & 0x1ffffffu;
+  h.v[2] = ((w[1] >> 19) | (w[2] << 13)) & 0x3ffffffu;
+  h.v[3] = ((w[2] >> 13) | (w[3] << 19)) & 0x1ffffffu;
+  h.v[4] = (w[3] >> 6) & 0x3ffffffu;
+  h.v[5] = w[4] & 0x1ffffffu;
+  h.v[6] = ((w[4] >> 25) | (w[5] << 7)) & 0x3ffffffu;
+  h.v[7] = ((w[5] >> 19) | (w[6] << 13)) & 0x1ffffffu;
+  h.v[8] = ((w[6] >> 12) | (w[7] << 20)) & 0x3ffffffu;
+  h.v[9] = (w[7] >> 6) & 0x1ffffffu;
+}
+
+// fe_is_negative (fe.rs:240-245): low bit of the canonical value
+KYB_HD uint32_t fe_is_negative(const fe& f) {
+  fe c;
+  fe_canon(c, f);
+  return c.v[0] & 1u;
+}
+// fe_is_non_zero (fe.rs:247-257)
+KYB_HD uint32_t fe_is_nonzero(const fe& f) {
+  fe c;
+  fe_canon(c, f);
+  uint32_t o = 0;
+  KYB_UNROLL for (int i = 0; i < 10; ++i) o |= c.v[i];
+  return o != 0;
+}
+
+// Import a reference-layout field element: ten SIGNED int32 limbs, radix 2^25.5 (fe.rs:4-8).
+// Accepts |limb_i| < 2^29 (the reference's own bound is 1.01*2^26): adds 16p limb-wise, then carries.
+KYB_HD void fe_from_ref10(fe& h, const int32_t s[10]) {
+  const uint32_t p4[10] = KYB_FE_4P;
+  fe t;
+  KYB_UNROLL for (int i = 0; i < 10; ++i) t.v[i] = (uint32_t)(s[i] + (int32_t)(4u * p4[i]));
+  fe_reduce_weak(h, t);
+}
+// Export canonical limbs in the reference layout (non-negative, within ref10's input bounds)
+KYB_HD void fe_to_ref10(int32_t s[10], const fe& f) {
+  fe c;
+  fe_canon(c, f);
+  KYB_UNROLL for (int i = 0; i < 10; ++i) s[i] = (int32_t)c.v[i];
+}
+
+}  // namespace kyb
