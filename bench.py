@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Ed25519 scalar-mults/sec on MI355X (BASELINE.json `metric`).
+
+  python bench.py --gpus N --steps K --warmup W [--workload mul|mul_base|sign] [--n ITEMS_PER_GPU]
+
+A "step" = one pass of the hot path over one batch that is already resident in HBM:
+  mul       2^20 variable-base mults, random scalars + random points   (BASELINE configs[1], default)
+  mul_base  2^20 fixed-base mults                                       (configs[2])
+  sign      2^18 Schnorr signatures, 32-byte messages                   (configs[3])
+For N > 1 the driver launches one process per GPU (torch.distributed.run); every rank owns its own
+shard of N x ITEMS_PER_GPU independent items (weak scaling, no data-path collective).  The only
+collective is the one-time RCCL broadcast of the 64 KiB base-point table built on rank 0.
+
+Rank 0 prints ONE JSON line.  `value` is whole-job items/s over the timed K steps (barrier +
+synchronize on both sides, max over ranks).  `roofline` prices the dominant kernel against the
+MEASURED v_mad_u64_u32 issue peak of the chip (profiles/r01_valu_rates_mi355x.jsonl): the path is
+integer-VALU bound by construction (BASELINE.json north_star), not HBM or MFMA bound, so the object
+carries `bound: "valu-int"` and additionally reports the (negligible) algorithmic HBM rate.
+`cpu_baseline` times the oracle — a C port of the reference algorithm, NOT the Rust binary — on this
+box's host cores (rank 0, N = 1 only)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# algorithmic 32x32->64 multiply(-add)s per unit, fixed by the reference's algorithm
+PRODUCTS = {"mul": 203_910, "mul_base": 62_250, "sign": 124_500}
+ALG_BYTES = {"mul": 32 + 160 + 32, "mul_base": 32 + 32, "sign": 32 + 32 + 32 + 64}
+UNIT = {"mul": "variable-base scalar-mults/s", "mul_base": "fixed-base scalar-mults/s", "sign": "signatures/s"}
+KERNEL = {"mul": "k_mul", "mul_base": "k_mul_base", "sign": "k_sign"}
+# measured on MI355X: 26.8e12 v_mad_u64_u32 lane-ops/s with every SIMD issuing (8 waves/SIMD, clock
+# settles at ~1.9 GHz under this load) — tools/microbench/valu_rates.hip
+PEAK_MAD_PER_S = 26.8e12
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="mul", choices=["mul", "mul_base", "sign"])
+    ap.add_argument("--n", type=int, default=0, help="items per GPU (default 2^20, 2^18 for sign)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", type=int, default=1024, help="items verified against the oracle after timing")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import kyber_rs_amd
+    import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- engine + base-point table (RCCL broadcast of rank 0's image over xGMI) ----
+    eng = kyber_rs_amd.Engine(local, build_table=(rank == 0))
+    if world > 1:
+        tbl = torch.empty(kyber_rs_amd.BASE_TABLE_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            eng.base_table_export_dev(tbl)
+            eng.sync()
+        dist.broadcast(tbl, src=0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            eng.base_table_import_dev(tbl)
+
+    wl = args.workload
+    n = args.n or ((1 << 18) if wl == "sign" else (1 << 20))
+    seed = 1 + rank          # every rank gets its own shard of the synthetic stream
+    t0 = time.time()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- synthetic inputs, resident in HBM before the timed region ----
+    sc_np = synth.scalars(n, seed)
+    sc = torch.from_numpy(sc_np).to(dev)
+    out = torch.empty((n, 64 if wl == "sign" else 32), dtype=torch.uint8, device=dev)
+    pts = k = msgs = off = None
+    if wl == "mul":
+        psc = torch.from_numpy(synth.scalars(n, seed, b"point")).to(dev)
+        pts = torch.empty((n, 40), dtype=torch.int32, device=dev)        # point_i = (hash mod L) * B, reference limbs
+        eng.mul_base_dev(psc, out_ext=pts, stream=stream)
+    elif wl == "sign":
+        k = torch.from_numpy(synth.scalars(n, seed, b"k")).to(dev)
+        msg_list = synth.messages(n, seed)
+        msgs = torch.from_numpy(np.frombuffer(b"".join(msg_list), dtype=np.uint8).copy()).to(dev)
+        off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+
+    def step():
+        if wl == "mul":
+            eng.mul_dev(sc, pts_ext=pts, out_enc=out, stream=stream)
+        elif wl == "mul_base":
+            eng.mul_base_dev(sc, out_enc=out, stream=stream)
+        else:
+            eng.sign_dev(sc, k, msgs, off, out, stream=stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t_start = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        step()
+        b.record()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    kern_ms = [a.elapsed_time(b) for a, b in evs]     # HIP events on the launch stream: one launch per step
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- parity spot-check of this rank's outputs against the oracle (outside the timed region) ----
+    checked = 0
+    cpu = None
+    if rank == 0:
+        import oracle_lib
+        orc = oracle_lib.Oracle()
+        m = min(args.check, n)
+        idx = np.random.default_rng(0).choice(n, m, replace=False)
+        got = out[torch.from_numpy(idx).to(dev)].cpu().numpy()
+        threads = os.cpu_count() or 1
+        if wl == "mul":
+            want = orc.mul_batch(sc_np[idx], pts[torch.from_numpy(idx).to(dev)].cpu().numpy(), nthreads=threads)
+        elif wl == "mul_base":
+            want = orc.mul_base_batch(sc_np[idx], nthreads=threads)
+        else:
+            want = orc.schnorr_sign_batch(sc_np[idx], k[torch.from_numpy(idx).to(dev)].cpu().numpy(), [msg_list[i] for i in idx], nthreads=threads)
+        if not np.array_equal(got, want):
+            raise SystemExit("PARITY FAILURE: GPU output differs from the oracle")
+        checked = m
+
+        # ---- CPU baseline: the oracle (C port of the reference algorithm) on a bounded sample ----
+        if world == 1 and not args.no_cpu_baseline:
+            per_core = {"mul": 1 << 14, "mul_base": 1 << 15, "sign": 1 << 14}[wl]
+
+            def run(cnt, th):
+                sub = np.arange(cnt) % n
+                t1 = time.perf_counter()
+                if wl == "mul":
+                    orc.mul_batch(sc_np[sub], pts_cpu[sub], nthreads=th)
+                elif wl == "mul_base":
+                    orc.mul_base_batch(sc_np[sub], nthreads=th)
+                else:
+                    orc.schnorr_sign_batch(sc_np[sub], k_cpu[sub], [msg_list[i] for i in sub], nthreads=th)
+                return cnt / (time.perf_counter() - t1)
+
+            cnt_all = per_core * threads
+            pts_cpu = pts[: min(n, cnt_all)].cpu().numpy() if wl == "mul" else None
+            k_cpu = k[: min(n, cnt_all)].cpu().numpy() if wl == "sign" else None
+            one = run(min(per_core, n), 1)
+            allc = run(min(cnt_all, n), threads)
+            cpu = {"value": round(allc, 1), "unit": UNIT[wl], "cores": threads, "kind": "port",
+                   "value_1core": round(one, 1),
+                   "sample": f"oracle/ed25519_oracle.c (C restatement of the reference algorithm, gcc -O3 -march=native; not the Rust binary): "
+                             f"{min(cnt_all, n)} items of the same workload on {threads} threads, {min(per_core, n)} items on 1 thread"}
+
+    if rank == 0:
+        total_items = n * world * args.steps
+        value = total_items / elapsed
+        avg_ms = sum(kern_ms) / len(kern_ms)
+        mad_rate = PRODUCTS[wl] * n / (avg_ms * 1e-3)
+        line = {
+            "metric": "Ed25519 scalar-mults/sec" if wl != "sign" else "Ed25519 Schnorr signatures/sec",
+            "value": round(value, 1), "unit": UNIT[wl], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 limbs (radix 2^25.5), u64 accumulators", "data": "synthetic",
+            "config": {"workload": {"mul": "2^20 variable-base scalar-mults, random scalars+points, reference-limb points in, 32-byte encodings out",
+                                    "mul_base": "2^20 fixed-base (generator) scalar-mults, 32-byte encodings out",
+                                    "sign": "2^18 Schnorr signs, 32-byte messages, 64-byte signatures out"}[wl] if not args.n else f"{wl} x {n} per GPU",
+                       "items_per_gpu": n, "sharding": f"independent shards x{world}, no data-path collective; one RCCL table broadcast at init",
+                       "select": {"mul": eng.get_option("mul.select"), "mul_base": eng.get_option("mul_base.select")}},
+            "roofline": {"bound": "valu-int", "kernel": KERNEL[wl], "achieved": round(mad_rate / 1e12, 3), "peak": PEAK_MAD_PER_S / 1e12,
+                         "unit": "T(32x32+64 mad)/s", "frac": round(mad_rate / PEAK_MAD_PER_S, 4),
+                         "algorithmic_mads_per_item": PRODUCTS[wl], "avg_kernel_ms": round(avg_ms, 4),
+                         "traffic": None,
+                         "hbm": {"achieved": round(ALG_BYTES[wl] * n / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(ALG_BYTES[wl] * n / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_item": ALG_BYTES[wl]}},
+            "cpu_baseline": cpu,
+            "parity_checked_items": checked, "input_gen_s": round(gen_s, 2),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+/*
+ * kyber_ed25519.h — C ABI of the MI355X-native batched Ed25519 engine.
+ *
+ * Drop-in boundary for the `impl group::Point for Point` of teleconsys/kyber-rs
+ * (/root/reference src/group/edwards25519/point.rs:75-225).  The reference has no FFI of its own;
+ * these are the entry points its Rust side would bind (INTEGRATION.md shows the `extern "C"` block
+ * and the trait impl that forwards to them).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   scalar     32 bytes little-endian, exactly `Scalar.v` (scalar.rs:23-26).  NOT reduced or range
+ *              checked: clamped EdDSA keys and scalars >= 2^255 behave as in ge.rs:442-568.
+ *   enc        32-byte point encoding = `Point::marshal_binary` (point.rs:35-41, ge.rs:112-122).
+ *   ext        40 x int32: X[10] Y[10] Z[10] T[10], radix-2^25.5 limbs = `Point.ge`
+ *              (`ExtendedGroupElement`, ge.rs:78-83).  Inputs may be any limbs the reference itself
+ *              produces (|limb| < 2^29 accepted); outputs are canonical non-negative limbs.
+ *   return     0 = ok; negative = KYB_E_* (nothing is written on error except where noted).
+ *   threading  every call may be made from any thread; calls are serialised on the engine's stream.
+ *   memory     the caller owns every buffer; the library keeps no pointer after return.
+ *
+ * Two flavours of every batch call:
+ *   kyb_xxx_batch      host pointers; H2D copy, kernel, D2H copy, synchronous.
+ *   kyb_xxx_batch_dev  device pointers (HBM-resident batches); asynchronous on `stream`
+ *                      (a hipStream_t passed as void*, NULL = the engine's own stream).
+ *
+ * There is NO CPU implementation behind this ABI: without a usable gfx950 device kyb_init fails
+ * with KYB_E_NO_DEVICE and every other call returns KYB_E_NOT_INIT.
+ */
+#ifndef KYBER_ED25519_H
+#define KYBER_ED25519_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KYB_OK 0
+#define KYB_E_NOT_INIT (-1)
+#define KYB_E_BAD_ARG (-2)
+#define KYB_E_NO_DEVICE (-3)
+#define KYB_E_HIP (-4)
+#define KYB_E_NOMEM (-5)
+
+/* table image exchanged between GPUs at init: uint32 [64 pos][8 quads][8 entries][4] = 65,536 bytes.
+ * Entry (pos, j) = (j+1) * 16^pos * B as affine (y+x, y-x, 2dxy), canonical limbs — the role of
+ * constants.rs:89 BASE (which holds the 32 even positions only). */
+#define KYB_BASE_TABLE_BYTES 65536u
+
+/* ---- lifecycle -------------------------------------------------------------------------------- */
+/* Bind this process to HIP device `device`, allocate the workspace, build the base-point table on
+ * the GPU.  Idempotent for the same device.  (One process per GPU: see DESIGN.md §multi-GPU.) */
+int kyb_init(int device);
+/* Same, but leave the base table empty: the caller fills it with kyb_base_table_import_dev after
+ * receiving rank 0's image over RCCL (torch.distributed.broadcast). */
+int kyb_init_no_table(int device);
+void kyb_shutdown(void);
+/* human-readable text of the last failure on the calling thread ("" if none) */
+const char* kyb_last_error(void);
+/* device name, CU count, bytes of workspace; any pointer may be NULL */
+int kyb_device_info(char* name, size_t name_cap, int* compute_units, size_t* workspace_bytes);
+/* block until everything queued on `stream` (NULL = engine stream) has finished */
+int kyb_sync(void* stream);
+
+/* ---- base-point table (multi-GPU init) -------------------------------------------------------- */
+int kyb_base_table_export_dev(void* dst_dev, void* stream);        /* engine table -> dst (device)  */
+int kyb_base_table_import_dev(const void* src_dev, void* stream);  /* src (device) -> engine table  */
+int kyb_base_table_export(uint8_t* dst_host);                      /* engine table -> host buffer   */
+
+/* ---- Point::mul(s, None): fixed base — ge_scalar_mult_base, ge.rs:442-486 --------------------- */
+/* out_enc (n x 32) and/or out_ext (n x 40 int32, Z = 1) may be NULL, not both. */
+int kyb_mul_base_batch(const uint8_t* scalars, size_t n, uint8_t* out_enc, int32_t* out_ext);
+int kyb_mul_base_batch_dev(const uint8_t* scalars, size_t n, uint8_t* out_enc, int32_t* out_ext, void* stream);
+
+/* ---- Point::mul(s, Some(P)): variable base — ge_scalar_mult, ge.rs:508-568 -------------------- */
+/* Exactly one of pts_enc (n x 32, decoded on the GPU as unmarshal_binary does) / pts_ext (n x 40).
+ * ok (n bytes, may be NULL unless pts_enc is given): 1 = point decoded, 0 = invalid encoding (the
+ * outputs of that item are then the encoding of the neutral element / unspecified limbs). */
+int kyb_mul_batch(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, size_t n,
+                  uint8_t* out_enc, int32_t* out_ext, uint8_t* ok);
+int kyb_mul_batch_dev(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, size_t n,
+                      uint8_t* out_enc, int32_t* out_ext, uint8_t* ok, void* stream);
+
+/* ---- Point::add / Point::sub, point.rs:179-197 (out = a +/- b, extended limbs, Z arbitrary) ---- */
+int kyb_add_batch(const int32_t* a_ext, const int32_t* b_ext, size_t n, int32_t* out_ext, int subtract);
+int kyb_add_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, int32_t* out_ext, int subtract, void* stream);
+
+/* ---- marshal_binary / unmarshal_binary, point.rs:35-51 ---------------------------------------- */
+int kyb_encode_batch(const int32_t* pts_ext, size_t n, uint8_t* out_enc);
+int kyb_encode_batch_dev(const int32_t* pts_ext, size_t n, uint8_t* out_enc, void* stream);
+/* ok[i] = 1 iff enc[i] decodes (ge.rs:124-179: non-canonical y accepted, x = 0 with sign accepted) */
+int kyb_decode_batch(const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok);
+int kyb_decode_batch_dev(const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok, void* stream);
+
+/* ---- schnorr::sign with caller-supplied nonce, schnorr_sig.rs:25-47 ---------------------------- */
+/* x, k: n x 32 scalars; msgs: concatenated messages, message i = msgs[msg_off[i] .. msg_off[i+1])
+ * (msg_off has n+1 entries); sig: n x 64 = enc(k*B) || (k + x*h mod L). */
+int kyb_schnorr_sign_batch(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* msg_off,
+                           size_t n, uint8_t* sig);
+int kyb_schnorr_sign_batch_dev(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* msg_off,
+                               size_t n, uint8_t* sig, void* stream);
+
+/* ---- introspection for benchmarks / tests ------------------------------------------------------ */
+/* kernel variant selection: key is e.g. "mul.select" / "mul_base.select"; returns
+ * KYB_E_BAD_ARG for unknown keys or values.  Defaults are the fastest measured variants. */
+int kyb_set_option(const char* key, int value);
+int kyb_get_option(const char* key, int* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KYBER_ED25519_H */

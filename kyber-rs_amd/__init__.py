@@ -1,0 +1,214 @@
+"""kyber-rs_amd — MI355X-native batched Ed25519 scalar-multiplication engine for kyber-rs.
+
+This package is the thin Python harness over the C ABI declared in include/kyber_ed25519.h
+(implemented by csrc/kernels.hip -> libkyber_ed25519_hip.so).  It exists for tests, bench.py and
+multi-GPU bring-up over torch.distributed; the product boundary is the C ABI itself (the Rust shim in
+rust/ and the C++ mirror in host/ bind the same symbols).
+
+There is no CPU implementation here: `load_library()` raises if the HIP library has not been built,
+and `Engine()` raises if no gfx950 device is usable.  (Directory name has a hyphen; import it as
+`kyber_rs_amd`, the one-file alias package at the repo root.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libkyber_ed25519_hip.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+BASE_TABLE_BYTES = 65536
+
+KYB_OK = 0
+ERRORS = {-1: "KYB_E_NOT_INIT", -2: "KYB_E_BAD_ARG", -3: "KYB_E_NO_DEVICE", -4: "KYB_E_HIP", -5: "KYB_E_NOMEM"}
+
+# every symbol include/kyber_ed25519.h declares (tests/test_abi_symbols.py checks header <-> library)
+ABI_SYMBOLS = [
+    "kyb_init", "kyb_init_no_table", "kyb_shutdown", "kyb_last_error", "kyb_device_info", "kyb_sync",
+    "kyb_base_table_export_dev", "kyb_base_table_import_dev", "kyb_base_table_export",
+    "kyb_mul_base_batch", "kyb_mul_base_batch_dev", "kyb_mul_batch", "kyb_mul_batch_dev",
+    "kyb_add_batch", "kyb_add_batch_dev", "kyb_encode_batch", "kyb_encode_batch_dev",
+    "kyb_decode_batch", "kyb_decode_batch_dev", "kyb_schnorr_sign_batch", "kyb_schnorr_sign_batch_dev",
+    "kyb_set_option", "kyb_get_option",
+]
+
+
+class KyberHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen the in-tree HIP library; never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KyberHipError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for this engine.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    lib.kyb_init.argtypes = [i32]
+    lib.kyb_init_no_table.argtypes = [i32]
+    lib.kyb_shutdown.restype = None
+    lib.kyb_last_error.restype = ctypes.c_char_p
+    lib.kyb_device_info.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(i32), ctypes.POINTER(sz)]
+    lib.kyb_sync.argtypes = [vp]
+    lib.kyb_base_table_export_dev.argtypes = [vp, vp]
+    lib.kyb_base_table_import_dev.argtypes = [vp, vp]
+    lib.kyb_base_table_export.argtypes = [vp]
+    lib.kyb_mul_base_batch.argtypes = [vp, sz, vp, vp]
+    lib.kyb_mul_base_batch_dev.argtypes = [vp, sz, vp, vp, vp]
+    lib.kyb_mul_batch.argtypes = [vp, vp, vp, sz, vp, vp, vp]
+    lib.kyb_mul_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp]
+    lib.kyb_add_batch.argtypes = [vp, vp, sz, vp, i32]
+    lib.kyb_add_batch_dev.argtypes = [vp, vp, sz, vp, i32, vp]
+    lib.kyb_encode_batch.argtypes = [vp, sz, vp]
+    lib.kyb_encode_batch_dev.argtypes = [vp, sz, vp, vp]
+    lib.kyb_decode_batch.argtypes = [vp, sz, vp, vp]
+    lib.kyb_decode_batch_dev.argtypes = [vp, sz, vp, vp, vp]
+    lib.kyb_schnorr_sign_batch.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.kyb_schnorr_sign_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+    lib.kyb_set_option.argtypes = [ctypes.c_char_p, i32]
+    lib.kyb_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32)]
+    for name in ABI_SYMBOLS:
+        if name not in ("kyb_shutdown", "kyb_last_error"):
+            getattr(lib, name).restype = i32
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != KYB_OK:
+        msg = load_library().kyb_last_error().decode(errors="replace")
+        raise KyberHipError(f"{what} failed: {ERRORS.get(rc, rc)}: {msg}")
+
+
+def _u8(a, width: int, name: str) -> np.ndarray:
+    arr = np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8) if isinstance(a, (bytes, bytearray)) else a, dtype=np.uint8)
+    arr = arr.reshape(-1, width)
+    return arr
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Engine:
+    """One engine per process, bound to one GPU (one process per GPU)."""
+
+    def __init__(self, device: int = 0, build_table: bool = True):
+        self.lib = load_library()
+        rc = self.lib.kyb_init(device) if build_table else self.lib.kyb_init_no_table(device)
+        _check(rc, "kyb_init")
+        self.device = device
+
+    # ---- info / options -------------------------------------------------------------------------
+    def device_info(self):
+        name = ctypes.create_string_buffer(128)
+        cus, ws = ctypes.c_int(0), ctypes.c_size_t(0)
+        _check(self.lib.kyb_device_info(name, 128, ctypes.byref(cus), ctypes.byref(ws)), "kyb_device_info")
+        return {"name": name.value.decode(), "compute_units": cus.value, "workspace_bytes": ws.value}
+
+    def set_option(self, key: str, value: int) -> None:
+        _check(self.lib.kyb_set_option(key.encode(), int(value)), f"kyb_set_option({key})")
+
+    def get_option(self, key: str) -> int:
+        v = ctypes.c_int(0)
+        _check(self.lib.kyb_get_option(key.encode(), ctypes.byref(v)), f"kyb_get_option({key})")
+        return v.value
+
+    def sync(self, stream: int = 0) -> None:
+        _check(self.lib.kyb_sync(ctypes.c_void_p(stream)), "kyb_sync")
+
+    def shutdown(self) -> None:
+        self.lib.kyb_shutdown()
+
+    # ---- host-buffer API (numpy in, numpy out) ---------------------------------------------------
+    def mul_base(self, scalars, want_ext: bool = False):
+        s = _u8(scalars, 32, "scalars")
+        n = s.shape[0]
+        enc = np.empty((n, 32), dtype=np.uint8)
+        ext = np.empty((n, 40), dtype=np.int32) if want_ext else None
+        _check(self.lib.kyb_mul_base_batch(_ptr(s), n, _ptr(enc), _ptr(ext)), "kyb_mul_base_batch")
+        return (enc, ext) if want_ext else enc
+
+    def mul(self, scalars, pts_ext=None, pts_enc=None, want_ext: bool = False, want_ok: bool = False):
+        s = _u8(scalars, 32, "scalars")
+        n = s.shape[0]
+        pe = None if pts_enc is None else _u8(pts_enc, 32, "pts_enc")
+        px = None if pts_ext is None else np.ascontiguousarray(pts_ext, dtype=np.int32).reshape(-1, 40)
+        enc = np.empty((n, 32), dtype=np.uint8)
+        ext = np.empty((n, 40), dtype=np.int32) if want_ext else None
+        ok = np.empty((n,), dtype=np.uint8) if (want_ok or pe is not None) else None
+        _check(self.lib.kyb_mul_batch(_ptr(s), _ptr(pe), _ptr(px), n, _ptr(enc), _ptr(ext), _ptr(ok)), "kyb_mul_batch")
+        out = [enc]
+        if want_ext:
+            out.append(ext)
+        if want_ok:
+            out.append(ok)
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def add(self, a_ext, b_ext, subtract: bool = False):
+        a = np.ascontiguousarray(a_ext, dtype=np.int32).reshape(-1, 40)
+        b = np.ascontiguousarray(b_ext, dtype=np.int32).reshape(-1, 40)
+        out = np.empty_like(a)
+        _check(self.lib.kyb_add_batch(_ptr(a), _ptr(b), a.shape[0], _ptr(out), 1 if subtract else 0), "kyb_add_batch")
+        return out
+
+    def encode(self, pts_ext):
+        p = np.ascontiguousarray(pts_ext, dtype=np.int32).reshape(-1, 40)
+        enc = np.empty((p.shape[0], 32), dtype=np.uint8)
+        _check(self.lib.kyb_encode_batch(_ptr(p), p.shape[0], _ptr(enc)), "kyb_encode_batch")
+        return enc
+
+    def decode(self, enc):
+        e = _u8(enc, 32, "enc")
+        ext = np.empty((e.shape[0], 40), dtype=np.int32)
+        ok = np.empty((e.shape[0],), dtype=np.uint8)
+        _check(self.lib.kyb_decode_batch(_ptr(e), e.shape[0], _ptr(ext), _ptr(ok)), "kyb_decode_batch")
+        return ext, ok
+
+    def schnorr_sign(self, x, k, msgs: Sequence[bytes]):
+        xs, ks = _u8(x, 32, "x"), _u8(k, 32, "k")
+        n = xs.shape[0]
+        off = np.zeros(n + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64).astype(np.uint32)
+        blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()
+        sig = np.empty((n, 64), dtype=np.uint8)
+        _check(self.lib.kyb_schnorr_sign_batch(_ptr(xs), _ptr(ks), _ptr(blob), _ptr(off), n, _ptr(sig)), "kyb_schnorr_sign_batch")
+        return sig
+
+    def base_table(self) -> np.ndarray:
+        t = np.empty(BASE_TABLE_BYTES, dtype=np.uint8)
+        _check(self.lib.kyb_base_table_export(_ptr(t)), "kyb_base_table_export")
+        return t
+
+    # ---- device-pointer API (torch tensors resident in HBM; asynchronous on `stream`) -------------
+    @staticmethod
+    def _dp(t):
+        return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+    def mul_base_dev(self, scalars, out_enc=None, out_ext=None, stream: int = 0) -> None:
+        n = scalars.numel() // 32
+        _check(self.lib.kyb_mul_base_batch_dev(self._dp(scalars), n, self._dp(out_enc), self._dp(out_ext), ctypes.c_void_p(stream)), "kyb_mul_base_batch_dev")
+
+    def mul_dev(self, scalars, pts_ext=None, pts_enc=None, out_enc=None, out_ext=None, ok=None, stream: int = 0) -> None:
+        n = scalars.numel() // 32
+        _check(self.lib.kyb_mul_batch_dev(self._dp(scalars), self._dp(pts_enc), self._dp(pts_ext), n, self._dp(out_enc), self._dp(out_ext), self._dp(ok), ctypes.c_void_p(stream)), "kyb_mul_batch_dev")
+
+    def sign_dev(self, x, k, msgs, msg_off, sig, stream: int = 0) -> None:
+        n = x.numel() // 32
+        _check(self.lib.kyb_schnorr_sign_batch_dev(self._dp(x), self._dp(k), self._dp(msgs), self._dp(msg_off), n, self._dp(sig), ctypes.c_void_p(stream)), "kyb_schnorr_sign_batch_dev")
+
+    def base_table_export_dev(self, dst, stream: int = 0) -> None:
+        _check(self.lib.kyb_base_table_export_dev(self._dp(dst), ctypes.c_void_p(stream)), "kyb_base_table_export_dev")
+
+    def base_table_import_dev(self, src, stream: int = 0) -> None:
+        _check(self.lib.kyb_base_table_import_dev(self._dp(src), ctypes.c_void_p(stream)), "kyb_base_table_import_dev")

@@ -1,0 +1,184 @@
+// Scalar multiplication drivers: variable base (ge.rs:508-568) and fixed base (ge.rs:442-486).
+//
+// Both are written against a small "table policy" so the same source runs
+//   * on the device with the per-lane table in an HBM/L2-resident workspace (variable base) or the
+//     shared base-point table in LDS (fixed base), and
+//   * in the g++ host-test build with plain arrays (tests/ only).
+// Selection is constant-time in the reference's sense (ge.rs:423-434, 488-500): every entry of the
+// window is read by every lane and merged under a mask; no lane-dependent address is formed.
+#pragma once
+#include "ge25519.h"
+
+namespace kyb {
+
+// Variable base.  Tbl must provide:
+//   void store(int e, const ge_cached& c)          e = 0..7 (wave-uniform)
+//   void select(ge_cached& c, uint32_t mag)        c = (mag ? entry[mag-1] : identity), full scan
+//   scan_begin / scan_issue(k) / scan_merge(k) / scan_end: the same scan cut into four slices
+// out = a * P as P2 (X:Y:Z), digit handling exactly as ge.rs:519-567 (see sc_recode).
+template <class Tbl>
+KYB_HD void ge_scalarmult(ge_p2& out, const uint32_t a[8], const ge_p3& P, Tbl& tbl) {
+  sc_digits dg;
+  sc_recode(dg, a);
+
+  // table 1P..8P in cached form (ge.rs:537-543): 1M + 7 x (4M + 4M + 1M)
+  ge_cached c;
+  ge_p3_to_cached(c, P);
+  tbl.store(0, c);
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+  for (int i = 1; i < 8; ++i) {
+    ge_p1p1 t;
+    ge_p3 u;
+    ge_add(t, P, c);
+    ge_p1p1_to_p3(u, t);
+    ge_p3_to_cached(c, u);
+    tbl.store(i, c);
+  }
+
+  // Main loop.  The table scan for digit i-1 does not depend on the accumulator, so it is split into
+  // four slices (two entries each) that ride along the four doublings of window i: the loads of a
+  // slice are issued before a doubling and merged after it, which hides their L2/MALL latency
+  // behind ~2,500 cycles of field arithmetic without holding more than two entries in flight.
+  ge_p1p1 t;
+  ge_p1p1_0(t);
+  uint32_t neg = 0;
+  tbl.select(c, dg.top);                            // digit 63: not recentred, never negative
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+  for (int i = 63; i >= 0; --i) {
+    ge_p3 u;
+    ge_p1p1_to_p3(u, t);                           // 4M
+    ge_cached_cneg(c, neg);
+    ge_add(t, u, c);                               // 4M
+    if (i > 0) {
+      uint32_t mag;
+      sc_digit(mag, neg, dg, i - 1);
+      typename Tbl::scan st;
+      tbl.scan_begin(st, mag);
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+      for (int k = 0; k < 4; ++k) {                // t <<= 4: 4 x (3M + 4S)
+        typename Tbl::slice sl;
+        tbl.scan_issue(sl, k);
+        ge_p2 r;
+        ge_p1p1_to_p2(r, t);
+        ge_p2_dbl(t, r.X, r.Y, r.Z);
+        tbl.scan_merge(st, sl, k);
+      }
+      tbl.scan_end(c, st);
+    }
+  }
+  ge_p1p1_to_p2(out, t);
+}
+
+// Fixed base.  Tbl must provide:
+//   void select(ge_precomp& c, int pos, uint32_t mag)   c = (mag ? T[pos][mag-1] : identity)
+// with T[pos][j] = (j+1) * 16^pos * B in affine precomputed form, pos = 0..63.  The reference keeps
+// only the 32 even positions (constants.rs:89) and spends 4 doublings to reach the odd ones
+// (ge.rs:470-479); a 64-position table (65,536 B, one LDS image per workgroup) removes the
+// doublings and makes the loop body one mixed addition.
+template <class Tbl>
+KYB_HD void ge_scalarmult_base(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
+  sc_digits dg;
+  sc_recode(dg, a);
+  ge_p3_0(h);
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+  for (int pos = 0; pos < 64; ++pos) {
+    uint32_t mag, neg;
+    sc_digit(mag, neg, dg, pos);
+    if (pos == 63) { mag = dg.top; neg = 0; }
+    ge_precomp c;
+    tbl.select(c, pos, mag);
+    ge_precomp_cneg(c, neg);
+    ge_p1p1 t;
+    ge_madd(t, h, c);                              // 3M
+    ge_p1p1_to_p3(h, t);                           // 4M
+  }
+}
+
+// --- plain-array policies (host-test build, and the one-off device table generator) ---
+struct tbl_array_cached {
+  ge_cached e[8];
+  struct scan { ge_cached c; uint32_t mag; };
+  struct slice {};
+  KYB_HD void store(int i, const ge_cached& c) { e[i] = c; }
+  KYB_HD void merge(ge_cached& c, int i, uint32_t mag) {
+    uint32_t m = (mag == (uint32_t)(i + 1));
+    fe_cmov(c.YpX, e[i].YpX, m); fe_cmov(c.YmX, e[i].YmX, m);
+    fe_cmov(c.Z, e[i].Z, m); fe_cmov(c.T2d, e[i].T2d, m);
+  }
+  KYB_HD void select(ge_cached& c, uint32_t mag) {
+    fe_one(c.YpX); fe_one(c.YmX); fe_one(c.Z); fe_zero(c.T2d);
+    for (int i = 0; i < 8; ++i) merge(c, i, mag);
+  }
+  KYB_HD void scan_begin(scan& st, uint32_t mag) {
+    st.mag = mag;
+    fe_one(st.c.YpX); fe_one(st.c.YmX); fe_one(st.c.Z); fe_zero(st.c.T2d);
+  }
+  KYB_HD void scan_issue(slice&, int) {}
+  KYB_HD void scan_merge(scan& st, slice&, int k) { merge(st.c, 2 * k, st.mag); merge(st.c, 2 * k + 1, st.mag); }
+  KYB_HD void scan_end(ge_cached& c, scan& st) { c = st.c; }
+};
+
+// base table image: uint32 [64 pos][8 quads][8 entries][4] = 65,536 B, limbs canonical.  Dword k
+// (0..29: ypx[10] ymx[10] xy2d[10]; 30,31 = 0) of entry (pos, j) sits in quad k/4; the eight entries
+// of one quad are contiguous, so eight lanes can fetch eight different entries with one
+// conflict-free ds_read_b128 (see tbl_lds_bperm in kernels.hip).
+#define KYB_BASE_TABLE_WORDS (64 * 8 * 8 * 4)
+#define KYB_BT_IDX(pos, j, k) ((((pos) * 8 + ((k) >> 2)) * 8 + (j)) * 4 + ((k) & 3))
+struct tbl_base_words {
+  const uint32_t* w;
+  KYB_HD void select(ge_precomp& c, int pos, uint32_t mag) {
+    fe_one(c.ypx); fe_one(c.ymx); fe_zero(c.xy2d);
+    for (int j = 0; j < 8; ++j) {
+      uint32_t m = (mag == (uint32_t)(j + 1));
+      for (int k = 0; k < 10; ++k) {
+        c.ypx.v[k] = m ? w[KYB_BT_IDX(pos, j, k)] : c.ypx.v[k];
+        c.ymx.v[k] = m ? w[KYB_BT_IDX(pos, j, 10 + k)] : c.ymx.v[k];
+        c.xy2d.v[k] = m ? w[KYB_BT_IDX(pos, j, 20 + k)] : c.xy2d.v[k];
+      }
+    }
+  }
+};
+
+// One entry of the base table: (j+1) * 16^pos * B, normalised to affine (y+x, y-x, 2dxy).
+// Used by the init kernel (one thread per entry); B is decoded from its RFC 8032 encoding.
+KYB_HD void ge_base_table_entry(uint32_t* image, int pos, int j) {
+  const uint32_t benc[8] = KYB_W_BASE_ENC;
+  const fe d2 = {KYB_FE_D2};
+  ge_p3 B;
+  ge_decode(B, benc);
+  uint32_t a[8];
+  for (int i = 0; i < 8; ++i) a[i] = 0;
+  a[pos >> 3] = (uint32_t)(j + 1) << ((pos & 7) * 4);   // (j+1) * 16^pos; 8*16^63 = 2^255 is a top digit of 8
+  tbl_array_cached tbl;
+  ge_p2 r;
+  ge_scalarmult(r, a, B, tbl);
+  fe recip, x, y, t;
+  fe_invert(recip, r.Z);
+  fe_mul(x, r.X, recip);
+  fe_mul(y, r.Y, recip);
+  fe ypx, ymx, xy2d;
+  fe_add(ypx, y, x);
+  fe_sub(ymx, y, x);
+  fe_mul(t, x, y);
+  fe_mul(xy2d, t, d2);
+  fe_canon(ypx, ypx);
+  fe_canon(ymx, ymx);
+  fe_canon(xy2d, xy2d);
+  for (int k = 0; k < 10; ++k) {
+    image[KYB_BT_IDX(pos, j, k)] = ypx.v[k];
+    image[KYB_BT_IDX(pos, j, 10 + k)] = ymx.v[k];
+    image[KYB_BT_IDX(pos, j, 20 + k)] = xy2d.v[k];
+  }
+  image[KYB_BT_IDX(pos, j, 30)] = 0;
+  image[KYB_BT_IDX(pos, j, 31)] = 0;
+}
+
+}  // namespace kyb

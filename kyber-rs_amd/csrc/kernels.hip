@@ -1,0 +1,717 @@
+// MI355X (gfx950) kernels and C-ABI implementation of the batched Ed25519 engine.
+//
+// One scalar(-point pair) per lane, 64 lanes per wavefront, field elements as ten 32-bit VGPRs,
+// products on v_mad_u64_u32 (see fe25519.h).  The path is integer-VALU bound: algorithmic HBM
+// traffic is 64..224 B per operation against ~2*10^5 multiply-adds, so there is no MFMA and no
+// LDS tiling of operands; LDS holds only the shared base-point table of the fixed-base kernels.
+//
+//   k_mul       Point::mul(s, Some(P))   ge.rs:508-568   per-lane table 1P..8P in an L2/MALL-resident
+//                                                        workspace, [entry][quad][lane] so that every
+//                                                        scan load is one coalesced 1 KiB request
+//   k_mul_base  Point::mul(s, None)      ge.rs:442-486   64x8 affine table in LDS (65,536 B)
+//   k_sign      schnorr::sign            schnorr_sig.rs:25-47
+//   k_add / k_encode / k_decode          point.rs:179-197 / 35-51
+//   k_base_table                         builds the LDS table image on the GPU at init
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/kyber_ed25519.h"
+#include "schnorr.h"
+
+using namespace kyb;
+
+// ------------------------------------------------------------------------------------------------
+// device table policies
+// ------------------------------------------------------------------------------------------------
+
+// Variable-base table of one wave: uint4 [8 entries][10 quads][64 lanes] = 81,920 B.
+// A cached point is 40 dwords: YpX[10] YmX[10] Z[10] T2d[10] -> 10 quads.
+// MASKED = 0: merge with v_cndmask_b32; 1: merge with (x & m) | acc.
+template <int MASKED>
+struct tbl_global {
+  uint4* p;  // wave base + lane
+  struct scan { uint32_t f[40]; uint32_t mag; };
+  struct slice { uint4 q[2][10]; };
+
+  __device__ __forceinline__ static void flatten(uint32_t f[40], const ge_cached& c) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { f[i] = c.YpX.v[i]; f[10 + i] = c.YmX.v[i]; f[20 + i] = c.Z.v[i]; f[30 + i] = c.T2d.v[i]; }
+  }
+  __device__ __forceinline__ static void unflatten(ge_cached& c, const uint32_t f[40]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c.YpX.v[i] = f[i]; c.YmX.v[i] = f[10 + i]; c.Z.v[i] = f[20 + i]; c.T2d.v[i] = f[30 + i]; }
+  }
+  __device__ __forceinline__ void store(int e, const ge_cached& c) {
+    uint32_t f[40];
+    flatten(f, c);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) p[(e * 10 + q) * 64] = make_uint4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+  }
+  __device__ __forceinline__ static void merge_entry(uint32_t f[40], const uint4 q[10], uint32_t hit) {
+    if (MASKED) {
+      const uint32_t m = 0u - hit;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        f[4 * i] |= q[i].x & m; f[4 * i + 1] |= q[i].y & m; f[4 * i + 2] |= q[i].z & m; f[4 * i + 3] |= q[i].w & m;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        f[4 * i] = hit ? q[i].x : f[4 * i]; f[4 * i + 1] = hit ? q[i].y : f[4 * i + 1];
+        f[4 * i + 2] = hit ? q[i].z : f[4 * i + 2]; f[4 * i + 3] = hit ? q[i].w : f[4 * i + 3];
+      }
+    }
+  }
+  __device__ __forceinline__ void scan_begin(scan& st, uint32_t mag) {
+    st.mag = mag;
+#pragma unroll
+    for (int i = 0; i < 40; ++i) st.f[i] = 0;
+  }
+  __device__ __forceinline__ void scan_issue(slice& sl, int k) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < 10; ++q) sl.q[h][q] = p[((2 * k + h) * 10 + q) * 64];
+  }
+  __device__ __forceinline__ void scan_merge(scan& st, slice& sl, int k) {
+    merge_entry(st.f, sl.q[0], st.mag == (uint32_t)(2 * k + 1));
+    merge_entry(st.f, sl.q[1], st.mag == (uint32_t)(2 * k + 2));
+  }
+  __device__ __forceinline__ void scan_end(ge_cached& c, scan& st) {
+    const uint32_t z = (st.mag == 0);   // neutral element in cached form: (1, 1, 1, 0)
+    st.f[0] |= z; st.f[10] |= z; st.f[20] |= z;
+    unflatten(c, st.f);
+  }
+  __device__ __forceinline__ void select(ge_cached& c, uint32_t mag) {
+    scan st;
+    scan_begin(st, mag);
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) { slice sl; scan_issue(sl, k); scan_merge(st, sl, k); }
+    scan_end(c, st);
+  }
+};
+
+// Fixed-base table in LDS, image layout [pos][quad][entry][4] (KYB_BT_IDX).
+// MODE 0: every lane reads all 8 entries (uniform address -> LDS broadcast) and merges under a mask.
+// MODE 1: lane l fetches entry (l & 7) with eight conflict-free ds_read_b128, then each of the 30
+//         limbs is pulled from the lane that holds the wanted entry with ds_bpermute_b32
+//         (data-independent instruction stream and addresses; the only per-lane quantity is the
+//         bpermute source lane, which goes through the conflict-free crossbar).
+template <int MODE>
+struct tbl_lds {
+  const uint32_t* t;  // LDS
+  __device__ __forceinline__ void select(ge_precomp& c, int pos, uint32_t mag) {
+    uint32_t f[32];
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) f[i] = 0;
+#pragma unroll 2
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t m = 0u - (uint32_t)(mag == (uint32_t)(j + 1));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const uint4 v = *reinterpret_cast<const uint4*>(t + ((pos * 8 + q) * 8 + j) * 4);
+          f[4 * q] |= v.x & m; f[4 * q + 1] |= v.y & m; f[4 * q + 2] |= v.z & m; f[4 * q + 3] |= v.w & m;
+        }
+      }
+    } else {
+      const uint32_t lane = threadIdx.x & 63u;
+      const uint32_t mine = lane & 7u;
+      uint32_t own[32];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint4 v = *reinterpret_cast<const uint4*>(t + ((pos * 8 + q) * 8 + mine) * 4);
+        own[4 * q] = v.x; own[4 * q + 1] = v.y; own[4 * q + 2] = v.z; own[4 * q + 3] = v.w;
+      }
+      const uint32_t want = (mag - 1u) & 7u;                   // mag == 0 reads entry 7, masked below
+      const int src = (int)(((lane & ~7u) | want) << 2);       // byte address of the source lane
+      const uint32_t m = 0u - (uint32_t)(mag != 0);
+#pragma unroll
+      for (int i = 0; i < 30; ++i) f[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own[i]) & m;
+    }
+    const uint32_t z = (mag == 0);       // neutral element in precomputed form: (1, 1, 0)
+    f[0] |= z; f[10] |= z;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c.ypx.v[i] = f[i]; c.ymx.v[i] = f[10 + i]; c.xy2d.v[i] = f[20 + i]; }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// load / store helpers (16-byte vector accesses; batches are arrays of 32- or 160-byte records)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_words8(uint32_t w[8], const uint8_t* base, size_t i) {
+  const uint4* p = reinterpret_cast<const uint4*>(base) + 2 * i;
+  const uint4 a = p[0], b = p[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void store_words8(uint8_t* base, size_t i, const uint32_t w[8]) {
+  uint4* p = reinterpret_cast<uint4*>(base) + 2 * i;
+  p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ void load_ext(ge_p3& P, const int32_t* base, size_t i) {
+  const uint4* p = reinterpret_cast<const uint4*>(base) + 10 * i;
+  int32_t s[40];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) { const uint4 v = p[q]; s[4 * q] = (int32_t)v.x; s[4 * q + 1] = (int32_t)v.y; s[4 * q + 2] = (int32_t)v.z; s[4 * q + 3] = (int32_t)v.w; }
+  fe_from_ref10(P.X, s); fe_from_ref10(P.Y, s + 10); fe_from_ref10(P.Z, s + 20); fe_from_ref10(P.T, s + 30);
+}
+__device__ __forceinline__ void store_ext(int32_t* base, size_t i, const fe& X, const fe& Y, const fe& Z, const fe& T) {
+  int32_t s[40];
+  fe_to_ref10(s, X); fe_to_ref10(s + 10, Y); fe_to_ref10(s + 20, Z); fe_to_ref10(s + 30, T);
+  uint4* p = reinterpret_cast<uint4*>(base) + 10 * i;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) p[q] = make_uint4((uint32_t)s[4 * q], (uint32_t)s[4 * q + 1], (uint32_t)s[4 * q + 2], (uint32_t)s[4 * q + 3]);
+}
+// encode (and optionally emit affine extended limbs, Z = 1) from a projective result
+__device__ __forceinline__ void finish_point(const fe& X, const fe& Y, const fe& Z, uint8_t* out_enc, int32_t* out_ext, size_t i, bool live) {
+  fe zi, x, y;
+  fe_invert(zi, Z);
+  fe_mul(x, X, zi);
+  fe_mul(y, Y, zi);
+  if (out_enc != nullptr) {
+    uint32_t w[8];
+    fe_to_words(w, y);
+    w[7] ^= fe_is_negative(x) << 31;
+    if (live) store_words8(out_enc, i, w);
+  }
+  if (out_ext != nullptr) {
+    fe one, t;
+    fe_one(one);
+    fe_mul(t, x, y);
+    if (live) store_ext(out_ext, i, x, y, one, t);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+constexpr int KYB_BLOCK = 256;
+
+__global__ void __launch_bounds__(64) k_base_table(uint32_t* image) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // 0..511
+  if (e < 512) ge_base_table_entry(image, e >> 3, e & 7);
+}
+
+// Variable base.  Persistent grid: block b handles chunks b, b+grid, ...; its four waves own four
+// table slots of the workspace for the whole launch.
+template <int MASKED, bool FROM_ENC>
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_mul(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ pts_enc, const int32_t* __restrict__ pts_ext,
+      size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, uint8_t* __restrict__ ok_out, uint4* __restrict__ ws) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const size_t wave_slot = (size_t)blockIdx.x * (KYB_BLOCK / 64) + (threadIdx.x >> 6);
+  tbl_global<MASKED> tbl{ws + wave_slot * (8 * 10 * 64) + lane};
+  const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
+  for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const size_t i = chunk * KYB_BLOCK + threadIdx.x;
+    const bool live = i < n;
+    const size_t ii = live ? i : 0;       // dead lanes redo item 0 and store nothing
+    uint32_t a[8];
+    load_words8(a, scalars, ii);
+    ge_p3 P;
+    uint32_t ok = 1;
+    if (FROM_ENC) {
+      uint32_t w[8];
+      load_words8(w, pts_enc, ii);
+      ok = ge_decode(P, w);
+      ge_p3 id;
+      ge_p3_0(id);
+      fe_cmov(P.X, id.X, 1u - ok); fe_cmov(P.Y, id.Y, 1u - ok); fe_cmov(P.Z, id.Z, 1u - ok); fe_cmov(P.T, id.T, 1u - ok);
+    } else {
+      load_ext(P, pts_ext, ii);
+    }
+    ge_p2 r;
+    ge_scalarmult(r, a, P, tbl);
+    finish_point(r.X, r.Y, r.Z, out_enc, out_ext, ii, live);
+    if (ok_out != nullptr && live) ok_out[i] = (uint8_t)ok;
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_mul_base(const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
+           const uint4* __restrict__ table_image) {
+  __shared__ uint4 lds_tbl[KYB_BASE_TABLE_BYTES / 16];
+  for (int k = threadIdx.x; k < (int)(KYB_BASE_TABLE_BYTES / 16); k += KYB_BLOCK) lds_tbl[k] = table_image[k];
+  __syncthreads();
+  tbl_lds<MODE> tbl{reinterpret_cast<const uint32_t*>(lds_tbl)};
+  const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
+  for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const size_t i = chunk * KYB_BLOCK + threadIdx.x;
+    const bool live = i < n;
+    const size_t ii = live ? i : 0;
+    uint32_t a[8];
+    load_words8(a, scalars, ii);
+    ge_p3 h;
+    ge_scalarmult_base(h, a, tbl);
+    finish_point(h.X, h.Y, h.Z, out_enc, out_ext, ii, live);
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_sign(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const uint8_t* __restrict__ msgs,
+       const uint32_t* __restrict__ msg_off, size_t n, uint8_t* __restrict__ sig, const uint4* __restrict__ table_image) {
+  __shared__ uint4 lds_tbl[KYB_BASE_TABLE_BYTES / 16];
+  for (int q = threadIdx.x; q < (int)(KYB_BASE_TABLE_BYTES / 16); q += KYB_BLOCK) lds_tbl[q] = table_image[q];
+  __syncthreads();
+  tbl_lds<MODE> tbl{reinterpret_cast<const uint32_t*>(lds_tbl)};
+  const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
+  for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const size_t i = chunk * KYB_BLOCK + threadIdx.x;
+    const bool live = i < n;
+    const size_t ii = live ? i : 0;
+    uint32_t wx[8], wk[8], s[16];
+    load_words8(wx, x, ii);
+    load_words8(wk, k, ii);
+    const uint32_t off = msg_off[ii], len = msg_off[ii + 1] - off;
+    schnorr_sign(s, wx, wk, msgs + off, len, tbl);
+    if (live) { store_words8(sig, 2 * ii, s); store_words8(sig, 2 * ii + 1, s + 8); }
+  }
+}
+
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_add(const int32_t* __restrict__ a_ext, const int32_t* __restrict__ b_ext, size_t n, int32_t* __restrict__ out_ext, int subtract) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  ge_p3 A, B, R;
+  load_ext(A, a_ext, i);
+  load_ext(B, b_ext, i);
+  ge_cached c;
+  ge_p3_to_cached(c, B);
+  ge_cached_cneg(c, subtract ? 1u : 0u);
+  ge_p1p1 r;
+  ge_add(r, A, c);
+  ge_p1p1_to_p3(R, r);
+  store_ext(out_ext, i, R.X, R.Y, R.Z, R.T);
+}
+
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_encode(const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  ge_p3 P;
+  load_ext(P, pts_ext, i);
+  uint32_t w[8];
+  ge_encode(w, P.X, P.Y, P.Z);
+  store_words8(out_enc, i, w);
+}
+
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_decode(const uint8_t* __restrict__ enc, size_t n, int32_t* __restrict__ out_ext, uint8_t* __restrict__ ok_out) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words8(w, enc, i);
+  ge_p3 P;
+  const uint32_t ok = ge_decode(P, w);
+  store_ext(out_ext, i, P.X, P.Y, P.Z, P.T);
+  if (ok_out != nullptr) ok_out[i] = (uint8_t)ok;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: context, staging, C ABI
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_err;
+
+struct Ctx {
+  bool ready = false;
+  int device = -1;
+  int cus = 0;
+  char name[128] = {0};
+  hipStream_t stream = nullptr;
+  uint32_t* table = nullptr;      // KYB_BASE_TABLE_BYTES
+  bool table_ready = false;
+  // variable-base table workspace: one per stream that has launched k_mul (two launches that
+  // overlap on different streams must not share table slots)
+  struct WsSlot { hipStream_t stream; uint4* ws; };
+  WsSlot ws_slots[8] = {};
+  int ws_count = 0;
+  size_t ws_bytes = 0;
+  int grid_mul = 0, grid_base = 0;
+  uint8_t* stage = nullptr;       // device staging for the host-pointer API
+  size_t stage_bytes = 0;
+  int opt_mul_select = 1;         // 0 cndmask, 1 and/or mask
+  int opt_base_select = 1;        // 0 LDS broadcast scan, 1 bpermute
+  std::mutex mu;
+};
+Ctx g;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[256];
+  if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+  else snprintf(buf, sizeof(buf), "%s", what);
+  g_err = buf;
+  return code;
+}
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(KYB_E_HIP, #x, e_); } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline hipStream_t pick(void* s) { return s ? reinterpret_cast<hipStream_t>(s) : g.stream; }
+
+int ensure_stage(size_t bytes) {
+  if (bytes <= g.stage_bytes) return KYB_OK;
+  if (g.stage) { HIPCK(hipFree(g.stage)); g.stage = nullptr; g.stage_bytes = 0; }
+  size_t want = bytes + (bytes >> 2) + 4096;
+  hipError_t e = hipMalloc(&g.stage, want);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "staging allocation", e);
+  g.stage_bytes = want;
+  return KYB_OK;
+}
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int do_init(int device, bool build_table) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (g.ready) {
+    if (g.device != device) return fail(KYB_E_BAD_ARG, "already initialised on another device (one process per GPU)");
+    return KYB_OK;
+  }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) return fail(KYB_E_NO_DEVICE, "no HIP device visible (this engine has no CPU path)", e);
+  if (device < 0 || device >= count) return fail(KYB_E_BAD_ARG, "device index out of range");
+  HIPCK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    char buf[200];
+    snprintf(buf, sizeof(buf), "device %d is %s; this library carries gfx950 code objects only", device, prop.gcnArchName);
+    return fail(KYB_E_NO_DEVICE, buf);
+  }
+  g.device = device;
+  g.cus = prop.multiProcessorCount;
+  snprintf(g.name, sizeof(g.name), "%s", prop.name);
+  HIPCK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  HIPCK(hipMalloc(&g.table, KYB_BASE_TABLE_BYTES));
+  // persistent grids: 2 blocks of 256 threads per CU = 2 waves per SIMD (needed to saturate
+  // v_mad_u64_u32 issue, profiles/r01_valu_rates_mi355x.jsonl)
+  g.grid_mul = g.cus * 2;
+  g.grid_base = g.cus * 2;
+  g.ws_bytes = (size_t)g.grid_mul * (KYB_BLOCK / 64) * (8 * 10 * 64) * sizeof(uint4);
+  hipError_t em = hipMalloc(&g.ws_slots[0].ws, g.ws_bytes);
+  if (em != hipSuccess) return fail(KYB_E_NOMEM, "workspace allocation", em);
+  g.ws_slots[0].stream = g.stream;
+  g.ws_count = 1;
+  if (build_table) {
+    hipLaunchKernelGGL(k_base_table, dim3(8), dim3(64), 0, g.stream, g.table);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(g.stream));
+    g.table_ready = true;
+  }
+  g.ready = true;
+  return KYB_OK;
+}
+
+#define REQUIRE_READY() do { if (!g.ready) return fail(KYB_E_NOT_INIT, "kyb_init has not succeeded in this process"); } while (0)
+#define REQUIRE_TABLE() do { if (!g.table_ready) return fail(KYB_E_NOT_INIT, "base table not built or imported"); } while (0)
+
+// workspace bound to a stream (allocated on first use; at most 8 streams)
+int ws_for(hipStream_t st, uint4** out) {
+  static std::mutex ws_mu;
+  std::lock_guard<std::mutex> lk(ws_mu);
+  for (int i = 0; i < g.ws_count; ++i) if (g.ws_slots[i].stream == st) { *out = g.ws_slots[i].ws; return KYB_OK; }
+  if (g.ws_count == 8) return fail(KYB_E_NOMEM, "variable-base kernels have been launched on more than 8 distinct streams");
+  uint4* p = nullptr;
+  hipError_t e = hipMalloc(&p, g.ws_bytes);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "workspace allocation", e);
+  g.ws_slots[g.ws_count].stream = st;
+  g.ws_slots[g.ws_count].ws = p;
+  g.ws_count++;
+  *out = p;
+  return KYB_OK;
+}
+
+int launch_mul(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  uint4* ws = nullptr;
+  { int rc = ws_for(st, &ws); if (rc) return rc; }
+  const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
+  const int grid = (int)(nchunks < (size_t)g.grid_mul ? nchunks : (size_t)g.grid_mul);
+  const bool enc = penc != nullptr;
+  if (g.opt_mul_select == 0) {
+    if (enc) hipLaunchKernelGGL((k_mul<0, true>), dim3(grid), dim3(KYB_BLOCK), 0, st, sc, penc, pext, n, oenc, oext, ok, ws);
+    else     hipLaunchKernelGGL((k_mul<0, false>), dim3(grid), dim3(KYB_BLOCK), 0, st, sc, penc, pext, n, oenc, oext, ok, ws);
+  } else {
+    if (enc) hipLaunchKernelGGL((k_mul<1, true>), dim3(grid), dim3(KYB_BLOCK), 0, st, sc, penc, pext, n, oenc, oext, ok, ws);
+    else     hipLaunchKernelGGL((k_mul<1, false>), dim3(grid), dim3(KYB_BLOCK), 0, st, sc, penc, pext, n, oenc, oext, ok, ws);
+  }
+  HIPCK(hipGetLastError());
+  return KYB_OK;
+}
+int launch_mul_base(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
+  const int grid = (int)(nchunks < (size_t)g.grid_base ? nchunks : (size_t)g.grid_base);
+  const uint4* img = reinterpret_cast<const uint4*>(g.table);
+  if (g.opt_base_select == 0) hipLaunchKernelGGL((k_mul_base<0>), dim3(grid), dim3(KYB_BLOCK), 0, st, sc, n, oenc, oext, img);
+  else                        hipLaunchKernelGGL((k_mul_base<1>), dim3(grid), dim3(KYB_BLOCK), 0, st, sc, n, oenc, oext, img);
+  HIPCK(hipGetLastError());
+  return KYB_OK;
+}
+int launch_sign(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* sig, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
+  const int grid = (int)(nchunks < (size_t)g.grid_base ? nchunks : (size_t)g.grid_base);
+  const uint4* img = reinterpret_cast<const uint4*>(g.table);
+  if (g.opt_base_select == 0) hipLaunchKernelGGL((k_sign<0>), dim3(grid), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, sig, img);
+  else                        hipLaunchKernelGGL((k_sign<1>), dim3(grid), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, sig, img);
+  HIPCK(hipGetLastError());
+  return KYB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kyb_init(int device) { return do_init(device, true); }
+int kyb_init_no_table(int device) { return do_init(device, false); }
+
+void kyb_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (!g.ready) return;
+  (void)hipSetDevice(g.device);
+  (void)hipStreamSynchronize(g.stream);
+  if (g.stage) (void)hipFree(g.stage);
+  for (int i = 0; i < g.ws_count; ++i) (void)hipFree(g.ws_slots[i].ws);
+  g.ws_count = 0;
+  if (g.table) (void)hipFree(g.table);
+  (void)hipStreamDestroy(g.stream);
+  g.stage = nullptr; g.stage_bytes = 0; g.table = nullptr; g.stream = nullptr;
+  g.table_ready = false; g.ready = false; g.device = -1;
+}
+
+const char* kyb_last_error(void) { return g_err.c_str(); }
+
+int kyb_device_info(char* name, size_t name_cap, int* compute_units, size_t* workspace_bytes) {
+  REQUIRE_READY();
+  if (name && name_cap) snprintf(name, name_cap, "%s", g.name);
+  if (compute_units) *compute_units = g.cus;
+  if (workspace_bytes) *workspace_bytes = g.ws_bytes;
+  return KYB_OK;
+}
+
+int kyb_sync(void* stream) {
+  REQUIRE_READY();
+  HIPCK(hipStreamSynchronize(pick(stream)));
+  return KYB_OK;
+}
+
+int kyb_base_table_export_dev(void* dst_dev, void* stream) {
+  REQUIRE_READY(); REQUIRE_TABLE();
+  if (!dst_dev) return fail(KYB_E_BAD_ARG, "null destination");
+  HIPCK(hipMemcpyAsync(dst_dev, g.table, KYB_BASE_TABLE_BYTES, hipMemcpyDeviceToDevice, pick(stream)));
+  return KYB_OK;
+}
+int kyb_base_table_import_dev(const void* src_dev, void* stream) {
+  REQUIRE_READY();
+  if (!src_dev) return fail(KYB_E_BAD_ARG, "null source");
+  HIPCK(hipMemcpyAsync(g.table, src_dev, KYB_BASE_TABLE_BYTES, hipMemcpyDeviceToDevice, pick(stream)));
+  HIPCK(hipStreamSynchronize(pick(stream)));
+  g.table_ready = true;
+  return KYB_OK;
+}
+int kyb_base_table_export(uint8_t* dst_host) {
+  REQUIRE_READY(); REQUIRE_TABLE();
+  if (!dst_host) return fail(KYB_E_BAD_ARG, "null destination");
+  HIPCK(hipMemcpy(dst_host, g.table, KYB_BASE_TABLE_BYTES, hipMemcpyDeviceToHost));
+  return KYB_OK;
+}
+
+// ---- device-pointer API ----
+int kyb_mul_base_batch_dev(const uint8_t* scalars, size_t n, uint8_t* out_enc, int32_t* out_ext, void* stream) {
+  REQUIRE_READY(); REQUIRE_TABLE();
+  if (n && (!scalars || (!out_enc && !out_ext))) return fail(KYB_E_BAD_ARG, "null buffer");
+  if (!aligned16(scalars) || !aligned16(out_enc) || !aligned16(out_ext)) return fail(KYB_E_BAD_ARG, "device buffers must be 16-byte aligned");
+  return launch_mul_base(scalars, n, out_enc, out_ext, pick(stream));
+}
+int kyb_mul_batch_dev(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, size_t n,
+                      uint8_t* out_enc, int32_t* out_ext, uint8_t* ok, void* stream) {
+  REQUIRE_READY();
+  if (n && (!scalars || (!out_enc && !out_ext))) return fail(KYB_E_BAD_ARG, "null buffer");
+  if (n && ((pts_enc == nullptr) == (pts_ext == nullptr))) return fail(KYB_E_BAD_ARG, "give exactly one of pts_enc / pts_ext");
+  if (!aligned16(scalars) || !aligned16(pts_enc) || !aligned16(pts_ext) || !aligned16(out_enc) || !aligned16(out_ext))
+    return fail(KYB_E_BAD_ARG, "device buffers must be 16-byte aligned");
+  return launch_mul(scalars, pts_enc, pts_ext, n, out_enc, out_ext, ok, pick(stream));
+}
+int kyb_add_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, int32_t* out_ext, int subtract, void* stream) {
+  REQUIRE_READY();
+  if (n == 0) return KYB_OK;
+  if (!a_ext || !b_ext || !out_ext) return fail(KYB_E_BAD_ARG, "null buffer");
+  if (!aligned16(a_ext) || !aligned16(b_ext) || !aligned16(out_ext)) return fail(KYB_E_BAD_ARG, "device buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(k_add, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, pick(stream), a_ext, b_ext, n, out_ext, subtract);
+  HIPCK(hipGetLastError());
+  return KYB_OK;
+}
+int kyb_encode_batch_dev(const int32_t* pts_ext, size_t n, uint8_t* out_enc, void* stream) {
+  REQUIRE_READY();
+  if (n == 0) return KYB_OK;
+  if (!pts_ext || !out_enc) return fail(KYB_E_BAD_ARG, "null buffer");
+  if (!aligned16(pts_ext) || !aligned16(out_enc)) return fail(KYB_E_BAD_ARG, "device buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(k_encode, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, pick(stream), pts_ext, n, out_enc);
+  HIPCK(hipGetLastError());
+  return KYB_OK;
+}
+int kyb_decode_batch_dev(const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok, void* stream) {
+  REQUIRE_READY();
+  if (n == 0) return KYB_OK;
+  if (!enc || !out_ext) return fail(KYB_E_BAD_ARG, "null buffer");
+  if (!aligned16(enc) || !aligned16(out_ext)) return fail(KYB_E_BAD_ARG, "device buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, pick(stream), enc, n, out_ext, ok);
+  HIPCK(hipGetLastError());
+  return KYB_OK;
+}
+int kyb_schnorr_sign_batch_dev(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* msg_off, size_t n, uint8_t* sig, void* stream) {
+  REQUIRE_READY(); REQUIRE_TABLE();
+  if (n == 0) return KYB_OK;
+  if (!x || !k || !msg_off || !sig) return fail(KYB_E_BAD_ARG, "null buffer");
+  if (!aligned16(x) || !aligned16(k) || !aligned16(sig)) return fail(KYB_E_BAD_ARG, "device buffers must be 16-byte aligned");
+  return launch_sign(x, k, msgs, msg_off, n, sig, pick(stream));
+}
+
+// ---- host-pointer API: stage through one device buffer, run on the engine stream, copy back ----
+int kyb_mul_base_batch(const uint8_t* scalars, size_t n, uint8_t* out_enc, int32_t* out_ext) {
+  REQUIRE_READY(); REQUIRE_TABLE();
+  if (n == 0) return KYB_OK;
+  if (!scalars || (!out_enc && !out_ext)) return fail(KYB_E_BAD_ARG, "null buffer");
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCK(hipSetDevice(g.device));
+  const size_t o_sc = 0, o_enc = up256(32 * n), o_ext = o_enc + up256(32 * n), total = o_ext + up256(160 * n);
+  int rc = ensure_stage(total);
+  if (rc) return rc;
+  uint8_t* d = g.stage;
+  HIPCK(hipMemcpyAsync(d + o_sc, scalars, 32 * n, hipMemcpyHostToDevice, g.stream));
+  rc = launch_mul_base(d + o_sc, n, out_enc ? d + o_enc : nullptr, out_ext ? reinterpret_cast<int32_t*>(d + o_ext) : nullptr, g.stream);
+  if (rc) return rc;
+  if (out_enc) HIPCK(hipMemcpyAsync(out_enc, d + o_enc, 32 * n, hipMemcpyDeviceToHost, g.stream));
+  if (out_ext) HIPCK(hipMemcpyAsync(out_ext, d + o_ext, 160 * n, hipMemcpyDeviceToHost, g.stream));
+  HIPCK(hipStreamSynchronize(g.stream));
+  return KYB_OK;
+}
+int kyb_mul_batch(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, size_t n,
+                  uint8_t* out_enc, int32_t* out_ext, uint8_t* ok) {
+  REQUIRE_READY();
+  if (n == 0) return KYB_OK;
+  if (!scalars || (!out_enc && !out_ext)) return fail(KYB_E_BAD_ARG, "null buffer");
+  if ((pts_enc == nullptr) == (pts_ext == nullptr)) return fail(KYB_E_BAD_ARG, "give exactly one of pts_enc / pts_ext");
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCK(hipSetDevice(g.device));
+  const size_t o_sc = 0, o_pt = up256(32 * n), o_enc = o_pt + up256(160 * n), o_ext = o_enc + up256(32 * n), o_ok = o_ext + up256(160 * n), total = o_ok + up256(n);
+  int rc = ensure_stage(total);
+  if (rc) return rc;
+  uint8_t* d = g.stage;
+  HIPCK(hipMemcpyAsync(d + o_sc, scalars, 32 * n, hipMemcpyHostToDevice, g.stream));
+  if (pts_enc) HIPCK(hipMemcpyAsync(d + o_pt, pts_enc, 32 * n, hipMemcpyHostToDevice, g.stream));
+  else         HIPCK(hipMemcpyAsync(d + o_pt, pts_ext, 160 * n, hipMemcpyHostToDevice, g.stream));
+  rc = launch_mul(d + o_sc, pts_enc ? d + o_pt : nullptr, pts_ext ? reinterpret_cast<const int32_t*>(d + o_pt) : nullptr, n,
+                  out_enc ? d + o_enc : nullptr, out_ext ? reinterpret_cast<int32_t*>(d + o_ext) : nullptr, ok ? d + o_ok : nullptr, g.stream);
+  if (rc) return rc;
+  if (out_enc) HIPCK(hipMemcpyAsync(out_enc, d + o_enc, 32 * n, hipMemcpyDeviceToHost, g.stream));
+  if (out_ext) HIPCK(hipMemcpyAsync(out_ext, d + o_ext, 160 * n, hipMemcpyDeviceToHost, g.stream));
+  if (ok) HIPCK(hipMemcpyAsync(ok, d + o_ok, n, hipMemcpyDeviceToHost, g.stream));
+  HIPCK(hipStreamSynchronize(g.stream));
+  return KYB_OK;
+}
+int kyb_add_batch(const int32_t* a_ext, const int32_t* b_ext, size_t n, int32_t* out_ext, int subtract) {
+  REQUIRE_READY();
+  if (n == 0) return KYB_OK;
+  if (!a_ext || !b_ext || !out_ext) return fail(KYB_E_BAD_ARG, "null buffer");
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCK(hipSetDevice(g.device));
+  const size_t o_a = 0, o_b = up256(160 * n), o_o = 2 * up256(160 * n), total = 3 * up256(160 * n);
+  int rc = ensure_stage(total);
+  if (rc) return rc;
+  uint8_t* d = g.stage;
+  HIPCK(hipMemcpyAsync(d + o_a, a_ext, 160 * n, hipMemcpyHostToDevice, g.stream));
+  HIPCK(hipMemcpyAsync(d + o_b, b_ext, 160 * n, hipMemcpyHostToDevice, g.stream));
+  hipLaunchKernelGGL(k_add, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, g.stream,
+                     reinterpret_cast<const int32_t*>(d + o_a), reinterpret_cast<const int32_t*>(d + o_b), n, reinterpret_cast<int32_t*>(d + o_o), subtract);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(out_ext, d + o_o, 160 * n, hipMemcpyDeviceToHost, g.stream));
+  HIPCK(hipStreamSynchronize(g.stream));
+  return KYB_OK;
+}
+int kyb_encode_batch(const int32_t* pts_ext, size_t n, uint8_t* out_enc) {
+  REQUIRE_READY();
+  if (n == 0) return KYB_OK;
+  if (!pts_ext || !out_enc) return fail(KYB_E_BAD_ARG, "null buffer");
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCK(hipSetDevice(g.device));
+  const size_t o_p = 0, o_e = up256(160 * n), total = o_e + up256(32 * n);
+  int rc = ensure_stage(total);
+  if (rc) return rc;
+  uint8_t* d = g.stage;
+  HIPCK(hipMemcpyAsync(d + o_p, pts_ext, 160 * n, hipMemcpyHostToDevice, g.stream));
+  hipLaunchKernelGGL(k_encode, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, g.stream, reinterpret_cast<const int32_t*>(d + o_p), n, d + o_e);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(out_enc, d + o_e, 32 * n, hipMemcpyDeviceToHost, g.stream));
+  HIPCK(hipStreamSynchronize(g.stream));
+  return KYB_OK;
+}
+int kyb_decode_batch(const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok) {
+  REQUIRE_READY();
+  if (n == 0) return KYB_OK;
+  if (!enc || !out_ext) return fail(KYB_E_BAD_ARG, "null buffer");
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCK(hipSetDevice(g.device));
+  const size_t o_e = 0, o_p = up256(32 * n), o_ok = o_p + up256(160 * n), total = o_ok + up256(n);
+  int rc = ensure_stage(total);
+  if (rc) return rc;
+  uint8_t* d = g.stage;
+  HIPCK(hipMemcpyAsync(d + o_e, enc, 32 * n, hipMemcpyHostToDevice, g.stream));
+  hipLaunchKernelGGL(k_decode, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, g.stream, d + o_e, n, reinterpret_cast<int32_t*>(d + o_p), d + o_ok);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(out_ext, d + o_p, 160 * n, hipMemcpyDeviceToHost, g.stream));
+  if (ok) HIPCK(hipMemcpyAsync(ok, d + o_ok, n, hipMemcpyDeviceToHost, g.stream));
+  HIPCK(hipStreamSynchronize(g.stream));
+  return KYB_OK;
+}
+int kyb_schnorr_sign_batch(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* msg_off, size_t n, uint8_t* sig) {
+  REQUIRE_READY(); REQUIRE_TABLE();
+  if (n == 0) return KYB_OK;
+  if (!x || !k || !msg_off || !sig) return fail(KYB_E_BAD_ARG, "null buffer");
+  const size_t mbytes = msg_off[n];
+  if (mbytes && !msgs) return fail(KYB_E_BAD_ARG, "null message buffer");
+  for (size_t i = 0; i < n; ++i) if (msg_off[i + 1] < msg_off[i]) return fail(KYB_E_BAD_ARG, "msg_off must be non-decreasing");
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCK(hipSetDevice(g.device));
+  const size_t o_x = 0, o_k = up256(32 * n), o_m = o_k + up256(32 * n), o_off = o_m + up256(mbytes + 16), o_sig = o_off + up256(4 * (n + 1)), total = o_sig + up256(64 * n);
+  int rc = ensure_stage(total);
+  if (rc) return rc;
+  uint8_t* d = g.stage;
+  HIPCK(hipMemcpyAsync(d + o_x, x, 32 * n, hipMemcpyHostToDevice, g.stream));
+  HIPCK(hipMemcpyAsync(d + o_k, k, 32 * n, hipMemcpyHostToDevice, g.stream));
+  if (mbytes) HIPCK(hipMemcpyAsync(d + o_m, msgs, mbytes, hipMemcpyHostToDevice, g.stream));
+  HIPCK(hipMemcpyAsync(d + o_off, msg_off, 4 * (n + 1), hipMemcpyHostToDevice, g.stream));
+  rc = launch_sign(d + o_x, d + o_k, d + o_m, reinterpret_cast<const uint32_t*>(d + o_off), n, d + o_sig, g.stream);
+  if (rc) return rc;
+  HIPCK(hipMemcpyAsync(sig, d + o_sig, 64 * n, hipMemcpyDeviceToHost, g.stream));
+  HIPCK(hipStreamSynchronize(g.stream));
+  return KYB_OK;
+}
+
+int kyb_set_option(const char* key, int value) {
+  if (!key) return fail(KYB_E_BAD_ARG, "null key");
+  if (!strcmp(key, "mul.select")) { if (value < 0 || value > 1) return fail(KYB_E_BAD_ARG, "mul.select in {0,1}"); g.opt_mul_select = value; return KYB_OK; }
+  if (!strcmp(key, "mul_base.select")) { if (value < 0 || value > 1) return fail(KYB_E_BAD_ARG, "mul_base.select in {0,1}"); g.opt_base_select = value; return KYB_OK; }
+  if (!strcmp(key, "mul.grid_per_cu")) { if (value < 1 || value > 8 || !g.ready) return fail(KYB_E_BAD_ARG, "mul.grid_per_cu in 1..8 after init");
+    if (value > 2) return fail(KYB_E_BAD_ARG, "workspace is sized for 2 blocks per CU");
+    g.grid_mul = g.cus * value; return KYB_OK; }
+  if (!strcmp(key, "mul_base.grid_per_cu")) { if (value < 1 || value > 2 || !g.ready) return fail(KYB_E_BAD_ARG, "mul_base.grid_per_cu in 1..2 after init"); g.grid_base = g.cus * value; return KYB_OK; }
+  return fail(KYB_E_BAD_ARG, "unknown option");
+}
+int kyb_get_option(const char* key, int* value) {
+  if (!key || !value) return fail(KYB_E_BAD_ARG, "null argument");
+  if (!strcmp(key, "mul.select")) { *value = g.opt_mul_select; return KYB_OK; }
+  if (!strcmp(key, "mul_base.select")) { *value = g.opt_base_select; return KYB_OK; }
+  if (!strcmp(key, "mul.grid_per_cu")) { *value = g.cus ? g.grid_mul / g.cus : 0; return KYB_OK; }
+  if (!strcmp(key, "mul_base.grid_per_cu")) { *value = g.cus ? g.grid_base / g.cus : 0; return KYB_OK; }
+  return fail(KYB_E_BAD_ARG, "unknown option");
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// Schnorr / EdDSA signing equation for one (x, k, msg) triple (BASELINE config 4).
+//
+// /root/reference src/sign/schnorr/schnorr_sig.rs:25-47 with the nonce k supplied by the caller
+// (the reference draws it from OS entropy, schnorr_sig.rs:31, so its output is not reproducible;
+// EdDSA::sign, eddsa_sig.rs:120-152, is the same computation with k = SHA-512(prefix||msg) mod L):
+//     R = k*B            (fixed-base mult #1)
+//     A = x*B            (fixed-base mult #2; recomputed on every call, schnorr_sig.rs:35)
+//     h = SHA-512(enc(R) || enc(A) || msg) as a little-endian integer mod L   (schnorr_sig.rs:128-141)
+//     s = k + x*h mod L  (scalar.rs sc_mul + sc_add; x and k may be any 256-bit strings)
+//     sig = enc(R) || s
+// The two encodings share one field inversion (Montgomery's trick on Z_R * Z_A).
+#pragma once
+#include "ge_scalarmult.h"
+#include "sc25519.h"
+#include "sha512.h"
+
+namespace kyb {
+
+template <class Tbl>
+KYB_HD void schnorr_sign(uint32_t sig[16], const uint32_t x[8], const uint32_t k[8], const uint8_t* msg,
+                         uint32_t msg_len, Tbl& tbl) {
+  ge_p3 R, A;
+  ge_scalarmult_base(R, k, tbl);
+  ge_scalarmult_base(A, x, tbl);
+  fe zz, zi, ziR, ziA;
+  fe_mul(zz, R.Z, A.Z);
+  fe_invert(zi, zz);
+  fe_mul(ziR, zi, A.Z);     // 1/Z_R
+  fe_mul(ziA, zi, R.Z);     // 1/Z_A
+  uint32_t renc[8], aenc[8];
+  ge_encode_with_recip(renc, R.X, R.Y, ziR);
+  ge_encode_with_recip(aenc, A.X, A.Y, ziA);
+  sha512_ctx c;
+  sha512_init(c);
+  sha512_words32(c, renc);
+  sha512_words32(c, aenc);
+  sha512_bytes(c, msg, msg_len);
+  uint32_t dig[16], h[8], s[8];
+  sha512_final(dig, c);
+  sc_reduce512(h, dig);
+  sc_muladd(s, x, h, k);
+  for (int i = 0; i < 8; ++i) { sig[i] = renc[i]; sig[8 + i] = s[i]; }
+}
+
+}  // namespace kyb

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/* from the reference tree (run in the build container only; the GPU box
+has no /root/reference and uses the committed files).
+
+What is copied is DATA the reference's own tests hold for this path, never source:
+  * sign.input.gz     — src/sign/eddsa/testdata/sign.input.gz, byte for byte (the 1024-line golden
+                        file checked by tests/sign/eddsa.rs:36-94; public-domain ed25519 test vectors)
+  * kats.json         — hex strings lifted from test code:
+        rfc8032        src/sign/eddsa/eddsa_test.rs:19-46   (RFC 8032 §7.1 vectors)
+        scalar_kats    src/group/edwards25519/scalar_test.rs:27-75
+        decode_kat     src/group/edwards25519/ge.rs:65-73
+        weak_keys      src/group/edwards25519/constants.rs:3744-3775
+    plus quirk vectors whose expected outputs come from the C oracle and are cross-checked against
+    oracle/bigint_model.py before being written (no reference test covers them).
+"""
+import json
+import os
+import re
+import shutil
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def main():
+    import bigint_model as M
+    import oracle_lib
+
+    orc = oracle_lib.Oracle()
+    shutil.copyfile(os.path.join(REF, "src/sign/eddsa/testdata/sign.input.gz"), os.path.join(HERE, "sign.input.gz"))
+
+    out = {}
+    # RFC 8032 vectors
+    txt = open(os.path.join(REF, "src/sign/eddsa/eddsa_test.rs")).read()
+    vecs = re.findall(r'private:\s*"([0-9a-f]*)",\s*public:\s*"([0-9a-f]*)",\s*message:\s*"([0-9a-f]*)",\s*signature:\s*"([0-9a-f]*)"', txt)
+    assert len(vecs) == 5
+    out["rfc8032"] = [dict(private=a, public=b, message=c, signature=d) for a, b, c, d in vecs]
+    # scalar KATs
+    out["scalar_kats"] = {
+        "int64_0x100_plus_1": "0101000000000000000000000000000000000000000000000000000000000000",
+        "int64_minus_1": "ecd3f55c1a631258d69cf7a2def9de1400000000000000000000000000000010",
+        "int64_1": "0100000000000000000000000000000000000000000000000000000000000000",
+        "set_bytes_00010203": "0001020300000000000000000000000000000000000000000000000000000000",
+    }
+    st = open(os.path.join(REF, "src/group/edwards25519/scalar_test.rs")).read()
+    for v in out["scalar_kats"].values():
+        assert v in st, v
+    # decode KAT
+    gt = open(os.path.join(REF, "src/group/edwards25519/ge.rs")).read()
+    m = re.search(r"let arr: \[u8; 32\] = \[([^\]]*)\]", gt)
+    out["decode_kat"] = bytes(int(x) for x in m.group(1).replace("\n", " ").split(",") if x.strip()).hex()
+    # weak keys
+    ct = open(os.path.join(REF, "src/group/edwards25519/constants.rs")).read()
+    wk = ct[ct.index("pub const WEAK_KEYS"):]
+    rows = re.findall(r"\[\s*((?:0x[0-9a-f]{2},\s*){32})\]", wk)
+    assert len(rows) == 5
+    out["weak_keys"] = [bytes(int(x, 16) for x in re.findall(r"0x[0-9a-f]{2}", r)).hex() for r in rows]
+
+    # quirk vectors: scalar x point -> encoding, oracle output cross-checked with the big-int model
+    L, P = M.L, M.P
+    sc = [0, 1, 2, 8, L - 1, L, L + 1, 8 * L, 2**252, 2**255 - 1, 2**255, 2**255 + 1, 2**256 - 1]
+    sc_bytes = [v.to_bytes(32, "little") for v in sc]
+    for top in (0x7F, 0x80, 0x8F, 0x90, 0xFF):
+        sc_bytes.append(bytes([0x11] * 31 + [top]))
+        sc_bytes.append(bytes([0xEE] * 31 + [top]))
+    pts = [M.encode(M.IDENT), M.encode(M.B)] + [bytes.fromhex(h) for h in out["weak_keys"]]
+    pts += [(P + k).to_bytes(32, "little") for k in (0, 1, 3, 18)]               # non-canonical y
+    pts += [bytes([1] + [0] * 30 + [0x80])]                                     # x = 0 with the sign bit
+    pts += [M.encode(M.point_mul((12345).to_bytes(32, "little")))]
+    q = []
+    for pe in pts:
+        ext, ok = orc.decode(pe)
+        pm = M.decode(pe)
+        assert (pm is not None) == bool(ok), pe.hex()
+        if not ok:
+            q.append(dict(point=pe.hex(), ok=0))
+            continue
+        assert orc.encode(ext) == M.encode(pm)
+        for s in sc_bytes:
+            o = orc.mul(s, ext)
+            assert o == M.encode(M.point_mul(s, pm)), (s.hex(), pe.hex())
+            q.append(dict(point=pe.hex(), ok=1, scalar=s.hex(), out=o.hex()))
+    out["quirk_mul"] = q
+    qb = []
+    for s in sc_bytes:
+        o = orc.mul_base(s)
+        assert o == M.encode(M.point_mul(s))
+        qb.append(dict(scalar=s.hex(), out=o.hex()))
+    out["quirk_mul_base"] = qb
+    # invalid encodings (no square root): first few y values that do not decode
+    bad = []
+    y = 2
+    while len(bad) < 4:
+        b = y.to_bytes(32, "little")
+        if M.decode(b) is None:
+            assert orc.decode(b)[1] == 0
+            bad.append(b.hex())
+        y += 1
+    out["invalid_encodings"] = bad
+    with open(os.path.join(HERE, "kats.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", len(q), "quirk_mul,", len(qb), "quirk_mul_base vectors")
+
+
+if __name__ == "__main__":
+    main()

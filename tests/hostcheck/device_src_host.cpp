@@ -1,0 +1,160 @@
+// TEST INFRASTRUCTURE: compiles the DEVICE arithmetic headers (kyber-rs_amd/csrc/*.h) with g++ so
+// that tests/test_device_source_on_host.py can run the exact source the HIP kernels inline — limb
+// bounds included, every multiply shadowed by a 128-bit overflow check — against the oracle on a
+// machine without a GPU.  Built into tests/hostcheck/_build/libdevsrc_host.so by the test itself.
+// This library is never loaded by the product (kyber-rs_amd/ loads only libkyber_ed25519_hip.so and
+// fails without a GPU); it is not a CPU fallback.
+#define KYB_HOST_TEST 1
+#include <atomic>
+#include <cstring>
+#include <vector>
+#include "../../kyber-rs_amd/csrc/schnorr.h"
+
+static std::atomic<long> g_overflows{0};
+extern "C" void kyb_host_overflow(const char*) { g_overflows++; }
+
+using namespace kyb;
+
+static std::vector<uint32_t> g_base_table;
+static void ensure_table() {
+  if (!g_base_table.empty()) return;
+  g_base_table.resize(KYB_BASE_TABLE_WORDS);
+  for (int pos = 0; pos < 64; ++pos)
+    for (int j = 0; j < 8; ++j) ge_base_table_entry(g_base_table.data(), pos, j);
+}
+static void load_words(uint32_t w[8], const uint8_t* b) { memcpy(w, b, 32); }
+
+extern "C" {
+long hd_overflows() { return g_overflows.load(); }
+const uint32_t* hd_base_table() { ensure_table(); return g_base_table.data(); }
+
+void hd_mul_base(uint8_t out[32], const uint8_t scalar[32]) {
+  ensure_table();
+  uint32_t a[8], w[8];
+  load_words(a, scalar);
+  tbl_base_words tbl{g_base_table.data()};
+  ge_p3 h;
+  ge_scalarmult_base(h, a, tbl);
+  ge_encode(w, h.X, h.Y, h.Z);
+  memcpy(out, w, 32);
+}
+void hd_mul(uint8_t out[32], int32_t out_ext[40], const uint8_t scalar[32], const int32_t pt[40]) {
+  uint32_t a[8], w[8];
+  load_words(a, scalar);
+  ge_p3 P;
+  fe_from_ref10(P.X, pt); fe_from_ref10(P.Y, pt + 10); fe_from_ref10(P.Z, pt + 20); fe_from_ref10(P.T, pt + 30);
+  tbl_array_cached tbl;
+  ge_p2 r;
+  ge_scalarmult(r, a, P, tbl);
+  ge_encode(w, r.X, r.Y, r.Z);
+  memcpy(out, w, 32);
+  if (out_ext) {
+    fe zi, x, y, t, one;
+    fe_invert(zi, r.Z); fe_mul(x, r.X, zi); fe_mul(y, r.Y, zi); fe_mul(t, x, y); fe_one(one);
+    fe_to_ref10(out_ext, x); fe_to_ref10(out_ext + 10, y); fe_to_ref10(out_ext + 20, one); fe_to_ref10(out_ext + 30, t);
+  }
+}
+int hd_decode(int32_t out_ext[40], const uint8_t enc[32]) {
+  uint32_t w[8];
+  load_words(w, enc);
+  ge_p3 h;
+  uint32_t ok = ge_decode(h, w);
+  fe_to_ref10(out_ext, h.X); fe_to_ref10(out_ext + 10, h.Y); fe_to_ref10(out_ext + 20, h.Z); fe_to_ref10(out_ext + 30, h.T);
+  return (int)ok;
+}
+void hd_encode(uint8_t enc[32], const int32_t pt[40]) {
+  ge_p3 P;
+  fe_from_ref10(P.X, pt); fe_from_ref10(P.Y, pt + 10); fe_from_ref10(P.Z, pt + 20); fe_from_ref10(P.T, pt + 30);
+  uint32_t w[8];
+  ge_encode(w, P.X, P.Y, P.Z);
+  memcpy(enc, w, 32);
+}
+void hd_add(int32_t out[40], const int32_t a[40], const int32_t b[40], int sub) {
+  ge_p3 A, B, R;
+  fe_from_ref10(A.X, a); fe_from_ref10(A.Y, a + 10); fe_from_ref10(A.Z, a + 20); fe_from_ref10(A.T, a + 30);
+  fe_from_ref10(B.X, b); fe_from_ref10(B.Y, b + 10); fe_from_ref10(B.Z, b + 20); fe_from_ref10(B.T, b + 30);
+  ge_cached c;
+  ge_p3_to_cached(c, B);
+  ge_cached_cneg(c, sub ? 1u : 0u);
+  ge_p1p1 r;
+  ge_add(r, A, c);
+  ge_p1p1_to_p3(R, r);
+  fe_to_ref10(out, R.X); fe_to_ref10(out + 10, R.Y); fe_to_ref10(out + 20, R.Z); fe_to_ref10(out + 30, R.T);
+}
+void hd_fe_mul(uint8_t out[32], const uint8_t a[32], const uint8_t b[32], int sq) {
+  uint32_t wa[8], wb[8], w[8];
+  load_words(wa, a); load_words(wb, b);
+  fe fa, fb, h;
+  fe_from_words(fa, wa); fe_from_words(fb, wb);
+  if (sq) fe_sq(h, fa); else fe_mul(h, fa, fb);
+  fe_to_words(w, h);
+  memcpy(out, w, 32);
+}
+void hd_fe_invert(uint8_t out[32], const uint8_t a[32]) {
+  uint32_t wa[8], w[8];
+  load_words(wa, a);
+  fe fa, h;
+  fe_from_words(fa, wa);
+  fe_invert(h, fa);
+  fe_to_words(w, h);
+  memcpy(out, w, 32);
+}
+// worst-case bound probe: all limbs of f at kf*T, of g at kg*T (in 1/100 units)
+void hd_fe_mul_bound_probe(int kf100, int kg100) {
+  fe f, g, h;
+  for (int i = 0; i < 10; ++i) {
+    uint64_t T = (i & 1) ? (1u << 25) : (1u << 26);
+    f.v[i] = (uint32_t)(T * kf100 / 100);
+    g.v[i] = (uint32_t)(T * kg100 / 100);
+  }
+  fe_mul(h, f, g);
+}
+void hd_fe_sq_bound_probe(int kf100) {
+  fe f, h;
+  for (int i = 0; i < 10; ++i) {
+    uint64_t T = (i & 1) ? (1u << 25) : (1u << 26);
+    f.v[i] = (uint32_t)(T * kf100 / 100);
+  }
+  fe_sq(h, f);
+}
+void hd_sc_muladd(uint8_t out[32], const uint8_t a[32], const uint8_t b[32], const uint8_t c[32]) {
+  uint32_t wa[8], wb[8], wc[8], w[8];
+  load_words(wa, a); load_words(wb, b); load_words(wc, c);
+  sc_muladd(w, wa, wb, wc);
+  memcpy(out, w, 32);
+}
+void hd_sc_reduce512(uint8_t out[32], const uint8_t in[64]) {
+  uint32_t x[16], w[8];
+  memcpy(x, in, 64);
+  sc_reduce512(w, x);
+  memcpy(out, w, 32);
+}
+void hd_sha512(uint8_t out[64], const uint8_t* msg, uint32_t n) {
+  sha512_ctx c;
+  sha512_init(c);
+  sha512_bytes(c, msg, n);
+  uint32_t d[16];
+  sha512_final(d, c);
+  memcpy(out, d, 64);
+}
+void hd_schnorr_sign(uint8_t sig[64], const uint8_t x[32], const uint8_t k[32], const uint8_t* msg, uint32_t n) {
+  ensure_table();
+  uint32_t wx[8], wk[8], s[16];
+  load_words(wx, x); load_words(wk, k);
+  tbl_base_words tbl{g_base_table.data()};
+  schnorr_sign(s, wx, wk, msg, n, tbl);
+  memcpy(sig, s, 64);
+}
+void hd_recode(int8_t e[64], const uint8_t scalar[32]) {
+  uint32_t a[8];
+  load_words(a, scalar);
+  sc_digits d;
+  sc_recode(d, a);
+  for (int i = 0; i < 63; ++i) {
+    uint32_t mag, neg;
+    sc_digit(mag, neg, d, i);
+    e[i] = (int8_t)(neg ? -(int)mag : (int)mag);
+  }
+  e[63] = (int8_t)d.top;
+}
+}

@@ -1,0 +1,162 @@
+"""ctypes binding of oracle/_build/liboracle.so (TEST INFRASTRUCTURE; see oracle/ed25519_oracle.c)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+
+
+def build():
+    src = os.path.join(ORACLE_DIR, "ed25519_oracle.c")
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+    return LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = ctypes.CDLL(build())
+        self.lib.orc_init()
+        self.lib.orc_decode.restype = ctypes.c_int
+
+    @staticmethod
+    def _b(n):
+        return ctypes.create_string_buffer(n)
+
+    def mul_base(self, scalar: bytes) -> bytes:
+        o = self._b(32)
+        self.lib.orc_mul_base(o, None, scalar)
+        return o.raw
+
+    def mul_base_ext(self, scalar: bytes) -> np.ndarray:
+        e = np.zeros(40, dtype=np.int32)
+        self.lib.orc_mul_base(None, _p(e), scalar)
+        return e
+
+    def mul(self, scalar: bytes, pt_ext) -> bytes:
+        o = self._b(32)
+        self.lib.orc_mul(o, None, scalar, _p(_i32(pt_ext)))
+        return o.raw
+
+    def mul_ext(self, scalar: bytes, pt_ext) -> np.ndarray:
+        e = np.zeros(40, dtype=np.int32)
+        self.lib.orc_mul(None, _p(e), scalar, _p(_i32(pt_ext)))
+        return e
+
+    def decode(self, enc: bytes):
+        e = np.zeros(40, dtype=np.int32)
+        ok = self.lib.orc_decode(_p(e), enc)
+        return e, int(ok)
+
+    def encode(self, ext) -> bytes:
+        o = self._b(32)
+        self.lib.orc_encode(o, _p(_i32(ext)))
+        return o.raw
+
+    def add(self, a, b, sub=False) -> np.ndarray:
+        o = np.zeros(40, dtype=np.int32)
+        self.lib.orc_add(_p(o), _p(_i32(a)), _p(_i32(b)), 1 if sub else 0)
+        return o
+
+    def neg(self, a) -> np.ndarray:
+        o = np.zeros(40, dtype=np.int32)
+        self.lib.orc_neg(_p(o), _p(_i32(a)))
+        return o
+
+    def base(self) -> np.ndarray:
+        o = np.zeros(40, dtype=np.int32)
+        self.lib.orc_base(_p(o))
+        return o
+
+    def null(self) -> np.ndarray:
+        o = np.zeros(40, dtype=np.int32)
+        self.lib.orc_null(_p(o))
+        return o
+
+    def sc_muladd(self, a, b, c) -> bytes:
+        o = self._b(32)
+        self.lib.orc_sc_muladd(o, a, b, c)
+        return o.raw
+
+    def sc_reduce64(self, x: bytes) -> bytes:
+        o = self._b(32)
+        self.lib.orc_sc_reduce64(o, x)
+        return o.raw
+
+    def sc_reduce32(self, x: bytes) -> bytes:
+        o = self._b(32)
+        self.lib.orc_sc_reduce32(o, x)
+        return o.raw
+
+    def sha512(self, m: bytes) -> bytes:
+        o = self._b(64)
+        self.lib.orc_sha512(o, m, ctypes.c_size_t(len(m)))
+        return o.raw
+
+    def schnorr_sign(self, x, k, msg) -> bytes:
+        o = self._b(64)
+        self.lib.orc_schnorr_sign(o, x, k, msg, ctypes.c_size_t(len(msg)))
+        return o.raw
+
+    def eddsa_expand(self, seed):
+        s, p, pub = self._b(32), self._b(32), self._b(32)
+        self.lib.orc_eddsa_expand(s, p, pub, seed)
+        return s.raw, p.raw, pub.raw
+
+    def eddsa_sign(self, seed, msg) -> bytes:
+        o = self._b(64)
+        self.lib.orc_eddsa_sign(o, seed, msg, ctypes.c_size_t(len(msg)))
+        return o.raw
+
+    def const_bytes(self, which: int) -> bytes:
+        o = self._b(32)
+        self.lib.orc_const_bytes(o, which)
+        return o.raw
+
+    def base_table_bytes(self, i: int, j: int) -> bytes:
+        o = self._b(96)
+        self.lib.orc_base_table_bytes(o, i, j)
+        return o.raw
+
+    # ---- batches (numpy) ----
+    def mul_base_batch(self, scalars, nthreads: int = 1) -> np.ndarray:
+        s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        out = np.empty_like(s)
+        self.lib.orc_mul_base_batch(_p(out), _p(s), ctypes.c_size_t(s.shape[0]), nthreads)
+        return out
+
+    def mul_batch(self, scalars, pts_ext, nthreads: int = 1) -> np.ndarray:
+        s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        out = np.empty_like(s)
+        p = _i32(pts_ext).reshape(-1, 40)
+        self.lib.orc_mul_batch(_p(out), _p(s), _p(p), ctypes.c_size_t(s.shape[0]), nthreads)
+        return out
+
+    def mul_base_ext_batch(self, scalars) -> np.ndarray:
+        s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        if s.shape[0] == 0:
+            return np.zeros((0, 40), np.int32)
+        return np.stack([self.mul_base_ext(s[i].tobytes()) for i in range(s.shape[0])])
+
+    def schnorr_sign_batch(self, x, k, msgs, nthreads: int = 1) -> np.ndarray:
+        xs = np.ascontiguousarray(x, dtype=np.uint8).reshape(-1, 32)
+        ks = np.ascontiguousarray(k, dtype=np.uint8).reshape(-1, 32)
+        n = xs.shape[0]
+        off = np.zeros(n + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(m) for m in msgs]).astype(np.uint32)
+        blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()
+        sig = np.empty((n, 64), dtype=np.uint8)
+        self.lib.orc_schnorr_sign_batch(_p(sig), _p(xs), _p(ks), _p(blob), _p(off), ctypes.c_size_t(n), nthreads)
+        return sig

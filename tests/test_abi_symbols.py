@@ -1,0 +1,54 @@
+"""The C-ABI library loads and exports every symbol include/kyber_ed25519.h declares.  CPU only:
+no compute call is made (kyb_init must FAIL here — there is no GPU and no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "kyber_ed25519.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(kyb_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_python_binding_agree():
+    import kyber_rs_amd
+    assert header_symbols() == sorted(kyber_rs_amd.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    import kyber_rs_amd
+    lib = kyber_rs_amd.load_library()
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    import torch
+    import kyber_rs_amd
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present; the failure path is for GPU-less hosts")
+    lib = kyber_rs_amd.load_library()
+    assert lib.kyb_init(0) == -3          # KYB_E_NO_DEVICE
+    assert b"no CPU path" in lib.kyb_last_error()
+    out = ctypes.create_string_buffer(32)
+    assert lib.kyb_mul_base_batch(bytes(32), 1, out, None) == -1    # KYB_E_NOT_INIT
+    with pytest.raises(kyber_rs_amd.KyberHipError):
+        kyber_rs_amd.Engine(0)
+
+
+def test_product_tree_does_not_reference_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/"""
+    bad = []
+    for base in ("kyber-rs_amd", "kyber_rs_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".inc", ".rs")):
+                    t = open(os.path.join(dp, f), errors="replace").read()
+                    if re.search(r"oracle/|liboracle|oracle_lib|bigint_model", t):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,169 @@
+"""Runs the DEVICE arithmetic source (kyber-rs_amd/csrc/*.h) compiled by g++ against the oracle.
+
+Purpose: catch limb-bound and formula errors in the code the HIP kernels inline, on a machine without
+a GPU.  Every 32x32 multiply and every limb add/sub in that build is shadowed by an overflow check
+(KYB_HOST_TEST).  This is a test of the device source, not a CPU implementation of the product: the
+library built here lives under tests/ and nothing outside tests/ loads it.  CPU only."""
+import ctypes
+import gzip
+import hashlib
+import json
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import bigint_model as M  # noqa: E402
+
+KATS = json.load(open(os.path.join(HERE, "golden", "kats.json")))
+
+
+@pytest.fixture(scope="module")
+def hd():
+    src = os.path.join(HERE, "hostcheck", "device_src_host.cpp")
+    out = os.path.join(HERE, "hostcheck", "_build", "libdevsrc_host.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    deps = [src] + [os.path.join(ROOT, "kyber-rs_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "kyber-rs_amd", "csrc")) if f.endswith((".h", ".inc"))]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-o", out, src])
+    lib = ctypes.CDLL(out)
+    lib.hd_overflows.restype = ctypes.c_long
+    lib.hd_decode.restype = ctypes.c_int
+    return lib
+
+
+def B(n):
+    return ctypes.create_string_buffer(n)
+
+
+def p32(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def test_field_ops_match_integers(hd):
+    rnd = random.Random(1)
+    mask = 2**255 - 1
+    for _ in range(3000):
+        a = bytes(rnd.getrandbits(8) for _ in range(32)); b = bytes(rnd.getrandbits(8) for _ in range(32)); o = B(32)
+        ai, bi = int.from_bytes(a, "little") & mask, int.from_bytes(b, "little") & mask
+        hd.hd_fe_mul(o, a, b, 0)
+        assert int.from_bytes(o.raw, "little") == ai * bi % M.P
+        hd.hd_fe_mul(o, a, b, 1)
+        assert int.from_bytes(o.raw, "little") == ai * ai % M.P
+    for v in [0, 1, 2, M.P - 1, M.P, M.P + 18, 2**255 - 1, 19, 2**254]:
+        o = B(32)
+        hd.hd_fe_invert(o, v.to_bytes(32, "little"))
+        assert int.from_bytes(o.raw, "little") == pow(v % M.P, M.P - 2, M.P)
+    assert hd.hd_overflows() == 0
+
+
+def test_limb_bound_contract(hd):
+    """fe_mul(f <= 6T, g <= 3.3T) and fe_sq(f <= 3.3T) never overflow; just beyond, they do."""
+    base = hd.hd_overflows()
+    for kf, kg in [(600, 330), (630, 336), (101, 101), (500, 101), (300, 300)]:
+        hd.hd_fe_mul_bound_probe(kf, kg)
+    for k in (101, 202, 330, 336):
+        hd.hd_fe_sq_bound_probe(k)
+    assert hd.hd_overflows() == base
+    hd.hd_fe_mul_bound_probe(640, 337)
+    hd.hd_fe_sq_bound_probe(340)
+    assert hd.hd_overflows() > base
+
+
+def test_recoding_matches_reference_recode(hd):
+    """sc_recode (one 256-bit add) == the reference's carry sweep (ge.rs:443-459), incl. e[63] in 9..16 -> 0"""
+    rnd = random.Random(2)
+    cases = [bytes(32), bytes([255] * 32), bytes([0x88] * 32), bytes([0x77] * 32), bytes([0] * 31 + [0x80])]
+    cases += [bytes(rnd.getrandbits(8) for _ in range(32)) for _ in range(2000)]
+    for s in cases:
+        e = (ctypes.c_int8 * 64)()
+        hd.hd_recode(e, s)
+        want = M.recode(s)
+        if not (0 <= want[63] <= 8):
+            want[63] = 0
+        assert list(e) == want
+
+
+def test_scalar_mult_matches_oracle(hd, oracle):
+    base = hd.hd_overflows()
+    rnd = random.Random(3)
+    for q in KATS["quirk_mul_base"]:
+        o = B(32); hd.hd_mul_base(o, bytes.fromhex(q["scalar"]))
+        assert o.raw.hex() == q["out"]
+    for q in KATS["quirk_mul"]:
+        if not q["ok"]:
+            continue
+        ext, _ = oracle.decode(bytes.fromhex(q["point"]))
+        o = B(32); hd.hd_mul(o, None, bytes.fromhex(q["scalar"]), p32(ext))
+        assert o.raw.hex() == q["out"], q
+    for _ in range(150):
+        s = bytes(rnd.getrandbits(8) for _ in range(32))
+        pt = oracle.mul_base_ext(bytes(rnd.getrandbits(8) for _ in range(32)))
+        o = B(32); ext = np.zeros(40, dtype=np.int32)
+        hd.hd_mul(o, p32(ext), s, p32(pt))
+        assert o.raw == oracle.mul(s, pt)
+        assert oracle.encode(ext) == o.raw and list(ext[20:30]) == [1] + [0] * 9
+        hd.hd_mul_base(o, s)
+        assert o.raw == oracle.mul_base(s)
+    assert hd.hd_overflows() == base
+
+
+def test_decode_encode_add(hd, oracle):
+    base = hd.hd_overflows()
+    rnd = random.Random(4)
+    encs = [bytes.fromhex(h) for h in KATS["weak_keys"] + KATS["invalid_encodings"] + [KATS["decode_kat"]]]
+    encs += [(M.P + k).to_bytes(32, "little") for k in range(19)]
+    encs += [bytes([1] + [0] * 30 + [0x80])]
+    encs += [bytes(rnd.getrandbits(8) for _ in range(32)) for _ in range(300)]
+    good = []
+    for e in encs:
+        ext = np.zeros(40, dtype=np.int32)
+        ok = hd.hd_decode(p32(ext), e)
+        oext, ook = oracle.decode(e)
+        assert ok == ook, e.hex()
+        if ok:
+            assert oracle.encode(ext) == oracle.encode(oext)
+            o = B(32); hd.hd_encode(o, p32(oext))
+            assert o.raw == oracle.encode(oext)
+            good.append(oext)
+    for i in range(len(good) - 1):
+        for sub in (0, 1):
+            out = np.zeros(40, dtype=np.int32)
+            hd.hd_add(p32(out), p32(good[i]), p32(good[i + 1]), sub)
+            assert oracle.encode(out) == oracle.encode(oracle.add(good[i], good[i + 1], sub=bool(sub)))
+    assert hd.hd_overflows() == base
+
+
+def test_scalar_mod_l_and_sha512(hd):
+    rnd = random.Random(5)
+    edge = [bytes(32), bytes([255] * 32), M.L.to_bytes(32, "little"), (M.L - 1).to_bytes(32, "little")]
+    cases = [(a, b, c) for a in edge for b in edge for c in edge]
+    cases += [tuple(bytes(rnd.getrandbits(8) for _ in range(32)) for _ in range(3)) for _ in range(2000)]
+    for a, b, c in cases:
+        o = B(32); hd.hd_sc_muladd(o, a, b, c)
+        assert int.from_bytes(o.raw, "little") == (int.from_bytes(a, "little") * int.from_bytes(b, "little") + int.from_bytes(c, "little")) % M.L
+    for x in [bytes(64), bytes([255] * 64)] + [bytes(rnd.getrandbits(8) for _ in range(64)) for _ in range(2000)]:
+        o = B(32); hd.hd_sc_reduce512(o, x)
+        assert int.from_bytes(o.raw, "little") == int.from_bytes(x, "little") % M.L
+    for n in [0, 1, 55, 111, 112, 113, 127, 128, 129, 239, 240, 241, 300, 1000]:
+        m = bytes(rnd.getrandbits(8) for _ in range(n)); o = B(64)
+        hd.hd_sha512(o, m, n)
+        assert o.raw == hashlib.sha512(m).digest()
+
+
+def test_sign_golden_lines(hd, oracle):
+    """device signing source on the first 96 golden EdDSA lines re-expressed as (x, k, msg) triples"""
+    lines = gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n")[:96]
+    for ln in lines:
+        p = ln.split(":")
+        seed, msg, sig = bytes.fromhex(p[0])[:32], bytes.fromhex(p[2]), bytes.fromhex(p[3])[:64]
+        x, prefix, _ = oracle.eddsa_expand(seed)
+        k = oracle.sc_reduce64(hashlib.sha512(prefix + msg).digest())
+        o = B(64); hd.hd_schnorr_sign(o, x, k, msg, len(msg))
+        assert o.raw == sig

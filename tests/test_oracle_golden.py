@@ -1,0 +1,153 @@
+"""Pins the CPU oracle (oracle/ed25519_oracle.c) against every known-answer vector the reference's
+own tests hold for the hot path and against the independent big-int model.
+CPU only."""
+import gzip
+import hashlib
+import json
+import os
+import random
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+import bigint_model as M  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden")
+KATS = json.load(open(os.path.join(GOLD, "kats.json")))
+
+
+def golden_lines():
+    for ln in gzip.open(os.path.join(GOLD, "sign.input.gz"), "rt").read().split("\n"):
+        if ln:
+            p = ln.split(":")
+            yield bytes.fromhex(p[0])[:32], bytes.fromhex(p[1]), bytes.fromhex(p[2]), bytes.fromhex(p[3])[:64]
+
+
+def test_golden_sign_input_all_1024_lines(oracle):
+    """tests/sign/eddsa.rs:36-94: public key and signature of every line (2 fixed-base mults, 2 encodes,
+    SHA-512 -> mod L, s = r + a*h mod L per line)."""
+    n = 0
+    for seed, pub, msg, sig in golden_lines():
+        secret, prefix, p = oracle.eddsa_expand(seed)
+        assert p == pub
+        assert oracle.eddsa_sign(seed, msg) == sig
+        n += 1
+    assert n == 1024
+
+
+def test_rfc8032_vectors(oracle):
+    """src/sign/eddsa/eddsa_test.rs:19-107"""
+    for v in KATS["rfc8032"]:
+        seed, msg = bytes.fromhex(v["private"]), bytes.fromhex(v["message"])
+        assert oracle.eddsa_expand(seed)[2].hex() == v["public"]
+        assert oracle.eddsa_sign(seed, msg).hex() == v["signature"]
+        assert M.eddsa_sign(seed, msg).hex() == v["signature"]
+
+
+def test_golden_verify_equation_pins_variable_base(oracle):
+    """eddsa_sig.rs:194-211: s*B == R + h*A on golden signatures — the only place the reference's
+    vectors reach the variable-base routine (h*A).  64 lines."""
+    for i, (seed, pub, msg, sig) in enumerate(golden_lines()):
+        if i % 16:
+            continue
+        a_ext, ok = oracle.decode(pub)
+        r_ext, ok2 = oracle.decode(sig[:32])
+        assert ok and ok2
+        h = oracle.sc_reduce64(hashlib.sha512(sig[:32] + pub + msg).digest())
+        ha = oracle.mul_ext(h, a_ext)
+        rha = oracle.add(r_ext, ha)
+        assert oracle.encode(rha) == oracle.mul_base(sig[32:])
+
+
+def test_scalar_kats(oracle):
+    """scalar_test.rs:27-75 (set_int64 / set_bytes / Display)"""
+    k = KATS["scalar_kats"]
+    L = M.L
+    one = (1).to_bytes(32, "little")
+    x100 = (0x100).to_bytes(32, "little")
+    zero = bytes(32)
+    assert oracle.sc_muladd(one, x100, one).hex() == k["int64_0x100_plus_1"]          # 0x100 + 1
+    assert oracle.sc_reduce32(((L - 1) % 2**256).to_bytes(32, "little")).hex() == k["int64_minus_1"]
+    assert oracle.sc_muladd(zero, zero, one).hex() == k["int64_1"]
+    assert oracle.sc_reduce64(bytes([0, 1, 2, 3]) + bytes(60)).hex() == k["set_bytes_00010203"]
+
+
+def test_scalar_arithmetic_is_canonical_mod_l(oracle):
+    """sc_mul_add / set_bytes restated with ref10 limbs must equal plain integer arithmetic mod L for
+    ANY 256/512-bit inputs (scalar.rs:279-744; integer.rs:386-397)."""
+    rnd = random.Random(7)
+    edge = [bytes(32), bytes([255] * 32), (M.L).to_bytes(32, "little"), (M.L - 1).to_bytes(32, "little"), (2**255).to_bytes(32, "little")]
+    cases = [(a, b, c) for a in edge for b in edge for c in edge]
+    cases += [tuple(bytes(rnd.getrandbits(8) for _ in range(32)) for _ in range(3)) for _ in range(3000)]
+    for a, b, c in cases:
+        want = (int.from_bytes(a, "little") * int.from_bytes(b, "little") + int.from_bytes(c, "little")) % M.L
+        assert int.from_bytes(oracle.sc_muladd(a, b, c), "little") == want
+    for x in [bytes(64), bytes([255] * 64)] + [bytes(rnd.getrandbits(8) for _ in range(64)) for _ in range(3000)]:
+        assert int.from_bytes(oracle.sc_reduce64(x), "little") == int.from_bytes(x, "little") % M.L
+
+
+def test_decode_kats(oracle):
+    """ge.rs:65-73 and point_test.rs:19-25 (the five WEAK_KEYS decode)"""
+    assert oracle.decode(bytes.fromhex(KATS["decode_kat"]))[1] == 1
+    for h in KATS["weak_keys"]:
+        ext, ok = oracle.decode(bytes.fromhex(h))
+        assert ok == 1
+        # small order: 8 * P == neutral element
+        assert oracle.mul((8).to_bytes(32, "little"), ext) == M.encode(M.IDENT)
+    for h in KATS["invalid_encodings"]:
+        assert oracle.decode(bytes.fromhex(h))[1] == 0
+
+
+def test_quirk_vectors_match_fixture(oracle):
+    """scalars >= 2^255, L, 8L, non-canonical encodings, x = 0 with sign bit, small-order points"""
+    for q in KATS["quirk_mul"]:
+        ext, ok = oracle.decode(bytes.fromhex(q["point"]))
+        assert ok == q["ok"]
+        if ok:
+            assert oracle.mul(bytes.fromhex(q["scalar"]), ext).hex() == q["out"]
+    for q in KATS["quirk_mul_base"]:
+        assert oracle.mul_base(bytes.fromhex(q["scalar"])).hex() == q["out"]
+
+
+def test_oracle_equals_bigint_model_on_random_inputs(oracle):
+    rnd = random.Random(11)
+    for _ in range(24):
+        s = bytes(rnd.getrandbits(8) for _ in range(32))
+        ps = bytes(rnd.getrandbits(8) for _ in range(32))
+        assert oracle.mul_base(s) == M.encode(M.point_mul(s))
+        pt = oracle.mul_base_ext(ps)                     # random point, arbitrary Z
+        affine = M.point_mul(ps)
+        assert oracle.encode(pt) == M.encode(affine)
+        assert oracle.mul(s, pt) == M.encode(M.point_mul(s, affine))
+        x, k, m = s, ps, bytes(rnd.getrandbits(8) for _ in range(rnd.randrange(0, 200)))
+        assert oracle.schnorr_sign(x, k, m) == M.schnorr_sign(x, k, m)
+
+
+def test_group_identities(oracle):
+    """util/test/group_test.rs:243-435 restated on encodings: B+B == 2B, (-1)B + B == 0, DH
+    commutativity, 0*P == 0, 1*P == P, mul(s, Some(B)) == mul(s, None)."""
+    rnd = random.Random(5)
+    Bext = oracle.base()
+    two = (2).to_bytes(32, "little")
+    assert oracle.encode(oracle.add(Bext, Bext)) == oracle.mul_base(two)
+    m1 = (M.L - 1).to_bytes(32, "little")
+    assert oracle.encode(oracle.add(oracle.mul_base_ext(m1), Bext)) == M.encode(M.IDENT)
+    assert oracle.encode(oracle.null()) == M.encode(M.IDENT)
+    for _ in range(8):
+        s1 = M.sc_bytes(rnd.getrandbits(300))
+        s2 = M.sc_bytes(rnd.getrandbits(300))
+        p1, p2 = oracle.mul_base_ext(s1), oracle.mul_base_ext(s2)
+        assert oracle.mul(s2, p1) == oracle.mul(s1, p2)
+        assert oracle.mul(s1, Bext) == oracle.mul_base(s1)
+        assert oracle.mul(bytes(32), p1) == M.encode(M.IDENT)
+        assert oracle.mul((1).to_bytes(32, "little"), p1) == oracle.encode(p1)
+        assert oracle.encode(oracle.add(p1, p2, sub=True)) == oracle.encode(oracle.add(p1, oracle.neg(p2)))
+
+
+def test_sha512(oracle):
+    rnd = random.Random(3)
+    for n in [0, 1, 55, 111, 112, 113, 127, 128, 129, 239, 240, 241, 1000]:
+        m = bytes(rnd.getrandbits(8) for _ in range(n))
+        assert oracle.sha512(m) == hashlib.sha512(m).digest()

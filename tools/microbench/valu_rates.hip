@@ -43,6 +43,7 @@ __device__ __forceinline__ unsigned long long memrealtime() {
   unsigned long long t0 = memtime(); unsigned long long r0 = memrealtime();
 
 #define KERNEL_EPILOGUE(T)                                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             \
   unsigned long long t1 = memtime(); unsigned long long r1 = memrealtime();     \
   T s = 0; for (int c = 0; c < CHAINS; ++c) s += acc[c];                         \
   if (s == (T)0x1234567) sink[0] = (unsigned)s;                                  \
@@ -113,6 +114,15 @@ DEF_K32(k_mad_u16, "v_mad_u16 %0, %0, %1, %0", "memory")
 DEF_K32(k_mov_b32, "v_mov_b32 %0, %1", "memory")
 DEF_K32(k_bpermute, "ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)", "memory")
 DEF_K32(k_accvgpr_rw, "v_accvgpr_write_b32 a0, %0\n\ts_nop 1\n\tv_accvgpr_read_b32 %0, a0", "a0")
+DEF_K32(k_cndmask_e64_sgpr, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]", "memory")
+DEF_K32(k_cmp_cndmask, "v_cmp_eq_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc", "vcc")
+DEF_K32(k_cmp_e64_cndmask, "v_cmp_eq_u32_e64 s[20:21], %1, %2\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]", "s20")
+DEF_K32(k_and_b32, "v_and_b32 %0, %0, %1", "memory")
+DEF_K32(k_or_b32, "v_or_b32 %0, %0, %1", "memory")
+DEF_K32(k_bfi_b32, "v_bfi_b32 %0, %1, %2, %0", "memory")
+DEF_K32(k_sub_u32, "v_sub_u32 %0, %0, %1", "memory")
+DEF_K32(k_lshlrev_b32, "v_lshlrev_b32 %0, 1, %0", "memory")
+DEF_K32(k_bpermute_nowait, "ds_bpermute_b32 %0, %1, %0", "memory")
 DEF_K32(k_mov_dpp, "v_mov_b32_dpp %0, %0 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf", "memory")
 
 // mixed stream approximating a field-multiply inner loop: 10 mads then 3 simple ops
@@ -178,6 +188,9 @@ int main(int argc, char** argv) {
     {"v_fma_f64", k_fma_f64, 1}, {"v_mul_f64", k_mul_f64, 1}, {"v_add_f64", k_add_f64, 1},
     {"v_dot4_u32_u8", k_dot4_u32_u8, 1}, {"v_pk_mul_lo_u16", k_pk_mul_lo_u16, 1}, {"v_pk_mad_u16", k_pk_mad_u16, 1}, {"v_mad_u16", k_mad_u16, 1},
     {"ds_bpermute_b32", k_bpermute, 1}, {"v_accvgpr_write+read", k_accvgpr_rw, 2}, {"v_mov_b32_dpp", k_mov_dpp, 1},
+    {"v_cndmask_b32_e64(sgpr)", k_cndmask_e64_sgpr, 1}, {"v_cmp+v_cndmask(vcc)", k_cmp_cndmask, 2}, {"v_cmp_e64+v_cndmask_e64", k_cmp_e64_cndmask, 2},
+    {"v_and_b32", k_and_b32, 1}, {"v_or_b32", k_or_b32, 1}, {"v_bfi_b32", k_bfi_b32, 1}, {"v_sub_u32", k_sub_u32, 1}, {"v_lshlrev_b32", k_lshlrev_b32, 1},
+    {"ds_bpermute_b32(nowait)", k_bpermute_nowait, 1},
     {"mix_femul(8mad+4simple)", k_mix_femul, 1}, {"lds_bcast_b128(+xor3+add)", k_lds_bcast_b128, 1},
   };
   const char* only = argc > 1 ? argv[1] : nullptr;
