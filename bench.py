@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="items per GPU (default 2^20, 2^18 for sign)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=1024, help="items verified against the oracle after timing")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (kernel variant), repeatable")
     args = ap.parse_args()
 
     import numpy as np
@@ -79,6 +80,10 @@ def main():
         torch.cuda.synchronize()
         if rank != 0:
             eng.base_table_import_dev(tbl)
+
+    for kv in args.opt:
+        key, val = kv.split("=")
+        eng.set_option(key, int(val))
 
     wl = args.workload
     n = args.n or ((1 << 18) if wl == "sign" else (1 << 20))

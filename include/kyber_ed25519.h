@@ -12,7 +12,10 @@
  *   enc        32-byte point encoding = `Point::marshal_binary` (point.rs:35-41, ge.rs:112-122).
  *   ext        40 x int32: X[10] Y[10] Z[10] T[10], radix-2^25.5 limbs = `Point.ge`
  *              (`ExtendedGroupElement`, ge.rs:78-83).  Inputs may be any limbs the reference itself
- *              produces (|limb| < 2^29 accepted); outputs are canonical non-negative limbs.
+ *              produces (|limb| < 2^29 accepted).  Outputs are the limbs `fe_from_bytes`
+ *              (fe.rs:67-122) yields for the canonical coordinate value: signed, centred,
+ *              |even limb| <= 2^25, |odd limb| <= 2^24 — inside the reference's fe_mul/fe_add input
+ *              bounds, so a returned point can be fed straight back into the CPU arithmetic.
  *   return     0 = ok; negative = KYB_E_* (nothing is written on error except where noted).
  *   threading  every call may be made from any thread; calls are serialised on the engine's stream.
  *   memory     the caller owns every buffer; the library keeps no pointer after return.

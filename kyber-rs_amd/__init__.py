@@ -48,6 +48,13 @@ def load_library() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch bundles its own libamdhip64.so.7 / libhsa-runtime64; whichever HIP runtime is loaded
+        # first owns the GPU for the process, so when torch is going to share device memory with the
+        # engine (tests, bench.py) it has to be imported before our library resolves its DT_NEEDED.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise KyberHipError(
             f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "

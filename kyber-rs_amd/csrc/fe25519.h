@@ -309,11 +309,33 @@ KYB_HD void fe_from_ref10(fe& h, const int32_t s[10]) {
   KYB_UNROLL for (int i = 0; i < 10; ++i) t.v[i] = (uint32_t)(s[i] + (int32_t)(4u * p4[i]));
   fe_reduce_weak(h, t);
 }
-// Export canonical limbs in the reference layout (non-negative, within ref10's input bounds)
+// Export in the reference layout: the limbs fe_from_bytes (fe.rs:67-122) produces for the canonical
+// value — signed, centred, |even| <= 2^25, |odd| <= 2^24.  Canonical NON-NEGATIVE limbs (up to 2^26)
+// would break the reference's own bounds as soon as it adds two of them (19*(y+x) no longer fits
+// an i32 in fe_mul, fe.rs:320-328), so the rounding-carry normal form is part of the ABI contract.
 KYB_HD void fe_to_ref10(int32_t s[10], const fe& f) {
-  fe c;
-  fe_canon(c, f);
-  KYB_UNROLL for (int i = 0; i < 10; ++i) s[i] = (int32_t)c.v[i];
+  uint32_t w[8];
+  fe_to_words(w, f);
+  int64_t h[10];
+  h[0] = (int64_t)w[0];                                              // bits   0..31
+  h[1] = (int64_t)(w[1] & 0xffffffu) << 6;                           // bits  32..55
+  h[2] = (int64_t)(((w[1] >> 24) | (w[2] << 8)) & 0xffffffu) << 5;   // bits  56..79
+  h[3] = (int64_t)(((w[2] >> 16) | (w[3] << 16)) & 0xffffffu) << 3;  // bits  80..103
+  h[4] = (int64_t)(w[3] >> 8) << 2;                                  // bits 104..127
+  h[5] = (int64_t)w[4];                                              // bits 128..159
+  h[6] = (int64_t)(w[5] & 0xffffffu) << 7;                           // bits 160..183
+  h[7] = (int64_t)(((w[5] >> 24) | (w[6] << 8)) & 0xffffffu) << 5;   // bits 184..207
+  h[8] = (int64_t)(((w[6] >> 16) | (w[7] << 16)) & 0xffffffu) << 4;  // bits 208..231
+  h[9] = (int64_t)((w[7] >> 8) & 0x7fffffu) << 2;                    // bits 232..254
+  const int order[10] = {9, 1, 3, 5, 7, 0, 2, 4, 6, 8};
+  KYB_UNROLL for (int k = 0; k < 10; ++k) {
+    const int i = order[k];
+    const int b = KYB_BITS(i);
+    const int64_t c = (h[i] + ((int64_t)1 << (b - 1))) >> b;
+    if (i == 9) h[0] += c * 19; else h[i + 1] += c;
+    h[i] -= c * ((int64_t)1 << b);
+  }
+  KYB_UNROLL for (int i = 0; i < 10; ++i) s[i] = (int32_t)h[i];
 }
 
 }  // namespace kyb

@@ -1,0 +1,347 @@
+// C++ mirror of kyber-rs's Ed25519 `Scalar` / `Point` / `Curve` surface over the C ABI.
+//
+// The reference is compiled Rust (no toolchain for it in this image), so the host side above the C ABI
+// is written in C++ with the reference's names, argument meaning and error behaviour:
+//   trait Scalar  /root/reference src/group.rs:22-69   impl: src/group/edwards25519/scalar.rs:144-222
+//   trait Point   src/group.rs:85-140                  impl: src/group/edwards25519/point.rs:75-225
+//   Marshaling    src/encoding/encodings.rs:12-27      point.rs:35-51, scalar.rs:91-112
+//   canonical / small-order checks  point.rs:286-337, scalar.rs:54-75
+//   Curve::new_key_and_seed_with_input  curve.rs:74-87
+// Every Point operation that does curve arithmetic is a batch-of-1 call into the GPU engine (the
+// trait is per-element and synchronous); throughput callers use the *_batch statics.
+// Scalar arithmetic stays on the host (microseconds) and shares sc25519.h with
+// the device sign kernel.  `mul`/`add`/... are infallible in the reference: an engine failure aborts.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/kyber_ed25519.h"
+#include "../csrc/sc25519.h"
+
+namespace kyber {
+
+// src/cipher/stream.rs:6-24
+struct Stream {
+  virtual ~Stream() = default;
+  // dst = src XOR keystream (src and dst have equal length)
+  virtual void xor_key_stream(uint8_t* dst, const uint8_t* src, size_t n) = 0;
+};
+
+// src/encoding/encodings.rs MarshallingError::InvalidInput
+struct MarshallingError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+// src/group.rs PointError::EmbedDataLength
+struct PointError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+namespace group {
+namespace edwards25519 {
+
+namespace detail {
+inline void engine_must(int rc, const char* what) {
+  if (rc != KYB_OK) {  // the trait has no error channel (group.rs:139): abort like a Rust panic
+    std::fprintf(stderr, "kyber-ed25519-hip: %s failed (%d): %s\n", what, rc, kyb_last_error());
+    std::abort();
+  }
+}
+inline void words(uint32_t w[8], const uint8_t b[32]) { std::memcpy(w, b, 32); }
+inline void bytes(uint8_t b[32], const uint32_t w[8]) { std::memcpy(b, w, 32); }
+static const uint8_t L_BYTES[32] = {0xed, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14,
+                                    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x10};
+}  // namespace detail
+
+// ------------------------------------------------------------------------------------------ Scalar
+class Scalar {
+ public:
+  std::array<uint8_t, 32> v{};  // little-endian, scalar.rs:23-26
+
+  Scalar set(const Scalar& a) { v = a.v; return *this; }                       // scalar.rs:146-149
+  Scalar zero() { v.fill(0); return *this; }
+  Scalar one() { v.fill(0); v[0] = 1; return *this; }
+  // scalar.rs:152-154: Int::new_int64(v, L) -> value mod L in [0, L)
+  Scalar set_int64(int64_t x) {
+    uint32_t a[8] = {0}, r[8];
+    uint64_t mag = x < 0 ? (uint64_t)(-(x + 1)) + 1 : (uint64_t)x;
+    a[0] = (uint32_t)mag; a[1] = (uint32_t)(mag >> 32);
+    if (x < 0) { uint32_t z[8] = {0}, lw[8] = KYB_W_L; kyb::mw_sub<8>(r, lw, a); (void)z; kyb::sc_reduce256(r, r); }
+    else kyb::sc_reduce256(r, a);
+    detail::bytes(v.data(), r);
+    return *this;
+  }
+  // scalar.rs:175-177: little-endian bytes (any length up to 64) mod L
+  Scalar set_bytes(const uint8_t* b, size_t n) {
+    if (n > 64) throw std::invalid_argument("Scalar::set_bytes: more than 64 bytes are not supported by this mirror");
+    uint8_t buf[64] = {0};
+    std::memcpy(buf, b, n);
+    uint32_t x[16], r[8];
+    std::memcpy(x, buf, 64);
+    kyb::sc_reduce512(r, x);
+    detail::bytes(v.data(), r);
+    return *this;
+  }
+  Scalar set_bytes(const std::vector<uint8_t>& b) { return set_bytes(b.data(), b.size()); }
+  // scalar.rs:167-173 -> util/random random_int(L): rejection sampling on 253-bit strings
+  Scalar pick(Stream& rand) {
+    for (;;) {
+      uint8_t b[32], z[32] = {0};
+      rand.xor_key_stream(b, z, 32);
+      // random_stream.rs:36-46 draws bit_len(L) = 253 bits big-endian and retries while >= L
+      uint8_t le[32];
+      for (int i = 0; i < 32; ++i) le[i] = b[31 - i];
+      le[31] &= 0x1f;
+      uint32_t w[8], lw[8] = KYB_W_L, t[8];
+      detail::words(w, le);
+      bool nonzero = false;
+      for (int i = 0; i < 8; ++i) nonzero |= w[i] != 0;
+      if (nonzero && kyb::mw_sub<8>(t, w, lw) == 1) { std::memcpy(v.data(), le, 32); return *this; }
+    }
+  }
+  Scalar sub(const Scalar& a, const Scalar& b) {                              // sc_sub, scalar.rs:1187
+    uint32_t wb[8], nb[8], lw[8] = KYB_W_L, one[8] = {1, 0, 0, 0, 0, 0, 0, 0}, wa[8], r[8];
+    detail::words(wb, b.v.data()); detail::words(wa, a.v.data());
+    kyb::sc_reduce256(nb, wb);
+    kyb::mw_sub<8>(nb, lw, nb);                                               // L - (b mod L) in (0, L]
+    kyb::sc_muladd(r, nb, one, wa);
+    detail::bytes(v.data(), r);
+    return *this;
+  }
+  Scalar neg(const Scalar& a) { Scalar z; return sub(z, a); }                 // scalar.rs:216-221
+  Scalar inv(const Scalar& a) {                                               // scalar.rs:191-214: a^(L-2)
+    uint32_t e[8] = KYB_W_L, acc[8] = {1, 0, 0, 0, 0, 0, 0, 0}, base[8], zero[8] = {0};
+    e[0] -= 2;
+    detail::words(base, a.v.data());
+    for (int i = 255; i >= 0; --i) {
+      kyb::sc_muladd(acc, acc, acc, zero);
+      if ((e[i >> 5] >> (i & 31)) & 1) kyb::sc_muladd(acc, acc, base, zero);
+    }
+    detail::bytes(v.data(), acc);
+    return *this;
+  }
+  Scalar div(const Scalar& a, const Scalar& b) { Scalar i; i.inv(b); *this = a * i; return *this; }  // scalar.rs:183-189
+  friend Scalar operator*(const Scalar& a, const Scalar& b) {                  // sc_mul, scalar.rs:132-136
+    uint32_t wa[8], wb[8], zero[8] = {0}, r[8];
+    detail::words(wa, a.v.data()); detail::words(wb, b.v.data());
+    kyb::sc_muladd(r, wa, wb, zero);
+    Scalar s; detail::bytes(s.v.data(), r); return s;
+  }
+  friend Scalar operator+(const Scalar& a, const Scalar& b) {                  // sc_add, scalar.rs:138-142
+    uint32_t wa[8], wb[8], one[8] = {1, 0, 0, 0, 0, 0, 0, 0}, r[8];
+    detail::words(wa, a.v.data()); detail::words(wb, b.v.data());
+    kyb::sc_muladd(r, wa, one, wb);
+    Scalar s; detail::bytes(s.v.data(), r); return s;
+  }
+  bool operator==(const Scalar& o) const { return v == o.v; }                  // byte equality, scalar.rs:78-83
+  bool operator!=(const Scalar& o) const { return !(*this == o); }
+  // Marshaling: marshal_binary reduces mod L (scalar.rs:91-100); unmarshal is a raw copy, length checked only
+  std::vector<uint8_t> marshal_binary() const {
+    uint32_t w[8], r[8];
+    detail::words(w, v.data());
+    kyb::sc_reduce256(r, w);
+    std::vector<uint8_t> out(32);
+    detail::bytes(out.data(), r);
+    return out;
+  }
+  void unmarshal_binary(const uint8_t* data, size_t n) {
+    if (n != 32) throw MarshallingError("wrong size buffer");
+    std::memcpy(v.data(), data, 32);
+  }
+  size_t marshal_size() const { return 32; }
+  // scalar.rs:54-75
+  bool is_canonical(const uint8_t* sb, size_t n) const {
+    if (n != 32) return false;
+    if ((sb[31] & 0xf0) == 0) return true;
+    uint8_t c = 0, m = 1;
+    for (int i = 31; i >= 0; --i) {
+      c |= (uint8_t)((((uint16_t)sb[i] - (uint16_t)detail::L_BYTES[i]) >> 8) & m);
+      m &= (uint8_t)(((((uint16_t)sb[i] ^ (uint16_t)detail::L_BYTES[i]) - 1) >> 8));
+    }
+    return c != 0;
+  }
+  std::string hex() const {
+    static const char* d = "0123456789abcdef";
+    std::string s;
+    for (uint8_t b : v) { s.push_back(d[b >> 4]); s.push_back(d[b & 15]); }
+    return s;
+  }
+};
+
+// ------------------------------------------------------------------------------------------- Point
+class Point {
+ public:
+  int32_t ge[40];        // X Y Z T, reference limb layout (ExtendedGroupElement, ge.rs:78-83)
+  bool var_time = false; // point.rs:26 (never set; kept for layout parity)
+
+  Point() { std::memset(ge, 0, sizeof(ge)); }
+
+  Point null() { std::memset(ge, 0, sizeof(ge)); ge[10] = 1; ge[20] = 1; return *this; }        // point.rs:79-82
+  Point base() {                                                                               // point.rs:85-88
+    uint8_t one[32] = {1};
+    detail::engine_must(kyb_mul_base_batch(one, 1, nullptr, ge), "Point::base");
+    return *this;
+  }
+  Point set(const Point& p) { std::memcpy(ge, p.ge, sizeof(ge)); return *this; }                // point.rs:94-97
+  size_t embed_len() const { return (255 - 8 - 8) / 8; }                                        // point.rs:99-104
+  Point pick(Stream& rand) { return embed(nullptr, 0, rand); }                                  // point.rs:90-92
+
+  // point.rs:106-167
+  Point embed(const uint8_t* data, size_t data_len, Stream& rand) {
+    size_t dl = embed_len();
+    if (dl > data_len) dl = data_len;
+    for (;;) {
+      uint8_t b[32], z[32] = {0};
+      rand.xor_key_stream(b, z, 32);
+      if (data != nullptr) { b[0] = (uint8_t)dl; std::memcpy(b + 1, data, dl); }
+      uint8_t ok = 0;
+      detail::engine_must(kyb_decode_batch(b, 1, ge, &ok), "Point::embed decode");
+      if (!ok) continue;
+      if (data == nullptr) {
+        uint8_t eight[32] = {8};                              // COFACTOR_SCALAR (constants.rs:47-49)
+        uint8_t enc[32];
+        int32_t out[40];
+        detail::engine_must(kyb_mul_batch(eight, nullptr, ge, 1, enc, out, nullptr), "Point::embed cofactor mul");
+        std::memcpy(ge, out, sizeof(ge));
+        if (is_identity_encoding(enc)) continue;
+        return *this;
+      }
+      uint8_t enc[32];
+      detail::engine_must(kyb_mul_batch(detail::L_BYTES, nullptr, ge, 1, enc, nullptr, nullptr), "Point::embed order check");  // PRIME_ORDER_SCALAR
+      if (is_identity_encoding(enc)) return *this;
+    }
+  }
+  // point.rs:169-177
+  std::vector<uint8_t> data() const {
+    std::vector<uint8_t> b = marshal_binary();
+    size_t dl = b[0];
+    if (dl > embed_len()) throw PointError("invalid embedded data length");
+    return std::vector<uint8_t>(b.begin() + 1, b.begin() + 1 + dl);
+  }
+  Point add(const Point& a, const Point& b) {                                                  // point.rs:179-188
+    int32_t out[40];
+    detail::engine_must(kyb_add_batch(a.ge, b.ge, 1, out, 0), "Point::add");
+    std::memcpy(ge, out, sizeof(ge));
+    return *this;
+  }
+  Point sub(const Point& a, const Point& b) {                                                  // point.rs:190-199
+    int32_t out[40];
+    detail::engine_must(kyb_add_batch(a.ge, b.ge, 1, out, 1), "Point::sub");
+    std::memcpy(ge, out, sizeof(ge));
+    return *this;
+  }
+  Point neg(const Point& a) {                                                                  // point.rs:201-204, ge.rs:86-91... neg X and T
+    for (int i = 0; i < 10; ++i) { ge[i] = -a.ge[i]; ge[10 + i] = a.ge[10 + i]; ge[20 + i] = a.ge[20 + i]; ge[30 + i] = -a.ge[30 + i]; }
+    return *this;
+  }
+  // point.rs:207-224: p == nullptr -> fixed base (ge_scalar_mult_base), else variable base
+  Point mul(const Scalar& s, const Point* p) {
+    int32_t out[40];
+    if (p == nullptr) detail::engine_must(kyb_mul_base_batch(s.v.data(), 1, nullptr, out), "Point::mul (base)");
+    else detail::engine_must(kyb_mul_batch(s.v.data(), nullptr, p->ge, 1, nullptr, out, nullptr), "Point::mul");
+    std::memcpy(ge, out, sizeof(ge));
+    return *this;
+  }
+  // Marshaling, point.rs:35-60
+  std::vector<uint8_t> marshal_binary() const {
+    std::vector<uint8_t> b(32);
+    detail::engine_must(kyb_encode_batch(ge, 1, b.data()), "Point::marshal_binary");
+    return b;
+  }
+  void unmarshal_binary(const uint8_t* data, size_t n) {
+    uint8_t ok = 0;
+    int32_t out[40];
+    if (n == 32) detail::engine_must(kyb_decode_batch(data, 1, out, &ok), "Point::unmarshal_binary");
+    if (n != 32 || !ok) throw MarshallingError("invalid Ed25519 curve point");
+    std::memcpy(ge, out, sizeof(ge));
+  }
+  size_t marshal_size() const { return 32; }
+  bool operator==(const Point& o) const { return marshal_binary() == o.marshal_binary(); }      // point.rs:227-241
+  bool operator!=(const Point& o) const { return !(*this == o); }
+  std::string hex() const {
+    static const char* d = "0123456789abcdef";
+    std::string s;
+    for (uint8_t b : marshal_binary()) { s.push_back(d[b >> 4]); s.push_back(d[b & 15]); }
+    return s;
+  }
+  // point.rs:286-313 (WEAK_KEYS, constants.rs:3744-3775: the five small-order encodings below p)
+  bool has_small_order() const {
+    static const uint8_t weak[5][32] = {
+        {0},
+        {1},
+        {0x26, 0xe8, 0x95, 0x8f, 0xc2, 0xb2, 0x27, 0xb0, 0x45, 0xc3, 0xf4, 0x89, 0xf2, 0xef, 0x98, 0xf0, 0xd5, 0xdf, 0xac, 0x05, 0xd3, 0xc6, 0x33, 0x39, 0xb1, 0x38, 0x02, 0x88, 0x6d, 0x53, 0xfc, 0x05},
+        {0xc7, 0x17, 0x6a, 0x70, 0x3d, 0x4d, 0xd8, 0x4f, 0xba, 0x3c, 0x0b, 0x76, 0x0d, 0x10, 0x67, 0x0f, 0x2a, 0x20, 0x53, 0xfa, 0x2c, 0x39, 0xcc, 0xc6, 0x4e, 0xc7, 0xfd, 0x77, 0x92, 0xac, 0x03, 0x7a},
+        {0xec, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0x7f}};
+    std::vector<uint8_t> s = marshal_binary();
+    uint8_t c[5] = {0};
+    for (int j = 0; j < 31; ++j)
+      for (int i = 0; i < 5; ++i) c[i] |= s[j] ^ weak[i][j];
+    for (int i = 0; i < 5; ++i) c[i] |= (s[31] & 0x7f) ^ weak[i][31];
+    uint16_t k = 0;
+    for (int i = 0; i < 5; ++i) k |= (uint16_t)((uint16_t)c[i] - 1);
+    return ((k >> 8) & 1) > 0;
+  }
+  // point.rs:315-337
+  bool is_canonical(const uint8_t* b, size_t n) const {
+    if (n != 32) return false;
+    uint8_t c = (b[31] & 0x7f) ^ 0x7f;
+    for (int i = 30; i >= 1; --i) c |= b[i] ^ 0xff;
+    c = (uint8_t)((((uint16_t)c) - 1) >> 8);
+    uint8_t d = (uint8_t)((uint16_t)(0xEDu - 1u - (uint16_t)b[0]) >> 8);
+    return 1 - (c & d & 1) == 1;
+  }
+
+  // ---- batch entry points for throughput callers (PriPoly::commit, poly.rs:195-206) ----
+  static std::vector<Point> mul_batch(const std::vector<Scalar>& s, const std::vector<Point>* pts) {
+    const size_t n = s.size();
+    std::vector<uint8_t> sc(32 * n);
+    std::vector<int32_t> in(40 * n), out(40 * n);
+    for (size_t i = 0; i < n; ++i) std::memcpy(&sc[32 * i], s[i].v.data(), 32);
+    if (pts) {
+      if (pts->size() != n) throw std::invalid_argument("mul_batch: size mismatch");
+      for (size_t i = 0; i < n; ++i) std::memcpy(&in[40 * i], (*pts)[i].ge, 160);
+      detail::engine_must(kyb_mul_batch(sc.data(), nullptr, in.data(), n, nullptr, out.data(), nullptr), "Point::mul_batch");
+    } else {
+      detail::engine_must(kyb_mul_base_batch(sc.data(), n, nullptr, out.data()), "Point::mul_batch (base)");
+    }
+    std::vector<Point> r(n);
+    for (size_t i = 0; i < n; ++i) std::memcpy(r[i].ge, &out[40 * i], 160);
+    return r;
+  }
+
+ private:
+  static bool is_identity_encoding(const uint8_t e[32]) {
+    if (e[0] != 1) return false;
+    for (int i = 1; i < 32; ++i) if (e[i]) return false;
+    return true;
+  }
+};
+
+// ------------------------------------------------------------------------------------------- Curve
+// curve.rs:21-87: Group impl (constructs default Scalar / Point) + Ed25519 key clamping.
+class Curve {
+ public:
+  size_t scalar_len() const { return 32; }
+  size_t point_len() const { return 32; }
+  Scalar scalar() const { return Scalar(); }
+  Point point() const { return Point(); }
+  // new_key_and_seed_with_input (curve.rs:74-87) needs SHA-512; the caller passes the 64-byte digest
+  // of the seed (the hash itself stays in the Rust/sha2 layer): secret = clamp(digest[0..32]) unreduced.
+  static Scalar clamp_digest(const uint8_t digest[64], uint8_t prefix[32]) {
+    Scalar s;
+    std::memcpy(s.v.data(), digest, 32);
+    s.v[0] &= 0xf8; s.v[31] &= 0x7f; s.v[31] |= 0x40;
+    if (prefix) std::memcpy(prefix, digest + 32, 32);
+    return s;
+  }
+};
+
+}  // namespace edwards25519
+}  // namespace group
+}  // namespace kyber

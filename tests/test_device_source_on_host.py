@@ -109,6 +109,11 @@ def test_scalar_mult_matches_oracle(hd, oracle):
         hd.hd_mul(o, p32(ext), s, p32(pt))
         assert o.raw == oracle.mul(s, pt)
         assert oracle.encode(ext) == o.raw and list(ext[20:30]) == [1] + [0] * 9
+        # reference limb bounds (fe.rs:275-281) and fe_from_bytes normal form: Y limbs equal the oracle's decode
+        assert all(abs(int(v)) <= (1 << 25 if i % 2 == 0 else 1 << 24) for i, v in enumerate(ext))
+        assert list(ext[10:20]) == list(oracle.decode(o.raw)[0][10:20])
+        # and the exported point is usable by the reference arithmetic: s2 * (ext) through the oracle
+        assert oracle.mul(s, ext) == oracle.mul(s, oracle.decode(o.raw)[0])
         hd.hd_mul_base(o, s)
         assert o.raw == oracle.mul_base(s)
     assert hd.hd_overflows() == base
