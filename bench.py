@@ -70,16 +70,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     # ---- engine + base-point table (RCCL broadcast of rank 0's image over xGMI) ----
+    from kyber_rs_amd import multi_gpu
     eng = kyber_rs_amd.Engine(local, build_table=(rank == 0))
-    if world > 1:
-        tbl = torch.empty(kyber_rs_amd.BASE_TABLE_BYTES, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            eng.base_table_export_dev(tbl)
-            eng.sync()
-        dist.broadcast(tbl, src=0)
-        torch.cuda.synchronize()
-        if rank != 0:
-            eng.base_table_import_dev(tbl)
+    multi_gpu.distribute_base_table(eng, rank, world, dev, dist)
 
     for kv in args.opt:
         key, val = kv.split("=")
@@ -89,7 +82,11 @@ def main():
     n = args.n or ((1 << 18) if wl == "sign" else (1 << 20))
     seed = 1 + rank          # every rank gets its own shard of the synthetic stream
     t0 = time.time()
-    stream = torch.cuda.current_stream().cuda_stream
+    # a dedicated (non-null) torch stream: the engine launches on it and the HIP events below are
+    # recorded on it, so they bracket exactly the kernel of each step
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
     sc_np = synth.scalars(n, seed)
@@ -147,7 +144,8 @@ def main():
         m = min(args.check, n)
         idx = np.random.default_rng(0).choice(n, m, replace=False)
         got = out[torch.from_numpy(idx).to(dev)].cpu().numpy()
-        threads = os.cpu_count() or 1
+        # the GPU box gives one GPU a share of 16 host CPUs although os.cpu_count() reports the whole machine
+        threads = max(1, min(len(os.sched_getaffinity(0)), 16))
         if wl == "mul":
             want = orc.mul_batch(sc_np[idx], pts[torch.from_numpy(idx).to(dev)].cpu().numpy(), nthreads=threads)
         elif wl == "mul_base":
@@ -160,7 +158,7 @@ def main():
 
         # ---- CPU baseline: the oracle (C port of the reference algorithm) on a bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
-            per_core = {"mul": 1 << 14, "mul_base": 1 << 15, "sign": 1 << 14}[wl]
+            per_core = {"mul": 1 << 15, "mul_base": 1 << 16, "sign": 1 << 15}[wl]
 
             def run(cnt, th):
                 sub = np.arange(cnt) % n

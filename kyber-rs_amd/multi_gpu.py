@@ -1,0 +1,38 @@
+"""Multi-GPU plumbing: one process per GPU, shards of independent items, ONE collective at init.
+
+SURVEY.md §8(e): every scalar-mult is independent, so rank r of G takes the index range
+[r*N/G, (r+1)*N/G) and no data-path collective exists.  The only exchange is the base-point table
+image (65,536 B) that rank 0 builds on its GPU and broadcasts over RCCL/xGMI (backend "nccl" on ROCm);
+on CPU-only hosts the same code runs over gloo with a stand-in engine (tests/test_multi_gpu_cpu.py).
+"""
+from __future__ import annotations
+
+BASE_TABLE_BYTES = 65536
+
+
+def shard(n_total: int, rank: int, world: int):
+    """index range of `rank`: [r*N/G, (r+1)*N/G) — contiguous, disjoint, covering, sizes differ by <= 1"""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return (n_total * rank) // world, (n_total * (rank + 1)) // world
+
+
+def distribute_base_table(engine, rank: int, world: int, device, dist=None) -> None:
+    """rank 0: export the engine's table into a device tensor and broadcast it; others: import it.
+
+    `engine` needs base_table_export_dev(tensor) / base_table_import_dev(tensor) / sync();
+    rank 0's engine must have been created with build_table=True, the others with build_table=False."""
+    if world == 1:
+        return
+    import torch
+    if dist is None:
+        import torch.distributed as dist  # noqa: PLW0642
+    tbl = torch.empty(BASE_TABLE_BYTES, dtype=torch.uint8, device=device)
+    if rank == 0:
+        engine.base_table_export_dev(tbl)
+        engine.sync()
+    dist.broadcast(tbl, src=0)
+    if device is not None and getattr(device, "type", "cpu") == "cuda":
+        torch.cuda.synchronize()
+    if rank != 0:
+        engine.base_table_import_dev(tbl)

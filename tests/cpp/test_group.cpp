@@ -1,0 +1,204 @@
+// GPU test program: the reference's generic group test, /root/reference
+// src/util/test/group_test.rs:210-555 (`test_group`), restated against the C++ mirror of the trait
+// surface (kyber-rs_amd/host/edwards25519.hpp) — i.e. every identity below runs through the C ABI and
+// the HIP kernels, one trait-level call at a time (batch-of-1), exactly as unmodified protocol code
+// would.  Built and run by tests/test_gpu_cpp_group.py; exit code 0 = all identities hold.
+// Prints the encodings of the points it produced (the role of `compare_groups`,
+// group_test.rs:567-585) so the Python side can re-check them against the oracle.
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../kyber-rs_amd/host/edwards25519.hpp"
+
+using namespace kyber;
+using namespace kyber::group::edwards25519;
+
+// deterministic test stream (the role of SuiteStable's unseeded XOF, group_test.rs:20-89)
+struct XorShiftStream : Stream {
+  uint64_t s[2] = {0x9E3779B97F4A7C15ULL, 0xD1B54A32D192ED03ULL};
+  uint64_t next() {
+    uint64_t a = s[0], b = s[1];
+    s[0] = b;
+    a ^= a << 23; a ^= a >> 17; a ^= b ^ (b >> 26);
+    s[1] = a;
+    return a + b;
+  }
+  void xor_key_stream(uint8_t* dst, const uint8_t* src, size_t n) override {
+    for (size_t i = 0; i < n; ++i) dst[i] = src[i] ^ (uint8_t)(next() >> 32);
+  }
+};
+
+static int failures = 0;
+#define CHECK(cond, msg) do { if (!(cond)) { std::printf("FAIL: %s (line %d)\n", msg, __LINE__); ++failures; } } while (0)
+
+static void test_embed(Curve& g, Stream& rand, std::vector<Point>& points, const std::string& s) {  // group_test.rs:91-115
+  Point p = g.point().embed((const uint8_t*)s.data(), s.size(), rand);
+  std::vector<uint8_t> x = p.data();
+  size_t max = g.point().embed_len();
+  if (max > s.size()) max = s.size();
+  CHECK(std::string(x.begin(), x.end()) == s.substr(0, max), "Point extraction/embedding corrupted the data");
+  points.push_back(p);
+}
+
+int main() {
+  if (kyb_init(0) != KYB_OK) { std::printf("kyb_init failed: %s\n", kyb_last_error()); return 2; }
+  Curve g;
+  XorShiftStream rand;
+  std::vector<Point> points;
+  Point ptmp = g.point();
+  Scalar stmp = g.scalar();
+  Point pzero = g.point().null();
+  Scalar szero = g.scalar().zero();
+  Scalar sone = g.scalar().one();
+
+  Scalar s1 = g.scalar().pick(rand), s2 = g.scalar().pick(rand);
+  CHECK(s1 != szero && s2 != szero && s1 != s2, "unique non-zero secrets");
+
+  Point gen = g.point().base();
+  points.push_back(gen);
+
+  // addition vs multiplication (group_test.rs:243-258)
+  Point p1 = g.point().add(gen, gen);
+  Point p2 = g.point().mul(Scalar().set_int64(2), nullptr);
+  CHECK(p1 == p2, "multiply by two");
+  p1 = Point().add(p1, p1);
+  p2 = p2.mul(Scalar().set_int64(4), nullptr);
+  CHECK(p1 == p2, "multiply by four");
+  points.push_back(p1);
+
+  // additive and multiplicative identities of the generator (:270-292)
+  ptmp = ptmp.mul(Scalar().set_int64(-1), nullptr);
+  ptmp = Point().add(ptmp, gen);
+  CHECK(ptmp == pzero, "generator additive identity");
+  stmp.set_int64(2);
+  ptmp = ptmp.mul(stmp, nullptr);
+  { Point q = ptmp; ptmp = ptmp.mul(Scalar().inv(stmp), &q); }
+  CHECK(ptmp == gen, "generator multiplicative identity");
+
+  // Diffie-Hellman (:294-322)
+  p1 = p1.mul(s1, &gen);
+  p2 = p2.mul(s2, &gen);
+  CHECK(p1 != p2, "encryption produces unique points");
+  points.push_back(p1);
+  Point dh1 = g.point().mul(s2, &p1), dh2 = g.point().mul(s1, &p2);
+  CHECK(dh1 == dh2, "Diffie-Hellman");
+  points.push_back(dh1);
+
+  // inverse, zero, one (:326-358)
+  ptmp = ptmp.mul(Scalar().inv(s2), &dh1);
+  CHECK(ptmp == p1, "scalar inverse");
+  CHECK(Point().mul(szero, &dh1) == pzero, "secret = 0");
+  CHECK(Point().mul(sone, &dh1) == dh1, "secret = 1");
+
+  // additive homomorphism (:361-420)
+  ptmp = ptmp.add(p1, p2);
+  stmp = s1 + s2;
+  Point pt2 = g.point().mul(stmp, &gen);
+  CHECK(pt2 == ptmp, "additive homomorphism (+)");
+  ptmp = ptmp.sub(p1, p2);
+  stmp = stmp.sub(s1, s2);
+  pt2 = pt2.mul(stmp, &gen);
+  CHECK(pt2 == ptmp, "additive homomorphism (-)");
+  Scalar st2 = g.scalar().neg(s2);
+  st2 = s1 + st2;
+  CHECK(stmp == st2, "Scalar.neg");
+  pt2 = pt2.neg(p2);
+  pt2 = Point().add(pt2, p1);
+  CHECK(pt2 == ptmp, "Point.neg");
+
+  // multiplicative homomorphism (:423-461)
+  stmp = s1 * s2;
+  CHECK(Point().mul(stmp, &gen) == dh1, "multiplicative homomorphism");
+  st2 = st2.inv(s2);
+  st2 = st2 * stmp;
+  CHECK(st2 == s1, "scalar division via inverse");
+  st2 = st2.div(stmp, s2);
+  CHECK(st2 == s1, "scalar division");
+
+  // randomly picked points (:465-502)
+  Point last = gen;
+  for (int i = 0; i < 5; ++i) {
+    Point rgen = g.point().pick(rand);
+    CHECK(rgen != last, "pick produces unique points");
+    last = rgen;
+    ptmp = Point().mul(Scalar().set_int64(-1), &rgen);
+    ptmp = Point().add(ptmp, rgen);
+    CHECK(ptmp == pzero, "random generator additive identity");
+    stmp.set_int64(2);
+    ptmp = Point().mul(stmp, &rgen);
+    { Point q = ptmp; ptmp = Point().mul(Scalar().inv(stmp), &q); }
+    CHECK(ptmp == rgen, "random generator multiplicative identity");
+    points.push_back(rgen);
+  }
+
+  // embedding (:505-511)
+  test_embed(g, rand, points, "Hi!");
+  test_embed(g, rand, points, "The quick brown fox jumps over the lazy dog");
+
+  // encoding / decoding (:516-540)
+  for (int i = 0; i < 5; ++i) {
+    Scalar s = g.scalar().pick(rand);
+    std::vector<uint8_t> buf = s.marshal_binary();
+    stmp.unmarshal_binary(buf.data(), buf.size());
+    CHECK(stmp == s, "scalar decode(encode)");
+    Point p = g.point().pick(rand);
+    buf = p.marshal_binary();
+    ptmp.unmarshal_binary(buf.data(), buf.size());
+    CHECK(ptmp == p, "point decode(encode)");
+    points.push_back(p);
+  }
+  // null point marshal round trip (:543-547)
+  {
+    std::vector<uint8_t> b = g.point().null().marshal_binary();
+    Point q;
+    bool threw = false;
+    try { q.unmarshal_binary(b.data(), b.size()); } catch (const MarshallingError&) { threw = true; }
+    CHECK(!threw && q == pzero, "null point round trip");
+  }
+  // error behaviour: invalid encoding -> MarshallingError("invalid Ed25519 curve point") (point.rs:43-50)
+  {
+    uint8_t bad[32] = {2};
+    bool threw = false;
+    try { Point().unmarshal_binary(bad, 32); } catch (const MarshallingError& e) { threw = std::string(e.what()) == "invalid Ed25519 curve point"; }
+    CHECK(threw, "invalid point is rejected with the reference's message");
+    threw = false;
+    try { Scalar().unmarshal_binary(bad, 31); } catch (const MarshallingError& e) { threw = std::string(e.what()) == "wrong size buffer"; }
+    CHECK(threw, "scalar length check");
+  }
+  // canonical / small-order checks (point.rs:286-337, scalar.rs:54-75; scalar_test.rs:89-105)
+  {
+    Point w; uint8_t wk[32] = {0}; w.unmarshal_binary(wk, 32);
+    CHECK(w.has_small_order(), "weak key 0 has small order");
+    CHECK(!gen.has_small_order(), "generator has large order");
+    std::vector<uint8_t> ge = gen.marshal_binary();
+    CHECK(gen.is_canonical(ge.data(), 32), "generator encoding canonical");
+    uint8_t pm[32]; for (int i = 0; i < 32; ++i) pm[i] = 0xff; pm[0] = 0xed; pm[31] = 0x7f;   // y = p
+    CHECK(!gen.is_canonical(pm, 32), "y = p is not canonical");
+    uint8_t l2[32]; std::memcpy(l2, detail::L_BYTES, 32); l2[0] -= 2;
+    bool exp[4] = {true, true, false, false};
+    for (int i = 0; i < 4; ++i) { CHECK(Scalar().is_canonical(l2, 32) == exp[i], "scalar canonical range L-2..L+1"); l2[0] += 1; }
+  }
+  // scalar KATs (scalar_test.rs:27-75)
+  CHECK((Scalar().set_int64(0x100) + sone).hex() == "0101000000000000000000000000000000000000000000000000000000000000", "set_int64(0x100)+1");
+  CHECK(Scalar().set_int64(-1).hex() == "ecd3f55c1a631258d69cf7a2def9de1400000000000000000000000000000010", "set_int64(-1)");
+  { uint8_t b[4] = {0, 1, 2, 3}; CHECK(Scalar().set_bytes(b, 4).hex() == "0001020300000000000000000000000000000000000000000000000000000000", "set_bytes LE"); }
+  { Scalar two = Scalar().set_int64(2); Scalar r = Scalar().pick(rand); CHECK(two * r == r + r, "2*s == s+s"); }
+
+  // batch entry point equals the per-call path
+  {
+    std::vector<Scalar> ss; std::vector<Point> pp;
+    for (int i = 0; i < 70; ++i) { ss.push_back(Scalar().pick(rand)); pp.push_back(points[i % points.size()]); }
+    std::vector<Point> rb = Point::mul_batch(ss, &pp), rf = Point::mul_batch(ss, nullptr);
+    for (int i = 0; i < 70; i += 23) {
+      CHECK(rb[i] == Point().mul(ss[i], &pp[i]), "mul_batch == mul");
+      CHECK(rf[i] == Point().mul(ss[i], nullptr), "mul_batch(base) == mul(None)");
+    }
+  }
+
+  for (const Point& p : points) std::printf("POINT %s\n", p.hex().c_str());
+  std::printf("S1 %s\nS2 %s\n", s1.hex().c_str(), s2.hex().c_str());
+  std::printf(failures ? "FAILED %d\n" : "OK\n", failures);
+  kyb_shutdown();
+  return failures ? 1 : 0;
+}
