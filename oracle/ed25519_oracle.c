@@ -46,15 +46,15 @@ static int64_t load4(const uint8_t* s) { return load3(s) | ((int64_t)s[3] << 24)
 
 #define BITS(i) (((i) & 1) ? 25 : 26)
 /* rounding carry from limb i into limb i+1 (limb 9 wraps into limb 0 times 19) */
-static void carry_at(int64_t h[10], int i) {
+static inline __attribute__((always_inline)) void carry_at(int64_t h[10], int i) {
   int64_t c = (h[i] + ((int64_t)1 << (BITS(i) - 1))) >> BITS(i);
   if (i == 9) h[0] += c * 19; else h[i + 1] += c;
   h[i] -= c * ((int64_t)1 << BITS(i));
 }
 /* the 12-carry schedule shared by fe_mul / fe_square / fe_square2 (fe.rs:463-523) */
-static void carry_mul_schedule(fe out, int64_t h[10]) {
-  static const int order[12] = {0, 4, 1, 5, 2, 6, 3, 7, 4, 8, 9, 0};
-  for (int k = 0; k < 12; k++) carry_at(h, order[k]);
+static inline __attribute__((always_inline)) void carry_mul_schedule(fe out, int64_t h[10]) {
+  carry_at(h, 0); carry_at(h, 4); carry_at(h, 1); carry_at(h, 5); carry_at(h, 2); carry_at(h, 6);
+  carry_at(h, 3); carry_at(h, 7); carry_at(h, 4); carry_at(h, 8); carry_at(h, 9); carry_at(h, 0);
   for (int i = 0; i < 10; i++) out[i] = (int32_t)h[i];
 }
 /* fe.rs:67-122 — ignores bit 255, accepts values >= p */
@@ -103,35 +103,45 @@ static int fe_isnonzero(const fe f) {                                           
   uint8_t x = 0; for (int i = 0; i < 32; i++) x |= s[i];
   return x != 0;
 }
-/* fe.rs:299-535: h_k = sum_{i+j=k} f_i g_j * (2 if i,j odd) + 19 * sum_{i+j=k+10} (same) */
+/* fe.rs:299-535: h_k = sum_{i+j=k} f_i g_j * (2 if i,j odd) + 19 * sum_{i+j=k+10} (same).
+ * The *19 and *2 are 32-bit precomputations exactly as in the reference (g1_19.., f1_2..,
+ * fe.rs:320-333): for even k an odd i always meets an odd j, so column k uses the "odd limbs doubled"
+ * copy of f; for odd k it uses f itself. */
 static void fe_mul(fe h, const fe f, const fe g) {
+  int32_t g19[10], fo[10];
   int64_t acc[10];
+  for (int i = 0; i < 10; i++) { g19[i] = 19 * g[i]; fo[i] = (i & 1) ? 2 * f[i] : f[i]; }
+#pragma GCC unroll 10
   for (int k = 0; k < 10; k++) {
+    const int32_t* ff = (k & 1) ? f : fo;
     int64_t s = 0;
-    for (int i = 0; i < 10; i++) {
-      int j = k - i, wrap = 0;
-      if (j < 0) { j += 10; wrap = 1; }
-      int32_t gj = wrap ? 19 * g[j] : g[j];            /* g1_19.. : 32-bit precomputation, fe.rs:320-328 */
-      int32_t fi = ((i & 1) && (j & 1)) ? 2 * f[i] : f[i]; /* f1_2.. , fe.rs:329-333 */
-      s += (int64_t)fi * (int64_t)gj;
-    }
+#pragma GCC unroll 10
+    for (int i = 0; i <= k; i++) s += (int64_t)ff[i] * (int64_t)g[k - i];
+#pragma GCC unroll 10
+    for (int i = k + 1; i < 10; i++) s += (int64_t)ff[i] * (int64_t)g19[k - i + 10];
     acc[k] = s;
   }
   carry_mul_schedule(h, acc);
 }
-/* fe.rs:544-688 (and fe.rs:700-855 with dbl=1: every h_k doubled before the carries) */
-static void fe_sq_impl(fe h, const fe f, int dbl) {
+/* fe.rs:544-688 (and fe.rs:700-855 with dbl=1: every h_k doubled before the carries).
+ * 55 products: each unordered pair once; multiplier (2 if i!=j)(2 if i,j odd)(19 if i+j>=10) split into
+ * the reference's 32-bit precomputations f0_2.., f5_38, f6_19, f7_38, f8_19, f9_38 (fe.rs:556-571). */
+static inline __attribute__((always_inline)) void fe_sq_impl(fe h, const fe f, int dbl) {
+  int32_t f2[10], f19[10], f38[10];
   int64_t acc[10];
+  for (int i = 0; i < 10; i++) { f2[i] = 2 * f[i]; f19[i] = 19 * f[i]; f38[i] = 38 * f[i]; }
+#pragma GCC unroll 10
   for (int k = 0; k < 10; k++) {
     int64_t s = 0;
+#pragma GCC unroll 10
     for (int i = 0; i < 10; i++) {
       int j = k - i, wrap = 0;
       if (j < 0) { j += 10; wrap = 1; }
       if (i > j) continue;
-      int64_t m = (i != j) ? 2 : 1;
-      if ((i & 1) && (j & 1)) m *= 2;
-      if (wrap) m *= 19;
-      s += m * (int64_t)f[i] * (int64_t)f[j];
+      const int oo = (i & 1) && (j & 1);
+      const int32_t a = (i != j) ? f2[i] : f[i];
+      const int32_t b = wrap ? (oo ? f38[j] : f19[j]) : (oo ? f2[j] : f[j]);
+      s += (int64_t)a * (int64_t)b;
     }
     acc[k] = dbl ? s + s : s;
   }
