@@ -19,7 +19,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libkyber_ed25519_hip.so"
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+LIB_PATH = os.environ.get("KYB_HIP_LIB") or os.path.join(_HERE, LIB_NAME)   # KYB_HIP_LIB: A/B builds of the same ABI
 BASE_TABLE_BYTES = 65536
 
 KYB_OK = 0

@@ -64,13 +64,36 @@ static inline uint32_t kyb_add32(uint32_t a, uint32_t b, const char* what) {
   return (uint32_t)w;
 }
 #else
-KYB_HD uint64_t kyb_mad(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+// The empty asm makes each partial sum opaque, so LLVM cannot reassociate a column into
+// "products first, carry last": it then has to feed the running 64-bit value (carry of the previous
+// column included) as the addend of the next v_mad_u64_u32, and the separate v_lshl_add_u64 per
+// column disappears (-10 half-rate instructions per fe_mul / fe_sq).  A wave cannot issue
+// v_mad_u64_u32 faster than one per ~9.5 cycles even on independent chains
+// (profiles/r01_valu_rates_mi355x.jsonl, w1 row), so the serial chain costs nothing.
+KYB_HD uint64_t kyb_mad(uint32_t a, uint32_t b, uint64_t c) {
+  uint64_t r = (uint64_t)a * b + c;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KYB_NO_CHAIN_BARRIER)
+  asm("" : "+v"(r));
+#endif
+  return r;
+}
 KYB_HD uint32_t kyb_mul32(uint32_t a, uint32_t b, const char*) { return a * b; }
 KYB_HD uint32_t kyb_sub32(uint32_t a, uint32_t b, const char*) { return a - b; }
 KYB_HD uint32_t kyb_add32(uint32_t a, uint32_t b, const char*) { return a + b; }
 #endif
 
 KYB_HD uint32_t kyb_x19(uint32_t a) { return kyb_mul32(a, 19u, "x19"); }
+// 2*a as v_add_u32 (full rate) instead of the v_lshlrev_b32 LLVM canonicalises x+x into (half rate
+// on gfx950, profiles/r01_valu_rates2_mi355x.jsonl): hide one operand behind an empty asm
+KYB_HD uint32_t kyb_x2(uint32_t a, const char* what) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KYB_NO_X2_ADD)
+  uint32_t t = a;
+  asm("" : "+v"(t));
+  return a + t;
+#else
+  return kyb_add32(a, a, what);
+#endif
+}
 
 KYB_HD void fe_zero(fe& h) {
   KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = 0;
@@ -128,7 +151,7 @@ KYB_HD void fe_reduce_weak(fe& h, const fe& f) {
 KYB_HD void fe_mul(fe& h, const fe& f, const fe& g) {
   uint32_t g19[10], f2[10];
   KYB_UNROLL for (int i = 1; i < 10; ++i) g19[i] = kyb_x19(g.v[i]);
-  KYB_UNROLL for (int i = 1; i < 10; i += 2) f2[i] = kyb_add32(f.v[i], f.v[i], "f2");
+  KYB_UNROLL for (int i = 1; i < 10; i += 2) f2[i] = kyb_x2(f.v[i], "f2");
   g19[0] = 0; f2[0] = f2[2] = f2[4] = f2[6] = f2[8] = 0;
   uint64_t acc = 0;
   uint32_t r[10];
@@ -153,10 +176,10 @@ KYB_HD void fe_mul(fe& h, const fe& f, const fe& g) {
 // h = f^2.  f <= 3.3T.  55 v_mad_u64_u32.  Output tight.
 KYB_HD void fe_sq(fe& h, const fe& f) {
   uint32_t f2[10], f19[10], f38[10];
-  KYB_UNROLL for (int i = 0; i < 10; ++i) f2[i] = kyb_add32(f.v[i], f.v[i], "sq f2");
+  KYB_UNROLL for (int i = 0; i < 10; ++i) f2[i] = kyb_x2(f.v[i], "sq f2");
   KYB_UNROLL for (int i = 0; i < 10; ++i) { f19[i] = 0; f38[i] = 0; }
   KYB_UNROLL for (int i = 5; i < 10; ++i) f19[i] = kyb_x19(f.v[i]);
-  KYB_UNROLL for (int i = 5; i < 10; i += 2) f38[i] = kyb_add32(f19[i], f19[i], "sq f38");
+  KYB_UNROLL for (int i = 5; i < 10; i += 2) f38[i] = kyb_x2(f19[i], "sq f38");
   uint64_t acc = 0;
   uint32_t r[10];
   KYB_UNROLL for (int k = 0; k < 10; ++k) {

@@ -187,6 +187,31 @@ __device__ __forceinline__ void finish_point(const fe& X, const fe& Y, const fe&
 }
 
 // ------------------------------------------------------------------------------------------------
+// projective staging buffer for the split finish: uint4 [8 quads][stride items]
+//   dwords 0..9 X, 10..19 Y, 20..29 Z (tight limbs), 30..31 unused.  Item-minor so that both the
+//   producer (lane = item) and the batched finish (lane j takes items j, j+M, j+2M, ...) are coalesced.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_proj(uint4* proj, size_t stride, size_t i, const fe& X, const fe& Y, const fe& Z) {
+  uint32_t f[32];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { f[k] = X.v[k]; f[10 + k] = Y.v[k]; f[20 + k] = Z.v[k]; }
+  f[30] = 0; f[31] = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) proj[q * stride + i] = make_uint4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+}
+__device__ __forceinline__ void load_proj_z(fe& Z, const uint4* proj, size_t stride, size_t i) {
+  const uint4 a = proj[5 * stride + i], b = proj[6 * stride + i], c = proj[7 * stride + i];
+  Z.v[0] = a.x; Z.v[1] = a.y; Z.v[2] = a.z; Z.v[3] = a.w; Z.v[4] = b.x; Z.v[5] = b.y; Z.v[6] = b.z; Z.v[7] = b.w; Z.v[8] = c.x; Z.v[9] = c.y;
+}
+__device__ __forceinline__ void load_proj_xy(fe& X, fe& Y, const uint4* proj, size_t stride, size_t i) {
+  uint32_t f[20];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) { const uint4 v = proj[q * stride + i]; f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w; }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { X.v[k] = f[k]; Y.v[k] = f[10 + k]; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
 constexpr int KYB_BLOCK = 256;
@@ -197,11 +222,13 @@ __global__ void __launch_bounds__(64) k_base_table(uint32_t* image) {
 }
 
 // Variable base.  Persistent grid: block b handles chunks b, b+grid, ...; its four waves own four
-// table slots of the workspace for the whole launch.
-template <int MASKED, bool FROM_ENC>
+// table slots of the workspace for the whole launch.  SPLIT: leave the result projective in `proj`
+// for k_finish (one field inversion per FINISH_K items instead of one per item).
+template <int MASKED, bool FROM_ENC, bool SPLIT>
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
 k_mul(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ pts_enc, const int32_t* __restrict__ pts_ext,
-      size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, uint8_t* __restrict__ ok_out, uint4* __restrict__ ws) {
+      size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, uint8_t* __restrict__ ok_out, uint4* __restrict__ ws,
+      uint4* __restrict__ proj, size_t proj_stride) {
   const uint32_t lane = threadIdx.x & 63u;
   const size_t wave_slot = (size_t)blockIdx.x * (KYB_BLOCK / 64) + (threadIdx.x >> 6);
   tbl_global<MASKED> tbl{ws + wave_slot * (8 * 10 * 64) + lane};
@@ -226,43 +253,108 @@ k_mul(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ pts_enc, 
     }
     ge_p2 r;
     ge_scalarmult(r, a, P, tbl);
-    finish_point(r.X, r.Y, r.Z, out_enc, out_ext, ii, live);
+    if (SPLIT) { if (live) store_proj(proj, proj_stride, i, r.X, r.Y, r.Z); }
+    else finish_point(r.X, r.Y, r.Z, out_enc, out_ext, ii, live);
     if (ok_out != nullptr && live) ok_out[i] = (uint8_t)ok;
   }
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(KYB_BLOCK, 2)
+// Fixed base.  BLOCK = 256 (2 waves/SIMD, <= 256 VGPRs) or 512 (one 64 KiB LDS table shared by 8 waves,
+// 2 blocks per CU = 4 waves/SIMD, 128 VGPRs).
+template <int MODE, int BLOCK, bool SPLIT>
+__global__ void __launch_bounds__(BLOCK, BLOCK == 512 ? 4 : 2)
 k_mul_base(const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
-           const uint4* __restrict__ table_image) {
+           const uint4* __restrict__ table_image, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
   __shared__ uint4 lds_tbl[KYB_BASE_TABLE_BYTES / 16];
-  for (int k = threadIdx.x; k < (int)(KYB_BASE_TABLE_BYTES / 16); k += KYB_BLOCK) lds_tbl[k] = table_image[k];
+  for (int k = threadIdx.x; k < (int)(KYB_BASE_TABLE_BYTES / 16); k += BLOCK) lds_tbl[k] = table_image[k];
   __syncthreads();
   tbl_lds<MODE> tbl{reinterpret_cast<const uint32_t*>(lds_tbl)};
-  const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
+  const size_t nchunks = (n + BLOCK - 1) / BLOCK;
   for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const size_t i = chunk * KYB_BLOCK + threadIdx.x;
+    const size_t i = chunk * BLOCK + threadIdx.x;
     const bool live = i < n;
     const size_t ii = live ? i : 0;
     uint32_t a[8];
     load_words8(a, scalars, ii);
     ge_p3 h;
     ge_scalarmult_base(h, a, tbl);
-    finish_point(h.X, h.Y, h.Z, out_enc, out_ext, ii, live);
+    if (SPLIT) { if (live) store_proj(proj, proj_stride, proj_offset + i, h.X, h.Y, h.Z); }
+    else finish_point(h.X, h.Y, h.Z, out_enc, out_ext, ii, live);
   }
 }
 
-template <int MODE>
+// Batched finish: lane j owns items j, j+M, ..., j+(K-1)M (M = ceil(n/K)) and inverts the product of
+// their Z's once (Montgomery's trick): 3(K-1) M + one inversion per K items instead of 254 S + 11 M
+// per item.  A zero Z (only reachable from invalid extended inputs) is replaced by 1 in the product
+// and gets the reference's own answer for it (0^(p-2) = 0 -> x = y = 0), so one bad item cannot
+// disturb its K-1 neighbours.
+constexpr int FINISH_K = 8;
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_finish(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext) {
+  const size_t M = (n + FINISH_K - 1) / FINISH_K;
+  const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (j >= M) return;
+  fe pre[FINISH_K];
+  uint32_t nz[FINISH_K];
+  fe one;
+  fe_one(one);
+#pragma unroll
+  for (int t = 0; t < FINISH_K; ++t) {
+    const size_t i = j + (size_t)t * M;
+    fe z;
+    if (i < n) load_proj_z(z, proj, stride, i); else fe_one(z);
+    nz[t] = fe_is_nonzero(z);
+    fe_cmov(z, one, 1u - nz[t]);
+    if (t == 0) fe_copy(pre[0], z); else fe_mul(pre[t], pre[t - 1], z);
+  }
+  fe inv;
+  fe_invert(inv, pre[FINISH_K - 1]);
+#pragma unroll
+  for (int t = FINISH_K - 1; t >= 0; --t) {
+    const size_t i = j + (size_t)t * M;
+    const bool live = i < n;
+    fe zi, z;
+    if (t > 0) {
+      fe_mul(zi, inv, pre[t - 1]);
+      if (live) load_proj_z(z, proj, stride, i); else fe_one(z);
+      fe_cmov(z, one, 1u - nz[t]);
+      fe_mul(inv, inv, z);
+    } else {
+      fe_copy(zi, inv);
+    }
+    fe zero;
+    fe_zero(zero);
+    fe_cmov(zi, zero, 1u - nz[t]);
+    fe X, Y, x, y;
+    if (live) load_proj_xy(X, Y, proj, stride, i); else { fe_zero(X); fe_one(Y); }
+    fe_mul(x, X, zi);
+    fe_mul(y, Y, zi);
+    if (out_enc != nullptr) {
+      uint32_t w[8];
+      fe_to_words(w, y);
+      w[7] ^= fe_is_negative(x) << 31;
+      if (live) store_words8(out_enc, i, w);
+    }
+    if (out_ext != nullptr) {
+      fe tt;
+      fe_mul(tt, x, y);
+      if (live) store_ext(out_ext, i, x, y, one, tt);
+    }
+  }
+}
+
+// fused signing kernel (small batches)
+template <int MODE, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, 2)
 k_sign(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const uint8_t* __restrict__ msgs,
        const uint32_t* __restrict__ msg_off, size_t n, uint8_t* __restrict__ sig, const uint4* __restrict__ table_image) {
   __shared__ uint4 lds_tbl[KYB_BASE_TABLE_BYTES / 16];
-  for (int q = threadIdx.x; q < (int)(KYB_BASE_TABLE_BYTES / 16); q += KYB_BLOCK) lds_tbl[q] = table_image[q];
+  for (int q = threadIdx.x; q < (int)(KYB_BASE_TABLE_BYTES / 16); q += BLOCK) lds_tbl[q] = table_image[q];
   __syncthreads();
   tbl_lds<MODE> tbl{reinterpret_cast<const uint32_t*>(lds_tbl)};
-  const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
+  const size_t nchunks = (n + BLOCK - 1) / BLOCK;
   for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const size_t i = chunk * KYB_BLOCK + threadIdx.x;
+    const size_t i = chunk * BLOCK + threadIdx.x;
     const bool live = i < n;
     const size_t ii = live ? i : 0;
     uint32_t wx[8], wk[8], s[16];
@@ -272,6 +364,31 @@ k_sign(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const uint8
     schnorr_sign(s, wx, wk, msgs + off, len, tbl);
     if (live) { store_words8(sig, 2 * ii, s); store_words8(sig, 2 * ii + 1, s + 8); }
   }
+}
+
+// split signing, last stage: enc holds enc(R_i) at record i and enc(A_i) at record n + i (produced by
+// two split fixed-base launches + k_finish); h = SHA-512(R || A || msg) mod L, s = k + x h mod L.
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_sign_hash(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const uint8_t* __restrict__ msgs,
+            const uint32_t* __restrict__ msg_off, size_t n, const uint8_t* __restrict__ enc, uint8_t* __restrict__ sig) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t wx[8], wk[8], ra[16];
+  load_words8(wx, x, i);
+  load_words8(wk, k, i);
+  load_words8(ra, enc, i);
+  load_words8(ra + 8, enc, n + i);
+  sha512_ctx c;
+  sha512_init(c);
+  sha512_words64(c, ra);
+  const uint32_t off = msg_off[i], len = msg_off[i + 1] - off;
+  sha512_bytes(c, msgs + off, len);
+  uint32_t dig[16], h[8], s[8];
+  sha512_final(dig, c);
+  sc_reduce512(h, dig);
+  sc_muladd(s, wx, h, wk);
+  store_words8(sig, 2 * i, ra);
+  store_words8(sig, 2 * i + 1, s);
 }
 
 __global__ void __launch_bounds__(KYB_BLOCK)
@@ -328,17 +445,22 @@ struct Ctx {
   hipStream_t stream = nullptr;
   uint32_t* table = nullptr;      // KYB_BASE_TABLE_BYTES
   bool table_ready = false;
-  // variable-base table workspace: one per stream that has launched k_mul (two launches that
-  // overlap on different streams must not share table slots)
-  struct WsSlot { hipStream_t stream; uint4* ws; };
-  WsSlot ws_slots[8] = {};
-  int ws_count = 0;
+  // per-stream device scratch (two launches that overlap on different streams must not share it):
+  //   ws    variable-base table workspace (fixed size)
+  //   proj  projective staging of the split finish (grows with the largest batch seen)
+  //   enc   encodings of R and A between the stages of the split signing path
+  struct StreamRes { hipStream_t stream; uint4* ws; uint4* proj; size_t proj_items; uint8_t* enc; size_t enc_bytes; };
+  StreamRes res[8] = {};
+  int res_count = 0;
   size_t ws_bytes = 0;
-  int grid_mul = 0, grid_base = 0;
+  int grid_mul = 0;
   uint8_t* stage = nullptr;       // device staging for the host-pointer API
   size_t stage_bytes = 0;
   int opt_mul_select = 1;         // 0 cndmask, 1 and/or mask
   int opt_base_select = 1;        // 0 LDS broadcast scan, 1 bpermute
+  int opt_base_block = 256;       // 256 (2 waves/SIMD) or 512 (4 waves/SIMD, 128 VGPRs)
+  int opt_finish = 1;             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
+  int opt_finish_min = 4096;
   std::mutex mu;
 };
 Ctx g;
@@ -392,12 +514,11 @@ int do_init(int device, bool build_table) {
   // persistent grids: 2 blocks of 256 threads per CU = 2 waves per SIMD (needed to saturate
   // v_mad_u64_u32 issue, profiles/r01_valu_rates_mi355x.jsonl)
   g.grid_mul = g.cus * 2;
-  g.grid_base = g.cus * 2;
   g.ws_bytes = (size_t)g.grid_mul * (KYB_BLOCK / 64) * (8 * 10 * 64) * sizeof(uint4);
-  hipError_t em = hipMalloc(&g.ws_slots[0].ws, g.ws_bytes);
+  hipError_t em = hipMalloc(&g.res[0].ws, g.ws_bytes);
   if (em != hipSuccess) return fail(KYB_E_NOMEM, "workspace allocation", em);
-  g.ws_slots[0].stream = g.stream;
-  g.ws_count = 1;
+  g.res[0].stream = g.stream;
+  g.res_count = 1;
   if (build_table) {
     hipLaunchKernelGGL(k_base_table, dim3(8), dim3(64), 0, g.stream, g.table);
     HIPCK(hipGetLastError());
@@ -411,56 +532,121 @@ int do_init(int device, bool build_table) {
 #define REQUIRE_READY() do { if (!g.ready) return fail(KYB_E_NOT_INIT, "kyb_init has not succeeded in this process"); } while (0)
 #define REQUIRE_TABLE() do { if (!g.table_ready) return fail(KYB_E_NOT_INIT, "base table not built or imported"); } while (0)
 
-// workspace bound to a stream (allocated on first use; at most 8 streams)
-int ws_for(hipStream_t st, uint4** out) {
-  static std::mutex ws_mu;
-  std::lock_guard<std::mutex> lk(ws_mu);
-  for (int i = 0; i < g.ws_count; ++i) if (g.ws_slots[i].stream == st) { *out = g.ws_slots[i].ws; return KYB_OK; }
-  if (g.ws_count == 8) return fail(KYB_E_NOMEM, "variable-base kernels have been launched on more than 8 distinct streams");
+// scratch bound to a stream (allocated on first use; at most 8 streams)
+int res_for(hipStream_t st, Ctx::StreamRes** out) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  for (int i = 0; i < g.res_count; ++i) if (g.res[i].stream == st) { *out = &g.res[i]; return KYB_OK; }
+  if (g.res_count == 8) return fail(KYB_E_NOMEM, "kernels have been launched on more than 8 distinct streams");
   uint4* p = nullptr;
   hipError_t e = hipMalloc(&p, g.ws_bytes);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "workspace allocation", e);
-  g.ws_slots[g.ws_count].stream = st;
-  g.ws_slots[g.ws_count].ws = p;
-  g.ws_count++;
-  *out = p;
+  g.res[g.res_count] = Ctx::StreamRes{st, p, nullptr, 0, nullptr, 0};
+  *out = &g.res[g.res_count++];
+  return KYB_OK;
+}
+// grow-only; growth synchronises the stream first because earlier launches may still use the old buffer
+int ensure_proj(Ctx::StreamRes* r, size_t items) {
+  if (items <= r->proj_items) return KYB_OK;
+  HIPCK(hipStreamSynchronize(r->stream));
+  if (r->proj) HIPCK(hipFree(r->proj));
+  r->proj = nullptr; r->proj_items = 0;
+  const size_t want = ((items + (items >> 3)) + 1023) & ~(size_t)1023;
+  hipError_t e = hipMalloc(&r->proj, want * 8 * sizeof(uint4));
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "projective staging allocation", e);
+  r->proj_items = want;
+  return KYB_OK;
+}
+int ensure_enc(Ctx::StreamRes* r, size_t bytes) {
+  if (bytes <= r->enc_bytes) return KYB_OK;
+  HIPCK(hipStreamSynchronize(r->stream));
+  if (r->enc) HIPCK(hipFree(r->enc));
+  r->enc = nullptr; r->enc_bytes = 0;
+  const size_t want = bytes + (bytes >> 3) + 4096;
+  hipError_t e = hipMalloc(&r->enc, want);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "encoding staging allocation", e);
+  r->enc_bytes = want;
+  return KYB_OK;
+}
+inline bool use_split(size_t n) { return g.opt_finish == 1 && n >= (size_t)g.opt_finish_min; }
+
+int launch_finish(Ctx::StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st) {
+  const size_t M = (n + FINISH_K - 1) / FINISH_K;
+  hipLaunchKernelGGL(k_finish, dim3((unsigned)((M + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, r->proj, r->proj_items, n, oenc, oext);
+  HIPCK(hipGetLastError());
   return KYB_OK;
 }
 
+template <bool SPLIT>
+void launch_mul_t(int sel, bool enc, int grid, hipStream_t st, const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n,
+                  uint8_t* oenc, int32_t* oext, uint8_t* ok, Ctx::StreamRes* r) {
+#define KYB_L(M_, E_) hipLaunchKernelGGL((k_mul<M_, E_, SPLIT>), dim3(grid), dim3(KYB_BLOCK), 0, st, sc, penc, pext, n, oenc, oext, ok, r->ws, r->proj, r->proj_items)
+  if (sel == 0) { if (enc) KYB_L(0, true); else KYB_L(0, false); }
+  else          { if (enc) KYB_L(1, true); else KYB_L(1, false); }
+#undef KYB_L
+}
 int launch_mul(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, hipStream_t st) {
   if (n == 0) return KYB_OK;
-  uint4* ws = nullptr;
-  { int rc = ws_for(st, &ws); if (rc) return rc; }
+  Ctx::StreamRes* r = nullptr;
+  { int rc = res_for(st, &r); if (rc) return rc; }
   const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
   const int grid = (int)(nchunks < (size_t)g.grid_mul ? nchunks : (size_t)g.grid_mul);
-  const bool enc = penc != nullptr;
-  if (g.opt_mul_select == 0) {
-    if (enc) hipLaunchKernelGGL((k_mul<0, true>), dim3(grid), dim3(KYB_BLOCK), 0, st, sc, penc, pext, n, oenc, oext, ok, ws);
-    else     hipLaunchKernelGGL((k_mul<0, false>), dim3(grid), dim3(KYB_BLOCK), 0, st, sc, penc, pext, n, oenc, oext, ok, ws);
-  } else {
-    if (enc) hipLaunchKernelGGL((k_mul<1, true>), dim3(grid), dim3(KYB_BLOCK), 0, st, sc, penc, pext, n, oenc, oext, ok, ws);
-    else     hipLaunchKernelGGL((k_mul<1, false>), dim3(grid), dim3(KYB_BLOCK), 0, st, sc, penc, pext, n, oenc, oext, ok, ws);
-  }
+  const bool split = use_split(n);
+  if (split) { int rc = ensure_proj(r, n); if (rc) return rc; }
+  if (split) launch_mul_t<true>(g.opt_mul_select, penc != nullptr, grid, st, sc, penc, pext, n, oenc, oext, ok, r);
+  else       launch_mul_t<false>(g.opt_mul_select, penc != nullptr, grid, st, sc, penc, pext, n, oenc, oext, ok, r);
+  HIPCK(hipGetLastError());
+  if (split) return launch_finish(r, n, oenc, oext, st);
+  return KYB_OK;
+}
+
+// fixed-base multiplication of n scalars; SPLIT leaves the points in r->proj at [offset, offset + n)
+template <bool SPLIT>
+int launch_base_t(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, Ctx::StreamRes* r, size_t offset, hipStream_t st) {
+  const uint4* img = reinterpret_cast<const uint4*>(g.table);
+  const int block = g.opt_base_block;
+  const size_t nchunks = (n + block - 1) / block;
+  const size_t cap = (size_t)g.cus * 2;                       // 2 blocks per CU: LDS holds two 64 KiB tables
+  const int grid = (int)(nchunks < cap ? nchunks : cap);
+#define KYB_L(M_, B_) hipLaunchKernelGGL((k_mul_base<M_, B_, SPLIT>), dim3(grid), dim3(B_), 0, st, sc, n, oenc, oext, img, r->proj, r->proj_items, offset)
+  if (g.opt_base_select == 0) { if (block == 512) KYB_L(0, 512); else KYB_L(0, 256); }
+  else                        { if (block == 512) KYB_L(1, 512); else KYB_L(1, 256); }
+#undef KYB_L
   HIPCK(hipGetLastError());
   return KYB_OK;
 }
 int launch_mul_base(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st) {
   if (n == 0) return KYB_OK;
-  const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
-  const int grid = (int)(nchunks < (size_t)g.grid_base ? nchunks : (size_t)g.grid_base);
-  const uint4* img = reinterpret_cast<const uint4*>(g.table);
-  if (g.opt_base_select == 0) hipLaunchKernelGGL((k_mul_base<0>), dim3(grid), dim3(KYB_BLOCK), 0, st, sc, n, oenc, oext, img);
-  else                        hipLaunchKernelGGL((k_mul_base<1>), dim3(grid), dim3(KYB_BLOCK), 0, st, sc, n, oenc, oext, img);
-  HIPCK(hipGetLastError());
-  return KYB_OK;
+  Ctx::StreamRes* r = nullptr;
+  { int rc = res_for(st, &r); if (rc) return rc; }
+  if (use_split(n)) {
+    int rc = ensure_proj(r, n); if (rc) return rc;
+    rc = launch_base_t<true>(sc, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
+    return launch_finish(r, n, oenc, oext, st);
+  }
+  return launch_base_t<false>(sc, n, oenc, oext, r, 0, st);
 }
 int launch_sign(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* sig, hipStream_t st) {
   if (n == 0) return KYB_OK;
+  Ctx::StreamRes* r = nullptr;
+  { int rc = res_for(st, &r); if (rc) return rc; }
+  if (use_split(2 * n)) {
+    // R = k*B -> proj[0, n), A = x*B -> proj[n, 2n); one batched finish; then hash + scalar arithmetic
+    int rc = ensure_proj(r, 2 * n); if (rc) return rc;
+    rc = ensure_enc(r, 64 * n); if (rc) return rc;
+    rc = launch_base_t<true>(k, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
+    rc = launch_base_t<true>(x, n, nullptr, nullptr, r, n, st); if (rc) return rc;
+    rc = launch_finish(r, 2 * n, r->enc, nullptr, st); if (rc) return rc;
+    hipLaunchKernelGGL(k_sign_hash, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, r->enc, sig);
+    HIPCK(hipGetLastError());
+    return KYB_OK;
+  }
   const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
-  const int grid = (int)(nchunks < (size_t)g.grid_base ? nchunks : (size_t)g.grid_base);
+  const size_t cap = (size_t)g.cus * 2;
+  const int grid = (int)(nchunks < cap ? nchunks : cap);
   const uint4* img = reinterpret_cast<const uint4*>(g.table);
-  if (g.opt_base_select == 0) hipLaunchKernelGGL((k_sign<0>), dim3(grid), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, sig, img);
-  else                        hipLaunchKernelGGL((k_sign<1>), dim3(grid), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, sig, img);
+  if (g.opt_base_select == 0) hipLaunchKernelGGL((k_sign<0, KYB_BLOCK>), dim3(grid), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, sig, img);
+  else                        hipLaunchKernelGGL((k_sign<1, KYB_BLOCK>), dim3(grid), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, sig, img);
   HIPCK(hipGetLastError());
   return KYB_OK;
 }
@@ -478,8 +664,13 @@ void kyb_shutdown(void) {
   (void)hipSetDevice(g.device);
   (void)hipStreamSynchronize(g.stream);
   if (g.stage) (void)hipFree(g.stage);
-  for (int i = 0; i < g.ws_count; ++i) (void)hipFree(g.ws_slots[i].ws);
-  g.ws_count = 0;
+  for (int i = 0; i < g.res_count; ++i) {
+    (void)hipFree(g.res[i].ws);
+    if (g.res[i].proj) (void)hipFree(g.res[i].proj);
+    if (g.res[i].enc) (void)hipFree(g.res[i].enc);
+    g.res[i] = Ctx::StreamRes{};
+  }
+  g.res_count = 0;
   if (g.table) (void)hipFree(g.table);
   (void)hipStreamDestroy(g.stream);
   g.stage = nullptr; g.stage_bytes = 0; g.table = nullptr; g.stream = nullptr;
@@ -699,18 +890,22 @@ int kyb_set_option(const char* key, int value) {
   if (!key) return fail(KYB_E_BAD_ARG, "null key");
   if (!strcmp(key, "mul.select")) { if (value < 0 || value > 1) return fail(KYB_E_BAD_ARG, "mul.select in {0,1}"); g.opt_mul_select = value; return KYB_OK; }
   if (!strcmp(key, "mul_base.select")) { if (value < 0 || value > 1) return fail(KYB_E_BAD_ARG, "mul_base.select in {0,1}"); g.opt_base_select = value; return KYB_OK; }
+  if (!strcmp(key, "mul_base.block")) { if (value != 256 && value != 512) return fail(KYB_E_BAD_ARG, "mul_base.block in {256,512}"); g.opt_base_block = value; return KYB_OK; }
+  if (!strcmp(key, "finish.batched")) { if (value < 0 || value > 1) return fail(KYB_E_BAD_ARG, "finish.batched in {0,1}"); g.opt_finish = value; return KYB_OK; }
+  if (!strcmp(key, "finish.min_items")) { if (value < 1) return fail(KYB_E_BAD_ARG, "finish.min_items >= 1"); g.opt_finish_min = value; return KYB_OK; }
   if (!strcmp(key, "mul.grid_per_cu")) { if (value < 1 || value > 8 || !g.ready) return fail(KYB_E_BAD_ARG, "mul.grid_per_cu in 1..8 after init");
     if (value > 2) return fail(KYB_E_BAD_ARG, "workspace is sized for 2 blocks per CU");
     g.grid_mul = g.cus * value; return KYB_OK; }
-  if (!strcmp(key, "mul_base.grid_per_cu")) { if (value < 1 || value > 2 || !g.ready) return fail(KYB_E_BAD_ARG, "mul_base.grid_per_cu in 1..2 after init"); g.grid_base = g.cus * value; return KYB_OK; }
   return fail(KYB_E_BAD_ARG, "unknown option");
 }
 int kyb_get_option(const char* key, int* value) {
   if (!key || !value) return fail(KYB_E_BAD_ARG, "null argument");
   if (!strcmp(key, "mul.select")) { *value = g.opt_mul_select; return KYB_OK; }
   if (!strcmp(key, "mul_base.select")) { *value = g.opt_base_select; return KYB_OK; }
+  if (!strcmp(key, "mul_base.block")) { *value = g.opt_base_block; return KYB_OK; }
+  if (!strcmp(key, "finish.batched")) { *value = g.opt_finish; return KYB_OK; }
+  if (!strcmp(key, "finish.min_items")) { *value = g.opt_finish_min; return KYB_OK; }
   if (!strcmp(key, "mul.grid_per_cu")) { *value = g.cus ? g.grid_mul / g.cus : 0; return KYB_OK; }
-  if (!strcmp(key, "mul_base.grid_per_cu")) { *value = g.cus ? g.grid_base / g.cus : 0; return KYB_OK; }
   return fail(KYB_E_BAD_ARG, "unknown option");
 }
 

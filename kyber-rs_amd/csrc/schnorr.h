@@ -32,8 +32,9 @@ KYB_HD void schnorr_sign(uint32_t sig[16], const uint32_t x[8], const uint32_t k
   ge_encode_with_recip(aenc, A.X, A.Y, ziA);
   sha512_ctx c;
   sha512_init(c);
-  sha512_words32(c, renc);
-  sha512_words32(c, aenc);
+  uint32_t ra[16];
+  for (int i = 0; i < 8; ++i) { ra[i] = renc[i]; ra[8 + i] = aenc[i]; }
+  sha512_words64(c, ra);
   sha512_bytes(c, msg, msg_len);
   uint32_t dig[16], h[8], s[8];
   sha512_final(dig, c);

@@ -94,6 +94,14 @@ KYB_HD void sha512_words32(sha512_ctx& c, const uint32_t w[8]) {
   for (int i = 0; i < 8; ++i)
     for (int b = 0; b < 4; ++b) sha512_byte(c, (w[i] >> (8 * b)) & 0xffu);
 }
+// absorb 64 bytes given as 16 little-endian 32-bit words into an EMPTY block position (fill == 0):
+// the R || A prefix of the signing hash; no per-byte select
+KYB_HD void sha512_words64(sha512_ctx& c, const uint32_t w[16]) {
+  for (int i = 0; i < 8; ++i)
+    c.w[i] = ((uint64_t)__builtin_bswap32(w[2 * i]) << 32) | (uint64_t)__builtin_bswap32(w[2 * i + 1]);
+  c.fill = 64;
+  c.total += 64;
+}
 KYB_HD void sha512_bytes(sha512_ctx& c, const uint8_t* p, uint32_t n) {
   for (uint32_t i = 0; i < n; ++i) sha512_byte(c, p[i]);
 }

@@ -209,3 +209,56 @@ def test_base_table_matches_oracle(engine, oracle):
             x = (ypx - ymx) * pow(2, P - 2, P) % P
             assert (ypx + ymx) * pow(2, P - 2, P) % P == y and (x & 1) == sign
             assert xy2d == 2 * d * x * y % P
+
+
+@pytest.mark.parametrize("block", [256, 512])
+def test_split_finish_and_block_variants(engine, oracle, block):
+    """batched-inversion finish (Montgomery trick over 8 items per lane) and the 512-thread fixed-base
+    kernel give the same bytes as the fused path / the oracle, including ragged tails"""
+    engine.set_option("finish.min_items", 1)
+    engine.set_option("mul_base.block", block)
+    try:
+        for n in (1, 7, 8, 9, 1000, 2051):
+            s = np.concatenate([synth.scalars(n - n // 3, 31), synth.raw256(n // 3, 31)])
+            engine.set_option("finish.batched", 1)
+            got, ext = engine.mul_base(s, want_ext=True)
+            assert np.array_equal(got, oracle.mul_base_batch(s, nthreads=8))
+            pts = rand_points_ext(oracle, n, 32)
+            got_v = engine.mul(s, pts_ext=pts)
+            assert np.array_equal(got_v, oracle.mul_batch(s, pts, nthreads=8))
+            engine.set_option("finish.batched", 0)
+            got0, ext0 = engine.mul_base(s, want_ext=True)
+            assert np.array_equal(got, got0) and np.array_equal(ext, ext0)
+        n = 600
+        x, k = synth.scalars(n, 33, b"x"), synth.raw256(n, 33, b"k")
+        msgs = [bytes([i & 255]) * (i % 97) for i in range(n)]
+        engine.set_option("finish.batched", 1)
+        assert np.array_equal(engine.schnorr_sign(x, k, msgs), oracle.schnorr_sign_batch(x, k, msgs, nthreads=8))
+    finally:
+        engine.set_option("finish.batched", 1)
+        engine.set_option("finish.min_items", 4096)
+        engine.set_option("mul_base.block", 256)
+
+
+def test_split_finish_isolates_degenerate_z(engine, oracle):
+    """an invalid extended input whose result has Z = 0 must not disturb the items that share its
+    batched inversion, and must give the same bytes as the per-item path"""
+    n = 64
+    s = synth.scalars(n, 41)
+    pts = rand_points_ext(oracle, n, 41)
+    pts[5] = 0          # X = Y = Z = T = 0: not a curve point; every formula output stays 0
+    pts[22] = 0
+    engine.set_option("finish.min_items", 1)
+    try:
+        engine.set_option("finish.batched", 1)
+        a = engine.mul(s, pts_ext=pts)
+        engine.set_option("finish.batched", 0)
+        b = engine.mul(s, pts_ext=pts)
+    finally:
+        engine.set_option("finish.batched", 1)
+        engine.set_option("finish.min_items", 4096)
+    assert np.array_equal(a, b)
+    want = oracle.mul_batch(s, pts, nthreads=8)
+    good = [i for i in range(n) if i not in (5, 22)]
+    assert np.array_equal(a[good], want[good])
+    assert np.array_equal(a[[5, 22]], want[[5, 22]])     # reference: 0^(p-2) = 0 -> all-zero encoding
