@@ -28,11 +28,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-# algorithmic 32x32->64 multiply(-add)s per unit, fixed by the reference's algorithm
+# algorithmic 32x32->64 multiply(-add)s per unit, fixed by the reference's algorithm:
+# whole step (mult + encode) and the dominant kernel alone (mult with projective output; the encode is
+# k_finish's work when the batched finish is on)
 PRODUCTS = {"mul": 203_910, "mul_base": 62_250, "sign": 124_500}
+PRODUCTS_DOMINANT = {"k_mul": 188_640, "k_mul_base": 46_980, "k_sign": 124_500}
 ALG_BYTES = {"mul": 32 + 160 + 32, "mul_base": 32 + 32, "sign": 32 + 32 + 32 + 64}
 UNIT = {"mul": "variable-base scalar-mults/s", "mul_base": "fixed-base scalar-mults/s", "sign": "signatures/s"}
-KERNEL = {"mul": "k_mul", "mul_base": "k_mul_base", "sign": "k_sign"}
+DOMINANT = {"mul": "k_mul", "mul_base": "k_mul_base", "sign": "k_mul_base"}
 # measured on MI355X: 26.8e12 v_mad_u64_u32 lane-ops/s with every SIMD issuing (8 waves/SIMD, clock
 # settles at ~1.9 GHz under this load) — tools/microbench/valu_rates.hip
 PEAK_MAD_PER_S = 26.8e12
@@ -121,7 +124,10 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # HIP events on the launch stream: per step (torch events) and per kernel launch (the engine's own
+    # event pairs around every kernel it launches, kyb_profile_begin / kyb_profile_read)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    eng.profile_begin(8 * args.steps)
     t_start = time.perf_counter()
     for a, b in evs:
         a.record()
@@ -129,7 +135,9 @@ def main():
         b.record()
     barrier()
     elapsed = time.perf_counter() - t_start
-    kern_ms = [a.elapsed_time(b) for a, b in evs]     # HIP events on the launch stream: one launch per step
+    step_ms = [a.elapsed_time(b) for a, b in evs]
+    launches = eng.profile_read(8 * args.steps)
+    eng.profile_begin(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,8 +192,22 @@ def main():
     if rank == 0:
         total_items = n * world * args.steps
         value = total_items / elapsed
-        avg_ms = sum(kern_ms) / len(kern_ms)
-        mad_rate = PRODUCTS[wl] * n / (avg_ms * 1e-3)
+        per_kernel = {}
+        for name, ms in launches:
+            per_kernel.setdefault(name, []).append(ms)
+        dom = DOMINANT[wl] if DOMINANT[wl] in per_kernel else max(per_kernel, key=lambda k_: sum(per_kernel[k_]))
+        dom_ms = sum(per_kernel[dom]) / len(per_kernel[dom])                  # average duration of ONE launch
+        launches_per_step = len(per_kernel[dom]) / args.steps
+        items_per_launch = n * (2 if wl == "sign" and dom == "k_mul_base" else 1) / launches_per_step
+        dom_products = PRODUCTS_DOMINANT.get(dom, PRODUCTS[wl]) if eng.get_option("finish.batched") and n >= eng.get_option("finish.min_items") else PRODUCTS[wl]
+        mad_rate = dom_products * items_per_launch / (dom_ms * 1e-3)
+        avg_step_ms = sum(step_ms) / len(step_ms)
+        # HBM/fabric bytes per launch from the PMC passes of the same command (profiles/, FETCH_SIZE x2 + WRITE_SIZE)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01", f"{wl}_pmc_summary.json")
+        if os.path.exists(pmc) and n == (1 << 20):
+            d_ = json.load(open(pmc))["_derived"]
+            traffic = round(d_["fetch_bytes_per_dispatch_corrected_x2"] + d_["write_bytes_per_dispatch"])
         line = {
             "metric": "Ed25519 scalar-mults/sec" if wl != "sign" else "Ed25519 Schnorr signatures/sec",
             "value": round(value, 1), "unit": UNIT[wl], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,13 +217,17 @@ def main():
                                     "mul_base": "2^20 fixed-base (generator) scalar-mults, 32-byte encodings out",
                                     "sign": "2^18 Schnorr signs, 32-byte messages, 64-byte signatures out"}[wl] if not args.n else f"{wl} x {n} per GPU",
                        "items_per_gpu": n, "sharding": f"independent shards x{world}, no data-path collective; one RCCL table broadcast at init",
-                       "select": {"mul": eng.get_option("mul.select"), "mul_base": eng.get_option("mul_base.select")}},
-            "roofline": {"bound": "valu-int", "kernel": KERNEL[wl], "achieved": round(mad_rate / 1e12, 3), "peak": PEAK_MAD_PER_S / 1e12,
+                       "options": {k_: eng.get_option(k_) for k_ in ("mul.select", "mul_base.select", "mul_base.block", "finish.batched", "finish.min_items")}},
+            "roofline": {"bound": "valu-int", "kernel": dom, "achieved": round(mad_rate / 1e12, 3), "peak": PEAK_MAD_PER_S / 1e12,
                          "unit": "T(32x32+64 mad)/s", "frac": round(mad_rate / PEAK_MAD_PER_S, 4),
-                         "algorithmic_mads_per_item": PRODUCTS[wl], "avg_kernel_ms": round(avg_ms, 4),
-                         "traffic": None,
-                         "hbm": {"achieved": round(ALG_BYTES[wl] * n / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(ALG_BYTES[wl] * n / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_item": ALG_BYTES[wl]}},
+                         "algorithmic_mads_per_item": dom_products, "items_per_launch": int(items_per_launch),
+                         "avg_launch_ms": round(dom_ms, 4), "launches_timed": len(per_kernel[dom]),
+                         "traffic": traffic,
+                         "step": {"avg_step_ms": round(avg_step_ms, 4), "kernels_ms": {k_: round(sum(v_) / args.steps, 4) for k_, v_ in per_kernel.items()},
+                                  "algorithmic_mads_per_item": PRODUCTS[wl],
+                                  "frac": round(PRODUCTS[wl] * n / (avg_step_ms * 1e-3) / PEAK_MAD_PER_S, 4)},
+                         "hbm": {"achieved": round(ALG_BYTES[wl] * n / (avg_step_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(ALG_BYTES[wl] * n / (avg_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_item": ALG_BYTES[wl]}},
             "cpu_baseline": cpu,
             "parity_checked_items": checked, "input_gen_s": round(gen_s, 2),
         }

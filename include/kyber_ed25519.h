@@ -105,9 +105,21 @@ int kyb_schnorr_sign_batch_dev(const uint8_t* x, const uint8_t* k, const uint8_t
 
 /* ---- introspection for benchmarks / tests ------------------------------------------------------ */
 /* kernel variant selection: key is e.g. "mul.select" / "mul_base.select"; returns
- * KYB_E_BAD_ARG for unknown keys or values.  Defaults are the fastest measured variants. */
+ * KYB_E_BAD_ARG for unknown keys or values.  Defaults are the fastest measured variants.
+ *   mul.select        0 v_cndmask merge, 1 and/or merge of the variable-base table scan
+ *   mul_base.select   0 LDS broadcast scan, 1 ds_bpermute selection
+ *   mul_base.block    256 | 512 threads per workgroup of the fixed-base kernel
+ *   finish.batched    1: results stay projective and one inversion serves 8 items (k_finish)
+ *   finish.min_items  smallest batch that takes the batched finish (default 4096) */
 int kyb_set_option(const char* key, int value);
 int kyb_get_option(const char* key, int* value);
+/* per-launch kernel timing for benchmarks: after kyb_profile_begin(m) the next m kernel launches are
+ * bracketed by HIP events on their launch stream; kyb_profile_read waits for them and returns
+ * (kernel id, milliseconds) pairs in launch order and stops recording.  kyb_profile_begin(0) frees
+ * the events.  kyb_kernel_name maps an id to the kernel's name ("k_mul", "k_mul_base", ...). */
+int kyb_profile_begin(int max_launches);
+int kyb_profile_read(int* kernel_ids, float* ms, int cap, int* count);
+const char* kyb_kernel_name(int kernel_id);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "kyb_mul_base_batch", "kyb_mul_base_batch_dev", "kyb_mul_batch", "kyb_mul_batch_dev",
     "kyb_add_batch", "kyb_add_batch_dev", "kyb_encode_batch", "kyb_encode_batch_dev",
     "kyb_decode_batch", "kyb_decode_batch_dev", "kyb_schnorr_sign_batch", "kyb_schnorr_sign_batch_dev",
-    "kyb_set_option", "kyb_get_option",
+    "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
 ]
 
 
@@ -84,8 +84,12 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_schnorr_sign_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     lib.kyb_set_option.argtypes = [ctypes.c_char_p, i32]
     lib.kyb_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32)]
+    lib.kyb_profile_begin.argtypes = [i32]
+    lib.kyb_profile_read.argtypes = [ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_float), i32, ctypes.POINTER(i32)]
+    lib.kyb_kernel_name.argtypes = [i32]
+    lib.kyb_kernel_name.restype = ctypes.c_char_p
     for name in ABI_SYMBOLS:
-        if name not in ("kyb_shutdown", "kyb_last_error"):
+        if name not in ("kyb_shutdown", "kyb_last_error", "kyb_kernel_name"):
             getattr(lib, name).restype = i32
     _lib = lib
     return lib
@@ -130,6 +134,17 @@ class Engine:
         v = ctypes.c_int(0)
         _check(self.lib.kyb_get_option(key.encode(), ctypes.byref(v)), f"kyb_get_option({key})")
         return v.value
+
+    def profile_begin(self, max_launches: int) -> None:
+        _check(self.lib.kyb_profile_begin(max_launches), "kyb_profile_begin")
+
+    def profile_read(self, cap: int = 4096):
+        """-> list of (kernel name, milliseconds) in launch order"""
+        ids = (ctypes.c_int * cap)()
+        ms = (ctypes.c_float * cap)()
+        cnt = ctypes.c_int(0)
+        _check(self.lib.kyb_profile_read(ids, ms, cap, ctypes.byref(cnt)), "kyb_profile_read")
+        return [(self.lib.kyb_kernel_name(ids[i]).decode(), float(ms[i])) for i in range(cnt.value)]
 
     def sync(self, stream: int = 0) -> None:
         _check(self.lib.kyb_sync(ctypes.c_void_p(stream)), "kyb_sync")

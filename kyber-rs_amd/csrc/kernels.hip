@@ -437,6 +437,23 @@ namespace {
 
 thread_local std::string g_err;
 
+// optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
+enum KernelId { KID_MUL = 0, KID_MUL_BASE = 1, KID_FINISH = 2, KID_SIGN = 3, KID_SIGN_HASH = 4, KID_COUNT = 5 };
+const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash"};
+struct ProfRec { int id; hipEvent_t a, b; };
+struct Prof {
+  bool on = false;
+  int cap = 0, used = 0;
+  ProfRec* recs = nullptr;
+} g_prof;
+struct ProfScope {
+  hipStream_t st; int slot;
+  ProfScope(hipStream_t s, int id) : st(s), slot(-1) {
+    if (g_prof.on && g_prof.used < g_prof.cap) { slot = g_prof.used++; g_prof.recs[slot].id = id; (void)hipEventRecord(g_prof.recs[slot].a, st); }
+  }
+  ~ProfScope() { if (slot >= 0) (void)hipEventRecord(g_prof.recs[slot].b, st); }
+};
+
 struct Ctx {
   bool ready = false;
   int device = -1;
@@ -572,6 +589,7 @@ inline bool use_split(size_t n) { return g.opt_finish == 1 && n >= (size_t)g.opt
 
 int launch_finish(Ctx::StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st) {
   const size_t M = (n + FINISH_K - 1) / FINISH_K;
+  ProfScope ps(st, KID_FINISH);
   hipLaunchKernelGGL(k_finish, dim3((unsigned)((M + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, r->proj, r->proj_items, n, oenc, oext);
   HIPCK(hipGetLastError());
   return KYB_OK;
@@ -593,8 +611,11 @@ int launch_mul(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size
   const int grid = (int)(nchunks < (size_t)g.grid_mul ? nchunks : (size_t)g.grid_mul);
   const bool split = use_split(n);
   if (split) { int rc = ensure_proj(r, n); if (rc) return rc; }
-  if (split) launch_mul_t<true>(g.opt_mul_select, penc != nullptr, grid, st, sc, penc, pext, n, oenc, oext, ok, r);
-  else       launch_mul_t<false>(g.opt_mul_select, penc != nullptr, grid, st, sc, penc, pext, n, oenc, oext, ok, r);
+  {
+    ProfScope ps(st, KID_MUL);
+    if (split) launch_mul_t<true>(g.opt_mul_select, penc != nullptr, grid, st, sc, penc, pext, n, oenc, oext, ok, r);
+    else       launch_mul_t<false>(g.opt_mul_select, penc != nullptr, grid, st, sc, penc, pext, n, oenc, oext, ok, r);
+  }
   HIPCK(hipGetLastError());
   if (split) return launch_finish(r, n, oenc, oext, st);
   return KYB_OK;
@@ -608,6 +629,7 @@ int launch_base_t(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, Ctx
   const size_t nchunks = (n + block - 1) / block;
   const size_t cap = (size_t)g.cus * 2;                       // 2 blocks per CU: LDS holds two 64 KiB tables
   const int grid = (int)(nchunks < cap ? nchunks : cap);
+  ProfScope ps(st, KID_MUL_BASE);
 #define KYB_L(M_, B_) hipLaunchKernelGGL((k_mul_base<M_, B_, SPLIT>), dim3(grid), dim3(B_), 0, st, sc, n, oenc, oext, img, r->proj, r->proj_items, offset)
   if (g.opt_base_select == 0) { if (block == 512) KYB_L(0, 512); else KYB_L(0, 256); }
   else                        { if (block == 512) KYB_L(1, 512); else KYB_L(1, 256); }
@@ -637,6 +659,7 @@ int launch_sign(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const u
     rc = launch_base_t<true>(k, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
     rc = launch_base_t<true>(x, n, nullptr, nullptr, r, n, st); if (rc) return rc;
     rc = launch_finish(r, 2 * n, r->enc, nullptr, st); if (rc) return rc;
+    ProfScope ps(st, KID_SIGN_HASH);
     hipLaunchKernelGGL(k_sign_hash, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, r->enc, sig);
     HIPCK(hipGetLastError());
     return KYB_OK;
@@ -645,6 +668,7 @@ int launch_sign(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const u
   const size_t cap = (size_t)g.cus * 2;
   const int grid = (int)(nchunks < cap ? nchunks : cap);
   const uint4* img = reinterpret_cast<const uint4*>(g.table);
+  ProfScope ps(st, KID_SIGN);
   if (g.opt_base_select == 0) hipLaunchKernelGGL((k_sign<0, KYB_BLOCK>), dim3(grid), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, sig, img);
   else                        hipLaunchKernelGGL((k_sign<1, KYB_BLOCK>), dim3(grid), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, sig, img);
   HIPCK(hipGetLastError());
@@ -885,6 +909,33 @@ int kyb_schnorr_sign_batch(const uint8_t* x, const uint8_t* k, const uint8_t* ms
   HIPCK(hipStreamSynchronize(g.stream));
   return KYB_OK;
 }
+
+int kyb_profile_begin(int max_launches) {
+  REQUIRE_READY();
+  if (max_launches < 0 || max_launches > 65536) return fail(KYB_E_BAD_ARG, "max_launches out of range");
+  for (int i = 0; i < g_prof.cap; ++i) { (void)hipEventDestroy(g_prof.recs[i].a); (void)hipEventDestroy(g_prof.recs[i].b); }
+  delete[] g_prof.recs;
+  g_prof = Prof{};
+  if (max_launches == 0) return KYB_OK;
+  g_prof.recs = new ProfRec[max_launches];
+  for (int i = 0; i < max_launches; ++i) { HIPCK(hipEventCreate(&g_prof.recs[i].a)); HIPCK(hipEventCreate(&g_prof.recs[i].b)); g_prof.cap = i + 1; }
+  g_prof.on = true;
+  return KYB_OK;
+}
+int kyb_profile_read(int* kernel_ids, float* ms, int cap, int* count) {
+  REQUIRE_READY();
+  if (!kernel_ids || !ms || !count) return fail(KYB_E_BAD_ARG, "null argument");
+  g_prof.on = false;
+  int nrec = g_prof.used < cap ? g_prof.used : cap;
+  for (int i = 0; i < nrec; ++i) {
+    HIPCK(hipEventSynchronize(g_prof.recs[i].b));
+    kernel_ids[i] = g_prof.recs[i].id;
+    HIPCK(hipEventElapsedTime(&ms[i], g_prof.recs[i].a, g_prof.recs[i].b));
+  }
+  *count = nrec;
+  return KYB_OK;
+}
+const char* kyb_kernel_name(int kernel_id) { return (kernel_id >= 0 && kernel_id < KID_COUNT) ? KERNEL_NAMES[kernel_id] : ""; }
 
 int kyb_set_option(const char* key, int value) {
   if (!key) return fail(KYB_E_BAD_ARG, "null key");
