@@ -31,11 +31,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # algorithmic 32x32->64 multiply(-add)s per unit, fixed by the reference's algorithm:
 # whole step (mult + encode) and the dominant kernel alone (mult with projective output; the encode is
 # k_finish's work when the batched finish is on)
-PRODUCTS = {"mul": 203_910, "mul_base": 62_250, "sign": 124_500}
+# verify (eddsa_sig.rs:159-212): 2 decodes (2 x 16,000) + 2 has_small_order encodes (2 x 15,270) + fixed-base
+# (46,980) + variable-base (188,640) + add (900) + eq = 2 encodes (2 x 15,270)
+PRODUCTS = {"mul": 203_910, "mul_base": 62_250, "sign": 124_500, "verify": 329_600}
 PRODUCTS_DOMINANT = {"k_mul": 188_640, "k_mul_base": 46_980, "k_sign": 124_500}
-ALG_BYTES = {"mul": 32 + 160 + 32, "mul_base": 32 + 32, "sign": 32 + 32 + 32 + 64}
-UNIT = {"mul": "variable-base scalar-mults/s", "mul_base": "fixed-base scalar-mults/s", "sign": "signatures/s"}
-DOMINANT = {"mul": "k_mul", "mul_base": "k_mul_base", "sign": "k_mul_base"}
+ALG_BYTES = {"mul": 32 + 160 + 32, "mul_base": 32 + 32, "sign": 32 + 32 + 32 + 64, "verify": 32 + 64 + 32 + 1}
+UNIT = {"mul": "variable-base scalar-mults/s", "mul_base": "fixed-base scalar-mults/s", "sign": "signatures/s", "verify": "verifications/s"}
+DOMINANT = {"mul": "k_mul", "mul_base": "k_mul_base", "sign": "k_mul_base", "verify": "k_mul"}
 # measured on MI355X: 26.8e12 v_mad_u64_u32 lane-ops/s with every SIMD issuing (8 waves/SIMD, clock
 # settles at ~1.9 GHz under this load) — tools/microbench/valu_rates.hip
 PEAK_MAD_PER_S = 26.8e12
@@ -47,7 +49,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="mul", choices=["mul", "mul_base", "sign"])
+    ap.add_argument("--workload", default="mul", choices=["mul", "mul_base", "sign", "verify"])
     ap.add_argument("--n", type=int, default=0, help="items per GPU (default 2^20, 2^18 for sign)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=1024, help="items verified against the oracle after timing")
@@ -94,17 +96,22 @@ def main():
     # ---- synthetic inputs, resident in HBM before the timed region ----
     sc_np = synth.scalars(n, seed)
     sc = torch.from_numpy(sc_np).to(dev)
-    out = torch.empty((n, 64 if wl == "sign" else 32), dtype=torch.uint8, device=dev)
-    pts = k = msgs = off = None
+    out = torch.empty((n, 64 if wl == "sign" else (1 if wl == "verify" else 32)), dtype=torch.uint8, device=dev)
+    pts = k = msgs = off = pubs = sigs = None
     if wl == "mul":
         psc = torch.from_numpy(synth.scalars(n, seed, b"point")).to(dev)
         pts = torch.empty((n, 40), dtype=torch.int32, device=dev)        # point_i = (hash mod L) * B, reference limbs
         eng.mul_base_dev(psc, out_ext=pts, stream=stream)
-    elif wl == "sign":
+    elif wl in ("sign", "verify"):
         k = torch.from_numpy(synth.scalars(n, seed, b"k")).to(dev)
         msg_list = synth.messages(n, seed)
         msgs = torch.from_numpy(np.frombuffer(b"".join(msg_list), dtype=np.uint8).copy()).to(dev)
         off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int32, device=dev)
+        if wl == "verify":      # valid signatures to verify: produced on the GPU (untimed), spot-checked below
+            sigs = torch.empty((n, 64), dtype=torch.uint8, device=dev)
+            pubs = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+            eng.sign_dev(sc, k, msgs, off, sigs, stream=stream)
+            eng.mul_base_dev(sc, out_enc=pubs, stream=stream)
     torch.cuda.synchronize()
     gen_s = time.time() - t0
 
@@ -113,8 +120,10 @@ def main():
             eng.mul_dev(sc, pts_ext=pts, out_enc=out, stream=stream)
         elif wl == "mul_base":
             eng.mul_base_dev(sc, out_enc=out, stream=stream)
-        else:
+        elif wl == "sign":
             eng.sign_dev(sc, k, msgs, off, out, stream=stream)
+        else:
+            eng.verify_dev(pubs, msgs, off, sigs, out, flavor=1, stream=stream)
 
     def barrier():
         if world > 1:
@@ -158,15 +167,21 @@ def main():
             want = orc.mul_batch(sc_np[idx], pts[torch.from_numpy(idx).to(dev)].cpu().numpy(), nthreads=threads)
         elif wl == "mul_base":
             want = orc.mul_base_batch(sc_np[idx], nthreads=threads)
-        else:
+        elif wl == "sign":
             want = orc.schnorr_sign_batch(sc_np[idx], k[torch.from_numpy(idx).to(dev)].cpu().numpy(), [msg_list[i] for i in idx], nthreads=threads)
+        else:
+            tidx = torch.from_numpy(idx).to(dev)
+            pub_s, sig_s = pubs[tidx].cpu().numpy(), sigs[tidx].cpu().numpy()
+            want = np.array([[orc.verify(1, bytes(pub_s[j]), msg_list[i], bytes(sig_s[j]))] for j, i in enumerate(idx)], dtype=np.uint8)
+            if want.any() or not np.array_equal(sig_s, orc.schnorr_sign_batch(sc_np[idx], k[tidx].cpu().numpy(), [msg_list[i] for i in idx], nthreads=threads)):
+                raise SystemExit("PARITY FAILURE: GPU-made signatures are not what the oracle signs / verifies")
         if not np.array_equal(got, want):
             raise SystemExit("PARITY FAILURE: GPU output differs from the oracle")
         checked = m
 
         # ---- CPU baseline: the oracle (C port of the reference algorithm) on a bounded sample ----
         if world == 1 and not args.no_cpu_baseline:
-            per_core = {"mul": 1 << 15, "mul_base": 1 << 16, "sign": 1 << 15}[wl]
+            per_core = {"mul": 1 << 15, "mul_base": 1 << 16, "sign": 1 << 15, "verify": 1 << 14}[wl]
 
             def run(cnt, th):
                 sub = np.arange(cnt) % n
@@ -175,13 +190,17 @@ def main():
                     orc.mul_batch(sc_np[sub], pts_cpu[sub], nthreads=th)
                 elif wl == "mul_base":
                     orc.mul_base_batch(sc_np[sub], nthreads=th)
-                else:
+                elif wl == "sign":
                     orc.schnorr_sign_batch(sc_np[sub], k_cpu[sub], [msg_list[i] for i in sub], nthreads=th)
+                else:
+                    orc.verify_batch(1, pub_cpu[sub], [msg_list[i] for i in sub], sig_cpu[sub], nthreads=th)
                 return cnt / (time.perf_counter() - t1)
 
             cnt_all = per_core * threads
             pts_cpu = pts[: min(n, cnt_all)].cpu().numpy() if wl == "mul" else None
             k_cpu = k[: min(n, cnt_all)].cpu().numpy() if wl == "sign" else None
+            pub_cpu = pubs[: min(n, cnt_all)].cpu().numpy() if wl == "verify" else None
+            sig_cpu = sigs[: min(n, cnt_all)].cpu().numpy() if wl == "verify" else None
             one = run(min(per_core, n), 1)
             allc = run(min(cnt_all, n), threads)
             cpu = {"value": round(allc, 1), "unit": UNIT[wl], "cores": threads, "kind": "port",
@@ -209,13 +228,14 @@ def main():
             d_ = json.load(open(pmc))["_derived"]
             traffic = round(d_["fetch_bytes_per_dispatch_corrected_x2"] + d_["write_bytes_per_dispatch"])
         line = {
-            "metric": "Ed25519 scalar-mults/sec" if wl != "sign" else "Ed25519 Schnorr signatures/sec",
+            "metric": {"mul": "Ed25519 scalar-mults/sec", "mul_base": "Ed25519 scalar-mults/sec", "sign": "Ed25519 Schnorr signatures/sec", "verify": "Ed25519 Schnorr verifications/sec"}[wl],
             "value": round(value, 1), "unit": UNIT[wl], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 limbs (radix 2^25.5), u64 accumulators", "data": "synthetic",
             "config": {"workload": {"mul": "2^20 variable-base scalar-mults, random scalars+points, reference-limb points in, 32-byte encodings out",
                                     "mul_base": "2^20 fixed-base (generator) scalar-mults, 32-byte encodings out",
-                                    "sign": "2^18 Schnorr signs, 32-byte messages, 64-byte signatures out"}[wl] if not args.n else f"{wl} x {n} per GPU",
+                                    "sign": "2^18 Schnorr signs, 32-byte messages, 64-byte signatures out",
+                                    "verify": "2^20 Schnorr verifications with the reference's checks, 32-byte messages, status bytes out"}[wl] if not args.n else f"{wl} x {n} per GPU",
                        "items_per_gpu": n, "sharding": f"independent shards x{world}, no data-path collective; one RCCL table broadcast at init",
                        "options": {k_: eng.get_option(k_) for k_ in ("mul.select", "mul_base.select", "mul_base.block", "finish.batched", "finish.min_items")}},
             "roofline": {"bound": "valu-int", "kernel": dom, "achieved": round(mad_rate / 1e12, 3), "peak": PEAK_MAD_PER_S / 1e12,

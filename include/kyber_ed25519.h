@@ -103,6 +103,19 @@ int kyb_schnorr_sign_batch(const uint8_t* x, const uint8_t* k, const uint8_t* ms
 int kyb_schnorr_sign_batch_dev(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* msg_off,
                                size_t n, uint8_t* sig, void* stream);
 
+/* ---- signature verification with the reference's checks --------------------- */
+/* eddsa::verify_with_checks (eddsa_sig.rs:159-212, flavor 0) / schnorr::verify_with_checks
+ * (schnorr_sig.rs:53-110, flavor 1): s*B == R + SHA-512(R || A || msg)*A after the canonical and
+ * small-order checks; the flavors differ only in which error wins when several apply.
+ * pubs: n x 32, sigs: n x 64 (R || s), msgs/msg_off as for signing.  status[i]: 0 valid,
+ * 2 SignatureNotCanonical, 3 RNotCanonical, 4 R does not decode, 5 RSmallOrder,
+ * 6 PublicKeyNotCanonical, 7 public key does not decode, 8 PublicKeySmallOrder, 9 InvalidSignature
+ * (1, wrong signature length, cannot occur with fixed 64-byte records). */
+int kyb_verify_batch(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* msg_off, const uint8_t* sigs,
+                     size_t n, int flavor, uint8_t* status);
+int kyb_verify_batch_dev(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* msg_off, const uint8_t* sigs,
+                         size_t n, int flavor, uint8_t* status, void* stream);
+
 /* ---- introspection for benchmarks / tests ------------------------------------------------------ */
 /* kernel variant selection: key is e.g. "mul.select" / "mul_base.select"; returns
  * KYB_E_BAD_ARG for unknown keys or values.  Defaults are the fastest measured variants.

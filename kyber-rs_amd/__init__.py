@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "kyb_mul_base_batch", "kyb_mul_base_batch_dev", "kyb_mul_batch", "kyb_mul_batch_dev",
     "kyb_add_batch", "kyb_add_batch_dev", "kyb_encode_batch", "kyb_encode_batch_dev",
     "kyb_decode_batch", "kyb_decode_batch_dev", "kyb_schnorr_sign_batch", "kyb_schnorr_sign_batch_dev",
+    "kyb_verify_batch", "kyb_verify_batch_dev",
     "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
 ]
 
@@ -82,6 +83,8 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_decode_batch_dev.argtypes = [vp, sz, vp, vp, vp]
     lib.kyb_schnorr_sign_batch.argtypes = [vp, vp, vp, vp, sz, vp]
     lib.kyb_schnorr_sign_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+    lib.kyb_verify_batch.argtypes = [vp, vp, vp, vp, sz, i32, vp]
+    lib.kyb_verify_batch_dev.argtypes = [vp, vp, vp, vp, sz, i32, vp, vp]
     lib.kyb_set_option.argtypes = [ctypes.c_char_p, i32]
     lib.kyb_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32)]
     lib.kyb_profile_begin.argtypes = [i32]
@@ -206,6 +209,21 @@ class Engine:
         sig = np.empty((n, 64), dtype=np.uint8)
         _check(self.lib.kyb_schnorr_sign_batch(_ptr(xs), _ptr(ks), _ptr(blob), _ptr(off), n, _ptr(sig)), "kyb_schnorr_sign_batch")
         return sig
+
+    def verify(self, pubs, msgs: Sequence[bytes], sigs, flavor: int = 0) -> np.ndarray:
+        """status per item (0 = valid); flavor 0 = eddsa::verify_with_checks order, 1 = schnorr order"""
+        ps, ss = _u8(pubs, 32, "pubs"), _u8(sigs, 64, "sigs")
+        n = ps.shape[0]
+        off = np.zeros(n + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64).astype(np.uint32)
+        blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()
+        st = np.empty((n,), dtype=np.uint8)
+        _check(self.lib.kyb_verify_batch(_ptr(ps), _ptr(blob), _ptr(off), _ptr(ss), n, flavor, _ptr(st)), "kyb_verify_batch")
+        return st
+
+    def verify_dev(self, pubs, msgs, msg_off, sigs, status, flavor: int = 0, stream: int = 0) -> None:
+        n = pubs.numel() // 32
+        _check(self.lib.kyb_verify_batch_dev(self._dp(pubs), self._dp(msgs), self._dp(msg_off), self._dp(sigs), n, flavor, self._dp(status), ctypes.c_void_p(stream)), "kyb_verify_batch_dev")
 
     def base_table(self) -> np.ndarray:
         t = np.empty(BASE_TABLE_BYTES, dtype=np.uint8)

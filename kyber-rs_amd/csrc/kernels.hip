@@ -20,6 +20,7 @@
 
 #include "../../include/kyber_ed25519.h"
 #include "schnorr.h"
+#include "verify.h"
 
 using namespace kyb;
 
@@ -391,6 +392,44 @@ k_sign_hash(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const 
   store_words8(sig, 2 * i + 1, s);
 }
 
+// verification stage 1: checks, decode R and A, h = SHA-512(R || A || msg) mod L.
+// Writes h and s as contiguous 32-byte records, A in reference limbs (input of k_mul), R into the
+// projective staging buffer at [proj_offset, proj_offset + n).
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_verify_prep(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ msgs,
+              const uint32_t* __restrict__ msg_off, size_t n, int flavor, uint8_t* __restrict__ status,
+              uint8_t* __restrict__ hbuf, uint8_t* __restrict__ sbuf, int32_t* __restrict__ a_ext,
+              uint4* __restrict__ proj, size_t stride, size_t proj_offset) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t pub[8], sig[16], h[8];
+  load_words8(pub, pubs, i);
+  load_words8(sig, sigs, 2 * i);
+  load_words8(sig + 8, sigs, 2 * i + 1);
+  const uint32_t off = msg_off[i], len = msg_off[i + 1] - off;
+  ge_p3 R, A;
+  const uint32_t st = verify_prep(h, R, A, pub, sig, msgs + off, len, flavor);
+  status[i] = (uint8_t)st;
+  store_words8(hbuf, i, h);
+  store_words8(sbuf, i, sig + 8);
+  store_ext(a_ext, i, A.X, A.Y, A.Z, A.T);
+  store_proj(proj, stride, proj_offset + i, R.X, R.Y, R.Z);
+}
+// verification stage 4: hA at proj[i], sB at proj[n + i], R at proj[2n + i]
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_verify_final(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __restrict__ status) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  ge_p2 hA, sB;
+  fe RX, RY;
+  load_proj_xy(hA.X, hA.Y, proj, stride, i);           load_proj_z(hA.Z, proj, stride, i);
+  load_proj_xy(sB.X, sB.Y, proj, stride, n + i);       load_proj_z(sB.Z, proj, stride, n + i);
+  load_proj_xy(RX, RY, proj, stride, 2 * n + i);
+  const uint32_t eq = verify_final(RX, RY, hA, sB);
+  const uint8_t st = status[i];
+  status[i] = (st == 0 && !eq) ? (uint8_t)9 : st;
+}
+
 __global__ void __launch_bounds__(KYB_BLOCK)
 k_add(const int32_t* __restrict__ a_ext, const int32_t* __restrict__ b_ext, size_t n, int32_t* __restrict__ out_ext, int subtract) {
   const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
@@ -438,8 +477,8 @@ namespace {
 thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
-enum KernelId { KID_MUL = 0, KID_MUL_BASE = 1, KID_FINISH = 2, KID_SIGN = 3, KID_SIGN_HASH = 4, KID_COUNT = 5 };
-const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash"};
+enum KernelId { KID_MUL = 0, KID_MUL_BASE = 1, KID_FINISH = 2, KID_SIGN = 3, KID_SIGN_HASH = 4, KID_VERIFY_PREP = 5, KID_VERIFY_FINAL = 6, KID_COUNT = 7 };
+const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   bool on = false;
@@ -675,6 +714,38 @@ int launch_sign(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const u
   return KYB_OK;
 }
 
+// verification pipeline on one stream: prep -> k_mul (h, A) -> k_mul_base (s) -> final
+int launch_verify(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, const uint8_t* sigs, size_t n, int flavor,
+                  uint8_t* status, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  Ctx::StreamRes* r = nullptr;
+  { int rc = res_for(st, &r); if (rc) return rc; }
+  int rc = ensure_proj(r, 3 * n); if (rc) return rc;
+  const size_t o_h = 0, o_s = up256(32 * n), o_a = o_s + up256(32 * n);
+  rc = ensure_enc(r, o_a + 160 * n); if (rc) return rc;
+  uint8_t* hbuf = r->enc + o_h; uint8_t* sbuf = r->enc + o_s; int32_t* a_ext = reinterpret_cast<int32_t*>(r->enc + o_a);
+  const unsigned blocks = (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK);
+  {
+    ProfScope ps(st, KID_VERIFY_PREP);
+    hipLaunchKernelGGL(k_verify_prep, dim3(blocks), dim3(KYB_BLOCK), 0, st, pubs, sigs, msgs, off, n, flavor, status, hbuf, sbuf, a_ext, r->proj, r->proj_items, 2 * n);
+  }
+  HIPCK(hipGetLastError());
+  {
+    const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
+    const int grid = (int)(nchunks < (size_t)g.grid_mul ? nchunks : (size_t)g.grid_mul);
+    ProfScope ps(st, KID_MUL);
+    launch_mul_t<true>(g.opt_mul_select, false, grid, st, hbuf, nullptr, a_ext, n, nullptr, nullptr, nullptr, r);
+  }
+  HIPCK(hipGetLastError());
+  rc = launch_base_t<true>(sbuf, n, nullptr, nullptr, r, n, st); if (rc) return rc;
+  {
+    ProfScope ps(st, KID_VERIFY_FINAL);
+    hipLaunchKernelGGL(k_verify_final, dim3(blocks), dim3(KYB_BLOCK), 0, st, r->proj, r->proj_items, n, status);
+  }
+  HIPCK(hipGetLastError());
+  return KYB_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -906,6 +977,40 @@ int kyb_schnorr_sign_batch(const uint8_t* x, const uint8_t* k, const uint8_t* ms
   rc = launch_sign(d + o_x, d + o_k, d + o_m, reinterpret_cast<const uint32_t*>(d + o_off), n, d + o_sig, g.stream);
   if (rc) return rc;
   HIPCK(hipMemcpyAsync(sig, d + o_sig, 64 * n, hipMemcpyDeviceToHost, g.stream));
+  HIPCK(hipStreamSynchronize(g.stream));
+  return KYB_OK;
+}
+
+int kyb_verify_batch_dev(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* msg_off, const uint8_t* sigs, size_t n, int flavor,
+                         uint8_t* status, void* stream) {
+  REQUIRE_READY(); REQUIRE_TABLE();
+  if (n == 0) return KYB_OK;
+  if (!pubs || !msg_off || !sigs || !status) return fail(KYB_E_BAD_ARG, "null buffer");
+  if (flavor != 0 && flavor != 1) return fail(KYB_E_BAD_ARG, "flavor: 0 = eddsa check order, 1 = schnorr check order");
+  if (!aligned16(pubs) || !aligned16(sigs)) return fail(KYB_E_BAD_ARG, "device buffers must be 16-byte aligned");
+  return launch_verify(pubs, msgs, msg_off, sigs, n, flavor, status, pick(stream));
+}
+int kyb_verify_batch(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* msg_off, const uint8_t* sigs, size_t n, int flavor, uint8_t* status) {
+  REQUIRE_READY(); REQUIRE_TABLE();
+  if (n == 0) return KYB_OK;
+  if (!pubs || !msg_off || !sigs || !status) return fail(KYB_E_BAD_ARG, "null buffer");
+  if (flavor != 0 && flavor != 1) return fail(KYB_E_BAD_ARG, "flavor: 0 = eddsa check order, 1 = schnorr check order");
+  const size_t mbytes = msg_off[n];
+  if (mbytes && !msgs) return fail(KYB_E_BAD_ARG, "null message buffer");
+  for (size_t i = 0; i < n; ++i) if (msg_off[i + 1] < msg_off[i]) return fail(KYB_E_BAD_ARG, "msg_off must be non-decreasing");
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCK(hipSetDevice(g.device));
+  const size_t o_p = 0, o_s = up256(32 * n), o_m = o_s + up256(64 * n), o_off = o_m + up256(mbytes + 16), o_st = o_off + up256(4 * (n + 1)), total = o_st + up256(n);
+  int rc = ensure_stage(total);
+  if (rc) return rc;
+  uint8_t* d = g.stage;
+  HIPCK(hipMemcpyAsync(d + o_p, pubs, 32 * n, hipMemcpyHostToDevice, g.stream));
+  HIPCK(hipMemcpyAsync(d + o_s, sigs, 64 * n, hipMemcpyHostToDevice, g.stream));
+  if (mbytes) HIPCK(hipMemcpyAsync(d + o_m, msgs, mbytes, hipMemcpyHostToDevice, g.stream));
+  HIPCK(hipMemcpyAsync(d + o_off, msg_off, 4 * (n + 1), hipMemcpyHostToDevice, g.stream));
+  rc = launch_verify(d + o_p, d + o_m, reinterpret_cast<const uint32_t*>(d + o_off), d + o_s, n, flavor, d + o_st, g.stream);
+  if (rc) return rc;
+  HIPCK(hipMemcpyAsync(status, d + o_st, n, hipMemcpyDeviceToHost, g.stream));
   HIPCK(hipStreamSynchronize(g.stream));
   return KYB_OK;
 }

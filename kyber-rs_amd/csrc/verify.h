@@ -1,0 +1,103 @@
+// Signature verification with the reference's checks.
+//
+//   eddsa::verify_with_checks     /root/reference src/sign/eddsa/eddsa_sig.rs:159-212   (flavor 0)
+//   schnorr::verify_with_checks   src/sign/schnorr/schnorr_sig.rs:53-110               (flavor 1)
+// Both evaluate  s*B == R + h*A  with h = SHA-512(enc R || enc A || msg) mod L after the canonical /
+// small-order checks of point.rs:286-337 and scalar.rs:54-75; they differ only in the ORDER of the
+// checks, i.e. in which error is reported when several apply.  Status codes (0 = valid):
+//   1 InvalidSignatureLength   2 SignatureNotCanonical   3 RNotCanonical   4 R does not decode
+//   5 RSmallOrder   6 PublicKeyNotCanonical   7 public key does not decode   8 PublicKeySmallOrder
+//   9 InvalidSignature (equation fails)
+// The batch is cut into four device stages (kernels.hip): prep (checks, two decodes, hash) ->
+// variable-base h*A -> fixed-base s*B -> final (one addition and a projective comparison: no field
+// inversion anywhere, where the reference's `eq` pays two, point.rs:227-241).
+#pragma once
+#include "ge_scalarmult.h"
+#include "sc25519.h"
+#include "sha512.h"
+
+namespace kyb {
+
+// scalar.rs:54-75: s < L
+KYB_HD uint32_t sc_is_canonical_w(const uint32_t s[8]) {
+  const uint32_t lw[8] = KYB_W_L;
+  uint32_t t[8];
+  return mw_sub<8>(t, s, lw);          // borrow <=> s < L
+}
+// point.rs:315-337: the 255-bit y of the encoding is < p (the sign bit is ignored)
+KYB_HD uint32_t pt_is_canonical_w(const uint32_t w[8]) {
+  uint32_t all = w[1] & w[2] & w[3] & w[4] & w[5] & w[6];
+  uint32_t ge_p = (all == 0xffffffffu) & ((w[7] & 0x7fffffffu) == 0x7fffffffu) & (w[0] >= 0xffffffedu);
+  return 1u - ge_p;
+}
+// point.rs:286-313: the canonical re-encoding, sign bit masked, equals one of the five WEAK_KEYS
+// (constants.rs:3744-3775) <=> canonical y in {0, 1, p-1, y8a, y8b}
+KYB_HD uint32_t pt_has_small_order(const fe& Y) {
+  const uint32_t y8a[8] = KYB_W_ORDER8_Y0, y8b[8] = KYB_W_ORDER8_Y1, pw[8] = KYB_W_P;
+  uint32_t w[8];
+  fe_to_words(w, Y);
+  uint32_t d0 = 0, d1 = 0, dm = 0, da = 0, db = 0;
+  KYB_UNROLL for (int i = 0; i < 8; ++i) {
+    d0 |= w[i];
+    d1 |= w[i] ^ (i == 0 ? 1u : 0u);
+    dm |= w[i] ^ (i == 0 ? pw[0] - 1u : pw[i]);
+    da |= w[i] ^ y8a[i];
+    db |= w[i] ^ y8b[i];
+  }
+  return (d0 == 0) | (d1 == 0) | (dm == 0) | (da == 0) | (db == 0);
+}
+
+// Stage 1.  sig = R (8 words) || s (8 words).  Outputs: status of the pre-equation checks, h, the
+// decoded points.  On a failed decode the point is replaced by the neutral element so that the later
+// stages stay well defined.
+KYB_HD uint32_t verify_prep(uint32_t h[8], ge_p3& R, ge_p3& A, const uint32_t pub[8], const uint32_t sig[16],
+                            const uint8_t* msg, uint32_t msg_len, int flavor) {
+  const uint32_t s_ok = sc_is_canonical_w(sig + 8);
+  const uint32_t r_can = pt_is_canonical_w(sig), a_can = pt_is_canonical_w(pub);
+  const uint32_t r_dec = ge_decode(R, sig), a_dec = ge_decode(A, pub);
+  const uint32_t r_small = pt_has_small_order(R.Y), a_small = pt_has_small_order(A.Y);
+  ge_p3 id;
+  ge_p3_0(id);
+  fe_cmov(R.X, id.X, 1u - r_dec); fe_cmov(R.Y, id.Y, 1u - r_dec); fe_cmov(R.Z, id.Z, 1u - r_dec); fe_cmov(R.T, id.T, 1u - r_dec);
+  fe_cmov(A.X, id.X, 1u - a_dec); fe_cmov(A.Y, id.Y, 1u - a_dec); fe_cmov(A.Z, id.Z, 1u - a_dec); fe_cmov(A.T, id.T, 1u - a_dec);
+  uint32_t st = 0;
+  // evaluate the checks last-to-first so that the FIRST failing one wins
+  if (flavor == 0) {
+    st = a_small ? 8u : st;  st = !a_dec ? 7u : st;  st = !a_can ? 6u : st;
+    st = (r_dec && r_small) ? 5u : st;  st = !r_dec ? 4u : st;  st = !r_can ? 3u : st;  st = !s_ok ? 2u : st;
+  } else {
+    st = (a_dec && a_small) ? 8u : st;  st = !a_can ? 6u : st;  st = !a_dec ? 7u : st;
+    st = !s_ok ? 2u : st;  st = (r_dec && r_small) ? 5u : st;  st = !r_can ? 3u : st;  st = !r_dec ? 4u : st;
+  }
+  uint32_t ra[16];
+  for (int i = 0; i < 8; ++i) { ra[i] = sig[i]; ra[8 + i] = pub[i]; }
+  sha512_ctx c;
+  sha512_init(c);
+  sha512_words64(c, ra);
+  sha512_bytes(c, msg, msg_len);
+  uint32_t dig[16];
+  sha512_final(dig, c);
+  sc_reduce512(h, dig);
+  return st;
+}
+
+// Stage 4.  R affine (X, Y, Z = 1), hA and sB projective (X:Y:Z).  Returns 1 iff R + hA == sB.
+KYB_HD uint32_t verify_final(const fe& RX, const fe& RY, const ge_p2& hA, const ge_p2& sB) {
+  ge_p3 R, H;
+  fe_copy(R.X, RX); fe_copy(R.Y, RY); fe_one(R.Z); fe_mul(R.T, RX, RY);
+  fe_mul(H.X, hA.X, hA.Z); fe_mul(H.Y, hA.Y, hA.Z); fe_sq(H.Z, hA.Z); fe_mul(H.T, hA.X, hA.Y);   // P2 -> P3
+  ge_cached c;
+  ge_p3_to_cached(c, H);
+  ge_p1p1 t;
+  ge_add(t, R, c);
+  ge_p2 sum;
+  ge_p1p1_to_p2(sum, t);
+  fe l, r, d;
+  fe_mul(l, sum.X, sB.Z); fe_mul(r, sB.X, sum.Z); fe_sub(d, l, r);
+  const uint32_t xne = fe_is_nonzero(d);
+  fe_mul(l, sum.Y, sB.Z); fe_mul(r, sB.Y, sum.Z); fe_sub(d, l, r);
+  const uint32_t yne = fe_is_nonzero(d);
+  return 1u - (xne | yne);
+}
+
+}  // namespace kyb

@@ -165,3 +165,78 @@ def eddsa_sign(seed, msg):
 def eddsa_public(seed):
     secret, _ = eddsa_expand(seed)
     return encode(point_mul(secret))
+
+
+# ---- verification (eddsa_sig.rs:159-212 / schnorr_sig.rs:53-110); status codes as in ed25519_oracle.c ----
+def _order8_ys():
+    # y-coordinates of the two order-8 point classes, derived from the group law
+    y = 2
+    while True:
+        pt = decode(y.to_bytes(32, "little"))
+        if pt is not None:
+            q = mul_int(L, pt)
+            if mul_int(4, q) == (0, P - 1):
+                return sorted({q[1], (P - q[1]) % P})
+        y += 1
+
+
+WEAK_Y = None
+
+
+def has_small_order(pt):
+    global WEAK_Y
+    if WEAK_Y is None:
+        WEAK_Y = {0, 1, P - 1, *_order8_ys()}
+    return pt[1] in WEAK_Y
+
+
+def point_is_canonical(b):
+    return (int.from_bytes(b, "little") & ((1 << 255) - 1)) < P
+
+
+def scalar_is_canonical(b):
+    return int.from_bytes(b, "little") < L
+
+
+def verify(flavor, pub, msg, sig):
+    if len(sig) != 64:
+        return 1
+    if flavor == 0:
+        if not scalar_is_canonical(sig[32:]):
+            return 2
+        if not point_is_canonical(sig[:32]):
+            return 3
+        r = decode(sig[:32])
+        if r is None:
+            return 4
+        if has_small_order(r):
+            return 5
+        if not point_is_canonical(pub):
+            return 6
+        a = decode(pub)
+        if a is None:
+            return 7
+        if has_small_order(a):
+            return 8
+    else:
+        r = decode(sig[:32])
+        if r is None:
+            return 4
+        if not point_is_canonical(sig[:32]):
+            return 3
+        if has_small_order(r):
+            return 5
+        if not scalar_is_canonical(sig[32:]):
+            return 2
+        a = decode(pub)
+        if a is None:
+            return 7
+        if not point_is_canonical(pub):
+            return 6
+        if has_small_order(a):
+            return 8
+    renc, aenc = (sig[:32], pub) if flavor == 0 else (encode(r), encode(a))
+    h = int.from_bytes(hashlib.sha512(renc + aenc + msg).digest(), "little") % L
+    lhs = add(r, mul_int(h, a))
+    rhs = point_mul(sig[32:])
+    return 0 if lhs == rhs else 9

@@ -608,14 +608,115 @@ void orc_eddsa_sign(uint8_t sig[64], const uint8_t seed[32], const uint8_t* msg,
   orc_schnorr_sign(sig, secret, r, msg, n);
 }
 
+/* ---- verification ---------------------------------------------------------------------------
+ * status codes (this repo's numbering of the reference's SignatureError variants):
+ *   0 valid, 1 InvalidSignatureLength, 2 SignatureNotCanonical, 3 RNotCanonical, 4 R does not decode
+ *   (MarshallingError), 5 RSmallOrder, 6 PublicKeyNotCanonical, 7 public key does not decode,
+ *   8 PublicKeySmallOrder, 9 InvalidSignature (equation fails) */
+/* scalar.rs:54-75 */
+static int sc_is_canonical(const uint8_t sb[32]) {
+  static const uint8_t Lb[32] = {0xed,0xd3,0xf5,0x5c,0x1a,0x63,0x12,0x58,0xd6,0x9c,0xf7,0xa2,0xde,0xf9,0xde,0x14,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0x10};
+  if ((sb[31] & 0xf0) == 0) return 1;
+  uint8_t c = 0, n = 1;
+  for (int i = 31; i >= 0; i--) {
+    c |= (uint8_t)((((uint16_t)sb[i] - (uint16_t)Lb[i]) >> 8) & n);
+    n &= (uint8_t)((((uint16_t)sb[i] ^ (uint16_t)Lb[i]) - 1) >> 8);
+  }
+  return c != 0;
+}
+/* point.rs:315-337 */
+static int pt_is_canonical(const uint8_t b[32]) {
+  uint8_t c = (uint8_t)((b[31] & 0x7f) ^ 0x7f);
+  for (int i = 30; i >= 1; i--) c |= (uint8_t)(b[i] ^ 0xff);
+  c = (uint8_t)((((uint16_t)c) - 1) >> 8);
+  uint8_t d = (uint8_t)(((uint16_t)(0xEDu - 1u - (uint16_t)b[0])) >> 8);
+  return 1 - (c & d & 1) == 1;
+}
+/* point.rs:286-313 with WEAK_KEYS (constants.rs:3744-3775) regenerated: the encodings of the points of
+ * order 4 (y=0), 1 (y=1), 8 (two values of y) and 2 (y=p-1); the order-8 y are +-sqrt of ... computed
+ * at init from the group law (8-torsion = the points killed by 8) */
+static uint8_t WEAK[5][32];
+static int weak_ready = 0;
+static void weak_init(void) {
+  if (weak_ready) return;
+  memset(WEAK, 0, sizeof(WEAK));
+  WEAK[1][0] = 1;                                      /* y = 1 */
+  memset(WEAK[4], 0xff, 32); WEAK[4][0] = 0xec; WEAK[4][31] = 0x7f;   /* y = p - 1 */
+  /* order-8 points: find T with 4T = (0,-1)... simplest: scan small y for a point P with 8P = O and 4P != O */
+  int found = 0;
+  for (uint32_t y = 2; found < 1; y++) {
+    uint8_t e[32]; memset(e, 0, 32); e[0] = (uint8_t)y; e[1] = (uint8_t)(y >> 8); e[2] = (uint8_t)(y >> 16);
+    ge_p3 P; if (!p3_frombytes(&P, e)) continue;
+    /* Q = L * P has order dividing 8 */
+    uint8_t Lb[32] = {0xed,0xd3,0xf5,0x5c,0x1a,0x63,0x12,0x58,0xd6,0x9c,0xf7,0xa2,0xde,0xf9,0xde,0x14,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0x10};
+    ge_p3 Q; ge_scalarmult(&Q, Lb, &P);
+    uint8_t four[32]; memset(four, 0, 32); four[0] = 4;
+    ge_p3 Q4; ge_scalarmult(&Q4, four, &Q);
+    uint8_t enc4[32]; p3_tobytes(enc4, &Q4);
+    if (memcmp(enc4, WEAK[4], 32) != 0) continue;      /* 4Q == (0,-1)  <=>  Q has order 8 */
+    uint8_t q[32]; p3_tobytes(q, &Q); q[31] &= 0x7f;
+    memcpy(WEAK[2], q, 32);
+    /* the other order-8 y is p - y */
+    fe fy, fny; fe_frombytes(fy, q); fe_neg(fny, fy); fe_tobytes(WEAK[3], fny);
+    if (memcmp(WEAK[2], WEAK[3], 32) > 0) { uint8_t t[32]; memcpy(t, WEAK[2], 32); memcpy(WEAK[2], WEAK[3], 32); memcpy(WEAK[3], t, 32); }
+    found = 1;
+  }
+  weak_ready = 1;
+}
+void orc_weak_keys(uint8_t out[160]) { ensure(); weak_init(); memcpy(out, WEAK, 160); }
+static int pt_has_small_order(const ge_p3* P) {
+  uint8_t s[32]; p3_tobytes(s, P);
+  uint8_t c[5] = {0, 0, 0, 0, 0};
+  for (int j = 0; j < 31; j++) for (int i = 0; i < 5; i++) c[i] |= (uint8_t)(s[j] ^ WEAK[i][j]);
+  for (int i = 0; i < 5; i++) c[i] |= (uint8_t)((s[31] & 0x7f) ^ WEAK[i][31]);
+  uint16_t k = 0;
+  for (int i = 0; i < 5; i++) k |= (uint16_t)((uint16_t)c[i] - 1);
+  return ((k >> 8) & 1) > 0;
+}
+/* flavor 0: eddsa::verify_with_checks (eddsa_sig.rs:159-212); 1: schnorr::verify_with_checks (schnorr_sig.rs:53-110) */
+int orc_verify(int flavor, const uint8_t pub[32], const uint8_t* msg, size_t n, const uint8_t* sig, size_t sig_len) {
+  ensure(); weak_init();
+  if (sig_len != 64) return 1;
+  ge_p3 R, A;
+  if (flavor == 0) {
+    if (!sc_is_canonical(sig + 32)) return 2;
+    if (!pt_is_canonical(sig)) return 3;
+    if (!p3_frombytes(&R, sig)) return 4;
+    if (pt_has_small_order(&R)) return 5;
+    if (!pt_is_canonical(pub)) return 6;
+    if (!p3_frombytes(&A, pub)) return 7;
+    if (pt_has_small_order(&A)) return 8;
+  } else {
+    if (!p3_frombytes(&R, sig)) return 4;
+    if (!pt_is_canonical(sig)) return 3;
+    if (pt_has_small_order(&R)) return 5;
+    if (!sc_is_canonical(sig + 32)) return 2;
+    if (!p3_frombytes(&A, pub)) return 7;
+    if (!pt_is_canonical(pub)) return 6;
+    if (pt_has_small_order(&A)) return 8;
+  }
+  uint8_t dig[64], h[32], Renc[32], Aenc[32];
+  if (flavor == 0) { memcpy(Renc, sig, 32); memcpy(Aenc, pub, 32); }      /* raw bytes, eddsa_sig.rs:194-197 */
+  else { p3_tobytes(Renc, &R); p3_tobytes(Aenc, &A); }                    /* marshal_to of the decoded points, schnorr_sig.rs:128-141 */
+  sha512_t c; sha_init(&c); sha_update(&c, Renc, 32); sha_update(&c, Aenc, 32); sha_update(&c, msg, n); sha_final(&c, dig);
+  orc_sc_reduce64(h, dig);
+  ge_p3 S, hA, RhA; ge_cached cc; ge_p1p1 r;
+  ge_scalarmult_base(&S, sig + 32);
+  ge_scalarmult(&hA, h, &A);
+  p3_to_cached(&cc, &hA); ge_addsub(&r, &R, &cc, 0); p1p1_to_p3(&RhA, &r);
+  uint8_t e1[32], e2[32]; p3_tobytes(e1, &RhA); p3_tobytes(e2, &S);
+  return memcmp(e1, e2, 32) == 0 ? 0 : 9;
+}
+
 /* ---- batches, optionally multi-threaded (CPU baseline: 1 core = the faithful comparison) ---- */
-typedef struct { int kind; size_t lo, hi; const uint8_t* sc; const int32_t* pts; const uint8_t* k; const uint8_t* msgs; const uint32_t* off; uint8_t* out; } job_t;
+typedef struct { int kind; int flavor; size_t lo, hi; const uint8_t* sc; const int32_t* pts; const uint8_t* k; const uint8_t* msgs; const uint32_t* off; uint8_t* out; } job_t;
 static void* worker(void* arg) {
   job_t* j = (job_t*)arg;
   for (size_t i = j->lo; i < j->hi; i++) {
     if (j->kind == 0) orc_mul_base(j->out + 32 * i, NULL, j->sc + 32 * i);
     else if (j->kind == 1) orc_mul(j->out + 32 * i, NULL, j->sc + 32 * i, j->pts + 40 * i);
-    else orc_schnorr_sign(j->out + 64 * i, j->sc + 32 * i, j->k + 32 * i, j->msgs + j->off[i], j->off[i + 1] - j->off[i]);
+    else if (j->kind == 2) orc_schnorr_sign(j->out + 64 * i, j->sc + 32 * i, j->k + 32 * i, j->msgs + j->off[i], j->off[i + 1] - j->off[i]);
+    else j->out[i] = (uint8_t)orc_verify(j->flavor, j->sc + 32 * i, j->msgs + j->off[i], j->off[i + 1] - j->off[i], j->k + 64 * i, 64);
   }
   return NULL;
 }
@@ -640,4 +741,8 @@ void orc_mul_batch(uint8_t* out_enc, const uint8_t* scalars, const int32_t* pts_
 }
 void orc_schnorr_sign_batch(uint8_t* sigs, const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n, int nthreads) {
   job_t j; memset(&j, 0, sizeof(j)); j.kind = 2; j.sc = x; j.k = k; j.msgs = msgs; j.off = off; j.out = sigs; run_batch(j, n, nthreads);
+}
+void orc_verify_batch(uint8_t* status, int flavor, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, const uint8_t* sigs, size_t n, int nthreads) {
+  weak_init();
+  job_t j; memset(&j, 0, sizeof(j)); j.kind = 3; j.flavor = flavor; j.sc = pubs; j.k = sigs; j.msgs = msgs; j.off = off; j.out = status; run_batch(j, n, nthreads);
 }

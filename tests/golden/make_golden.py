@@ -101,6 +101,18 @@ def main():
             bad.append(b.hex())
         y += 1
     out["invalid_encodings"] = bad
+    # negative verification vectors (eddsa_test.rs:142-163 golang malleability vector; :169-173 and :199-203
+    # non-canonical R / pk; :223-227 and :251-255 small-order R / pk)
+    blocks = re.findall(r"\[u8; (?:32|64)\] = \[(.*?)\];", txt, flags=re.S)
+    arrs = [bytes(int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]{2}", b)) for b in blocks]
+    sig2 = [a for a in arrs if len(a) == 64][0]
+    pk2 = [a for a in arrs if len(a) == 32 and a[0] == 0x7d][0]
+    noncanon = [a for a in arrs if len(a) == 32 and a[0] == 0xef][0]
+    small = [a for a in arrs if len(a) == 32 and a[0] == 0xc7][0]
+    assert small.hex() == out["weak_keys"][3]
+    out["verify_negative"] = dict(golang_msg="54657374", golang_sig=sig2.hex(), golang_pk=pk2.hex(),
+                                  non_canonical_point=noncanon.hex(), small_order_point=small.hex())
+    assert orc.verify(0, pk2, bytes.fromhex("54657374"), sig2) == 2 == M.verify(0, pk2, bytes.fromhex("54657374"), sig2)
     with open(os.path.join(HERE, "kats.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", len(q), "quirk_mul,", len(qb), "quirk_mul_base vectors")

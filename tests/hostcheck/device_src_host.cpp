@@ -9,6 +9,7 @@
 #include <cstring>
 #include <vector>
 #include "../../kyber-rs_amd/csrc/schnorr.h"
+#include "../../kyber-rs_amd/csrc/verify.h"
 
 static std::atomic<long> g_overflows{0};
 extern "C" void kyb_host_overflow(const char*) { g_overflows++; }
@@ -144,6 +145,28 @@ void hd_schnorr_sign(uint8_t sig[64], const uint8_t x[32], const uint8_t k[32], 
   tbl_base_words tbl{g_base_table.data()};
   schnorr_sign(s, wx, wk, msg, n, tbl);
   memcpy(sig, s, 64);
+}
+int hd_verify(int flavor, const uint8_t pub[32], const uint8_t* msg, uint32_t n, const uint8_t sig[64]) {
+  ensure_table();
+  uint32_t wp[8], ws[16], h[8];
+  load_words(wp, pub); memcpy(ws, sig, 64);
+  ge_p3 R, A;
+  uint32_t st = verify_prep(h, R, A, wp, ws, msg, n, flavor);
+  // round-trip A through the reference limb layout exactly as the kernels do
+  int32_t a_ext[40];
+  fe_to_ref10(a_ext, A.X); fe_to_ref10(a_ext + 10, A.Y); fe_to_ref10(a_ext + 20, A.Z); fe_to_ref10(a_ext + 30, A.T);
+  ge_p3 A2;
+  fe_from_ref10(A2.X, a_ext); fe_from_ref10(A2.Y, a_ext + 10); fe_from_ref10(A2.Z, a_ext + 20); fe_from_ref10(A2.T, a_ext + 30);
+  tbl_array_cached tv;
+  ge_p2 hA;
+  ge_scalarmult(hA, h, A2, tv);
+  tbl_base_words tb{g_base_table.data()};
+  ge_p3 S;
+  ge_scalarmult_base(S, ws + 8, tb);
+  ge_p2 sB;
+  fe_copy(sB.X, S.X); fe_copy(sB.Y, S.Y); fe_copy(sB.Z, S.Z);
+  uint32_t eq = verify_final(R.X, R.Y, hA, sB);
+  return (int)((st == 0 && !eq) ? 9u : st);
 }
 void hd_recode(int8_t e[64], const uint8_t scalar[32]) {
   uint32_t a[8];

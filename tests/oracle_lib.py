@@ -120,6 +120,15 @@ class Oracle:
         self.lib.orc_eddsa_sign(o, seed, msg, ctypes.c_size_t(len(msg)))
         return o.raw
 
+    def verify(self, flavor: int, pub: bytes, msg: bytes, sig: bytes) -> int:
+        self.lib.orc_verify.restype = ctypes.c_int
+        return int(self.lib.orc_verify(flavor, pub, msg, ctypes.c_size_t(len(msg)), sig, ctypes.c_size_t(len(sig))))
+
+    def weak_keys(self):
+        o = self._b(160)
+        self.lib.orc_weak_keys(o)
+        return [o.raw[32 * i:32 * i + 32] for i in range(5)]
+
     def const_bytes(self, which: int) -> bytes:
         o = self._b(32)
         self.lib.orc_const_bytes(o, which)
@@ -160,3 +169,14 @@ class Oracle:
         sig = np.empty((n, 64), dtype=np.uint8)
         self.lib.orc_schnorr_sign_batch(_p(sig), _p(xs), _p(ks), _p(blob), _p(off), ctypes.c_size_t(n), nthreads)
         return sig
+
+    def verify_batch(self, flavor, pubs, msgs, sigs, nthreads: int = 1) -> np.ndarray:
+        ps = np.ascontiguousarray(pubs, dtype=np.uint8).reshape(-1, 32)
+        ss = np.ascontiguousarray(sigs, dtype=np.uint8).reshape(-1, 64)
+        n = ps.shape[0]
+        off = np.zeros(n + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(m) for m in msgs]).astype(np.uint32)
+        blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()
+        st = np.empty((n,), dtype=np.uint8)
+        self.lib.orc_verify_batch(_p(st), flavor, _p(ps), _p(blob), _p(off), _p(ss), ctypes.c_size_t(n), nthreads)
+        return st

@@ -172,3 +172,45 @@ def test_sign_golden_lines(hd, oracle):
         k = oracle.sc_reduce64(hashlib.sha512(prefix + msg).digest())
         o = B(64); hd.hd_schnorr_sign(o, x, k, msg, len(msg))
         assert o.raw == sig
+
+
+def verify_cases(oracle):
+    """(pub, msg, sig) triples: valid golden signatures, every reject reason, and random corruptions"""
+    lines = gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n")[:24]
+    cases = []
+    neg = KATS["verify_negative"]
+    nonc, small = bytes.fromhex(neg["non_canonical_point"]), bytes.fromhex(neg["small_order_point"])
+    cases.append((bytes.fromhex(neg["golang_pk"]), bytes.fromhex(neg["golang_msg"]), bytes.fromhex(neg["golang_sig"])))
+    rnd = random.Random(9)
+    for ln in lines:
+        p = ln.split(":")
+        pub, msg, sig = bytes.fromhex(p[1]), bytes.fromhex(p[2]), bytes.fromhex(p[3])[:64]
+        cases.append((pub, msg, sig))
+        s_plus_l = ((int.from_bytes(sig[32:], "little") + M.L) % 2**256).to_bytes(32, "little")
+        cases.append((pub, msg, sig[:32] + s_plus_l))                       # malleability: s + L
+        cases.append((pub, msg, nonc + sig[32:]))                           # non-canonical R
+        cases.append((nonc, msg, sig))                                      # non-canonical pk
+        cases.append((pub, msg, small + sig[32:]))                          # small-order R
+        cases.append((small, msg, sig))                                     # small-order pk
+        cases.append((pub, msg + b"x", sig))                                # wrong message
+        bad = bytearray(sig); bad[rnd.randrange(64)] ^= 1 << rnd.randrange(8)
+        cases.append((pub, msg, bytes(bad)))                                # one flipped bit
+        cases.append((bytes.fromhex(KATS["invalid_encodings"][0]), msg, sig))   # pk does not decode
+        cases.append((pub, msg, bytes.fromhex(KATS["invalid_encodings"][1]) + sig[32:]))   # R does not decode
+        cases.append((nonc, msg, nonc + s_plus_l))                          # several failures at once: order matters
+        cases.append((small, msg, small + s_plus_l))
+    return cases
+
+
+def test_verify_matches_oracle_and_model(hd, oracle):
+    base = hd.hd_overflows()
+    seen = set()
+    for i, (pub, msg, sig) in enumerate(verify_cases(oracle)):
+        for flavor in (0, 1):
+            want = oracle.verify(flavor, pub, msg, sig)
+            if i % 7 == 0:
+                assert M.verify(flavor, pub, msg, sig) == want
+            assert hd.hd_verify(flavor, pub, msg, len(msg), sig) == want, (i, flavor, want)
+            seen.add(want)
+    assert seen >= {0, 2, 3, 4, 5, 6, 7, 8, 9}
+    assert hd.hd_overflows() == base

@@ -262,3 +262,45 @@ def test_split_finish_isolates_degenerate_z(engine, oracle):
     good = [i for i in range(n) if i not in (5, 22)]
     assert np.array_equal(a[good], want[good])
     assert np.array_equal(a[[5, 22]], want[[5, 22]])     # reference: 0^(p-2) = 0 -> all-zero encoding
+
+
+def test_verify_matches_oracle(engine, oracle):
+    """kyb_verify_batch: every status code of eddsa::/schnorr::verify_with_checks, both check orders,
+    on golden signatures, the reference's negative vectors and corrupted inputs"""
+    from test_device_source_on_host import verify_cases
+    cases = verify_cases(oracle)
+    pubs = np.frombuffer(b"".join(c[0] for c in cases), dtype=np.uint8)
+    sigs = np.frombuffer(b"".join(c[2] for c in cases), dtype=np.uint8)
+    msgs = [c[1] for c in cases]
+    for flavor in (0, 1):
+        got = engine.verify(pubs, msgs, sigs, flavor)
+        want = np.array([oracle.verify(flavor, *c) for c in cases], dtype=np.uint8)
+        assert np.array_equal(got, want)
+        assert set(want.tolist()) >= {0, 2, 3, 4, 5, 6, 7, 8, 9}
+    # all 1024 golden signatures verify; their messages are 0..1023 bytes long
+    ps, ms, ss = [], [], []
+    for ln in gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n"):
+        if ln:
+            p = ln.split(":")
+            ps.append(bytes.fromhex(p[1])); ms.append(bytes.fromhex(p[2])); ss.append(bytes.fromhex(p[3])[:64])
+    st = engine.verify(np.frombuffer(b"".join(ps), dtype=np.uint8), ms, np.frombuffer(b"".join(ss), dtype=np.uint8), 0)
+    assert not st.any()
+
+
+def test_sign_then_verify_round_trip_2_16(engine, oracle):
+    """size-independent property at a large size: every GPU signature verifies on the GPU; flipping one
+    bit of each makes every one fail"""
+    n = 1 << 16
+    rng = np.random.default_rng(77)
+    x = rng.integers(0, 256, (n, 32), dtype=np.uint8); x[:, 31] &= 0x0F
+    k = rng.integers(0, 256, (n, 32), dtype=np.uint8); k[:, 31] &= 0x0F
+    msgs = synth.messages(n, 77)
+    sig = engine.schnorr_sign(x, k, msgs)
+    pub = engine.mul_base(x)
+    assert not engine.verify(pub, msgs, sig, 1).any()
+    bad = sig.copy()
+    bad[np.arange(n), rng.integers(32, 63, n)] ^= 1        # corrupt s (below the top byte: stays < L mostly)
+    st = engine.verify(pub, msgs, bad, 1)
+    assert (st != 0).all()
+    idx = rng.choice(n, 64, replace=False)
+    assert [oracle.verify(1, bytes(pub[i]), msgs[i], bytes(bad[i])) for i in idx] == st[idx].tolist()

@@ -151,3 +151,29 @@ def test_sha512(oracle):
     for n in [0, 1, 55, 111, 112, 113, 127, 128, 129, 239, 240, 241, 1000]:
         m = bytes(rnd.getrandbits(8) for _ in range(n))
         assert oracle.sha512(m) == hashlib.sha512(m).digest()
+
+
+def test_verify_golden_and_negative_vectors(oracle):
+    """eddsa_test.rs:51-107 (verify after sign), :110-272 (malleability, non-canonical R / pk, small-order R / pk)"""
+    neg = KATS["verify_negative"]
+    msg2, sig2, pk2 = (bytes.fromhex(neg[k]) for k in ("golang_msg", "golang_sig", "golang_pk"))
+    nonc, small = bytes.fromhex(neg["non_canonical_point"]), bytes.fromhex(neg["small_order_point"])
+    assert oracle.verify(0, pk2, msg2, sig2) == 2                      # "signature is not canonical"
+    assert oracle.weak_keys() == [bytes.fromhex(h) for h in KATS["weak_keys"]]   # regenerated from the group law
+    for i, (seed, pub, msg, sig) in enumerate(golden_lines()):
+        if i % 8:
+            continue
+        for flavor in (0, 1):
+            assert oracle.verify(flavor, pub, msg, sig) == 0
+        s_plus_l = ((int.from_bytes(sig[32:], "little") + M.L) % 2**256).to_bytes(32, "little")
+        assert oracle.verify(0, pub, msg, sig[:32] + s_plus_l) == 2    # eddsa_test.rs:127-137
+        assert oracle.verify(0, pub, msg, nonc + sig[32:]) == 3        # "R is not canonical"
+        assert oracle.verify(0, nonc, msg, sig) == 6                   # "public key is not canonical"
+        assert oracle.verify(0, pub, msg, small + sig[32:]) == 5       # "R has small order"
+        assert oracle.verify(0, small, msg, sig) == 8                  # "public key has small order"
+        assert oracle.verify(0, pub, msg + b"!", sig) == 9
+        assert oracle.verify(0, pub, msg, sig[:63]) == 1
+        if i % 64 == 0:
+            for flavor in (0, 1):
+                for p_, m_, s_ in ((pub, msg, sig), (nonc, msg, nonc + s_plus_l), (small, msg, small + sig[32:]), (pub, msg + b"!", sig)):
+                    assert M.verify(flavor, p_, m_, s_) == oracle.verify(flavor, p_, m_, s_)
