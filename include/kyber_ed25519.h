@@ -116,6 +116,23 @@ int kyb_verify_batch(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* m
 int kyb_verify_batch_dev(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* msg_off, const uint8_t* sigs,
                          size_t n, int flavor, uint8_t* status, void* stream);
 
+/* ---- PubPoly::eval / shares, poly.rs:457-478 ------------------------------- */
+/* One public polynomial (t commitments, extended limbs) evaluated at n share indices:
+ * out[i] = sum_j commits[j] * (indices[i] + 1)^j, exactly what eval(indices[i]) returns.  The share
+ * index is public, so the small scalar x = index + 1 is handled by a short binary ladder instead of the
+ * reference's 64-window multiplication; the resulting point (hence its encoding) is the same.
+ * max_index (dev flavour) = an upper bound of indices[], it sets the ladder length. */
+int kyb_pubpoly_eval_batch(const int32_t* commits_ext, size_t t, const uint32_t* indices, size_t n,
+                           uint8_t* out_enc, int32_t* out_ext);
+int kyb_pubpoly_eval_batch_dev(const int32_t* commits_ext, size_t t, const uint32_t* indices, size_t n, uint32_t max_index,
+                               uint8_t* out_enc, int32_t* out_ext, void* stream);
+
+/* ---- Point::eq, point.rs:227-241 -------------------------------------------- */
+/* eq[i] = 1 iff a[i] and b[i] are the same point (the reference compares the two encodings = two
+ * inversions; here a projective cross-multiplication).  Inputs must be curve points (Z != 0). */
+int kyb_equal_batch(const int32_t* a_ext, const int32_t* b_ext, size_t n, uint8_t* eq);
+int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, uint8_t* eq, void* stream);
+
 /* ---- introspection for benchmarks / tests ------------------------------------------------------ */
 /* kernel variant selection: key is e.g. "mul.select" / "mul_base.select"; returns
  * KYB_E_BAD_ARG for unknown keys or values.  Defaults are the fastest measured variants.

@@ -32,7 +32,8 @@ ABI_SYMBOLS = [
     "kyb_mul_base_batch", "kyb_mul_base_batch_dev", "kyb_mul_batch", "kyb_mul_batch_dev",
     "kyb_add_batch", "kyb_add_batch_dev", "kyb_encode_batch", "kyb_encode_batch_dev",
     "kyb_decode_batch", "kyb_decode_batch_dev", "kyb_schnorr_sign_batch", "kyb_schnorr_sign_batch_dev",
-    "kyb_verify_batch", "kyb_verify_batch_dev",
+    "kyb_verify_batch", "kyb_verify_batch_dev", "kyb_pubpoly_eval_batch", "kyb_pubpoly_eval_batch_dev",
+    "kyb_equal_batch", "kyb_equal_batch_dev",
     "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
 ]
 
@@ -85,6 +86,10 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_schnorr_sign_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     lib.kyb_verify_batch.argtypes = [vp, vp, vp, vp, sz, i32, vp]
     lib.kyb_verify_batch_dev.argtypes = [vp, vp, vp, vp, sz, i32, vp, vp]
+    lib.kyb_pubpoly_eval_batch.argtypes = [vp, sz, vp, sz, vp, vp]
+    lib.kyb_pubpoly_eval_batch_dev.argtypes = [vp, sz, vp, sz, ctypes.c_uint32, vp, vp, vp]
+    lib.kyb_equal_batch.argtypes = [vp, vp, sz, vp]
+    lib.kyb_equal_batch_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.kyb_set_option.argtypes = [ctypes.c_char_p, i32]
     lib.kyb_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32)]
     lib.kyb_profile_begin.argtypes = [i32]
@@ -224,6 +229,23 @@ class Engine:
     def verify_dev(self, pubs, msgs, msg_off, sigs, status, flavor: int = 0, stream: int = 0) -> None:
         n = pubs.numel() // 32
         _check(self.lib.kyb_verify_batch_dev(self._dp(pubs), self._dp(msgs), self._dp(msg_off), self._dp(sigs), n, flavor, self._dp(status), ctypes.c_void_p(stream)), "kyb_verify_batch_dev")
+
+    def pubpoly_eval(self, commits_ext, indices, want_ext: bool = False):
+        """PubPoly::eval of one polynomial (t x 40 limbs) at every index of `indices` (x = index + 1)"""
+        c = np.ascontiguousarray(commits_ext, dtype=np.int32).reshape(-1, 40)
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        n = idx.shape[0]
+        enc = np.empty((n, 32), dtype=np.uint8)
+        ext = np.empty((n, 40), dtype=np.int32) if want_ext else None
+        _check(self.lib.kyb_pubpoly_eval_batch(_ptr(c), c.shape[0], _ptr(idx), n, _ptr(enc), _ptr(ext)), "kyb_pubpoly_eval_batch")
+        return (enc, ext) if want_ext else enc
+
+    def equal(self, a_ext, b_ext) -> np.ndarray:
+        a = np.ascontiguousarray(a_ext, dtype=np.int32).reshape(-1, 40)
+        b = np.ascontiguousarray(b_ext, dtype=np.int32).reshape(-1, 40)
+        eq = np.empty((a.shape[0],), dtype=np.uint8)
+        _check(self.lib.kyb_equal_batch(_ptr(a), _ptr(b), a.shape[0], _ptr(eq)), "kyb_equal_batch")
+        return eq
 
     def base_table(self) -> np.ndarray:
         t = np.empty(BASE_TABLE_BYTES, dtype=np.uint8)

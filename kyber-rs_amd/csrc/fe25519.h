@@ -64,15 +64,15 @@ static inline uint32_t kyb_add32(uint32_t a, uint32_t b, const char* what) {
   return (uint32_t)w;
 }
 #else
-// The empty asm makes each partial sum opaque, so LLVM cannot reassociate a column into
-// "products first, carry last": it then has to feed the running 64-bit value (carry of the previous
-// column included) as the addend of the next v_mad_u64_u32, and the separate v_lshl_add_u64 per
-// column disappears (-10 half-rate instructions per fe_mul / fe_sq).  A wave cannot issue
-// v_mad_u64_u32 faster than one per ~9.5 cycles even on independent chains
-// (profiles/r01_valu_rates_mi355x.jsonl, w1 row), so the serial chain costs nothing.
+// LLVM reassociates each column into "products first, carry last", which costs one v_lshl_add_u64 per
+// column on top of the mads.  -DKYB_CHAIN_BARRIER makes every partial sum opaque (empty asm) so the
+// carry becomes the addend of the column's first v_mad_u64_u32 and those adds disappear — but hipcc
+// then pads every asm boundary that feeds the next VALU with an s_nop, and the A/B on MI355X
+// (profiles/r01/ab_chain_barrier.log) came out 2-3 % SLOWER for k_mul and equal for k_mul_base, so it
+// is off by default.
 KYB_HD uint64_t kyb_mad(uint32_t a, uint32_t b, uint64_t c) {
   uint64_t r = (uint64_t)a * b + c;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(KYB_NO_CHAIN_BARRIER)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(KYB_CHAIN_BARRIER)
   asm("" : "+v"(r));
 #endif
   return r;
@@ -83,10 +83,11 @@ KYB_HD uint32_t kyb_add32(uint32_t a, uint32_t b, const char*) { return a + b; }
 #endif
 
 KYB_HD uint32_t kyb_x19(uint32_t a) { return kyb_mul32(a, 19u, "x19"); }
-// 2*a as v_add_u32 (full rate) instead of the v_lshlrev_b32 LLVM canonicalises x+x into (half rate
-// on gfx950, profiles/r01_valu_rates2_mi355x.jsonl): hide one operand behind an empty asm
+// 2*a: LLVM canonicalises x+x into v_lshlrev_b32 (half rate on gfx950,
+// profiles/r01_valu_rates2_mi355x.jsonl).  -DKYB_X2_ADD hides one operand behind an empty asm to get a
+// full-rate v_add_u32; same A/B as above: no measurable gain (the asm pad eats it), off by default.
 KYB_HD uint32_t kyb_x2(uint32_t a, const char* what) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(KYB_NO_X2_ADD)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(KYB_X2_ADD)
   uint32_t t = a;
   asm("" : "+v"(t));
   return a + t;

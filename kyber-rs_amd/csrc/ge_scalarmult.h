@@ -102,6 +102,66 @@ KYB_HD void ge_scalarmult_base(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
   }
 }
 
+// Multiplication by a SMALL PUBLIC scalar x < 2^nbits (PubPoly::eval's x_i = i + 1, poly.rs:457-469:
+// the share index is public, so neither the bit length nor the operation count needs hiding; lanes
+// still run the same nbits steps and merge the conditional addition under a mask because the bits
+// differ between lanes of a wave).  Left-to-right binary: nbits x (double + masked add).
+// The reference routes this through the full 64-window ge_scalar_mult (point.rs:214-220).
+KYB_HD void ge_small_mul(ge_p3& out, const ge_p3& in, uint32_t x, int nbits) {
+  ge_cached cin;
+  ge_p3_to_cached(cin, in);
+  ge_p3 acc;
+  ge_p3_0(acc);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int b = nbits - 1; b >= 0; --b) {
+    ge_p1p1 t;
+    ge_p3 d, a;
+    ge_p2_dbl(t, acc.X, acc.Y, acc.Z);
+    ge_p1p1_to_p3(d, t);
+    ge_add(t, d, cin);
+    ge_p1p1_to_p3(a, t);
+    const uint32_t bit = (x >> b) & 1u;
+    fe_select(acc.X, d.X, a.X, bit); fe_select(acc.Y, d.Y, a.Y, bit);
+    fe_select(acc.Z, d.Z, a.Z, bit); fe_select(acc.T, d.T, a.T, bit);
+  }
+  out = acc;
+}
+
+// PubPoly::eval (poly.rs:457-469): v = sum_j commit_j * x^j by Horner, x = index + 1.
+// `load_commit(j, P)` supplies commitment j as an extended point.
+template <class LoadCommit>
+KYB_HD void ge_poly_eval(ge_p2& out, LoadCommit load_commit, int t, uint32_t x, int nbits) {
+  ge_p3 v;
+  ge_p3_0(v);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int j = t - 1; j >= 0; --j) {
+    ge_p3 m, c;
+    ge_small_mul(m, v, x, nbits);
+    load_commit(j, c);
+    ge_cached cc;
+    ge_p3_to_cached(cc, c);
+    ge_p1p1 r;
+    ge_add(r, m, cc);
+    ge_p1p1_to_p3(v, r);
+  }
+  fe_copy(out.X, v.X); fe_copy(out.Y, v.Y); fe_copy(out.Z, v.Z);
+}
+
+// Point equality without inversions (the reference's eq encodes both sides, point.rs:227-241):
+// X1 Z2 == X2 Z1 and Y1 Z2 == Y2 Z1.  Valid curve points only (Z != 0).
+KYB_HD uint32_t ge_equal(const ge_p3& a, const ge_p3& b) {
+  fe l, r, d;
+  fe_mul(l, a.X, b.Z); fe_mul(r, b.X, a.Z); fe_sub(d, l, r);
+  const uint32_t xne = fe_is_nonzero(d);
+  fe_mul(l, a.Y, b.Z); fe_mul(r, b.Y, a.Z); fe_sub(d, l, r);
+  const uint32_t yne = fe_is_nonzero(d);
+  return 1u - (xne | yne);
+}
+
 // --- plain-array policies (host-test build, and the one-off device table generator) ---
 struct tbl_array_cached {
   ge_cached e[8];

@@ -430,6 +430,31 @@ k_verify_final(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t*
   status[i] = (st == 0 && !eq) ? (uint8_t)9 : st;
 }
 
+// PubPoly::eval for one polynomial at n share indices (poly.rs:457-469, shares :472-478)
+template <bool SPLIT>
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_poly_eval(const int32_t* __restrict__ commits_ext, int t, const uint32_t* __restrict__ indices, size_t n, int nbits,
+            uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, uint4* __restrict__ proj, size_t stride) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  const bool live = i < n;
+  const size_t ii = live ? i : 0;
+  const uint32_t x = indices[ii] + 1u;
+  ge_p2 r;
+  ge_poly_eval(r, [&](int j, ge_p3& c) { load_ext(c, commits_ext, (size_t)j); }, t, x, nbits);
+  if (SPLIT) { if (live) store_proj(proj, stride, i, r.X, r.Y, r.Z); }
+  else finish_point(r.X, r.Y, r.Z, out_enc, out_ext, ii, live);
+}
+// batched Point::eq (point.rs:227-241) without inversions
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_equal(const int32_t* __restrict__ a_ext, const int32_t* __restrict__ b_ext, size_t n, uint8_t* __restrict__ eq_out) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  ge_p3 A, B;
+  load_ext(A, a_ext, i);
+  load_ext(B, b_ext, i);
+  eq_out[i] = (uint8_t)ge_equal(A, B);
+}
+
 __global__ void __launch_bounds__(KYB_BLOCK)
 k_add(const int32_t* __restrict__ a_ext, const int32_t* __restrict__ b_ext, size_t n, int32_t* __restrict__ out_ext, int subtract) {
   const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
@@ -477,8 +502,8 @@ namespace {
 thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
-enum KernelId { KID_MUL = 0, KID_MUL_BASE = 1, KID_FINISH = 2, KID_SIGN = 3, KID_SIGN_HASH = 4, KID_VERIFY_PREP = 5, KID_VERIFY_FINAL = 6, KID_COUNT = 7 };
-const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final"};
+enum KernelId { KID_MUL = 0, KID_MUL_BASE = 1, KID_FINISH = 2, KID_SIGN = 3, KID_SIGN_HASH = 4, KID_VERIFY_PREP = 5, KID_VERIFY_FINAL = 6, KID_POLY_EVAL = 7, KID_COUNT = 8 };
+const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   bool on = false;
@@ -743,6 +768,25 @@ int launch_verify(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off,
     hipLaunchKernelGGL(k_verify_final, dim3(blocks), dim3(KYB_BLOCK), 0, st, r->proj, r->proj_items, n, status);
   }
   HIPCK(hipGetLastError());
+  return KYB_OK;
+}
+
+int launch_poly_eval(const int32_t* commits, size_t t, const uint32_t* idx, size_t n, uint32_t max_index, uint8_t* oenc, int32_t* oext, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  Ctx::StreamRes* r = nullptr;
+  { int rc = res_for(st, &r); if (rc) return rc; }
+  int nbits = 1;
+  while (nbits < 32 && ((uint64_t)max_index + 1) >> nbits) ++nbits;      // bit length of max x = max_index + 1
+  const unsigned blocks = (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK);
+  const bool split = use_split(n);
+  if (split) { int rc = ensure_proj(r, n); if (rc) return rc; }
+  {
+    ProfScope ps(st, KID_POLY_EVAL);
+    if (split) hipLaunchKernelGGL((k_poly_eval<true>), dim3(blocks), dim3(KYB_BLOCK), 0, st, commits, (int)t, idx, n, nbits, oenc, oext, r->proj, r->proj_items);
+    else       hipLaunchKernelGGL((k_poly_eval<false>), dim3(blocks), dim3(KYB_BLOCK), 0, st, commits, (int)t, idx, n, nbits, oenc, oext, r->proj, r->proj_items);
+  }
+  HIPCK(hipGetLastError());
+  if (split) return launch_finish(r, n, oenc, oext, st);
   return KYB_OK;
 }
 
@@ -1011,6 +1055,67 @@ int kyb_verify_batch(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* m
   rc = launch_verify(d + o_p, d + o_m, reinterpret_cast<const uint32_t*>(d + o_off), d + o_s, n, flavor, d + o_st, g.stream);
   if (rc) return rc;
   HIPCK(hipMemcpyAsync(status, d + o_st, n, hipMemcpyDeviceToHost, g.stream));
+  HIPCK(hipStreamSynchronize(g.stream));
+  return KYB_OK;
+}
+
+int kyb_pubpoly_eval_batch_dev(const int32_t* commits_ext, size_t t, const uint32_t* indices, size_t n, uint32_t max_index,
+                               uint8_t* out_enc, int32_t* out_ext, void* stream) {
+  REQUIRE_READY();
+  if (n == 0) return KYB_OK;
+  if (!commits_ext || !indices || (!out_enc && !out_ext) || t == 0 || t > (1u << 20)) return fail(KYB_E_BAD_ARG, "bad argument");
+  if (max_index == 0xffffffffu) return fail(KYB_E_BAD_ARG, "index + 1 must fit 32 bits");
+  if (!aligned16(commits_ext) || !aligned16(out_enc) || !aligned16(out_ext)) return fail(KYB_E_BAD_ARG, "device buffers must be 16-byte aligned");
+  return launch_poly_eval(commits_ext, t, indices, n, max_index, out_enc, out_ext, pick(stream));
+}
+int kyb_pubpoly_eval_batch(const int32_t* commits_ext, size_t t, const uint32_t* indices, size_t n, uint8_t* out_enc, int32_t* out_ext) {
+  REQUIRE_READY();
+  if (n == 0) return KYB_OK;
+  if (!commits_ext || !indices || (!out_enc && !out_ext) || t == 0 || t > (1u << 20)) return fail(KYB_E_BAD_ARG, "bad argument");
+  uint32_t mx = 0;
+  for (size_t i = 0; i < n; ++i) mx = indices[i] > mx ? indices[i] : mx;
+  if (mx == 0xffffffffu) return fail(KYB_E_BAD_ARG, "index + 1 must fit 32 bits");
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCK(hipSetDevice(g.device));
+  const size_t o_c = 0, o_i = up256(160 * t), o_e = o_i + up256(4 * n), o_x = o_e + up256(32 * n), total = o_x + up256(160 * n);
+  int rc = ensure_stage(total);
+  if (rc) return rc;
+  uint8_t* d = g.stage;
+  HIPCK(hipMemcpyAsync(d + o_c, commits_ext, 160 * t, hipMemcpyHostToDevice, g.stream));
+  HIPCK(hipMemcpyAsync(d + o_i, indices, 4 * n, hipMemcpyHostToDevice, g.stream));
+  rc = launch_poly_eval(reinterpret_cast<const int32_t*>(d + o_c), t, reinterpret_cast<const uint32_t*>(d + o_i), n, mx,
+                        out_enc ? d + o_e : nullptr, out_ext ? reinterpret_cast<int32_t*>(d + o_x) : nullptr, g.stream);
+  if (rc) return rc;
+  if (out_enc) HIPCK(hipMemcpyAsync(out_enc, d + o_e, 32 * n, hipMemcpyDeviceToHost, g.stream));
+  if (out_ext) HIPCK(hipMemcpyAsync(out_ext, d + o_x, 160 * n, hipMemcpyDeviceToHost, g.stream));
+  HIPCK(hipStreamSynchronize(g.stream));
+  return KYB_OK;
+}
+int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, uint8_t* eq, void* stream) {
+  REQUIRE_READY();
+  if (n == 0) return KYB_OK;
+  if (!a_ext || !b_ext || !eq) return fail(KYB_E_BAD_ARG, "null buffer");
+  if (!aligned16(a_ext) || !aligned16(b_ext)) return fail(KYB_E_BAD_ARG, "device buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(k_equal, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, pick(stream), a_ext, b_ext, n, eq);
+  HIPCK(hipGetLastError());
+  return KYB_OK;
+}
+int kyb_equal_batch(const int32_t* a_ext, const int32_t* b_ext, size_t n, uint8_t* eq) {
+  REQUIRE_READY();
+  if (n == 0) return KYB_OK;
+  if (!a_ext || !b_ext || !eq) return fail(KYB_E_BAD_ARG, "null buffer");
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCK(hipSetDevice(g.device));
+  const size_t o_a = 0, o_b = up256(160 * n), o_e = 2 * up256(160 * n), total = o_e + up256(n);
+  int rc = ensure_stage(total);
+  if (rc) return rc;
+  uint8_t* d = g.stage;
+  HIPCK(hipMemcpyAsync(d + o_a, a_ext, 160 * n, hipMemcpyHostToDevice, g.stream));
+  HIPCK(hipMemcpyAsync(d + o_b, b_ext, 160 * n, hipMemcpyHostToDevice, g.stream));
+  hipLaunchKernelGGL(k_equal, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, g.stream,
+                     reinterpret_cast<const int32_t*>(d + o_a), reinterpret_cast<const int32_t*>(d + o_b), n, d + o_e);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(eq, d + o_e, n, hipMemcpyDeviceToHost, g.stream));
   HIPCK(hipStreamSynchronize(g.stream));
   return KYB_OK;
 }

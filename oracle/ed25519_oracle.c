@@ -608,6 +608,22 @@ void orc_eddsa_sign(uint8_t sig[64], const uint8_t seed[32], const uint8_t* msg,
   orc_schnorr_sign(sig, secret, r, msg, n);
 }
 
+/* PubPoly::eval (share/poly.rs:457-469): xi = set_int64(1 + i); v = null; for j = t-1..0: v = v.mul(xi, Some(v)); v = v.add(v, commits[j]) */
+void orc_pubpoly_eval(uint8_t out_enc[32], const int32_t* commits_ext, size_t t, uint32_t index) {
+  ensure();
+  uint8_t xi[32]; memset(xi, 0, 32);
+  uint64_t x = (uint64_t)index + 1;
+  for (int b = 0; b < 8; b++) xi[b] = (uint8_t)(x >> (8 * b));
+  ge_p3 v, m, c; ge_cached cc; ge_p1p1 r;
+  p3_0(&v);
+  for (size_t j = t; j-- > 0;) {
+    ge_scalarmult(&m, xi, &v);
+    ext_in(&c, commits_ext + 40 * j);
+    p3_to_cached(&cc, &c); ge_addsub(&r, &m, &cc, 0); p1p1_to_p3(&v, &r);
+  }
+  p3_tobytes(out_enc, &v);
+}
+
 /* ---- verification ---------------------------------------------------------------------------
  * status codes (this repo's numbering of the reference's SignatureError variants):
  *   0 valid, 1 InvalidSignatureLength, 2 SignatureNotCanonical, 3 RNotCanonical, 4 R does not decode

@@ -168,6 +168,22 @@ int hd_verify(int flavor, const uint8_t pub[32], const uint8_t* msg, uint32_t n,
   uint32_t eq = verify_final(R.X, R.Y, hA, sB);
   return (int)((st == 0 && !eq) ? 9u : st);
 }
+void hd_pubpoly_eval(uint8_t out[32], const int32_t* commits, int t, uint32_t index, int nbits) {
+  ge_p2 r;
+  ge_poly_eval(r, [&](int j, ge_p3& c) {
+    const int32_t* p = commits + 40 * j;
+    fe_from_ref10(c.X, p); fe_from_ref10(c.Y, p + 10); fe_from_ref10(c.Z, p + 20); fe_from_ref10(c.T, p + 30);
+  }, t, index + 1u, nbits);
+  uint32_t w[8];
+  ge_encode(w, r.X, r.Y, r.Z);
+  memcpy(out, w, 32);
+}
+int hd_equal(const int32_t a[40], const int32_t b[40]) {
+  ge_p3 A, B;
+  fe_from_ref10(A.X, a); fe_from_ref10(A.Y, a + 10); fe_from_ref10(A.Z, a + 20); fe_from_ref10(A.T, a + 30);
+  fe_from_ref10(B.X, b); fe_from_ref10(B.Y, b + 10); fe_from_ref10(B.Z, b + 20); fe_from_ref10(B.T, b + 30);
+  return (int)ge_equal(A, B);
+}
 void hd_recode(int8_t e[64], const uint8_t scalar[32]) {
   uint32_t a[8];
   load_words(a, scalar);

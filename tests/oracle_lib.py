@@ -180,3 +180,9 @@ class Oracle:
         st = np.empty((n,), dtype=np.uint8)
         self.lib.orc_verify_batch(_p(st), flavor, _p(ps), _p(blob), _p(off), _p(ss), ctypes.c_size_t(n), nthreads)
         return st
+
+    def pubpoly_eval(self, commits_ext, index: int) -> bytes:
+        c = _i32(commits_ext).reshape(-1, 40)
+        o = self._b(32)
+        self.lib.orc_pubpoly_eval(o, _p(c), ctypes.c_size_t(c.shape[0]), ctypes.c_uint32(index))
+        return o.raw

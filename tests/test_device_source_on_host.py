@@ -197,6 +197,9 @@ def verify_cases(oracle):
         cases.append((pub, msg, bytes(bad)))                                # one flipped bit
         cases.append((bytes.fromhex(KATS["invalid_encodings"][0]), msg, sig))   # pk does not decode
         cases.append((pub, msg, bytes.fromhex(KATS["invalid_encodings"][1]) + sig[32:]))   # R does not decode
+        nc1 = (M.P + 1).to_bytes(32, "little")                              # y = p + 1: decodes (to the neutral element) but is not canonical
+        cases.append((pub, msg, nc1 + sig[32:]))
+        cases.append((nc1, msg, sig))
         cases.append((nonc, msg, nonc + s_plus_l))                          # several failures at once: order matters
         cases.append((small, msg, small + s_plus_l))
     return cases
@@ -204,13 +207,32 @@ def verify_cases(oracle):
 
 def test_verify_matches_oracle_and_model(hd, oracle):
     base = hd.hd_overflows()
-    seen = set()
+    seen = {0: set(), 1: set()}
     for i, (pub, msg, sig) in enumerate(verify_cases(oracle)):
         for flavor in (0, 1):
             want = oracle.verify(flavor, pub, msg, sig)
             if i % 7 == 0:
                 assert M.verify(flavor, pub, msg, sig) == want
             assert hd.hd_verify(flavor, pub, msg, len(msg), sig) == want, (i, flavor, want)
-            seen.add(want)
-    assert seen >= {0, 2, 3, 4, 5, 6, 7, 8, 9}
+            seen[flavor].add(want)
+    assert seen[0] >= {0, 2, 3, 4, 5, 6, 7, 8, 9} and seen[1] >= {0, 2, 3, 4, 5, 6, 7, 8, 9}
+    assert hd.hd_overflows() == base
+
+
+def test_pubpoly_eval_and_equal(hd, oracle):
+    """short-ladder Horner == the reference's eval (64-window mult by x = i + 1, then add), poly.rs:457-469"""
+    base = hd.hd_overflows()
+    rnd = random.Random(12)
+    for t in (1, 2, 5):
+        commits = np.stack([oracle.mul_base_ext(bytes(rnd.getrandbits(8) for _ in range(32))) for _ in range(t)])
+        for idx in (0, 1, 2, 6, 255, 256, 65534, 2**32 - 2):
+            nbits = (idx + 1).bit_length()
+            for nb in {nbits, min(32, nbits + 3)}:
+                o = B(32)
+                hd.hd_pubpoly_eval(o, p32(commits), t, ctypes.c_uint32(idx), nb)
+                assert o.raw == oracle.pubpoly_eval(commits, idx), (t, idx, nb)
+    a = oracle.mul_base_ext((5).to_bytes(32, "little"))
+    b = oracle.add(oracle.mul_base_ext((2).to_bytes(32, "little")), oracle.mul_base_ext((3).to_bytes(32, "little")))   # same point, other Z
+    c = oracle.mul_base_ext((6).to_bytes(32, "little"))
+    assert hd.hd_equal(p32(a), p32(b)) == 1 and hd.hd_equal(p32(a), p32(c)) == 0 and hd.hd_equal(p32(a), p32(oracle.neg(a))) == 0
     assert hd.hd_overflows() == base

@@ -276,7 +276,7 @@ def test_verify_matches_oracle(engine, oracle):
         got = engine.verify(pubs, msgs, sigs, flavor)
         want = np.array([oracle.verify(flavor, *c) for c in cases], dtype=np.uint8)
         assert np.array_equal(got, want)
-        assert set(want.tolist()) >= {0, 2, 3, 4, 5, 6, 7, 8, 9}
+        assert set(want.tolist()) >= {0, 2, 3, 4, 5, 6, 7, 8, 9}      # every reject reason is exercised
     # all 1024 golden signatures verify; their messages are 0..1023 bytes long
     ps, ms, ss = [], [], []
     for ln in gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n"):
@@ -304,3 +304,27 @@ def test_sign_then_verify_round_trip_2_16(engine, oracle):
     assert (st != 0).all()
     idx = rng.choice(n, 64, replace=False)
     assert [oracle.verify(1, bytes(pub[i]), msgs[i], bytes(bad[i])) for i in idx] == st[idx].tolist()
+
+
+def test_pubpoly_eval_and_equal(engine, oracle):
+    """kyb_pubpoly_eval_batch == PubPoly::eval (poly.rs:457-469) for every index; kyb_equal_batch == Point::eq"""
+    rng = np.random.default_rng(50)
+    t = 7
+    commits = oracle.mul_base_ext_batch(synth.scalars(t, 50))
+    idx = np.concatenate([np.arange(0, 300), rng.integers(0, 2**32 - 2, 40), [2**32 - 2]]).astype(np.uint32)
+    enc, ext = engine.pubpoly_eval(commits, idx, want_ext=True)
+    sample = list(range(0, 300, 13)) + list(range(300, len(idx)))
+    for i in sample:
+        assert bytes(enc[i]) == oracle.pubpoly_eval(commits, int(idx[i])), int(idx[i])
+        assert oracle.encode(ext[i]) == bytes(enc[i])
+    # Point::eq on different projective representatives of equal / unequal points
+    a = oracle.mul_base_ext_batch(synth.scalars(200, 51))
+    b = np.stack([oracle.add(oracle.add(p, q), q, sub=True) for p, q in zip(a, np.roll(a, 1, axis=0))])   # (p + q) - q == p, other limbs
+    eq = engine.equal(a, b)
+    assert eq.all()
+    assert not engine.equal(a, np.roll(a, 1, axis=0)).any()
+    # check (poly.rs:526-530): eval(i) == s_i * B for the matching private polynomial
+    coeffs = [int.from_bytes(bytes(c), "little") for c in synth.scalars(t, 50)]
+    shares = [sum(c * pow(int(i) + 1, j, synth.L) for j, c in enumerate(coeffs)) % synth.L for i in idx[:64]]
+    want = engine.mul_base(np.frombuffer(b"".join(s.to_bytes(32, "little") for s in shares), dtype=np.uint8))
+    assert np.array_equal(enc[:64], want)
