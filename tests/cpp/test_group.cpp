@@ -10,6 +10,8 @@
 #include <vector>
 
 #include "../../kyber-rs_amd/host/edwards25519.hpp"
+#include "../../kyber-rs_amd/host/poly.hpp"
+#include "../../kyber-rs_amd/host/schnorr.hpp"
 
 using namespace kyber;
 using namespace kyber::group::edwards25519;
@@ -194,6 +196,52 @@ int main() {
       CHECK(rb[i] == Point().mul(ss[i], &pp[i]), "mul_batch == mul");
       CHECK(rf[i] == Point().mul(ss[i], nullptr), "mul_batch(base) == mul(None)");
     }
+  }
+
+  // Schnorr sign / verify through the mirror (schnorr_test.rs:15-82): round trip, wrong message, tampering
+  {
+    using namespace kyber::sign;
+    Scalar x = Scalar().pick(rand);
+    Point X = Point().mul(x, nullptr);
+    const uint8_t msg[] = "Hello Schnorr";
+    std::vector<uint8_t> sig = schnorr::sign(rand, x, msg, sizeof(msg) - 1);
+    bool ok = true;
+    try { schnorr::verify(X, msg, sizeof(msg) - 1, sig.data(), sig.size()); } catch (const SignatureError&) { ok = false; }
+    CHECK(ok, "schnorr sign/verify round trip");
+    std::string err;
+    try { schnorr::verify(X, (const uint8_t*)"wrong", 5, sig.data(), sig.size()); } catch (const SignatureError& e) { err = e.what(); }
+    CHECK(err == "reconstructed S is not equal to signature", "wrong message is rejected");
+    err.clear();
+    try { schnorr::verify(X, msg, sizeof(msg) - 1, sig.data(), 63); } catch (const SignatureError& e) { err = e.what(); }
+    CHECK(err == "schnorr: signature of invalid length 63 instead of 64", "length check");
+    std::vector<uint8_t> mal = sig;                        // s + L: malleability (schnorr_test.rs:84-110)
+    unsigned c = 0;
+    for (int i = 0; i < 32; ++i) { c += (unsigned)mal[32 + i] + kyber::group::edwards25519::detail::L_BYTES[i]; mal[32 + i] = (uint8_t)c; c >>= 8; }
+    err.clear();
+    try { schnorr::verify(X, msg, sizeof(msg) - 1, mal.data(), 64); } catch (const SignatureError& e) { err = e.what(); }
+    CHECK(err == "signature is not canonical", "s + L is rejected");
+    std::vector<uint8_t> pb = X.marshal_binary();
+    ok = true;
+    try { eddsa::verify_with_checks(pb.data(), 32, msg, sizeof(msg) - 1, sig.data(), 64); } catch (const SignatureError&) { ok = false; }
+    CHECK(ok, "a Schnorr signature is a valid EdDSA signature (schnorr_sig.rs:22-24)");
+  }
+  // polynomials (poly_test.rs: public shares of the commitment equal the commitments of the private shares)
+  {
+    using namespace kyber::share;
+    PriPoly pp;
+    for (int i = 0; i < 5; ++i) pp.coeffs.push_back(Scalar().pick(rand));
+    PubPoly pub = pp.commit(nullptr);
+    std::vector<PubShare> sh = pub.shares(9);
+    for (size_t i = 0; i < 9; ++i) {
+      PriShare ps = pp.eval(i);
+      CHECK(sh[i].v == Point().mul(ps.v, nullptr), "PubPoly::eval(i) == commit of PriPoly::eval(i)");
+      CHECK(pub.check(ps), "PubPoly::check accepts a good share");
+    }
+    PriShare badshare = pp.eval(3); badshare.v = badshare.v + Scalar().one();
+    CHECK(!pub.check(badshare), "PubPoly::check rejects a bad share");
+    Point h = points[5];
+    PubPoly pubh = pp.commit(&h);
+    CHECK(pubh.eval(2).v == Point().mul(pp.eval(2).v, &h), "commit with an explicit base");
   }
 
   for (const Point& p : points) std::printf("POINT %s\n", p.hex().c_str());
