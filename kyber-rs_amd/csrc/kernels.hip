@@ -21,6 +21,7 @@
 #include "../../include/kyber_ed25519.h"
 #include "schnorr.h"
 #include "verify.h"
+#include "ge_ladder.h"
 
 using namespace kyb;
 
@@ -392,6 +393,81 @@ k_sign_hash(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const 
   store_words8(sig, 2 * i + 1, s);
 }
 
+// unmarshal_binary for the ladder path: extended limbs out, failed decodes replaced by the neutral element
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_decode_or_identity(const uint8_t* __restrict__ enc, size_t n, int32_t* __restrict__ out_ext, uint8_t* __restrict__ ok_out) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words8(w, enc, i);
+  ge_p3 P, id;
+  const uint32_t ok = ge_decode(P, w);
+  ge_p3_0(id);
+  fe_cmov(P.X, id.X, 1u - ok); fe_cmov(P.Y, id.Y, 1u - ok); fe_cmov(P.Z, id.Z, 1u - ok); fe_cmov(P.T, id.T, 1u - ok);
+  store_ext(out_ext, i, P.X, P.Y, P.Z, P.T);
+  if (ok_out != nullptr) ok_out[i] = (uint8_t)ok;
+}
+
+// ---- table-free variable base (ge_ladder.h) -------------------------------------------------------
+// Montgomery images of the input points, one field inversion per FINISH_K items.  Output record of item
+// i in the staging buffer: quads 0..4 = u[10] v[10], quad 5.x = flags (the ladder kernel later overwrites
+// the same record with the projective result).
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_mont_prep(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ proj, size_t stride) {
+  const size_t M = (n + FINISH_K - 1) / FINISH_K;
+  const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (j >= M) return;
+  fe pre[FINISH_K];
+  uint32_t flags[FINISH_K];
+#pragma unroll
+  for (int t = 0; t < FINISH_K; ++t) {
+    const size_t i = j + (size_t)t * M;
+    fe d;
+    if (i < n) { ge_p3 P; load_ext(P, pts_ext, i); mont_prep_den(d, flags[t], P); }
+    else { fe_one(d); flags[t] = 1; }
+    if (t == 0) fe_copy(pre[0], d); else fe_mul(pre[t], pre[t - 1], d);
+  }
+  fe inv;
+  fe_invert(inv, pre[FINISH_K - 1]);
+#pragma unroll
+  for (int t = FINISH_K - 1; t >= 0; --t) {
+    const size_t i = j + (size_t)t * M;
+    if (i >= n) continue;                       // tail items carry d = 1: nothing to divide out
+    ge_p3 P;
+    load_ext(P, pts_ext, i);
+    fe d, di;
+    uint32_t fl;
+    mont_prep_den(d, fl, P);
+    if (t > 0) { fe_mul(di, inv, pre[t - 1]); fe_mul(inv, inv, d); } else fe_copy(di, inv);
+    mont_point m;
+    mont_prep_finish(m, P, di, fl);
+    uint32_t f[24];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { f[k] = m.u.v[k]; f[10 + k] = m.v.v[k]; }
+    f[20] = m.flags; f[21] = f[22] = f[23] = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) proj[q * stride + i] = make_uint4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+  }
+}
+template <int WAVES>
+__global__ void __launch_bounds__(KYB_BLOCK, WAVES)
+k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ proj, size_t stride) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t a[8];
+  load_words8(a, scalars, i);
+  uint32_t f[24];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) { const uint4 v = proj[q * stride + i]; f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w; }
+  mont_point m;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { m.u.v[k] = f[k]; m.v.v[k] = f[10 + k]; }
+  m.flags = f[20];
+  ge_p2 r;
+  ge_scalarmult_ladder(r, a, m);
+  store_proj(proj, stride, i, r.X, r.Y, r.Z);
+}
+
 // verification stage 1: checks, decode R and A, h = SHA-512(R || A || msg) mod L.
 // Writes h and s as contiguous 32-byte records, A in reference limbs (input of k_mul), R into the
 // projective staging buffer at [proj_offset, proj_offset + n).
@@ -502,8 +578,8 @@ namespace {
 thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
-enum KernelId { KID_MUL = 0, KID_MUL_BASE = 1, KID_FINISH = 2, KID_SIGN = 3, KID_SIGN_HASH = 4, KID_VERIFY_PREP = 5, KID_VERIFY_FINAL = 6, KID_POLY_EVAL = 7, KID_COUNT = 8 };
-const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval"};
+enum KernelId { KID_MUL = 0, KID_MUL_BASE = 1, KID_FINISH = 2, KID_SIGN = 3, KID_SIGN_HASH = 4, KID_VERIFY_PREP = 5, KID_VERIFY_FINAL = 6, KID_POLY_EVAL = 7, KID_MONT_PREP = 8, KID_MUL_LADDER = 9, KID_DECODE = 10, KID_COUNT = 11 };
+const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval", "k_mont_prep", "k_mul_ladder", "k_decode"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   bool on = false;
@@ -540,6 +616,8 @@ struct Ctx {
   int opt_mul_select = 1;         // 0 cndmask, 1 and/or mask
   int opt_base_select = 1;        // 0 LDS broadcast scan, 1 bpermute
   int opt_base_block = 256;       // 256 (2 waves/SIMD) or 512 (4 waves/SIMD, 128 VGPRs)
+  int opt_mul_algo = 0;           // 0 windowed table (ge.rs structure), 1 Montgomery ladder (table-free)
+  int opt_ladder_waves = 2;       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
   int opt_finish = 1;             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
   int opt_finish_min = 4096;
   std::mutex mu;
@@ -667,10 +745,42 @@ void launch_mul_t(int sel, bool enc, int grid, hipStream_t st, const uint8_t* sc
   else          { if (enc) KYB_L(1, true); else KYB_L(1, false); }
 #undef KYB_L
 }
+// leaves the results projective in r->proj[0, n): prep (batched inversion) -> 256-step ladder
+int launch_ladder_core(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* ok, Ctx::StreamRes* r, hipStream_t st) {
+  int rc = ensure_proj(r, n); if (rc) return rc;
+  const unsigned blocks = (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK);
+  if (penc != nullptr) {           // unmarshal_binary of the operands first (ok flags; failed decodes become the neutral element)
+    rc = ensure_enc(r, 160 * n + 256); if (rc) return rc;
+    int32_t* tmp = reinterpret_cast<int32_t*>(r->enc);
+    ProfScope ps(st, KID_DECODE);
+    hipLaunchKernelGGL(k_decode_or_identity, dim3(blocks), dim3(KYB_BLOCK), 0, st, penc, n, tmp, ok);
+    pext = tmp;
+  }
+  HIPCK(hipGetLastError());
+  {
+    const size_t M = (n + FINISH_K - 1) / FINISH_K;
+    ProfScope ps(st, KID_MONT_PREP);
+    hipLaunchKernelGGL(k_mont_prep, dim3((unsigned)((M + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, pext, n, r->proj, r->proj_items);
+  }
+  HIPCK(hipGetLastError());
+  {
+    ProfScope ps(st, KID_MUL_LADDER);
+    if (g.opt_ladder_waves >= 4)      hipLaunchKernelGGL((k_mul_ladder<4>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items);
+    else if (g.opt_ladder_waves == 3) hipLaunchKernelGGL((k_mul_ladder<3>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items);
+    else                              hipLaunchKernelGGL((k_mul_ladder<2>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items);
+  }
+  HIPCK(hipGetLastError());
+  return KYB_OK;
+}
+
 int launch_mul(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, hipStream_t st) {
   if (n == 0) return KYB_OK;
   Ctx::StreamRes* r = nullptr;
   { int rc = res_for(st, &r); if (rc) return rc; }
+  if (g.opt_mul_algo == 1) {
+    int rc = launch_ladder_core(sc, penc, pext, n, ok, r, st); if (rc) return rc;
+    return launch_finish(r, n, oenc, oext, st);
+  }
   const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
   const int grid = (int)(nchunks < (size_t)g.grid_mul ? nchunks : (size_t)g.grid_mul);
   const bool split = use_split(n);
@@ -1151,6 +1261,8 @@ int kyb_set_option(const char* key, int value) {
   if (!key) return fail(KYB_E_BAD_ARG, "null key");
   if (!strcmp(key, "mul.select")) { if (value < 0 || value > 1) return fail(KYB_E_BAD_ARG, "mul.select in {0,1}"); g.opt_mul_select = value; return KYB_OK; }
   if (!strcmp(key, "mul_base.select")) { if (value < 0 || value > 1) return fail(KYB_E_BAD_ARG, "mul_base.select in {0,1}"); g.opt_base_select = value; return KYB_OK; }
+  if (!strcmp(key, "mul.algo")) { if (value < 0 || value > 1) return fail(KYB_E_BAD_ARG, "mul.algo in {0 window table, 1 ladder}"); g.opt_mul_algo = value; return KYB_OK; }
+  if (!strcmp(key, "mul.ladder_waves")) { if (value < 2 || value > 4) return fail(KYB_E_BAD_ARG, "mul.ladder_waves in 2..4"); g.opt_ladder_waves = value; return KYB_OK; }
   if (!strcmp(key, "mul_base.block")) { if (value != 256 && value != 512) return fail(KYB_E_BAD_ARG, "mul_base.block in {256,512}"); g.opt_base_block = value; return KYB_OK; }
   if (!strcmp(key, "finish.batched")) { if (value < 0 || value > 1) return fail(KYB_E_BAD_ARG, "finish.batched in {0,1}"); g.opt_finish = value; return KYB_OK; }
   if (!strcmp(key, "finish.min_items")) { if (value < 1) return fail(KYB_E_BAD_ARG, "finish.min_items >= 1"); g.opt_finish_min = value; return KYB_OK; }
@@ -1163,6 +1275,8 @@ int kyb_get_option(const char* key, int* value) {
   if (!key || !value) return fail(KYB_E_BAD_ARG, "null argument");
   if (!strcmp(key, "mul.select")) { *value = g.opt_mul_select; return KYB_OK; }
   if (!strcmp(key, "mul_base.select")) { *value = g.opt_base_select; return KYB_OK; }
+  if (!strcmp(key, "mul.algo")) { *value = g.opt_mul_algo; return KYB_OK; }
+  if (!strcmp(key, "mul.ladder_waves")) { *value = g.opt_ladder_waves; return KYB_OK; }
   if (!strcmp(key, "mul_base.block")) { *value = g.opt_base_block; return KYB_OK; }
   if (!strcmp(key, "finish.batched")) { *value = g.opt_finish; return KYB_OK; }
   if (!strcmp(key, "finish.min_items")) { *value = g.opt_finish_min; return KYB_OK; }

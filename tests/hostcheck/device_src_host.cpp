@@ -10,6 +10,7 @@
 #include <vector>
 #include "../../kyber-rs_amd/csrc/schnorr.h"
 #include "../../kyber-rs_amd/csrc/verify.h"
+#include "../../kyber-rs_amd/csrc/ge_ladder.h"
 
 static std::atomic<long> g_overflows{0};
 extern "C" void kyb_host_overflow(const char*) { g_overflows++; }
@@ -183,6 +184,29 @@ int hd_equal(const int32_t a[40], const int32_t b[40]) {
   fe_from_ref10(A.X, a); fe_from_ref10(A.Y, a + 10); fe_from_ref10(A.Z, a + 20); fe_from_ref10(A.T, a + 30);
   fe_from_ref10(B.X, b); fe_from_ref10(B.Y, b + 10); fe_from_ref10(B.Z, b + 20); fe_from_ref10(B.T, b + 30);
   return (int)ge_equal(A, B);
+}
+void hd_mul_ladder(uint8_t out[32], const uint8_t scalar[32], const int32_t pt[40]) {
+  uint32_t a[8], w[8];
+  load_words(a, scalar);
+  ge_p3 P;
+  fe_from_ref10(P.X, pt); fe_from_ref10(P.Y, pt + 10); fe_from_ref10(P.Z, pt + 20); fe_from_ref10(P.T, pt + 30);
+  fe d, dinv;
+  uint32_t flags;
+  mont_prep_den(d, flags, P);
+  fe_invert(dinv, d);
+  mont_point m;
+  mont_prep_finish(m, P, dinv, flags);
+  ge_p2 r;
+  ge_scalarmult_ladder(r, a, m);
+  ge_encode(w, r.X, r.Y, r.Z);
+  memcpy(out, w, 32);
+}
+void hd_effective(uint8_t mag[32], int* neg, const uint8_t scalar[32]) {
+  uint32_t a[8], m[8], n;
+  load_words(a, scalar);
+  sc_effective(n, m, a);
+  memcpy(mag, m, 32);
+  *neg = (int)n;
 }
 void hd_recode(int8_t e[64], const uint8_t scalar[32]) {
   uint32_t a[8];

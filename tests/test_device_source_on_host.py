@@ -236,3 +236,35 @@ def test_pubpoly_eval_and_equal(hd, oracle):
     c = oracle.mul_base_ext((6).to_bytes(32, "little"))
     assert hd.hd_equal(p32(a), p32(b)) == 1 and hd.hd_equal(p32(a), p32(c)) == 0 and hd.hd_equal(p32(a), p32(oracle.neg(a))) == 0
     assert hd.hd_overflows() == base
+
+
+def test_ladder_path_matches_oracle(hd, oracle):
+    """table-free variable-base path (ge_ladder.h) == the reference's windowed multiplication on every
+    quirk vector (small-order / mixed-order / non-canonical points; scalars 0, L, 8L, >= 2^255) and on
+    random inputs; sc_effective == the integer the reference's recoding multiplies by"""
+    base = hd.hd_overflows()
+    rnd = random.Random(21)
+    cases = [bytes(32), bytes([255] * 32), bytes([0x88] * 32), bytes([0] * 31 + [0x80]), bytes([0xff] * 31 + [0x8f])]
+    cases += [bytes(rnd.getrandbits(8) for _ in range(32)) for _ in range(500)]
+    for s in cases:
+        mag = B(32); neg = ctypes.c_int(0)
+        hd.hd_effective(mag, ctypes.byref(neg), s)
+        want = M.effective_scalar(s)
+        assert (-1 if neg.value else 1) * int.from_bytes(mag.raw, "little") == want
+    for q in KATS["quirk_mul"]:
+        if not q["ok"]:
+            continue
+        ext, _ = oracle.decode(bytes.fromhex(q["point"]))
+        o = B(32); hd.hd_mul_ladder(o, bytes.fromhex(q["scalar"]), p32(ext))
+        assert o.raw.hex() == q["out"], q
+    weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
+    for i in range(120):
+        s = bytes(rnd.getrandbits(8) for _ in range(32))
+        pt = oracle.mul_base_ext(bytes(rnd.getrandbits(8) for _ in range(32)))
+        if i % 3 == 0:
+            pt = oracle.add(pt, weak[rnd.choice([0, 2, 3, 4])])       # mixed-order point
+        if i % 10 == 0:
+            s = ((rnd.choice([1, 2, 4, 8]) * M.L + rnd.choice([-1, 0, 1])) % 2**256).to_bytes(32, "little")
+        o = B(32); hd.hd_mul_ladder(o, s, p32(pt))
+        assert o.raw == oracle.mul(s, pt), (i, s.hex())
+    assert hd.hd_overflows() == base

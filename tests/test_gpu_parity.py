@@ -262,6 +262,13 @@ def test_split_finish_isolates_degenerate_z(engine, oracle):
     good = [i for i in range(n) if i not in (5, 22)]
     assert np.array_equal(a[good], want[good])
     assert np.array_equal(a[[5, 22]], want[[5, 22]])     # reference: 0^(p-2) = 0 -> all-zero encoding
+    # the table-free path must isolate the bad items too (what it returns for them is unspecified)
+    engine.set_option("mul.algo", 1)
+    try:
+        c = engine.mul(s, pts_ext=pts)
+    finally:
+        engine.set_option("mul.algo", 0)
+    assert np.array_equal(c[good], want[good])
 
 
 def test_verify_matches_oracle(engine, oracle):
@@ -328,3 +335,52 @@ def test_pubpoly_eval_and_equal(engine, oracle):
     shares = [sum(c * pow(int(i) + 1, j, synth.L) for j, c in enumerate(coeffs)) % synth.L for i in idx[:64]]
     want = engine.mul_base(np.frombuffer(b"".join(s.to_bytes(32, "little") for s in shares), dtype=np.uint8))
     assert np.array_equal(enc[:64], want)
+
+
+@pytest.mark.parametrize("waves", [2, 4])
+def test_ladder_path_matches_oracle(engine, oracle, waves):
+    """mul.algo=1 (Montgomery ladder + y-recovery, no per-lane table): same bytes as the oracle on quirk
+    vectors, mixed-order points, scalars around multiples of L, encoded inputs incl. invalid ones, ragged sizes"""
+    engine.set_option("mul.algo", 1)
+    engine.set_option("mul.ladder_waves", waves)
+    try:
+        q = [v for v in KATS["quirk_mul"] if v["ok"]]
+        sc = np.frombuffer(b"".join(bytes.fromhex(v["scalar"]) for v in q), dtype=np.uint8)
+        pe = np.frombuffer(b"".join(bytes.fromhex(v["point"]) for v in q), dtype=np.uint8)
+        got, ok = engine.mul(sc, pts_enc=pe, want_ok=True)
+        assert ok.all() and [bytes(r).hex() for r in got] == [v["out"] for v in q]
+        ext = np.stack([oracle.decode(bytes.fromhex(v["point"]))[0] for v in q])
+        assert [bytes(r).hex() for r in engine.mul(sc, pts_ext=ext)] == [v["out"] for v in q]
+        # random + mixed-order points, raw 256-bit scalars, scalars k*L + {-1,0,1}
+        n = 1500
+        rng = np.random.default_rng(61)
+        s = np.concatenate([synth.scalars(600, 61), synth.raw256(n - 600, 61)])
+        Lq = synth.L
+        for j, k in enumerate([1, 2, 4, 8]):
+            for d in (-1, 0, 1):
+                s[3 * j + d + 1] = np.frombuffer(((k * Lq + d) % 2**256).to_bytes(32, "little"), dtype=np.uint8)
+        pts = rand_points_ext(oracle, n, 61)
+        weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
+        for i in range(0, n, 3):
+            pts[i] = oracle.add(pts[i], weak[int(rng.integers(0, 5))])
+        got, gext = engine.mul(s, pts_ext=pts, want_ext=True)
+        assert np.array_equal(got, oracle.mul_batch(s, pts, nthreads=8))
+        for i in range(0, n, 131):
+            assert oracle.encode(gext[i]) == bytes(got[i])
+        # encoded inputs with invalid encodings in between
+        good = [oracle.encode(p) for p in pts[:30]]
+        bad = [bytes.fromhex(h) for h in KATS["invalid_encodings"]]
+        encs = good[:11] + bad + good[11:]
+        s2 = synth.scalars(len(encs), 62)
+        got, ok = engine.mul(s2, pts_enc=np.frombuffer(b"".join(encs), dtype=np.uint8), want_ok=True)
+        for i, e in enumerate(encs):
+            pe_, okk = oracle.decode(e)
+            assert ok[i] == okk
+            assert bytes(got[i]) == (oracle.mul(bytes(s2[i]), pe_) if okk else IDENT)
+        for m in (1, 7, 8, 9, 63, 65, 257):
+            sm = synth.scalars(m, 63)
+            pm = rand_points_ext(oracle, m, 63)
+            assert np.array_equal(engine.mul(sm, pts_ext=pm), oracle.mul_batch(sm, pm, nthreads=8))
+    finally:
+        engine.set_option("mul.algo", 0)
+        engine.set_option("mul.ladder_waves", 2)
