@@ -34,10 +34,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # verify (eddsa_sig.rs:159-212): 2 decodes (2 x 16,000) + 2 has_small_order encodes (2 x 15,270) + fixed-base
 # (46,980) + variable-base (188,640) + add (900) + eq = 2 encodes (2 x 15,270)
 PRODUCTS = {"mul": 203_910, "mul_base": 62_250, "sign": 124_500, "verify": 329_600}
-PRODUCTS_DOMINANT = {"k_mul": 188_640, "k_mul_base": 46_980, "k_sign": 124_500}
+PRODUCTS_DOMINANT = {"k_mul": 188_640, "k_mul_ladder": 188_640, "k_mul_base": 46_980, "k_sign": 124_500}
 ALG_BYTES = {"mul": 32 + 160 + 32, "mul_base": 32 + 32, "sign": 32 + 32 + 32 + 64, "verify": 32 + 64 + 32 + 1}
 UNIT = {"mul": "variable-base scalar-mults/s", "mul_base": "fixed-base scalar-mults/s", "sign": "signatures/s", "verify": "verifications/s"}
-DOMINANT = {"mul": "k_mul", "mul_base": "k_mul_base", "sign": "k_mul_base", "verify": "k_mul"}
+DOMINANT = {"mul": "k_mul_ladder", "mul_base": "k_mul_base", "sign": "k_mul_base", "verify": "k_mul_ladder"}
 # measured on MI355X: 26.8e12 v_mad_u64_u32 lane-ops/s with every SIMD issuing (8 waves/SIMD, clock
 # settles at ~1.9 GHz under this load) — tools/microbench/valu_rates.hip
 PEAK_MAD_PER_S = 26.8e12
@@ -237,7 +237,7 @@ def main():
                                     "sign": "2^18 Schnorr signs, 32-byte messages, 64-byte signatures out",
                                     "verify": "2^20 Schnorr verifications with the reference's checks, 32-byte messages, status bytes out"}[wl] if not args.n else f"{wl} x {n} per GPU",
                        "items_per_gpu": n, "sharding": f"independent shards x{world}, no data-path collective; one RCCL table broadcast at init",
-                       "options": {k_: eng.get_option(k_) for k_ in ("mul.select", "mul_base.select", "mul_base.block", "finish.batched", "finish.min_items")}},
+                       "options": {k_: eng.get_option(k_) for k_ in ("mul.algo", "mul.ladder_waves", "mul.select", "mul_base.select", "mul_base.block", "finish.batched", "finish.min_items")}},
             "roofline": {"bound": "valu-int", "kernel": dom, "achieved": round(mad_rate / 1e12, 3), "peak": PEAK_MAD_PER_S / 1e12,
                          "unit": "T(32x32+64 mad)/s", "frac": round(mad_rate / PEAK_MAD_PER_S, 4),
                          "algorithmic_mads_per_item": dom_products, "items_per_launch": int(items_per_launch),

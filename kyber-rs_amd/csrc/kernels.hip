@@ -616,8 +616,8 @@ struct Ctx {
   int opt_mul_select = 1;         // 0 cndmask, 1 and/or mask
   int opt_base_select = 1;        // 0 LDS broadcast scan, 1 bpermute
   int opt_base_block = 256;       // 256 (2 waves/SIMD) or 512 (4 waves/SIMD, 128 VGPRs)
-  int opt_mul_algo = 0;           // 0 windowed table (ge.rs structure), 1 Montgomery ladder (table-free)
-  int opt_ladder_waves = 2;       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
+  int opt_mul_algo = 1;           // 0 windowed table (ge.rs structure), 1 Montgomery ladder (table-free, 1.33x faster: profiles/r01/sweep_mul_algo.log)
+  int opt_ladder_waves = 3;       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
   int opt_finish = 1;             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
   int opt_finish_min = 4096;
   std::mutex mu;
@@ -865,13 +865,15 @@ int launch_verify(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off,
     hipLaunchKernelGGL(k_verify_prep, dim3(blocks), dim3(KYB_BLOCK), 0, st, pubs, sigs, msgs, off, n, flavor, status, hbuf, sbuf, a_ext, r->proj, r->proj_items, 2 * n);
   }
   HIPCK(hipGetLastError());
-  {
+  if (g.opt_mul_algo == 1) {
+    rc = launch_ladder_core(hbuf, nullptr, a_ext, n, nullptr, r, st); if (rc) return rc;
+  } else {
     const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
     const int grid = (int)(nchunks < (size_t)g.grid_mul ? nchunks : (size_t)g.grid_mul);
     ProfScope ps(st, KID_MUL);
     launch_mul_t<true>(g.opt_mul_select, false, grid, st, hbuf, nullptr, a_ext, n, nullptr, nullptr, nullptr, r);
+    HIPCK(hipGetLastError());
   }
-  HIPCK(hipGetLastError());
   rc = launch_base_t<true>(sbuf, n, nullptr, nullptr, r, n, st); if (rc) return rc;
   {
     ProfScope ps(st, KID_VERIFY_FINAL);

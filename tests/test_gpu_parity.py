@@ -43,6 +43,8 @@ def test_mul_base_matches_oracle(engine, oracle, select):
 
 @pytest.mark.parametrize("select", [0, 1])
 def test_mul_matches_oracle(engine, oracle, select):
+    """the windowed-table kernel (mul.algo=0), both merge variants"""
+    engine.set_option("mul.algo", 0)
     engine.set_option("mul.select", select)
     n = 1029
     s = np.concatenate([synth.scalars(700, 2), synth.raw256(n - 700, 2)])
@@ -55,6 +57,7 @@ def test_mul_matches_oracle(engine, oracle, select):
     for i in range(0, n, 97):
         assert oracle.encode(ext[i]) == bytes(got[i])
     engine.set_option("mul.select", 1)
+    engine.set_option("mul.algo", 1)
 
 
 def test_quirk_vectors(engine, oracle):
@@ -224,8 +227,9 @@ def test_split_finish_and_block_variants(engine, oracle, block):
             got, ext = engine.mul_base(s, want_ext=True)
             assert np.array_equal(got, oracle.mul_base_batch(s, nthreads=8))
             pts = rand_points_ext(oracle, n, 32)
-            got_v = engine.mul(s, pts_ext=pts)
-            assert np.array_equal(got_v, oracle.mul_batch(s, pts, nthreads=8))
+            for algo in (0, 1):
+                engine.set_option("mul.algo", algo)
+                assert np.array_equal(engine.mul(s, pts_ext=pts), oracle.mul_batch(s, pts, nthreads=8))
             engine.set_option("finish.batched", 0)
             got0, ext0 = engine.mul_base(s, want_ext=True)
             assert np.array_equal(got, got0) and np.array_equal(ext, ext0)
@@ -249,6 +253,7 @@ def test_split_finish_isolates_degenerate_z(engine, oracle):
     pts[5] = 0          # X = Y = Z = T = 0: not a curve point; every formula output stays 0
     pts[22] = 0
     engine.set_option("finish.min_items", 1)
+    engine.set_option("mul.algo", 0)
     try:
         engine.set_option("finish.batched", 1)
         a = engine.mul(s, pts_ext=pts)
@@ -257,17 +262,14 @@ def test_split_finish_isolates_degenerate_z(engine, oracle):
     finally:
         engine.set_option("finish.batched", 1)
         engine.set_option("finish.min_items", 4096)
+        engine.set_option("mul.algo", 1)
     assert np.array_equal(a, b)
     want = oracle.mul_batch(s, pts, nthreads=8)
     good = [i for i in range(n) if i not in (5, 22)]
     assert np.array_equal(a[good], want[good])
     assert np.array_equal(a[[5, 22]], want[[5, 22]])     # reference: 0^(p-2) = 0 -> all-zero encoding
     # the table-free path must isolate the bad items too (what it returns for them is unspecified)
-    engine.set_option("mul.algo", 1)
-    try:
-        c = engine.mul(s, pts_ext=pts)
-    finally:
-        engine.set_option("mul.algo", 0)
+    c = engine.mul(s, pts_ext=pts)
     assert np.array_equal(c[good], want[good])
 
 
@@ -382,5 +384,4 @@ def test_ladder_path_matches_oracle(engine, oracle, waves):
             pm = rand_points_ext(oracle, m, 63)
             assert np.array_equal(engine.mul(sm, pts_ext=pm), oracle.mul_batch(sm, pm, nthreads=8))
     finally:
-        engine.set_option("mul.algo", 0)
-        engine.set_option("mul.ladder_waves", 2)
+        engine.set_option("mul.ladder_waves", 3)
