@@ -20,6 +20,16 @@
 
 #include "../../include/kyber_ed25519.h"
 #include "schnorr.h"
+namespace kyb {
+// one out-of-line copy of the decompression (255 S + 20 M): called twice per item by k_verify_prep
+__device__ __noinline__ uint32_t ge_decode_outlined(ge_p3& h, const uint32_t w[8]) { return ge_decode(h, w); }
+__host__ inline uint32_t ge_decode_outlined_host(ge_p3& h, const uint32_t w[8]) { return ge_decode(h, w); }
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KYB_GE_DECODE ge_decode_outlined
+#else
+#define KYB_GE_DECODE ge_decode_outlined_host
+#endif
 #include "verify.h"
 #include "ge_ladder.h"
 
@@ -674,9 +684,7 @@ int do_init(int device, bool build_table) {
   // v_mad_u64_u32 issue, profiles/r01_valu_rates_mi355x.jsonl)
   g.grid_mul = g.cus * 2;
   g.ws_bytes = (size_t)g.grid_mul * (KYB_BLOCK / 64) * (8 * 10 * 64) * sizeof(uint4);
-  hipError_t em = hipMalloc(&g.res[0].ws, g.ws_bytes);
-  if (em != hipSuccess) return fail(KYB_E_NOMEM, "workspace allocation", em);
-  g.res[0].stream = g.stream;
+  g.res[0] = Ctx::StreamRes{g.stream, nullptr, nullptr, 0, nullptr, 0};   // scratch is allocated on first use
   g.res_count = 1;
   if (build_table) {
     hipLaunchKernelGGL(k_base_table, dim3(8), dim3(64), 0, g.stream, g.table);
@@ -697,11 +705,15 @@ int res_for(hipStream_t st, Ctx::StreamRes** out) {
   std::lock_guard<std::mutex> lk(mu);
   for (int i = 0; i < g.res_count; ++i) if (g.res[i].stream == st) { *out = &g.res[i]; return KYB_OK; }
   if (g.res_count == 8) return fail(KYB_E_NOMEM, "kernels have been launched on more than 8 distinct streams");
-  uint4* p = nullptr;
-  hipError_t e = hipMalloc(&p, g.ws_bytes);
-  if (e != hipSuccess) return fail(KYB_E_NOMEM, "workspace allocation", e);
-  g.res[g.res_count] = Ctx::StreamRes{st, p, nullptr, 0, nullptr, 0};
+  g.res[g.res_count] = Ctx::StreamRes{st, nullptr, nullptr, 0, nullptr, 0};
   *out = &g.res[g.res_count++];
+  return KYB_OK;
+}
+// the windowed-table kernel's per-wave table slots (160 MiB): only allocated if that kernel is used
+int ensure_ws(Ctx::StreamRes* r) {
+  if (r->ws) return KYB_OK;
+  hipError_t e = hipMalloc(&r->ws, g.ws_bytes);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "table workspace allocation", e);
   return KYB_OK;
 }
 // grow-only; growth synchronises the stream first because earlier launches may still use the old buffer
@@ -781,6 +793,7 @@ int launch_mul(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size
     int rc = launch_ladder_core(sc, penc, pext, n, ok, r, st); if (rc) return rc;
     return launch_finish(r, n, oenc, oext, st);
   }
+  { int rc = ensure_ws(r); if (rc) return rc; }
   const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
   const int grid = (int)(nchunks < (size_t)g.grid_mul ? nchunks : (size_t)g.grid_mul);
   const bool split = use_split(n);
@@ -868,6 +881,7 @@ int launch_verify(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off,
   if (g.opt_mul_algo == 1) {
     rc = launch_ladder_core(hbuf, nullptr, a_ext, n, nullptr, r, st); if (rc) return rc;
   } else {
+    rc = ensure_ws(r); if (rc) return rc;
     const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
     const int grid = (int)(nchunks < (size_t)g.grid_mul ? nchunks : (size_t)g.grid_mul);
     ProfScope ps(st, KID_MUL);
@@ -916,7 +930,7 @@ void kyb_shutdown(void) {
   (void)hipStreamSynchronize(g.stream);
   if (g.stage) (void)hipFree(g.stage);
   for (int i = 0; i < g.res_count; ++i) {
-    (void)hipFree(g.res[i].ws);
+    if (g.res[i].ws) (void)hipFree(g.res[i].ws);
     if (g.res[i].proj) (void)hipFree(g.res[i].proj);
     if (g.res[i].enc) (void)hipFree(g.res[i].enc);
     g.res[i] = Ctx::StreamRes{};

@@ -16,6 +16,12 @@
 #include "sc25519.h"
 #include "sha512.h"
 
+// kernels.hip routes the two point decodes of verify_prep through ONE out-of-line copy of ge_decode
+// (two inlined copies made k_verify_prep 118 KB of code with 3.2 KB of scratch per lane)
+#ifndef KYB_GE_DECODE
+#define KYB_GE_DECODE ge_decode
+#endif
+
 namespace kyb {
 
 // scalar.rs:54-75: s < L
@@ -54,7 +60,8 @@ KYB_HD uint32_t verify_prep(uint32_t h[8], ge_p3& R, ge_p3& A, const uint32_t pu
                             const uint8_t* msg, uint32_t msg_len, int flavor) {
   const uint32_t s_ok = sc_is_canonical_w(sig + 8);
   const uint32_t r_can = pt_is_canonical_w(sig), a_can = pt_is_canonical_w(pub);
-  const uint32_t r_dec = ge_decode(R, sig), a_dec = ge_decode(A, pub);
+  const uint32_t r_dec = KYB_GE_DECODE(R, sig);
+  const uint32_t a_dec = KYB_GE_DECODE(A, pub);
   const uint32_t r_small = pt_has_small_order(R.Y), a_small = pt_has_small_order(A.Y);
   ge_p3 id;
   ge_p3_0(id);
