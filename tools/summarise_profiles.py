@@ -15,15 +15,15 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = "gpurun_out/prof"
 dst = os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-DOM = {"mul": "k_mul<", "mul_base": "k_mul_base<", "sign": "k_mul_base<"}
+DOM = {"mul": "k_mul_ladder<", "mul_base": "k_mul_base<", "sign": "k_mul_base<"}
 ITEMS = {"mul": 1 << 20, "mul_base": 1 << 20, "sign": 1 << 18}
 for w in ("mul", "mul_base", "sign"):
-    ks = glob.glob(f"{src}/{w}_trace/*/*kernel_stats.csv")
+    ks = sorted(glob.glob(f"{src}/{w}_trace/*/*kernel_stats.csv"), key=os.path.getmtime)
     if ks:
-        shutil.copyfile(ks[0], os.path.join(dst, f"{w}_kernel_stats.csv"))
+        shutil.copyfile(ks[-1], os.path.join(dst, f"{w}_kernel_stats.csv"))      # newest run only
     out = {}
     for p in ("sq", "fetch", "write"):
-        for f in glob.glob(f"{src}/{w}_pmc_{p}/*/*counter_collection.csv"):
+        for f in sorted(glob.glob(f"{src}/{w}_pmc_{p}/*/*counter_collection.csv"), key=os.path.getmtime)[-1:]:
             agg = collections.defaultdict(list)
             meta = {}
             for r in csv.DictReader(open(f)):
