@@ -96,6 +96,39 @@ KYB_HD uint32_t kyb_x2(uint32_t a, const char* what) {
 #endif
 }
 
+// ---- device-only: one asm statement per COLUMN ---------------------------------------------------
+// hipcc reassociates a column into "products first, carry last" and then needs a separate 64-bit add
+// per column (v_lshl_add_u64, half rate).  Writing the column's mads as one asm statement keeps the
+// running sum — carry of the previous column included — as the addend chain (no extra add), and costs
+// one asm-boundary pad per column instead of one per mad (the per-mad barrier variant lost to its
+// s_nops, profiles/r01/ab_chain_barrier.log).  -DKYB_NO_ASM_COLUMNS restores the plain C++ columns.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KYB_NO_ASM_COLUMNS)
+#define KYB_ASM_COLUMNS 1
+#define KYB_M1(a, b) "v_mad_u64_u32 %0, vcc, %" #a ", %" #b ", %0\n\t"
+__device__ __forceinline__ uint64_t kyb_col10(uint64_t acc, const uint32_t* A, const uint32_t* B) {
+  asm(KYB_M1(1, 11) KYB_M1(2, 12) KYB_M1(3, 13) KYB_M1(4, 14) KYB_M1(5, 15) KYB_M1(6, 16) KYB_M1(7, 17) KYB_M1(8, 18) KYB_M1(9, 19) KYB_M1(10, 20)
+      : "+v"(acc)
+      : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(A[6]), "v"(A[7]), "v"(A[8]), "v"(A[9]),
+        "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]), "v"(B[5]), "v"(B[6]), "v"(B[7]), "v"(B[8]), "v"(B[9])
+      : "vcc");
+  return acc;
+}
+__device__ __forceinline__ uint64_t kyb_col6(uint64_t acc, const uint32_t* A, const uint32_t* B) {
+  asm(KYB_M1(1, 7) KYB_M1(2, 8) KYB_M1(3, 9) KYB_M1(4, 10) KYB_M1(5, 11) KYB_M1(6, 12)
+      : "+v"(acc)
+      : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]), "v"(B[5])
+      : "vcc");
+  return acc;
+}
+__device__ __forceinline__ uint64_t kyb_col5(uint64_t acc, const uint32_t* A, const uint32_t* B) {
+  asm(KYB_M1(1, 6) KYB_M1(2, 7) KYB_M1(3, 8) KYB_M1(4, 9) KYB_M1(5, 10)
+      : "+v"(acc)
+      : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4])
+      : "vcc");
+  return acc;
+}
+#endif
+
 KYB_HD void fe_zero(fe& h) {
   KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = 0;
 }
@@ -157,6 +190,15 @@ KYB_HD void fe_mul(fe& h, const fe& f, const fe& g) {
   uint64_t acc = 0;
   uint32_t r[10];
   KYB_UNROLL for (int k = 0; k < 10; ++k) {
+#if defined(KYB_ASM_COLUMNS)
+    uint32_t ca[10], cb[10];
+    KYB_UNROLL for (int i = 0; i < 10; ++i) {
+      const int j = (k - i + 10) % 10;
+      ca[i] = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
+      cb[i] = (i > k) ? g19[j] : g.v[j];
+    }
+    acc = kyb_col10(acc, ca, cb);
+#else
     KYB_UNROLL for (int i = 0; i < 10; ++i) {
       const int j = (k - i + 10) % 10;
       const bool wrap = i > k;
@@ -164,6 +206,7 @@ KYB_HD void fe_mul(fe& h, const fe& f, const fe& g) {
       const uint32_t gj = wrap ? g19[j] : g.v[j];
       acc = kyb_mad(fi, gj, acc);
     }
+#endif
     r[k] = (uint32_t)acc & KYB_MASK(k);
     acc >>= KYB_BITS(k);
   }
@@ -184,6 +227,10 @@ KYB_HD void fe_sq(fe& h, const fe& f) {
   uint64_t acc = 0;
   uint32_t r[10];
   KYB_UNROLL for (int k = 0; k < 10; ++k) {
+#if defined(KYB_ASM_COLUMNS)
+    uint32_t ca[6], cb[6];
+    int nt = 0;
+#endif
     KYB_UNROLL for (int i = 0; i < 10; ++i) {
       const int j = (k - i + 10) % 10;
       if (i > j) continue;                    // each unordered pair once
@@ -194,8 +241,15 @@ KYB_HD void fe_sq(fe& h, const fe& f) {
       uint32_t a, b;
       if (!wrap) { a = cross ? f2[i] : f.v[i]; b = oo ? f2[j] : f.v[j]; }
       else       { a = cross ? f2[i] : f.v[i]; b = oo ? f38[j] : f19[j]; }
+#if defined(KYB_ASM_COLUMNS)
+      ca[nt] = a; cb[nt] = b; ++nt;
+#else
       acc = kyb_mad(a, b, acc);
+#endif
     }
+#if defined(KYB_ASM_COLUMNS)
+    if ((k & 1) == 0) acc = kyb_col6(acc, ca, cb); else acc = kyb_col5(acc, ca, cb);   // 6 pairs in even columns, 5 in odd ones
+#endif
     r[k] = (uint32_t)acc & KYB_MASK(k);
     acc >>= KYB_BITS(k);
   }
