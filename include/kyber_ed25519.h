@@ -136,7 +136,9 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
 /* ---- introspection for benchmarks / tests ------------------------------------------------------ */
 /* kernel variant selection: key is e.g. "mul.select" / "mul_base.select"; returns
  * KYB_E_BAD_ARG for unknown keys or values.  Defaults are the fastest measured variants.
- *   mul.select        0 v_cndmask merge, 1 and/or merge of the variable-base table scan
+ *   mul.algo          1 Montgomery ladder + y-recovery (table-free, default), 0 windowed table 1P..8P per lane
+ *   mul.ladder_waves  2..4: waves per SIMD the ladder kernel's register allocation must allow
+ *   mul.select        0 v_cndmask merge, 1 and/or merge of the windowed kernel's table scan
  *   mul_base.select   0 LDS broadcast scan, 1 ds_bpermute selection
  *   mul_base.block    256 | 512 threads per workgroup of the fixed-base kernel
  *   finish.batched    1: results stay projective and one inversion serves 8 items (k_finish)
