@@ -9,7 +9,7 @@ A "step" = one pass of the hot path over one batch that is already resident in H
   sign      2^18 Schnorr signatures, 32-byte messages                   (configs[3])
 For N > 1 the driver launches one process per GPU (torch.distributed.run); every rank owns its own
 shard of N x ITEMS_PER_GPU independent items (weak scaling, no data-path collective).  The only
-collective is the one-time RCCL broadcast of the 64 KiB base-point table built on rank 0.
+collective is the one-time RCCL broadcast of the 168 KiB base-point table image built on rank 0.
 
 Rank 0 prints ONE JSON line.  `value` is whole-job items/s over the timed K steps (barrier +
 synchronize on both sides, max over ranks).  `roofline` prices the dominant kernel against the

@@ -45,10 +45,11 @@ extern "C" {
 #define KYB_E_HIP (-4)
 #define KYB_E_NOMEM (-5)
 
-/* table image exchanged between GPUs at init: uint32 [64 pos][8 quads][8 entries][4] = 65,536 bytes.
- * Entry (pos, j) = (j+1) * 16^pos * B as affine (y+x, y-x, 2dxy), canonical limbs — the role of
- * constants.rs:89 BASE (which holds the 32 even positions only). */
-#define KYB_BASE_TABLE_BYTES 65536u
+/* table image exchanged between GPUs at init — the role of constants.rs:89 BASE (which holds the 32 even
+ * radix-16 positions only); affine (y+x, y-x, 2dxy), canonical limbs:
+ *   bytes [0, 65536)        uint32 [64 pos][8 quads][ 8 entries][4]   entry (pos, j) = (j+1) * 16^pos * B
+ *   bytes [65536, 172032)   uint32 [52 pos][8 quads][16 entries][4]   entry (pos, j) = (j+1) * 32^pos * B */
+#define KYB_BASE_TABLE_BYTES 172032u
 
 /* ---- lifecycle -------------------------------------------------------------------------------- */
 /* Bind this process to HIP device `device`, allocate the workspace, build the base-point table on
@@ -140,7 +141,8 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *   mul.ladder_waves  2..4: waves per SIMD the ladder kernel's register allocation must allow
  *   mul.select        0 v_cndmask merge, 1 and/or merge of the windowed kernel's table scan
  *   mul_base.select   0 LDS broadcast scan, 1 ds_bpermute selection
- *   mul_base.block    256 | 512 threads per workgroup of the fixed-base kernel
+ *   mul_base.radix    32: 52-window kernel (1024-thread workgroups) for batches >= finish.min_items; 16: 64 windows
+ *   mul_base.block    256 | 512 threads per workgroup of the radix-16 fixed-base kernel
  *   finish.batched    1: results stay projective and one inversion serves 8 items (k_finish)
  *   finish.min_items  smallest batch that takes the batched finish (default 4096) */
 int kyb_set_option(const char* key, int value);

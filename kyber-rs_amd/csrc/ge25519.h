@@ -204,4 +204,32 @@ KYB_HD void sc_digit(uint32_t& mag, uint32_t& neg, const sc_digits& d, int i) {
   mag = neg ? (uint32_t)(-v) : (uint32_t)v;
 }
 
+// The integer a' the reference's routines multiply by (see sc_recode): a itself unless the top radix-16
+// digit is 9..16, in which case that digit is dropped: a' = (a mod 2^252) - c63 * 2^252 with c63 the
+// carry into digit 63.  Returned as sign (1 = negative) and 256-bit magnitude.
+KYB_HD void sc_effective(uint32_t& neg, uint32_t mag[8], const uint32_t a[8]) {
+  uint64_t c = 0;
+  uint32_t b7 = 0;
+  KYB_UNROLL for (int i = 0; i < 8; ++i) {
+    c += (uint64_t)a[i] + (i == 7 ? 0x08888888u : 0x88888888u);
+    if (i == 7) b7 = (uint32_t)c;
+    c >>= 32;
+  }
+  const uint32_t e63 = (b7 >> 28) + ((uint32_t)c << 4);          // 0..16
+  const uint32_t dropped = e63 > 8u;
+  const uint32_t c63 = e63 - (a[7] >> 28);                       // carry into digit 63: 0 or 1
+  // candidate magnitudes: a (not dropped), low252(a) (dropped, c63 = 0), 2^252 - low252(a) (dropped, c63 = 1)
+  uint32_t low[8], negm[8];
+  KYB_UNROLL for (int i = 0; i < 8; ++i) low[i] = a[i];
+  low[7] &= 0x0fffffffu;
+  int64_t bw = 0;
+  KYB_UNROLL for (int i = 0; i < 8; ++i) {
+    bw += (int64_t)(i == 7 ? 0x10000000u : 0u) - (int64_t)low[i];
+    negm[i] = (uint32_t)bw;
+    bw >>= 32;
+  }
+  neg = dropped & c63;
+  KYB_UNROLL for (int i = 0; i < 8; ++i) mag[i] = dropped ? (c63 ? negm[i] : low[i]) : a[i];
+}
+
 }  // namespace kyb

@@ -151,6 +151,31 @@ struct tbl_lds {
   }
 };
 
+// Radix-32 fixed-base table in LDS, image layout [pos][quad][16 entries][4] (KYB_BT32_IDX): lane l holds
+// entry (l & 15) after eight conflict-free ds_read_b128, the wanted one is pulled with ds_bpermute_b32.
+struct tbl_lds32 {
+  const uint32_t* t;  // LDS
+  __device__ __forceinline__ void select(ge_precomp& c, int pos, uint32_t mag) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t mine = lane & 15u;
+    uint32_t own[32], f[30];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint4 v = *reinterpret_cast<const uint4*>(t + ((pos * 8 + q) * 16 + mine) * 4);
+      own[4 * q] = v.x; own[4 * q + 1] = v.y; own[4 * q + 2] = v.z; own[4 * q + 3] = v.w;
+    }
+    const uint32_t want = (mag - 1u) & 15u;                  // mag == 0 reads entry 15, masked below
+    const int src = (int)(((lane & ~15u) | want) << 2);
+    const uint32_t m = 0u - (uint32_t)(mag != 0);
+#pragma unroll
+    for (int i = 0; i < 30; ++i) f[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own[i]) & m;
+    const uint32_t z = (mag == 0);
+    f[0] |= z; f[10] |= z;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c.ypx.v[i] = f[i]; c.ymx.v[i] = f[10 + i]; c.xy2d.v[i] = f[20 + i]; }
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // load / store helpers (16-byte vector accesses; batches are arrays of 32- or 160-byte records)
 // ------------------------------------------------------------------------------------------------
@@ -233,6 +258,36 @@ __global__ void __launch_bounds__(64) k_base_table(uint32_t* image) {
   if (e < 512) ge_base_table_entry(image, e >> 3, e & 7);
 }
 
+__global__ void __launch_bounds__(64) k_base_table32(uint32_t* image) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // 0..831
+  if (e < KYB_BASE32_POS * 16) ge_base32_table_entry(image, e >> 4, e & 15);
+}
+
+// Fixed base, signed radix 32: one 1024-thread workgroup per CU shares the 106,496-byte table in LDS
+// (4 waves per SIMD, <= 128 VGPRs); 52 mixed additions per item.
+constexpr int KYB_BLOCK32 = 1024;
+template <bool SPLIT>
+__global__ void __launch_bounds__(KYB_BLOCK32, 4)
+k_mul_base32(const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
+             const uint4* __restrict__ table_image, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
+  __shared__ uint4 lds_tbl[KYB_BASE32_TABLE_WORDS / 4];
+  for (int k = threadIdx.x; k < KYB_BASE32_TABLE_WORDS / 4; k += KYB_BLOCK32) lds_tbl[k] = table_image[k];
+  __syncthreads();
+  tbl_lds32 tbl{reinterpret_cast<const uint32_t*>(lds_tbl)};
+  const size_t nchunks = (n + KYB_BLOCK32 - 1) / KYB_BLOCK32;
+  for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const size_t i = chunk * KYB_BLOCK32 + threadIdx.x;
+    const bool live = i < n;
+    const size_t ii = live ? i : 0;
+    uint32_t a[8];
+    load_words8(a, scalars, ii);
+    ge_p3 h;
+    ge_scalarmult_base32(h, a, tbl);
+    if (SPLIT) { if (live) store_proj(proj, proj_stride, proj_offset + i, h.X, h.Y, h.Z); }
+    else finish_point(h.X, h.Y, h.Z, out_enc, out_ext, ii, live);
+  }
+}
+
 // Variable base.  Persistent grid: block b handles chunks b, b+grid, ...; its four waves own four
 // table slots of the workspace for the whole launch.  SPLIT: leave the result projective in `proj`
 // for k_finish (one field inversion per FINISH_K items instead of one per item).
@@ -277,8 +332,8 @@ template <int MODE, int BLOCK, bool SPLIT>
 __global__ void __launch_bounds__(BLOCK, BLOCK == 512 ? 4 : 2)
 k_mul_base(const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
            const uint4* __restrict__ table_image, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
-  __shared__ uint4 lds_tbl[KYB_BASE_TABLE_BYTES / 16];
-  for (int k = threadIdx.x; k < (int)(KYB_BASE_TABLE_BYTES / 16); k += BLOCK) lds_tbl[k] = table_image[k];
+  __shared__ uint4 lds_tbl[KYB_BASE_TABLE_WORDS / 4];
+  for (int k = threadIdx.x; k < KYB_BASE_TABLE_WORDS / 4; k += BLOCK) lds_tbl[k] = table_image[k];
   __syncthreads();
   tbl_lds<MODE> tbl{reinterpret_cast<const uint32_t*>(lds_tbl)};
   const size_t nchunks = (n + BLOCK - 1) / BLOCK;
@@ -360,8 +415,8 @@ template <int MODE, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, 2)
 k_sign(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const uint8_t* __restrict__ msgs,
        const uint32_t* __restrict__ msg_off, size_t n, uint8_t* __restrict__ sig, const uint4* __restrict__ table_image) {
-  __shared__ uint4 lds_tbl[KYB_BASE_TABLE_BYTES / 16];
-  for (int q = threadIdx.x; q < (int)(KYB_BASE_TABLE_BYTES / 16); q += BLOCK) lds_tbl[q] = table_image[q];
+  __shared__ uint4 lds_tbl[KYB_BASE_TABLE_WORDS / 4];
+  for (int q = threadIdx.x; q < KYB_BASE_TABLE_WORDS / 4; q += BLOCK) lds_tbl[q] = table_image[q];
   __syncthreads();
   tbl_lds<MODE> tbl{reinterpret_cast<const uint32_t*>(lds_tbl)};
   const size_t nchunks = (n + BLOCK - 1) / BLOCK;
@@ -610,7 +665,7 @@ struct Ctx {
   int cus = 0;
   char name[128] = {0};
   hipStream_t stream = nullptr;
-  uint32_t* table = nullptr;      // KYB_BASE_TABLE_BYTES
+  uint32_t* table = nullptr;      // KYB_BASE_TABLE_BYTES: radix-16 image (65,536 B) followed by the radix-32 image (106,496 B)
   bool table_ready = false;
   // per-stream device scratch (two launches that overlap on different streams must not share it):
   //   ws    variable-base table workspace (fixed size)
@@ -625,7 +680,8 @@ struct Ctx {
   size_t stage_bytes = 0;
   int opt_mul_select = 1;         // 0 cndmask, 1 and/or mask
   int opt_base_select = 1;        // 0 LDS broadcast scan, 1 bpermute
-  int opt_base_block = 256;       // 256 (2 waves/SIMD) or 512 (4 waves/SIMD, 128 VGPRs)
+  int opt_base_block = 256;       // 256 (2 waves/SIMD) or 512 (4 waves/SIMD, 128 VGPRs)   [radix-16 kernel]
+  int opt_base_radix = 32;        // 32: 52-window kernel for batches >= finish.min_items; 16: always the 64-window kernel
   int opt_mul_algo = 1;           // 0 windowed table (ge.rs structure), 1 Montgomery ladder (table-free, 1.33x faster: profiles/r01/sweep_mul_algo.log)
   int opt_ladder_waves = 3;       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
   int opt_finish = 1;             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
@@ -688,6 +744,8 @@ int do_init(int device, bool build_table) {
   g.res_count = 1;
   if (build_table) {
     hipLaunchKernelGGL(k_base_table, dim3(8), dim3(64), 0, g.stream, g.table);
+    HIPCK(hipGetLastError());
+    hipLaunchKernelGGL(k_base_table32, dim3(13), dim3(64), 0, g.stream, g.table + KYB_BASE_TABLE_WORDS);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(g.stream));
     g.table_ready = true;
@@ -811,6 +869,15 @@ int launch_mul(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size
 // fixed-base multiplication of n scalars; SPLIT leaves the points in r->proj at [offset, offset + n)
 template <bool SPLIT>
 int launch_base_t(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, Ctx::StreamRes* r, size_t offset, hipStream_t st) {
+  if (g.opt_base_radix == 32 && n >= (size_t)g.opt_finish_min) {
+    const uint4* img32 = reinterpret_cast<const uint4*>(g.table + KYB_BASE_TABLE_WORDS);
+    const size_t nchunks32 = (n + KYB_BLOCK32 - 1) / KYB_BLOCK32;
+    const int grid32 = (int)(nchunks32 < (size_t)g.cus ? nchunks32 : (size_t)g.cus);     // one workgroup per CU: the table fills its LDS
+    ProfScope ps(st, KID_MUL_BASE);
+    hipLaunchKernelGGL((k_mul_base32<SPLIT>), dim3(grid32), dim3(KYB_BLOCK32), 0, st, sc, n, oenc, oext, img32, r->proj, r->proj_items, offset);
+    HIPCK(hipGetLastError());
+    return KYB_OK;
+  }
   const uint4* img = reinterpret_cast<const uint4*>(g.table);
   const int block = g.opt_base_block;
   const size_t nchunks = (n + block - 1) / block;
@@ -1279,6 +1346,7 @@ int kyb_set_option(const char* key, int value) {
   if (!strcmp(key, "mul_base.select")) { if (value < 0 || value > 1) return fail(KYB_E_BAD_ARG, "mul_base.select in {0,1}"); g.opt_base_select = value; return KYB_OK; }
   if (!strcmp(key, "mul.algo")) { if (value < 0 || value > 1) return fail(KYB_E_BAD_ARG, "mul.algo in {0 window table, 1 ladder}"); g.opt_mul_algo = value; return KYB_OK; }
   if (!strcmp(key, "mul.ladder_waves")) { if (value < 2 || value > 4) return fail(KYB_E_BAD_ARG, "mul.ladder_waves in 2..4"); g.opt_ladder_waves = value; return KYB_OK; }
+  if (!strcmp(key, "mul_base.radix")) { if (value != 16 && value != 32) return fail(KYB_E_BAD_ARG, "mul_base.radix in {16,32}"); g.opt_base_radix = value; return KYB_OK; }
   if (!strcmp(key, "mul_base.block")) { if (value != 256 && value != 512) return fail(KYB_E_BAD_ARG, "mul_base.block in {256,512}"); g.opt_base_block = value; return KYB_OK; }
   if (!strcmp(key, "finish.batched")) { if (value < 0 || value > 1) return fail(KYB_E_BAD_ARG, "finish.batched in {0,1}"); g.opt_finish = value; return KYB_OK; }
   if (!strcmp(key, "finish.min_items")) { if (value < 1) return fail(KYB_E_BAD_ARG, "finish.min_items >= 1"); g.opt_finish_min = value; return KYB_OK; }
@@ -1293,6 +1361,7 @@ int kyb_get_option(const char* key, int* value) {
   if (!strcmp(key, "mul_base.select")) { *value = g.opt_base_select; return KYB_OK; }
   if (!strcmp(key, "mul.algo")) { *value = g.opt_mul_algo; return KYB_OK; }
   if (!strcmp(key, "mul.ladder_waves")) { *value = g.opt_ladder_waves; return KYB_OK; }
+  if (!strcmp(key, "mul_base.radix")) { *value = g.opt_base_radix; return KYB_OK; }
   if (!strcmp(key, "mul_base.block")) { *value = g.opt_base_block; return KYB_OK; }
   if (!strcmp(key, "finish.batched")) { *value = g.opt_finish; return KYB_OK; }
   if (!strcmp(key, "finish.min_items")) { *value = g.opt_finish_min; return KYB_OK; }

@@ -2,12 +2,12 @@
 
 SURVEY.md §8(e): every scalar-mult is independent, so rank r of G takes the index range
 [r*N/G, (r+1)*N/G) and no data-path collective exists.  The only exchange is the base-point table
-image (65,536 B) that rank 0 builds on its GPU and broadcasts over RCCL/xGMI (backend "nccl" on ROCm);
+image (172,032 B: radix-16 and radix-32 tables) that rank 0 builds on its GPU and broadcasts over RCCL/xGMI (backend "nccl" on ROCm);
 on CPU-only hosts the same code runs over gloo with a stand-in engine (tests/test_multi_gpu_cpu.py).
 """
 from __future__ import annotations
 
-BASE_TABLE_BYTES = 65536
+BASE_TABLE_BYTES = 172032
 
 
 def shard(n_total: int, rank: int, world: int):

@@ -208,6 +208,21 @@ void hd_effective(uint8_t mag[32], int* neg, const uint8_t scalar[32]) {
   memcpy(mag, m, 32);
   *neg = (int)n;
 }
+static std::vector<uint32_t> g_base32_table;
+void hd_mul_base32(uint8_t out[32], const uint8_t scalar[32]) {
+  if (g_base32_table.empty()) {
+    g_base32_table.resize(KYB_BASE32_TABLE_WORDS);
+    for (int pos = 0; pos < KYB_BASE32_POS; ++pos)
+      for (int j = 0; j < 16; ++j) ge_base32_table_entry(g_base32_table.data(), pos, j);
+  }
+  uint32_t a[8], w[8];
+  load_words(a, scalar);
+  tbl_base32_words tbl{g_base32_table.data()};
+  ge_p3 h;
+  ge_scalarmult_base32(h, a, tbl);
+  ge_encode(w, h.X, h.Y, h.Z);
+  memcpy(out, w, 32);
+}
 void hd_recode(int8_t e[64], const uint8_t scalar[32]) {
   uint32_t a[8];
   load_words(a, scalar);

@@ -268,3 +268,19 @@ def test_ladder_path_matches_oracle(hd, oracle):
         o = B(32); hd.hd_mul_ladder(o, s, p32(pt))
         assert o.raw == oracle.mul(s, pt), (i, s.hex())
     assert hd.hd_overflows() == base
+
+
+def test_fixed_base_radix32_matches_oracle(hd, oracle):
+    """52-window signed radix-32 fixed-base multiplication (sc_effective + sc_recode32) == the
+    reference's 64-window routine, quirk scalars included"""
+    base = hd.hd_overflows()
+    rnd = random.Random(31)
+    for q in KATS["quirk_mul_base"]:
+        o = B(32); hd.hd_mul_base32(o, bytes.fromhex(q["scalar"]))
+        assert o.raw.hex() == q["out"], q["scalar"]
+    cases = [bytes([0xff] * 32), bytes([0xf8] * 32), bytes([0x10] * 32), bytes([0x84] * 32), bytes([0x42, 0x08, 0x21, 0x84, 0x10] * 6 + [0x42, 0x08])]
+    cases += [bytes(rnd.getrandbits(8) for _ in range(32)) for _ in range(200)]
+    for s in cases:
+        o = B(32); hd.hd_mul_base32(o, s)
+        assert o.raw == oracle.mul_base(s), s.hex()
+    assert hd.hd_overflows() == base

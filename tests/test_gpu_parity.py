@@ -385,3 +385,49 @@ def test_ladder_path_matches_oracle(engine, oracle, waves):
             assert np.array_equal(engine.mul(sm, pts_ext=pm), oracle.mul_batch(sm, pm, nthreads=8))
     finally:
         engine.set_option("mul.ladder_waves", 3)
+
+
+def test_fixed_base_radix32_kernel(engine, oracle):
+    """the 52-window radix-32 kernel (1024-thread workgroups, 104 KiB LDS table) == the radix-16 kernel == oracle,
+    through mul_base, sign and verify; quirk scalars included"""
+    engine.set_option("finish.min_items", 1)       # route even small batches through it
+    try:
+        qb = KATS["quirk_mul_base"]
+        qs = np.frombuffer(b"".join(bytes.fromhex(q["scalar"]) for q in qb), dtype=np.uint8)
+        for radix in (32, 16):
+            engine.set_option("mul_base.radix", radix)
+            assert [bytes(r).hex() for r in engine.mul_base(qs)] == [q["out"] for q in qb]
+            for n in (1, 1023, 1024, 1025, 3000):
+                s = np.concatenate([synth.scalars(n - n // 2, 70 + n), synth.raw256(n // 2, 70 + n)])
+                enc, ext = engine.mul_base(s, want_ext=True)
+                assert np.array_equal(enc, oracle.mul_base_batch(s, nthreads=8))
+                assert oracle.encode(ext[n // 2]) == bytes(enc[n // 2])
+            x, k = synth.scalars(700, 71, b"x"), synth.raw256(700, 71, b"k")
+            msgs = synth.messages(700, 71, length=17)
+            sig = engine.schnorr_sign(x, k, msgs)
+            assert np.array_equal(sig, oracle.schnorr_sign_batch(x, k, msgs, nthreads=8))
+            assert not engine.verify(engine.mul_base(x), msgs, sig, 1).any()
+    finally:
+        engine.set_option("mul_base.radix", 32)
+        engine.set_option("finish.min_items", 4096)
+    # table image, radix-32 part: entry (pos, j) = (j+1) * 32^pos * B
+    P = 2**255 - 19
+    img = np.frombuffer(engine.base_table().tobytes(), dtype=np.uint32)[65536 // 4:]
+    bits = [26, 25] * 5
+
+    def val(limbs):
+        v, off = 0, 0
+        for l, b in zip(limbs, bits):
+            v += int(l) << off
+            off += b
+        return v
+
+    def idx(pos, j, k):
+        return ((pos * 8 + (k >> 2)) * 16 + j) * 4 + (k & 3)
+
+    import bigint_model as M
+    for pos, j in ((0, 0), (0, 15), (1, 7), (25, 3), (50, 15), (51, 0), (51, 1)):
+        x, y = M.mul_int((j + 1) << (5 * pos), M.B)
+        assert val([img[idx(pos, j, k)] for k in range(10)]) == (y + x) % P
+        assert val([img[idx(pos, j, 10 + k)] for k in range(10)]) == (y - x) % P
+        assert val([img[idx(pos, j, 20 + k)] for k in range(10)]) == 2 * M.D * x * y % P
