@@ -406,7 +406,14 @@ def test_fixed_base_radix32_kernel(engine, oracle):
             msgs = synth.messages(700, 71, length=17)
             sig = engine.schnorr_sign(x, k, msgs)
             assert np.array_equal(sig, oracle.schnorr_sign_batch(x, k, msgs, nthreads=8))
-            assert not engine.verify(engine.mul_base(x), msgs, sig, 1).any()
+            # raw 256-bit nonces >= 2^255 lose their top digit in R = k*B (ge.rs:459) but not in s = k + x*h, so those
+            # signatures are invalid in the reference too: compare the verdicts, do not expect all-valid
+            pub = engine.mul_base(x)
+            st = engine.verify(pub, msgs, sig, 1)
+            assert np.array_equal(st, oracle.verify_batch(1, pub, msgs, sig, nthreads=8))
+            assert set(st.tolist()) == {0, 9}
+            kc = synth.scalars(700, 72, b"k")
+            assert not engine.verify(pub, msgs, engine.schnorr_sign(x, kc, msgs), 1).any()
     finally:
         engine.set_option("mul_base.radix", 32)
         engine.set_option("finish.min_items", 4096)
