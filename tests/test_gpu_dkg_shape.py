@@ -1,0 +1,48 @@
+"""The batch entry points at the shape a Pedersen DKG round uses them:
+n dealers each commit to a degree-(t-1) polynomial (PriPoly::commit, poly.rs:195-206 -> one fixed-base
+batch), every verifier checks every dealer's share against the public polynomial
+(vss.rs:904-909: fig = mul(fi, None); PubPoly::eval(i) == fig), and the distributed public key is
+the sum of the constant-term commitments (dkg.rs:905-953).  Everything runs on the GPU through the C
+ABI; a sample is re-checked against the oracle's restatement of the reference's own routines."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+L = synth.L
+
+
+def test_pedersen_round_shape(engine, oracle):
+    n, t = 24, 17
+    coeffs = synth.scalars(n * t, 90).reshape(n, t, 32)                       # dealer d, coefficient j
+    # commitments of all dealers: n*t fixed-base mults in one call
+    enc, ext = engine.mul_base(coeffs.reshape(-1, 32), want_ext=True)
+    commits = ext.reshape(n, t, 40)
+    assert np.array_equal(enc, oracle.mul_base_batch(coeffs.reshape(-1, 32), nthreads=8))
+    # private shares f_d(i) = sum_j c_dj (i+1)^j mod L  (PriPoly::eval, poly.rs:133-141; host-side scalar arithmetic)
+    ci = [[int.from_bytes(bytes(coeffs[d, j]), "little") for j in range(t)] for d in range(n)]
+    shares = np.zeros((n, n, 32), dtype=np.uint8)
+    for d in range(n):
+        for i in range(n):
+            v = sum(c * pow(i + 1, j, L) for j, c in enumerate(ci[d])) % L
+            shares[d, i] = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8)
+    # every verifier's check of every dealer: PubPoly::eval(i) on the GPU vs mul(share, None) on the GPU
+    idx = np.arange(n, dtype=np.uint32)
+    fig = engine.mul_base(shares.reshape(-1, 32)).reshape(n, n, 32)
+    for d in range(n):
+        ev = engine.pubpoly_eval(commits[d], idx)
+        assert np.array_equal(ev, fig[d])                                       # all n checks of dealer d pass
+        if d % 8 == 0:
+            for i in (0, n - 1):
+                assert bytes(ev[i]) == oracle.pubpoly_eval(commits[d], i)       # the reference's own eval
+    # a corrupted share is caught by exactly its check
+    bad = shares[3, 5].copy(); bad[0] ^= 1
+    assert bytes(engine.mul_base(bad)[0]) != bytes(engine.pubpoly_eval(commits[3], idx[5:6])[0])
+    # distributed public key: sum of the constant-term commitments == (sum of the constant terms) * B
+    acc = commits[0, 0].copy()
+    for d in range(1, n):
+        acc = engine.add(acc[None, :], commits[d, 0][None, :])[0]
+    secret = sum(ci[d][0] for d in range(n)) % L
+    assert bytes(engine.encode(acc[None, :])[0]) == oracle.mul_base(secret.to_bytes(32, "little"))
+    assert engine.equal(acc[None, :], oracle.mul_base_ext(secret.to_bytes(32, "little"))[None, :])[0] == 1

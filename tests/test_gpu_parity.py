@@ -438,3 +438,50 @@ def test_fixed_base_radix32_kernel(engine, oracle):
         assert val([img[idx(pos, j, k)] for k in range(10)]) == (y + x) % P
         assert val([img[idx(pos, j, 10 + k)] for k in range(10)]) == (y - x) % P
         assert val([img[idx(pos, j, 20 + k)] for k in range(10)]) == 2 * M.D * x * y % P
+
+
+def test_two_streams_and_two_threads(engine, oracle):
+    """device-pointer calls on two different streams may overlap (each stream owns its staging buffers);
+    host-pointer calls from two threads are serialised by the engine — both give oracle-exact results"""
+    import threading
+    import torch
+    dev = torch.device("cuda:0")
+    n = 20000
+    s1, s2 = synth.scalars(n, 81), synth.scalars(n, 82)
+    p1 = rand_points_ext(oracle, 300, 81)
+    p2 = rand_points_ext(oracle, 300, 82)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    P1, P2 = t(np.tile(p1, (n // 300 + 1, 1))[:n]), t(np.tile(p2, (n // 300 + 1, 1))[:n])
+    S1, S2 = t(s1), t(s2)
+    O1 = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    O2 = torch.empty_like(O1)
+    B1, B2 = torch.empty_like(O1), torch.empty_like(O1)
+    st1, st2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for _ in range(3):                       # interleave launches on the two streams
+        engine.mul_dev(S1, pts_ext=P1, out_enc=O1, stream=st1.cuda_stream)
+        engine.mul_dev(S2, pts_ext=P2, out_enc=O2, stream=st2.cuda_stream)
+        engine.mul_base_dev(S1, out_enc=B1, stream=st1.cuda_stream)
+        engine.mul_base_dev(S2, out_enc=B2, stream=st2.cuda_stream)
+    torch.cuda.synchronize()
+    idx = np.arange(0, n, 37)
+    P1n, P2n = P1.cpu().numpy(), P2.cpu().numpy()
+    assert np.array_equal(O1.cpu().numpy()[idx], oracle.mul_batch(s1[idx], P1n[idx], nthreads=8))
+    assert np.array_equal(O2.cpu().numpy()[idx], oracle.mul_batch(s2[idx], P2n[idx], nthreads=8))
+    assert np.array_equal(B1.cpu().numpy()[idx], oracle.mul_base_batch(s1[idx], nthreads=8))
+    assert np.array_equal(B2.cpu().numpy()[idx], oracle.mul_base_batch(s2[idx], nthreads=8))
+    # two host threads through the host-pointer API
+    res = {}
+
+    def work(tag, s, p):
+        res[tag] = (engine.mul(s[:3000], pts_ext=np.tile(p, (10, 1))), engine.mul_base(s[:5000]))
+
+    th = [threading.Thread(target=work, args=(1, s1, p1)), threading.Thread(target=work, args=(2, s2, p2))]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert np.array_equal(res[1][0], oracle.mul_batch(s1[:3000], np.tile(p1, (10, 1)), nthreads=8))
+    assert np.array_equal(res[2][0], oracle.mul_batch(s2[:3000], np.tile(p2, (10, 1)), nthreads=8))
+    assert np.array_equal(res[1][1], oracle.mul_base_batch(s1[:5000], nthreads=8))
+    assert np.array_equal(res[2][1], oracle.mul_base_batch(s2[:5000], nthreads=8))
