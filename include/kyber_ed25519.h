@@ -17,7 +17,9 @@
  *              |even limb| <= 2^25, |odd limb| <= 2^24 — inside the reference's fe_mul/fe_add input
  *              bounds, so a returned point can be fed straight back into the CPU arithmetic.
  *   return     0 = ok; negative = KYB_E_* (nothing is written on error except where noted).
- *   threading  every call may be made from any thread; calls are serialised on the engine's stream.
+ *   threading  every call may be made from any thread: host-pointer calls are serialised on the engine's own
+ *              stream; device-pointer calls on different streams may overlap on the GPU (each stream gets its
+ *              own scratch, at most 8 streams), their launch bookkeeping is serialised internally.
  *   memory     the caller owns every buffer; the library keeps no pointer after return.
  *
  * Two flavours of every batch call:

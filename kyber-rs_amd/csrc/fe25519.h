@@ -394,25 +394,31 @@ KYB_HD void fe_from_ref10(fe& h, const int32_t s[10]) {
 KYB_HD void fe_to_ref10(int32_t s[10], const fe& f) {
   uint32_t w[8];
   fe_to_words(w, f);
-  int64_t h[10];
-  h[0] = (int64_t)w[0];                                              // bits   0..31
-  h[1] = (int64_t)(w[1] & 0xffffffu) << 6;                           // bits  32..55
-  h[2] = (int64_t)(((w[1] >> 24) | (w[2] << 8)) & 0xffffffu) << 5;   // bits  56..79
-  h[3] = (int64_t)(((w[2] >> 16) | (w[3] << 16)) & 0xffffffu) << 3;  // bits  80..103
-  h[4] = (int64_t)(w[3] >> 8) << 2;                                  // bits 104..127
-  h[5] = (int64_t)w[4];                                              // bits 128..159
-  h[6] = (int64_t)(w[5] & 0xffffffu) << 7;                           // bits 160..183
-  h[7] = (int64_t)(((w[5] >> 24) | (w[6] << 8)) & 0xffffffu) << 5;   // bits 184..207
-  h[8] = (int64_t)(((w[6] >> 16) | (w[7] << 16)) & 0xffffffu) << 4;  // bits 208..231
-  h[9] = (int64_t)((w[7] >> 8) & 0x7fffffu) << 2;                    // bits 232..254
-  const int order[10] = {9, 1, 3, 5, 7, 0, 2, 4, 6, 8};
-  KYB_UNROLL for (int k = 0; k < 10; ++k) {
-    const int i = order[k];
-    const int b = KYB_BITS(i);
-    const int64_t c = (h[i] + ((int64_t)1 << (b - 1))) >> b;
-    if (i == 9) h[0] += c * 19; else h[i + 1] += c;
-    h[i] -= c * ((int64_t)1 << b);
-  }
+  // 32-bit modular arithmetic throughout (two's complement gives the signed limbs); only limbs 0 and 5
+  // start as full 32-bit words and need a 64-bit intermediate for their rounding carry
+  uint32_t h[10];
+  h[0] = w[0];                                                       // bits   0..31
+  h[1] = (w[1] & 0xffffffu) << 6;                                    // bits  32..55
+  h[2] = (((w[1] >> 24) | (w[2] << 8)) & 0xffffffu) << 5;            // bits  56..79
+  h[3] = (((w[2] >> 16) | (w[3] << 16)) & 0xffffffu) << 3;           // bits  80..103
+  h[4] = (w[3] >> 8) << 2;                                           // bits 104..127
+  h[5] = w[4];                                                       // bits 128..159
+  h[6] = (w[5] & 0xffffffu) << 7;                                    // bits 160..183
+  h[7] = (((w[5] >> 24) | (w[6] << 8)) & 0xffffffu) << 5;            // bits 184..207
+  h[8] = (((w[6] >> 16) | (w[7] << 16)) & 0xffffffu) << 4;           // bits 208..231
+  h[9] = ((w[7] >> 8) & 0x7fffffu) << 2;                             // bits 232..254
+  // fe_from_bytes' carry order: 9, 1, 3, 5, 7, then 0, 2, 4, 6, 8 (fe.rs:79-108)
+  uint32_t c;
+  c = (h[9] + (1u << 24)) >> 25; const uint64_t h0w = (uint64_t)h[0] + 19u * c; h[9] -= c << 25;
+  c = (h[1] + (1u << 24)) >> 25; h[2] += c; h[1] -= c << 25;
+  c = (h[3] + (1u << 24)) >> 25; h[4] += c; h[3] -= c << 25;
+  c = (uint32_t)(((uint64_t)h[5] + (1u << 24)) >> 25); h[6] += c; h[5] -= c << 25;
+  c = (h[7] + (1u << 24)) >> 25; h[8] += c; h[7] -= c << 25;
+  c = (uint32_t)((h0w + (1u << 25)) >> 26); h[1] += c; h[0] = (uint32_t)h0w - (c << 26);
+  c = (h[2] + (1u << 25)) >> 26; h[3] += c; h[2] -= c << 26;
+  c = (h[4] + (1u << 25)) >> 26; h[5] += c; h[4] -= c << 26;
+  c = (h[6] + (1u << 25)) >> 26; h[7] += c; h[6] -= c << 26;
+  c = (h[8] + (1u << 25)) >> 26; h[9] += c; h[8] -= c << 26;
   KYB_UNROLL for (int i = 0; i < 10; ++i) s[i] = (int32_t)h[i];
 }
 

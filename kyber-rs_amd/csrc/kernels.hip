@@ -686,7 +686,8 @@ struct Ctx {
   int opt_ladder_waves = 3;       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
   int opt_finish = 1;             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
   int opt_finish_min = 4096;
-  std::mutex mu;
+  std::mutex mu;          // host-pointer API: staging buffer + engine stream
+  std::mutex launch_mu;   // every launch_* entry: per-stream scratch bookkeeping (calls from any thread, any stream)
 };
 Ctx g;
 
@@ -845,6 +846,7 @@ int launch_ladder_core(const uint8_t* sc, const uint8_t* penc, const int32_t* pe
 
 int launch_mul(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, hipStream_t st) {
   if (n == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
   Ctx::StreamRes* r = nullptr;
   { int rc = res_for(st, &r); if (rc) return rc; }
   if (g.opt_mul_algo == 1) {
@@ -893,6 +895,7 @@ int launch_base_t(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, Ctx
 }
 int launch_mul_base(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st) {
   if (n == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
   Ctx::StreamRes* r = nullptr;
   { int rc = res_for(st, &r); if (rc) return rc; }
   if (use_split(n)) {
@@ -904,6 +907,7 @@ int launch_mul_base(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, h
 }
 int launch_sign(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* sig, hipStream_t st) {
   if (n == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
   Ctx::StreamRes* r = nullptr;
   { int rc = res_for(st, &r); if (rc) return rc; }
   if (use_split(2 * n)) {
@@ -933,6 +937,7 @@ int launch_sign(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const u
 int launch_verify(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, const uint8_t* sigs, size_t n, int flavor,
                   uint8_t* status, hipStream_t st) {
   if (n == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
   Ctx::StreamRes* r = nullptr;
   { int rc = res_for(st, &r); if (rc) return rc; }
   int rc = ensure_proj(r, 3 * n); if (rc) return rc;
@@ -966,6 +971,7 @@ int launch_verify(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off,
 
 int launch_poly_eval(const int32_t* commits, size_t t, const uint32_t* idx, size_t n, uint32_t max_index, uint8_t* oenc, int32_t* oext, hipStream_t st) {
   if (n == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
   Ctx::StreamRes* r = nullptr;
   { int rc = res_for(st, &r); if (rc) return rc; }
   int nbits = 1;
