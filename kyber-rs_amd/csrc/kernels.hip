@@ -665,6 +665,7 @@ struct Ctx {
   int cus = 0;
   char name[128] = {0};
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // second lane of the pipelined host-pointer path
   uint32_t* table = nullptr;      // KYB_BASE_TABLE_BYTES: radix-16 image (65,536 B) followed by the radix-32 image (106,496 B)
   bool table_ready = false;
   // per-stream device scratch (two launches that overlap on different streams must not share it):
@@ -678,6 +679,8 @@ struct Ctx {
   int grid_mul = 0;
   uint8_t* stage = nullptr;       // device staging for the host-pointer API
   size_t stage_bytes = 0;
+  uint8_t* stage2 = nullptr;      // staging of the second pipeline lane
+  size_t stage2_bytes = 0;
   int opt_mul_select = 1;         // 0 cndmask, 1 and/or mask
   int opt_base_select = 1;        // 0 LDS broadcast scan, 1 bpermute
   int opt_base_block = 256;       // 256 (2 waves/SIMD) or 512 (4 waves/SIMD, 128 VGPRs)   [radix-16 kernel]
@@ -713,6 +716,65 @@ int ensure_stage(size_t bytes) {
   return KYB_OK;
 }
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+int ensure_stage2(size_t bytes) {
+  if (bytes <= g.stage2_bytes) return KYB_OK;
+  if (g.stage2) { HIPCK(hipFree(g.stage2)); g.stage2 = nullptr; g.stage2_bytes = 0; }
+  size_t want = bytes + (bytes >> 2) + 4096;
+  hipError_t e = hipMalloc(&g.stage2, want);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "staging allocation", e);
+  g.stage2_bytes = want;
+  return KYB_OK;
+}
+
+// Host-pointer batches of fixed-size records: the batch is cut into chunks that alternate between two
+// streams (each with its own staging and scratch) so that the H2D copy of chunk c+1 and the D2H copy
+// of chunk c-1 overlap the kernels of chunk c.  (Caller buffers are pageable, so the copies block the
+// calling thread; the order below is what creates the overlap.)
+struct HostArr { const void* in; void* out; size_t bytes; };    // per-item size; exactly one of in/out, or neither = absent
+constexpr size_t PIPE_MIN_ITEMS = (size_t)1 << 16;
+constexpr int PIPE_CHUNKS = 8;
+template <class Fn>
+int run_host_batch(size_t n, const HostArr* arrs, int na, Fn launch) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCK(hipSetDevice(g.device));
+  const int nchunks = n >= PIPE_MIN_ITEMS ? PIPE_CHUNKS : 1;
+  const size_t cap = (((n + nchunks - 1) / nchunks) + 1023) & ~(size_t)1023;      // items per chunk
+  size_t off[8], total = 0;
+  for (int k = 0; k < na; ++k) { off[k] = total; total += up256(arrs[k].bytes * cap); }
+  int rc = ensure_stage(total);
+  if (rc) return rc;
+  if (nchunks > 1) { rc = ensure_stage2(total); if (rc) return rc; }
+  hipStream_t streams[2] = {g.stream, g.stream2};
+  uint8_t* stages[2] = {g.stage, g.stage2};
+  auto d2h = [&](int c) -> int {
+    const int lane = c & 1;
+    const size_t lo = (size_t)c * cap, cn = (lo + cap <= n) ? cap : n - lo;
+    for (int k = 0; k < na; ++k)
+      if (arrs[k].out) HIPCK(hipMemcpyAsync(static_cast<uint8_t*>(arrs[k].out) + arrs[k].bytes * lo, stages[lane] + off[k], arrs[k].bytes * cn, hipMemcpyDeviceToHost, streams[lane]));
+    return KYB_OK;
+  };
+  int last = -1;
+  for (int c = 0; c < nchunks; ++c) {
+    const size_t lo = (size_t)c * cap;
+    if (lo >= n) break;
+    const size_t cn = (lo + cap <= n) ? cap : n - lo;
+    const int lane = c & 1;
+    if (c >= 2) HIPCK(hipStreamSynchronize(streams[lane]));      // chunk c-2 has left this lane's staging
+    uint8_t* dptr[8];
+    for (int k = 0; k < na; ++k) {
+      dptr[k] = (arrs[k].in || arrs[k].out) ? stages[lane] + off[k] : nullptr;
+      if (arrs[k].in) HIPCK(hipMemcpyAsync(dptr[k], static_cast<const uint8_t*>(arrs[k].in) + arrs[k].bytes * lo, arrs[k].bytes * cn, hipMemcpyHostToDevice, streams[lane]));
+    }
+    rc = launch(streams[lane], cn, dptr);
+    if (rc) return rc;
+    if (c >= 1) { rc = d2h(c - 1); if (rc) return rc; }
+    last = c;
+  }
+  if (last >= 0) { rc = d2h(last); if (rc) return rc; }
+  HIPCK(hipStreamSynchronize(g.stream));
+  if (nchunks > 1) HIPCK(hipStreamSynchronize(g.stream2));
+  return KYB_OK;
+}
 
 int do_init(int device, bool build_table) {
   std::lock_guard<std::mutex> lk(g.mu);
@@ -736,6 +798,7 @@ int do_init(int device, bool build_table) {
   g.cus = prop.multiProcessorCount;
   snprintf(g.name, sizeof(g.name), "%s", prop.name);
   HIPCK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  HIPCK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
   HIPCK(hipMalloc(&g.table, KYB_BASE_TABLE_BYTES));
   // persistent grids: 2 blocks of 256 threads per CU = 2 waves per SIMD (needed to saturate
   // v_mad_u64_u32 issue, profiles/r01_valu_rates_mi355x.jsonl)
@@ -1002,6 +1065,9 @@ void kyb_shutdown(void) {
   (void)hipSetDevice(g.device);
   (void)hipStreamSynchronize(g.stream);
   if (g.stage) (void)hipFree(g.stage);
+  if (g.stage2) (void)hipFree(g.stage2);
+  g.stage2 = nullptr; g.stage2_bytes = 0;
+  if (g.stream2) { (void)hipStreamSynchronize(g.stream2); (void)hipStreamDestroy(g.stream2); g.stream2 = nullptr; }
   for (int i = 0; i < g.res_count; ++i) {
     if (g.res[i].ws) (void)hipFree(g.res[i].ws);
     if (g.res[i].proj) (void)hipFree(g.res[i].proj);
@@ -1108,19 +1174,10 @@ int kyb_mul_base_batch(const uint8_t* scalars, size_t n, uint8_t* out_enc, int32
   REQUIRE_READY(); REQUIRE_TABLE();
   if (n == 0) return KYB_OK;
   if (!scalars || (!out_enc && !out_ext)) return fail(KYB_E_BAD_ARG, "null buffer");
-  std::lock_guard<std::mutex> lk(g.mu);
-  HIPCK(hipSetDevice(g.device));
-  const size_t o_sc = 0, o_enc = up256(32 * n), o_ext = o_enc + up256(32 * n), total = o_ext + up256(160 * n);
-  int rc = ensure_stage(total);
-  if (rc) return rc;
-  uint8_t* d = g.stage;
-  HIPCK(hipMemcpyAsync(d + o_sc, scalars, 32 * n, hipMemcpyHostToDevice, g.stream));
-  rc = launch_mul_base(d + o_sc, n, out_enc ? d + o_enc : nullptr, out_ext ? reinterpret_cast<int32_t*>(d + o_ext) : nullptr, g.stream);
-  if (rc) return rc;
-  if (out_enc) HIPCK(hipMemcpyAsync(out_enc, d + o_enc, 32 * n, hipMemcpyDeviceToHost, g.stream));
-  if (out_ext) HIPCK(hipMemcpyAsync(out_ext, d + o_ext, 160 * n, hipMemcpyDeviceToHost, g.stream));
-  HIPCK(hipStreamSynchronize(g.stream));
-  return KYB_OK;
+  const HostArr arrs[3] = {{scalars, nullptr, 32}, {nullptr, out_enc, 32}, {nullptr, out_ext, 160}};
+  return run_host_batch(n, arrs, 3, [&](hipStream_t st, size_t cn, uint8_t** d) {
+    return launch_mul_base(d[0], cn, d[1], reinterpret_cast<int32_t*>(d[2]), st);
+  });
 }
 int kyb_mul_batch(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, size_t n,
                   uint8_t* out_enc, int32_t* out_ext, uint8_t* ok) {
@@ -1128,23 +1185,11 @@ int kyb_mul_batch(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t*
   if (n == 0) return KYB_OK;
   if (!scalars || (!out_enc && !out_ext)) return fail(KYB_E_BAD_ARG, "null buffer");
   if ((pts_enc == nullptr) == (pts_ext == nullptr)) return fail(KYB_E_BAD_ARG, "give exactly one of pts_enc / pts_ext");
-  std::lock_guard<std::mutex> lk(g.mu);
-  HIPCK(hipSetDevice(g.device));
-  const size_t o_sc = 0, o_pt = up256(32 * n), o_enc = o_pt + up256(160 * n), o_ext = o_enc + up256(32 * n), o_ok = o_ext + up256(160 * n), total = o_ok + up256(n);
-  int rc = ensure_stage(total);
-  if (rc) return rc;
-  uint8_t* d = g.stage;
-  HIPCK(hipMemcpyAsync(d + o_sc, scalars, 32 * n, hipMemcpyHostToDevice, g.stream));
-  if (pts_enc) HIPCK(hipMemcpyAsync(d + o_pt, pts_enc, 32 * n, hipMemcpyHostToDevice, g.stream));
-  else         HIPCK(hipMemcpyAsync(d + o_pt, pts_ext, 160 * n, hipMemcpyHostToDevice, g.stream));
-  rc = launch_mul(d + o_sc, pts_enc ? d + o_pt : nullptr, pts_ext ? reinterpret_cast<const int32_t*>(d + o_pt) : nullptr, n,
-                  out_enc ? d + o_enc : nullptr, out_ext ? reinterpret_cast<int32_t*>(d + o_ext) : nullptr, ok ? d + o_ok : nullptr, g.stream);
-  if (rc) return rc;
-  if (out_enc) HIPCK(hipMemcpyAsync(out_enc, d + o_enc, 32 * n, hipMemcpyDeviceToHost, g.stream));
-  if (out_ext) HIPCK(hipMemcpyAsync(out_ext, d + o_ext, 160 * n, hipMemcpyDeviceToHost, g.stream));
-  if (ok) HIPCK(hipMemcpyAsync(ok, d + o_ok, n, hipMemcpyDeviceToHost, g.stream));
-  HIPCK(hipStreamSynchronize(g.stream));
-  return KYB_OK;
+  const HostArr arrs[6] = {{scalars, nullptr, 32}, {pts_enc, nullptr, 32}, {pts_ext, nullptr, 160},
+                           {nullptr, out_enc, 32}, {nullptr, out_ext, 160}, {nullptr, ok, 1}};
+  return run_host_batch(n, arrs, 6, [&](hipStream_t st, size_t cn, uint8_t** d) {
+    return launch_mul(d[0], d[1], reinterpret_cast<const int32_t*>(d[2]), cn, d[3], reinterpret_cast<int32_t*>(d[4]), d[5], st);
+  });
 }
 int kyb_add_batch(const int32_t* a_ext, const int32_t* b_ext, size_t n, int32_t* out_ext, int subtract) {
   REQUIRE_READY();
