@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "kyb_decode_batch", "kyb_decode_batch_dev", "kyb_schnorr_sign_batch", "kyb_schnorr_sign_batch_dev",
     "kyb_verify_batch", "kyb_verify_batch_dev", "kyb_pubpoly_eval_batch", "kyb_pubpoly_eval_batch_dev",
     "kyb_equal_batch", "kyb_equal_batch_dev",
+    "kyb_host_alloc", "kyb_host_free",
     "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
 ]
 
@@ -92,12 +93,16 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_equal_batch_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.kyb_set_option.argtypes = [ctypes.c_char_p, i32]
     lib.kyb_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32)]
+    lib.kyb_host_alloc.argtypes = [sz]
+    lib.kyb_host_alloc.restype = vp
+    lib.kyb_host_free.argtypes = [vp]
+    lib.kyb_host_free.restype = None
     lib.kyb_profile_begin.argtypes = [i32]
     lib.kyb_profile_read.argtypes = [ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_float), i32, ctypes.POINTER(i32)]
     lib.kyb_kernel_name.argtypes = [i32]
     lib.kyb_kernel_name.restype = ctypes.c_char_p
     for name in ABI_SYMBOLS:
-        if name not in ("kyb_shutdown", "kyb_last_error", "kyb_kernel_name"):
+        if name not in ("kyb_shutdown", "kyb_last_error", "kyb_kernel_name", "kyb_host_alloc", "kyb_host_free"):
             getattr(lib, name).restype = i32
     _lib = lib
     return lib
@@ -142,6 +147,27 @@ class Engine:
         v = ctypes.c_int(0)
         _check(self.lib.kyb_get_option(key.encode(), ctypes.byref(v)), f"kyb_get_option({key})")
         return v.value
+
+    def pinned_array(self, shape, dtype) -> np.ndarray:
+        """numpy array over page-locked host memory (kyb_host_alloc); freed when the array is collected"""
+        dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dt.itemsize
+        ptr = self.lib.kyb_host_alloc(nbytes)
+        if not ptr:
+            _check(-5, "kyb_host_alloc")
+        buf = (ctypes.c_uint8 * nbytes).from_address(ptr)
+        arr = np.frombuffer(buf, dtype=dt).reshape(shape)
+        lib = self.lib
+        import weakref
+        weakref.finalize(buf, lib.kyb_host_free, ctypes.c_void_p(ptr))
+        return arr
+
+    def mul_into(self, scalars, pts_ext, out_enc) -> None:
+        """kyb_mul_batch on caller-provided arrays (e.g. pinned ones); no allocation, no copy on the Python side"""
+        _check(self.lib.kyb_mul_batch(_ptr(scalars), None, _ptr(pts_ext), scalars.shape[0], _ptr(out_enc), None, None), "kyb_mul_batch")
+
+    def mul_base_into(self, scalars, out_enc) -> None:
+        _check(self.lib.kyb_mul_base_batch(_ptr(scalars), scalars.shape[0], _ptr(out_enc), None), "kyb_mul_base_batch")
 
     def profile_begin(self, max_launches: int) -> None:
         _check(self.lib.kyb_profile_begin(max_launches), "kyb_profile_begin")

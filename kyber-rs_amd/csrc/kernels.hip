@@ -1364,6 +1364,15 @@ int kyb_equal_batch(const int32_t* a_ext, const int32_t* b_ext, size_t n, uint8_
   return KYB_OK;
 }
 
+void* kyb_host_alloc(size_t bytes) {
+  if (!g.ready) { (void)fail(KYB_E_NOT_INIT, "kyb_init has not succeeded in this process"); return nullptr; }
+  void* p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) { (void)fail(KYB_E_NOMEM, "pinned host allocation", e); return nullptr; }
+  return p;
+}
+void kyb_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 int kyb_profile_begin(int max_launches) {
   REQUIRE_READY();
   if (max_launches < 0 || max_launches > 65536) return fail(KYB_E_BAD_ARG, "max_launches out of range");

@@ -14,7 +14,17 @@ for name, fn in (("mul_base", lambda: eng.mul_base(s)), ("mul(ext in)", lambda: 
     for _ in range(3): out = fn()
     dt = (time.perf_counter() - t) / 3
     print(f"{name:12s} n=2^20 host-pointer API: {dt*1e3:8.2f} ms  -> {n/dt:.3e} items/s")
+# the same with batch buffers in pinned memory (kyb_host_alloc)
+ps = eng.pinned_array((n, 32), np.uint8); ps[:] = s
+pe = eng.pinned_array((n, 40), np.int32); pe[:] = ext
+po = eng.pinned_array((n, 32), np.uint8)
+for name, fn in (("mul_base", lambda: eng.mul_base_into(ps, po)), ("mul(ext in)", lambda: eng.mul_into(ps, pe, po))):
+    fn(); t = time.perf_counter()
+    for _ in range(3): fn()
+    dt = (time.perf_counter() - t) / 3
+    print(f"{name:12s} n=2^20 host-pointer API, pinned buffers: {dt*1e3:8.2f} ms  -> {n/dt:.3e} items/s")
 idx = rng.choice(n, 512, replace=False)
+assert np.array_equal(po[idx], orc.mul_batch(s[idx], ext[idx], nthreads=8))
 assert np.array_equal(eng.mul(s, pts_ext=ext)[idx], orc.mul_batch(s[idx], ext[idx], nthreads=8))
 assert np.array_equal(eng.mul_base(s)[idx], orc.mul_base_batch(s[idx], nthreads=8))
 print("parity ok")
