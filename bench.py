@@ -35,6 +35,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # (46,980) + variable-base (188,640) + add (900) + eq = 2 encodes (2 x 15,270)
 PRODUCTS = {"mul": 203_910, "mul_base": 62_250, "sign": 124_500, "verify": 329_600}
 PRODUCTS_DOMINANT = {"k_mul": 188_640, "k_mul_ladder": 188_640, "k_mul_base": 46_980, "k_sign": 124_500}
+# multiply-adds the kernels of THIS repository actually execute per item (the algorithms differ from the
+# reference's: 256-step ladder; 52 radix-32 or 64 radix-16 mixed additions) — reported next to the
+# algorithmic figure so that `frac` (algorithmic, may exceed 1 where less work is done) is not mistaken
+# for pipe utilisation
+EXECUTED = {"k_mul": 188_640, "k_mul_ladder": 256 * (5 * 100 + 4 * 55 + 10) + 2_300, "k_mul_base": {32: 52 * 700, 16: 64 * 700}, "k_sign": 2 * 64 * 700 + 15_270}
 ALG_BYTES = {"mul": 32 + 160 + 32, "mul_base": 32 + 32, "sign": 32 + 32 + 32 + 64, "verify": 32 + 64 + 32 + 1}
 UNIT = {"mul": "variable-base scalar-mults/s", "mul_base": "fixed-base scalar-mults/s", "sign": "signatures/s", "verify": "verifications/s"}
 DOMINANT = {"mul": "k_mul_ladder", "mul_base": "k_mul_base", "sign": "k_mul_base", "verify": "k_mul_ladder"}
@@ -220,6 +225,9 @@ def main():
         items_per_launch = n * (2 if wl == "sign" and dom == "k_mul_base" else 1) / launches_per_step
         dom_products = PRODUCTS_DOMINANT.get(dom, PRODUCTS[wl]) if eng.get_option("finish.batched") and n >= eng.get_option("finish.min_items") else PRODUCTS[wl]
         mad_rate = dom_products * items_per_launch / (dom_ms * 1e-3)
+        executed = EXECUTED.get(dom, dom_products)
+        if isinstance(executed, dict):
+            executed = executed[eng.get_option("mul_base.radix") if n >= eng.get_option("finish.min_items") else 16]
         avg_step_ms = sum(step_ms) / len(step_ms)
         # HBM/fabric bytes per launch from the PMC passes of the same command (profiles/, FETCH_SIZE x2 + WRITE_SIZE)
         traffic = None
@@ -237,11 +245,12 @@ def main():
                                     "sign": "2^18 Schnorr signs, 32-byte messages, 64-byte signatures out",
                                     "verify": "2^20 Schnorr verifications with the reference's checks, 32-byte messages, status bytes out"}[wl] if not args.n else f"{wl} x {n} per GPU",
                        "items_per_gpu": n, "sharding": f"independent shards x{world}, no data-path collective; one RCCL table broadcast at init",
-                       "options": {k_: eng.get_option(k_) for k_ in ("mul.algo", "mul.ladder_waves", "mul.select", "mul_base.select", "mul_base.block", "finish.batched", "finish.min_items")}},
+                       "options": {k_: eng.get_option(k_) for k_ in ("mul.algo", "mul.ladder_waves", "mul.select", "mul_base.radix", "mul_base.select", "mul_base.block", "finish.batched", "finish.min_items")}},
             "roofline": {"bound": "valu-int", "kernel": dom, "achieved": round(mad_rate / 1e12, 3), "peak": PEAK_MAD_PER_S / 1e12,
                          "unit": "T(32x32+64 mad)/s", "frac": round(mad_rate / PEAK_MAD_PER_S, 4),
                          "algorithmic_mads_per_item": dom_products, "items_per_launch": int(items_per_launch),
                          "avg_launch_ms": round(dom_ms, 4), "launches_timed": len(per_kernel[dom]),
+                         "executed_mads_per_item": executed, "executed_frac": round(executed * items_per_launch / (dom_ms * 1e-3) / PEAK_MAD_PER_S, 4),
                          "traffic": traffic,
                          "step": {"avg_step_ms": round(avg_step_ms, 4), "kernels_ms": {k_: round(sum(v_) / args.steps, 4) for k_, v_ in per_kernel.items()},
                                   "algorithmic_mads_per_item": PRODUCTS[wl],

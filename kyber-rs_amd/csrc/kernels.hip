@@ -350,6 +350,21 @@ k_mul_base(const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ 
   }
 }
 
+// Montgomery's trick over K values with the running prefixes held in locals of a template recursion (an
+// indexed `fe pre[K]` array ends up in scratch): level T multiplies d_T onto the prefix, the innermost level
+// inverts once, and on the way back every level peels its own 1/d_T off.
+//   load(t, d)   supplies d_t (already forced non-zero)        emit(t, dinv)   consumes 1/d_t
+template <int T, int K, class Load, class Emit>
+__device__ __forceinline__ void batch_invert(const fe& prefix_prev, fe& inv_prev, Load& load, Emit& emit) {
+  fe d, pre, inv, di;
+  load(T, d);
+  if (T == 0) fe_copy(pre, d); else fe_mul(pre, prefix_prev, d);
+  if constexpr (T + 1 < K) batch_invert<T + 1, K>(pre, inv, load, emit); else fe_invert(inv, pre);
+  if (T == 0) fe_copy(di, inv); else fe_mul(di, inv, prefix_prev);
+  emit(T, di);
+  if (T > 0) { load(T, d); fe_mul(inv_prev, inv, d); }
+}
+
 // Batched finish: lane j owns items j, j+M, ..., j+(K-1)M (M = ceil(n/K)) and inverts the product of
 // their Z's once (Montgomery's trick): 3(K-1) M + one inversion per K items instead of 254 S + 11 M
 // per item.  A zero Z (only reachable from invalid extended inputs) is replaced by 1 in the product
@@ -361,53 +376,39 @@ k_finish(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __res
   const size_t M = (n + FINISH_K - 1) / FINISH_K;
   const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (j >= M) return;
-  fe pre[FINISH_K];
-  uint32_t nz[FINISH_K];
-  fe one;
-  fe_one(one);
-#pragma unroll
-  for (int t = 0; t < FINISH_K; ++t) {
+  auto load = [&](int t, fe& z) {
     const size_t i = j + (size_t)t * M;
-    fe z;
+    fe one;
+    fe_one(one);
     if (i < n) load_proj_z(z, proj, stride, i); else fe_one(z);
-    nz[t] = fe_is_nonzero(z);
-    fe_cmov(z, one, 1u - nz[t]);
-    if (t == 0) fe_copy(pre[0], z); else fe_mul(pre[t], pre[t - 1], z);
-  }
-  fe inv;
-  fe_invert(inv, pre[FINISH_K - 1]);
-#pragma unroll
-  for (int t = FINISH_K - 1; t >= 0; --t) {
+    fe_cmov(z, one, 1u - fe_is_nonzero(z));
+  };
+  auto emit = [&](int t, const fe& zinv) {
     const size_t i = j + (size_t)t * M;
-    const bool live = i < n;
-    fe zi, z;
-    if (t > 0) {
-      fe_mul(zi, inv, pre[t - 1]);
-      if (live) load_proj_z(z, proj, stride, i); else fe_one(z);
-      fe_cmov(z, one, 1u - nz[t]);
-      fe_mul(inv, inv, z);
-    } else {
-      fe_copy(zi, inv);
-    }
-    fe zero;
-    fe_zero(zero);
-    fe_cmov(zi, zero, 1u - nz[t]);
-    fe X, Y, x, y;
-    if (live) load_proj_xy(X, Y, proj, stride, i); else { fe_zero(X); fe_one(Y); }
+    if (i >= n) return;
+    fe z, zi, zero, one, X, Y, x, y;
+    fe_zero(zero); fe_one(one);
+    load_proj_z(z, proj, stride, i);
+    fe_copy(zi, zinv);
+    fe_cmov(zi, zero, 1u - fe_is_nonzero(z));          // Z == 0: the reference's 0^(p-2) = 0
+    load_proj_xy(X, Y, proj, stride, i);
     fe_mul(x, X, zi);
     fe_mul(y, Y, zi);
     if (out_enc != nullptr) {
       uint32_t w[8];
       fe_to_words(w, y);
       w[7] ^= fe_is_negative(x) << 31;
-      if (live) store_words8(out_enc, i, w);
+      store_words8(out_enc, i, w);
     }
     if (out_ext != nullptr) {
       fe tt;
       fe_mul(tt, x, y);
-      if (live) store_ext(out_ext, i, x, y, one, tt);
+      store_ext(out_ext, i, x, y, one, tt);
     }
-  }
+  };
+  fe unused_prefix, unused_inv;
+  fe_one(unused_prefix);
+  batch_invert<0, FINISH_K>(unused_prefix, unused_inv, load, emit);
 }
 
 // fused signing kernel (small batches)
@@ -482,37 +483,31 @@ k_mont_prep(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ p
   const size_t M = (n + FINISH_K - 1) / FINISH_K;
   const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (j >= M) return;
-  fe pre[FINISH_K];
-  uint32_t flags[FINISH_K];
-#pragma unroll
-  for (int t = 0; t < FINISH_K; ++t) {
+  auto load = [&](int t, fe& d) {
     const size_t i = j + (size_t)t * M;
-    fe d;
-    if (i < n) { ge_p3 P; load_ext(P, pts_ext, i); mont_prep_den(d, flags[t], P); }
-    else { fe_one(d); flags[t] = 1; }
-    if (t == 0) fe_copy(pre[0], d); else fe_mul(pre[t], pre[t - 1], d);
-  }
-  fe inv;
-  fe_invert(inv, pre[FINISH_K - 1]);
-#pragma unroll
-  for (int t = FINISH_K - 1; t >= 0; --t) {
+    if (i < n) { ge_p3 P; uint32_t fl; load_ext(P, pts_ext, i); mont_prep_den(d, fl, P); }
+    else fe_one(d);
+  };
+  auto emit = [&](int t, const fe& dinv) {
     const size_t i = j + (size_t)t * M;
-    if (i >= n) continue;                       // tail items carry d = 1: nothing to divide out
+    if (i >= n) return;
     ge_p3 P;
     load_ext(P, pts_ext, i);
-    fe d, di;
+    fe d;
     uint32_t fl;
     mont_prep_den(d, fl, P);
-    if (t > 0) { fe_mul(di, inv, pre[t - 1]); fe_mul(inv, inv, d); } else fe_copy(di, inv);
     mont_point m;
-    mont_prep_finish(m, P, di, fl);
+    mont_prep_finish(m, P, dinv, fl);
     uint32_t f[24];
 #pragma unroll
     for (int k = 0; k < 10; ++k) { f[k] = m.u.v[k]; f[10 + k] = m.v.v[k]; }
     f[20] = m.flags; f[21] = f[22] = f[23] = 0;
 #pragma unroll
     for (int q = 0; q < 6; ++q) proj[q * stride + i] = make_uint4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
-  }
+  };
+  fe unused_prefix, unused_inv;
+  fe_one(unused_prefix);
+  batch_invert<0, FINISH_K>(unused_prefix, unused_inv, load, emit);
 }
 template <int WAVES>
 __global__ void __launch_bounds__(KYB_BLOCK, WAVES)
