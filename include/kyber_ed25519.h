@@ -114,6 +114,14 @@ int kyb_schnorr_sign_batch(const uint8_t* x, const uint8_t* k, const uint8_t* ms
 int kyb_schnorr_sign_batch_dev(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* msg_off,
                                size_t n, uint8_t* sig, void* stream);
 
+/* ---- EdDSA::sign, eddsa_sig.rs:120-152 with the key expansion of curve.rs:74-87 ------------------ */
+/* seeds: n x 32.  Per item: d = SHA-512(seed), x = clamp(d[0..32)) (unreduced), prefix = d[32..64),
+ * r = SHA-512(prefix || msg) mod L, then the Schnorr equations with nonce r: sig = enc(r*B) || (r + x*h mod L),
+ * h = SHA-512(enc R || enc A || msg) mod L, A = x*B.  pub (n x 32, may be NULL) receives enc(A), the public key
+ * (`EdDSA::new`, eddsa_sig.rs:31-43).  This is the computation the reference's golden file pins. */
+int kyb_eddsa_sign_batch(const uint8_t* seeds, const uint8_t* msgs, const uint32_t* msg_off, size_t n, uint8_t* sig, uint8_t* pub);
+int kyb_eddsa_sign_batch_dev(const uint8_t* seeds, const uint8_t* msgs, const uint32_t* msg_off, size_t n, uint8_t* sig, uint8_t* pub, void* stream);
+
 /* ---- signature verification with the reference's checks --------------------- */
 /* eddsa::verify_with_checks (eddsa_sig.rs:159-212, flavor 0) / schnorr::verify_with_checks
  * (schnorr_sig.rs:53-110, flavor 1): s*B == R + SHA-512(R || A || msg)*A after the canonical and

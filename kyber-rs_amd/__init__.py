@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "kyb_mul_base_batch", "kyb_mul_base_batch_dev", "kyb_mul_batch", "kyb_mul_batch_dev",
     "kyb_add_batch", "kyb_add_batch_dev", "kyb_encode_batch", "kyb_encode_batch_dev",
     "kyb_decode_batch", "kyb_decode_batch_dev", "kyb_schnorr_sign_batch", "kyb_schnorr_sign_batch_dev",
+    "kyb_eddsa_sign_batch", "kyb_eddsa_sign_batch_dev",
     "kyb_verify_batch", "kyb_verify_batch_dev", "kyb_pubpoly_eval_batch", "kyb_pubpoly_eval_batch_dev",
     "kyb_equal_batch", "kyb_equal_batch_dev",
     "kyb_host_alloc", "kyb_host_free",
@@ -85,6 +86,8 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_decode_batch_dev.argtypes = [vp, sz, vp, vp, vp]
     lib.kyb_schnorr_sign_batch.argtypes = [vp, vp, vp, vp, sz, vp]
     lib.kyb_schnorr_sign_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+    lib.kyb_eddsa_sign_batch.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.kyb_eddsa_sign_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     lib.kyb_verify_batch.argtypes = [vp, vp, vp, vp, sz, i32, vp]
     lib.kyb_verify_batch_dev.argtypes = [vp, vp, vp, vp, sz, i32, vp, vp]
     lib.kyb_pubpoly_eval_batch.argtypes = [vp, sz, vp, sz, vp, vp]
@@ -240,6 +243,18 @@ class Engine:
         sig = np.empty((n, 64), dtype=np.uint8)
         _check(self.lib.kyb_schnorr_sign_batch(_ptr(xs), _ptr(ks), _ptr(blob), _ptr(off), n, _ptr(sig)), "kyb_schnorr_sign_batch")
         return sig
+
+    def eddsa_sign(self, seeds, msgs: Sequence[bytes], want_pub: bool = False):
+        """EdDSA::sign for (seed, msg) pairs; optionally also the public keys"""
+        sd = _u8(seeds, 32, "seeds")
+        n = sd.shape[0]
+        off = np.zeros(n + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64).astype(np.uint32)
+        blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()
+        sig = np.empty((n, 64), dtype=np.uint8)
+        pub = np.empty((n, 32), dtype=np.uint8) if want_pub else None
+        _check(self.lib.kyb_eddsa_sign_batch(_ptr(sd), _ptr(blob), _ptr(off), n, _ptr(sig), _ptr(pub)), "kyb_eddsa_sign_batch")
+        return (sig, pub) if want_pub else sig
 
     def verify(self, pubs, msgs: Sequence[bytes], sigs, flavor: int = 0) -> np.ndarray:
         """status per item (0 = valid); flavor 0 = eddsa::verify_with_checks order, 1 = schnorr order"""

@@ -434,6 +434,21 @@ k_sign(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const uint8
   }
 }
 
+// EdDSA front end: secret scalar and deterministic nonce of every (seed, msg) pair (curve.rs:74-87,
+// eddsa_sig.rs:120-131); the signing pipeline proper follows
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_eddsa_prep(const uint8_t* __restrict__ seeds, const uint8_t* __restrict__ msgs, const uint32_t* __restrict__ msg_off, size_t n,
+             uint8_t* __restrict__ xbuf, uint8_t* __restrict__ kbuf) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t seed[8], x[8], r[8];
+  load_words8(seed, seeds, i);
+  const uint32_t off = msg_off[i], len = msg_off[i + 1] - off;
+  eddsa_expand_and_nonce(x, r, seed, msgs + off, len);
+  store_words8(xbuf, i, x);
+  store_words8(kbuf, i, r);
+}
+
 // split signing, last stage: enc holds enc(R_i) at record i and enc(A_i) at record n + i (produced by
 // two split fixed-base launches + k_finish); h = SHA-512(R || A || msg) mod L, s = k + x h mod L.
 __global__ void __launch_bounds__(KYB_BLOCK)
@@ -638,8 +653,8 @@ namespace {
 thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
-enum KernelId { KID_MUL = 0, KID_MUL_BASE = 1, KID_FINISH = 2, KID_SIGN = 3, KID_SIGN_HASH = 4, KID_VERIFY_PREP = 5, KID_VERIFY_FINAL = 6, KID_POLY_EVAL = 7, KID_MONT_PREP = 8, KID_MUL_LADDER = 9, KID_DECODE = 10, KID_COUNT = 11 };
-const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval", "k_mont_prep", "k_mul_ladder", "k_decode"};
+enum KernelId { KID_EDDSA_PREP = 11, KID_MUL = 0, KID_MUL_BASE = 1, KID_FINISH = 2, KID_SIGN = 3, KID_SIGN_HASH = 4, KID_VERIFY_PREP = 5, KID_VERIFY_FINAL = 6, KID_POLY_EVAL = 7, KID_MONT_PREP = 8, KID_MUL_LADDER = 9, KID_DECODE = 10, KID_COUNT = 12 };
+const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval", "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   bool on = false;
@@ -991,6 +1006,26 @@ int launch_sign(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const u
   return KYB_OK;
 }
 
+// EdDSA::sign for n (seed, msg) pairs: expansion + nonce, then the Schnorr pipeline; optionally the public keys
+int launch_eddsa_sign(const uint8_t* seeds, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* sig, uint8_t* pub, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  uint8_t *xbuf = nullptr, *kbuf = nullptr;
+  {
+    std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+    Ctx::StreamRes* r = nullptr;
+    int rc = res_for(st, &r); if (rc) return rc;
+    // the signing pipeline uses r->enc[0, 64n) for the encodings of R and A: keep x and k behind that
+    rc = ensure_enc(r, up256(64 * n) + 2 * up256(32 * n)); if (rc) return rc;
+    xbuf = r->enc + up256(64 * n); kbuf = xbuf + up256(32 * n);
+    ProfScope ps(st, KID_EDDSA_PREP);
+    hipLaunchKernelGGL(k_eddsa_prep, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, seeds, msgs, off, n, xbuf, kbuf);
+    HIPCK(hipGetLastError());
+  }
+  int rc = launch_sign(xbuf, kbuf, msgs, off, n, sig, st); if (rc) return rc;
+  if (pub != nullptr) return launch_mul_base(xbuf, n, pub, nullptr, st);
+  return KYB_OK;
+}
+
 // verification pipeline on one stream: prep -> k_mul (h, A) -> k_mul_base (s) -> final
 int launch_verify(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, const uint8_t* sigs, size_t n, int flavor,
                   uint8_t* status, hipStream_t st) {
@@ -1260,6 +1295,37 @@ int kyb_schnorr_sign_batch(const uint8_t* x, const uint8_t* k, const uint8_t* ms
   rc = launch_sign(d + o_x, d + o_k, d + o_m, reinterpret_cast<const uint32_t*>(d + o_off), n, d + o_sig, g.stream);
   if (rc) return rc;
   HIPCK(hipMemcpyAsync(sig, d + o_sig, 64 * n, hipMemcpyDeviceToHost, g.stream));
+  HIPCK(hipStreamSynchronize(g.stream));
+  return KYB_OK;
+}
+
+int kyb_eddsa_sign_batch_dev(const uint8_t* seeds, const uint8_t* msgs, const uint32_t* msg_off, size_t n, uint8_t* sig, uint8_t* pub, void* stream) {
+  REQUIRE_READY(); REQUIRE_TABLE();
+  if (n == 0) return KYB_OK;
+  if (!seeds || !msg_off || !sig) return fail(KYB_E_BAD_ARG, "null buffer");
+  if (!aligned16(seeds) || !aligned16(sig) || !aligned16(pub)) return fail(KYB_E_BAD_ARG, "device buffers must be 16-byte aligned");
+  return launch_eddsa_sign(seeds, msgs, msg_off, n, sig, pub, pick(stream));
+}
+int kyb_eddsa_sign_batch(const uint8_t* seeds, const uint8_t* msgs, const uint32_t* msg_off, size_t n, uint8_t* sig, uint8_t* pub) {
+  REQUIRE_READY(); REQUIRE_TABLE();
+  if (n == 0) return KYB_OK;
+  if (!seeds || !msg_off || !sig) return fail(KYB_E_BAD_ARG, "null buffer");
+  const size_t mbytes = msg_off[n];
+  if (mbytes && !msgs) return fail(KYB_E_BAD_ARG, "null message buffer");
+  for (size_t i = 0; i < n; ++i) if (msg_off[i + 1] < msg_off[i]) return fail(KYB_E_BAD_ARG, "msg_off must be non-decreasing");
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCK(hipSetDevice(g.device));
+  const size_t o_s = 0, o_m = up256(32 * n), o_off = o_m + up256(mbytes + 16), o_sig = o_off + up256(4 * (n + 1)), o_pub = o_sig + up256(64 * n), total = o_pub + up256(32 * n);
+  int rc = ensure_stage(total);
+  if (rc) return rc;
+  uint8_t* d = g.stage;
+  HIPCK(hipMemcpyAsync(d + o_s, seeds, 32 * n, hipMemcpyHostToDevice, g.stream));
+  if (mbytes) HIPCK(hipMemcpyAsync(d + o_m, msgs, mbytes, hipMemcpyHostToDevice, g.stream));
+  HIPCK(hipMemcpyAsync(d + o_off, msg_off, 4 * (n + 1), hipMemcpyHostToDevice, g.stream));
+  rc = launch_eddsa_sign(d + o_s, d + o_m, reinterpret_cast<const uint32_t*>(d + o_off), n, d + o_sig, pub ? d + o_pub : nullptr, g.stream);
+  if (rc) return rc;
+  HIPCK(hipMemcpyAsync(sig, d + o_sig, 64 * n, hipMemcpyDeviceToHost, g.stream));
+  if (pub) HIPCK(hipMemcpyAsync(pub, d + o_pub, 32 * n, hipMemcpyDeviceToHost, g.stream));
   HIPCK(hipStreamSynchronize(g.stream));
   return KYB_OK;
 }

@@ -43,4 +43,26 @@ KYB_HD void schnorr_sign(uint32_t sig[16], const uint32_t x[8], const uint32_t k
   for (int i = 0; i < 8; ++i) { sig[i] = renc[i]; sig[8 + i] = s[i]; }
 }
 
+// EdDSA key expansion and deterministic nonce (curve.rs:74-87, eddsa_sig.rs:120-131):
+//   d = SHA-512(seed); x = clamp(d[0..32)) (NOT reduced mod L); prefix = d[32..64)
+//   r = SHA-512(prefix || msg) as a little-endian integer mod L
+// EdDSA::sign is then schnorr_sign(x, r, msg).
+KYB_HD void eddsa_expand_and_nonce(uint32_t x[8], uint32_t r[8], const uint32_t seed[8], const uint8_t* msg, uint32_t msg_len) {
+  sha512_ctx c;
+  uint32_t d[16];
+  sha512_init(c);
+  sha512_words32_at0(c, seed);
+  sha512_final(d, c);
+  for (int i = 0; i < 8; ++i) x[i] = d[i];
+  x[0] &= 0xfffffff8u;
+  x[7] &= 0x7fffffffu;
+  x[7] |= 0x40000000u;
+  sha512_init(c);
+  sha512_words32_at0(c, d + 8);
+  sha512_bytes(c, msg, msg_len);
+  uint32_t dig[16];
+  sha512_final(dig, c);
+  sc_reduce512(r, dig);
+}
+
 }  // namespace kyb

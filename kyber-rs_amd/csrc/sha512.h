@@ -102,6 +102,13 @@ KYB_HD void sha512_words64(sha512_ctx& c, const uint32_t w[16]) {
   c.fill = 64;
   c.total += 64;
 }
+// the same for 32 bytes (8 words): a seed or a prefix at the start of a block
+KYB_HD void sha512_words32_at0(sha512_ctx& c, const uint32_t w[8]) {
+  for (int i = 0; i < 4; ++i)
+    c.w[i] = ((uint64_t)__builtin_bswap32(w[2 * i]) << 32) | (uint64_t)__builtin_bswap32(w[2 * i + 1]);
+  c.fill = 32;
+  c.total += 32;
+}
 KYB_HD void sha512_bytes(sha512_ctx& c, const uint8_t* p, uint32_t n) {
   for (uint32_t i = 0; i < n; ++i) sha512_byte(c, p[i]);
 }

@@ -223,6 +223,15 @@ void hd_mul_base32(uint8_t out[32], const uint8_t scalar[32]) {
   ge_encode(w, h.X, h.Y, h.Z);
   memcpy(out, w, 32);
 }
+void hd_eddsa_sign(uint8_t sig[64], const uint8_t seed[32], const uint8_t* msg, uint32_t n) {
+  ensure_table();
+  uint32_t ws[8], x[8], r[8], s[16];
+  load_words(ws, seed);
+  eddsa_expand_and_nonce(x, r, ws, msg, n);
+  tbl_base_words tbl{g_base_table.data()};
+  schnorr_sign(s, x, r, msg, n, tbl);
+  memcpy(sig, s, 64);
+}
 void hd_recode(int8_t e[64], const uint8_t scalar[32]) {
   uint32_t a[8];
   load_words(a, scalar);

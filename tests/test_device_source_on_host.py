@@ -284,3 +284,12 @@ def test_fixed_base_radix32_matches_oracle(hd, oracle):
         o = B(32); hd.hd_mul_base32(o, s)
         assert o.raw == oracle.mul_base(s), s.hex()
     assert hd.hd_overflows() == base
+
+
+def test_eddsa_sign_golden_lines_device_source(hd):
+    """EdDSA::sign (key expansion + deterministic nonce + Schnorr equations) straight from (seed, msg)"""
+    for ln in gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n")[:64]:
+        p = ln.split(":")
+        seed, msg, sig = bytes.fromhex(p[0])[:32], bytes.fromhex(p[2]), bytes.fromhex(p[3])[:64]
+        o = B(64); hd.hd_eddsa_sign(o, seed, msg, len(msg))
+        assert o.raw == sig

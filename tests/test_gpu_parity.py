@@ -485,3 +485,26 @@ def test_two_streams_and_two_threads(engine, oracle):
     assert np.array_equal(res[2][0], oracle.mul_batch(s2[:3000], np.tile(p2, (10, 1)), nthreads=8))
     assert np.array_equal(res[1][1], oracle.mul_base_batch(s1[:5000], nthreads=8))
     assert np.array_equal(res[2][1], oracle.mul_base_batch(s2[:5000], nthreads=8))
+
+
+def test_eddsa_sign_golden_file_on_gpu(engine, oracle):
+    """the reference's own golden test (tests/sign/eddsa.rs:36-94) end to end on the GPU: all 1024 (seed, msg)
+    lines -> public key and signature bytes; plus the five RFC 8032 vectors"""
+    seeds, pubs, msgs, sigs = [], [], [], []
+    for ln in gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n"):
+        if ln:
+            p = ln.split(":")
+            seeds.append(bytes.fromhex(p[0])[:32]); pubs.append(bytes.fromhex(p[1])); msgs.append(bytes.fromhex(p[2])); sigs.append(bytes.fromhex(p[3])[:64])
+    for v in KATS["rfc8032"]:
+        seeds.append(bytes.fromhex(v["private"])); pubs.append(bytes.fromhex(v["public"])); msgs.append(bytes.fromhex(v["message"])); sigs.append(bytes.fromhex(v["signature"]))
+    sig, pub = engine.eddsa_sign(np.frombuffer(b"".join(seeds), dtype=np.uint8), msgs, want_pub=True)
+    assert rows(pub) == pubs
+    assert rows(sig) == sigs
+    assert not engine.verify(pub, msgs, sig, 0).any()
+    # a large batch goes through the split pipeline: spot-check against the oracle
+    n = 6000
+    sd = synth.raw256(n, 95)
+    ms = synth.messages(n, 95, length=24)
+    sig2 = engine.eddsa_sign(sd, ms)
+    for i in range(0, n, 499):
+        assert bytes(sig2[i]) == oracle.eddsa_sign(bytes(sd[i]), ms[i])
