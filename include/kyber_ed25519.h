@@ -146,6 +146,22 @@ int kyb_pubpoly_eval_batch(const int32_t* commits_ext, size_t t, const uint32_t*
 int kyb_pubpoly_eval_batch_dev(const int32_t* commits_ext, size_t t, const uint32_t* indices, size_t n, uint32_t max_index,
                                uint8_t* out_enc, int32_t* out_ext, void* stream);
 
+/* ---- recover_commit / recover_pub_poly / PubPoly::add, poly.rs:486-507, 566-634 -- */
+/* m linear combinations of t points each:  out[g] = sum_{j<t} scalars[g*t + j] * P(g, j).
+ *   shared_points == 0:  P(g, j) = pts[g*t + j]   (m*t points)   - m independent recover_commit calls
+ *                        (scalars = the Lagrange coefficients num/den of poly.rs:580-594, computed by the caller)
+ *   shared_points == 1:  P(g, j) = pts[j]         (t points)     - recover_pub_poly: coefficient g of
+ *                        sum_j L_j * y_j with scalars[g*t + j] = coefficient g of the Lagrange basis L_j
+ * Exactly one of pts_enc (32-byte encodings, decoded like kyb_mul_batch; `ok` gets one flag per POINT,
+ * failed decodes count as the neutral element) / pts_ext (reference limbs).  The reference performs the t
+ * multiplications and t additions one by one; here: one ladder launch over the m*t products and
+ * ceil(log2 t) pairwise-addition passes in HBM.  The sum is a group element, so its encoding does not
+ * depend on the order of the additions.  t = 1 degenerates to kyb_mul_batch. */
+int kyb_lincomb_batch(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, int shared_points,
+                      size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok);
+int kyb_lincomb_batch_dev(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, int shared_points,
+                          size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok, void* stream);
+
 /* ---- Point::eq, point.rs:227-241 -------------------------------------------- */
 /* eq[i] = 1 iff a[i] and b[i] are the same point (the reference compares the two encodings = two
  * inversions; here a projective cross-multiplication).  Inputs must be curve points (Z != 0). */

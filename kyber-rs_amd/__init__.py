@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "kyb_decode_batch", "kyb_decode_batch_dev", "kyb_schnorr_sign_batch", "kyb_schnorr_sign_batch_dev",
     "kyb_eddsa_sign_batch", "kyb_eddsa_sign_batch_dev",
     "kyb_verify_batch", "kyb_verify_batch_dev", "kyb_pubpoly_eval_batch", "kyb_pubpoly_eval_batch_dev",
-    "kyb_equal_batch", "kyb_equal_batch_dev",
+    "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev",
     "kyb_host_alloc", "kyb_host_free",
     "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
 ]
@@ -281,6 +281,39 @@ class Engine:
         _check(self.lib.kyb_pubpoly_eval_batch(_ptr(c), c.shape[0], _ptr(idx), n, _ptr(enc), _ptr(ext)), "kyb_pubpoly_eval_batch")
         return (enc, ext) if want_ext else enc
 
+    def lincomb(self, scalars, pts_ext=None, pts_enc=None, want_ext: bool = False, want_ok: bool = False):
+        """out[g] = sum_j scalars[g, j] * P[g, j]  (points of shape (m, t, ..)) or * P[j] (points of shape (t, ..), shared
+        by all groups) -- recover_commit / recover_pub_poly / PubPoly::add accumulation, poly.rs:486-507, 566-634"""
+        sc = np.ascontiguousarray(scalars, dtype=np.uint8)
+        if sc.ndim != 3 or sc.shape[2] != 32:
+            raise ValueError("scalars must have shape (m, t, 32)")
+        m, t = sc.shape[0], sc.shape[1]
+        if (pts_ext is None) == (pts_enc is None):
+            raise ValueError("give exactly one of pts_ext / pts_enc")
+        if pts_ext is not None:
+            pts = np.ascontiguousarray(pts_ext, dtype=np.int32)
+            width = 40
+        else:
+            pts = np.ascontiguousarray(pts_enc, dtype=np.uint8)
+            width = 32
+        if pts.shape == (t, width):
+            shared = 1
+        elif pts.shape == (m, t, width):
+            shared = 0
+        else:
+            raise ValueError(f"points must have shape ({t}, {width}) or ({m}, {t}, {width})")
+        enc = np.empty((m, 32), dtype=np.uint8)
+        ext = np.empty((m, 40), dtype=np.int32) if want_ext else None
+        ok = np.empty((t if shared else m * t,), dtype=np.uint8) if want_ok else None
+        _check(self.lib.kyb_lincomb_batch(_ptr(sc), _ptr(pts) if pts_enc is not None else None, _ptr(pts) if pts_ext is not None else None,
+                                          shared, m, t, _ptr(enc), _ptr(ext), _ptr(ok)), "kyb_lincomb_batch")
+        out = (enc,)
+        if want_ext:
+            out += (ext,)
+        if want_ok:
+            out += (ok,)
+        return out if len(out) > 1 else enc
+
     def equal(self, a_ext, b_ext) -> np.ndarray:
         a = np.ascontiguousarray(a_ext, dtype=np.int32).reshape(-1, 40)
         b = np.ascontiguousarray(b_ext, dtype=np.int32).reshape(-1, 40)
@@ -305,6 +338,10 @@ class Engine:
     def mul_dev(self, scalars, pts_ext=None, pts_enc=None, out_enc=None, out_ext=None, ok=None, stream: int = 0) -> None:
         n = scalars.numel() // 32
         _check(self.lib.kyb_mul_batch_dev(self._dp(scalars), self._dp(pts_enc), self._dp(pts_ext), n, self._dp(out_enc), self._dp(out_ext), self._dp(ok), ctypes.c_void_p(stream)), "kyb_mul_batch_dev")
+
+    def lincomb_dev(self, scalars, m: int, t: int, pts_ext=None, pts_enc=None, shared: bool = False, out_enc=None, out_ext=None, ok=None, stream: int = 0) -> None:
+        _check(self.lib.kyb_lincomb_batch_dev(self._dp(scalars), self._dp(pts_enc), self._dp(pts_ext), int(shared), m, t,
+                                              self._dp(out_enc), self._dp(out_ext), self._dp(ok), ctypes.c_void_p(stream)), "kyb_lincomb_batch_dev")
 
     def sign_dev(self, x, k, msgs, msg_off, sig, stream: int = 0) -> None:
         n = x.numel() // 32

@@ -101,6 +101,26 @@ KYB_HD void ge_p3_to_cached(ge_cached& r, const ge_p3& p) {
   fe_mul(r.T2d, p.T, d2);
 }
 
+// (X:Y:Z) -> extended (XZ : YZ : Z^2 : XY), 3M + 1S; and the sum of two projective points through
+// the unified (complete) addition above -- the accumulation step of recover_commit (share/poly.rs:596-597)
+// when the operands come out of a scalar multiplication in projective form.
+KYB_HD void ge_p2_to_p3(ge_p3& r, const ge_p2& p) {
+  fe_mul(r.X, p.X, p.Z);
+  fe_mul(r.Y, p.Y, p.Z);
+  fe_sq(r.Z, p.Z);
+  fe_mul(r.T, p.X, p.Y);
+}
+KYB_HD void ge_p2_add(ge_p2& r, const ge_p2& a, const ge_p2& b) {
+  ge_p3 A, B;
+  ge_p2_to_p3(A, a);
+  ge_p2_to_p3(B, b);
+  ge_cached c;
+  ge_p3_to_cached(c, B);
+  ge_p1p1 t;
+  ge_add(t, A, c);
+  ge_p1p1_to_p2(r, t);
+}
+
 // conditional negation of a cached / precomputed entry (ge.rs:314-318, 354-359), neg in {0,1}
 KYB_HD void ge_cached_cneg(ge_cached& c, uint32_t neg) {
   fe nt;

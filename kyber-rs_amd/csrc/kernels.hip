@@ -369,10 +369,11 @@ __device__ __forceinline__ void batch_invert(const fe& prefix_prev, fe& inv_prev
 // their Z's once (Montgomery's trick): 3(K-1) M + one inversion per K items instead of 254 S + 11 M
 // per item.  A zero Z (only reachable from invalid extended inputs) is replaced by 1 in the product
 // and gets the reference's own answer for it (0^(p-2) = 0 -> x = y = 0), so one bad item cannot
-// disturb its K-1 neighbours.
+// disturb its K-1 neighbours.  Item i is read from record i * src_mul (src_mul = group length after a
+// segmented sum, 1 otherwise).
 constexpr int FINISH_K = 8;
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
-k_finish(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext) {
+k_finish(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, size_t src_mul) {
   const size_t M = (n + FINISH_K - 1) / FINISH_K;
   const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (j >= M) return;
@@ -380,7 +381,7 @@ k_finish(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __res
     const size_t i = j + (size_t)t * M;
     fe one;
     fe_one(one);
-    if (i < n) load_proj_z(z, proj, stride, i); else fe_one(z);
+    if (i < n) load_proj_z(z, proj, stride, i * src_mul); else fe_one(z);
     fe_cmov(z, one, 1u - fe_is_nonzero(z));
   };
   auto emit = [&](int t, const fe& zinv) {
@@ -388,10 +389,10 @@ k_finish(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __res
     if (i >= n) return;
     fe z, zi, zero, one, X, Y, x, y;
     fe_zero(zero); fe_one(one);
-    load_proj_z(z, proj, stride, i);
+    load_proj_z(z, proj, stride, i * src_mul);
     fe_copy(zi, zinv);
     fe_cmov(zi, zero, 1u - fe_is_nonzero(z));          // Z == 0: the reference's 0^(p-2) = 0
-    load_proj_xy(X, Y, proj, stride, i);
+    load_proj_xy(X, Y, proj, stride, i * src_mul);
     fe_mul(x, X, zi);
     fe_mul(y, Y, zi);
     if (out_enc != nullptr) {
@@ -526,14 +527,16 @@ k_mont_prep(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ p
 }
 template <int WAVES>
 __global__ void __launch_bounds__(KYB_BLOCK, WAVES)
-k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ proj, size_t stride) {
+k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ proj, size_t stride, size_t img_offset, size_t img_mod) {
   const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t a[8];
   load_words8(a, scalars, i);
+  // Montgomery image of the operand: record i itself, or (shared operands) record img_offset + i mod img_mod
+  const size_t src = img_mod ? img_offset + i % img_mod : i;
   uint32_t f[24];
 #pragma unroll
-  for (int q = 0; q < 6; ++q) { const uint4 v = proj[q * stride + i]; f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w; }
+  for (int q = 0; q < 6; ++q) { const uint4 v = proj[q * stride + src]; f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w; }
   mont_point m;
 #pragma unroll
   for (int k = 0; k < 10; ++k) { m.u.v[k] = f[k]; m.v.v[k] = f[10 + k]; }
@@ -541,6 +544,23 @@ k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ 
   ge_p2 r;
   ge_scalarmult_ladder(r, a, m);
   store_proj(proj, stride, i, r.X, r.Y, r.Z);
+}
+
+// One halving pass of the segmented sum behind kyb_lincomb_batch: in each of the m groups (group g
+// starts at record g * gstride and currently holds `len` partial sums) record j + half is added onto
+// record j for j < len - half.  ceil(log2 t) passes leave the group total in the group's first record.
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_pair_sum(uint4* __restrict__ proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half) {
+  const size_t cnt = len - half;
+  const size_t idx = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (idx >= m * cnt) return;
+  const size_t g = idx / cnt, j = idx - g * cnt;
+  const size_t ia = g * gstride + j, ib = ia + half;
+  ge_p2 a, b, r;
+  load_proj_xy(a.X, a.Y, proj, stride, ia); load_proj_z(a.Z, proj, stride, ia);
+  load_proj_xy(b.X, b.Y, proj, stride, ib); load_proj_z(b.Z, proj, stride, ib);
+  ge_p2_add(r, a, b);
+  store_proj(proj, stride, ia, r.X, r.Y, r.Z);
 }
 
 // verification stage 1: checks, decode R and A, h = SHA-512(R || A || msg) mod L.
@@ -653,8 +673,8 @@ namespace {
 thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
-enum KernelId { KID_EDDSA_PREP = 11, KID_MUL = 0, KID_MUL_BASE = 1, KID_FINISH = 2, KID_SIGN = 3, KID_SIGN_HASH = 4, KID_VERIFY_PREP = 5, KID_VERIFY_FINAL = 6, KID_POLY_EVAL = 7, KID_MONT_PREP = 8, KID_MUL_LADDER = 9, KID_DECODE = 10, KID_COUNT = 12 };
-const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval", "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep"};
+enum KernelId { KID_EDDSA_PREP = 11, KID_MUL = 0, KID_MUL_BASE = 1, KID_FINISH = 2, KID_SIGN = 3, KID_SIGN_HASH = 4, KID_VERIFY_PREP = 5, KID_VERIFY_FINAL = 6, KID_POLY_EVAL = 7, KID_MONT_PREP = 8, KID_MUL_LADDER = 9, KID_DECODE = 10, KID_PAIR_SUM = 12, KID_COUNT = 13 };
+const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval", "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   bool on = false;
@@ -873,10 +893,10 @@ int ensure_enc(Ctx::StreamRes* r, size_t bytes) {
 }
 inline bool use_split(size_t n) { return g.opt_finish == 1 && n >= (size_t)g.opt_finish_min; }
 
-int launch_finish(Ctx::StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st) {
+int launch_finish(Ctx::StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st, size_t src_mul = 1) {
   const size_t M = (n + FINISH_K - 1) / FINISH_K;
   ProfScope ps(st, KID_FINISH);
-  hipLaunchKernelGGL(k_finish, dim3((unsigned)((M + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, r->proj, r->proj_items, n, oenc, oext);
+  hipLaunchKernelGGL(k_finish, dim3((unsigned)((M + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, r->proj, r->proj_items, n, oenc, oext, src_mul);
   HIPCK(hipGetLastError());
   return KYB_OK;
 }
@@ -889,32 +909,57 @@ void launch_mul_t(int sel, bool enc, int grid, hipStream_t st, const uint8_t* sc
   else          { if (enc) KYB_L(1, true); else KYB_L(1, false); }
 #undef KYB_L
 }
-// leaves the results projective in r->proj[0, n): prep (batched inversion) -> 256-step ladder
-int launch_ladder_core(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* ok, Ctx::StreamRes* r, hipStream_t st) {
-  int rc = ensure_proj(r, n); if (rc) return rc;
+// leaves the results projective in r->proj[0, n): prep (batched inversion) -> 256-step ladder.
+// npts == 0: item i multiplies point i.  npts > 0: the npts points are shared, item i multiplies point
+// i mod npts (their Montgomery images live in records [n, n + npts)).
+int launch_ladder_core(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* ok, Ctx::StreamRes* r, hipStream_t st,
+                       size_t npts = 0) {
+  const size_t np = npts ? npts : n;
+  int rc = ensure_proj(r, n + npts); if (rc) return rc;
   const unsigned blocks = (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK);
   if (penc != nullptr) {           // unmarshal_binary of the operands first (ok flags; failed decodes become the neutral element)
-    rc = ensure_enc(r, 160 * n + 256); if (rc) return rc;
+    rc = ensure_enc(r, 160 * np + 256); if (rc) return rc;
     int32_t* tmp = reinterpret_cast<int32_t*>(r->enc);
     ProfScope ps(st, KID_DECODE);
-    hipLaunchKernelGGL(k_decode_or_identity, dim3(blocks), dim3(KYB_BLOCK), 0, st, penc, n, tmp, ok);
+    hipLaunchKernelGGL(k_decode_or_identity, dim3((unsigned)((np + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, penc, np, tmp, ok);
     pext = tmp;
+  } else if (ok != nullptr) {
+    HIPCK(hipMemsetAsync(ok, 1, np, st));          // extended operands are taken as they are (k_mul does the same)
   }
   HIPCK(hipGetLastError());
   {
-    const size_t M = (n + FINISH_K - 1) / FINISH_K;
+    const size_t M = (np + FINISH_K - 1) / FINISH_K;
     ProfScope ps(st, KID_MONT_PREP);
-    hipLaunchKernelGGL(k_mont_prep, dim3((unsigned)((M + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, pext, n, r->proj, r->proj_items);
+    hipLaunchKernelGGL(k_mont_prep, dim3((unsigned)((M + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, pext, np, r->proj + (npts ? n : 0), r->proj_items);
   }
   HIPCK(hipGetLastError());
   {
     ProfScope ps(st, KID_MUL_LADDER);
-    if (g.opt_ladder_waves >= 4)      hipLaunchKernelGGL((k_mul_ladder<4>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items);
-    else if (g.opt_ladder_waves == 3) hipLaunchKernelGGL((k_mul_ladder<3>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items);
-    else                              hipLaunchKernelGGL((k_mul_ladder<2>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items);
+    if (g.opt_ladder_waves >= 4)      hipLaunchKernelGGL((k_mul_ladder<4>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items, n, npts);
+    else if (g.opt_ladder_waves == 3) hipLaunchKernelGGL((k_mul_ladder<3>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items, n, npts);
+    else                              hipLaunchKernelGGL((k_mul_ladder<2>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items, n, npts);
   }
   HIPCK(hipGetLastError());
   return KYB_OK;
+}
+
+// out[g] = sum_j scalars[g*t + j] * P[g*t + j]  (shared == false)  or  * P[j]  (shared == true)
+int launch_lincomb(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, bool shared, size_t m, size_t t, uint8_t* ok,
+                   uint8_t* oenc, int32_t* oext, hipStream_t st) {
+  if (m == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  Ctx::StreamRes* r = nullptr;
+  { int rc = res_for(st, &r); if (rc) return rc; }
+  const size_t n = m * t;
+  { int rc = launch_ladder_core(sc, penc, pext, n, ok, r, st, shared ? t : 0); if (rc) return rc; }
+  for (size_t len = t; len > 1;) {
+    const size_t half = (len + 1) / 2, lanes = m * (len - half);
+    ProfScope ps(st, KID_PAIR_SUM);
+    hipLaunchKernelGGL(k_pair_sum, dim3((unsigned)((lanes + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, r->proj, r->proj_items, m, t, len, half);
+    HIPCK(hipGetLastError());
+    len = half;
+  }
+  return launch_finish(r, m, oenc, oext, st, t);
 }
 
 int launch_mul(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, hipStream_t st) {
@@ -1393,6 +1438,42 @@ int kyb_pubpoly_eval_batch(const int32_t* commits_ext, size_t t, const uint32_t*
   if (rc) return rc;
   if (out_enc) HIPCK(hipMemcpyAsync(out_enc, d + o_e, 32 * n, hipMemcpyDeviceToHost, g.stream));
   if (out_ext) HIPCK(hipMemcpyAsync(out_ext, d + o_x, 160 * n, hipMemcpyDeviceToHost, g.stream));
+  HIPCK(hipStreamSynchronize(g.stream));
+  return KYB_OK;
+}
+int kyb_lincomb_batch_dev(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, int shared_points,
+                          size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok, void* stream) {
+  REQUIRE_READY();
+  if (m == 0) return KYB_OK;
+  if (t == 0 || t > (size_t(1) << 24) || m > (size_t(1) << 28) / t) return fail(KYB_E_BAD_ARG, "m * t out of range");
+  if (!scalars || (!out_enc && !out_ext)) return fail(KYB_E_BAD_ARG, "null buffer");
+  if ((pts_enc == nullptr) == (pts_ext == nullptr)) return fail(KYB_E_BAD_ARG, "give exactly one of pts_enc / pts_ext");
+  if (!aligned16(scalars) || !aligned16(pts_enc) || !aligned16(pts_ext) || !aligned16(out_enc) || !aligned16(out_ext))
+    return fail(KYB_E_BAD_ARG, "device buffers must be 16-byte aligned");
+  return launch_lincomb(scalars, pts_enc, pts_ext, shared_points != 0, m, t, ok, out_enc, out_ext, pick(stream));
+}
+int kyb_lincomb_batch(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, int shared_points,
+                      size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok) {
+  REQUIRE_READY();
+  if (m == 0) return KYB_OK;
+  if (t == 0 || t > (size_t(1) << 24) || m > (size_t(1) << 28) / t) return fail(KYB_E_BAD_ARG, "m * t out of range");
+  if (!scalars || (!out_enc && !out_ext)) return fail(KYB_E_BAD_ARG, "null buffer");
+  if ((pts_enc == nullptr) == (pts_ext == nullptr)) return fail(KYB_E_BAD_ARG, "give exactly one of pts_enc / pts_ext");
+  std::lock_guard<std::mutex> lk(g.mu);
+  HIPCK(hipSetDevice(g.device));
+  const size_t n = m * t, np = shared_points ? t : n, pt_bytes = (pts_enc ? 32 : 160) * np;
+  const size_t o_s = 0, o_p = up256(32 * n), o_e = o_p + up256(pt_bytes), o_x = o_e + up256(32 * m), o_k = o_x + up256(160 * m), total = o_k + up256(np);
+  int rc = ensure_stage(total);
+  if (rc) return rc;
+  uint8_t* d = g.stage;
+  HIPCK(hipMemcpyAsync(d + o_s, scalars, 32 * n, hipMemcpyHostToDevice, g.stream));
+  HIPCK(hipMemcpyAsync(d + o_p, pts_enc ? static_cast<const void*>(pts_enc) : static_cast<const void*>(pts_ext), pt_bytes, hipMemcpyHostToDevice, g.stream));
+  rc = launch_lincomb(d + o_s, pts_enc ? d + o_p : nullptr, pts_enc ? nullptr : reinterpret_cast<const int32_t*>(d + o_p), shared_points != 0, m, t,
+                      ok ? d + o_k : nullptr, out_enc ? d + o_e : nullptr, out_ext ? reinterpret_cast<int32_t*>(d + o_x) : nullptr, g.stream);
+  if (rc) return rc;
+  if (out_enc) HIPCK(hipMemcpyAsync(out_enc, d + o_e, 32 * m, hipMemcpyDeviceToHost, g.stream));
+  if (out_ext) HIPCK(hipMemcpyAsync(out_ext, d + o_x, 160 * m, hipMemcpyDeviceToHost, g.stream));
+  if (ok) HIPCK(hipMemcpyAsync(ok, d + o_k, np, hipMemcpyDeviceToHost, g.stream));
   HIPCK(hipStreamSynchronize(g.stream));
   return KYB_OK;
 }

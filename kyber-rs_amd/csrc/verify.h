@@ -92,7 +92,7 @@ KYB_HD uint32_t verify_prep(uint32_t h[8], ge_p3& R, ge_p3& A, const uint32_t pu
 KYB_HD uint32_t verify_final(const fe& RX, const fe& RY, const ge_p2& hA, const ge_p2& sB) {
   ge_p3 R, H;
   fe_copy(R.X, RX); fe_copy(R.Y, RY); fe_one(R.Z); fe_mul(R.T, RX, RY);
-  fe_mul(H.X, hA.X, hA.Z); fe_mul(H.Y, hA.Y, hA.Z); fe_sq(H.Z, hA.Z); fe_mul(H.T, hA.X, hA.Y);   // P2 -> P3
+  ge_p2_to_p3(H, hA);
   ge_cached c;
   ge_p3_to_cached(c, H);
   ge_p1p1 t;

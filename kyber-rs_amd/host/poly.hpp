@@ -3,8 +3,14 @@
 //   PubPoly::eval     src/share/poly.rs:457-469                   Horner with x = i + 1
 //   PubPoly::shares   src/share/poly.rs:472-478                   eval at 0..n-1 -> one batch
 //   PubPoly::check    src/share/poly.rs:526-530                   eval(s.i) == mul(s.v, b)
+//   PubPoly::add / equal   src/share/poly.rs:486-523              one add batch / one eq batch
+//   recover_commit    src/share/poly.rs:566-603                   Lagrange at 0: one linear combination
+//   recover_pub_poly  src/share/poly.rs:607-634                   t linear combinations over shared points
+//   PriPoly::mul, minus_const, lagrange_basis   src/share/poly.rs:213-235, 313-319, 640-668   scalar side, host
 #pragma once
+#include <algorithm>
 #include <optional>
+#include <stdexcept>
 #include <vector>
 
 #include "edwards25519.hpp"
@@ -17,6 +23,9 @@ using group::edwards25519::Scalar;
 
 struct PubShare { size_t i; Point v; };
 struct PriShare { size_t i; Scalar v; };
+
+// poly.rs:671-688
+struct PolyError : std::runtime_error { using std::runtime_error::runtime_error; };
 
 class PubPoly {
  public:
@@ -46,6 +55,31 @@ class PubPoly {
     Point ps = Point().mul(s.v, b ? &*b : nullptr);
     return pv.v == ps;
   }
+  // poly.rs:486-507
+  PubPoly add(const PubPoly& q) const {
+    if (threshold() != q.threshold()) throw PolyError("different number of coefficients");
+    const size_t t = commits.size();
+    std::vector<int32_t> a(40 * t), c(40 * t), out(40 * t);
+    for (size_t j = 0; j < t; ++j) { std::memcpy(&a[40 * j], commits[j].ge, 160); std::memcpy(&c[40 * j], q.commits[j].ge, 160); }
+    group::edwards25519::detail::engine_must(kyb_add_batch(a.data(), c.data(), t, out.data(), 0), "PubPoly::add");
+    PubPoly r;
+    r.b = b;
+    r.commits.resize(t);
+    for (size_t j = 0; j < t; ++j) std::memcpy(r.commits[j].ge, &out[40 * j], 160);
+    return r;
+  }
+  // poly.rs:511-523 (compares the first threshold() commitments of both sides)
+  bool equal(const PubPoly& q) const {
+    const size_t t = commits.size();
+    if (q.commits.size() < t) throw std::out_of_range("PubPoly::equal: q has fewer commitments");   // the reference indexes q.commits[i] and panics
+    std::vector<int32_t> a(40 * t), c(40 * t);
+    std::vector<uint8_t> eq(t);
+    for (size_t j = 0; j < t; ++j) { std::memcpy(&a[40 * j], commits[j].ge, 160); std::memcpy(&c[40 * j], q.commits[j].ge, 160); }
+    group::edwards25519::detail::engine_must(kyb_equal_batch(a.data(), c.data(), t, eq.data()), "PubPoly::equal");
+    bool all = true;
+    for (uint8_t e : eq) all &= e != 0;
+    return all;
+  }
 };
 
 class PriPoly {
@@ -57,6 +91,14 @@ class PriPoly {
     Scalar xi = Scalar().set_int64(1 + (int64_t)i), v = Scalar().zero();
     for (size_t j = coeffs.size(); j-- > 0;) v = v * xi + coeffs[j];
     return PriShare{i, v};
+  }
+  // poly.rs:213-235
+  PriPoly mul(const PriPoly& q) const {
+    PriPoly r;
+    r.coeffs.assign(coeffs.size() + q.coeffs.size() - 1, Scalar().zero());
+    for (size_t i = 0; i < coeffs.size(); ++i)
+      for (size_t j = 0; j < q.coeffs.size(); ++j) r.coeffs[i + j] = r.coeffs[i + j] + coeffs[i] * q.coeffs[j];
+    return r;
   }
   // poly.rs:195-206
   PubPoly commit(const Point* base) const {
@@ -71,6 +113,107 @@ class PriPoly {
     return p;
   }
 };
+
+// poly.rs:534-563: the first t shares by index; x_i = i + 1
+struct XYCommit { std::vector<size_t> idx; std::vector<Scalar> x; std::vector<Point> y; };
+inline XYCommit xy_commit(const std::vector<std::optional<PubShare>>& shares, size_t t, size_t /*n*/) {
+  std::vector<const PubShare*> sorted;
+  for (const auto& s : shares) if (s) sorted.push_back(&*s);
+  std::stable_sort(sorted.begin(), sorted.end(), [](const PubShare* a, const PubShare* b) { return a->i < b->i; });
+  XYCommit r;
+  for (const PubShare* s : sorted) {
+    if (!r.idx.empty() && r.idx.back() == s->i) { r.y.back() = s->v; continue; }      // HashMap::insert: a repeated index overwrites
+    r.idx.push_back(s->i);
+    r.x.push_back(Scalar().set_int64((int64_t)(s->i + 1)));
+    r.y.push_back(s->v);
+    if (r.idx.size() == t) break;
+  }
+  return r;
+}
+
+namespace detail {
+// Lagrange coefficients at 0 (poly.rs:585-594): prod_{j != i} x_j / (x_j - x_i)
+inline std::vector<Scalar> lagrange_at_zero(const std::vector<Scalar>& x) {
+  std::vector<Scalar> lam(x.size());
+  for (size_t i = 0; i < x.size(); ++i) {
+    Scalar num = Scalar().one(), den = Scalar().one();
+    for (size_t j = 0; j < x.size(); ++j) {
+      if (i == j) continue;
+      num = num * x[j];
+      den = den * Scalar().sub(x[j], x[i]);
+    }
+    lam[i] = Scalar().div(num, den);
+  }
+  return lam;
+}
+inline std::vector<Point> lincomb(const std::vector<Scalar>& sc, const std::vector<Point>& pts, bool shared, size_t m, size_t t, const char* what) {
+  std::vector<uint8_t> s(32 * m * t);
+  std::vector<int32_t> p(40 * pts.size()), out(40 * m);
+  for (size_t i = 0; i < m * t; ++i) std::memcpy(&s[32 * i], sc[i].v.data(), 32);
+  for (size_t i = 0; i < pts.size(); ++i) std::memcpy(&p[40 * i], pts[i].ge, 160);
+  group::edwards25519::detail::engine_must(kyb_lincomb_batch(s.data(), nullptr, p.data(), shared ? 1 : 0, m, t, nullptr, out.data(), nullptr), what);
+  std::vector<Point> r(m);
+  for (size_t g = 0; g < m; ++g) std::memcpy(r[g].ge, &out[40 * g], 160);
+  return r;
+}
+}  // namespace detail
+
+// poly.rs:566-603
+inline Point recover_commit(const std::vector<std::optional<PubShare>>& shares, size_t t, size_t n) {
+  XYCommit xy = xy_commit(shares, t, n);
+  if (xy.x.size() < t) throw PolyError("not enough good public shares to reconstruct secret commitment");
+  if (xy.x.empty()) return Point().null();
+  return detail::lincomb(detail::lagrange_at_zero(xy.x), xy.y, false, 1, xy.x.size(), "recover_commit")[0];
+}
+// the same for many share sets in one launch (every peer's commitment of a DKG round)
+inline std::vector<Point> recover_commit_batch(const std::vector<std::vector<std::optional<PubShare>>>& sets, size_t t, size_t n) {
+  if (t == 0) return std::vector<Point>(sets.size(), Point().null());
+  std::vector<Scalar> sc;
+  std::vector<Point> pts;
+  for (const auto& shares : sets) {
+    XYCommit xy = xy_commit(shares, t, n);
+    if (xy.x.size() < t) throw PolyError("not enough good public shares to reconstruct secret commitment");
+    std::vector<Scalar> lam = detail::lagrange_at_zero(xy.x);
+    sc.insert(sc.end(), lam.begin(), lam.end());
+    pts.insert(pts.end(), xy.y.begin(), xy.y.end());
+  }
+  return detail::lincomb(sc, pts, false, sets.size(), t, "recover_commit_batch");
+}
+
+// poly.rs:313-319 (minus_const: x - c) and :640-668 (lagrange_basis)
+inline PriPoly minus_const(const Scalar& c) {
+  PriPoly p;
+  p.coeffs = {Scalar().neg(c), Scalar().one()};
+  return p;
+}
+inline PriPoly lagrange_basis(size_t i, const std::vector<Scalar>& xs) {
+  PriPoly basis;
+  basis.coeffs = {Scalar().one()};
+  Scalar acc = Scalar().one();
+  for (size_t m = 0; m < xs.size(); ++m) {
+    if (m == i) continue;
+    basis = basis.mul(minus_const(xs[m]));
+    Scalar den = Scalar().sub(xs[i], xs[m]);
+    acc = acc * Scalar().inv(den);
+  }
+  for (Scalar& c : basis.coeffs) c = c * acc;
+  return basis;
+}
+// poly.rs:607-634: sum_j L_j * y_j in point space = for every coefficient g: sum_j L_j[g] * y_j
+inline PubPoly recover_pub_poly(const std::vector<std::optional<PubShare>>& shares, size_t t, size_t n) {
+  XYCommit xy = xy_commit(shares, t, n);
+  if (xy.x.size() < t) throw PolyError("not enough good public shares to reconstruct secret commitment");
+  const size_t k = xy.x.size();
+  PubPoly r;
+  if (k == 0) return r;
+  std::vector<Scalar> sc(k * k);
+  for (size_t j = 0; j < k; ++j) {
+    PriPoly basis = lagrange_basis(j, xy.x);
+    for (size_t g = 0; g < k; ++g) sc[g * k + j] = basis.coeffs[g];
+  }
+  r.commits = detail::lincomb(sc, xy.y, true, k, k, "recover_pub_poly");
+  return r;
+}
 
 }  // namespace share
 }  // namespace kyber

@@ -624,6 +624,21 @@ void orc_pubpoly_eval(uint8_t out_enc[32], const int32_t* commits_ext, size_t t,
   p3_tobytes(out_enc, &v);
 }
 
+/* recover_commit's accumulation (share/poly.rs:579-600): acc = null; for each i: tmp = mul(c_i, Some(y_i)); acc = add(acc, tmp).
+ * (The Lagrange coefficients c_i are scalar arithmetic and are the caller's; PubPoly::add / recover_pub_poly, poly.rs:486-507,
+ * 607-634, reduce to the same sum per coefficient.) */
+void orc_lincomb(uint8_t out_enc[32], const uint8_t* scalars, const int32_t* pts_ext, size_t t) {
+  ensure();
+  ge_p3 acc, p, m; ge_cached cc; ge_p1p1 r;
+  p3_0(&acc);
+  for (size_t i = 0; i < t; i++) {
+    ext_in(&p, pts_ext + 40 * i);
+    ge_scalarmult(&m, scalars + 32 * i, &p);
+    p3_to_cached(&cc, &m); ge_addsub(&r, &acc, &cc, 0); p1p1_to_p3(&acc, &r);
+  }
+  p3_tobytes(out_enc, &acc);
+}
+
 /* ---- verification ---------------------------------------------------------------------------
  * status codes (this repo's numbering of the reference's SignatureError variants):
  *   0 valid, 1 InvalidSignatureLength, 2 SignatureNotCanonical, 3 RNotCanonical, 4 R does not decode

@@ -244,6 +244,50 @@ int main() {
     CHECK(pubh.eval(2).v == Point().mul(pp.eval(2).v, &h), "commit with an explicit base");
   }
 
+  // public recovery (poly_test.rs:140-225, 250-303): recover_commit / recover_pub_poly / add / equal
+  {
+    using namespace kyber::share;
+    const size_t n = 10, t = n / 2 + 1;
+    auto new_pri_poly = [&](size_t k) { PriPoly p; for (size_t i = 0; i < k; ++i) p.coeffs.push_back(Scalar().pick(rand)); return p; };
+    auto opt = [](const std::vector<PubShare>& v) { return std::vector<std::optional<PubShare>>(v.begin(), v.end()); };
+    PriPoly pri = new_pri_poly(t);
+    PubPoly pub = pri.commit(nullptr);
+    std::vector<std::optional<PubShare>> shares = opt(pub.shares(n));
+    CHECK(recover_commit(shares, t, n) == pub.commit(), "test_public_recovery: recover_commit");
+    CHECK(pub.equal(recover_pub_poly(shares, t, n)), "test_public_recovery: recover_pub_poly");
+    std::vector<std::optional<PubShare>> selected(shares.begin() + (n - t), shares.end());
+    CHECK(recover_commit(selected, t, t + 1) == pub.commit(), "test_public_recovery_out_index");
+    std::vector<std::optional<PubShare>> holes = shares;
+    holes[2].reset(); holes[5].reset(); holes[7].reset(); holes[8].reset();
+    CHECK(recover_commit(holes, t, n) == pub.commit(), "test_public_recovery_delete");
+    CHECK(pub.equal(recover_pub_poly(holes, t, n)), "recover_pub_poly from the surviving shares");
+    holes[1].reset();
+    std::string err;
+    try { (void)recover_commit(holes, t, n); } catch (const PolyError& e) { err = e.what(); }
+    CHECK(err == "not enough good public shares to reconstruct secret commitment", "test_public_recovery_delete_fail");
+    // batch of share sets in one launch == one by one
+    {
+      std::vector<std::vector<std::optional<PubShare>>> sets;
+      std::vector<Point> want;
+      for (int k = 0; k < 5; ++k) { PubPoly q = new_pri_poly(t).commit(nullptr); sets.push_back(opt(q.shares(n))); sets.back()[k].reset(); want.push_back(q.commit()); }
+      std::vector<Point> got = recover_commit_batch(sets, t, n);
+      for (int k = 0; k < 5; ++k) CHECK(got[k] == want[k], "recover_commit_batch");
+    }
+    // test_public_add
+    Point gp = points[5], h = points[6];
+    PriPoly p = new_pri_poly(t), q = new_pri_poly(t);
+    PubPoly pP = p.commit(&gp), qP = q.commit(&h);
+    PubPoly r = pP.add(qP);
+    CHECK(recover_commit(opt(r.shares(n)), t, n) == Point().add(pP.commit(), qP.commit()), "test_public_add");
+    err.clear();
+    try { (void)pP.add(new_pri_poly(t - 1).commit(&gp)); } catch (const PolyError& e) { err = e.what(); }
+    CHECK(err == "different number of coefficients", "PubPoly::add threshold mismatch");
+    // test_public_poly_equal
+    PubPoly p1 = new_pri_poly(t).commit(&gp), p2 = new_pri_poly(t).commit(&gp), p3 = new_pri_poly(t).commit(&gp);
+    CHECK(p1.add(p2).add(p3).equal(p1.add(p3).add(p2)), "test_public_poly_equal");
+    CHECK(!p1.equal(p2), "different polynomials are not equal");
+  }
+
   for (const Point& p : points) std::printf("POINT %s\n", p.hex().c_str());
   std::printf("S1 %s\nS2 %s\n", s1.hex().c_str(), s2.hex().c_str());
   std::printf(failures ? "FAILED %d\n" : "OK\n", failures);

@@ -201,6 +201,32 @@ void hd_mul_ladder(uint8_t out[32], const uint8_t scalar[32], const int32_t pt[4
   ge_encode(w, r.X, r.Y, r.Z);
   memcpy(out, w, 32);
 }
+// the flow of kyb_lincomb_batch for one group: t ladder multiplications, the halving passes of k_pair_sum, encode
+void hd_lincomb(uint8_t out[32], const uint8_t* scalars, const int32_t* pts, int t) {
+  std::vector<ge_p2> v((size_t)t);
+  for (int i = 0; i < t; ++i) {
+    uint32_t a[8];
+    load_words(a, scalars + 32 * i);
+    const int32_t* pt = pts + 40 * i;
+    ge_p3 P;
+    fe_from_ref10(P.X, pt); fe_from_ref10(P.Y, pt + 10); fe_from_ref10(P.Z, pt + 20); fe_from_ref10(P.T, pt + 30);
+    fe d, dinv;
+    uint32_t flags;
+    mont_prep_den(d, flags, P);
+    fe_invert(dinv, d);
+    mont_point m;
+    mont_prep_finish(m, P, dinv, flags);
+    ge_scalarmult_ladder(v[i], a, m);
+  }
+  for (size_t len = (size_t)t; len > 1;) {
+    const size_t half = (len + 1) / 2;
+    for (size_t j = 0; j < len - half; ++j) { ge_p2 r; ge_p2_add(r, v[j], v[j + half]); v[j] = r; }
+    len = half;
+  }
+  uint32_t w[8];
+  ge_encode(w, v[0].X, v[0].Y, v[0].Z);
+  memcpy(out, w, 32);
+}
 void hd_effective(uint8_t mag[32], int* neg, const uint8_t scalar[32]) {
   uint32_t a[8], m[8], n;
   load_words(a, scalar);

@@ -186,3 +186,11 @@ class Oracle:
         o = self._b(32)
         self.lib.orc_pubpoly_eval(o, _p(c), ctypes.c_size_t(c.shape[0]), ctypes.c_uint32(index))
         return o.raw
+
+    def lincomb(self, scalars, pts_ext) -> bytes:
+        sc = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        c = _i32(pts_ext).reshape(-1, 40)
+        assert sc.shape[0] == c.shape[0]
+        o = self._b(32)
+        self.lib.orc_lincomb(o, _p(sc), _p(c), ctypes.c_size_t(c.shape[0]))
+        return o.raw

@@ -293,3 +293,41 @@ def test_eddsa_sign_golden_lines_device_source(hd):
         seed, msg, sig = bytes.fromhex(p[0])[:32], bytes.fromhex(p[2]), bytes.fromhex(p[3])[:64]
         o = B(64); hd.hd_eddsa_sign(o, seed, msg, len(msg))
         assert o.raw == sig
+
+
+def test_lincomb_flow_matches_oracle(hd, oracle):
+    """kyb_lincomb_batch's flow (ladder products + pairwise halving sums) == recover_commit's one-by-one
+    accumulation (poly.rs:579-600), incl. equal / opposite / small-order / neutral operands; and Lagrange
+    interpolation of public shares at 0 gives back the secret commitment"""
+    base = hd.hd_overflows()
+    rnd = random.Random(33)
+    weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
+    for t in (1, 2, 3, 5, 8, 13):
+        sc = [bytes(rnd.getrandbits(8) for _ in range(32)) for _ in range(t)]
+        pts = [oracle.mul_base_ext(bytes(rnd.getrandbits(8) for _ in range(32))) for _ in range(t)]
+        if t >= 3:
+            pts[1] = pts[0]; sc[1] = sc[0]                         # P + P through the unified addition
+            pts[2] = oracle.add(pts[2], weak[3])                    # mixed-order operand
+        if t >= 5:
+            pts[3] = oracle.neg(pts[4]); sc[3] = sc[4]              # s P + s (-P) = neutral element
+        if t >= 8:
+            pts[5] = oracle.null(); pts[6] = weak[2]; sc[7] = bytes(32)
+        scb = b"".join(sc); ptb = np.stack(pts)
+        o = B(32); hd.hd_lincomb(o, scb, p32(ptb), t)
+        assert o.raw == oracle.lincomb(np.frombuffer(scb, dtype=np.uint8), ptb), t
+    # recover_commit: shares y_i = eval(i) of a threshold-4 public polynomial at indices {1, 3, 4, 6}
+    t = 4
+    coeffs = [rnd.randrange(M.L) for _ in range(t)]
+    xs = [i + 1 for i in (1, 3, 4, 6)]
+    ys = np.stack([oracle.mul_base_ext((sum(c * pow(x, j, M.L) for j, c in enumerate(coeffs)) % M.L).to_bytes(32, "little")) for x in xs])
+    lam = []
+    for xi in xs:
+        num = den = 1
+        for xj in xs:
+            if xj != xi:
+                num = num * xj % M.L
+                den = den * (xj - xi) % M.L
+        lam.append(num * pow(den, M.L - 2, M.L) % M.L)
+    o = B(32); hd.hd_lincomb(o, b"".join(v.to_bytes(32, "little") for v in lam), p32(ys), t)
+    assert o.raw == oracle.mul_base(coeffs[0].to_bytes(32, "little"))
+    assert hd.hd_overflows() == base

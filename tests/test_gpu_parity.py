@@ -508,3 +508,61 @@ def test_eddsa_sign_golden_file_on_gpu(engine, oracle):
     sig2 = engine.eddsa_sign(sd, ms)
     for i in range(0, n, 499):
         assert bytes(sig2[i]) == oracle.eddsa_sign(bytes(sd[i]), ms[i])
+
+
+def test_lincomb_matches_oracle(engine, oracle):
+    """kyb_lincomb_batch == recover_commit's accumulation (poly.rs:579-600) per group: own points per group,
+    shared points (recover_pub_poly shape), encoded inputs with an invalid one, group lengths that are not powers
+    of two, one long group, t = 1"""
+    rng = np.random.default_rng(60)
+    weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
+    for m, t in ((1, 1), (5, 1), (3, 2), (7, 3), (4, 13), (33, 8), (2, 100)):
+        sc = synth.scalars(m * t, 60 + t).reshape(m, t, 32).copy()
+        pts = oracle.mul_base_ext_batch(synth.scalars(m * t, 160 + t)).reshape(m, t, 40).copy()
+        if t >= 3:
+            pts[0, 1] = pts[0, 0]; sc[0, 1] = sc[0, 0]
+            pts[0, 2] = oracle.add(pts[0, 2], weak[3])
+            sc[m - 1, 0] = 0
+            sc[m - 1, 1] = np.frombuffer(bytes([255] * 32), dtype=np.uint8)
+        if t >= 8:
+            pts[1, 3] = oracle.neg(pts[1, 4]); sc[1, 3] = sc[1, 4]
+            pts[1, 5] = oracle.null(); pts[1, 6] = weak[2]
+        enc, ext = engine.lincomb(sc, pts_ext=pts, want_ext=True)
+        for g in range(m):
+            want = oracle.lincomb(sc[g], pts[g])
+            assert bytes(enc[g]) == want, (m, t, g)
+            assert oracle.encode(ext[g]) == want
+        # shared points: every group uses the points of group 0
+        enc_s = engine.lincomb(sc, pts_ext=pts[0])
+        for g in range(m):
+            assert bytes(enc_s[g]) == oracle.lincomb(sc[g], pts[0]), (m, t, g, "shared")
+    # encoded operands; one encoding does not decode -> counts as the neutral element, ok flag 0
+    m, t = 6, 5
+    sc = synth.scalars(m * t, 77).reshape(m, t, 32)
+    pts = oracle.mul_base_ext_batch(synth.scalars(m * t, 78)).reshape(m, t, 40).copy()
+    pe = np.stack([np.frombuffer(oracle.encode(p), dtype=np.uint8) for p in pts.reshape(-1, 40)]).reshape(m, t, 32).copy()
+    bad = next(bytes([v]) + bytes(31) for v in range(2, 50) if not oracle.decode(bytes([v]) + bytes(31))[1])
+    pe[2, 3] = np.frombuffer(bad, dtype=np.uint8)
+    pts[2, 3] = oracle.null()
+    enc, ok = engine.lincomb(sc, pts_enc=pe, want_ok=True)
+    assert ok.sum() == m * t - 1 and ok.reshape(m, t)[2, 3] == 0
+    for g in range(m):
+        assert bytes(enc[g]) == oracle.lincomb(sc[g], pts[g])
+    # Lagrange: recover the secret commitment of a threshold-6 polynomial from 6 of its public shares, 64 polynomials at once
+    t, m = 6, 64
+    xs = [i + 1 for i in (0, 2, 3, 5, 8, 9)]
+    lam = []
+    for xi in xs:
+        num = den = 1
+        for xj in xs:
+            if xj != xi:
+                num = num * xj % synth.L
+                den = den * (xj - xi) % synth.L
+        lam.append(num * pow(den, synth.L - 2, synth.L) % synth.L)
+    lam_b = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in lam), dtype=np.uint8).reshape(t, 32)
+    coeffs = [[int.from_bytes(bytes(c), "little") for c in synth.scalars(t, 900 + g)] for g in range(m)]
+    share_sc = b"".join((sum(c * pow(x, j, synth.L) for j, c in enumerate(cg)) % synth.L).to_bytes(32, "little") for cg in coeffs for x in xs)
+    _, share_pts = engine.mul_base(np.frombuffer(share_sc, dtype=np.uint8), want_ext=True)
+    rec = engine.lincomb(np.broadcast_to(lam_b, (m, t, 32)), pts_ext=share_pts.reshape(m, t, 40))
+    want = engine.mul_base(np.frombuffer(b"".join(cg[0].to_bytes(32, "little") for cg in coeffs), dtype=np.uint8))
+    assert np.array_equal(rec, want)
