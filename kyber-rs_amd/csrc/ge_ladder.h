@@ -93,16 +93,19 @@ KYB_HD void mont_ladder(fe& x2, fe& z2, fe& x3, fe& z3, const fe& u1, const uint
       const uint32_t bit = word >> 31;
       word <<= 1;
       swap ^= bit;
-      fe_cswap(x2, x3, swap);
-      fe_cswap(z2, z3, swap);
-      swap = bit;
-      fe a, aa, b, bb, e, c, d, da, cb, t;
+      // RFC 7748 swaps (x2,z2) <-> (x3,z3) here.  The swap only exchanges (a,b) with (c,d): da + cb is
+      // symmetric under it and da - cb merely changes sign before being squared, so the differential
+      // addition does not see it; only the two operands of the doubling need the selection.
+      fe a, aa, b, bb, e, c, d, da, cb, t, sa, sb;
       fe_add(a, x2, z2);                 // 2T
       fe_sub(b, x2, z2);                 // 3T
       fe_add(c, x3, z3);                 // 2T
       fe_sub(d, x3, z3);                 // 3T
-      fe_sq(aa, a);
-      fe_sq(bb, b);
+      fe_select(sa, a, c, swap);
+      fe_select(sb, b, d, swap);
+      swap = bit;
+      fe_sq(aa, sa);
+      fe_sq(bb, sb);
       fe_mul(da, d, a);                  // f 3T, g 2T
       fe_mul(cb, b, c);                  // f 3T, g 2T
       fe_sub(e, aa, bb);                 // 3T
