@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../kyber-rs_amd/host/edwards25519.hpp"
+#include "../../kyber-rs_amd/host/dh.hpp"
 #include "../../kyber-rs_amd/host/poly.hpp"
 #include "../../kyber-rs_amd/host/schnorr.hpp"
 
@@ -286,6 +287,24 @@ int main() {
     PubPoly p1 = new_pri_poly(t).commit(&gp), p2 = new_pri_poly(t).commit(&gp), p3 = new_pri_poly(t).commit(&gp);
     CHECK(p1.add(p2).add(p3).equal(p1.add(p3).add(p2)), "test_public_poly_equal");
     CHECK(!p1.equal(p2), "different polynomials are not equal");
+  }
+
+  // Diffie-Hellman (dh_test.rs / vss.rs:371-375): both sides derive the same pre-shared key; batch == single
+  {
+    using namespace kyber::dh;
+    Scalar a = Scalar().pick(rand);
+    Point A = Point().mul(a, nullptr);
+    std::vector<Scalar> bs; std::vector<std::vector<uint8_t>> Bs;
+    for (int i = 0; i < 9; ++i) { bs.push_back(Scalar().pick(rand)); Bs.push_back(Point().mul(bs.back(), nullptr).marshal_binary()); }
+    std::vector<std::vector<uint8_t>> pre = dh_exchange_batch({a}, Bs);
+    for (int i = 0; i < 9; ++i) {
+      CHECK(pre[i] == dh_exchange(bs[i], A).marshal_binary(), "dh_exchange_batch: a*B_i == b_i*A");
+    }
+    std::vector<std::vector<uint8_t>> badkeys = Bs;
+    badkeys[4].assign(32, 0); badkeys[4][0] = 2;                      // y = 2 is not on the curve
+    std::string err;
+    try { (void)dh_exchange_batch({a}, badkeys); } catch (const MarshallingError& e) { err = e.what(); }
+    CHECK(err == "invalid Ed25519 curve point", "dh_exchange_batch rejects an invalid remote key");
   }
 
   for (const Point& p : points) std::printf("POINT %s\n", p.hex().c_str());
