@@ -94,6 +94,8 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_pubpoly_eval_batch_dev.argtypes = [vp, sz, vp, sz, ctypes.c_uint32, vp, vp, vp]
     lib.kyb_equal_batch.argtypes = [vp, vp, sz, vp]
     lib.kyb_equal_batch_dev.argtypes = [vp, vp, sz, vp, vp]
+    lib.kyb_lincomb_batch.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp]
+    lib.kyb_lincomb_batch_dev.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp, vp]
     lib.kyb_set_option.argtypes = [ctypes.c_char_p, i32]
     lib.kyb_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32)]
     lib.kyb_host_alloc.argtypes = [sz]
@@ -342,6 +344,22 @@ class Engine:
     def lincomb_dev(self, scalars, m: int, t: int, pts_ext=None, pts_enc=None, shared: bool = False, out_enc=None, out_ext=None, ok=None, stream: int = 0) -> None:
         _check(self.lib.kyb_lincomb_batch_dev(self._dp(scalars), self._dp(pts_enc), self._dp(pts_ext), int(shared), m, t,
                                               self._dp(out_enc), self._dp(out_ext), self._dp(ok), ctypes.c_void_p(stream)), "kyb_lincomb_batch_dev")
+
+    def add_dev(self, a_ext, b_ext, out_ext, subtract: bool = False, stream: int = 0) -> None:
+        n = a_ext.numel() // 40
+        _check(self.lib.kyb_add_batch_dev(self._dp(a_ext), self._dp(b_ext), n, self._dp(out_ext), int(subtract), ctypes.c_void_p(stream)), "kyb_add_batch_dev")
+
+    def equal_dev(self, a_ext, b_ext, eq, stream: int = 0) -> None:
+        n = a_ext.numel() // 40
+        _check(self.lib.kyb_equal_batch_dev(self._dp(a_ext), self._dp(b_ext), n, self._dp(eq), ctypes.c_void_p(stream)), "kyb_equal_batch_dev")
+
+    def encode_dev(self, pts_ext, out_enc, stream: int = 0) -> None:
+        n = pts_ext.numel() // 40
+        _check(self.lib.kyb_encode_batch_dev(self._dp(pts_ext), n, self._dp(out_enc), ctypes.c_void_p(stream)), "kyb_encode_batch_dev")
+
+    def decode_dev(self, enc, out_ext, ok=None, stream: int = 0) -> None:
+        n = enc.numel() // 32
+        _check(self.lib.kyb_decode_batch_dev(self._dp(enc), n, self._dp(out_ext), self._dp(ok), ctypes.c_void_p(stream)), "kyb_decode_batch_dev")
 
     def sign_dev(self, x, k, msgs, msg_off, sig, stream: int = 0) -> None:
         n = x.numel() // 32

@@ -566,3 +566,51 @@ def test_lincomb_matches_oracle(engine, oracle):
     rec = engine.lincomb(np.broadcast_to(lam_b, (m, t, 32)), pts_ext=share_pts.reshape(m, t, 40))
     want = engine.mul_base(np.frombuffer(b"".join(cg[0].to_bytes(32, "little") for cg in coeffs), dtype=np.uint8))
     assert np.array_equal(rec, want)
+
+
+def test_cfg5_shard_2_21_linearity(engine, oracle):
+    """BASELINE config 5 hands every GPU 2^21 items.  One such shard through the device-pointer API, checked by a
+    size-independent property on ALL items - linearity, s*P + t*P == (s + t)*P with the sum formed mod L on the
+    host - plus an oracle-checked sample and the largest index's neighbours (grid tail)."""
+    import torch
+    n = (1 << 21) + 77                                   # not a multiple of any block size
+    rng = np.random.default_rng(21)
+    limbs = rng.integers(0, 1 << 63, (n, 4), dtype=np.uint64)
+    limbs[:, 3] &= (1 << 59) - 1                         # < 2^251 so that s + t < L without reduction
+    s_np = limbs.view(np.uint8).reshape(n, 32)
+    limbs_t = rng.integers(0, 1 << 63, (n, 4), dtype=np.uint64)
+    limbs_t[:, 3] &= (1 << 59) - 1
+    t_np = limbs_t.view(np.uint8).reshape(n, 32)
+    dev = torch.device("cuda:0")
+    s = torch.from_numpy(s_np.copy()).to(dev)
+    t = torch.from_numpy(t_np.copy()).to(dev)
+    # s + t as a 256-bit integer (< 2^252 < L, no reduction needed), formed with carries over 32-bit words
+    a32 = s_np.view(np.uint32).astype(np.uint64)
+    b32 = t_np.view(np.uint32).astype(np.uint64)
+    c = np.zeros(n, dtype=np.uint64)
+    st32 = np.empty((n, 8), dtype=np.uint32)
+    for j in range(8):
+        v = a32[:, j] + b32[:, j] + c
+        st32[:, j] = (v & 0xFFFFFFFF).astype(np.uint32)
+        c = v >> np.uint64(32)
+    assert not c.any()
+    st_np = st32.view(np.uint8).reshape(n, 32)
+    st = torch.from_numpy(st_np).to(dev)
+    pts = torch.empty((n, 40), dtype=torch.int32, device=dev)
+    engine.mul_base_dev(t, out_ext=pts)                  # P_i = t_i * B
+    sp = torch.empty((n, 40), dtype=torch.int32, device=dev)
+    tp = torch.empty((n, 40), dtype=torch.int32, device=dev)
+    stp = torch.empty((n, 40), dtype=torch.int32, device=dev)
+    engine.mul_dev(s, pts_ext=pts, out_ext=sp)
+    engine.mul_dev(t, pts_ext=pts, out_ext=tp)
+    engine.mul_dev(st, pts_ext=pts, out_ext=stp)
+    summed = torch.empty_like(sp)
+    eq = torch.empty((n,), dtype=torch.uint8, device=dev)
+    engine.add_dev(sp, tp, summed)
+    engine.equal_dev(summed, stp, eq)
+    engine.sync()
+    assert int(eq.sum().item()) == n
+    idx = np.concatenate([rng.choice(n, 1024, replace=False), [0, n - 1, n - 2, (1 << 21) - 1, 1 << 21]])
+    want = oracle.mul_batch(s_np[idx], pts[idx].cpu().numpy(), nthreads=8)
+    got = engine.encode(sp[idx].cpu().numpy())
+    assert np.array_equal(got, want)
