@@ -1,0 +1,216 @@
+// Device-side table policies and memory helpers of the engine (included by kernels.hip only).
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// device table policies
+// ------------------------------------------------------------------------------------------------
+
+// Variable-base table of one wave: uint4 [8 entries][10 quads][64 lanes] = 81,920 B.
+// A cached point is 40 dwords: YpX[10] YmX[10] Z[10] T2d[10] -> 10 quads.
+// MASKED = 0: merge with v_cndmask_b32; 1: merge with (x & m) | acc.
+template <int MASKED>
+struct tbl_global {
+  uint4* p;  // wave base + lane
+  struct scan { uint32_t f[40]; uint32_t mag; };
+  struct slice { uint4 q[2][10]; };
+
+  __device__ __forceinline__ static void flatten(uint32_t f[40], const ge_cached& c) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { f[i] = c.YpX.v[i]; f[10 + i] = c.YmX.v[i]; f[20 + i] = c.Z.v[i]; f[30 + i] = c.T2d.v[i]; }
+  }
+  __device__ __forceinline__ static void unflatten(ge_cached& c, const uint32_t f[40]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c.YpX.v[i] = f[i]; c.YmX.v[i] = f[10 + i]; c.Z.v[i] = f[20 + i]; c.T2d.v[i] = f[30 + i]; }
+  }
+  __device__ __forceinline__ void store(int e, const ge_cached& c) {
+    uint32_t f[40];
+    flatten(f, c);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) p[(e * 10 + q) * 64] = make_uint4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+  }
+  __device__ __forceinline__ static void merge_entry(uint32_t f[40], const uint4 q[10], uint32_t hit) {
+    if (MASKED) {
+      const uint32_t m = 0u - hit;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        f[4 * i] |= q[i].x & m; f[4 * i + 1] |= q[i].y & m; f[4 * i + 2] |= q[i].z & m; f[4 * i + 3] |= q[i].w & m;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        f[4 * i] = hit ? q[i].x : f[4 * i]; f[4 * i + 1] = hit ? q[i].y : f[4 * i + 1];
+        f[4 * i + 2] = hit ? q[i].z : f[4 * i + 2]; f[4 * i + 3] = hit ? q[i].w : f[4 * i + 3];
+      }
+    }
+  }
+  __device__ __forceinline__ void scan_begin(scan& st, uint32_t mag) {
+    st.mag = mag;
+#pragma unroll
+    for (int i = 0; i < 40; ++i) st.f[i] = 0;
+  }
+  __device__ __forceinline__ void scan_issue(slice& sl, int k) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < 10; ++q) sl.q[h][q] = p[((2 * k + h) * 10 + q) * 64];
+  }
+  __device__ __forceinline__ void scan_merge(scan& st, slice& sl, int k) {
+    merge_entry(st.f, sl.q[0], st.mag == (uint32_t)(2 * k + 1));
+    merge_entry(st.f, sl.q[1], st.mag == (uint32_t)(2 * k + 2));
+  }
+  __device__ __forceinline__ void scan_end(ge_cached& c, scan& st) {
+    const uint32_t z = (st.mag == 0);   // neutral element in cached form: (1, 1, 1, 0)
+    st.f[0] |= z; st.f[10] |= z; st.f[20] |= z;
+    unflatten(c, st.f);
+  }
+  __device__ __forceinline__ void select(ge_cached& c, uint32_t mag) {
+    scan st;
+    scan_begin(st, mag);
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) { slice sl; scan_issue(sl, k); scan_merge(st, sl, k); }
+    scan_end(c, st);
+  }
+};
+
+// Fixed-base table in LDS, image layout [pos][quad][entry][4] (KYB_BT_IDX).
+// MODE 0: every lane reads all 8 entries (uniform address -> LDS broadcast) and merges under a mask.
+// MODE 1: lane l fetches entry (l & 7) with eight conflict-free ds_read_b128, then each of the 30
+//         limbs is pulled from the lane that holds the wanted entry with ds_bpermute_b32
+//         (data-independent instruction stream and addresses; the only per-lane quantity is the
+//         bpermute source lane, which goes through the conflict-free crossbar).
+template <int MODE>
+struct tbl_lds {
+  const uint32_t* t;  // LDS
+  __device__ __forceinline__ void select(ge_precomp& c, int pos, uint32_t mag) {
+    uint32_t f[32];
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) f[i] = 0;
+#pragma unroll 2
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t m = 0u - (uint32_t)(mag == (uint32_t)(j + 1));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const uint4 v = *reinterpret_cast<const uint4*>(t + ((pos * 8 + q) * 8 + j) * 4);
+          f[4 * q] |= v.x & m; f[4 * q + 1] |= v.y & m; f[4 * q + 2] |= v.z & m; f[4 * q + 3] |= v.w & m;
+        }
+      }
+    } else {
+      const uint32_t lane = threadIdx.x & 63u;
+      const uint32_t mine = lane & 7u;
+      uint32_t own[32];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint4 v = *reinterpret_cast<const uint4*>(t + ((pos * 8 + q) * 8 + mine) * 4);
+        own[4 * q] = v.x; own[4 * q + 1] = v.y; own[4 * q + 2] = v.z; own[4 * q + 3] = v.w;
+      }
+      const uint32_t want = (mag - 1u) & 7u;                   // mag == 0 reads entry 7, masked below
+      const int src = (int)(((lane & ~7u) | want) << 2);       // byte address of the source lane
+      const uint32_t m = 0u - (uint32_t)(mag != 0);
+#pragma unroll
+      for (int i = 0; i < 30; ++i) f[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own[i]) & m;
+    }
+    const uint32_t z = (mag == 0);       // neutral element in precomputed form: (1, 1, 0)
+    f[0] |= z; f[10] |= z;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c.ypx.v[i] = f[i]; c.ymx.v[i] = f[10 + i]; c.xy2d.v[i] = f[20 + i]; }
+  }
+};
+
+// Radix-32 fixed-base table in LDS, image layout [pos][quad][16 entries][4] (KYB_BT32_IDX): lane l holds
+// entry (l & 15) after eight conflict-free ds_read_b128, the wanted one is pulled with ds_bpermute_b32.
+struct tbl_lds32 {
+  const uint32_t* t;  // LDS
+  __device__ __forceinline__ void select(ge_precomp& c, int pos, uint32_t mag) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t mine = lane & 15u;
+    uint32_t own[32], f[30];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const uint4 v = *reinterpret_cast<const uint4*>(t + ((pos * 8 + q) * 16 + mine) * 4);
+      own[4 * q] = v.x; own[4 * q + 1] = v.y; own[4 * q + 2] = v.z; own[4 * q + 3] = v.w;
+    }
+    const uint32_t want = (mag - 1u) & 15u;                  // mag == 0 reads entry 15, masked below
+    const int src = (int)(((lane & ~15u) | want) << 2);
+    const uint32_t m = 0u - (uint32_t)(mag != 0);
+#pragma unroll
+    for (int i = 0; i < 30; ++i) f[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own[i]) & m;
+    const uint32_t z = (mag == 0);
+    f[0] |= z; f[10] |= z;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { c.ypx.v[i] = f[i]; c.ymx.v[i] = f[10 + i]; c.xy2d.v[i] = f[20 + i]; }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// load / store helpers (16-byte vector accesses; batches are arrays of 32- or 160-byte records)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_words8(uint32_t w[8], const uint8_t* base, size_t i) {
+  const uint4* p = reinterpret_cast<const uint4*>(base) + 2 * i;
+  const uint4 a = p[0], b = p[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void store_words8(uint8_t* base, size_t i, const uint32_t w[8]) {
+  uint4* p = reinterpret_cast<uint4*>(base) + 2 * i;
+  p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ void load_ext(ge_p3& P, const int32_t* base, size_t i) {
+  const uint4* p = reinterpret_cast<const uint4*>(base) + 10 * i;
+  int32_t s[40];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) { const uint4 v = p[q]; s[4 * q] = (int32_t)v.x; s[4 * q + 1] = (int32_t)v.y; s[4 * q + 2] = (int32_t)v.z; s[4 * q + 3] = (int32_t)v.w; }
+  fe_from_ref10(P.X, s); fe_from_ref10(P.Y, s + 10); fe_from_ref10(P.Z, s + 20); fe_from_ref10(P.T, s + 30);
+}
+__device__ __forceinline__ void store_ext(int32_t* base, size_t i, const fe& X, const fe& Y, const fe& Z, const fe& T) {
+  int32_t s[40];
+  fe_to_ref10(s, X); fe_to_ref10(s + 10, Y); fe_to_ref10(s + 20, Z); fe_to_ref10(s + 30, T);
+  uint4* p = reinterpret_cast<uint4*>(base) + 10 * i;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) p[q] = make_uint4((uint32_t)s[4 * q], (uint32_t)s[4 * q + 1], (uint32_t)s[4 * q + 2], (uint32_t)s[4 * q + 3]);
+}
+// encode (and optionally emit affine extended limbs, Z = 1) from a projective result
+__device__ __forceinline__ void finish_point(const fe& X, const fe& Y, const fe& Z, uint8_t* out_enc, int32_t* out_ext, size_t i, bool live) {
+  fe zi, x, y;
+  fe_invert(zi, Z);
+  fe_mul(x, X, zi);
+  fe_mul(y, Y, zi);
+  if (out_enc != nullptr) {
+    uint32_t w[8];
+    fe_to_words(w, y);
+    w[7] ^= fe_is_negative(x) << 31;
+    if (live) store_words8(out_enc, i, w);
+  }
+  if (out_ext != nullptr) {
+    fe one, t;
+    fe_one(one);
+    fe_mul(t, x, y);
+    if (live) store_ext(out_ext, i, x, y, one, t);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// projective staging buffer for the split finish: uint4 [8 quads][stride items]
+//   dwords 0..9 X, 10..19 Y, 20..29 Z (tight limbs), 30..31 unused.  Item-minor so that both the
+//   producer (lane = item) and the batched finish (lane j takes items j, j+M, j+2M, ...) are coalesced.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_proj(uint4* proj, size_t stride, size_t i, const fe& X, const fe& Y, const fe& Z) {
+  uint32_t f[32];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { f[k] = X.v[k]; f[10 + k] = Y.v[k]; f[20 + k] = Z.v[k]; }
+  f[30] = 0; f[31] = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) proj[q * stride + i] = make_uint4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+}
+__device__ __forceinline__ void load_proj_z(fe& Z, const uint4* proj, size_t stride, size_t i) {
+  const uint4 a = proj[5 * stride + i], b = proj[6 * stride + i], c = proj[7 * stride + i];
+  Z.v[0] = a.x; Z.v[1] = a.y; Z.v[2] = a.z; Z.v[3] = a.w; Z.v[4] = b.x; Z.v[5] = b.y; Z.v[6] = b.z; Z.v[7] = b.w; Z.v[8] = c.x; Z.v[9] = c.y;
+}
+__device__ __forceinline__ void load_proj_xy(fe& X, fe& Y, const uint4* proj, size_t stride, size_t i) {
+  uint32_t f[20];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) { const uint4 v = proj[q * stride + i]; f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w; }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { X.v[k] = f[k]; Y.v[k] = f[10 + k]; }
+}
+
