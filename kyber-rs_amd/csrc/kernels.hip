@@ -12,6 +12,7 @@
 //   device_tables.h      table policies (workspace / LDS selection), 16-byte load/store helpers,
 //                        the projective staging buffer of the split finish
 //   device_kernels.h     every __global__ kernel
+//   host_copy_pool.h     threaded memcpy for pageable caller buffers (plain C++, host only)
 //   kernels.hip (this)   engine context, per-stream scratch, launch sequences, host-pointer pipeline
 //   c_abi.inc            the extern "C" entry points of include/kyber_ed25519.h
 //
@@ -29,8 +30,12 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/kyber_ed25519.h"
 #include "schnorr.h"
@@ -52,6 +57,7 @@ using namespace kyb;
 
 #include "device_tables.h"
 #include "device_kernels.h"
+#include "host_copy_pool.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side: context, staging, C ABI
@@ -99,6 +105,9 @@ struct Ctx {
   size_t stage_bytes = 0;
   uint8_t* stage2 = nullptr;      // staging of the second pipeline lane
   size_t stage2_bytes = 0;
+  uint8_t* pin[2] = {nullptr, nullptr};   // page-locked bounce buffers of the two lanes (pageable caller memory)
+  size_t pin_bytes[2] = {0, 0};
+  int opt_copy_threads = 0;       // host threads that move pageable batches through the bounce buffers (0 = auto)
   int opt_mul_select = 1;         // 0 cndmask, 1 and/or mask
   int opt_base_select = 1;        // 0 LDS broadcast scan, 1 bpermute
   int opt_base_block = 256;       // 256 (2 waves/SIMD) or 512 (4 waves/SIMD, 128 VGPRs)   [radix-16 kernel]
@@ -144,10 +153,37 @@ int ensure_stage2(size_t bytes) {
   return KYB_OK;
 }
 
+int ensure_pin(int lane, size_t bytes) {
+  if (bytes <= g.pin_bytes[lane]) return KYB_OK;
+  if (g.pin[lane]) { HIPCK(hipHostFree(g.pin[lane])); g.pin[lane] = nullptr; g.pin_bytes[lane] = 0; }
+  size_t want = bytes + (bytes >> 2) + 4096;
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&g.pin[lane]), want, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "pinned bounce buffer allocation", e);
+  g.pin_bytes[lane] = want;
+  return KYB_OK;
+}
+
+kyb::CopyPool g_copy;
+
+int copy_threads() {
+  if (g.opt_copy_threads > 0) return g.opt_copy_threads;
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int t = (int)(hw / 2);
+  return t < 1 ? 1 : (t > 8 ? 8 : t);
+}
+// page-locked (hipHostMalloc / hipHostRegister) memory is copied by the DMA engines directly
+bool is_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
 // Host-pointer batches of fixed-size records: the batch is cut into chunks that alternate between two
 // streams (each with its own staging and scratch) so that the H2D copy of chunk c+1 and the D2H copy
-// of chunk c-1 overlap the kernels of chunk c.  (Caller buffers are pageable, so the copies block the
-// calling thread; the order below is what creates the overlap.)
+// of chunk c-1 overlap the kernels of chunk c.  Page-locked caller buffers (kyb_host_alloc) are handed to
+// the DMA engines as they are.  Pageable ones would make every hipMemcpyAsync a blocking, single-threaded
+// staging copy inside the runtime (~7 GB/s); they go through the engine's own page-locked bounce buffers
+// instead, filled and drained by CopyPool threads while the GPU works on the neighbouring chunk.
 struct HostArr { const void* in; void* out; size_t bytes; };    // per-item size; exactly one of in/out, or neither = absent
 constexpr size_t PIPE_MIN_ITEMS = (size_t)1 << 16;
 constexpr int PIPE_CHUNKS = 8;
@@ -164,6 +200,51 @@ int run_host_batch(size_t n, const HostArr* arrs, int na, Fn launch) {
   if (nchunks > 1) { rc = ensure_stage2(total); if (rc) return rc; }
   hipStream_t streams[2] = {g.stream, g.stream2};
   uint8_t* stages[2] = {g.stage, g.stage2};
+  bool pinned = true;
+  for (int k = 0; k < na; ++k) {
+    if (arrs[k].in) pinned = pinned && is_pinned(arrs[k].in);
+    if (arrs[k].out) pinned = pinned && is_pinned(arrs[k].out);
+  }
+  if (nchunks > 1 && !pinned) {
+    rc = ensure_pin(0, total); if (rc) return rc;
+    rc = ensure_pin(1, total); if (rc) return rc;
+    const int threads = copy_threads();
+    kyb::CopyPool::Job jobs[8];
+    auto chunk_items = [&](int c) { const size_t lo = (size_t)c * cap; return lo >= n ? (size_t)0 : ((lo + cap <= n) ? cap : n - lo); };
+    auto copy_out = [&](int c) -> int {             // chunk c has been queued on its lane: wait for it, hand the results over
+      const int lane = c & 1;
+      HIPCK(hipStreamSynchronize(streams[lane]));
+      const size_t lo = (size_t)c * cap, cn = chunk_items(c);
+      int nj = 0;
+      for (int k = 0; k < na; ++k)
+        if (arrs[k].out) jobs[nj++] = kyb::CopyPool::Job{static_cast<uint8_t*>(arrs[k].out) + arrs[k].bytes * lo, g.pin[lane] + off[k], arrs[k].bytes * cn};
+      g_copy.run(jobs, nj, threads);
+      return KYB_OK;
+    };
+    int queued = -1;
+    for (int c = 0; c < nchunks && chunk_items(c) > 0; ++c) {
+      const int lane = c & 1;
+      const size_t lo = (size_t)c * cap, cn = chunk_items(c);
+      if (c >= 2) { rc = copy_out(c - 2); if (rc) return rc; }     // frees this lane's bounce and staging buffers
+      int nj = 0;
+      for (int k = 0; k < na; ++k)
+        if (arrs[k].in) jobs[nj++] = kyb::CopyPool::Job{g.pin[lane] + off[k], static_cast<const uint8_t*>(arrs[k].in) + arrs[k].bytes * lo, arrs[k].bytes * cn};
+      g_copy.run(jobs, nj, threads);
+      uint8_t* dptr[8];
+      for (int k = 0; k < na; ++k) {
+        dptr[k] = (arrs[k].in || arrs[k].out) ? stages[lane] + off[k] : nullptr;
+        if (arrs[k].in) HIPCK(hipMemcpyAsync(dptr[k], g.pin[lane] + off[k], arrs[k].bytes * cn, hipMemcpyHostToDevice, streams[lane]));
+      }
+      rc = launch(streams[lane], cn, dptr);
+      if (rc) return rc;
+      for (int k = 0; k < na; ++k)
+        if (arrs[k].out) HIPCK(hipMemcpyAsync(g.pin[lane] + off[k], stages[lane] + off[k], arrs[k].bytes * cn, hipMemcpyDeviceToHost, streams[lane]));
+      queued = c;
+    }
+    if (queued >= 1) { rc = copy_out(queued - 1); if (rc) return rc; }
+    if (queued >= 0) { rc = copy_out(queued); if (rc) return rc; }
+    return KYB_OK;
+  }
   auto d2h = [&](int c) -> int {
     const int lane = c & 1;
     const size_t lo = (size_t)c * cap, cn = (lo + cap <= n) ? cap : n - lo;

@@ -614,3 +614,37 @@ def test_cfg5_shard_2_21_linearity(engine, oracle):
     want = oracle.mul_batch(s_np[idx], pts[idx].cpu().numpy(), nthreads=8)
     got = engine.encode(sp[idx].cpu().numpy())
     assert np.array_equal(got, want)
+
+
+def test_host_pointer_paths_agree(engine, oracle):
+    """The chunked host-pointer pipeline gives the same bytes whichever way the batch travels: pageable
+    caller memory (engine's bounce buffers + copy threads), page-locked caller memory (direct DMA), one
+    copy thread, and the device-pointer API; ragged size so that the last chunk is short"""
+    import torch
+    n = (1 << 17) + 12345
+    rng = np.random.default_rng(88)
+    s = rng.integers(0, 256, (n, 32), dtype=np.uint8); s[:, 31] &= 0x0F
+    enc_b, ext = engine.mul_base(s, want_ext=True)                       # pageable in/out, two outputs
+    ref = torch.empty((n, 32), dtype=torch.uint8, device="cuda:0")
+    engine.mul_base_dev(torch.from_numpy(s).to("cuda:0"), out_enc=ref)
+    engine.sync()
+    assert np.array_equal(enc_b, ref.cpu().numpy())
+    t = rng.integers(0, 256, (n, 32), dtype=np.uint8); t[:, 31] &= 0x0F
+    enc_m, ok = engine.mul(t, pts_enc=enc_b, want_ok=True)               # pageable, encoded points in, ok flags out
+    assert ok.all()
+    enc_m2 = engine.mul(t, pts_ext=ext)                                  # pageable, 160-byte points in
+    assert np.array_equal(enc_m, enc_m2)
+    ps = engine.pinned_array((n, 32), np.uint8); ps[:] = t
+    pe = engine.pinned_array((n, 40), np.int32); pe[:] = ext
+    po = engine.pinned_array((n, 32), np.uint8)
+    engine.mul_into(ps, pe, po)                                          # page-locked: direct DMA path
+    assert np.array_equal(po, enc_m)
+    threads = engine.get_option("host.copy_threads")
+    assert threads >= 1
+    engine.set_option("host.copy_threads", 1)
+    try:
+        assert np.array_equal(engine.mul(t, pts_ext=ext), enc_m)
+    finally:
+        engine.set_option("host.copy_threads", 0)
+    idx = np.concatenate([rng.choice(n, 256, replace=False), [0, n - 1, (1 << 17) - 1, 1 << 17]])
+    assert np.array_equal(enc_m[idx], oracle.mul_batch(t[idx], ext[idx], nthreads=8))
