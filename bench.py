@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="mul", choices=["mul", "mul_base", "sign", "verify"])
+    ap.add_argument("--keyed", action="store_true", help="sign: the signers hold their public keys (EdDSA objects, DSS long-term keys): "
+                    "one fixed-base mult per signature instead of the two of schnorr::sign")
     ap.add_argument("--n", type=int, default=0, help="items per GPU (default 2^20, 2^18 for sign)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=1024, help="items verified against the oracle after timing")
@@ -112,6 +114,9 @@ def main():
         msg_list = synth.messages(n, seed)
         msgs = torch.from_numpy(np.frombuffer(b"".join(msg_list), dtype=np.uint8).copy()).to(dev)
         off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int32, device=dev)
+        if wl == "sign" and args.keyed:
+            pubs = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+            eng.mul_base_dev(sc, out_enc=pubs, stream=stream)
         if wl == "verify":      # valid signatures to verify: produced on the GPU (untimed), spot-checked below
             sigs = torch.empty((n, 64), dtype=torch.uint8, device=dev)
             pubs = torch.empty((n, 32), dtype=torch.uint8, device=dev)
@@ -126,7 +131,7 @@ def main():
         elif wl == "mul_base":
             eng.mul_base_dev(sc, out_enc=out, stream=stream)
         elif wl == "sign":
-            eng.sign_dev(sc, k, msgs, off, out, stream=stream)
+            eng.sign_dev(sc, k, msgs, off, out, stream=stream, pubs=pubs if args.keyed else None)
         else:
             eng.verify_dev(pubs, msgs, off, sigs, out, flavor=1, stream=stream)
 
@@ -213,6 +218,8 @@ def main():
                    "sample": f"oracle/ed25519_oracle.c (C restatement of the reference algorithm, gcc -O3 -march=native; not the Rust binary): "
                              f"{min(cnt_all, n)} items of the same workload on {threads} threads, {min(per_core, n)} items on 1 thread"}
 
+    if wl == "sign" and args.keyed:
+        PRODUCTS["sign"] = 62_250 + 2_000        # EdDSA::sign on a key object: one fixed-base mult + encode, two hashes, one sc_mul_add
     if rank == 0:
         total_items = n * world * args.steps
         value = total_items / elapsed
@@ -222,7 +229,7 @@ def main():
         dom = DOMINANT[wl] if DOMINANT[wl] in per_kernel else max(per_kernel, key=lambda k_: sum(per_kernel[k_]))
         dom_ms = sum(per_kernel[dom]) / len(per_kernel[dom])                  # average duration of ONE launch
         launches_per_step = len(per_kernel[dom]) / args.steps
-        items_per_launch = n * (2 if wl == "sign" and dom == "k_mul_base" else 1) / launches_per_step
+        items_per_launch = n * (2 if wl == "sign" and dom == "k_mul_base" and not args.keyed else 1) / launches_per_step
         dom_products = PRODUCTS_DOMINANT.get(dom, PRODUCTS[wl]) if eng.get_option("finish.batched") and n >= eng.get_option("finish.min_items") else PRODUCTS[wl]
         mad_rate = dom_products * items_per_launch / (dom_ms * 1e-3)
         executed = EXECUTED.get(dom, dom_products)
@@ -243,7 +250,7 @@ def main():
             "config": {"workload": {"mul": "2^20 variable-base scalar-mults, random scalars+points, reference-limb points in, 32-byte encodings out",
                                     "mul_base": "2^20 fixed-base (generator) scalar-mults, 32-byte encodings out",
                                     "sign": "2^18 Schnorr signs, 32-byte messages, 64-byte signatures out",
-                                    "verify": "2^20 Schnorr verifications with the reference's checks, 32-byte messages, status bytes out"}[wl] if not args.n else f"{wl} x {n} per GPU",
+                                    "verify": "2^20 Schnorr verifications with the reference's checks, 32-byte messages, status bytes out"}[wl] + (", signers hold their public keys (one fixed-base mult per signature)" if wl == "sign" and args.keyed else "") if not args.n else f"{wl} x {n} per GPU",
                        "items_per_gpu": n, "sharding": f"independent shards x{world}, no data-path collective; one RCCL table broadcast at init",
                        "options": {k_: eng.get_option(k_) for k_ in ("mul.algo", "mul.ladder_waves", "mul.select", "mul_base.radix", "mul_base.select", "mul_base.block", "finish.batched", "finish.min_items")}},
             "roofline": {"bound": "valu-int", "kernel": dom, "achieved": round(mad_rate / 1e12, 3), "peak": PEAK_MAD_PER_S / 1e12,

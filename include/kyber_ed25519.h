@@ -113,6 +113,15 @@ int kyb_schnorr_sign_batch(const uint8_t* x, const uint8_t* k, const uint8_t* ms
                            size_t n, uint8_t* sig);
 int kyb_schnorr_sign_batch_dev(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* msg_off,
                                size_t n, uint8_t* sig, void* stream);
+/* The same for callers that hold the public keys (DSS long-term keys, dss_sig.rs:215-237; EdDSA objects):
+ * pubs = n x 32 encodings of x*B, hashed as given, so A is not recomputed and a signature costs one
+ * fixed-base multiplication instead of two.  pubs == NULL behaves like kyb_schnorr_sign_batch.  A pubs[i]
+ * that is not enc(x[i]*B) yields a signature that does not verify (as it would in the reference if a key
+ * object held a wrong public key). */
+int kyb_schnorr_sign_keyed_batch(const uint8_t* x, const uint8_t* pubs, const uint8_t* k, const uint8_t* msgs,
+                                 const uint32_t* msg_off, size_t n, uint8_t* sig);
+int kyb_schnorr_sign_keyed_batch_dev(const uint8_t* x, const uint8_t* pubs, const uint8_t* k, const uint8_t* msgs,
+                                     const uint32_t* msg_off, size_t n, uint8_t* sig, void* stream);
 
 /* ---- EdDSA::sign, eddsa_sig.rs:120-152 with the key expansion of curve.rs:74-87 ------------------ */
 /* seeds: n x 32.  Per item: d = SHA-512(seed), x = clamp(d[0..32)) (unreduced), prefix = d[32..64),
@@ -121,6 +130,10 @@ int kyb_schnorr_sign_batch_dev(const uint8_t* x, const uint8_t* k, const uint8_t
  * (`EdDSA::new`, eddsa_sig.rs:31-43).  This is the computation the reference's golden file pins. */
 int kyb_eddsa_sign_batch(const uint8_t* seeds, const uint8_t* msgs, const uint32_t* msg_off, size_t n, uint8_t* sig, uint8_t* pub);
 int kyb_eddsa_sign_batch_dev(const uint8_t* seeds, const uint8_t* msgs, const uint32_t* msg_off, size_t n, uint8_t* sig, uint8_t* pub, void* stream);
+/* EdDSA::sign on existing key objects: the struct already holds the public key (eddsa_sig.rs:22-29, used at
+ * :132-137), so only R = r*B is computed.  pubs = n x 32, required. */
+int kyb_eddsa_sign_keyed_batch(const uint8_t* seeds, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* msg_off, size_t n, uint8_t* sig);
+int kyb_eddsa_sign_keyed_batch_dev(const uint8_t* seeds, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* msg_off, size_t n, uint8_t* sig, void* stream);
 
 /* ---- signature verification with the reference's checks --------------------- */
 /* eddsa::verify_with_checks (eddsa_sig.rs:159-212, flavor 0) / schnorr::verify_with_checks

@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "kyb_add_batch", "kyb_add_batch_dev", "kyb_encode_batch", "kyb_encode_batch_dev",
     "kyb_decode_batch", "kyb_decode_batch_dev", "kyb_schnorr_sign_batch", "kyb_schnorr_sign_batch_dev",
     "kyb_eddsa_sign_batch", "kyb_eddsa_sign_batch_dev",
+    "kyb_schnorr_sign_keyed_batch", "kyb_schnorr_sign_keyed_batch_dev", "kyb_eddsa_sign_keyed_batch", "kyb_eddsa_sign_keyed_batch_dev",
     "kyb_verify_batch", "kyb_verify_batch_dev", "kyb_pubpoly_eval_batch", "kyb_pubpoly_eval_batch_dev",
     "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev",
     "kyb_host_alloc", "kyb_host_free",
@@ -87,6 +88,10 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_schnorr_sign_batch.argtypes = [vp, vp, vp, vp, sz, vp]
     lib.kyb_schnorr_sign_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     lib.kyb_eddsa_sign_batch.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.kyb_schnorr_sign_keyed_batch.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    lib.kyb_schnorr_sign_keyed_batch_dev.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp]
+    lib.kyb_eddsa_sign_keyed_batch.argtypes = [vp, vp, vp, vp, sz, vp]
+    lib.kyb_eddsa_sign_keyed_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     lib.kyb_eddsa_sign_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     lib.kyb_verify_batch.argtypes = [vp, vp, vp, vp, sz, i32, vp]
     lib.kyb_verify_batch_dev.argtypes = [vp, vp, vp, vp, sz, i32, vp, vp]
@@ -236,24 +241,34 @@ class Engine:
         _check(self.lib.kyb_decode_batch(_ptr(e), e.shape[0], _ptr(ext), _ptr(ok)), "kyb_decode_batch")
         return ext, ok
 
-    def schnorr_sign(self, x, k, msgs: Sequence[bytes]):
+    def schnorr_sign(self, x, k, msgs: Sequence[bytes], pubs=None):
+        """schnorr::sign with caller-supplied nonces; pubs = the stored public keys enc(x*B) (then A is not recomputed)"""
         xs, ks = _u8(x, 32, "x"), _u8(k, 32, "k")
         n = xs.shape[0]
         off = np.zeros(n + 1, dtype=np.uint32)
         off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64).astype(np.uint32)
         blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()
         sig = np.empty((n, 64), dtype=np.uint8)
-        _check(self.lib.kyb_schnorr_sign_batch(_ptr(xs), _ptr(ks), _ptr(blob), _ptr(off), n, _ptr(sig)), "kyb_schnorr_sign_batch")
+        if pubs is None:
+            _check(self.lib.kyb_schnorr_sign_batch(_ptr(xs), _ptr(ks), _ptr(blob), _ptr(off), n, _ptr(sig)), "kyb_schnorr_sign_batch")
+        else:
+            ps = _u8(pubs, 32, "pubs")
+            _check(self.lib.kyb_schnorr_sign_keyed_batch(_ptr(xs), _ptr(ps), _ptr(ks), _ptr(blob), _ptr(off), n, _ptr(sig)), "kyb_schnorr_sign_keyed_batch")
         return sig
 
-    def eddsa_sign(self, seeds, msgs: Sequence[bytes], want_pub: bool = False):
-        """EdDSA::sign for (seed, msg) pairs; optionally also the public keys"""
+    def eddsa_sign(self, seeds, msgs: Sequence[bytes], want_pub: bool = False, pubs=None):
+        """EdDSA::sign for (seed, msg) pairs; optionally also the public keys; pubs = the public keys the key
+        objects already hold (then only R is computed)"""
         sd = _u8(seeds, 32, "seeds")
         n = sd.shape[0]
         off = np.zeros(n + 1, dtype=np.uint32)
         off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64).astype(np.uint32)
         blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()
         sig = np.empty((n, 64), dtype=np.uint8)
+        if pubs is not None:
+            ps = _u8(pubs, 32, "pubs")
+            _check(self.lib.kyb_eddsa_sign_keyed_batch(_ptr(sd), _ptr(ps), _ptr(blob), _ptr(off), n, _ptr(sig)), "kyb_eddsa_sign_keyed_batch")
+            return (sig, ps) if want_pub else sig
         pub = np.empty((n, 32), dtype=np.uint8) if want_pub else None
         _check(self.lib.kyb_eddsa_sign_batch(_ptr(sd), _ptr(blob), _ptr(off), n, _ptr(sig), _ptr(pub)), "kyb_eddsa_sign_batch")
         return (sig, pub) if want_pub else sig
@@ -361,8 +376,11 @@ class Engine:
         n = enc.numel() // 32
         _check(self.lib.kyb_decode_batch_dev(self._dp(enc), n, self._dp(out_ext), self._dp(ok), ctypes.c_void_p(stream)), "kyb_decode_batch_dev")
 
-    def sign_dev(self, x, k, msgs, msg_off, sig, stream: int = 0) -> None:
+    def sign_dev(self, x, k, msgs, msg_off, sig, stream: int = 0, pubs=None) -> None:
         n = x.numel() // 32
+        if pubs is not None:
+            _check(self.lib.kyb_schnorr_sign_keyed_batch_dev(self._dp(x), self._dp(pubs), self._dp(k), self._dp(msgs), self._dp(msg_off), n, self._dp(sig), ctypes.c_void_p(stream)), "kyb_schnorr_sign_keyed_batch_dev")
+            return
         _check(self.lib.kyb_schnorr_sign_batch_dev(self._dp(x), self._dp(k), self._dp(msgs), self._dp(msg_off), n, self._dp(sig), ctypes.c_void_p(stream)), "kyb_schnorr_sign_batch_dev")
 
     def base_table_export_dev(self, dst, stream: int = 0) -> None:

@@ -203,18 +203,19 @@ k_eddsa_prep(const uint8_t* __restrict__ seeds, const uint8_t* __restrict__ msgs
   store_words8(kbuf, i, r);
 }
 
-// split signing, last stage: enc holds enc(R_i) at record i and enc(A_i) at record n + i (produced by
-// two split fixed-base launches + k_finish); h = SHA-512(R || A || msg) mod L, s = k + x h mod L.
+// split signing, last stage: r_enc[i] = enc(R_i), a_enc[i] = enc(A_i) (from the fixed-base launches + k_finish,
+// or the caller's stored public keys); h = SHA-512(R || A || msg) mod L, s = k + x h mod L.
 __global__ void __launch_bounds__(KYB_BLOCK)
 k_sign_hash(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const uint8_t* __restrict__ msgs,
-            const uint32_t* __restrict__ msg_off, size_t n, const uint8_t* __restrict__ enc, uint8_t* __restrict__ sig) {
+            const uint32_t* __restrict__ msg_off, size_t n, const uint8_t* __restrict__ r_enc, const uint8_t* __restrict__ a_enc,
+            uint8_t* __restrict__ sig) {
   const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t wx[8], wk[8], ra[16];
   load_words8(wx, x, i);
   load_words8(wk, k, i);
-  load_words8(ra, enc, i);
-  load_words8(ra + 8, enc, n + i);
+  load_words8(ra, r_enc, i);
+  load_words8(ra + 8, a_enc, i);
   sha512_ctx c;
   sha512_init(c);
   sha512_words64(c, ra);

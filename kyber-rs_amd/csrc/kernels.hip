@@ -492,11 +492,30 @@ int launch_mul_base(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, h
   }
   return launch_base_t<false>(sc, n, oenc, oext, r, 0, st);
 }
-int launch_sign(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* sig, hipStream_t st) {
-  if (n == 0) return KYB_OK;
-  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
-  Ctx::StreamRes* r = nullptr;
-  { int rc = res_for(st, &r); if (rc) return rc; }
+// schnorr::sign for n (x, k, msg) triples.  pub_in != nullptr: the callers' stored public keys enc(x*B) are
+// hashed as they are and A is not recomputed (EdDSA::sign, eddsa_sig.rs:132-137; DSS long-term keys);
+// pub_out != nullptr: receives enc(x*B).
+int sign_locked(Ctx::StreamRes* r, const uint8_t* x, const uint8_t* k, const uint8_t* pub_in, const uint8_t* msgs, const uint32_t* off, size_t n,
+                uint8_t* sig, uint8_t* pub_out, hipStream_t st) {
+  const unsigned blocks = (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK);
+  if (pub_in != nullptr) {
+    // R = k*B only
+    int rc = ensure_enc(r, 32 * n); if (rc) return rc;
+    if (use_split(n)) {
+      rc = ensure_proj(r, n); if (rc) return rc;
+      rc = launch_base_t<true>(k, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
+      rc = launch_finish(r, n, r->enc, nullptr, st); if (rc) return rc;
+    } else {
+      rc = launch_base_t<false>(k, n, r->enc, nullptr, r, 0, st); if (rc) return rc;
+    }
+    {
+      ProfScope ps(st, KID_SIGN_HASH);
+      hipLaunchKernelGGL(k_sign_hash, dim3(blocks), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, r->enc, pub_in, sig);
+      HIPCK(hipGetLastError());
+    }
+    if (pub_out != nullptr && pub_out != pub_in) HIPCK(hipMemcpyAsync(pub_out, pub_in, 32 * n, hipMemcpyDeviceToDevice, st));
+    return KYB_OK;
+  }
   if (use_split(2 * n)) {
     // R = k*B -> proj[0, n), A = x*B -> proj[n, 2n); one batched finish; then hash + scalar arithmetic
     int rc = ensure_proj(r, 2 * n); if (rc) return rc;
@@ -504,40 +523,52 @@ int launch_sign(const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const u
     rc = launch_base_t<true>(k, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
     rc = launch_base_t<true>(x, n, nullptr, nullptr, r, n, st); if (rc) return rc;
     rc = launch_finish(r, 2 * n, r->enc, nullptr, st); if (rc) return rc;
-    ProfScope ps(st, KID_SIGN_HASH);
-    hipLaunchKernelGGL(k_sign_hash, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, r->enc, sig);
-    HIPCK(hipGetLastError());
+    {
+      ProfScope ps(st, KID_SIGN_HASH);
+      hipLaunchKernelGGL(k_sign_hash, dim3(blocks), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, r->enc, r->enc + 32 * n, sig);
+      HIPCK(hipGetLastError());
+    }
+    if (pub_out != nullptr) HIPCK(hipMemcpyAsync(pub_out, r->enc + 32 * n, 32 * n, hipMemcpyDeviceToDevice, st));
     return KYB_OK;
   }
   const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
   const size_t cap = (size_t)g.cus * 2;
   const int grid = (int)(nchunks < cap ? nchunks : cap);
   const uint4* img = reinterpret_cast<const uint4*>(g.table);
-  ProfScope ps(st, KID_SIGN);
-  if (g.opt_base_select == 0) hipLaunchKernelGGL((k_sign<0, KYB_BLOCK>), dim3(grid), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, sig, img);
-  else                        hipLaunchKernelGGL((k_sign<1, KYB_BLOCK>), dim3(grid), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, sig, img);
-  HIPCK(hipGetLastError());
+  {
+    ProfScope ps(st, KID_SIGN);
+    if (g.opt_base_select == 0) hipLaunchKernelGGL((k_sign<0, KYB_BLOCK>), dim3(grid), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, sig, img);
+    else                        hipLaunchKernelGGL((k_sign<1, KYB_BLOCK>), dim3(grid), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, sig, img);
+    HIPCK(hipGetLastError());
+  }
+  if (pub_out != nullptr) return launch_base_t<false>(x, n, pub_out, nullptr, r, 0, st);
   return KYB_OK;
 }
-
-// EdDSA::sign for n (seed, msg) pairs: expansion + nonce, then the Schnorr pipeline; optionally the public keys
-int launch_eddsa_sign(const uint8_t* seeds, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* sig, uint8_t* pub, hipStream_t st) {
+int launch_sign(const uint8_t* x, const uint8_t* k, const uint8_t* pub_in, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* sig, hipStream_t st) {
   if (n == 0) return KYB_OK;
-  uint8_t *xbuf = nullptr, *kbuf = nullptr;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  Ctx::StreamRes* r = nullptr;
+  { int rc = res_for(st, &r); if (rc) return rc; }
+  return sign_locked(r, x, k, pub_in, msgs, off, n, sig, nullptr, st);
+}
+
+// EdDSA::sign for n (seed, msg) pairs: expansion + nonce, then the Schnorr pipeline.  pub_in: the public keys
+// the EdDSA objects hold (eddsa_sig.rs:22-29), or nullptr = derive them here; pub_out: optional copy of them.
+int launch_eddsa_sign(const uint8_t* seeds, const uint8_t* pub_in, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* sig, uint8_t* pub_out, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  Ctx::StreamRes* r = nullptr;
+  int rc = res_for(st, &r); if (rc) return rc;
+  // the signing pipeline uses r->enc[0, 64n) for the encodings of R and A: keep x and k behind that
+  rc = ensure_enc(r, up256(64 * n) + 2 * up256(32 * n)); if (rc) return rc;
+  uint8_t* xbuf = r->enc + up256(64 * n);
+  uint8_t* kbuf = xbuf + up256(32 * n);
   {
-    std::lock_guard<std::mutex> launch_lock(g.launch_mu);
-    Ctx::StreamRes* r = nullptr;
-    int rc = res_for(st, &r); if (rc) return rc;
-    // the signing pipeline uses r->enc[0, 64n) for the encodings of R and A: keep x and k behind that
-    rc = ensure_enc(r, up256(64 * n) + 2 * up256(32 * n)); if (rc) return rc;
-    xbuf = r->enc + up256(64 * n); kbuf = xbuf + up256(32 * n);
     ProfScope ps(st, KID_EDDSA_PREP);
     hipLaunchKernelGGL(k_eddsa_prep, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, seeds, msgs, off, n, xbuf, kbuf);
     HIPCK(hipGetLastError());
   }
-  int rc = launch_sign(xbuf, kbuf, msgs, off, n, sig, st); if (rc) return rc;
-  if (pub != nullptr) return launch_mul_base(xbuf, n, pub, nullptr, st);
-  return KYB_OK;
+  return sign_locked(r, xbuf, kbuf, pub_in, msgs, off, n, sig, pub_out, st);
 }
 
 // verification pipeline on one stream: prep -> k_mul (h, A) -> k_mul_base (s) -> final

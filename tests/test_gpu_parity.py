@@ -505,9 +505,23 @@ def test_eddsa_sign_golden_file_on_gpu(engine, oracle):
     n = 6000
     sd = synth.raw256(n, 95)
     ms = synth.messages(n, 95, length=24)
-    sig2 = engine.eddsa_sign(sd, ms)
+    sig2, pub2 = engine.eddsa_sign(sd, ms, want_pub=True)
     for i in range(0, n, 499):
         assert bytes(sig2[i]) == oracle.eddsa_sign(bytes(sd[i]), ms[i])
+        assert bytes(pub2[i]) == oracle.eddsa_expand(bytes(sd[i]))[2]
+    # EdDSA::sign on key objects that hold their public key (eddsa_sig.rs:132-137): same bytes, one mult less;
+    # both batch regimes (fused / split), and the Schnorr flavour of the same
+    assert rows(engine.eddsa_sign(np.frombuffer(b"".join(seeds), dtype=np.uint8), msgs, pubs=pub)) == sigs
+    assert np.array_equal(engine.eddsa_sign(sd, ms, pubs=pub2), sig2)
+    assert np.array_equal(engine.eddsa_sign(sd[:100], ms[:100], pubs=pub2[:100]), sig2[:100])
+    x = synth.scalars(n, 96); k = synth.scalars(n, 97)
+    xpub = engine.mul_base(x)
+    want = engine.schnorr_sign(x, k, ms)
+    assert np.array_equal(engine.schnorr_sign(x, k, ms, pubs=xpub), want)
+    assert np.array_equal(engine.schnorr_sign(x[:64], k[:64], ms[:64], pubs=xpub[:64]), want[:64])
+    # a key object with a wrong public key signs something that does not verify (as in the reference)
+    wrong = engine.schnorr_sign(x[:8], k[:8], ms[:8], pubs=xpub[1:9])
+    assert (engine.verify(xpub[:8], ms[:8], wrong, 1) == 9).all()
 
 
 def test_lincomb_matches_oracle(engine, oracle):
