@@ -2,6 +2,7 @@
 //   sign                /root/reference src/sign/schnorr/schnorr_sig.rs:25-47
 //   verify_with_checks  src/sign/schnorr/schnorr_sig.rs:53-110, verify :114-126
 //   eddsa::verify_with_checks  src/sign/eddsa/eddsa_sig.rs:159-212
+//   eddsa::EdDSA (new / from seed / marshal / unmarshal / sign)   src/sign/eddsa/eddsa_sig.rs:17-152, curve.rs:74-99
 // Error texts are the reference's (src/sign/error.rs as surfaced by the tests: "signature is not
 // canonical", "R is not canonical", "R has small order", "public key is not canonical", "public key has
 // small order", "reconstructed S is not equal to signature").
@@ -11,6 +12,7 @@
 #include <vector>
 
 #include "edwards25519.hpp"
+#include "../csrc/sha512.h"
 
 namespace kyber {
 namespace sign {
@@ -70,10 +72,92 @@ inline void verify(const Point& pub, const uint8_t* msg, size_t n, const uint8_t
 }  // namespace schnorr
 
 namespace eddsa {
+using group::edwards25519::Point;
+using group::edwards25519::Scalar;
+
+// eddsa_sig.rs:17-152.  The key object keeps the public key, so sign() costs one fixed-base multiplication
+// (kyb_schnorr_sign_keyed_batch); hashing the prefix into the nonce is host work as in the reference.
+class EdDSA {
+ public:
+  Scalar secret;                 // hashed + bit-tweaked, NOT reduced mod L (curve.rs:79-84)
+  Point public_key;
+  std::vector<uint8_t> seed, prefix;
+
+  EdDSA() { public_key.null(); }                                           // Default (eddsa_sig.rs:45-54)
+  // EdDSA::new (eddsa_sig.rs:31-43) with Curve::new_key_and_seed (curve.rs:91-99): 32 bytes from the stream
+  explicit EdDSA(Stream& stream) {
+    uint8_t buf[32], z[32] = {0};
+    stream.xor_key_stream(buf, z, 32);
+    from_seed(buf);
+  }
+  static EdDSA from_seed_bytes(const uint8_t s[32]) { EdDSA e; e.from_seed(s); return e; }
+  // From<Pair> (eddsa_sig.rs:107-117): no seed, empty prefix
+  static EdDSA from_pair(const Scalar& priv, const Point& pub) { EdDSA e; e.secret = priv; e.public_key = pub; return e; }
+
+  // "seed || Public" (eddsa_sig.rs:94-105)
+  std::vector<uint8_t> marshal_binary() const {
+    std::vector<uint8_t> out(64, 0), pb = public_key.marshal_binary();
+    std::memcpy(out.data(), seed.data(), seed.size() < 32 ? seed.size() : 32);
+    std::memcpy(out.data() + 32, pb.data(), 32);
+    return out;
+  }
+  // eddsa_sig.rs:75-91
+  void unmarshal_binary(const uint8_t* buff, size_t n) {
+    if (n != 64) throw MarshallingError("wrong length for decoding EdDSA private");
+    from_seed(buff);
+  }
+  bool operator==(const EdDSA& o) const { return seed == o.seed && prefix == o.prefix && secret == o.secret && public_key == o.public_key; }
+
+  // eddsa_sig.rs:120-152
+  std::vector<uint8_t> sign(const uint8_t* msg, size_t n) const {
+    kyb::sha512_ctx c;
+    kyb::sha512_init(c);
+    if (!prefix.empty()) kyb::sha512_bytes(c, prefix.data(), (uint32_t)prefix.size());
+    if (n) kyb::sha512_bytes(c, msg, (uint32_t)n);
+    uint32_t dig[16], r[8];
+    kyb::sha512_final(dig, c);
+    kyb::sc_reduce512(r, dig);
+    uint8_t rb[32];
+    std::memcpy(rb, r, 32);
+    std::vector<uint8_t> pb = public_key.marshal_binary(), sig(64);
+    uint32_t off[2] = {0, (uint32_t)n};
+    uint8_t dummy = 0;
+    group::edwards25519::detail::engine_must(
+        kyb_schnorr_sign_keyed_batch(secret.v.data(), pb.data(), rb, n ? msg : &dummy, off, 1, sig.data()), "EdDSA::sign");
+    return sig;
+  }
+  void verify(const uint8_t* msg, size_t n, const uint8_t* sig, size_t sig_len) const;   // eddsa_sig.rs:214-222, below
+
+ private:
+  void from_seed(const uint8_t s[32]) {
+    kyb::sha512_ctx c;
+    kyb::sha512_init(c);
+    kyb::sha512_bytes(c, s, 32);
+    uint32_t dig[16];
+    kyb::sha512_final(dig, c);
+    uint8_t d[64];
+    std::memcpy(d, dig, 64);
+    uint8_t pre[32];
+    secret = group::edwards25519::Curve::clamp_digest(d, pre);
+    seed.assign(s, s + 32);
+    prefix.assign(pre, pre + 32);
+    public_key = Point().mul(secret, nullptr);
+  }
+};
+
 // eddsa_sig.rs:159-212
 inline void verify_with_checks(const uint8_t* pub, size_t pub_len, const uint8_t* msg, size_t n, const uint8_t* sig, size_t sig_len) {
   if (pub_len != 32) throw SignatureError(7, "invalid Ed25519 curve point");
   detail::throw_status(detail::verify_one(pub, msg, n, sig, sig_len, 0), sig_len, true);
+}
+// eddsa_sig.rs:214-222
+inline void verify(const Point& pub, const uint8_t* msg, size_t n, const uint8_t* sig, size_t sig_len) {
+  std::vector<uint8_t> pb = pub.marshal_binary();
+  verify_with_checks(pb.data(), pb.size(), msg, n, sig, sig_len);
+}
+inline void EdDSA::verify(const uint8_t* msg, size_t n, const uint8_t* sig, size_t sig_len) const {
+  std::vector<uint8_t> pb = public_key.marshal_binary();
+  verify_with_checks(pb.data(), pb.size(), msg, n, sig, sig_len);
 }
 }  // namespace eddsa
 

@@ -226,6 +226,48 @@ int main() {
     try { eddsa::verify_with_checks(pb.data(), 32, msg, sizeof(msg) - 1, sig.data(), 64); } catch (const SignatureError&) { ok = false; }
     CHECK(ok, "a Schnorr signature is a valid EdDSA signature (schnorr_sig.rs:22-24)");
   }
+  // EdDSA key objects (eddsa_test.rs:19-46, 48-77): RFC 8032 section 7.1 tests 1 and 2, marshal round trip, fresh key
+  {
+    using namespace kyber::sign;
+    auto unhex = [](const char* h) { std::vector<uint8_t> v; for (size_t i = 0; h[i] && h[i + 1]; i += 2) { unsigned b; std::sscanf(h + i, "%2x", &b); v.push_back((uint8_t)b); } return v; };
+    auto hexs = [](const std::vector<uint8_t>& v) { static const char* d = "0123456789abcdef"; std::string s; for (uint8_t b : v) { s.push_back(d[b >> 4]); s.push_back(d[b & 15]); } return s; };
+    struct { const char *seed, *pub, *msg, *sig; } vec[2] = {
+        {"9d61b19deffd5a60ba844af492ec2cc44449c5697b326919703bac031cae7f60", "d75a980182b10ab7d54bfed3c964073a0ee172f3daa62325af021a68f707511a", "",
+         "e5564300c360ac729086e2cc806e828a84877f1eb8e5d974d873e065224901555fb8821590a33bacc61e39701cf9b46bd25bf5f0595bbe24655141438e7a100b"},
+        {"4ccd089b28ff96da9db6c346ec114e0f5b8a319f35aba624da8cf6ed4fb8a6fb", "3d4017c3e843895a92b70aa74d1b7ebc9c982ccf2ec4968cc0cd55f12af4660c", "72",
+         "92a009a9f0d4cab8720e820b5f642540a2b27b5416503f8fb3762223ebdb69da085ac1e43e15996e458f3613d0f11d8c387b2eaeb4302aeeb00d291612bb0c00"}};
+    for (auto& v : vec) {
+      std::vector<uint8_t> seed = unhex(v.seed), msg = unhex(v.msg);
+      eddsa::EdDSA ed = eddsa::EdDSA::from_seed_bytes(seed.data());
+      CHECK(ed.public_key.hex() == v.pub, "RFC 8032 public key");
+      std::vector<uint8_t> sig = ed.sign(msg.data(), msg.size());
+      CHECK(hexs(sig) == v.sig, "RFC 8032 signature");
+      bool ok = true;
+      try { ed.verify(msg.data(), msg.size(), sig.data(), sig.size()); } catch (const SignatureError&) { ok = false; }
+      CHECK(ok, "EdDSA::verify accepts its own signature");
+      std::vector<uint8_t> m = ed.marshal_binary();
+      CHECK(hexs(m) == std::string(v.seed) + v.pub, "marshal_binary = seed || public");
+      eddsa::EdDSA back;
+      back.unmarshal_binary(m.data(), m.size());
+      CHECK(back == ed, "unmarshal_binary(marshal_binary) round trip");
+    }
+    eddsa::EdDSA fresh(rand);
+    const uint8_t msg[] = "Hello Gophers";
+    std::vector<uint8_t> sig = fresh.sign(msg, sizeof(msg) - 1);
+    bool ok = true;
+    try { eddsa::verify(fresh.public_key, msg, sizeof(msg) - 1, sig.data(), 64); } catch (const SignatureError&) { ok = false; }
+    CHECK(ok, "fresh EdDSA key signs and verifies");
+    std::string err;
+    try { eddsa::EdDSA().unmarshal_binary(sig.data(), 63); } catch (const MarshallingError& e) { err = e.what(); }
+    CHECK(err == "wrong length for decoding EdDSA private", "EdDSA::unmarshal_binary length check");
+    // From<Pair>: empty prefix, nonce = H(msg)
+    Scalar x = Scalar().pick(rand);
+    eddsa::EdDSA pairkey = eddsa::EdDSA::from_pair(x, Point().mul(x, nullptr));
+    sig = pairkey.sign(msg, sizeof(msg) - 1);
+    ok = true;
+    try { pairkey.verify(msg, sizeof(msg) - 1, sig.data(), 64); } catch (const SignatureError&) { ok = false; }
+    CHECK(ok, "EdDSA from a key pair signs and verifies");
+  }
   // polynomials (poly_test.rs: public shares of the commitment equal the commitments of the private shares)
   {
     using namespace kyber::share;
