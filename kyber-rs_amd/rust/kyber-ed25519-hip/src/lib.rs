@@ -25,6 +25,21 @@ extern "C" {
                                   n: size_t, sig: *mut u8) -> c_int;
     pub fn kyb_mul_batch_dev(scalars: *const u8, pts_enc: *const u8, pts_ext: *const i32, n: size_t,
                              out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8, stream: *mut c_void) -> c_int;
+    // callers that hold the public key (EdDSA objects, DSS long-term keys): one fixed-base mult per signature
+    pub fn kyb_schnorr_sign_keyed_batch(x: *const u8, pubs: *const u8, k: *const u8, msgs: *const u8, msg_off: *const u32,
+                                        n: size_t, sig: *mut u8) -> c_int;
+    pub fn kyb_eddsa_sign_batch(seeds: *const u8, msgs: *const u8, msg_off: *const u32, n: size_t, sig: *mut u8, pub_out: *mut u8) -> c_int;
+    pub fn kyb_eddsa_sign_keyed_batch(seeds: *const u8, pubs: *const u8, msgs: *const u8, msg_off: *const u32, n: size_t, sig: *mut u8) -> c_int;
+    // verify_with_checks (eddsa_sig.rs:159-212 = flavor 0, schnorr_sig.rs:53-110 = flavor 1): status[i] 0 = valid, else the first failing check
+    pub fn kyb_verify_batch(pubs: *const u8, msgs: *const u8, msg_off: *const u32, sigs: *const u8, n: size_t, flavor: c_int, status: *mut u8) -> c_int;
+    // PubPoly::eval / shares (poly.rs:457-478), recover_commit / recover_pub_poly accumulation (poly.rs:566-634), Point::eq
+    pub fn kyb_pubpoly_eval_batch(commits_ext: *const i32, t: size_t, indices: *const u32, n: size_t, out_enc: *mut u8, out_ext: *mut i32) -> c_int;
+    pub fn kyb_lincomb_batch(scalars: *const u8, pts_enc: *const u8, pts_ext: *const i32, shared_points: c_int, m: size_t, t: size_t,
+                             out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8) -> c_int;
+    pub fn kyb_equal_batch(a_ext: *const i32, b_ext: *const i32, n: size_t, eq: *mut u8) -> c_int;
+    // page-locked batch buffers (optional: pageable slices work, through the engine's bounce buffers)
+    pub fn kyb_host_alloc(bytes: size_t) -> *mut c_void;
+    pub fn kyb_host_free(p: *mut c_void);
 }
 
 fn must(rc: c_int, what: &str) {
@@ -53,9 +68,7 @@ impl Point {
         let n = s.len();
         let sc: Vec<u8> = s.iter().flat_map(|x| x.v).collect();
         let mut out = vec![Point::default(); n];
-        let out_ext = out.as_mut_ptr() as *mut i32; // NB: stride must be 160 B — use a [[i32;10];4] staging Vec in real code
-        let _ = out_ext;
-        let mut staged = vec![[[0i32; 10]; 4]; n];
+        let mut staged = vec![[[0i32; 10]; 4]; n];   // 160-byte stride (Point itself carries `var_time` behind the limbs)
         match p {
             None => must(unsafe { kyb_mul_base_batch(sc.as_ptr(), n, std::ptr::null_mut(), staged.as_mut_ptr() as *mut i32) }, "mul_base_batch"),
             Some(ps) => {
@@ -67,6 +80,33 @@ impl Point {
         for (o, g) in out.iter_mut().zip(staged) { o.ge = g; }
         out
     }
+}
+
+/// `recover_commit` (poly.rs:566-603) with the accumulation on the GPU: the Lagrange coefficients stay scalar
+/// arithmetic on the CPU, the t multiplications and additions are one `kyb_lincomb_batch` call.
+pub fn recover_commit_accumulate(lagrange: &[Scalar], shares: &[Point]) -> Point {
+    assert_eq!(lagrange.len(), shares.len());
+    let sc: Vec<u8> = lagrange.iter().flat_map(|x| x.v).collect();
+    let inp: Vec<[[i32; 10]; 4]> = shares.iter().map(|q| q.ge).collect();
+    let mut out = Point::default();
+    must(unsafe { kyb_lincomb_batch(sc.as_ptr(), std::ptr::null(), inp.as_ptr() as *const i32, 0, 1, shares.len(),
+                                    std::ptr::null_mut(), out.ext_mut(), std::ptr::null_mut()) }, "lincomb");
+    out
+}
+
+/// `schnorr::verify_with_checks` for a batch (every DKG deal / response / DSS partial signature is verified by every peer).
+/// msgs[i] are concatenated; returns the per-item status (0 = valid; see include/kyber_ed25519.h for the codes).
+pub fn verify_batch(pubs: &[[u8; 32]], msgs: &[&[u8]], sigs: &[[u8; 64]], eddsa_order: bool) -> Vec<u8> {
+    let n = pubs.len();
+    let mut off = Vec::with_capacity(n + 1);
+    let mut blob = Vec::new();
+    off.push(0u32);
+    for m in msgs { blob.extend_from_slice(m); off.push(blob.len() as u32); }
+    blob.push(0);
+    let mut status = vec![0u8; n];
+    must(unsafe { kyb_verify_batch(pubs.as_ptr() as *const u8, blob.as_ptr(), off.as_ptr(), sigs.as_ptr() as *const u8, n,
+                                   if eddsa_order { 0 } else { 1 }, status.as_mut_ptr()) }, "verify_batch");
+    status
 }
 
 impl kyber_rs::encoding::BinaryMarshaler for Point {
