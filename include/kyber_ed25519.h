@@ -50,8 +50,10 @@ extern "C" {
 /* table image exchanged between GPUs at init — the role of constants.rs:89 BASE (which holds the 32 even
  * radix-16 positions only); affine (y+x, y-x, 2dxy), canonical limbs:
  *   bytes [0, 65536)        uint32 [64 pos][8 quads][ 8 entries][4]   entry (pos, j) = (j+1) * 16^pos * B
- *   bytes [65536, 172032)   uint32 [52 pos][8 quads][16 entries][4]   entry (pos, j) = (j+1) * 32^pos * B */
-#define KYB_BASE_TABLE_BYTES 172032u
+ *   bytes [65536, 172032)   uint32 [52 pos][8 quads][16 entries][4]   entry (pos, j) = (j+1) * 32^pos * B
+ *   bytes [172032, 335232)  42 windows of 3840 B: uint32 [7 quads][32 entries][4] + [32 entries][2], then a top window
+ *                           of 1920 B with 16 entries                 entry (pos, j) = (j+1) * 64^pos * B */
+#define KYB_BASE_TABLE_BYTES 335232u
 
 /* ---- lifecycle -------------------------------------------------------------------------------- */
 /* Bind this process to HIP device `device`, allocate the workspace, build the base-point table on

@@ -20,7 +20,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libkyber_ed25519_hip.so"
 LIB_PATH = os.environ.get("KYB_HIP_LIB") or os.path.join(_HERE, LIB_NAME)   # KYB_HIP_LIB: A/B builds of the same ABI
-BASE_TABLE_BYTES = 172032
+BASE_TABLE_BYTES = 335232
 
 KYB_OK = 0
 ERRORS = {-1: "KYB_E_NOT_INIT", -2: "KYB_E_BAD_ARG", -3: "KYB_E_NO_DEVICE", -4: "KYB_E_HIP", -5: "KYB_E_NOMEM"}

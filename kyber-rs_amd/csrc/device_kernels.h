@@ -16,6 +16,36 @@ __global__ void __launch_bounds__(64) k_base_table32(uint32_t* image) {
   if (e < KYB_BASE32_POS * 16) ge_base32_table_entry(image, e >> 4, e & 15);
 }
 
+__global__ void __launch_bounds__(64) k_base_table64(uint32_t* image) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // 0..1359: 42 windows x 32 entries, then the top window's 16
+  if (e < 42 * 32) ge_base64_table_entry(image, e >> 5, e & 31);
+  else if (e < 42 * 32 + 16) ge_base64_table_entry(image, 42, e - 42 * 32);
+}
+
+// Fixed base, signed radix 64: one 1024-thread workgroup per CU owns the whole LDS (163,200 B table);
+// 43 mixed additions per item.
+template <bool SPLIT>
+__global__ void __launch_bounds__(1024, 4)
+k_mul_base64(const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
+             const uint4* __restrict__ table_image, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
+  __shared__ uint4 lds_tbl[KYB_BASE64_TABLE_WORDS / 4];
+  for (int k = threadIdx.x; k < KYB_BASE64_TABLE_WORDS / 4; k += 1024) lds_tbl[k] = table_image[k];
+  __syncthreads();
+  tbl_lds64 tbl{reinterpret_cast<const uint32_t*>(lds_tbl)};
+  const size_t nchunks = (n + 1023) / 1024;
+  for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const size_t i = chunk * 1024 + threadIdx.x;
+    const bool live = i < n;
+    const size_t ii = live ? i : 0;
+    uint32_t a[8];
+    load_words8(a, scalars, ii);
+    ge_p3 h;
+    ge_scalarmult_base64(h, a, tbl);
+    if (SPLIT) { if (live) store_proj(proj, proj_stride, proj_offset + i, h.X, h.Y, h.Z); }
+    else finish_point(h.X, h.Y, h.Z, out_enc, out_ext, ii, live);
+  }
+}
+
 // Fixed base, signed radix 32: one 1024-thread workgroup per CU shares the 106,496-byte table in LDS
 // (4 waves per SIMD, <= 128 VGPRs); 52 mixed additions per item.
 constexpr int KYB_BLOCK32 = 1024;

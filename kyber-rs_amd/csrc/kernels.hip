@@ -19,14 +19,15 @@
 //   k_mul_ladder   Point::mul(s, Some(P))  ge.rs:508-568   Montgomery ladder + y-recovery (default)
 //   k_mul          the same, windowed      ge.rs:508-568   per-lane table 1P..8P in an L2/MALL-resident
 //                                                          workspace, [entry][quad][lane] (mul.algo=0)
-//   k_mul_base32   Point::mul(s, None)     ge.rs:442-486   52x16 affine table in LDS (106,496 B), batches
+//   k_mul_base64   Point::mul(s, None)     ge.rs:442-486   42x32+16 affine table = the whole LDS (163,200 B), batches
+//   k_mul_base32   the same                ge.rs:442-486   52x16 affine table in LDS (106,496 B)   (mul_base.radix=32)
 //   k_mul_base     the same                ge.rs:442-486   64x8 affine table in LDS (65,536 B), small n
 //   k_finish       batched inversion + encode (ge.rs:112-122)
 //   k_sign / k_sign_hash / k_eddsa_prep    schnorr_sig.rs:25-47, eddsa_sig.rs:120-152
 //   k_verify_prep / k_verify_final         eddsa_sig.rs:159-212, schnorr_sig.rs:53-110
 //   k_poly_eval / k_pair_sum               share/poly.rs:457-469, 566-634
 //   k_add / k_equal / k_encode / k_decode  point.rs:179-241 / 35-51
-//   k_base_table / k_base_table32          build the LDS table images on the GPU at init
+//   k_base_table / k_base_table32 / k_base_table64   build the LDS table images on the GPU at init
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -90,7 +91,7 @@ struct Ctx {
   char name[128] = {0};
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // second lane of the pipelined host-pointer path
-  uint32_t* table = nullptr;      // KYB_BASE_TABLE_BYTES: radix-16 image (65,536 B) followed by the radix-32 image (106,496 B)
+  uint32_t* table = nullptr;      // KYB_BASE_TABLE_BYTES: radix-16 image (65,536 B), radix-32 image (106,496 B), radix-64 image (163,200 B)
   bool table_ready = false;
   // per-stream device scratch (two launches that overlap on different streams must not share it):
   //   ws    variable-base table workspace (fixed size)
@@ -111,7 +112,7 @@ struct Ctx {
   int opt_mul_select = 1;         // 0 cndmask, 1 and/or mask
   int opt_base_select = 1;        // 0 LDS broadcast scan, 1 bpermute
   int opt_base_block = 256;       // 256 (2 waves/SIMD) or 512 (4 waves/SIMD, 128 VGPRs)   [radix-16 kernel]
-  int opt_base_radix = 32;        // 32: 52-window kernel for batches >= finish.min_items; 16: always the 64-window kernel
+  int opt_base_radix = 64;        // 64 / 32: 43- / 52-window kernel for batches >= finish.min_items; 16: always the 64-window kernel
   int opt_mul_algo = 1;           // 0 windowed table (ge.rs structure), 1 Montgomery ladder (table-free, 1.33x faster: profiles/r01/sweep_mul_algo.log)
   int opt_ladder_waves = 3;       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
   int opt_finish = 1;             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
@@ -275,6 +276,8 @@ int run_host_batch(size_t n, const HostArr* arrs, int na, Fn launch) {
   return KYB_OK;
 }
 
+static_assert(KYB_BASE_TABLE_BYTES == 4u * (KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS + KYB_BASE64_TABLE_WORDS), "table image layout");
+
 int do_init(int device, bool build_table) {
   std::lock_guard<std::mutex> lk(g.mu);
   if (g.ready) {
@@ -309,6 +312,8 @@ int do_init(int device, bool build_table) {
     hipLaunchKernelGGL(k_base_table, dim3(8), dim3(64), 0, g.stream, g.table);
     HIPCK(hipGetLastError());
     hipLaunchKernelGGL(k_base_table32, dim3(13), dim3(64), 0, g.stream, g.table + KYB_BASE_TABLE_WORDS);
+    HIPCK(hipGetLastError());
+    hipLaunchKernelGGL(k_base_table64, dim3(22), dim3(64), 0, g.stream, g.table + KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(g.stream));
     g.table_ready = true;
@@ -458,6 +463,15 @@ int launch_mul(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size
 // fixed-base multiplication of n scalars; SPLIT leaves the points in r->proj at [offset, offset + n)
 template <bool SPLIT>
 int launch_base_t(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, Ctx::StreamRes* r, size_t offset, hipStream_t st) {
+  if (g.opt_base_radix == 64 && n >= (size_t)g.opt_finish_min) {
+    const uint4* img64 = reinterpret_cast<const uint4*>(g.table + KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS);
+    const size_t nchunks64 = (n + 1023) / 1024;
+    const int grid64 = (int)(nchunks64 < (size_t)g.cus ? nchunks64 : (size_t)g.cus);     // one workgroup per CU: the table is its whole LDS
+    ProfScope ps(st, KID_MUL_BASE);
+    hipLaunchKernelGGL((k_mul_base64<SPLIT>), dim3(grid64), dim3(1024), 0, st, sc, n, oenc, oext, img64, r->proj, r->proj_items, offset);
+    HIPCK(hipGetLastError());
+    return KYB_OK;
+  }
   if (g.opt_base_radix == 32 && n >= (size_t)g.opt_finish_min) {
     const uint4* img32 = reinterpret_cast<const uint4*>(g.table + KYB_BASE_TABLE_WORDS);
     const size_t nchunks32 = (n + KYB_BLOCK32 - 1) / KYB_BLOCK32;

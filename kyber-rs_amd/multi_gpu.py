@@ -7,7 +7,7 @@ on CPU-only hosts the same code runs over gloo with a stand-in engine (tests/tes
 """
 from __future__ import annotations
 
-BASE_TABLE_BYTES = 172032
+BASE_TABLE_BYTES = 335232
 
 
 def shard(n_total: int, rank: int, world: int):

@@ -249,6 +249,21 @@ void hd_mul_base32(uint8_t out[32], const uint8_t scalar[32]) {
   ge_encode(w, h.X, h.Y, h.Z);
   memcpy(out, w, 32);
 }
+static std::vector<uint32_t> g_base64_table;
+void hd_mul_base64(uint8_t out[32], const uint8_t scalar[32]) {
+  if (g_base64_table.empty()) {
+    g_base64_table.resize(KYB_BASE64_TABLE_WORDS);
+    for (int pos = 0; pos < KYB_BASE64_POS; ++pos)
+      for (int j = 0; j < (pos == KYB_BASE64_POS - 1 ? 16 : 32); ++j) ge_base64_table_entry(g_base64_table.data(), pos, j);
+  }
+  uint32_t a[8], w[8];
+  load_words(a, scalar);
+  tbl_base64_words tbl{g_base64_table.data()};
+  ge_p3 h;
+  ge_scalarmult_base64(h, a, tbl);
+  ge_encode(w, h.X, h.Y, h.Z);
+  memcpy(out, w, 32);
+}
 void hd_eddsa_sign(uint8_t sig[64], const uint8_t seed[32], const uint8_t* msg, uint32_t n) {
   ensure_table();
   uint32_t ws[8], x[8], r[8], s[16];

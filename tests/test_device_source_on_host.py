@@ -286,6 +286,25 @@ def test_fixed_base_radix32_matches_oracle(hd, oracle):
     assert hd.hd_overflows() == base
 
 
+def test_fixed_base_radix64_matches_oracle(hd, oracle):
+    """52 -> 43 windows: the radix-64 recoding / table / routine gives the reference's bytes on the quirk scalars
+    (>= 2^255, top digits 8..16), on digit patterns that hit the window extremes (-32, +31, 0), and at random"""
+    base = hd.hd_overflows()
+    rnd = random.Random(64)
+    for q in KATS["quirk_mul_base"]:
+        o = B(32); hd.hd_mul_base64(o, bytes.fromhex(q["scalar"]))
+        assert o.raw.hex() == q["out"], q["scalar"]
+    L = M.L
+    ints = [0, 1, 31, 32, 33, 63, 64, 2**252 - 1, 2**252, 2**252 + 1, 9 * 2**252 - 1, 8 * 2**252 + 5, 2**255 - 19, 2**256 - 1, L, L - 1, 8 * L,
+            sum(32 << (6 * i) for i in range(42)), sum(31 << (6 * i) for i in range(43)) % 2**256, sum(33 << (6 * i) for i in range(42))]
+    cases = [v.to_bytes(32, "little") for v in ints] + [bytes([0xff] * 32), bytes([0xf8] * 32), bytes([0x10] * 32), bytes([0x84] * 32)]
+    cases += [bytes(rnd.getrandbits(8) for _ in range(32)) for _ in range(200)]
+    for s in cases:
+        o = B(32); hd.hd_mul_base64(o, s)
+        assert o.raw == oracle.mul_base(s), s.hex()
+    assert hd.hd_overflows() == base
+
+
 def test_eddsa_sign_golden_lines_device_source(hd):
     """EdDSA::sign (key expansion + deterministic nonce + Schnorr equations) straight from (seed, msg)"""
     for ln in gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n")[:64]:

@@ -388,13 +388,13 @@ def test_ladder_path_matches_oracle(engine, oracle, waves):
 
 
 def test_fixed_base_radix32_kernel(engine, oracle):
-    """the 52-window radix-32 kernel (1024-thread workgroups, 104 KiB LDS table) == the radix-16 kernel == oracle,
-    through mul_base, sign and verify; quirk scalars included"""
+    """the 43-window radix-64 kernel (1024-thread workgroups, the whole 160 KiB LDS as table) == the 52-window radix-32
+    kernel (104 KiB table) == the radix-16 kernel == oracle, through mul_base, sign and verify; quirk scalars included"""
     engine.set_option("finish.min_items", 1)       # route even small batches through it
     try:
         qb = KATS["quirk_mul_base"]
         qs = np.frombuffer(b"".join(bytes.fromhex(q["scalar"]) for q in qb), dtype=np.uint8)
-        for radix in (32, 16):
+        for radix in (64, 32, 16):
             engine.set_option("mul_base.radix", radix)
             assert [bytes(r).hex() for r in engine.mul_base(qs)] == [q["out"] for q in qb]
             for n in (1, 1023, 1024, 1025, 3000):
@@ -415,11 +415,12 @@ def test_fixed_base_radix32_kernel(engine, oracle):
             kc = synth.scalars(700, 72, b"k")
             assert not engine.verify(pub, msgs, engine.schnorr_sign(x, kc, msgs), 1).any()
     finally:
-        engine.set_option("mul_base.radix", 32)
+        engine.set_option("mul_base.radix", 64)
         engine.set_option("finish.min_items", 4096)
     # table image, radix-32 part: entry (pos, j) = (j+1) * 32^pos * B
     P = 2**255 - 19
-    img = np.frombuffer(engine.base_table().tobytes(), dtype=np.uint32)[65536 // 4:]
+    whole = np.frombuffer(engine.base_table().tobytes(), dtype=np.uint32)
+    img = whole[65536 // 4:]
     bits = [26, 25] * 5
 
     def val(limbs):
@@ -438,6 +439,20 @@ def test_fixed_base_radix32_kernel(engine, oracle):
         assert val([img[idx(pos, j, k)] for k in range(10)]) == (y + x) % P
         assert val([img[idx(pos, j, 10 + k)] for k in range(10)]) == (y - x) % P
         assert val([img[idx(pos, j, 20 + k)] for k in range(10)]) == 2 * M.D * x * y % P
+    # radix-64 part: entry (pos, j) = (j+1) * 64^pos * B, 30 packed words per entry
+    img64 = whole[172032 // 4:]
+    assert img64.shape[0] == 163200 // 4
+
+    def idx64(pos, j, k):
+        if pos < 42:
+            return pos * 960 + (((k >> 2) * 32 + j) * 4 + (k & 3) if k < 28 else 896 + j * 2 + (k - 28))
+        return 42 * 960 + (((k >> 2) * 16 + j) * 4 + (k & 3) if k < 28 else 448 + j * 2 + (k - 28))
+
+    for pos, j in ((0, 0), (0, 31), (1, 7), (20, 30), (41, 31), (42, 0), (42, 8), (42, 15)):
+        x, y = M.mul_int((j + 1) << (6 * pos), M.B)
+        assert val([img64[idx64(pos, j, k)] for k in range(10)]) == (y + x) % P
+        assert val([img64[idx64(pos, j, 10 + k)] for k in range(10)]) == (y - x) % P
+        assert val([img64[idx64(pos, j, 20 + k)] for k in range(10)]) == 2 * M.D * x * y % P
 
 
 def test_two_streams_and_two_threads(engine, oracle):

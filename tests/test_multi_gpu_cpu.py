@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 
 class FakeEngine:
     def __init__(self, have_table):
-        self.table = bytes((i * 131 + 7) & 0xFF for i in range(172032)) if have_table else None
+        self.table = bytes((i * 131 + 7) & 0xFF for i in range(335232)) if have_table else None
 
     def base_table_export_dev(self, t):
         t.copy_(torch.frombuffer(bytearray(self.table), dtype=torch.uint8))
@@ -56,7 +56,7 @@ def test_two_rank_shards_and_table_broadcast(n_total):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    want = hashlib.sha256(bytes((i * 131 + 7) & 0xFF for i in range(172032))).hexdigest()
+    want = hashlib.sha256(bytes((i * 131 + 7) & 0xFF for i in range(335232))).hexdigest()
     assert [r[3] for r in res] == [want, want]                 # rank 1 received rank 0's table
     assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == n_total   # disjoint + covering
     assert abs((res[0][2] - res[0][1]) - (res[1][2] - res[1][1])) <= 1
