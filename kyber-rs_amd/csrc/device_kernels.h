@@ -311,7 +311,7 @@ k_mont_prep(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ p
 }
 template <int WAVES>
 __global__ void __launch_bounds__(KYB_BLOCK, WAVES)
-k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ proj, size_t stride, size_t img_offset, size_t img_mod) {
+k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits) {
   const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t a[8];
@@ -326,7 +326,7 @@ k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ 
   for (int k = 0; k < 10; ++k) { m.u.v[k] = f[k]; m.v.v[k] = f[10 + k]; }
   m.flags = f[20];
   ge_p2 r;
-  ge_scalarmult_ladder(r, a, m);
+  ge_scalarmult_ladder(r, a, m, skip_bits);
   store_proj(proj, stride, i, r.X, r.Y, r.Z);
 }
 

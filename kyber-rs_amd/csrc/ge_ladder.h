@@ -77,7 +77,9 @@ KYB_HD void mont_prep_finish(mont_point& m, const ge_p3& P, const fe& dinv, uint
 }
 
 // x-only ladder: (x2:z2) = k*P, (x3:z3) = (k+1)*P for the 256-bit k = mag, u1 = u(P) affine.
-KYB_HD void mont_ladder(fe& x2, fe& z2, fe& x3, fe& z3, const fe& u1, const uint32_t mag[8]) {
+// skip: leading bits of the 256-bit register known to be zero for EVERY item of the launch on public grounds
+// (3 for a scalar reduced mod L, as the challenge h of a verification): the ladder starts below them.
+KYB_HD void mont_ladder(fe& x2, fe& z2, fe& x3, fe& z3, const fe& u1, const uint32_t mag[8], int skip = 0) {
   fe_one(x2); fe_zero(z2); fe_copy(x3, u1); fe_one(z3);
   uint32_t swap = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -86,10 +88,12 @@ KYB_HD void mont_ladder(fe& x2, fe& z2, fe& x3, fe& z3, const fe& u1, const uint
   for (int w = 7; w >= 0; --w) {
     uint32_t word = 0;
     KYB_UNROLL for (int k = 0; k < 8; ++k) word = (w == k) ? mag[k] : word;
+    const int first = (w == 7) ? skip : 0;
+    word <<= first;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-    for (int j = 0; j < 32; ++j) {
+    for (int j = first; j < 32; ++j) {
       const uint32_t bit = word >> 31;
       word <<= 1;
       swap ^= bit;
@@ -194,11 +198,11 @@ KYB_HD void mont_recover_to_edwards(ge_p2& out, const mont_point& m, const fe& x
 }
 
 // whole multiplication for one item given its prepared Montgomery image
-KYB_HD void ge_scalarmult_ladder(ge_p2& out, const uint32_t a[8], const mont_point& m) {
+KYB_HD void ge_scalarmult_ladder(ge_p2& out, const uint32_t a[8], const mont_point& m, int skip = 0) {
   uint32_t neg, mag[8];
   sc_effective(neg, mag, a);
   fe x2, z2, x3, z3;
-  mont_ladder(x2, z2, x3, z3, m.u, mag);
+  mont_ladder(x2, z2, x3, z3, m.u, mag, skip);
   mont_recover_to_edwards(out, m, x2, z2, x3, z3, mag[0] & 1u, neg);
 }
 

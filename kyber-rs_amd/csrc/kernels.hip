@@ -386,8 +386,9 @@ void launch_mul_t(int sel, bool enc, int grid, hipStream_t st, const uint8_t* sc
 // leaves the results projective in r->proj[0, n): prep (batched inversion) -> 256-step ladder.
 // npts == 0: item i multiplies point i.  npts > 0: the npts points are shared, item i multiplies point
 // i mod npts (their Montgomery images live in records [n, n + npts)).
+// skip_bits: leading zero bits every scalar of the launch has for public reasons (3 for values reduced mod L).
 int launch_ladder_core(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* ok, Ctx::StreamRes* r, hipStream_t st,
-                       size_t npts = 0) {
+                       size_t npts = 0, int skip_bits = 0) {
   const size_t np = npts ? npts : n;
   int rc = ensure_proj(r, n + npts); if (rc) return rc;
   const unsigned blocks = (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK);
@@ -409,9 +410,9 @@ int launch_ladder_core(const uint8_t* sc, const uint8_t* penc, const int32_t* pe
   HIPCK(hipGetLastError());
   {
     ProfScope ps(st, KID_MUL_LADDER);
-    if (g.opt_ladder_waves >= 4)      hipLaunchKernelGGL((k_mul_ladder<4>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items, n, npts);
-    else if (g.opt_ladder_waves == 3) hipLaunchKernelGGL((k_mul_ladder<3>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items, n, npts);
-    else                              hipLaunchKernelGGL((k_mul_ladder<2>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items, n, npts);
+    if (g.opt_ladder_waves >= 4)      hipLaunchKernelGGL((k_mul_ladder<4>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items, n, npts, skip_bits);
+    else if (g.opt_ladder_waves == 3) hipLaunchKernelGGL((k_mul_ladder<3>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items, n, npts, skip_bits);
+    else                              hipLaunchKernelGGL((k_mul_ladder<2>), dim3(blocks), dim3(KYB_BLOCK), 0, st, sc, n, r->proj, r->proj_items, n, npts, skip_bits);
   }
   HIPCK(hipGetLastError());
   return KYB_OK;
@@ -603,7 +604,7 @@ int launch_verify(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off,
   }
   HIPCK(hipGetLastError());
   if (g.opt_mul_algo == 1) {
-    rc = launch_ladder_core(hbuf, nullptr, a_ext, n, nullptr, r, st); if (rc) return rc;
+    rc = launch_ladder_core(hbuf, nullptr, a_ext, n, nullptr, r, st, 0, 3); if (rc) return rc;      // h < L < 2^253
   } else {
     rc = ensure_ws(r); if (rc) return rc;
     const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;

@@ -185,7 +185,9 @@ int hd_equal(const int32_t a[40], const int32_t b[40]) {
   fe_from_ref10(B.X, b); fe_from_ref10(B.Y, b + 10); fe_from_ref10(B.Z, b + 20); fe_from_ref10(B.T, b + 30);
   return (int)ge_equal(A, B);
 }
-void hd_mul_ladder(uint8_t out[32], const uint8_t scalar[32], const int32_t pt[40]) {
+void hd_mul_ladder_skip(uint8_t out[32], const uint8_t scalar[32], const int32_t pt[40], int skip);
+void hd_mul_ladder(uint8_t out[32], const uint8_t scalar[32], const int32_t pt[40]) { hd_mul_ladder_skip(out, scalar, pt, 0); }
+void hd_mul_ladder_skip(uint8_t out[32], const uint8_t scalar[32], const int32_t pt[40], int skip) {
   uint32_t a[8], w[8];
   load_words(a, scalar);
   ge_p3 P;

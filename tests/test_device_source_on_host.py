@@ -267,6 +267,12 @@ def test_ladder_path_matches_oracle(hd, oracle):
             s = ((rnd.choice([1, 2, 4, 8]) * M.L + rnd.choice([-1, 0, 1])) % 2**256).to_bytes(32, "little")
         o = B(32); hd.hd_mul_ladder(o, s, p32(pt))
         assert o.raw == oracle.mul(s, pt), (i, s.hex())
+    # verification multiplies by h < L < 2^253: the ladder may start three bits lower
+    for v in [0, 1, 2, M.L - 1, M.L - 2, 2**252, 2**252 - 1, 2**252 + 12345] + [rnd.randrange(M.L) for _ in range(40)]:
+        s = v.to_bytes(32, "little")
+        pt = oracle.add(oracle.mul_base_ext(bytes(rnd.getrandbits(8) for _ in range(32))), weak[rnd.choice([0, 2, 3, 4])])
+        o = B(32); hd.hd_mul_ladder_skip(o, s, p32(pt), 3)
+        assert o.raw == oracle.mul(s, pt), v
     assert hd.hd_overflows() == base
 
 

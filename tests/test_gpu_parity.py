@@ -677,3 +677,45 @@ def test_host_pointer_paths_agree(engine, oracle):
         engine.set_option("host.copy_threads", 0)
     idx = np.concatenate([rng.choice(n, 256, replace=False), [0, n - 1, (1 << 17) - 1, 1 << 17]])
     assert np.array_equal(enc_m[idx], oracle.mul_batch(t[idx], ext[idx], nthreads=8))
+
+
+def test_bad_arguments_are_rejected(engine, oracle):
+    """error behaviour of the C ABI (INTEGRATION.md §3): a bad call returns a negative code with a message and
+    leaves the engine usable; nothing is written on error"""
+    import ctypes
+    import torch
+    import kyber_rs_amd
+    lib = engine.lib
+    s = synth.scalars(4, 5)
+    out = np.full((4, 32), 0xAB, dtype=np.uint8)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert lib.kyb_mul_base_batch(None, 4, p(out), None) == -2
+    assert b"null" in lib.kyb_last_error()
+    assert lib.kyb_mul_base_batch(p(s), 4, None, None) == -2                         # no output requested
+    assert lib.kyb_mul_batch(p(s), None, None, 4, p(out), None, None) == -2          # neither encodings nor limbs
+    ext = oracle.mul_base_ext_batch(s)
+    enc = np.stack([np.frombuffer(oracle.encode(e), dtype=np.uint8) for e in ext])
+    assert lib.kyb_mul_batch(p(s), p(enc), p(ext), 4, p(out), None, None) == -2      # both given
+    assert (out == 0xAB).all()
+    off_bad = np.array([0, 8, 4, 12, 16], dtype=np.uint32)
+    msgs = np.zeros(17, dtype=np.uint8)
+    sig = np.zeros((4, 64), dtype=np.uint8)
+    assert lib.kyb_schnorr_sign_batch(p(s), p(s), p(msgs), p(off_bad), 4, p(sig)) == -2
+    assert b"non-decreasing" in lib.kyb_last_error()
+    assert lib.kyb_verify_batch(p(enc), p(msgs), p(off_bad), p(sig), 4, 7, p(out)) == -2   # unknown flavor / bad offsets
+    assert lib.kyb_lincomb_batch(p(s), None, p(ext), 0, 2, 0, p(out), None, None) == -2    # t = 0
+    assert lib.kyb_pubpoly_eval_batch(p(ext), 4, p(np.array([0xFFFFFFFF], dtype=np.uint32)), 1, p(out), None) == -2   # index + 1 overflows
+    assert lib.kyb_set_option(b"no.such.option", 1) == -2
+    assert lib.kyb_set_option(b"mul_base.radix", 48) == -2
+    # device-pointer API: misaligned buffers are refused before any launch
+    d = torch.zeros(4 * 32 + 16, dtype=torch.uint8, device="cuda:0")
+    o = torch.zeros((4, 32), dtype=torch.uint8, device="cuda:0")
+    assert lib.kyb_mul_base_batch_dev(ctypes.c_void_p(d.data_ptr() + 4), 4, ctypes.c_void_p(o.data_ptr()), None, None) == -2
+    assert b"aligned" in lib.kyb_last_error()
+    # n = 0 is a no-op that succeeds even with null buffers
+    assert lib.kyb_mul_base_batch(None, 0, None, None) == 0
+    assert lib.kyb_verify_batch(None, None, None, None, 0, 0, None) == 0
+    # and the engine still works
+    assert np.array_equal(engine.mul_base(s), oracle.mul_base_batch(s))
+    with pytest.raises(kyber_rs_amd.KyberHipError):
+        engine.set_option("finish.min_items", 0)
