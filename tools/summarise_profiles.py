@@ -15,19 +15,21 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = "gpurun_out/prof"
 dst = os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-DOM = {"mul": "k_mul_ladder<", "mul_base": "k_mul_base<", "sign": "k_mul_base<"}
-ITEMS = {"mul": 1 << 20, "mul_base": 1 << 20, "sign": 1 << 18}
-for w in ("mul", "mul_base", "sign"):
+DOM = {"mul": "k_mul_ladder<", "mul_base": "k_mul_base", "sign": "k_mul_base", "verify": "k_mul_ladder<"}
+ITEMS = {"mul": 1 << 20, "mul_base": 1 << 20, "sign": 1 << 18, "verify": 1 << 20}
+for w in ("mul", "mul_base", "sign", "verify"):
     ks = sorted(glob.glob(f"{src}/{w}_trace/*/*kernel_stats.csv"), key=os.path.getmtime)
     if ks:
         shutil.copyfile(ks[-1], os.path.join(dst, f"{w}_kernel_stats.csv"))      # newest run only
     out = {}
+    names = set()
     for p in ("sq", "fetch", "write"):
         for f in sorted(glob.glob(f"{src}/{w}_pmc_{p}/*/*counter_collection.csv"), key=os.path.getmtime)[-1:]:
             agg = collections.defaultdict(list)
             meta = {}
             for r in csv.DictReader(open(f)):
                 if DOM[w] in r["Kernel_Name"]:
+                    names.add(r["Kernel_Name"].split("(")[0])
                     agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                     meta = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size") if k in r}
             for k, v in agg.items():
@@ -37,7 +39,7 @@ for w in ("mul", "mul_base", "sign"):
     if not out:
         continue
     g = lambda k: out[k]["mean_per_dispatch"]
-    d = {"kernel": DOM[w].rstrip("<"), "note": "separate --pmc passes (SQ / FETCH_SIZE+GRBM / WRITE_SIZE+TCC), MI355X, means over the dispatches of the dominant kernel"}
+    d = {"kernel": "/".join(sorted(names)) or DOM[w].rstrip("<"), "note": "separate --pmc passes (SQ / FETCH_SIZE+GRBM / WRITE_SIZE+TCC), MI355X, means over the dispatches of the dominant kernel"}
     if "SQ_ACTIVE_INST_VALU" in out and "GRBM_GUI_ACTIVE" in out:
         d["VALUBusy_pct"] = 100 * g("SQ_ACTIVE_INST_VALU") * 4 / 1024 / (g("GRBM_GUI_ACTIVE") / 8)
     if "FETCH_SIZE" in out:
