@@ -12,9 +12,4 @@ for w in mul mul_base sign verify; do
   rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/${w}_pmc_write -- python3 bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --check 64 > /dev/null 2> $out/${w}_pmc_write.err
   echo "profiled $w"
 done
-# plain bench lines (no profiler attached) of the same build, CPU baseline included for the headline workload
-: > gpurun_out/bench_lines.jsonl
-python3 bench.py --workload mul 2>/dev/null | tail -1 >> gpurun_out/bench_lines.jsonl
-for w in mul_base sign verify; do python3 bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 >> gpurun_out/bench_lines.jsonl; done
-python3 bench.py --workload sign --keyed --no-cpu-baseline 2>/dev/null | tail -1 >> gpurun_out/bench_lines.jsonl
-echo "bench lines done"
+# then: python tools/summarise_profiles.py <round> (here or in the build container), and tools/bench_lines.sh for the plain lines
