@@ -2,7 +2,7 @@
 
 SURVEY.md §8(e): every scalar-mult is independent, so rank r of G takes the index range
 [r*N/G, (r+1)*N/G) and no data-path collective exists.  The only exchange is the base-point table
-image (172,032 B: radix-16 and radix-32 tables) that rank 0 builds on its GPU and broadcasts over RCCL/xGMI (backend "nccl" on ROCm);
+image (335,232 B: radix-16, -32 and -64 tables) that rank 0 builds on its GPU and broadcasts over RCCL/xGMI (backend "nccl" on ROCm);
 on CPU-only hosts the same code runs over gloo with a stand-in engine (tests/test_multi_gpu_cpu.py).
 """
 from __future__ import annotations
@@ -36,3 +36,4 @@ def distribute_base_table(engine, rank: int, world: int, device, dist=None) -> N
         torch.cuda.synchronize()
     if rank != 0:
         engine.base_table_import_dev(tbl)
+        engine.sync()          # the copy reads `tbl`: finish it before the tensor goes back to the allocator
