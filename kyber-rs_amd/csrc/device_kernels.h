@@ -22,19 +22,20 @@ __global__ void __launch_bounds__(64) k_base_table64(uint32_t* image) {
   else if (e < 42 * 32 + 16) ge_base64_table_entry(image, 42, e - 42 * 32);
 }
 
-// Fixed base, signed radix 64: one 1024-thread workgroup per CU owns the whole LDS (163,200 B table);
-// 43 mixed additions per item.
-template <bool SPLIT>
-__global__ void __launch_bounds__(1024, 4)
+// Fixed base, signed radix 64: one workgroup per CU owns the whole LDS (163,200 B table); 43 mixed additions
+// per item.  BLOCK = 1024 (4 waves/SIMD) when the batch fills the chip, 256 (1 wave/SIMD, four times as many
+// CUs busy) for batches that do not.
+template <bool SPLIT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, BLOCK / 256)
 k_mul_base64(const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
              const uint4* __restrict__ table_image, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
   __shared__ uint4 lds_tbl[KYB_BASE64_TABLE_WORDS / 4];
-  for (int k = threadIdx.x; k < KYB_BASE64_TABLE_WORDS / 4; k += 1024) lds_tbl[k] = table_image[k];
+  for (int k = threadIdx.x; k < KYB_BASE64_TABLE_WORDS / 4; k += BLOCK) lds_tbl[k] = table_image[k];
   __syncthreads();
   tbl_lds64 tbl{reinterpret_cast<const uint32_t*>(lds_tbl)};
-  const size_t nchunks = (n + 1023) / 1024;
+  const size_t nchunks = (n + BLOCK - 1) / BLOCK;
   for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const size_t i = chunk * 1024 + threadIdx.x;
+    const size_t i = chunk * BLOCK + threadIdx.x;
     const bool live = i < n;
     const size_t ii = live ? i : 0;
     uint32_t a[8];

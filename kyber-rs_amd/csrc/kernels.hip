@@ -113,10 +113,11 @@ struct Ctx {
   int opt_base_select = 1;        // 0 LDS broadcast scan, 1 bpermute
   int opt_base_block = 256;       // 256 (2 waves/SIMD) or 512 (4 waves/SIMD, 128 VGPRs)   [radix-16 kernel]
   int opt_base_radix = 64;        // 64 / 32: 43- / 52-window kernel for batches >= finish.min_items; 16: always the 64-window kernel
+  int opt_base_small_chunks = 2;  // radix-64 kernel: 256-thread workgroups up to this many chunks per CU, 1024-thread beyond
   int opt_mul_algo = 1;           // 0 windowed table (ge.rs structure), 1 Montgomery ladder (table-free, 1.33x faster: profiles/r01/sweep_mul_algo.log)
   int opt_ladder_waves = 3;       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
   int opt_finish = 1;             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
-  int opt_finish_min = 4096;
+  int opt_finish_min = 64;            // below: fused per-item inversion in the radix-16 kernels (tools/midsize_bench.py)
   std::mutex mu;          // host-pointer API: staging buffer + engine stream
   std::mutex launch_mu;   // every launch_* entry: per-stream scratch bookkeeping (calls from any thread, any stream)
 };
@@ -465,11 +466,15 @@ int launch_mul(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size
 template <bool SPLIT>
 int launch_base_t(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, Ctx::StreamRes* r, size_t offset, hipStream_t st) {
   if (g.opt_base_radix == 64 && n >= (size_t)g.opt_finish_min) {
+    // one workgroup per CU (the table is its whole LDS); 256-thread workgroups while that leaves CUs idle
     const uint4* img64 = reinterpret_cast<const uint4*>(g.table + KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS);
-    const size_t nchunks64 = (n + 1023) / 1024;
-    const int grid64 = (int)(nchunks64 < (size_t)g.cus ? nchunks64 : (size_t)g.cus);     // one workgroup per CU: the table is its whole LDS
+    const bool small = n <= (size_t)256 * (size_t)g.cus * (size_t)g.opt_base_small_chunks;
+    const size_t block = small ? 256 : 1024;
+    const size_t nchunks64 = (n + block - 1) / block;
+    const int grid64 = (int)(nchunks64 < (size_t)g.cus ? nchunks64 : (size_t)g.cus);
     ProfScope ps(st, KID_MUL_BASE);
-    hipLaunchKernelGGL((k_mul_base64<SPLIT>), dim3(grid64), dim3(1024), 0, st, sc, n, oenc, oext, img64, r->proj, r->proj_items, offset);
+    if (small) hipLaunchKernelGGL((k_mul_base64<SPLIT, 256>), dim3(grid64), dim3(256), 0, st, sc, n, oenc, oext, img64, r->proj, r->proj_items, offset);
+    else       hipLaunchKernelGGL((k_mul_base64<SPLIT, 1024>), dim3(grid64), dim3(1024), 0, st, sc, n, oenc, oext, img64, r->proj, r->proj_items, offset);
     HIPCK(hipGetLastError());
     return KYB_OK;
   }

@@ -33,12 +33,21 @@ def rand_points_ext(oracle, n, seed):
 
 @pytest.mark.parametrize("select", [0, 1])
 def test_mul_base_matches_oracle(engine, oracle, select):
-    engine.set_option("mul_base.select", select)
+    """the radix-16 kernel (64 x 8 table), both selection variants, fused and split finish; then the default kernel"""
     s = np.concatenate([synth.scalars(1500, 1), synth.raw256(549, 1)])
-    got = engine.mul_base(s)
     want = oracle.mul_base_batch(s, nthreads=8)
-    assert np.array_equal(got, want)
-    engine.set_option("mul_base.select", 1)
+    engine.set_option("mul_base.select", select)
+    engine.set_option("mul_base.radix", 16)
+    try:
+        assert np.array_equal(engine.mul_base(s), want)
+        engine.set_option("finish.min_items", 1 << 20)          # fused per-item inversion
+        assert np.array_equal(engine.mul_base(s), want)
+    finally:
+        engine.set_option("finish.min_items", 64)
+        engine.set_option("mul_base.radix", 64)
+        engine.set_option("mul_base.select", 1)
+    assert np.array_equal(engine.mul_base(s), want)
+    assert np.array_equal(engine.mul_base(s[:63]), want[:63])   # below finish.min_items: the fused radix-16 kernel
 
 
 @pytest.mark.parametrize("select", [0, 1])
@@ -220,6 +229,7 @@ def test_split_finish_and_block_variants(engine, oracle, block):
     kernel give the same bytes as the fused path / the oracle, including ragged tails"""
     engine.set_option("finish.min_items", 1)
     engine.set_option("mul_base.block", block)
+    engine.set_option("mul_base.radix", 16)
     try:
         for n in (1, 7, 8, 9, 1000, 2051):
             s = np.concatenate([synth.scalars(n - n // 3, 31), synth.raw256(n // 3, 31)])
@@ -240,8 +250,9 @@ def test_split_finish_and_block_variants(engine, oracle, block):
         assert np.array_equal(engine.schnorr_sign(x, k, msgs), oracle.schnorr_sign_batch(x, k, msgs, nthreads=8))
     finally:
         engine.set_option("finish.batched", 1)
-        engine.set_option("finish.min_items", 4096)
+        engine.set_option("finish.min_items", 64)
         engine.set_option("mul_base.block", 256)
+        engine.set_option("mul_base.radix", 64)
 
 
 def test_split_finish_isolates_degenerate_z(engine, oracle):
@@ -261,7 +272,7 @@ def test_split_finish_isolates_degenerate_z(engine, oracle):
         b = engine.mul(s, pts_ext=pts)
     finally:
         engine.set_option("finish.batched", 1)
-        engine.set_option("finish.min_items", 4096)
+        engine.set_option("finish.min_items", 64)
         engine.set_option("mul.algo", 1)
     assert np.array_equal(a, b)
     want = oracle.mul_batch(s, pts, nthreads=8)
@@ -416,7 +427,7 @@ def test_fixed_base_radix32_kernel(engine, oracle):
             assert not engine.verify(pub, msgs, engine.schnorr_sign(x, kc, msgs), 1).any()
     finally:
         engine.set_option("mul_base.radix", 64)
-        engine.set_option("finish.min_items", 4096)
+        engine.set_option("finish.min_items", 64)
     # table image, radix-32 part: entry (pos, j) = (j+1) * 32^pos * B
     P = 2**255 - 19
     whole = np.frombuffer(engine.base_table().tobytes(), dtype=np.uint32)
