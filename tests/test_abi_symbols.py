@@ -52,3 +52,14 @@ def test_product_tree_does_not_reference_the_oracle():
                     if re.search(r"oracle/|liboracle|oracle_lib|bigint_model", t):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: the header must compile as C99 (no C++-isms, no torch / HIP types)"""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "kyber_ed25519.h"\nint main(void) { return (int)(KYB_BASE_TABLE_BYTES == 0); }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+    txt = open(os.path.join(ROOT, "include", "kyber_ed25519.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    assert not re.search(r"hipStream_t|hipError_t|torch|at::|std::|#include\s*<hip", code)

@@ -730,3 +730,27 @@ def test_bad_arguments_are_rejected(engine, oracle):
     assert np.array_equal(engine.mul_base(s), oracle.mul_base_batch(s))
     with pytest.raises(kyber_rs_amd.KyberHipError):
         engine.set_option("finish.min_items", 0)
+
+
+def test_cfg5_whole_2_24_on_one_gpu(engine, oracle):
+    """BASELINE config 5's whole batch (2^24 items) as ONE launch: buffers beyond 2^31 bytes (2^24 x 160 B of points,
+    2^24 x 128 B of staging) exercise the 64-bit index arithmetic; variable base on P = B must equal fixed base for
+    every item, and a sample must equal the oracle"""
+    import torch
+    n = 1 << 24
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(24)
+    s = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
+    s[:, 31] &= 0x1F                                        # up to 2^253: reduced and unreduced scalars
+    enc_fixed = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    engine.mul_base_dev(s, out_enc=enc_fixed)
+    bext = torch.from_numpy(oracle.base()).to(dev).repeat(n, 1)
+    assert bext.numel() * 4 > 2**31
+    enc_var = torch.empty_like(enc_fixed)
+    engine.mul_dev(s, pts_ext=bext, out_enc=enc_var)
+    engine.sync()
+    assert torch.equal(enc_fixed, enc_var)
+    idx = torch.cat([torch.randint(0, n, (500,), generator=torch.Generator().manual_seed(1)), torch.tensor([0, n - 1, (1 << 23) - 1, 1 << 23, (1 << 24) - 1025])])
+    assert np.array_equal(enc_fixed[idx.to(dev)].cpu().numpy(), oracle.mul_base_batch(s[idx.to(dev)].cpu().numpy(), nthreads=8))
+    del bext, enc_var, enc_fixed, s
+    torch.cuda.empty_cache()
