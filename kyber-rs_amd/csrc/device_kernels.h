@@ -25,9 +25,12 @@ __global__ void __launch_bounds__(64) k_base_table64(uint32_t* image) {
 // Fixed base, signed radix 64: one workgroup per CU owns the whole LDS (163,200 B table); 43 mixed additions
 // per item.  BLOCK = 1024 (4 waves/SIMD) when the batch fills the chip, 256 (1 wave/SIMD, four times as many
 // CUs busy) for batches that do not.
+// Two scalar arrays may be multiplied in one launch (signing: the nonces and the private keys): items
+// [0, n_a) come from `scalars`, items [n_a, n) from `scalars_b`.
 template <bool SPLIT, int BLOCK>
 __global__ void __launch_bounds__(BLOCK, BLOCK / 256)
-k_mul_base64(const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
+k_mul_base64(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ scalars_b, size_t n_a, size_t n,
+             uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
              const uint4* __restrict__ table_image, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
   __shared__ uint4 lds_tbl[KYB_BASE64_TABLE_WORDS / 4];
   for (int k = threadIdx.x; k < KYB_BASE64_TABLE_WORDS / 4; k += BLOCK) lds_tbl[k] = table_image[k];
@@ -39,7 +42,7 @@ k_mul_base64(const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict_
     const bool live = i < n;
     const size_t ii = live ? i : 0;
     uint32_t a[8];
-    load_words8(a, scalars, ii);
+    if (ii < n_a) load_words8(a, scalars, ii); else load_words8(a, scalars_b, ii - n_a);
     ge_p3 h;
     ge_scalarmult_base64(h, a, tbl);
     if (SPLIT) { if (live) store_proj(proj, proj_stride, proj_offset + i, h.X, h.Y, h.Z); }

@@ -117,7 +117,7 @@ struct Ctx {
   int opt_mul_algo = 1;           // 0 windowed table (ge.rs structure), 1 Montgomery ladder (table-free, 1.33x faster: profiles/r01/sweep_mul_algo.log)
   int opt_ladder_waves = 3;       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
   int opt_finish = 1;             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
-  int opt_finish_min = 64;            // below: fused per-item inversion in the radix-16 kernels (tools/midsize_bench.py)
+  int opt_finish_min = 1;             // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size, tools/midsize_bench.py; kept as a cross-check)
   std::mutex mu;          // host-pointer API: staging buffer + engine stream
   std::mutex launch_mu;   // every launch_* entry: per-stream scratch bookkeeping (calls from any thread, any stream)
 };
@@ -463,9 +463,18 @@ int launch_mul(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size
 }
 
 // fixed-base multiplication of n scalars; SPLIT leaves the points in r->proj at [offset, offset + n)
+// sc_b != nullptr: a second array of n_b scalars follows the first in the same launch (radix-64 kernel), their
+// results land behind the first n
 template <bool SPLIT>
-int launch_base_t(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, Ctx::StreamRes* r, size_t offset, hipStream_t st) {
-  if (g.opt_base_radix == 64 && n >= (size_t)g.opt_finish_min) {
+int launch_base_t(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, Ctx::StreamRes* r, size_t offset, hipStream_t st,
+                  const uint8_t* sc_b = nullptr, size_t n_b = 0) {
+  if (sc_b != nullptr && !(g.opt_base_radix == 64 && n + n_b >= (size_t)g.opt_finish_min)) {
+    int rc = launch_base_t<SPLIT>(sc, n, oenc, oext, r, offset, st); if (rc) return rc;
+    return launch_base_t<SPLIT>(sc_b, n_b, oenc ? oenc + 32 * n : nullptr, oext ? oext + 40 * n : nullptr, r, offset + n, st);
+  }
+  if (g.opt_base_radix == 64 && n + n_b >= (size_t)g.opt_finish_min) {
+    const size_t n_a = n;
+    n += n_b;
     // one workgroup per CU (the table is its whole LDS); 256-thread workgroups while that leaves CUs idle
     const uint4* img64 = reinterpret_cast<const uint4*>(g.table + KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS);
     const bool small = n <= (size_t)256 * (size_t)g.cus * (size_t)g.opt_base_small_chunks;
@@ -473,8 +482,8 @@ int launch_base_t(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, Ctx
     const size_t nchunks64 = (n + block - 1) / block;
     const int grid64 = (int)(nchunks64 < (size_t)g.cus ? nchunks64 : (size_t)g.cus);
     ProfScope ps(st, KID_MUL_BASE);
-    if (small) hipLaunchKernelGGL((k_mul_base64<SPLIT, 256>), dim3(grid64), dim3(256), 0, st, sc, n, oenc, oext, img64, r->proj, r->proj_items, offset);
-    else       hipLaunchKernelGGL((k_mul_base64<SPLIT, 1024>), dim3(grid64), dim3(1024), 0, st, sc, n, oenc, oext, img64, r->proj, r->proj_items, offset);
+    if (small) hipLaunchKernelGGL((k_mul_base64<SPLIT, 256>), dim3(grid64), dim3(256), 0, st, sc, sc_b, n_a, n, oenc, oext, img64, r->proj, r->proj_items, offset);
+    else       hipLaunchKernelGGL((k_mul_base64<SPLIT, 1024>), dim3(grid64), dim3(1024), 0, st, sc, sc_b, n_a, n, oenc, oext, img64, r->proj, r->proj_items, offset);
     HIPCK(hipGetLastError());
     return KYB_OK;
   }
@@ -540,8 +549,7 @@ int sign_locked(Ctx::StreamRes* r, const uint8_t* x, const uint8_t* k, const uin
     // R = k*B -> proj[0, n), A = x*B -> proj[n, 2n); one batched finish; then hash + scalar arithmetic
     int rc = ensure_proj(r, 2 * n); if (rc) return rc;
     rc = ensure_enc(r, 64 * n); if (rc) return rc;
-    rc = launch_base_t<true>(k, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
-    rc = launch_base_t<true>(x, n, nullptr, nullptr, r, n, st); if (rc) return rc;
+    rc = launch_base_t<true>(k, n, nullptr, nullptr, r, 0, st, x, n); if (rc) return rc;
     rc = launch_finish(r, 2 * n, r->enc, nullptr, st); if (rc) return rc;
     {
       ProfScope ps(st, KID_SIGN_HASH);

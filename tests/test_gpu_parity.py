@@ -43,11 +43,12 @@ def test_mul_base_matches_oracle(engine, oracle, select):
         engine.set_option("finish.min_items", 1 << 20)          # fused per-item inversion
         assert np.array_equal(engine.mul_base(s), want)
     finally:
-        engine.set_option("finish.min_items", 64)
+        engine.set_option("finish.min_items", 1)
         engine.set_option("mul_base.radix", 64)
         engine.set_option("mul_base.select", 1)
     assert np.array_equal(engine.mul_base(s), want)
-    assert np.array_equal(engine.mul_base(s[:63]), want[:63])   # below finish.min_items: the fused radix-16 kernel
+    for n in (1, 2, 63):                                         # tiny batches through the default (radix-64, split) path
+        assert np.array_equal(engine.mul_base(s[:n]), want[:n])
 
 
 @pytest.mark.parametrize("select", [0, 1])
@@ -150,6 +151,16 @@ def test_sign_random_and_golden(engine, oracle):
         xs.append(bytes(d[:32])); ks.append(r.to_bytes(32, "little")); ms.append(msg); sigs.append(sig)
     got = engine.schnorr_sign(np.frombuffer(b"".join(xs), dtype=np.uint8), np.frombuffer(b"".join(ks), dtype=np.uint8), ms)
     assert rows(got) == sigs
+    # the fused single-kernel signer (k_sign: both multiplications, inversions, hash in one kernel) stays selectable
+    engine.set_option("finish.batched", 0)
+    try:
+        got = engine.schnorr_sign(np.frombuffer(b"".join(xs), dtype=np.uint8), np.frombuffer(b"".join(ks), dtype=np.uint8), ms)
+        assert rows(got) == sigs
+        assert np.array_equal(engine.schnorr_sign(x[:3], k[:3], msgs[:3]), oracle.schnorr_sign_batch(x[:3], k[:3], msgs[:3]))
+    finally:
+        engine.set_option("finish.batched", 1)
+    for m in (1, 2, 31, 33):                              # tiny batches through the default pipeline (one launch for k*B and x*B)
+        assert np.array_equal(engine.schnorr_sign(x[:m], k[:m], msgs[:m]), oracle.schnorr_sign_batch(x[:m], k[:m], msgs[:m]))
 
 
 def test_full_size_properties_2_20(engine, oracle):
@@ -250,7 +261,7 @@ def test_split_finish_and_block_variants(engine, oracle, block):
         assert np.array_equal(engine.schnorr_sign(x, k, msgs), oracle.schnorr_sign_batch(x, k, msgs, nthreads=8))
     finally:
         engine.set_option("finish.batched", 1)
-        engine.set_option("finish.min_items", 64)
+        engine.set_option("finish.min_items", 1)
         engine.set_option("mul_base.block", 256)
         engine.set_option("mul_base.radix", 64)
 
@@ -272,7 +283,7 @@ def test_split_finish_isolates_degenerate_z(engine, oracle):
         b = engine.mul(s, pts_ext=pts)
     finally:
         engine.set_option("finish.batched", 1)
-        engine.set_option("finish.min_items", 64)
+        engine.set_option("finish.min_items", 1)
         engine.set_option("mul.algo", 1)
     assert np.array_equal(a, b)
     want = oracle.mul_batch(s, pts, nthreads=8)
@@ -427,7 +438,7 @@ def test_fixed_base_radix32_kernel(engine, oracle):
             assert not engine.verify(pub, msgs, engine.schnorr_sign(x, kc, msgs), 1).any()
     finally:
         engine.set_option("mul_base.radix", 64)
-        engine.set_option("finish.min_items", 64)
+        engine.set_option("finish.min_items", 1)
     # table image, radix-32 part: entry (pos, j) = (j+1) * 32^pos * B
     P = 2**255 - 19
     whole = np.frombuffer(engine.base_table().tobytes(), dtype=np.uint32)

@@ -30,8 +30,8 @@ def t(fn, reps=20):
 
 
 print("n, small_chunks, mul_base_ms, mul_ms")
-for n in (4096, 8192, 16384, 32768, 65536, 131072, 262144, 524288):
-    for sc in (0, 1, 2, 4):
+for n in (4096, 65536, 131072, 262144):
+    for sc in (0, 2):
         eng.set_option("mul_base.small_chunks", sc)
         a = t(lambda: eng.mul_base_dev(s[:n], out_enc=out[:n]))
         b = t(lambda: eng.mul_dev(s[:n], pts_ext=ext[:n], out_enc=out[:n]), 8) if sc == 0 else float("nan")
@@ -43,11 +43,11 @@ msgs = torch.zeros(4096 * 32, dtype=torch.uint8, device="cuda:0")
 off = torch.arange(0, 32 * 4097, 32, dtype=torch.int32, device="cuda:0")
 sig = torch.empty((4096, 64), dtype=torch.uint8, device="cuda:0")
 eng.set_option("mul_base.small_chunks", 2)
-for n in (64, 256, 512, 1024, 2048, 4095):
-    for fm in (4096, 1024, 256, 64):
+for n in (1, 8, 32, 64, 512, 4095):
+    for fm in (4096, 64, 8, 1):
         eng.set_option("finish.min_items", fm)
         a = t(lambda: eng.mul_base_dev(s[:n], out_enc=out[:n]))
         b = t(lambda: eng.sign_dev(s[:n], k[:n], msgs, off[: n + 1], sig[:n]))
         c = t(lambda: eng.mul_dev(s[:n], pts_ext=ext[:n], out_enc=out[:n]), 8)
         print(f"{n}, {fm}, {a:.3f}, {b:.3f}, {c:.3f}", flush=True)
-eng.set_option("finish.min_items", 64)
+eng.set_option("finish.min_items", 1)
