@@ -68,8 +68,10 @@ namespace {
 thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
-enum KernelId { KID_EDDSA_PREP = 11, KID_MUL = 0, KID_MUL_BASE = 1, KID_FINISH = 2, KID_SIGN = 3, KID_SIGN_HASH = 4, KID_VERIFY_PREP = 5, KID_VERIFY_FINAL = 6, KID_POLY_EVAL = 7, KID_MONT_PREP = 8, KID_MUL_LADDER = 9, KID_DECODE = 10, KID_PAIR_SUM = 12, KID_COUNT = 13 };
-const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval", "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum"};
+enum KernelId { KID_MUL, KID_MUL_BASE, KID_FINISH, KID_SIGN, KID_SIGN_HASH, KID_VERIFY_PREP, KID_VERIFY_FINAL, KID_POLY_EVAL, KID_MONT_PREP,
+                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_COUNT };
+const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval",
+                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   bool on = false;
@@ -117,7 +119,7 @@ struct Ctx {
   int opt_mul_algo = 1;           // 0 windowed table (ge.rs structure), 1 Montgomery ladder (table-free, 1.33x faster: profiles/r01/sweep_mul_algo.log)
   int opt_ladder_waves = 3;       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
   int opt_finish = 1;             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
-  int opt_finish_min = 1;             // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size, tools/midsize_bench.py; kept as a cross-check)
+  int opt_finish_min = 1;         // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size, tools/midsize_bench.py; kept as a cross-check)
   std::mutex mu;          // host-pointer API: staging buffer + engine stream
   std::mutex launch_mu;   // every launch_* entry: per-stream scratch bookkeeping (calls from any thread, any stream)
 };
