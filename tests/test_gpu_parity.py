@@ -765,3 +765,50 @@ def test_cfg5_whole_2_24_on_one_gpu(engine, oracle):
     assert np.array_equal(enc_fixed[idx.to(dev)].cpu().numpy(), oracle.mul_base_batch(s[idx.to(dev)].cpu().numpy(), nthreads=8))
     del bext, enc_var, enc_fixed, s
     torch.cuda.empty_cache()
+
+
+def test_structured_fuzz_against_oracle(engine, oracle):
+    """2^16 structured (scalar, point) pairs, every output compared with the oracle: scalars with long runs of equal
+    bits, single bits, digit patterns at the recoding extremes (radix 16 / 32 / 64 windows all 0x8.., 0x7.., 31, 32),
+    values around multiples of L and around 2^252..2^256; points with a torsion component, small-order points, the
+    neutral element; both multiplications and the fixed-base routine"""
+    rng = np.random.default_rng(2024)
+    L = synth.L
+    n = 1 << 16
+    ints = []
+    for i in range(256):
+        ints += [1 << i, (1 << i) - 1, (1 << 256) - (1 << i)]
+    for k in range(1, 17):
+        ints += [(k * L + d) % (1 << 256) for d in (-2, -1, 0, 1, 2)]
+    for w, vals in ((4, (7, 8, 9, 15)), (5, (15, 16, 17, 31)), (6, (31, 32, 33, 63))):
+        for v in vals:
+            ints.append(sum(v << (w * i) for i in range(256 // w + 1)) % (1 << 256))
+            ints.append(sum((v if i % 2 else 0) << (w * i) for i in range(256 // w + 1)) % (1 << 256))
+    while len(ints) < n:
+        kind = len(ints) % 4
+        if kind == 0:      # runs of ones and zeros
+            v, pos = 0, 0
+            while pos < 256:
+                run = int(rng.integers(1, 40))
+                if rng.integers(0, 2):
+                    v |= ((1 << run) - 1) << pos
+                pos += run
+            ints.append(v % (1 << 256))
+        elif kind == 1:    # sparse
+            v = 0
+            for _ in range(int(rng.integers(1, 6))):
+                v |= 1 << int(rng.integers(0, 256))
+            ints.append(v)
+        elif kind == 2:    # reduced random
+            ints.append(int.from_bytes(rng.bytes(32), "little") % L)
+        else:              # raw 256-bit
+            ints.append(int.from_bytes(rng.bytes(32), "little"))
+    ints = ints[:n]
+    s = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in ints), dtype=np.uint8).reshape(n, 32)
+    assert np.array_equal(engine.mul_base(s), oracle.mul_base_batch(s, nthreads=8))
+    weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
+    base_pts = oracle.mul_base_ext_batch(synth.scalars(64, 2024))
+    pool = [p for p in base_pts] + [oracle.add(base_pts[i], weak[2 + i % 3]) for i in range(16)] + weak + [oracle.null()]
+    pts = np.stack([pool[int(j)] for j in rng.integers(0, len(pool), n)])
+    got = engine.mul(s, pts_ext=pts)
+    assert np.array_equal(got, oracle.mul_batch(s, pts, nthreads=8))
