@@ -55,6 +55,11 @@ extern "C" {
  *                           of 1920 B with 16 entries                 entry (pos, j) = (j+1) * 64^pos * B */
 #define KYB_BASE_TABLE_BYTES 335232u
 
+/* Version of this interface: bumped on any change of an existing signature, of KYB_BASE_TABLE_BYTES or of a status /
+ * error code (a binding checks it once after loading the library).  Callable before kyb_init. */
+#define KYB_ABI_VERSION 1
+int kyb_abi_version(void);
+
 /* ---- lifecycle -------------------------------------------------------------------------------- */
 /* Bind this process to HIP device `device`, allocate the workspace, build the base-point table on
  * the GPU.  Idempotent for the same device.  (One process per GPU: see DESIGN.md §multi-GPU.) */

@@ -21,13 +21,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libkyber_ed25519_hip.so"
 LIB_PATH = os.environ.get("KYB_HIP_LIB") or os.path.join(_HERE, LIB_NAME)   # KYB_HIP_LIB: A/B builds of the same ABI
 BASE_TABLE_BYTES = 335232
+ABI_VERSION = 1
 
 KYB_OK = 0
 ERRORS = {-1: "KYB_E_NOT_INIT", -2: "KYB_E_BAD_ARG", -3: "KYB_E_NO_DEVICE", -4: "KYB_E_HIP", -5: "KYB_E_NOMEM"}
 
 # every symbol include/kyber_ed25519.h declares (tests/test_abi_symbols.py checks header <-> library)
 ABI_SYMBOLS = [
-    "kyb_init", "kyb_init_no_table", "kyb_shutdown", "kyb_last_error", "kyb_device_info", "kyb_sync",
+    "kyb_abi_version", "kyb_init", "kyb_init_no_table", "kyb_shutdown", "kyb_last_error", "kyb_device_info", "kyb_sync",
     "kyb_base_table_export_dev", "kyb_base_table_import_dev", "kyb_base_table_export",
     "kyb_mul_base_batch", "kyb_mul_base_batch_dev", "kyb_mul_batch", "kyb_mul_batch_dev",
     "kyb_add_batch", "kyb_add_batch_dev", "kyb_encode_batch", "kyb_encode_batch_dev",
@@ -114,6 +115,8 @@ def load_library() -> ctypes.CDLL:
     for name in ABI_SYMBOLS:
         if name not in ("kyb_shutdown", "kyb_last_error", "kyb_kernel_name", "kyb_host_alloc", "kyb_host_free"):
             getattr(lib, name).restype = i32
+    if lib.kyb_abi_version() != ABI_VERSION:
+        raise KyberHipError(f"{LIB_PATH} implements ABI version {lib.kyb_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 

@@ -12,6 +12,7 @@ use std::os::raw::{c_char, c_int, c_void};
 type size_t = usize;
 
 extern "C" {
+    pub fn kyb_abi_version() -> c_int; // == 1 for this file
     pub fn kyb_init(device: c_int) -> c_int;
     pub fn kyb_shutdown();
     pub fn kyb_last_error() -> *const c_char;
