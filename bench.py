@@ -241,7 +241,7 @@ def main():
         # HBM/fabric bytes per launch from the PMC passes of the same command (profiles/, FETCH_SIZE x2 + WRITE_SIZE)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01", f"{wl}_pmc_summary.json")
-        if os.path.exists(pmc) and n == (1 << 20):
+        if os.path.exists(pmc) and n == ((1 << 18) if wl == "sign" else (1 << 20)) and not args.keyed:      # the sizes the PMC passes ran at
             d_ = json.load(open(pmc))["_derived"]
             traffic = round(d_["fetch_bytes_per_dispatch_corrected_x2"] + d_["write_bytes_per_dispatch"])
         line = {
