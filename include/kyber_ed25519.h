@@ -166,6 +166,14 @@ int kyb_pubpoly_eval_batch(const int32_t* commits_ext, size_t t, const uint32_t*
 int kyb_pubpoly_eval_batch_dev(const int32_t* commits_ext, size_t t, const uint32_t* indices, size_t n, uint32_t max_index,
                                uint8_t* out_enc, int32_t* out_ext, void* stream);
 
+/* m public polynomials of the same threshold t (commits_ext = m x t x 40 int32), each evaluated at its own k
+ * indices: out[g*k + j] = polynomial g at indices[g*k + j].  k = 1 is the verifier's side of a DKG round: the deals
+ * of m dealers checked at the verifier's own index (vss/pedersen/vss.rs:904-909) in one launch. */
+int kyb_pubpoly_eval_multi_batch(const int32_t* commits_ext, size_t t, size_t m, const uint32_t* indices, size_t k,
+                                 uint8_t* out_enc, int32_t* out_ext);
+int kyb_pubpoly_eval_multi_batch_dev(const int32_t* commits_ext, size_t t, size_t m, const uint32_t* indices, size_t k, uint32_t max_index,
+                                     uint8_t* out_enc, int32_t* out_ext, void* stream);
+
 /* ---- recover_commit / recover_pub_poly / PubPoly::add, poly.rs:486-507, 566-634 -- */
 /* m linear combinations of t points each:  out[g] = sum_{j<t} scalars[g*t + j] * P(g, j).
  *   shared_points == 0:  P(g, j) = pts[g*t + j]   (m*t points)   - m independent recover_commit calls

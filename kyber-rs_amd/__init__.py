@@ -36,6 +36,7 @@ ABI_SYMBOLS = [
     "kyb_eddsa_sign_batch", "kyb_eddsa_sign_batch_dev",
     "kyb_schnorr_sign_keyed_batch", "kyb_schnorr_sign_keyed_batch_dev", "kyb_eddsa_sign_keyed_batch", "kyb_eddsa_sign_keyed_batch_dev",
     "kyb_verify_batch", "kyb_verify_batch_dev", "kyb_pubpoly_eval_batch", "kyb_pubpoly_eval_batch_dev",
+    "kyb_pubpoly_eval_multi_batch", "kyb_pubpoly_eval_multi_batch_dev",
     "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev",
     "kyb_host_alloc", "kyb_host_free",
     "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
@@ -98,6 +99,8 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_verify_batch_dev.argtypes = [vp, vp, vp, vp, sz, i32, vp, vp]
     lib.kyb_pubpoly_eval_batch.argtypes = [vp, sz, vp, sz, vp, vp]
     lib.kyb_pubpoly_eval_batch_dev.argtypes = [vp, sz, vp, sz, ctypes.c_uint32, vp, vp, vp]
+    lib.kyb_pubpoly_eval_multi_batch.argtypes = [vp, sz, sz, vp, sz, vp, vp]
+    lib.kyb_pubpoly_eval_multi_batch_dev.argtypes = [vp, sz, sz, vp, sz, ctypes.c_uint32, vp, vp, vp]
     lib.kyb_equal_batch.argtypes = [vp, vp, sz, vp]
     lib.kyb_equal_batch_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.kyb_lincomb_batch.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp]
@@ -299,6 +302,19 @@ class Engine:
         enc = np.empty((n, 32), dtype=np.uint8)
         ext = np.empty((n, 40), dtype=np.int32) if want_ext else None
         _check(self.lib.kyb_pubpoly_eval_batch(_ptr(c), c.shape[0], _ptr(idx), n, _ptr(enc), _ptr(ext)), "kyb_pubpoly_eval_batch")
+        return (enc, ext) if want_ext else enc
+
+    def pubpoly_eval_multi(self, commits_ext, indices, want_ext: bool = False):
+        """m polynomials (m x t x 40 limbs), polynomial g evaluated at indices[g, :] -> (m, k, 32) encodings"""
+        c = np.ascontiguousarray(commits_ext, dtype=np.int32)
+        if c.ndim != 3 or c.shape[2] != 40:
+            raise ValueError("commits_ext must have shape (m, t, 40)")
+        m, t = c.shape[0], c.shape[1]
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(m, -1)
+        k = idx.shape[1]
+        enc = np.empty((m, k, 32), dtype=np.uint8)
+        ext = np.empty((m, k, 40), dtype=np.int32) if want_ext else None
+        _check(self.lib.kyb_pubpoly_eval_multi_batch(_ptr(c), t, m, _ptr(idx), k, _ptr(enc), _ptr(ext)), "kyb_pubpoly_eval_multi_batch")
         return (enc, ext) if want_ext else enc
 
     def lincomb(self, scalars, pts_ext=None, pts_enc=None, want_ext: bool = False, want_ok: bool = False):

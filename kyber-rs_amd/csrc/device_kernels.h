@@ -389,17 +389,19 @@ k_verify_final(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t*
   status[i] = (st == 0 && !eq) ? (uint8_t)9 : st;
 }
 
-// PubPoly::eval for one polynomial at n share indices (poly.rs:457-469, shares :472-478)
+// PubPoly::eval (poly.rs:457-469, shares :472-478) at n share indices: of one polynomial (per_poly == 0) or of
+// polynomial i / per_poly for item i (a verifier checking the deals of many dealers at its own index)
 template <bool SPLIT>
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
-k_poly_eval(const int32_t* __restrict__ commits_ext, int t, const uint32_t* __restrict__ indices, size_t n, int nbits,
+k_poly_eval(const int32_t* __restrict__ commits_ext, int t, const uint32_t* __restrict__ indices, size_t n, int nbits, size_t per_poly,
             uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, uint4* __restrict__ proj, size_t stride) {
   const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   const bool live = i < n;
   const size_t ii = live ? i : 0;
   const uint32_t x = indices[ii] + 1u;
+  const size_t first = per_poly ? (ii / per_poly) * (size_t)t : 0;      // first commitment of this item's polynomial
   ge_p2 r;
-  ge_poly_eval(r, [&](int j, ge_p3& c) { load_ext(c, commits_ext, (size_t)j); }, t, x, nbits);
+  ge_poly_eval(r, [&](int j, ge_p3& c) { load_ext(c, commits_ext, first + (size_t)j); }, t, x, nbits);
   if (SPLIT) { if (live) store_proj(proj, stride, i, r.X, r.Y, r.Z); }
   else finish_point(r.X, r.Y, r.Z, out_enc, out_ext, ii, live);
 }

@@ -637,7 +637,8 @@ int launch_verify(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off,
   return KYB_OK;
 }
 
-int launch_poly_eval(const int32_t* commits, size_t t, const uint32_t* idx, size_t n, uint32_t max_index, uint8_t* oenc, int32_t* oext, hipStream_t st) {
+int launch_poly_eval(const int32_t* commits, size_t t, const uint32_t* idx, size_t n, uint32_t max_index, uint8_t* oenc, int32_t* oext, hipStream_t st,
+                     size_t per_poly = 0) {
   if (n == 0) return KYB_OK;
   std::lock_guard<std::mutex> launch_lock(g.launch_mu);
   Ctx::StreamRes* r = nullptr;
@@ -649,8 +650,8 @@ int launch_poly_eval(const int32_t* commits, size_t t, const uint32_t* idx, size
   if (split) { int rc = ensure_proj(r, n); if (rc) return rc; }
   {
     ProfScope ps(st, KID_POLY_EVAL);
-    if (split) hipLaunchKernelGGL((k_poly_eval<true>), dim3(blocks), dim3(KYB_BLOCK), 0, st, commits, (int)t, idx, n, nbits, oenc, oext, r->proj, r->proj_items);
-    else       hipLaunchKernelGGL((k_poly_eval<false>), dim3(blocks), dim3(KYB_BLOCK), 0, st, commits, (int)t, idx, n, nbits, oenc, oext, r->proj, r->proj_items);
+    if (split) hipLaunchKernelGGL((k_poly_eval<true>), dim3(blocks), dim3(KYB_BLOCK), 0, st, commits, (int)t, idx, n, nbits, per_poly, oenc, oext, r->proj, r->proj_items);
+    else       hipLaunchKernelGGL((k_poly_eval<false>), dim3(blocks), dim3(KYB_BLOCK), 0, st, commits, (int)t, idx, n, nbits, per_poly, oenc, oext, r->proj, r->proj_items);
   }
   HIPCK(hipGetLastError());
   if (split) return launch_finish(r, n, oenc, oext, st);

@@ -114,6 +114,24 @@ class PriPoly {
   }
 };
 
+// Verifier's side of a DKG round (vss/pedersen/vss.rs:904-909 for every dealer): polynomial g evaluated at idx[g],
+// all in one launch.  The polynomials must share one threshold.
+inline std::vector<PubShare> eval_each(const std::vector<PubPoly>& polys, const std::vector<uint32_t>& idx) {
+  const size_t m = polys.size();
+  if (idx.size() != m) throw std::invalid_argument("eval_each: one index per polynomial");
+  if (m == 0) return {};
+  const size_t t = polys[0].threshold();
+  std::vector<int32_t> c(40 * t * m), out(40 * m);
+  for (size_t g = 0; g < m; ++g) {
+    if (polys[g].threshold() != t) throw PolyError("different number of coefficients");
+    for (size_t j = 0; j < t; ++j) std::memcpy(&c[40 * (g * t + j)], polys[g].commits[j].ge, 160);
+  }
+  group::edwards25519::detail::engine_must(kyb_pubpoly_eval_multi_batch(c.data(), t, m, idx.data(), 1, nullptr, out.data()), "eval_each");
+  std::vector<PubShare> r(m);
+  for (size_t g = 0; g < m; ++g) { r[g].i = idx[g]; std::memcpy(r[g].v.ge, &out[40 * g], 160); }
+  return r;
+}
+
 // poly.rs:534-563: the first t shares by index; x_i = i + 1
 struct XYCommit { std::vector<size_t> idx; std::vector<Scalar> x; std::vector<Point> y; };
 inline XYCommit xy_commit(const std::vector<std::optional<PubShare>>& shares, size_t t, size_t /*n*/) {

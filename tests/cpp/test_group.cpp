@@ -316,6 +316,14 @@ int main() {
       std::vector<Point> got = recover_commit_batch(sets, t, n);
       for (int k = 0; k < 5; ++k) CHECK(got[k] == want[k], "recover_commit_batch");
     }
+    // one launch for a verifier's checks of several dealers at its own index
+    {
+      std::vector<PubPoly> polys; std::vector<PriPoly> pris; std::vector<uint32_t> at;
+      for (int k = 0; k < 6; ++k) { pris.push_back(new_pri_poly(t)); polys.push_back(pris.back().commit(nullptr)); at.push_back(3); }
+      at[4] = 9;
+      std::vector<PubShare> got = eval_each(polys, at);
+      for (int k = 0; k < 6; ++k) CHECK(got[k].v == Point().mul(pris[k].eval(at[k]).v, nullptr), "eval_each == commit of the private share");
+    }
     // test_public_add
     Point gp = points[5], h = points[6];
     PriPoly p = new_pri_poly(t), q = new_pri_poly(t);

@@ -36,6 +36,13 @@ def test_pedersen_round_shape(engine, oracle):
         if d % 8 == 0:
             for i in (0, n - 1):
                 assert bytes(ev[i]) == oracle.pubpoly_eval(commits[d], i)       # the reference's own eval
+    # the verifier's side in one launch: the deals of all n dealers checked at verifier v's own index (vss.rs:904-909),
+    # and the whole n x n matrix of checks as n polynomials x n indices
+    for v in (0, 7, n - 1):
+        col = engine.pubpoly_eval_multi(commits, np.full((n, 1), v, dtype=np.uint32))
+        assert np.array_equal(col[:, 0], fig[:, v])
+    allchk = engine.pubpoly_eval_multi(commits, np.tile(idx, (n, 1)))
+    assert np.array_equal(allchk, fig)
     # a corrupted share is caught by exactly its check
     bad = shares[3, 5].copy(); bad[0] ^= 1
     assert bytes(engine.mul_base(bad)[0]) != bytes(engine.pubpoly_eval(commits[3], idx[5:6])[0])
