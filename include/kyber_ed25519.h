@@ -190,6 +190,13 @@ int kyb_lincomb_batch(const uint8_t* scalars, const uint8_t* pts_enc, const int3
 int kyb_lincomb_batch_dev(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, int shared_points,
                           size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok, void* stream);
 
+/* Sums of points without scalars: out[g] = sum_{j<t} pts[g*t + j] (m groups of t points, extended limbs).  The
+ * distributed public polynomial of a DKG round is the coefficient-wise sum of the dealers' commitment polynomials
+ * (dkg.rs:905-953 applies PubPoly::add, poly.rs:486-507, dealer after dealer): m = threshold, t = number of dealers,
+ * with the commitments laid out coefficient-major. */
+int kyb_sum_batch(const int32_t* pts_ext, size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext);
+int kyb_sum_batch_dev(const int32_t* pts_ext, size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext, void* stream);
+
 /* ---- Point::eq, point.rs:227-241 -------------------------------------------- */
 /* eq[i] = 1 iff a[i] and b[i] are the same point (the reference compares the two encodings = two
  * inversions; here a projective cross-multiplication).  Inputs must be curve points (Z != 0). */

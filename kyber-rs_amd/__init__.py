@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "kyb_verify_batch", "kyb_verify_batch_dev", "kyb_pubpoly_eval_batch", "kyb_pubpoly_eval_batch_dev",
     "kyb_pubpoly_eval_multi_batch", "kyb_pubpoly_eval_multi_batch_dev",
     "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev",
+    "kyb_sum_batch", "kyb_sum_batch_dev",
     "kyb_host_alloc", "kyb_host_free",
     "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
 ]
@@ -101,6 +102,8 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_pubpoly_eval_batch_dev.argtypes = [vp, sz, vp, sz, ctypes.c_uint32, vp, vp, vp]
     lib.kyb_pubpoly_eval_multi_batch.argtypes = [vp, sz, sz, vp, sz, vp, vp]
     lib.kyb_pubpoly_eval_multi_batch_dev.argtypes = [vp, sz, sz, vp, sz, ctypes.c_uint32, vp, vp, vp]
+    lib.kyb_sum_batch.argtypes = [vp, sz, sz, vp, vp]
+    lib.kyb_sum_batch_dev.argtypes = [vp, sz, sz, vp, vp, vp]
     lib.kyb_equal_batch.argtypes = [vp, vp, sz, vp]
     lib.kyb_equal_batch_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.kyb_lincomb_batch.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp]
@@ -315,6 +318,17 @@ class Engine:
         enc = np.empty((m, k, 32), dtype=np.uint8)
         ext = np.empty((m, k, 40), dtype=np.int32) if want_ext else None
         _check(self.lib.kyb_pubpoly_eval_multi_batch(_ptr(c), t, m, _ptr(idx), k, _ptr(enc), _ptr(ext)), "kyb_pubpoly_eval_multi_batch")
+        return (enc, ext) if want_ext else enc
+
+    def sum_points(self, pts_ext, want_ext: bool = False):
+        """out[g] = sum_j pts[g, j] for points of shape (m, t, 40)"""
+        p = np.ascontiguousarray(pts_ext, dtype=np.int32)
+        if p.ndim != 3 or p.shape[2] != 40:
+            raise ValueError("pts_ext must have shape (m, t, 40)")
+        m, t = p.shape[0], p.shape[1]
+        enc = np.empty((m, 32), dtype=np.uint8)
+        ext = np.empty((m, 40), dtype=np.int32) if want_ext else None
+        _check(self.lib.kyb_sum_batch(_ptr(p), m, t, _ptr(enc), _ptr(ext)), "kyb_sum_batch")
         return (enc, ext) if want_ext else enc
 
     def lincomb(self, scalars, pts_ext=None, pts_enc=None, want_ext: bool = False, want_ok: bool = False):

@@ -351,6 +351,16 @@ k_pair_sum(uint4* __restrict__ proj, size_t stride, size_t m, size_t gstride, si
   store_proj(proj, stride, ia, r.X, r.Y, r.Z);
 }
 
+// extended limbs -> projective staging records (input of the k_pair_sum passes of kyb_sum_batch)
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_ext_to_proj(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ proj, size_t stride) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  ge_p3 P;
+  load_ext(P, pts_ext, i);
+  store_proj(proj, stride, i, P.X, P.Y, P.Z);
+}
+
 // verification stage 1: checks, decode R and A, h = SHA-512(R || A || msg) mod L.
 // Writes h and s as contiguous 32-byte records, A in reference limbs (input of k_mul), R into the
 // projective staging buffer at [proj_offset, proj_offset + n).

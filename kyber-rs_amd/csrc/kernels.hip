@@ -440,6 +440,26 @@ int launch_lincomb(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, 
   return launch_finish(r, m, oenc, oext, st, t);
 }
 
+// out[g] = sum_j P[g*t + j]: the halving passes of launch_lincomb on the points themselves
+int launch_sum(const int32_t* pext, size_t m, size_t t, uint8_t* oenc, int32_t* oext, hipStream_t st) {
+  if (m == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  Ctx::StreamRes* r = nullptr;
+  { int rc = res_for(st, &r); if (rc) return rc; }
+  const size_t n = m * t;
+  { int rc = ensure_proj(r, n); if (rc) return rc; }
+  hipLaunchKernelGGL(k_ext_to_proj, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, pext, n, r->proj, r->proj_items);
+  HIPCK(hipGetLastError());
+  for (size_t len = t; len > 1;) {
+    const size_t half = (len + 1) / 2, lanes = m * (len - half);
+    ProfScope ps(st, KID_PAIR_SUM);
+    hipLaunchKernelGGL(k_pair_sum, dim3((unsigned)((lanes + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, r->proj, r->proj_items, m, t, len, half);
+    HIPCK(hipGetLastError());
+    len = half;
+  }
+  return launch_finish(r, m, oenc, oext, st, t);
+}
+
 int launch_mul(const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, hipStream_t st) {
   if (n == 0) return KYB_OK;
   std::lock_guard<std::mutex> launch_lock(g.launch_mu);

@@ -132,6 +132,24 @@ inline std::vector<PubShare> eval_each(const std::vector<PubPoly>& polys, const 
   return r;
 }
 
+// The distributed public polynomial of a DKG round (dkg.rs:905-953 folds PubPoly::add over the dealers): the
+// coefficient-wise sum of all polynomials in one launch.
+inline PubPoly sum_polys(const std::vector<PubPoly>& polys) {
+  if (polys.empty()) throw std::invalid_argument("sum_polys: no polynomial");
+  const size_t n = polys.size(), t = polys[0].threshold();
+  std::vector<int32_t> c(40 * t * n), out(40 * t);
+  for (size_t d = 0; d < n; ++d) {
+    if (polys[d].threshold() != t) throw PolyError("different number of coefficients");
+    for (size_t j = 0; j < t; ++j) std::memcpy(&c[40 * (j * n + d)], polys[d].commits[j].ge, 160);     // coefficient-major
+  }
+  group::edwards25519::detail::engine_must(kyb_sum_batch(c.data(), t, n, nullptr, out.data()), "sum_polys");
+  PubPoly r;
+  r.b = polys[0].b;
+  r.commits.resize(t);
+  for (size_t j = 0; j < t; ++j) std::memcpy(r.commits[j].ge, &out[40 * j], 160);
+  return r;
+}
+
 // poly.rs:534-563: the first t shares by index; x_i = i + 1
 struct XYCommit { std::vector<size_t> idx; std::vector<Scalar> x; std::vector<Point> y; };
 inline XYCommit xy_commit(const std::vector<std::optional<PubShare>>& shares, size_t t, size_t /*n*/) {

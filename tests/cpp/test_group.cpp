@@ -336,6 +336,7 @@ int main() {
     // test_public_poly_equal
     PubPoly p1 = new_pri_poly(t).commit(&gp), p2 = new_pri_poly(t).commit(&gp), p3 = new_pri_poly(t).commit(&gp);
     CHECK(p1.add(p2).add(p3).equal(p1.add(p3).add(p2)), "test_public_poly_equal");
+    CHECK(sum_polys({p1, p2, p3}).equal(p1.add(p2).add(p3)), "sum_polys == PubPoly::add folded over the dealers");
     CHECK(!p1.equal(p2), "different polynomials are not equal");
   }
 

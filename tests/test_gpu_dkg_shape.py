@@ -53,6 +53,17 @@ def test_pedersen_round_shape(engine, oracle):
     secret = sum(ci[d][0] for d in range(n)) % L
     assert bytes(engine.encode(acc[None, :])[0]) == oracle.mul_base(secret.to_bytes(32, "little"))
     assert engine.equal(acc[None, :], oracle.mul_base_ext(secret.to_bytes(32, "little"))[None, :])[0] == 1
+    # the whole distributed public polynomial: coefficient-wise sum over the dealers in one launch (t groups of n points)
+    dist_poly, dist_ext = engine.sum_points(np.ascontiguousarray(commits.transpose(1, 0, 2)), want_ext=True)
+    for j in (0, 1, t - 1):
+        sj = sum(ci[d][j] for d in range(n)) % L
+        assert bytes(dist_poly[j]) == oracle.mul_base(sj.to_bytes(32, "little"))
+    assert engine.equal(dist_ext[0][None, :], acc[None, :])[0] == 1
+    # sums with awkward operands: P + P, P + (-P), neutral elements, a single-element group
+    odd = np.stack([commits[0, 0], commits[0, 0], oracle.neg(commits[0, 1]), commits[0, 1], oracle.null(), commits[0, 2], oracle.null()])[None, :, :]
+    want = oracle.add(oracle.add(commits[0, 0], commits[0, 0]), commits[0, 2])
+    assert bytes(engine.sum_points(odd)[0]) == oracle.encode(want)
+    assert bytes(engine.sum_points(commits[3, 4][None, None, :])[0]) == bytes(enc.reshape(n, t, 32)[3, 4])
     # Diffie-Hellman of every dealer with every verifier (vss.rs:371-375, dh_impl.rs:74-80): n*n variable-base
     # mults straight from the wire encodings; both directions agree and match the reference's mul
     longterm = synth.scalars(n, 91)
