@@ -1,0 +1,81 @@
+"""One node's curve work in a Pedersen DKG round, through the host-pointer C ABI, against the
+single-thread CPU port: what a kyber-rs node would gain by routing its loops to the batch entry points.
+
+Per node with n participants and threshold t (call sites: dkg.rs / vss/pedersen/vss.rs / poly.rs):
+  dealer    commit                 t  x mul(coeff, Some(B))                     vss.rs:303
+            deals                  n  x (schnorr::sign + dh_exchange)           vss.rs:361-386
+  verifier  process n deals        n  x (schnorr::verify + dh_exchange)         vss.rs:640-660
+            verify_deal            n  x (mul(f_i, None) + PubPoly::eval(i))     vss.rs:904-909
+  finish    distributed public polynomial: sum of n commitment polynomials      dkg.rs:905-953
+Outputs are spot-checked against the oracle."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import kyber_rs_amd
+import oracle_lib
+import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, nargs="+", default=[16, 64, 256, 1024])
+args = ap.parse_args()
+eng = kyber_rs_amd.Engine(0)
+orc = oracle_lib.Oracle()
+L = synth.L
+
+
+def timed(fn):
+    fn()
+    t0 = time.perf_counter(); out = fn(); return out, (time.perf_counter() - t0) * 1e3
+
+
+# single-thread CPU port: per-operation times on this host
+s256 = synth.scalars(256, 1); p256 = orc.mul_base_ext_batch(s256); m256 = synth.messages(256, 1)
+sig256 = orc.schnorr_sign_batch(s256, synth.scalars(256, 2), m256)
+pub256 = np.stack([np.frombuffer(orc.encode(p), dtype=np.uint8) for p in p256])
+cpu = {}
+for name, fn in (("mul", lambda: orc.mul_batch(s256, p256)), ("mul_base", lambda: orc.mul_base_batch(s256)),
+                 ("sign", lambda: orc.schnorr_sign_batch(s256, s256, m256)), ("verify", lambda: orc.verify_batch(1, pub256, m256, sig256))):
+    t0 = time.perf_counter(); fn(); cpu[name] = (time.perf_counter() - t0) / 256 * 1e3
+t0 = time.perf_counter()
+for i in range(8):
+    orc.pubpoly_eval(p256[:32], i)
+cpu["eval_per_coeff"] = (time.perf_counter() - t0) / 8 / 32 * 1e3
+print("CPU port, 1 thread, ms per op:", {k: round(v, 4) for k, v in cpu.items()})
+print("n, t, gpu_ms_total, cpu_ms_estimate, speedup, breakdown_ms")
+for n in args.n:
+    t = n * 2 // 3 + 1
+    coeffs = synth.scalars(t, 100 + n)
+    longterm = synth.scalars(n, 200 + n)
+    pubs = eng.mul_base(longterm)                                            # everybody's long-term public keys (given)
+    base = np.tile(orc.base(), (t, 1))
+    br = {}
+    (commit_enc, commit_ext), br["commit"] = timed(lambda: eng.mul(coeffs, pts_ext=base, want_ext=True))
+    ci = [int.from_bytes(bytes(c), "little") for c in coeffs]
+    shares = np.frombuffer(b"".join((sum(c * pow(i + 1, j, L) for j, c in enumerate(ci)) % L).to_bytes(32, "little") for i in range(n)), dtype=np.uint8).reshape(n, 32)
+    msgs = synth.messages(n, n)
+    nonces = synth.scalars(n, 300 + n)
+    me = np.tile(longterm[0], (n, 1))
+    mypub = np.tile(pubs[0], (n, 1))
+    sigs, br["sign_deals"] = timed(lambda: eng.schnorr_sign(me, nonces, msgs, pubs=mypub))
+    dh, br["dh_out"] = timed(lambda: eng.mul(me, pts_enc=pubs))
+    # verifier side: n incoming deals (here: the same dealer n times, which costs the same as n dealers)
+    st, br["verify_deals"] = timed(lambda: eng.verify(mypub, msgs, sigs, 1))
+    assert not st.any()
+    dh2, br["dh_in"] = timed(lambda: eng.mul(me, pts_enc=pubs))
+    polys = np.tile(commit_ext[None, :, :], (n, 1, 1))
+    idx = np.zeros((n, 1), dtype=np.uint32)
+    fig, br["fig"] = timed(lambda: eng.mul_base(np.tile(shares[0], (n, 1))))
+    ev, br["eval"] = timed(lambda: eng.pubpoly_eval_multi(polys, idx))
+    assert np.array_equal(ev[:, 0], fig)
+    dist, br["dist_poly"] = timed(lambda: eng.sum_points(np.ascontiguousarray(polys.transpose(1, 0, 2))))
+    assert bytes(commit_enc[1]) == orc.mul(bytes(coeffs[1]), orc.base()) and bytes(dh[3]) == orc.mul(bytes(longterm[0]), orc.decode(bytes(pubs[3]))[0])
+    gpu_ms = sum(br.values())
+    cpu_ms = t * cpu["mul"] + n * (cpu["sign"] + cpu["mul"]) + n * (cpu["verify"] + cpu["mul"]) + n * (cpu["mul_base"] + t * cpu["eval_per_coeff"]) + n * t * 0.0005
+    print(f"{n}, {t}, {gpu_ms:.2f}, {cpu_ms:.0f}, {cpu_ms / gpu_ms:.0f}x, " + " ".join(f"{k}={v:.2f}" for k, v in br.items()), flush=True)
