@@ -101,10 +101,18 @@ class PriPoly {
     return r;
   }
   // poly.rs:195-206
+  // Every in-tree caller passes Some(base) (vss.rs:303: the suite's generator), which sends the reference down the
+  // variable-base routine with P = B.  When the limbs handed in are the generator's own (as Point::base() returns
+  // them) the fixed-base kernel gives the same points (same affine normal form) at a quarter of the call time.
   PubPoly commit(const Point* base) const {
     PubPoly p;
     if (base) {
       p.b = *base;
+      static const Point generator = Point().base();
+      if (std::memcmp(base->ge, generator.ge, sizeof(generator.ge)) == 0) {
+        p.commits = Point::mul_batch(coeffs, nullptr);
+        return p;
+      }
       std::vector<Point> bs(coeffs.size(), *base);
       p.commits = Point::mul_batch(coeffs, &bs);
     } else {

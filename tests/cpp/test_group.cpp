@@ -282,6 +282,11 @@ int main() {
     }
     PriShare badshare = pp.eval(3); badshare.v = badshare.v + Scalar().one();
     CHECK(!pub.check(badshare), "PubPoly::check rejects a bad share");
+    Point genb = Point().base();
+    PubPoly pubg = pp.commit(&genb);                     // Some(generator): fixed-base shortcut, same points as None
+    CHECK(pubg.equal(pub) && pubg.b.has_value(), "commit(Some(B)) == commit(None)");
+    Point gen2 = Point().add(Point().mul(Scalar().set_int64(3), nullptr), Point().neg(Point().mul(Scalar().set_int64(2), nullptr)));   // B with other limbs
+    CHECK(pp.commit(&gen2).equal(pub), "commit(Some(B in another representation)) == commit(None)");
     Point h = points[5];
     PubPoly pubh = pp.commit(&h);
     CHECK(pubh.eval(2).v == Point().mul(pp.eval(2).v, &h), "commit with an explicit base");
