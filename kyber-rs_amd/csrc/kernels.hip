@@ -99,7 +99,9 @@ struct Ctx {
   //   ws    variable-base table workspace (fixed size)
   //   proj  projective staging of the split finish (grows with the largest batch seen)
   //   enc   encodings of R and A between the stages of the split signing path
-  struct StreamRes { hipStream_t stream; uint4* ws; uint4* proj; size_t proj_items; uint8_t* enc; size_t enc_bytes; };
+  //   aux   internal side stream (+ fork/join events) on which a small verification batch runs s*B next to the ladder
+  struct StreamRes { hipStream_t stream; uint4* ws; uint4* proj; size_t proj_items; uint8_t* enc; size_t enc_bytes;
+                     hipStream_t aux; hipEvent_t ev_fork, ev_join; };
   StreamRes res[8] = {};
   int res_count = 0;
   size_t ws_bytes = 0;
@@ -116,6 +118,7 @@ struct Ctx {
   int opt_base_block = 256;       // 256 (2 waves/SIMD) or 512 (4 waves/SIMD, 128 VGPRs)   [radix-16 kernel]
   int opt_base_radix = 64;        // 64 / 32: 43- / 52-window kernel for batches >= finish.min_items; 16: always the 64-window kernel
   int opt_base_small_chunks = 2;  // radix-64 kernel: 256-thread workgroups up to this many chunks per CU, 1024-thread beyond
+  int opt_verify_overlap = 1;     // small verification batches: s*B on a side stream next to the ladder
   int opt_mul_algo = 1;           // 0 windowed table (ge.rs structure), 1 Montgomery ladder (table-free, 1.33x faster: profiles/r01/sweep_mul_algo.log)
   int opt_ladder_waves = 3;       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
   int opt_finish = 1;             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
@@ -366,6 +369,13 @@ int ensure_enc(Ctx::StreamRes* r, size_t bytes) {
   hipError_t e = hipMalloc(&r->enc, want);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "encoding staging allocation", e);
   r->enc_bytes = want;
+  return KYB_OK;
+}
+int ensure_aux(Ctx::StreamRes* r) {
+  if (r->aux) return KYB_OK;
+  HIPCK(hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking));
+  HIPCK(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
+  HIPCK(hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming));
   return KYB_OK;
 }
 inline bool use_split(size_t n) { return g.opt_finish == 1 && n >= (size_t)g.opt_finish_min; }
@@ -638,6 +648,15 @@ int launch_verify(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off,
     hipLaunchKernelGGL(k_verify_prep, dim3(blocks), dim3(KYB_BLOCK), 0, st, pubs, sigs, msgs, off, n, flavor, status, hbuf, sbuf, a_ext, r->proj, r->proj_items, 2 * n);
   }
   HIPCK(hipGetLastError());
+  // s*B is independent of h*A: while the batch leaves most of the chip idle it runs on the side stream, next to the ladder
+  const bool fork = g.opt_verify_overlap && n <= (size_t)64 * (size_t)g.cus;
+  if (fork) {
+    rc = ensure_aux(r); if (rc) return rc;
+    HIPCK(hipEventRecord(r->ev_fork, st));
+    HIPCK(hipStreamWaitEvent(r->aux, r->ev_fork, 0));
+    rc = launch_base_t<true>(sbuf, n, nullptr, nullptr, r, n, r->aux); if (rc) return rc;
+    HIPCK(hipEventRecord(r->ev_join, r->aux));
+  }
   if (g.opt_mul_algo == 1) {
     rc = launch_ladder_core(hbuf, nullptr, a_ext, n, nullptr, r, st, 0, 3); if (rc) return rc;      // h < L < 2^253
   } else {
@@ -648,7 +667,8 @@ int launch_verify(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off,
     launch_mul_t<true>(g.opt_mul_select, false, grid, st, hbuf, nullptr, a_ext, n, nullptr, nullptr, nullptr, r);
     HIPCK(hipGetLastError());
   }
-  rc = launch_base_t<true>(sbuf, n, nullptr, nullptr, r, n, st); if (rc) return rc;
+  if (fork) HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
+  else { rc = launch_base_t<true>(sbuf, n, nullptr, nullptr, r, n, st); if (rc) return rc; }
   {
     ProfScope ps(st, KID_VERIFY_FINAL);
     hipLaunchKernelGGL(k_verify_final, dim3(blocks), dim3(KYB_BLOCK), 0, st, r->proj, r->proj_items, n, status);

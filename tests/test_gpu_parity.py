@@ -303,10 +303,15 @@ def test_verify_matches_oracle(engine, oracle):
     sigs = np.frombuffer(b"".join(c[2] for c in cases), dtype=np.uint8)
     msgs = [c[1] for c in cases]
     for flavor in (0, 1):
-        got = engine.verify(pubs, msgs, sigs, flavor)
         want = np.array([oracle.verify(flavor, *c) for c in cases], dtype=np.uint8)
-        assert np.array_equal(got, want)
         assert set(want.tolist()) >= {0, 2, 3, 4, 5, 6, 7, 8, 9}      # every reject reason is exercised
+        for overlap in (1, 0):                                         # s*B on the side stream / in line
+            engine.set_option("verify.overlap", overlap)
+            try:
+                for _ in range(3):                                     # back-to-back calls reuse the scratch of the one before
+                    assert np.array_equal(engine.verify(pubs, msgs, sigs, flavor), want)
+            finally:
+                engine.set_option("verify.overlap", 1)
     # all 1024 golden signatures verify; their messages are 0..1023 bytes long
     ps, ms, ss = [], [], []
     for ln in gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n"):
