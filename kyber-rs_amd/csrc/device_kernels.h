@@ -361,14 +361,12 @@ k_ext_to_proj(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__
   store_proj(proj, stride, i, P.X, P.Y, P.Z);
 }
 
-// verification stage 1: checks, decode R and A, h = SHA-512(R || A || msg) mod L.
-// Writes h and s as contiguous 32-byte records, A in reference limbs (input of k_mul), R into the
-// projective staging buffer at [proj_offset, proj_offset + n).
+// verification, A half: s < L, checks and decode of the public key, h = SHA-512(R || A || msg) mod L.
+// Writes h and s as contiguous 32-byte records and A in reference limbs (inputs of the two multiplications).
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
 k_verify_prep(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ msgs,
-              const uint32_t* __restrict__ msg_off, size_t n, int flavor, uint8_t* __restrict__ status,
-              uint8_t* __restrict__ hbuf, uint8_t* __restrict__ sbuf, int32_t* __restrict__ a_ext,
-              uint4* __restrict__ proj, size_t stride, size_t proj_offset) {
+              const uint32_t* __restrict__ msg_off, size_t n, uint8_t* __restrict__ flags_a,
+              uint8_t* __restrict__ hbuf, uint8_t* __restrict__ sbuf, int32_t* __restrict__ a_ext) {
   const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t pub[8], sig[16], h[8];
@@ -376,17 +374,28 @@ k_verify_prep(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs
   load_words8(sig, sigs, 2 * i);
   load_words8(sig + 8, sigs, 2 * i + 1);
   const uint32_t off = msg_off[i], len = msg_off[i + 1] - off;
-  ge_p3 R, A;
-  const uint32_t st = verify_prep(h, R, A, pub, sig, msgs + off, len, flavor);
-  status[i] = (uint8_t)st;
+  ge_p3 A;
+  flags_a[i] = (uint8_t)verify_prep_a(h, A, pub, sig, msgs + off, len);
   store_words8(hbuf, i, h);
   store_words8(sbuf, i, sig + 8);
   store_ext(a_ext, i, A.X, A.Y, A.Z, A.T);
+}
+// verification, R half: checks and decode of R into the projective staging buffer at [proj_offset, proj_offset + n)
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_verify_prep_r(const uint8_t* __restrict__ sigs, size_t n, uint8_t* __restrict__ flags_r, uint4* __restrict__ proj, size_t stride, size_t proj_offset) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t sig[16];
+  load_words8(sig, sigs, 2 * i);
+  load_words8(sig + 8, sigs, 2 * i + 1);
+  ge_p3 R;
+  flags_r[i] = (uint8_t)verify_prep_r(R, sig);
   store_proj(proj, stride, proj_offset + i, R.X, R.Y, R.Z);
 }
-// verification stage 4: hA at proj[i], sB at proj[n + i], R at proj[2n + i]
+// verification, last stage: hA at proj[i], sB at proj[n + i], R at proj[2n + i]; status = first failing check, else the equation
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
-k_verify_final(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __restrict__ status) {
+k_verify_final(const uint4* __restrict__ proj, size_t stride, size_t n, const uint8_t* __restrict__ flags_a, const uint8_t* __restrict__ flags_r,
+               int flavor, uint8_t* __restrict__ status) {
   const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (i >= n) return;
   ge_p2 hA, sB;
@@ -395,8 +404,8 @@ k_verify_final(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t*
   load_proj_xy(sB.X, sB.Y, proj, stride, n + i);       load_proj_z(sB.Z, proj, stride, n + i);
   load_proj_xy(RX, RY, proj, stride, 2 * n + i);
   const uint32_t eq = verify_final(RX, RY, hA, sB);
-  const uint8_t st = status[i];
-  status[i] = (st == 0 && !eq) ? (uint8_t)9 : st;
+  const uint32_t st = verify_status(flags_a[i], flags_r[i], flavor);
+  status[i] = (st == 0 && !eq) ? (uint8_t)9 : (uint8_t)st;
 }
 
 // PubPoly::eval (poly.rs:457-469, shares :472-478) at n share indices: of one polynomial (per_poly == 0) or of

@@ -69,9 +69,9 @@ thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
 enum KernelId { KID_MUL, KID_MUL_BASE, KID_FINISH, KID_SIGN, KID_SIGN_HASH, KID_VERIFY_PREP, KID_VERIFY_FINAL, KID_POLY_EVAL, KID_MONT_PREP,
-                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_COUNT };
+                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_COUNT };
 const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval",
-                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum"};
+                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   bool on = false;
@@ -639,23 +639,36 @@ int launch_verify(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off,
   Ctx::StreamRes* r = nullptr;
   { int rc = res_for(st, &r); if (rc) return rc; }
   int rc = ensure_proj(r, 3 * n); if (rc) return rc;
-  const size_t o_h = 0, o_s = up256(32 * n), o_a = o_s + up256(32 * n);
-  rc = ensure_enc(r, o_a + 160 * n); if (rc) return rc;
+  const size_t o_h = 0, o_s = up256(32 * n), o_a = o_s + up256(32 * n), o_fa = o_a + up256(160 * n), o_fr = o_fa + up256(n);
+  rc = ensure_enc(r, o_fr + up256(n)); if (rc) return rc;
   uint8_t* hbuf = r->enc + o_h; uint8_t* sbuf = r->enc + o_s; int32_t* a_ext = reinterpret_cast<int32_t*>(r->enc + o_a);
+  uint8_t* flags_a = r->enc + o_fa; uint8_t* flags_r = r->enc + o_fr;
   const unsigned blocks = (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK);
-  {
-    ProfScope ps(st, KID_VERIFY_PREP);
-    hipLaunchKernelGGL(k_verify_prep, dim3(blocks), dim3(KYB_BLOCK), 0, st, pubs, sigs, msgs, off, n, flavor, status, hbuf, sbuf, a_ext, r->proj, r->proj_items, 2 * n);
-  }
-  HIPCK(hipGetLastError());
-  // s*B is independent of h*A: while the batch leaves most of the chip idle it runs on the side stream, next to the ladder
+  // the R half (decode of R, s*B) is independent of the A half (decode of A, hash, h*A): while the batch leaves most of
+  // the chip idle it runs on the side stream
   const bool fork = g.opt_verify_overlap && n <= (size_t)64 * (size_t)g.cus;
+  hipStream_t side = st;
   if (fork) {
     rc = ensure_aux(r); if (rc) return rc;
-    HIPCK(hipEventRecord(r->ev_fork, st));
-    HIPCK(hipStreamWaitEvent(r->aux, r->ev_fork, 0));
-    rc = launch_base_t<true>(sbuf, n, nullptr, nullptr, r, n, r->aux); if (rc) return rc;
-    HIPCK(hipEventRecord(r->ev_join, r->aux));
+    side = r->aux;
+    HIPCK(hipEventRecord(r->ev_fork, st));                 // behind whatever the caller queued before this call
+    HIPCK(hipStreamWaitEvent(side, r->ev_fork, 0));
+  }
+  {
+    ProfScope ps(side, KID_VERIFY_PREP_R);
+    hipLaunchKernelGGL(k_verify_prep_r, dim3(blocks), dim3(KYB_BLOCK), 0, side, sigs, n, flags_r, r->proj, r->proj_items, 2 * n);
+  }
+  HIPCK(hipGetLastError());
+  {
+    ProfScope ps(st, KID_VERIFY_PREP);
+    hipLaunchKernelGGL(k_verify_prep, dim3(blocks), dim3(KYB_BLOCK), 0, st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext);
+  }
+  HIPCK(hipGetLastError());
+  if (fork) {
+    HIPCK(hipEventRecord(r->ev_fork, st));                 // s*B reads sbuf, which the A-half kernel has just been asked to write
+    HIPCK(hipStreamWaitEvent(side, r->ev_fork, 0));
+    rc = launch_base_t<true>(sbuf, n, nullptr, nullptr, r, n, side); if (rc) return rc;
+    HIPCK(hipEventRecord(r->ev_join, side));
   }
   if (g.opt_mul_algo == 1) {
     rc = launch_ladder_core(hbuf, nullptr, a_ext, n, nullptr, r, st, 0, 3); if (rc) return rc;      // h < L < 2^253
@@ -671,7 +684,7 @@ int launch_verify(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off,
   else { rc = launch_base_t<true>(sbuf, n, nullptr, nullptr, r, n, st); if (rc) return rc; }
   {
     ProfScope ps(st, KID_VERIFY_FINAL);
-    hipLaunchKernelGGL(k_verify_final, dim3(blocks), dim3(KYB_BLOCK), 0, st, r->proj, r->proj_items, n, status);
+    hipLaunchKernelGGL(k_verify_final, dim3(blocks), dim3(KYB_BLOCK), 0, st, r->proj, r->proj_items, n, flags_a, flags_r, flavor, status);
   }
   HIPCK(hipGetLastError());
   return KYB_OK;

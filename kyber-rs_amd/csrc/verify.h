@@ -8,16 +8,16 @@
 //   1 InvalidSignatureLength   2 SignatureNotCanonical   3 RNotCanonical   4 R does not decode
 //   5 RSmallOrder   6 PublicKeyNotCanonical   7 public key does not decode   8 PublicKeySmallOrder
 //   9 InvalidSignature (equation fails)
-// The batch is cut into four device stages (kernels.hip): prep (checks, two decodes, hash) ->
-// variable-base h*A -> fixed-base s*B -> final (one addition and a projective comparison: no field
-// inversion anywhere, where the reference's `eq` pays two, point.rs:227-241).
+// The batch is cut into device stages (kernels.hip): A half (checks, decode, hash) -> variable-base h*A;
+// R half (checks, decode) and fixed-base s*B, independent of the former; final (status of the checks, one
+// addition and a projective comparison: no field inversion anywhere, where the reference's `eq` pays two,
+// point.rs:227-241).
 #pragma once
 #include "ge_scalarmult.h"
 #include "sc25519.h"
 #include "sha512.h"
 
-// kernels.hip routes the two point decodes of verify_prep through ONE out-of-line copy of ge_decode
-// (two inlined copies made k_verify_prep 118 KB of code with 3.2 KB of scratch per lane)
+// kernels.hip may route the point decodes through an out-of-line copy of ge_decode
 #ifndef KYB_GE_DECODE
 #define KYB_GE_DECODE ge_decode
 #endif
@@ -53,29 +53,20 @@ KYB_HD uint32_t pt_has_small_order(const fe& Y) {
   return (d0 == 0) | (d1 == 0) | (dm == 0) | (da == 0) | (db == 0);
 }
 
-// Stage 1.  sig = R (8 words) || s (8 words).  Outputs: status of the pre-equation checks, h, the
-// decoded points.  On a failed decode the point is replaced by the neutral element so that the later
-// stages stay well defined.
-KYB_HD uint32_t verify_prep(uint32_t h[8], ge_p3& R, ge_p3& A, const uint32_t pub[8], const uint32_t sig[16],
-                            const uint8_t* msg, uint32_t msg_len, int flavor) {
+// Stage 1 is cut in two independent halves (the kernels run them on different streams when the batch is small):
+//   A half  s < L, checks and decode of the public key, the challenge h          -> flags_a, h, A
+//   R half  checks and decode of R                                               -> flags_r, R
+// A failed decode is replaced by the neutral element so that the later stages stay well defined.
+//   flags_a: bit 0 s canonical, 1 A canonical, 2 A decodes, 3 A has small order
+//   flags_r: bit 0 R canonical, 1 R decodes, 2 R has small order
+KYB_HD uint32_t verify_prep_a(uint32_t h[8], ge_p3& A, const uint32_t pub[8], const uint32_t sig[16], const uint8_t* msg, uint32_t msg_len) {
   const uint32_t s_ok = sc_is_canonical_w(sig + 8);
-  const uint32_t r_can = pt_is_canonical_w(sig), a_can = pt_is_canonical_w(pub);
-  const uint32_t r_dec = KYB_GE_DECODE(R, sig);
+  const uint32_t a_can = pt_is_canonical_w(pub);
   const uint32_t a_dec = KYB_GE_DECODE(A, pub);
-  const uint32_t r_small = pt_has_small_order(R.Y), a_small = pt_has_small_order(A.Y);
+  const uint32_t a_small = pt_has_small_order(A.Y);
   ge_p3 id;
   ge_p3_0(id);
-  fe_cmov(R.X, id.X, 1u - r_dec); fe_cmov(R.Y, id.Y, 1u - r_dec); fe_cmov(R.Z, id.Z, 1u - r_dec); fe_cmov(R.T, id.T, 1u - r_dec);
   fe_cmov(A.X, id.X, 1u - a_dec); fe_cmov(A.Y, id.Y, 1u - a_dec); fe_cmov(A.Z, id.Z, 1u - a_dec); fe_cmov(A.T, id.T, 1u - a_dec);
-  uint32_t st = 0;
-  // evaluate the checks last-to-first so that the FIRST failing one wins
-  if (flavor == 0) {
-    st = a_small ? 8u : st;  st = !a_dec ? 7u : st;  st = !a_can ? 6u : st;
-    st = (r_dec && r_small) ? 5u : st;  st = !r_dec ? 4u : st;  st = !r_can ? 3u : st;  st = !s_ok ? 2u : st;
-  } else {
-    st = (a_dec && a_small) ? 8u : st;  st = !a_can ? 6u : st;  st = !a_dec ? 7u : st;
-    st = !s_ok ? 2u : st;  st = (r_dec && r_small) ? 5u : st;  st = !r_can ? 3u : st;  st = !r_dec ? 4u : st;
-  }
   uint32_t ra[16];
   for (int i = 0; i < 8; ++i) { ra[i] = sig[i]; ra[8 + i] = pub[i]; }
   sha512_ctx c;
@@ -85,7 +76,37 @@ KYB_HD uint32_t verify_prep(uint32_t h[8], ge_p3& R, ge_p3& A, const uint32_t pu
   uint32_t dig[16];
   sha512_final(dig, c);
   sc_reduce512(h, dig);
+  return s_ok | (a_can << 1) | (a_dec << 2) | (a_small << 3);
+}
+KYB_HD uint32_t verify_prep_r(ge_p3& R, const uint32_t sig[16]) {
+  const uint32_t r_can = pt_is_canonical_w(sig);
+  const uint32_t r_dec = KYB_GE_DECODE(R, sig);
+  const uint32_t r_small = pt_has_small_order(R.Y);
+  ge_p3 id;
+  ge_p3_0(id);
+  fe_cmov(R.X, id.X, 1u - r_dec); fe_cmov(R.Y, id.Y, 1u - r_dec); fe_cmov(R.Z, id.Z, 1u - r_dec); fe_cmov(R.T, id.T, 1u - r_dec);
+  return r_can | (r_dec << 1) | (r_small << 2);
+}
+// status of the pre-equation checks: the FIRST failing one in the order of the flavour (evaluated last-to-first)
+KYB_HD uint32_t verify_status(uint32_t flags_a, uint32_t flags_r, int flavor) {
+  const uint32_t s_ok = flags_a & 1u, a_can = (flags_a >> 1) & 1u, a_dec = (flags_a >> 2) & 1u, a_small = (flags_a >> 3) & 1u;
+  const uint32_t r_can = flags_r & 1u, r_dec = (flags_r >> 1) & 1u, r_small = (flags_r >> 2) & 1u;
+  uint32_t st = 0;
+  if (flavor == 0) {
+    st = a_small ? 8u : st;  st = !a_dec ? 7u : st;  st = !a_can ? 6u : st;
+    st = (r_dec && r_small) ? 5u : st;  st = !r_dec ? 4u : st;  st = !r_can ? 3u : st;  st = !s_ok ? 2u : st;
+  } else {
+    st = (a_dec && a_small) ? 8u : st;  st = !a_can ? 6u : st;  st = !a_dec ? 7u : st;
+    st = !s_ok ? 2u : st;  st = (r_dec && r_small) ? 5u : st;  st = !r_can ? 3u : st;  st = !r_dec ? 4u : st;
+  }
   return st;
+}
+// both halves and the status in one go (host-compiled check build)
+KYB_HD uint32_t verify_prep(uint32_t h[8], ge_p3& R, ge_p3& A, const uint32_t pub[8], const uint32_t sig[16],
+                            const uint8_t* msg, uint32_t msg_len, int flavor) {
+  const uint32_t fa = verify_prep_a(h, A, pub, sig, msg, msg_len);
+  const uint32_t fr = verify_prep_r(R, sig);
+  return verify_status(fa, fr, flavor);
 }
 
 // Stage 4.  R affine (X, Y, Z = 1), hA and sB projective (X:Y:Z).  Returns 1 iff R + hA == sB.
