@@ -9,6 +9,7 @@ import hashlib
 import json
 import os
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -838,3 +839,65 @@ def test_cfg4_full_2_18_signatures(engine, oracle):
     threads = min(16, len(os.sched_getaffinity(0)))
     assert np.array_equal(sig, oracle.schnorr_sign_batch(x, k, msgs, nthreads=threads))
     assert np.array_equal(engine.schnorr_sign(x, k, msgs, pubs=engine.mul_base(x)), sig)
+
+
+def test_soak_three_threads_mixed_operations(engine, oracle):
+    """three host threads hammer the engine for a few seconds with mixed operations and sizes (host-pointer API:
+    staging, bounce buffers, copy threads, the verification side stream; device-pointer API on a stream of their own):
+    every result must equal what the same call gives alone"""
+    import threading
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(99)
+    N = 70000
+    s = synth.scalars(4096, 500)
+    s = np.tile(s, (N // 4096 + 1, 1))[:N].copy()
+    k = np.roll(s, 1, axis=0).copy()
+    pts = rand_points_ext(oracle, 256, 500)
+    pts = np.tile(pts, (N // 256 + 1, 1))[:N].copy()
+    msgs = synth.messages(2048, 500)
+    # reference results, computed alone
+    ref_mul = engine.mul(s, pts_ext=pts)
+    ref_base = engine.mul_base(s)
+    ref_sig = engine.schnorr_sign(s[:2048], k[:2048], msgs)
+    ref_pub = ref_base[:2048]
+    bad_sig = ref_sig.copy(); bad_sig[::3, 40] ^= 1
+    ref_st = engine.verify(ref_pub, msgs, bad_sig, 1)
+    assert (ref_st[1::3] == 0).all() and (ref_st[::3] != 0).all()
+    errors = []
+    stop = time.time() + 4.0
+
+    def worker(tid):
+        r = np.random.default_rng(1000 + tid)
+        stream = torch.cuda.Stream(device=dev)
+        S = torch.from_numpy(s).to(dev); P = torch.from_numpy(pts).to(dev)
+        O = torch.empty((N, 32), dtype=torch.uint8, device=dev)
+        it = 0
+        try:
+            while time.time() < stop:
+                it += 1
+                n = int(r.choice([1, 7, 64, 300, 2048, 5000, 66000]))
+                op = it % 5
+                if op == 0:
+                    assert np.array_equal(engine.mul(s[:n], pts_ext=pts[:n]), ref_mul[:n]), ("mul", n)
+                elif op == 1:
+                    assert np.array_equal(engine.mul_base(s[:n]), ref_base[:n]), ("mul_base", n)
+                elif op == 2:
+                    m = min(n, 2048)
+                    assert np.array_equal(engine.schnorr_sign(s[:m], k[:m], msgs[:m]), ref_sig[:m]), ("sign", m)
+                elif op == 3:
+                    m = min(n, 2048)
+                    assert np.array_equal(engine.verify(ref_pub[:m], msgs[:m], bad_sig[:m], 1), ref_st[:m]), ("verify", m)
+                else:
+                    engine.mul_dev(S[:n], pts_ext=P[:n], out_enc=O[:n], stream=stream.cuda_stream)
+                    stream.synchronize()
+                    assert np.array_equal(O[:n].cpu().numpy(), ref_mul[:n]), ("mul_dev", n)
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, it, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
