@@ -284,6 +284,52 @@ int run_host_batch(size_t n, const HostArr* arrs, int na, Fn launch) {
 
 static_assert(KYB_BASE_TABLE_BYTES == 4u * (KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS + KYB_BASE64_TABLE_WORDS), "table image layout");
 
+// One synchronous host-pointer call of the small (non-pipelined) kind: the caller's arrays are laid out in the
+// engine's device staging buffer, inputs copied in, `body` queues the kernels on the engine stream, outputs copied
+// back, stream synchronised.  An array whose host pointer is null takes no space and maps to a null device pointer.
+class HostCall {
+ public:
+  int in(const void* p, size_t bytes, size_t pad = 0) { return add(p, nullptr, bytes, pad); }
+  int out(void* p, size_t bytes) { return add(nullptr, p, bytes, 0); }
+  int inout(const void* p_in, void* p_out, size_t bytes) { return add(p_in, p_out, bytes, 0); }      // one device array, filled from p_in and/or returned to p_out
+  template <class T = uint8_t>
+  T* dev(int slot) const { return a_[slot].present ? reinterpret_cast<T*>(g.stage + a_[slot].off) : nullptr; }
+  template <class Body>
+  int run(Body body) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    HIPCK(hipSetDevice(g.device));
+    int rc = ensure_stage(total_);
+    if (rc) return rc;
+    for (int i = 0; i < n_; ++i)
+      if (a_[i].src && a_[i].bytes) HIPCK(hipMemcpyAsync(g.stage + a_[i].off, a_[i].src, a_[i].bytes, hipMemcpyHostToDevice, g.stream));
+    rc = body(g.stream);
+    if (rc) return rc;
+    for (int i = 0; i < n_; ++i)
+      if (a_[i].dst && a_[i].bytes) HIPCK(hipMemcpyAsync(a_[i].dst, g.stage + a_[i].off, a_[i].bytes, hipMemcpyDeviceToHost, g.stream));
+    HIPCK(hipStreamSynchronize(g.stream));
+    return KYB_OK;
+  }
+
+ private:
+  struct Arr { const void* src; void* dst; size_t bytes, off; bool present; };
+  int add(const void* src, void* dst, size_t bytes, size_t pad) {
+    const bool present = src != nullptr || dst != nullptr;
+    a_[n_] = Arr{src, dst, bytes, total_, present};
+    if (present) total_ += up256(bytes + pad);
+    return n_++;
+  }
+  Arr a_[12];
+  int n_ = 0;
+  size_t total_ = 0;
+};
+// message blobs: offsets must not decrease; returns the blob size through *mbytes
+int check_messages(const uint8_t* msgs, const uint32_t* msg_off, size_t n, size_t* mbytes) {
+  *mbytes = msg_off[n];
+  if (*mbytes && !msgs) return fail(KYB_E_BAD_ARG, "null message buffer");
+  for (size_t i = 0; i < n; ++i) if (msg_off[i + 1] < msg_off[i]) return fail(KYB_E_BAD_ARG, "msg_off must be non-decreasing");
+  return KYB_OK;
+}
+
 int do_init(int device, bool build_table) {
   std::lock_guard<std::mutex> lk(g.mu);
   if (g.ready) {
