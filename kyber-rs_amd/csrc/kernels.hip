@@ -117,6 +117,7 @@ struct Ctx {
   int opt_base_select = 1;        // 0 LDS broadcast scan, 1 bpermute
   int opt_base_block = 256;       // 256 (2 waves/SIMD) or 512 (4 waves/SIMD, 128 VGPRs)   [radix-16 kernel]
   int opt_base_radix = 64;        // 64 / 32: 43- / 52-window kernel for batches >= finish.min_items; 16: always the 64-window kernel
+  int opt_base_block64 = 1024;    // radix-64 kernel, full batches: 1024 (4 waves/SIMD, <= 128 VGPRs) or 512 (2 waves/SIMD)
   int opt_base_small_chunks = 2;  // radix-64 kernel: 256-thread workgroups up to this many chunks per CU, 1024-thread beyond
   int opt_verify_overlap = 1;     // small verification batches: s*B on a side stream next to the ladder
   int opt_mul_algo = 1;           // 0 windowed table (ge.rs structure), 1 Montgomery ladder (table-free, 1.33x faster: profiles/r01/sweep_mul_algo.log)
@@ -556,11 +557,12 @@ int launch_base_t(const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, Ctx
     // one workgroup per CU (the table is its whole LDS); 256-thread workgroups while that leaves CUs idle
     const uint4* img64 = reinterpret_cast<const uint4*>(g.table + KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS);
     const bool small = n <= (size_t)256 * (size_t)g.cus * (size_t)g.opt_base_small_chunks;
-    const size_t block = small ? 256 : 1024;
+    const size_t block = small ? 256 : (size_t)g.opt_base_block64;
     const size_t nchunks64 = (n + block - 1) / block;
     const int grid64 = (int)(nchunks64 < (size_t)g.cus ? nchunks64 : (size_t)g.cus);
     ProfScope ps(st, KID_MUL_BASE);
     if (small) hipLaunchKernelGGL((k_mul_base64<SPLIT, 256>), dim3(grid64), dim3(256), 0, st, sc, sc_b, n_a, n, oenc, oext, img64, r->proj, r->proj_items, offset);
+    else if (g.opt_base_block64 == 512) hipLaunchKernelGGL((k_mul_base64<SPLIT, 512>), dim3(grid64), dim3(512), 0, st, sc, sc_b, n_a, n, oenc, oext, img64, r->proj, r->proj_items, offset);
     else       hipLaunchKernelGGL((k_mul_base64<SPLIT, 1024>), dim3(grid64), dim3(1024), 0, st, sc, sc_b, n_a, n, oenc, oext, img64, r->proj, r->proj_items, offset);
     HIPCK(hipGetLastError());
     return KYB_OK;
