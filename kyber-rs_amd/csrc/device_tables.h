@@ -144,11 +144,12 @@ struct tbl_lds32 {
 
 // Radix-64 fixed-base table in LDS (KYB_BT64_IDX): per window seven quad planes [q][entry][4] and one pair
 // plane [entry][2]; lane l holds entry l mod 32 (top window: l mod 16) after seven conflict-free ds_read_b128
-// and one ds_read_b64, the wanted one is pulled with ds_bpermute_b32.
+// and one ds_read_b64, the wanted one is pulled with ds_bpermute_b32.  Digits are odd, so there is no
+// neutral-element case: idx = (|digit| - 1) / 2 addresses the entry directly.
 struct tbl_lds64 {
   const uint32_t* t;  // LDS
   template <int ENTRIES>
-  __device__ __forceinline__ void fetch(ge_precomp& c, const uint32_t* win, uint32_t mag) {
+  __device__ __forceinline__ void fetch(ge_precomp& c, const uint32_t* win, uint32_t idx) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t mine = lane & (uint32_t)(ENTRIES - 1);
     uint32_t own[30], f[30];
@@ -159,18 +160,14 @@ struct tbl_lds64 {
     }
     const uint2 pr = *reinterpret_cast<const uint2*>(win + 7 * ENTRIES * 4 + mine * 2);
     own[28] = pr.x; own[29] = pr.y;
-    const uint32_t want = (mag - 1u) & (uint32_t)(ENTRIES - 1);      // mag == 0 reads the last entry, masked below
-    const int src = (int)(((lane & ~(uint32_t)(ENTRIES - 1)) | want) << 2);
-    const uint32_t m = 0u - (uint32_t)(mag != 0);
+    const int src = (int)(((lane & ~(uint32_t)(ENTRIES - 1)) | idx) << 2);
 #pragma unroll
-    for (int i = 0; i < 30; ++i) f[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own[i]) & m;
-    const uint32_t z = (mag == 0);
-    f[0] |= z; f[10] |= z;
+    for (int i = 0; i < 30; ++i) f[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own[i]);
 #pragma unroll
     for (int i = 0; i < 10; ++i) { c.ypx.v[i] = f[i]; c.ymx.v[i] = f[10 + i]; c.xy2d.v[i] = f[20 + i]; }
   }
-  __device__ __forceinline__ void select(ge_precomp& c, int pos, uint32_t mag) { fetch<32>(c, t + pos * KYB_BASE64_WIN_WORDS, mag); }
-  __device__ __forceinline__ void select_top(ge_precomp& c, uint32_t mag) { fetch<16>(c, t + KYB_BASE64_TOP_BASE, mag); }
+  __device__ __forceinline__ void select(ge_precomp& c, int pos, uint32_t idx) { fetch<32>(c, t + pos * KYB_BASE64_WIN_WORDS, idx); }
+  __device__ __forceinline__ void select_top(ge_precomp& c, uint32_t idx) { fetch<16>(c, t + KYB_BASE64_TOP_BASE, idx); }
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -282,13 +282,16 @@ struct tbl_base32_words {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Fixed base, signed radix 64: 42 windows x 32 multiples + a top window of 16,
-// T64[pos][j] = (j+1) * 64^pos * B.  43 mixed additions instead of 52 (-17 %).  The image packs an
+// Fixed base, radix 64 with ODD signed digits: 42 windows x 32 odd multiples + a top window of 16,
+// T64[pos][j] = (2j+1) * 64^pos * B.  43 mixed additions instead of 52 (-17 %).  The image packs an
 // entry into its 30 words (no padding): 42 * 3840 + 1920 = 163,200 B, i.e. the whole 160 KiB LDS of
 // a CU, owned by one 1024-thread workgroup.  Per window: seven quad planes [q][entry][4] (words
 // 0..27) followed by one pair plane [entry][2] (words 28, 29), so that lane l can fetch "its" entry
 // (l mod 32, top window l mod 16) with seven conflict-free 16-byte reads and one 8-byte read.
-//     b = mag + sum_{i<42} 32*64^i;  digit_i = group_i(b) - 32 in [-32, 31],  digit_42 = b >> 252 in 0..9
+// Recoding (regular, Joye-Tunstall style: no zero digit, hence no neutral-element case in the loop):
+//     k = mag, made odd by adding L when it is even (L*B is the neutral element; mag < 10 * 2^252 stays < 2^256);
+//     c_i = 6-bit groups of k >> 1;  digit_i = 2 c_i - 63 in {-63, -61, .., 63} for i < 42;
+//     digit_42 = 2 c_42 + 1 in {1, 3, .., 11}            (sum_i digit_i 64^i = 2 (k >> 1) + 1 = k)
 // (mag < 9 * 2^252: sc_effective keeps a top radix-16 digit of at most 8).
 #define KYB_BASE64_POS 43
 #define KYB_BASE64_WIN_WORDS 960
@@ -298,29 +301,33 @@ struct tbl_base32_words {
   ((pos) < 42 ? (pos) * KYB_BASE64_WIN_WORDS + ((k) < 28 ? (((k) >> 2) * 32 + (j)) * 4 + ((k) & 3) : 896 + (j) * 2 + ((k) - 28)) \
               : KYB_BASE64_TOP_BASE + ((k) < 28 ? (((k) >> 2) * 16 + (j)) * 4 + ((k) & 3) : 448 + (j) * 2 + ((k) - 28)))
 struct sc_digits64 {
-  uint32_t w[8];     // b (< 2^256), consumed 6 bits at a time from the bottom
+  uint32_t w[8];     // k >> 1, consumed 6 bits at a time from the bottom
   uint32_t neg;      // the whole scalar is negative: negate the result
 };
 KYB_HD void sc_recode64(sc_digits64& d, const uint32_t a[8]) {
-  const uint32_t c64[8] = KYB_W_RECODE64;
+  const uint32_t lw[8] = KYB_W_L;
   uint32_t mag[8];
   sc_effective(d.neg, mag, a);
+  const uint32_t even = 1u - (mag[0] & 1u);
   uint64_t c = 0;
   KYB_UNROLL for (int i = 0; i < 8; ++i) {
-    c += (uint64_t)mag[i] + c64[i];
-    d.w[i] = (uint32_t)c;
+    c += (uint64_t)mag[i] + (even ? lw[i] : 0u);
+    mag[i] = (uint32_t)c;
     c >>= 32;
   }
+  KYB_UNROLL for (int i = 0; i < 7; ++i) d.w[i] = (mag[i] >> 1) | (mag[i + 1] << 31);
+  d.w[7] = mag[7] >> 1;
 }
-KYB_HD void sc_next_digit64(uint32_t& mag, uint32_t& neg, sc_digits64& d, bool top) {
-  const int v = (int)(d.w[0] & 63u) - (top ? 0 : 32);
-  neg = v < 0;
-  mag = neg ? (uint32_t)(-v) : (uint32_t)v;
+// next digit as (table index = (|digit| - 1) / 2, negative flag), then shift the register down by 6 bits
+KYB_HD void sc_next_digit64(uint32_t& idx, uint32_t& neg, sc_digits64& d, bool top) {
+  const uint32_t c = d.w[0] & 63u;
+  neg = top ? 0u : (uint32_t)(c < 32u);
+  idx = top ? c : (neg ? 31u - c : c - 32u);
   KYB_UNROLL for (int i = 0; i < 7; ++i) d.w[i] = (d.w[i] >> 6) | (d.w[i + 1] << 26);
   d.w[7] >>= 6;
 }
-// Tbl: void select(ge_precomp& c, int pos, uint32_t mag) for pos < 42 (mag in 0..32) and
-//      void select_top(ge_precomp& c, uint32_t mag) for the top window (mag in 0..16)
+// Tbl: void select(ge_precomp& c, int pos, uint32_t idx) for pos < 42 (idx in 0..31) and
+//      void select_top(ge_precomp& c, uint32_t idx) for the top window (idx in 0..15)
 template <class Tbl>
 KYB_HD void ge_scalarmult_base64(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
   sc_digits64 dg;
@@ -356,10 +363,10 @@ KYB_HD void ge_scalarmult_base64(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
 }
 struct tbl_base64_words {
   const uint32_t* w;
-  KYB_HD void scan(ge_precomp& c, int pos, uint32_t mag, int entries) {
+  KYB_HD void scan(ge_precomp& c, int pos, uint32_t idx, int entries) {
     fe_one(c.ypx); fe_one(c.ymx); fe_zero(c.xy2d);
     for (int j = 0; j < entries; ++j) {
-      uint32_t m = (mag == (uint32_t)(j + 1));
+      uint32_t m = (idx == (uint32_t)j);
       for (int k = 0; k < 10; ++k) {
         c.ypx.v[k] = m ? w[KYB_BT64_IDX(pos, j, k)] : c.ypx.v[k];
         c.ymx.v[k] = m ? w[KYB_BT64_IDX(pos, j, 10 + k)] : c.ymx.v[k];
@@ -367,8 +374,8 @@ struct tbl_base64_words {
       }
     }
   }
-  KYB_HD void select(ge_precomp& c, int pos, uint32_t mag) { scan(c, pos, mag, 32); }
-  KYB_HD void select_top(ge_precomp& c, uint32_t mag) { scan(c, 42, mag, 16); }
+  KYB_HD void select(ge_precomp& c, int pos, uint32_t idx) { scan(c, pos, idx, 32); }
+  KYB_HD void select_top(ge_precomp& c, uint32_t idx) { scan(c, 42, idx, 16); }
 };
 
 // One entry of the base table: (j+1) * 16^pos * B, normalised to affine (y+x, y-x, 2dxy).
@@ -439,7 +446,7 @@ KYB_HD void ge_base32_table_entry(uint32_t* image, int pos, int j) {
   image[KYB_BT32_IDX(pos, j, 31)] = 0;
 }
 
-// One entry of the radix-64 table: (j+1) * 64^pos * B = (j+1) * (2^(6 pos) * B); 2^252 (pos 42) is a top
+// One entry of the radix-64 table: (2j+1) * 64^pos * B = (2j+1) * (2^(6 pos) * B); 2^252 (pos 42) is a top
 // radix-16 digit of 1.
 KYB_HD void ge_base64_table_entry(uint32_t* image, int pos, int j) {
   const uint32_t benc[8] = KYB_W_BASE_ENC;
@@ -454,7 +461,7 @@ KYB_HD void ge_base64_table_entry(uint32_t* image, int pos, int j) {
   ge_scalarmult(r, a, B, tbl);
   ge_p3 Ppos, Q;
   ge_p2_to_p3(Ppos, r);
-  ge_small_mul(Q, Ppos, (uint32_t)(j + 1), 6);
+  ge_small_mul(Q, Ppos, (uint32_t)(2 * j + 1), 6);
   fe recip, x, y, t, ypx, ymx, xy2d;
   fe_invert(recip, Q.Z);
   fe_mul(x, Q.X, recip);

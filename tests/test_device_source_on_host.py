@@ -293,8 +293,9 @@ def test_fixed_base_radix32_matches_oracle(hd, oracle):
 
 
 def test_fixed_base_radix64_matches_oracle(hd, oracle):
-    """52 -> 43 windows: the radix-64 recoding / table / routine gives the reference's bytes on the quirk scalars
-    (>= 2^255, top digits 8..16), on digit patterns that hit the window extremes (-32, +31, 0), and at random"""
+    """52 -> 43 windows: the radix-64 odd-digit recoding / table / routine gives the reference's bytes on the quirk
+    scalars (>= 2^255, top digits 8..16), on even and odd values (even ones go through k + L), on digit patterns that
+    hit the window extremes (c = 0, 31, 32, 63), and at random"""
     base = hd.hd_overflows()
     rnd = random.Random(64)
     for q in KATS["quirk_mul_base"]:
@@ -302,7 +303,11 @@ def test_fixed_base_radix64_matches_oracle(hd, oracle):
         assert o.raw.hex() == q["out"], q["scalar"]
     L = M.L
     ints = [0, 1, 31, 32, 33, 63, 64, 2**252 - 1, 2**252, 2**252 + 1, 9 * 2**252 - 1, 8 * 2**252 + 5, 2**255 - 19, 2**256 - 1, L, L - 1, 8 * L,
-            sum(32 << (6 * i) for i in range(42)), sum(31 << (6 * i) for i in range(43)) % 2**256, sum(33 << (6 * i) for i in range(42))]
+            sum(32 << (6 * i) for i in range(42)), sum(31 << (6 * i) for i in range(43)) % 2**256, sum(33 << (6 * i) for i in range(42)),
+            2, 3, 4, 2 * L, 2 * L + 1, 2**253 - 2, 2**253 - 1]
+    for c in (0, 31, 32, 63):          # k >> 1 has every 6-bit group equal to c; k odd
+        ints.append((2 * sum(c << (6 * i) for i in range(42)) + 1) % 2**256)
+        ints.append((2 * sum(c << (6 * i) for i in range(42))) % 2**256)
     cases = [v.to_bytes(32, "little") for v in ints] + [bytes([0xff] * 32), bytes([0xf8] * 32), bytes([0x10] * 32), bytes([0x84] * 32)]
     cases += [bytes(rnd.getrandbits(8) for _ in range(32)) for _ in range(200)]
     for s in cases:

@@ -466,7 +466,7 @@ def test_fixed_base_radix32_kernel(engine, oracle):
         assert val([img[idx(pos, j, k)] for k in range(10)]) == (y + x) % P
         assert val([img[idx(pos, j, 10 + k)] for k in range(10)]) == (y - x) % P
         assert val([img[idx(pos, j, 20 + k)] for k in range(10)]) == 2 * M.D * x * y % P
-    # radix-64 part: entry (pos, j) = (j+1) * 64^pos * B, 30 packed words per entry
+    # radix-64 part: entry (pos, j) = (2j+1) * 64^pos * B (odd multiples: the recoding has no zero digit), 30 packed words per entry
     img64 = whole[172032 // 4:]
     assert img64.shape[0] == 163200 // 4
 
@@ -476,7 +476,7 @@ def test_fixed_base_radix32_kernel(engine, oracle):
         return 42 * 960 + (((k >> 2) * 16 + j) * 4 + (k & 3) if k < 28 else 448 + j * 2 + (k - 28))
 
     for pos, j in ((0, 0), (0, 31), (1, 7), (20, 30), (41, 31), (42, 0), (42, 8), (42, 15)):
-        x, y = M.mul_int((j + 1) << (6 * pos), M.B)
+        x, y = M.mul_int((2 * j + 1) << (6 * pos), M.B)
         assert val([img64[idx64(pos, j, k)] for k in range(10)]) == (y + x) % P
         assert val([img64[idx64(pos, j, 10 + k)] for k in range(10)]) == (y - x) % P
         assert val([img64[idx64(pos, j, 20 + k)] for k in range(10)]) == 2 * M.D * x * y % P
