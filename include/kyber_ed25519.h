@@ -51,8 +51,10 @@ extern "C" {
  * radix-16 positions only); affine (y+x, y-x, 2dxy), canonical limbs:
  *   bytes [0, 65536)        uint32 [64 pos][8 quads][ 8 entries][4]   entry (pos, j) = (j+1) * 16^pos * B
  *   bytes [65536, 172032)   uint32 [52 pos][8 quads][16 entries][4]   entry (pos, j) = (j+1) * 32^pos * B
- *   bytes [172032, 335232)  42 windows of 3840 B: uint32 [7 quads][32 entries][4] + [32 entries][2], then a top window
- *                           of 1920 B with 16 entries                 entry (pos, j) = (2j+1) * 64^pos * B */
+ *   bytes [172032, 335232)  42 windows of 3840 B with E = 32 entries, then a top window of 1920 B with E = 16:
+ *                           per window the planes  y+x [2][E][4] | y-x [2][E][4] | y+x [E][2] | y-x [E][2] |
+ *                           2dxy [2][E][4] | 2dxy [E][2]  (limbs 0..7 in the quad planes, 8..9 in the pair planes)
+ *                                                                     entry (pos, j) = (2j+1) * 64^pos * B */
 #define KYB_BASE_TABLE_BYTES 335232u
 
 /* Version of this interface: bumped on any change of an existing signature, of KYB_BASE_TABLE_BYTES or of a status /

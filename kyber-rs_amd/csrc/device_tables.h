@@ -142,32 +142,56 @@ struct tbl_lds32 {
   }
 };
 
-// Radix-64 fixed-base table in LDS (KYB_BT64_IDX): per window seven quad planes [q][entry][4] and one pair
-// plane [entry][2]; lane l holds entry l mod 32 (top window: l mod 16) after seven conflict-free ds_read_b128
-// and one ds_read_b64, the wanted one is pulled with ds_bpermute_b32.  Digits are odd, so there is no
-// neutral-element case: idx = (|digit| - 1) / 2 addresses the entry directly.
+// Radix-64 fixed-base table in LDS (kyb_bt64_in_win: separate planes for ypx / ymx / xy2d).  Lane l of a wave holds
+// entry l mod 32 — lanes 32..63 hold it NEGATED, (ymx, ypx, -xy2d): the exchange of ypx and ymx is an exchange of
+// the two plane addresses (free), the negation of xy2d is 2p - x done as (x ^ m) + (m & (2p + 1)) with the lane's
+// constant mask m.  The wanted entry with the wanted sign is then pulled from lane (neg << 5 | idx) with
+// ds_bpermute_b32: the requesting lane needs no conditional negation and, the digits being odd, no neutral-element
+// case.  The top window (16 entries, digit always positive) has no negated copies.
 struct tbl_lds64 {
   const uint32_t* t;  // LDS
-  template <int ENTRIES>
-  __device__ __forceinline__ void fetch(ge_precomp& c, const uint32_t* win, uint32_t idx) {
+  template <int E, bool SIGNED>
+  __device__ __forceinline__ void fetch(ge_precomp& c, const uint32_t* win, uint32_t src_lane) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t mine = lane & (uint32_t)(ENTRIES - 1);
+    const uint32_t mine = lane & (uint32_t)(E - 1);
+    const uint32_t s = SIGNED ? (lane >> 5) & 1u : 0u;                 // this lane holds the negated entry
+    const uint32_t* pa = win + (s ? 8 * E : 0);                        // plane A (ypx 0..7) or B (ymx 0..7)
+    const uint32_t* pb = win + (s ? 0 : 8 * E);
+    const uint32_t* qa = win + (s ? 18 * E : 16 * E);                  // plane a (ypx 8, 9) or b
+    const uint32_t* qb = win + (s ? 16 * E : 18 * E);
     uint32_t own[30], f[30];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) {
-      const uint4 v = *reinterpret_cast<const uint4*>(win + (q * ENTRIES + mine) * 4);
-      own[4 * q] = v.x; own[4 * q + 1] = v.y; own[4 * q + 2] = v.z; own[4 * q + 3] = v.w;
+    for (int q = 0; q < 2; ++q) {
+      const uint4 va = *reinterpret_cast<const uint4*>(pa + (q * E + mine) * 4);
+      const uint4 vb = *reinterpret_cast<const uint4*>(pb + (q * E + mine) * 4);
+      const uint4 vc = *reinterpret_cast<const uint4*>(win + 20 * E + (q * E + mine) * 4);
+      own[4 * q] = va.x; own[4 * q + 1] = va.y; own[4 * q + 2] = va.z; own[4 * q + 3] = va.w;
+      own[10 + 4 * q] = vb.x; own[10 + 4 * q + 1] = vb.y; own[10 + 4 * q + 2] = vb.z; own[10 + 4 * q + 3] = vb.w;
+      own[20 + 4 * q] = vc.x; own[20 + 4 * q + 1] = vc.y; own[20 + 4 * q + 2] = vc.z; own[20 + 4 * q + 3] = vc.w;
     }
-    const uint2 pr = *reinterpret_cast<const uint2*>(win + 7 * ENTRIES * 4 + mine * 2);
-    own[28] = pr.x; own[29] = pr.y;
-    const int src = (int)(((lane & ~(uint32_t)(ENTRIES - 1)) | idx) << 2);
+    const uint2 wa = *reinterpret_cast<const uint2*>(qa + mine * 2);
+    const uint2 wb = *reinterpret_cast<const uint2*>(qb + mine * 2);
+    const uint2 wc = *reinterpret_cast<const uint2*>(win + 28 * E + mine * 2);
+    own[8] = wa.x; own[9] = wa.y; own[18] = wb.x; own[19] = wb.y; own[28] = wc.x; own[29] = wc.y;
+    if (SIGNED) {
+      const uint32_t p2[10] = KYB_FE_2P;
+      const uint32_t m = 0u - s;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) own[20 + i] = (own[20 + i] ^ m) + (m & (p2[i] + 1u));        // s ? 2p - x : x
+    }
+    const int src = (int)(((lane & ~63u) | src_lane) << 2);
 #pragma unroll
     for (int i = 0; i < 30; ++i) f[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own[i]);
 #pragma unroll
     for (int i = 0; i < 10; ++i) { c.ypx.v[i] = f[i]; c.ymx.v[i] = f[10 + i]; c.xy2d.v[i] = f[20 + i]; }
   }
-  __device__ __forceinline__ void select(ge_precomp& c, int pos, uint32_t idx) { fetch<32>(c, t + pos * KYB_BASE64_WIN_WORDS, idx); }
-  __device__ __forceinline__ void select_top(ge_precomp& c, uint32_t idx) { fetch<16>(c, t + KYB_BASE64_TOP_BASE, idx); }
+  __device__ __forceinline__ void select(ge_precomp& c, int pos, uint32_t idx, uint32_t neg) {
+    fetch<32, true>(c, t + pos * KYB_BASE64_WIN_WORDS, (neg << 5) | idx);
+  }
+  __device__ __forceinline__ void select_top(ge_precomp& c, uint32_t idx) {
+    const uint32_t lane = threadIdx.x & 63u;
+    fetch<16, false>(c, t + KYB_BASE64_TOP_BASE, (lane & 48u) | idx);
+  }
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -285,9 +285,9 @@ struct tbl_base32_words {
 // Fixed base, radix 64 with ODD signed digits: 42 windows x 32 odd multiples + a top window of 16,
 // T64[pos][j] = (2j+1) * 64^pos * B.  43 mixed additions instead of 52 (-17 %).  The image packs an
 // entry into its 30 words (no padding): 42 * 3840 + 1920 = 163,200 B, i.e. the whole 160 KiB LDS of
-// a CU, owned by one 1024-thread workgroup.  Per window: seven quad planes [q][entry][4] (words
-// 0..27) followed by one pair plane [entry][2] (words 28, 29), so that lane l can fetch "its" entry
-// (l mod 32, top window l mod 16) with seven conflict-free 16-byte reads and one 8-byte read.
+// a CU, owned by one 1024-thread workgroup.  Per window the three field elements of an entry live in
+// separately addressable planes (kyb_bt64_in_win), read with six conflict-free 16-byte and three 8-byte
+// LDS loads; the 64 lanes of a wave hold the 32 entries (lanes 0..31) and their negatives (lanes 32..63).
 // Recoding (regular, Joye-Tunstall style: no zero digit, hence no neutral-element case in the loop):
 //     k = mag, made odd by adding L when it is even (L*B is the neutral element; mag < 10 * 2^252 stays < 2^256);
 //     c_i = 6-bit groups of k >> 1;  digit_i = 2 c_i - 63 in {-63, -61, .., 63} for i < 42;
@@ -297,9 +297,19 @@ struct tbl_base32_words {
 #define KYB_BASE64_WIN_WORDS 960
 #define KYB_BASE64_TOP_BASE (42 * KYB_BASE64_WIN_WORDS)
 #define KYB_BASE64_TABLE_WORDS (KYB_BASE64_TOP_BASE + 480)
-#define KYB_BT64_IDX(pos, j, k)                                                                                      \
-  ((pos) < 42 ? (pos) * KYB_BASE64_WIN_WORDS + ((k) < 28 ? (((k) >> 2) * 32 + (j)) * 4 + ((k) & 3) : 896 + (j) * 2 + ((k) - 28)) \
-              : KYB_BASE64_TOP_BASE + ((k) < 28 ? (((k) >> 2) * 16 + (j)) * 4 + ((k) & 3) : 448 + (j) * 2 + ((k) - 28)))
+// word k (0..9 ypx, 10..19 ymx, 20..29 xy2d) of entry j of a window with E entries, relative to the window:
+//   plane A  words [ 0E,  8E)  [2 quads][E][4]  ypx 0..7        plane a  words [16E, 18E)  [E][2]  ypx 8, 9
+//   plane B  words [ 8E, 16E)  [2 quads][E][4]  ymx 0..7        plane b  words [18E, 20E)  [E][2]  ymx 8, 9
+//   plane C  words [20E, 28E)  [2 quads][E][4]  xy2d 0..7       plane c  words [28E, 30E)  [E][2]  xy2d 8, 9
+// ypx and ymx sit in separately addressable planes: a lane that holds the NEGATED entry (ymx, ypx, -xy2d) reads
+// A/a and B/b with exchanged base addresses instead of swapping registers afterwards.
+KYB_HD constexpr int kyb_bt64_in_win(int E, int j, int k) {
+  const int g = k / 10, r = k % 10;                  // g: 0 ypx, 1 ymx, 2 xy2d
+  const int big = g == 0 ? 0 : (g == 1 ? 8 * E : 20 * E), small = g == 0 ? 16 * E : (g == 1 ? 18 * E : 28 * E);
+  return r < 8 ? big + ((r >> 2) * E + j) * 4 + (r & 3) : small + j * 2 + (r - 8);
+}
+#define KYB_BT64_IDX(pos, j, k) \
+  ((pos) < 42 ? (pos) * KYB_BASE64_WIN_WORDS + kyb_bt64_in_win(32, j, k) : KYB_BASE64_TOP_BASE + kyb_bt64_in_win(16, j, k))
 struct sc_digits64 {
   uint32_t w[8];     // k >> 1, consumed 6 bits at a time from the bottom
   uint32_t neg;      // the whole scalar is negative: negate the result
@@ -326,8 +336,8 @@ KYB_HD void sc_next_digit64(uint32_t& idx, uint32_t& neg, sc_digits64& d, bool t
   KYB_UNROLL for (int i = 0; i < 7; ++i) d.w[i] = (d.w[i] >> 6) | (d.w[i + 1] << 26);
   d.w[7] >>= 6;
 }
-// Tbl: void select(ge_precomp& c, int pos, uint32_t idx) for pos < 42 (idx in 0..31) and
-//      void select_top(ge_precomp& c, uint32_t idx) for the top window (idx in 0..15)
+// Tbl: void select(ge_precomp& c, int pos, uint32_t idx, uint32_t neg) for pos < 42: entry idx in 0..31, negated when neg
+//      void select_top(ge_precomp& c, uint32_t idx) for the top window (idx in 0..15, never negative)
 template <class Tbl>
 KYB_HD void ge_scalarmult_base64(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
   sc_digits64 dg;
@@ -340,8 +350,7 @@ KYB_HD void ge_scalarmult_base64(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
     uint32_t mag, neg;
     sc_next_digit64(mag, neg, dg, false);
     ge_precomp c;
-    tbl.select(c, pos, mag);
-    ge_precomp_cneg(c, neg);
+    tbl.select(c, pos, mag, neg);
     ge_p1p1 t;
     ge_madd(t, h, c);
     ge_p1p1_to_p3(h, t);
@@ -374,7 +383,7 @@ struct tbl_base64_words {
       }
     }
   }
-  KYB_HD void select(ge_precomp& c, int pos, uint32_t idx) { scan(c, pos, idx, 32); }
+  KYB_HD void select(ge_precomp& c, int pos, uint32_t idx, uint32_t neg) { scan(c, pos, idx, 32); ge_precomp_cneg(c, neg); }
   KYB_HD void select_top(ge_precomp& c, uint32_t idx) { scan(c, 42, idx, 16); }
 };
 

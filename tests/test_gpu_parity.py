@@ -471,9 +471,11 @@ def test_fixed_base_radix32_kernel(engine, oracle):
     assert img64.shape[0] == 163200 // 4
 
     def idx64(pos, j, k):
-        if pos < 42:
-            return pos * 960 + (((k >> 2) * 32 + j) * 4 + (k & 3) if k < 28 else 896 + j * 2 + (k - 28))
-        return 42 * 960 + (((k >> 2) * 16 + j) * 4 + (k & 3) if k < 28 else 448 + j * 2 + (k - 28))
+        E = 32 if pos < 42 else 16
+        g, r = divmod(k, 10)                          # g: 0 ypx, 1 ymx, 2 xy2d, each in its own planes
+        big, small = ((0, 16 * E), (8 * E, 18 * E), (20 * E, 28 * E))[g]
+        inner = big + ((r >> 2) * E + j) * 4 + (r & 3) if r < 8 else small + j * 2 + (r - 8)
+        return (pos * 960 if pos < 42 else 42 * 960) + inner
 
     for pos, j in ((0, 0), (0, 31), (1, 7), (20, 30), (41, 31), (42, 0), (42, 8), (42, 15)):
         x, y = M.mul_int((2 * j + 1) << (6 * pos), M.B)
