@@ -37,3 +37,24 @@ def distribute_base_table(engine, rank: int, world: int, device, dist=None) -> N
     if rank != 0:
         engine.base_table_import_dev(tbl)
         engine.sync()          # the copy reads `tbl`: finish it before the tensor goes back to the allocator
+
+
+def gather_outputs(local, n_total: int, rank: int, world: int, dist=None):
+    """Optional: every rank ends up with the outputs of ALL shards (only when a follow-on step needs them on
+    one GPU, e.g. summing commitments).  `local` holds this rank's shard, records along dim 0; shards differ in length
+    by at most one, so they travel padded to the longest and are trimmed on arrival.  One all_gather (RCCL over xGMI on
+    GPU ranks, gloo on CPU)."""
+    if world == 1:
+        return local
+    import torch
+    if dist is None:
+        import torch.distributed as dist  # noqa: PLW0642
+    sizes = [shard(n_total, r, world)[1] - shard(n_total, r, world)[0] for r in range(world)]
+    if local.shape[0] != sizes[rank]:
+        raise ValueError("local shard has the wrong length")
+    longest = max(sizes)
+    padded = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: sizes[rank]] = local
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded)
+    return torch.cat([parts[r][: sizes[r]] for r in range(world)], dim=0)

@@ -38,6 +38,10 @@ def _worker(rank, world, port, n_total, q):
     # "process" the shard: checksum of the item indices, then max-over-ranks timing style reduction
     t = torch.tensor([float(hi - lo)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    # optional gather of the shard outputs: record i carries its own global index
+    local = torch.arange(lo, hi, dtype=torch.int64).unsqueeze(1).repeat(1, 4)
+    full = multi_gpu.gather_outputs(local, n_total, rank, world, dist)
+    assert full.shape == (n_total, 4) and bool((full[:, 0] == torch.arange(n_total)).all())
     q.put((rank, lo, hi, hashlib.sha256(eng.table).hexdigest(), float(t.item())))
     dist.barrier()
     dist.destroy_process_group()
