@@ -313,6 +313,11 @@ k_mont_prep(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ p
   fe_one(unused_prefix);
   batch_invert<0, FINISH_K>(unused_prefix, unused_inv, load, emit);
 }
+#if defined(KYB_DIAG_STAMPS)
+// diagnostic build only: per-wave (cycles, 100 MHz ticks) of the ladder loop go to a buffer of their own
+__device__ uint64_t* kyb_diag_stamp_buf = nullptr;
+__device__ size_t kyb_diag_stamp_cap = 0;
+#endif
 template <int WAVES>
 __global__ void __launch_bounds__(KYB_BLOCK, WAVES)
 k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits) {
@@ -330,7 +335,14 @@ k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ 
   for (int k = 0; k < 10; ++k) { m.u.v[k] = f[k]; m.v.v[k] = f[10 + k]; }
   m.flags = f[20];
   ge_p2 r;
+#if defined(KYB_DIAG_STAMPS)
+  uint64_t stamp[2];
+  ge_scalarmult_ladder_stamped(r, a, m, skip_bits, stamp);
+  const size_t wave = i >> 6;
+  if ((threadIdx.x & 63u) == 0 && kyb_diag_stamp_buf != nullptr && wave < kyb_diag_stamp_cap) { kyb_diag_stamp_buf[2 * wave] = stamp[0]; kyb_diag_stamp_buf[2 * wave + 1] = stamp[1]; }
+#else
   ge_scalarmult_ladder(r, a, m, skip_bits);
+#endif
   store_proj(proj, stride, i, r.X, r.Y, r.Z);
 }
 

@@ -30,11 +30,15 @@ KYB_HD uint32_t sc_is_canonical_w(const uint32_t s[8]) {
   uint32_t t[8];
   return mw_sub<8>(t, s, lw);          // borrow <=> s < L
 }
-// point.rs:315-337: the 255-bit y of the encoding is < p (the sign bit is ignored)
+// point.rs:315-337 AS THE REFERENCE EVALUATES IT (the sign bit is ignored).  The reference cites libsodium's
+// (0xED - 1 - b0) >> 8 but computes (0xED - (1 - b0)) >> 8 in wrapping u16 arithmetic (overflow-checks = false,
+// Cargo.toml:9-10): with bytes 1..30 = 0xff and b31 & 0x7f = 0x7f it answers "not canonical" for every b0 >= 0x14,
+// i.e. for y in [2^255 - 236, 2^255 - 1] — the 19 values >= p and also the 217 canonical values p-217 .. p-1.
+// A drop-in reproduces that answer (KATs at b0 = 0x13, 0x14, 0xec, 0xed in tests/golden/kats.json).
 KYB_HD uint32_t pt_is_canonical_w(const uint32_t w[8]) {
   uint32_t all = w[1] & w[2] & w[3] & w[4] & w[5] & w[6];
-  uint32_t ge_p = (all == 0xffffffffu) & ((w[7] & 0x7fffffffu) == 0x7fffffffu) & (w[0] >= 0xffffffedu);
-  return 1u - ge_p;
+  uint32_t rejected = (all == 0xffffffffu) & ((w[7] & 0x7fffffffu) == 0x7fffffffu) & (w[0] >= 0xffffff14u);
+  return 1u - rejected;
 }
 // point.rs:286-313: the canonical re-encoding, sign bit masked, equals one of the five WEAK_KEYS
 // (constants.rs:3744-3775) <=> canonical y in {0, 1, p-1, y8a, y8b}

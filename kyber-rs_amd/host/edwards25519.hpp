@@ -293,7 +293,9 @@ class Point {
     uint8_t c = (b[31] & 0x7f) ^ 0x7f;
     for (int i = 30; i >= 1; --i) c |= b[i] ^ 0xff;
     c = (uint8_t)((((uint16_t)c) - 1) >> 8);
-    uint8_t d = (uint8_t)((uint16_t)(0xEDu - 1u - (uint16_t)b[0]) >> 8);
+    // the reference's own expression, 0xED - (1 - b0) in wrapping u16 (not libsodium's 0xED - 1 - b0): see csrc/verify.h
+    const uint16_t inner = (uint16_t)(1u - (uint16_t)b[0]);
+    uint8_t d = (uint8_t)((uint16_t)(0xEDu - inner) >> 8);
     return 1 - (c & d & 1) == 1;
   }
 

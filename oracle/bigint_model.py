@@ -191,7 +191,11 @@ def has_small_order(pt):
 
 
 def point_is_canonical(b):
-    return (int.from_bytes(b, "little") & ((1 << 255) - 1)) < P
+    """point.rs:315-337 as the reference evaluates it: its `d` is (0xED - (1 - b0)) >> 8 in wrapping u16 arithmetic (libsodium has
+    0xED - 1 - b0), so with bytes 1..30 = 0xff and b31 & 0x7f = 0x7f every b0 >= 0x14 is reported non-canonical:
+    y in [2^255 - 236, 2^255 - 1] = the 19 values >= p AND the 217 canonical values p-217 .. p-1."""
+    y = int.from_bytes(b, "little") & ((1 << 255) - 1)
+    return y < (1 << 255) - 256 + 0x14
 
 
 def scalar_is_canonical(b):

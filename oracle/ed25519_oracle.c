@@ -655,12 +655,16 @@ static int sc_is_canonical(const uint8_t sb[32]) {
   }
   return c != 0;
 }
-/* point.rs:315-337 */
+/* point.rs:315-337, expression for expression (u16 wrapping arithmetic: Cargo.toml:9-10 sets overflow-checks = false).
+ * NB the reference writes  d = (0xED - (1 - b0)) >> 8  where libsodium, which it cites, has (0xED - 1 - b0) >> 8:
+ * with bytes 1..30 = 0xff and b31 & 0x7f = 0x7f it therefore reports "not canonical" for every b0 >= 0x14, i.e. also
+ * for the 217 canonical values y = p-217 .. p-1, and that is what a drop-in has to answer too. */
 static int pt_is_canonical(const uint8_t b[32]) {
   uint8_t c = (uint8_t)((b[31] & 0x7f) ^ 0x7f);
   for (int i = 30; i >= 1; i--) c |= (uint8_t)(b[i] ^ 0xff);
-  c = (uint8_t)((((uint16_t)c) - 1) >> 8);
-  uint8_t d = (uint8_t)(((uint16_t)(0xEDu - 1u - (uint16_t)b[0])) >> 8);
+  c = (uint8_t)(((uint16_t)((uint16_t)c - 1u)) >> 8);
+  uint16_t inner = (uint16_t)(1u - (uint16_t)b[0]);
+  uint8_t d = (uint8_t)(((uint16_t)(0xEDu - inner)) >> 8);
   return 1 - (c & d & 1) == 1;
 }
 /* point.rs:286-313 with WEAK_KEYS (constants.rs:3744-3775) regenerated: the encodings of the points of

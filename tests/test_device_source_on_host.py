@@ -202,6 +202,14 @@ def verify_cases(oracle):
         cases.append((nc1, msg, sig))
         cases.append((nonc, msg, nonc + s_plus_l))                          # several failures at once: order matters
         cases.append((small, msg, small + s_plus_l))
+    # the edge of the reference's is_canonical (point.rs:315-337 computes 0xED - (1 - b0), not libsodium's 0xED - 1 - b0):
+    # with bytes 1..30 = ff, b31 = 7f / ff the answer flips between b0 = 0x13 and 0x14, not between 0xec and 0xed
+    pub, msg, sig = cases[1]
+    for b0 in (0x00, 0x01, 0x13, 0x14, 0x15, 0x80, 0xeb, 0xec, 0xed, 0xee, 0xff):
+        for top in (0x7f, 0xff):
+            edge = bytes([b0]) + b"\xff" * 30 + bytes([top])
+            cases.append((edge, msg, sig))
+            cases.append((pub, msg, edge + sig[32:]))
     return cases
 
 

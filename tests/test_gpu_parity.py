@@ -903,3 +903,31 @@ def test_soak_three_threads_mixed_operations(engine, oracle):
     for x in th:
         x.join()
     assert not errors, errors
+
+
+def test_verify_equation_on_raw_kernels_all_golden_lines(engine):
+    """eddsa_sig.rs:194-211 on the reference's own 1024 golden signatures, built from the RAW batch entry points —
+    kyb_decode_batch (A, R), kyb_mul_batch (h*A: the ladder), kyb_add_batch (R + h*A), kyb_encode_batch, kyb_mul_base_batch
+    (s*B) — with h computed by hashlib and Python integers: ties the variable-base kernel to reference-held data
+    without the oracle and without kyb_verify_batch's own plumbing."""
+    L = 2**252 + 27742317777372353535851937790883648493
+    pubs, rs, ss, hs = [], [], [], []
+    for ln in gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n"):
+        if not ln:
+            continue
+        p = ln.split(":")
+        pub, msg, sig = bytes.fromhex(p[1]), bytes.fromhex(p[2]), bytes.fromhex(p[3])[:64]
+        pubs.append(pub); rs.append(sig[:32]); ss.append(sig[32:])
+        hs.append((int.from_bytes(hashlib.sha512(sig[:32] + pub + msg).digest(), "little") % L).to_bytes(32, "little"))
+    assert len(pubs) == 1024
+    as_u8 = lambda lst: np.frombuffer(b"".join(lst), dtype=np.uint8).reshape(-1, 32)
+    a_ext, ok_a = engine.decode(as_u8(pubs))
+    r_ext, ok_r = engine.decode(as_u8(rs))
+    assert ok_a.all() and ok_r.all()
+    _, ha_ext = engine.mul(as_u8(hs), pts_ext=a_ext, want_ext=True)
+    lhs = engine.encode(engine.add(r_ext, ha_ext))
+    rhs = engine.mul_base(as_u8(ss))
+    assert np.array_equal(lhs, rhs)
+    # and from the wire encodings of A (the decode runs inside kyb_mul_batch)
+    _, ha2 = engine.mul(as_u8(hs), pts_enc=as_u8(pubs), want_ext=True)
+    assert np.array_equal(engine.encode(engine.add(r_ext, ha2)), rhs)

@@ -48,10 +48,8 @@ def test_rfc8032_vectors(oracle):
 
 def test_golden_verify_equation_pins_variable_base(oracle):
     """eddsa_sig.rs:194-211: s*B == R + h*A on golden signatures — the only place the reference's
-    vectors reach the variable-base routine (h*A).  64 lines."""
+    vectors reach the variable-base routine (h*A).  All 1024 lines."""
     for i, (seed, pub, msg, sig) in enumerate(golden_lines()):
-        if i % 16:
-            continue
         a_ext, ok = oracle.decode(pub)
         r_ext, ok2 = oracle.decode(sig[:32])
         assert ok and ok2
@@ -177,3 +175,38 @@ def test_verify_golden_and_negative_vectors(oracle):
             for flavor in (0, 1):
                 for p_, m_, s_ in ((pub, msg, sig), (nonc, msg, nonc + s_plus_l), (small, msg, small + sig[32:]), (pub, msg + b"!", sig)):
                     assert M.verify(flavor, p_, m_, s_) == oracle.verify(flavor, p_, m_, s_)
+
+
+def _ref_is_canonical(b: bytes) -> bool:
+    """point.rs:315-337 transliterated operation by operation (u8 / u16 wrapping, Cargo.toml:9-10 overflow-checks = false)"""
+    if len(b) != 32:
+        return False
+    c = (b[31] & 0x7f) ^ 0x7f
+    for i in range(30, 0, -1):
+        c |= b[i] ^ 0xff
+    c = (((c - 1) & 0xffff) >> 8) & 0xff
+    d = (((0xED - ((1 - b[0]) & 0xffff)) & 0xffff) >> 8) & 0xff
+    return 1 - (c & d & 1) == 1
+
+
+def test_point_is_canonical_follows_the_reference_expression(oracle):
+    """The reference's is_canonical deviates from the libsodium routine it cites (0xED - (1 - b0) instead of 0xED - 1 - b0):
+    oracle and big-int model must answer what the reference answers, for every low byte, through verify's status codes."""
+    assert [_ref_is_canonical(bytes([b0]) + b"\xff" * 30 + b"\x7f") for b0 in (0x13, 0x14, 0xec, 0xed)] == [True, False, False, False]
+    lines = list(golden_lines())
+    _, pub, msg, sig = lines[0]
+    for b0 in range(256):
+        for top in (0x7f, 0xff):
+            for mid in (0xff, 0xfe):
+                enc = bytes([b0]) + bytes([mid]) + b"\xff" * 29 + bytes([top])
+                can = _ref_is_canonical(enc)
+                assert M.point_is_canonical(enc) == can, enc.hex()
+                # flavor 0 checks the canonical form of the public key before anything else about it (eddsa_sig.rs:176-190)
+                st = oracle.verify(0, enc, msg, sig)
+                assert (st == 6) == (not can), (enc.hex(), st)
+                st_r = oracle.verify(0, pub, msg, enc + sig[32:])
+                assert (st_r == 3) == (not can), (enc.hex(), st_r)
+                if b0 % 16 == 4:
+                    for flavor in (0, 1):
+                        assert M.verify(flavor, enc, msg, sig) == oracle.verify(flavor, enc, msg, sig)
+                        assert M.verify(flavor, pub, msg, enc + sig[32:]) == oracle.verify(flavor, pub, msg, enc + sig[32:])

@@ -55,26 +55,26 @@ __device__ __forceinline__ unsigned long long memrealtime() {
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
 // ---- 64-bit accumulator kernels ----
-#define DEF_K64(NAME, ASMSTR, CLOB)                                                             \
+#define DEF_K64(NAME, ASMSTR, ...)                                                             \
 __global__ void NAME(int iters, unsigned seed, Stamp* stamps, unsigned* sink) {                 \
   KERNEL_PROLOGUE(unsigned long long)                                                           \
   for (int it = 0; it < iters; ++it) {                                                          \
     _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                                        \
       _Pragma("unroll") for (int c = 0; c < CHAINS; ++c)                                        \
-        asm volatile(ASMSTR : "+v"(acc[c]) : "v"(a), "v"(b) : CLOB);                            \
+        asm volatile(ASMSTR : "+v"(acc[c]) : "v"(a), "v"(b) : __VA_ARGS__);                            \
     }                                                                                           \
   }                                                                                             \
   KERNEL_EPILOGUE(unsigned long long)                                                           \
 }
 
 // ---- 32-bit accumulator kernels ----
-#define DEF_K32(NAME, ASMSTR, CLOB)                                                             \
+#define DEF_K32(NAME, ASMSTR, ...)                                                             \
 __global__ void NAME(int iters, unsigned seed, Stamp* stamps, unsigned* sink) {                 \
   KERNEL_PROLOGUE(unsigned)                                                                     \
   for (int it = 0; it < iters; ++it) {                                                          \
     _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                                        \
       _Pragma("unroll") for (int c = 0; c < CHAINS; ++c)                                        \
-        asm volatile(ASMSTR : "+v"(acc[c]) : "v"(a), "v"(b) : CLOB);                            \
+        asm volatile(ASMSTR : "+v"(acc[c]) : "v"(a), "v"(b) : __VA_ARGS__);                            \
     }                                                                                           \
   }                                                                                             \
   KERNEL_EPILOGUE(unsigned)                                                                     \
@@ -82,6 +82,7 @@ __global__ void NAME(int iters, unsigned seed, Stamp* stamps, unsigned* sink) { 
 
 DEF_K64(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0", "vcc")
 DEF_K64(k_mad_i64_i32, "v_mad_i64_i32 %0, vcc, %1, %2, %0", "vcc")
+DEF_K64(k_mad_u64_u32_sgprcarry, "v_mad_u64_u32 %0, s[20:21], %1, %2, %0", "s20", "s21")
 DEF_K64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 1, %0", "memory")
 DEF_K64(k_lshrrev_b64, "v_lshrrev_b64 %0, 3, %0", "memory")
 DEF_K64(k_fma_f64, "v_fma_f64 %0, %0, %0, %0", "memory")
@@ -146,6 +147,51 @@ __global__ void k_mix_femul(int iters, unsigned seed, Stamp* stamps, unsigned* s
   KERNEL_EPILOGUE(unsigned long long)
 }
 
+// the same multiply-add on operands shaped like field limbs (26 significant bits): the clock the chip holds is power
+// limited, so the data matters (MI355X_MICROARCH.md, DVFS give-back items 1 and 7)
+#define DEF_K64_LIMB(NAME, ASMSTR)                                                                \
+__global__ void NAME(int iters, unsigned seed, Stamp* stamps, unsigned* sink) {                 \
+  KERNEL_PROLOGUE(unsigned long long)                                                           \
+  a &= 0x3ffffffu; b &= 0x3ffffffu;                                                             \
+  for (int c = 0; c < CHAINS; ++c) acc[c] &= 0xffffffffffffull;                                 \
+  for (int it = 0; it < iters; ++it) {                                                          \
+    _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                                        \
+      _Pragma("unroll") for (int c = 0; c < CHAINS; ++c)                                        \
+        asm volatile(ASMSTR : "+v"(acc[c]) : "v"(a), "v"(b) : "vcc");                           \
+    }                                                                                           \
+    _Pragma("unroll") for (int c = 0; c < CHAINS; ++c) acc[c] &= 0xffffffffffffull;             \
+  }                                                                                             \
+  KERNEL_EPILOGUE(unsigned long long)                                                           \
+}
+DEF_K64_LIMB(k_mad_u64_u32_limbs, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
+DEF_K64_LIMB(k_mad_i64_i32_limbs, "v_mad_i64_i32 %0, vcc, %1, %2, %0")
+
+// one field-multiplication column as the kernels execute it: 10 chained mads, one mask, one 64-bit shift
+__global__ void k_mix_column(int iters, unsigned seed, Stamp* stamps, unsigned* sink) {
+  KERNEL_PROLOGUE(unsigned long long)
+  a &= 0x3ffffffu; b &= 0x3ffffffu;
+  unsigned r = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) {
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+                     "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+                     "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+                     "v_mad_u64_u32 %0, vcc, %1, %2, %0"
+                     : "+v"(acc[c]), "+v"(a), "+v"(b) :: "vcc");
+        r = (unsigned)acc[c] & 0x3ffffffu;
+        acc[c] >>= 26;
+        asm volatile("" : "+v"(r), "+v"(acc[c]));
+        b ^= r & 1u;
+      }
+    }
+  }
+  acc[0] += r;
+  KERNEL_EPILOGUE(unsigned long long)
+}
+
 // LDS uniform-address (broadcast) b128 read throughput
 __global__ void k_lds_bcast_b128(int iters, unsigned seed, Stamp* stamps, unsigned* sink) {
   __shared__ uint4 tbl[1024];
@@ -191,6 +237,8 @@ int main(int argc, char** argv) {
     {"v_cndmask_b32_e64(sgpr)", k_cndmask_e64_sgpr, 1}, {"v_cmp+v_cndmask(vcc)", k_cmp_cndmask, 2}, {"v_cmp_e64+v_cndmask_e64", k_cmp_e64_cndmask, 2},
     {"v_and_b32", k_and_b32, 1}, {"v_or_b32", k_or_b32, 1}, {"v_bfi_b32", k_bfi_b32, 1}, {"v_sub_u32", k_sub_u32, 1}, {"v_lshlrev_b32", k_lshlrev_b32, 1},
     {"ds_bpermute_b32(nowait)", k_bpermute_nowait, 1},
+    {"v_mad_u64_u32(sgpr carry-out)", k_mad_u64_u32_sgprcarry, 1}, {"v_mad_u64_u32(26-bit operands)", k_mad_u64_u32_limbs, 1},
+    {"v_mad_i64_i32(26-bit operands)", k_mad_i64_i32_limbs, 1}, {"mix_column(10mad+and+lshr64)", k_mix_column, 12},
     {"mix_femul(8mad+4simple)", k_mix_femul, 1}, {"lds_bcast_b128(+xor3+add)", k_lds_bcast_b128, 1},
   };
   const char* only = argc > 1 ? argv[1] : nullptr;
@@ -222,12 +270,17 @@ int main(int argc, char** argv) {
       double med_cyc = cyc[nw / 2], med_mhz = mhz[nw / 2];
       double instr_per_wave = (double)iters * UNROLL * CHAINS * e.instr_per_group;
       if (!strcmp(e.name, "mix_femul(8mad+4simple)")) instr_per_wave = (double)iters * UNROLL * (CHAINS + 4);
-      // cycles one SIMD spends per wave-instruction (wps waves share the SIMD)
-      double cyc_per_winstr_simd = med_cyc / (instr_per_wave * wps);
+      // Cycles one SIMD spends per wave-instruction.  The waves of a SIMD are served oldest first, so they do not finish
+      // together and the MEDIAN wave's lifetime understates the time the SIMD was busy (round 1 divided the median by the
+      // wave count and got figures that disagreed with the chip-wide rate at 4 and 8 waves).  The self-consistent figure is
+      // the kernel's wall time in shader cycles over the wave-instructions one SIMD issued:
+      //   cyc = ms x shader clock / (instructions per wave x waves per SIMD),  and  chip rate = SIMDs x 64 x clock / cyc.
+      double max_cyc = cyc[nw - 1];
+      double cyc_wall = ms * 1e-3 * med_mhz * 1e6 / (instr_per_wave * wps);
       double total_lane_ops = instr_per_wave * 64.0 * nw;
       double gops = total_lane_ops / (ms * 1e-3) / 1e9;
-      printf("{\"instr\": \"%s\", \"waves_per_simd\": %d, \"cyc_per_waveinstr_per_simd\": %.3f, \"wave_cycles\": %.0f, \"shader_mhz\": %.0f, \"ms\": %.4f, \"chip_Glaneops_s\": %.1f}\n",
-             e.name, wps, cyc_per_winstr_simd, med_cyc, med_mhz, ms, gops);
+      printf("{\"instr\": \"%s\", \"waves_per_simd\": %d, \"cyc_per_waveinstr_per_simd\": %.3f, \"cyc_from_longest_wave\": %.3f, \"median_wave_cycles\": %.0f, \"longest_wave_cycles\": %.0f, \"shader_mhz\": %.0f, \"ms\": %.4f, \"chip_Glaneops_s\": %.1f}\n",
+             e.name, wps, cyc_wall, max_cyc / (instr_per_wave * wps), med_cyc, max_cyc, med_mhz, ms, gops);
       fflush(stdout);
     }
   }
