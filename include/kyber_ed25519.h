@@ -17,9 +17,13 @@
  *              |even limb| <= 2^25, |odd limb| <= 2^24 — inside the reference's fe_mul/fe_add input
  *              bounds, so a returned point can be fed straight back into the CPU arithmetic.
  *   return     0 = ok; negative = KYB_E_* (nothing is written on error except where noted).
- *   threading  every call may be made from any thread: host-pointer calls are serialised on the engine's own
- *              stream; device-pointer calls on different streams may overlap on the GPU (each stream gets its
- *              own scratch, at most 8 streams), their launch bookkeeping is serialised internally.
+ *   threading  every call may be made from any thread.  Calls act on the calling thread's CONTEXT (kyb_ctx_set_current;
+ *              default = the context kyb_init made) and make that context's device current first.  Host-pointer calls
+ *              on one context are serialised on its own streams (use one context per concurrent caller, or per GPU);
+ *              device-pointer calls on different streams may overlap on the GPU — each stream gets its own scratch
+ *              slot (up to 32 streams registered at a time; kyb_stream_release frees one, beyond 32 the least recently
+ *              used slot is recycled after its last launch); their launch bookkeeping is serialised per context.
+ *              kyb_set_option / kyb_profile_* are safe against concurrent launches.
  *   memory     the caller owns every buffer; the library keeps no pointer after return.
  *
  * Two flavours of every batch call:
@@ -59,23 +63,63 @@ extern "C" {
 
 /* Version of this interface: bumped on any change of an existing signature, of KYB_BASE_TABLE_BYTES or of a status /
  * error code (a binding checks it once after loading the library).  Callable before kyb_init. */
-#define KYB_ABI_VERSION 1
+#define KYB_ABI_VERSION 2
 int kyb_abi_version(void);
 
 /* ---- lifecycle -------------------------------------------------------------------------------- */
-/* Bind this process to HIP device `device`, allocate the workspace, build the base-point table on
- * the GPU.  Idempotent for the same device.  (One process per GPU: see DESIGN.md §multi-GPU.) */
+/* Create this process's DEFAULT context on HIP device `device`: streams, table image built on the GPU.  Idempotent for
+ * the same device; a second device is refused here — more GPUs from one process go through kyb_ctx_create /
+ * kyb_group_create below (or one process per GPU, as bench.py does: DESIGN.md §multi-GPU). */
 int kyb_init(int device);
 /* Same, but leave the base table empty: the caller fills it with kyb_base_table_import_dev after
  * receiving rank 0's image over RCCL (torch.distributed.broadcast). */
 int kyb_init_no_table(int device);
-void kyb_shutdown(void);
+void kyb_shutdown(void);           /* destroys the default context */
 /* human-readable text of the last failure on the calling thread ("" if none) */
 const char* kyb_last_error(void);
 /* device name, CU count, bytes of workspace; any pointer may be NULL */
 int kyb_device_info(char* name, size_t name_cap, int* compute_units, size_t* workspace_bytes);
 /* block until everything queued on `stream` (NULL = engine stream) has finished */
 int kyb_sync(void* stream);
+/* Give back the scratch the context keeps for a caller stream (staging buffers, side stream, events).  Call it before
+ * destroying a stream that carried kyb_*_dev calls; waits for the stream's last engine launch.  Unknown streams are
+ * ignored. */
+int kyb_stream_release(void* stream);
+
+/* ---- explicit contexts: several GPUs (or several independent pipelines on one GPU) in one process ---------------- */
+/* A context owns everything the calls need on one device: two streams, per-stream scratch, staging and bounce buffers,
+ * the table image, options, profiling state.  Every kyb_* call acts on the calling thread's current context.
+ *   kyb_ctx_create       new context on `device` (build_table = 0: import an image later); any number per device
+ *   kyb_ctx_set_current  bind it to the calling thread (NULL = back to the default context of kyb_init)
+ *   kyb_ctx_destroy      no thread may still be using it */
+typedef struct kyb_ctx kyb_ctx;
+int kyb_ctx_create(int device, int build_table, kyb_ctx** out);
+int kyb_ctx_destroy(kyb_ctx* ctx);
+int kyb_ctx_set_current(kyb_ctx* ctx);
+kyb_ctx* kyb_ctx_get_current(void);
+int kyb_ctx_device(const kyb_ctx* ctx);
+
+/* ---- groups: SURVEY.md §8(e) in one process ------------------------------------------------------------------- */
+/* kyb_group_create(devices, n): one context and (per call) one host thread per listed device.  The table image is built
+ * on devices[0] and moved to the others with one ncclBroadcast (librccl over xGMI, loaded on demand; falls back to a
+ * host copy when RCCL is unavailable or the list repeats a device) and validated against its embedded checksum.
+ * kyb_group_table_transport reports which: "rccl", "host-copy" or "none" (one rank).
+ * The kyb_group_*_batch calls shard a host-pointer batch: rank r takes items [floor(n r / G), floor(n (r+1) / G)) of
+ * every array and runs the ordinary call on its own device; there is no data-path collective.  For device-resident
+ * shards use kyb_group_ctx(g, r) + kyb_ctx_set_current and the kyb_*_dev calls from one thread per rank. */
+typedef struct kyb_group kyb_group;
+int kyb_group_create(const int* devices, int n, kyb_group** out);
+void kyb_group_destroy(kyb_group* g);
+int kyb_group_size(const kyb_group* g);
+kyb_ctx* kyb_group_ctx(kyb_group* g, int rank);
+const char* kyb_group_table_transport(const kyb_group* g);
+int kyb_group_mul_base_batch(kyb_group* g, const uint8_t* scalars, size_t n, uint8_t* out_enc, int32_t* out_ext);
+int kyb_group_mul_batch(kyb_group* g, const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, size_t n,
+                        uint8_t* out_enc, int32_t* out_ext, uint8_t* ok);
+int kyb_group_schnorr_sign_batch(kyb_group* g, const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* msg_off,
+                                 size_t n, uint8_t* sig);
+int kyb_group_verify_batch(kyb_group* g, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* msg_off, const uint8_t* sigs,
+                           size_t n, int flavor, uint8_t* status);
 
 /* ---- pinned host memory for the host-pointer API ------------------------------------------------ */
 /* The host-pointer calls accept any host memory.  From pageable memory the copies run at ~7 GB/s and
@@ -86,9 +130,13 @@ void* kyb_host_alloc(size_t bytes);
 void kyb_host_free(void* p);
 
 /* ---- base-point table (multi-GPU init) -------------------------------------------------------- */
+/* The image carries a 64-bit checksum of itself (in the two padding words of radix-16 entry (0, 0)); both import calls
+ * recompute it on the GPU and refuse an image that does not match (KYB_E_BAD_ARG, the table stays unusable): a truncated
+ * or corrupted broadcast cannot silently produce wrong points. */
 int kyb_base_table_export_dev(void* dst_dev, void* stream);        /* engine table -> dst (device)  */
 int kyb_base_table_import_dev(const void* src_dev, void* stream);  /* src (device) -> engine table  */
 int kyb_base_table_export(uint8_t* dst_host);                      /* engine table -> host buffer   */
+int kyb_base_table_import(const uint8_t* src_host);                /* host buffer -> engine table   */
 
 /* ---- Point::mul(s, None): fixed base — ge_scalar_mult_base, ge.rs:442-486 --------------------- */
 /* out_enc (n x 32) and/or out_ext (n x 40 int32, Z = 1) may be NULL, not both. */
@@ -97,6 +145,10 @@ int kyb_mul_base_batch_dev(const uint8_t* scalars, size_t n, uint8_t* out_enc, i
 
 /* ---- Point::mul(s, Some(P)): variable base — ge_scalar_mult, ge.rs:508-568 -------------------- */
 /* Exactly one of pts_enc (n x 32, decoded on the GPU as unmarshal_binary does) / pts_ext (n x 40).
+ * pts_ext must hold points ON the curve (what kyb_decode_batch, any kyb_* output or the reference's own arithmetic
+ * produce): the default kernel is an x-only Montgomery ladder that never reads T and relies on the curve equation, so
+ * for off-curve limbs — where the reference's formulas return some deterministic garbage — the result here is
+ * unspecified (the other items of the batch are unaffected).
  * ok (n bytes, may be NULL unless pts_enc is given): 1 = point decoded, 0 = invalid encoding (the
  * outputs of that item are then the encoding of the neutral element / unspecified limbs). */
 int kyb_mul_batch(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, size_t n,
@@ -109,6 +161,8 @@ int kyb_add_batch(const int32_t* a_ext, const int32_t* b_ext, size_t n, int32_t*
 int kyb_add_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, int32_t* out_ext, int subtract, void* stream);
 
 /* ---- marshal_binary / unmarshal_binary, point.rs:35-51 ---------------------------------------- */
+/* encode: one field inversion per 8 points (Montgomery's trick, k_encode_batched) instead of the reference's one per
+ * point (ge.rs:112-122); the encodings are identical. */
 int kyb_encode_batch(const int32_t* pts_ext, size_t n, uint8_t* out_enc);
 int kyb_encode_batch_dev(const int32_t* pts_ext, size_t n, uint8_t* out_enc, void* stream);
 /* ok[i] = 1 iff enc[i] decodes (ge.rs:124-179: non-canonical y accepted, x = 0 with sign accepted) */
@@ -209,13 +263,19 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
 /* kernel variant selection: key is e.g. "mul.select" / "mul_base.select"; returns
  * KYB_E_BAD_ARG for unknown keys or values.  Defaults are the fastest measured variants.
  *   mul.algo          1 Montgomery ladder + y-recovery (table-free, default), 0 windowed table 1P..8P per lane
- *   mul.ladder_waves  2..4: waves per SIMD the ladder kernel's register allocation must allow
+ *   mul.ladder_waves  2..4 (default 3): waves per SIMD the ladder kernel's register allocation must allow
  *   mul.select        0 v_cndmask merge, 1 and/or merge of the windowed kernel's table scan
- *   mul_base.select   0 LDS broadcast scan, 1 ds_bpermute selection
- *   mul_base.radix    32: 52-window kernel (1024-thread workgroups) for batches >= finish.min_items; 16: 64 windows
- *   mul_base.block    256 | 512 threads per workgroup of the radix-16 fixed-base kernel
- *   finish.batched    1: results stay projective and one inversion serves 8 items (k_finish)
- *   finish.min_items  smallest batch that takes the batched finish (default 4096) */
+ *   mul_base.radix    64 (default): 43-window kernel, the table fills a CU's LDS; 32: 52 windows; 16: 64 windows
+ *   mul_base.select   0 LDS broadcast scan, 1 ds_bpermute selection                       [radix-16 kernel]
+ *   mul_base.block    256 | 512 threads per workgroup                                     [radix-16 kernel]
+ *   mul_base.block64  1024 | 512 threads per workgroup of the radix-64 kernel on full batches
+ *   mul_base.small_chunks  radix-64 kernel: 256-thread workgroups up to this many chunks per CU (default 2)
+ *   finish.batched    1 (default): results stay projective and one inversion serves 8 items (k_finish)
+ *   finish.min_items  smallest batch that takes the batched finish / the radix-64, -32 kernels (default 1)
+ *   encode.batched    1 (default): kyb_encode_batch shares one inversion between 8 points; 0: one per point
+ *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder
+ *   host.copy_threads host threads that move pageable batches through the bounce buffers (0 = auto)
+ * Options belong to the calling thread's context. */
 int kyb_set_option(const char* key, int value);
 int kyb_get_option(const char* key, int* value);
 /* per-launch kernel timing for benchmarks: after kyb_profile_begin(m) the next m kernel launches are

@@ -1,7 +1,7 @@
 """kyber-rs_amd — MI355X-native batched Ed25519 scalar-multiplication engine for kyber-rs.
 
 This package is the thin Python harness over the C ABI declared in include/kyber_ed25519.h
-(implemented by csrc/kernels.hip -> libkyber_ed25519_hip.so).  It exists for tests, bench.py and
+(implemented by csrc/engine.hip + csrc/kernels_*.hip -> libkyber_ed25519_hip.so).  It exists for tests, bench.py and
 multi-GPU bring-up over torch.distributed; the product boundary is the C ABI itself (the Rust shim in
 rust/ and the C++ mirror in host/ bind the same symbols).
 
@@ -21,15 +21,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libkyber_ed25519_hip.so"
 LIB_PATH = os.environ.get("KYB_HIP_LIB") or os.path.join(_HERE, LIB_NAME)   # KYB_HIP_LIB: A/B builds of the same ABI
 BASE_TABLE_BYTES = 335232
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 KYB_OK = 0
 ERRORS = {-1: "KYB_E_NOT_INIT", -2: "KYB_E_BAD_ARG", -3: "KYB_E_NO_DEVICE", -4: "KYB_E_HIP", -5: "KYB_E_NOMEM"}
 
 # every symbol include/kyber_ed25519.h declares (tests/test_abi_symbols.py checks header <-> library)
 ABI_SYMBOLS = [
-    "kyb_abi_version", "kyb_init", "kyb_init_no_table", "kyb_shutdown", "kyb_last_error", "kyb_device_info", "kyb_sync",
-    "kyb_base_table_export_dev", "kyb_base_table_import_dev", "kyb_base_table_export",
+    "kyb_abi_version", "kyb_init", "kyb_init_no_table", "kyb_shutdown", "kyb_last_error", "kyb_device_info", "kyb_sync", "kyb_stream_release",
+    "kyb_ctx_create", "kyb_ctx_destroy", "kyb_ctx_set_current", "kyb_ctx_get_current", "kyb_ctx_device",
+    "kyb_group_create", "kyb_group_destroy", "kyb_group_size", "kyb_group_ctx", "kyb_group_table_transport",
+    "kyb_group_mul_base_batch", "kyb_group_mul_batch", "kyb_group_schnorr_sign_batch", "kyb_group_verify_batch",
+    "kyb_base_table_export_dev", "kyb_base_table_import_dev", "kyb_base_table_export", "kyb_base_table_import",
     "kyb_mul_base_batch", "kyb_mul_base_batch_dev", "kyb_mul_batch", "kyb_mul_batch_dev",
     "kyb_add_batch", "kyb_add_batch_dev", "kyb_encode_batch", "kyb_encode_batch_dev",
     "kyb_decode_batch", "kyb_decode_batch_dev", "kyb_schnorr_sign_batch", "kyb_schnorr_sign_batch_dev",
@@ -75,6 +78,25 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_last_error.restype = ctypes.c_char_p
     lib.kyb_device_info.argtypes = [ctypes.c_char_p, sz, ctypes.POINTER(i32), ctypes.POINTER(sz)]
     lib.kyb_sync.argtypes = [vp]
+    lib.kyb_stream_release.argtypes = [vp]
+    lib.kyb_ctx_create.argtypes = [i32, i32, ctypes.POINTER(vp)]
+    lib.kyb_ctx_destroy.argtypes = [vp]
+    lib.kyb_ctx_set_current.argtypes = [vp]
+    lib.kyb_ctx_get_current.restype = vp
+    lib.kyb_ctx_device.argtypes = [vp]
+    lib.kyb_group_create.argtypes = [ctypes.POINTER(i32), i32, ctypes.POINTER(vp)]
+    lib.kyb_group_destroy.argtypes = [vp]
+    lib.kyb_group_destroy.restype = None
+    lib.kyb_group_size.argtypes = [vp]
+    lib.kyb_group_ctx.argtypes = [vp, i32]
+    lib.kyb_group_ctx.restype = vp
+    lib.kyb_group_table_transport.argtypes = [vp]
+    lib.kyb_group_table_transport.restype = ctypes.c_char_p
+    lib.kyb_group_mul_base_batch.argtypes = [vp, vp, sz, vp, vp]
+    lib.kyb_group_mul_batch.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
+    lib.kyb_group_schnorr_sign_batch.argtypes = [vp, vp, vp, vp, vp, sz, vp]
+    lib.kyb_group_verify_batch.argtypes = [vp, vp, vp, vp, vp, sz, i32, vp]
+    lib.kyb_base_table_import.argtypes = [vp]
     lib.kyb_base_table_export_dev.argtypes = [vp, vp]
     lib.kyb_base_table_import_dev.argtypes = [vp, vp]
     lib.kyb_base_table_export.argtypes = [vp]
@@ -119,7 +141,8 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_kernel_name.argtypes = [i32]
     lib.kyb_kernel_name.restype = ctypes.c_char_p
     for name in ABI_SYMBOLS:
-        if name not in ("kyb_shutdown", "kyb_last_error", "kyb_kernel_name", "kyb_host_alloc", "kyb_host_free"):
+        if name not in ("kyb_shutdown", "kyb_last_error", "kyb_kernel_name", "kyb_host_alloc", "kyb_host_free", "kyb_ctx_get_current",
+                        "kyb_group_destroy", "kyb_group_ctx", "kyb_group_table_transport"):
             getattr(lib, name).restype = i32
     if lib.kyb_abi_version() != ABI_VERSION:
         raise KyberHipError(f"{LIB_PATH} implements ABI version {lib.kyb_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
@@ -143,14 +166,76 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
-class Engine:
-    """One engine per process, bound to one GPU (one process per GPU)."""
+def _rows(a: Optional[np.ndarray], n: int, name: str) -> None:
+    """every per-item array must hold exactly n records: a shorter one would make the C side read past its buffer"""
+    if a is not None and a.shape[0] != n:
+        raise ValueError(f"{name} holds {a.shape[0]} records, expected {n}")
 
-    def __init__(self, device: int = 0, build_table: bool = True):
-        self.lib = load_library()
-        rc = self.lib.kyb_init(device) if build_table else self.lib.kyb_init_no_table(device)
-        _check(rc, "kyb_init")
+
+def _msg_blob(msgs: Sequence[bytes], n: int):
+    """concatenated messages + the n+1 offsets of the C ABI (uint32: the blob must stay below 4 GiB)"""
+    if len(msgs) != n:
+        raise ValueError(f"{len(msgs)} messages for {n} items")
+    total = sum(len(m) for m in msgs)
+    if total >= 1 << 32:
+        raise ValueError("message blob of 4 GiB or more: msg_off is uint32")
+    off = np.zeros(n + 1, dtype=np.uint32)
+    if n:
+        off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64).astype(np.uint32)
+    blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()
+    return blob, off
+
+
+class _CtxLib:
+    """the ctypes library seen through one explicit context: every call first makes that context current on the calling
+    thread (kyb_ctx_set_current is thread-local and costs nanoseconds)"""
+
+    def __init__(self, lib, ctx):
+        object.__setattr__(self, "_lib", lib)
+        object.__setattr__(self, "_ctx", ctx)
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        lib, ctx = self._lib, self._ctx
+
+        def call(*args):
+            lib.kyb_ctx_set_current(ctx)
+            return fn(*args)
+        return call
+
+
+class Engine:
+    """One engine = one context of the C ABI.  Engine(device) is the process's default context (kyb_init: one process per
+    GPU, bench.py); Engine(device, private=True) is an additional context of its own (kyb_ctx_create) — several may live
+    in one process, on the same or on different GPUs."""
+
+    def __init__(self, device: int = 0, build_table: bool = True, private: bool = False, _ctx=None):
+        lib = load_library()
         self.device = device
+        self.ctx = None
+        if _ctx is not None:                 # a context owned by a Group
+            self.ctx, self._owned = _ctx, False
+            self.lib = _CtxLib(lib, ctypes.c_void_p(_ctx))
+        elif private:
+            h = ctypes.c_void_p()
+            _check(lib.kyb_ctx_create(device, 1 if build_table else 0, ctypes.byref(h)), "kyb_ctx_create")
+            self.ctx, self._owned = h.value, True
+            self.lib = _CtxLib(lib, ctypes.c_void_p(h.value))
+        else:
+            self.lib = _CtxLib(lib, None)    # None = the default context, whatever this thread had made current before
+            rc = lib.kyb_init(device) if build_table else lib.kyb_init_no_table(device)
+            _check(rc, "kyb_init")
+
+    def close(self) -> None:
+        """destroy a private context (the default one goes with shutdown())"""
+        if self.ctx is not None and getattr(self, "_owned", False):
+            raw = load_library()
+            raw.kyb_ctx_set_current(None)
+            _check(raw.kyb_ctx_destroy(ctypes.c_void_p(self.ctx)), "kyb_ctx_destroy")
+            self.ctx = None
+
+    def stream_release(self, stream: int) -> None:
+        _check(self.lib.kyb_stream_release(ctypes.c_void_p(stream)), "kyb_stream_release")
 
     # ---- info / options -------------------------------------------------------------------------
     def device_info(self):
@@ -219,6 +304,7 @@ class Engine:
         n = s.shape[0]
         pe = None if pts_enc is None else _u8(pts_enc, 32, "pts_enc")
         px = None if pts_ext is None else np.ascontiguousarray(pts_ext, dtype=np.int32).reshape(-1, 40)
+        _rows(pe, n, "pts_enc"); _rows(px, n, "pts_ext")
         enc = np.empty((n, 32), dtype=np.uint8)
         ext = np.empty((n, 40), dtype=np.int32) if want_ext else None
         ok = np.empty((n,), dtype=np.uint8) if (want_ok or pe is not None) else None
@@ -233,6 +319,7 @@ class Engine:
     def add(self, a_ext, b_ext, subtract: bool = False):
         a = np.ascontiguousarray(a_ext, dtype=np.int32).reshape(-1, 40)
         b = np.ascontiguousarray(b_ext, dtype=np.int32).reshape(-1, 40)
+        _rows(b, a.shape[0], "b_ext")
         out = np.empty_like(a)
         _check(self.lib.kyb_add_batch(_ptr(a), _ptr(b), a.shape[0], _ptr(out), 1 if subtract else 0), "kyb_add_batch")
         return out
@@ -254,14 +341,14 @@ class Engine:
         """schnorr::sign with caller-supplied nonces; pubs = the stored public keys enc(x*B) (then A is not recomputed)"""
         xs, ks = _u8(x, 32, "x"), _u8(k, 32, "k")
         n = xs.shape[0]
-        off = np.zeros(n + 1, dtype=np.uint32)
-        off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64).astype(np.uint32)
-        blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()
+        _rows(ks, n, "k")
+        blob, off = _msg_blob(msgs, n)
         sig = np.empty((n, 64), dtype=np.uint8)
         if pubs is None:
             _check(self.lib.kyb_schnorr_sign_batch(_ptr(xs), _ptr(ks), _ptr(blob), _ptr(off), n, _ptr(sig)), "kyb_schnorr_sign_batch")
         else:
             ps = _u8(pubs, 32, "pubs")
+            _rows(ps, n, "pubs")
             _check(self.lib.kyb_schnorr_sign_keyed_batch(_ptr(xs), _ptr(ps), _ptr(ks), _ptr(blob), _ptr(off), n, _ptr(sig)), "kyb_schnorr_sign_keyed_batch")
         return sig
 
@@ -270,12 +357,11 @@ class Engine:
         objects already hold (then only R is computed)"""
         sd = _u8(seeds, 32, "seeds")
         n = sd.shape[0]
-        off = np.zeros(n + 1, dtype=np.uint32)
-        off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64).astype(np.uint32)
-        blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()
+        blob, off = _msg_blob(msgs, n)
         sig = np.empty((n, 64), dtype=np.uint8)
         if pubs is not None:
             ps = _u8(pubs, 32, "pubs")
+            _rows(ps, n, "pubs")
             _check(self.lib.kyb_eddsa_sign_keyed_batch(_ptr(sd), _ptr(ps), _ptr(blob), _ptr(off), n, _ptr(sig)), "kyb_eddsa_sign_keyed_batch")
             return (sig, ps) if want_pub else sig
         pub = np.empty((n, 32), dtype=np.uint8) if want_pub else None
@@ -286,9 +372,8 @@ class Engine:
         """status per item (0 = valid); flavor 0 = eddsa::verify_with_checks order, 1 = schnorr order"""
         ps, ss = _u8(pubs, 32, "pubs"), _u8(sigs, 64, "sigs")
         n = ps.shape[0]
-        off = np.zeros(n + 1, dtype=np.uint32)
-        off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64).astype(np.uint32)
-        blob = np.frombuffer(b"".join(msgs) + b"\0", dtype=np.uint8).copy()
+        _rows(ss, n, "sigs")
+        blob, off = _msg_blob(msgs, n)
         st = np.empty((n,), dtype=np.uint8)
         _check(self.lib.kyb_verify_batch(_ptr(ps), _ptr(blob), _ptr(off), _ptr(ss), n, flavor, _ptr(st)), "kyb_verify_batch")
         return st
@@ -367,6 +452,7 @@ class Engine:
     def equal(self, a_ext, b_ext) -> np.ndarray:
         a = np.ascontiguousarray(a_ext, dtype=np.int32).reshape(-1, 40)
         b = np.ascontiguousarray(b_ext, dtype=np.int32).reshape(-1, 40)
+        _rows(b, a.shape[0], "b_ext")
         eq = np.empty((a.shape[0],), dtype=np.uint8)
         _check(self.lib.kyb_equal_batch(_ptr(a), _ptr(b), a.shape[0], _ptr(eq)), "kyb_equal_batch")
         return eq
@@ -375,6 +461,12 @@ class Engine:
         t = np.empty(BASE_TABLE_BYTES, dtype=np.uint8)
         _check(self.lib.kyb_base_table_export(_ptr(t)), "kyb_base_table_export")
         return t
+
+    def base_table_import(self, image) -> None:
+        t = np.ascontiguousarray(image, dtype=np.uint8).reshape(-1)
+        if t.shape[0] != BASE_TABLE_BYTES:
+            raise ValueError("table image has the wrong size")
+        _check(self.lib.kyb_base_table_import(_ptr(t)), "kyb_base_table_import")
 
     # ---- device-pointer API (torch tensors resident in HBM; asynchronous on `stream`) -------------
     @staticmethod
@@ -421,3 +513,62 @@ class Engine:
 
     def base_table_import_dev(self, src, stream: int = 0) -> None:
         _check(self.lib.kyb_base_table_import_dev(self._dp(src), ctypes.c_void_p(stream)), "kyb_base_table_import_dev")
+
+
+class Group:
+    """kyb_group: one process driving several GPUs (one context + one host thread per device, shards [rN/G, (r+1)N/G),
+    table image moved with ncclBroadcast / a host copy and validated by checksum).  `devices` may repeat a device
+    (several contexts on one GPU: how the single-GPU test box exercises the sharding)."""
+
+    def __init__(self, devices: Sequence[int]):
+        self.lib = load_library()
+        arr = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        _check(self.lib.kyb_group_create(arr, len(devices), ctypes.byref(h)), "kyb_group_create")
+        self.handle = h
+        self.size = self.lib.kyb_group_size(h)
+        self.transport = self.lib.kyb_group_table_transport(h).decode()
+
+    def engine(self, rank: int) -> Engine:
+        ctx = self.lib.kyb_group_ctx(self.handle, rank)
+        return Engine(self.lib.kyb_ctx_device(ctypes.c_void_p(ctx)), _ctx=ctx)
+
+    def close(self) -> None:
+        if self.handle is not None:
+            self.lib.kyb_group_destroy(self.handle)
+            self.handle = None
+
+    def mul_base(self, scalars):
+        s = _u8(scalars, 32, "scalars")
+        enc = np.empty((s.shape[0], 32), dtype=np.uint8)
+        _check(self.lib.kyb_group_mul_base_batch(self.handle, _ptr(s), s.shape[0], _ptr(enc), None), "kyb_group_mul_base_batch")
+        return enc
+
+    def mul(self, scalars, pts_ext=None, pts_enc=None):
+        s = _u8(scalars, 32, "scalars")
+        n = s.shape[0]
+        pe = None if pts_enc is None else _u8(pts_enc, 32, "pts_enc")
+        px = None if pts_ext is None else np.ascontiguousarray(pts_ext, dtype=np.int32).reshape(-1, 40)
+        _rows(pe, n, "pts_enc"); _rows(px, n, "pts_ext")
+        enc = np.empty((n, 32), dtype=np.uint8)
+        ok = np.empty((n,), dtype=np.uint8)
+        _check(self.lib.kyb_group_mul_batch(self.handle, _ptr(s), _ptr(pe), _ptr(px), n, _ptr(enc), None, _ptr(ok)), "kyb_group_mul_batch")
+        return enc, ok
+
+    def schnorr_sign(self, x, k, msgs: Sequence[bytes]):
+        xs, ks = _u8(x, 32, "x"), _u8(k, 32, "k")
+        n = xs.shape[0]
+        _rows(ks, n, "k")
+        blob, off = _msg_blob(msgs, n)
+        sig = np.empty((n, 64), dtype=np.uint8)
+        _check(self.lib.kyb_group_schnorr_sign_batch(self.handle, _ptr(xs), _ptr(ks), _ptr(blob), _ptr(off), n, _ptr(sig)), "kyb_group_schnorr_sign_batch")
+        return sig
+
+    def verify(self, pubs, msgs: Sequence[bytes], sigs, flavor: int = 0):
+        ps, ss = _u8(pubs, 32, "pubs"), _u8(sigs, 64, "sigs")
+        n = ps.shape[0]
+        _rows(ss, n, "sigs")
+        blob, off = _msg_blob(msgs, n)
+        st = np.empty((n,), dtype=np.uint8)
+        _check(self.lib.kyb_group_verify_batch(self.handle, _ptr(ps), _ptr(blob), _ptr(off), _ptr(ss), n, flavor, _ptr(st)), "kyb_group_verify_batch")
+        return st

@@ -1,0 +1,851 @@
+// MI355X (gfx950) batched Ed25519 engine: the host side behind libkyber_ed25519_hip.so.
+//
+// One scalar(-point pair) per lane, 64 lanes per wavefront, field elements as ten 32-bit VGPRs, products on
+// v_mad_u64_u32 (fe25519.h).  The path is integer-VALU bound: algorithmic HBM traffic is 64..224 B per operation
+// against ~2*10^5 multiply-adds, so there is no MFMA and no LDS tiling of operands; LDS holds only the shared
+// base-point table of the fixed-base kernels.  The kernels live in the kernels_*.hip units (map: launch.h); this
+// unit holds
+//   * contexts: one per (process, device) by default (kyb_init), any number through kyb_ctx_create — each with its own
+//     streams, per-stream scratch, staging buffers, table image, options and profiling state;
+//   * the launch sequences (which kernels a batch call runs, in which scratch);
+//   * the host-pointer pipeline (chunked two-stream H2D / kernels / D2H with page-locked bounce buffers);
+//   * multi-device groups: one context and one host thread per GPU, shards [rN/G, (r+1)N/G), the table image moved
+//     with ncclBroadcast (librccl, loaded on demand) — engine_group.inc;
+//   * the extern "C" entry points of include/kyber_ed25519.h — c_abi.inc.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/kyber_ed25519.h"
+#include "launch.h"
+#include "ge_scalarmult.h"      // table image geometry (KYB_BASE*_TABLE_WORDS, KYB_BT_IDX); plain C++ on the host
+#include "host_copy_pool.h"
+
+using namespace kyb;
+
+namespace {
+
+thread_local std::string g_err;
+
+// optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
+enum KernelId { KID_MUL, KID_MUL_BASE, KID_FINISH, KID_SIGN, KID_SIGN_HASH, KID_VERIFY_PREP, KID_VERIFY_FINAL, KID_POLY_EVAL, KID_MONT_PREP,
+                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_COUNT };
+const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval",
+                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched"};
+struct ProfRec { int id; hipEvent_t a, b; };
+struct Prof {
+  std::mutex mu;                  // begin / read / every ProfScope: callable from any thread
+  bool on = false;
+  int cap = 0, used = 0;
+  ProfRec* recs = nullptr;
+};
+
+// per-stream device scratch (two launches that overlap on different streams must not share it):
+//   ws       variable-base table workspace of the windowed kernel (fixed size, allocated on first use)
+//   proj     projective staging of the split finish (grows with the largest batch seen)
+//   enc      encodings of R and A between the stages of the split signing path, verification scratch
+//   aux      internal side stream (+ fork/join events) on which a small verification batch runs s*B next to the ladder
+//   ev_last  recorded behind the last launch that used the slot: a slot is only recycled / released / re-bound to a
+//            recycled stream handle after it (so a destroyed caller stream is never touched again)
+struct StreamRes {
+  hipStream_t stream = nullptr;
+  uint4* ws = nullptr; uint4* proj = nullptr; size_t proj_items = 0; uint8_t* enc = nullptr; size_t enc_bytes = 0;
+  hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_last = nullptr;
+  bool used = false, own = false;
+  uint64_t last_use = 0;
+};
+constexpr size_t MAX_STREAM_SLOTS = 32;
+
+struct Ctx {
+  bool ready = false;
+  int device = -1;
+  int cus = 0;
+  char name[128] = {0};
+  hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // second lane of the pipelined host-pointer path
+  uint32_t* table = nullptr;       // KYB_BASE_TABLE_BYTES: radix-16 image (65,536 B), radix-32 image (106,496 B), radix-64 image (163,200 B)
+  uint64_t* ck_dev = nullptr;      // 8 bytes: checksum of an imported table image
+  std::atomic<bool> table_ready{false};
+  std::vector<StreamRes*> res;
+  uint64_t use_clock = 0;
+  size_t ws_bytes = 0;
+  std::atomic<int> grid_mul{0};
+  uint8_t* stage = nullptr;       // device staging for the host-pointer API
+  size_t stage_bytes = 0;
+  uint8_t* stage2 = nullptr;      // staging of the second pipeline lane
+  size_t stage2_bytes = 0;
+  uint8_t* pin[2] = {nullptr, nullptr};   // page-locked bounce buffers of the two lanes (pageable caller memory)
+  size_t pin_bytes[2] = {0, 0};
+  kyb::CopyPool copy;
+  // kernel variant selection (kyb_set_option): atomics, so a set_option from one thread and launches from others do not race
+  std::atomic<int> opt_copy_threads{0};       // host threads that move pageable batches through the bounce buffers (0 = auto)
+  std::atomic<int> opt_mul_select{1};         // 0 cndmask, 1 and/or mask
+  std::atomic<int> opt_base_select{1};        // 0 LDS broadcast scan, 1 bpermute
+  std::atomic<int> opt_base_block{256};       // 256 (2 waves/SIMD) or 512 (4 waves/SIMD, 128 VGPRs)   [radix-16 kernel]
+  std::atomic<int> opt_base_radix{64};        // 64 / 32: 43- / 52-window kernel for batches >= finish.min_items; 16: always the 64-window kernel
+  std::atomic<int> opt_base_block64{1024};    // radix-64 kernel, full batches: 1024 (4 waves/SIMD, <= 128 VGPRs) or 512 (2 waves/SIMD)
+  std::atomic<int> opt_base_small_chunks{2};  // radix-64 kernel: 256-thread workgroups up to this many chunks per CU, 1024-thread beyond
+  std::atomic<int> opt_verify_overlap{1};     // small verification batches: s*B on a side stream next to the ladder
+  std::atomic<int> opt_mul_algo{1};           // 0 windowed table (ge.rs structure), 1 Montgomery ladder (table-free, 1.33x faster: profiles/r01/sweep_mul_algo.log)
+  std::atomic<int> opt_ladder_waves{3};       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
+  std::atomic<int> opt_finish{1};             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
+  std::atomic<int> opt_finish_min{1};         // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size; cross-check)
+  std::atomic<int> opt_encode_batched{1};     // kyb_encode_batch: 1 shared inversion per 8 points (k_encode_batched), 0 one inversion per point (k_encode)
+  std::mutex mu;          // host-pointer API: staging buffers + engine streams of this context
+  std::mutex launch_mu;   // every launch_* entry: per-stream scratch bookkeeping (calls from any thread, any stream)
+  Prof prof;
+};
+
+// ---- context registry --------------------------------------------------------------------------------
+std::mutex g_reg_mu;
+std::vector<Ctx*> g_all;               // every live context (default one included)
+Ctx* g_default = nullptr;              // created by kyb_init / kyb_init_no_table, destroyed by kyb_shutdown
+thread_local Ctx* tl_cur = nullptr;    // kyb_ctx_set_current; nullptr = the default context
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+  char buf[320];
+  if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+  else snprintf(buf, sizeof(buf), "%s", what);
+  g_err = buf;
+  return code;
+}
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(KYB_E_HIP, #x, e_); } while (0)
+#define LAUNCHCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(KYB_E_HIP, #x, e_); } while (0)
+
+Ctx* cur() {
+  Ctx* c = tl_cur;
+  if (c == nullptr) return g_default;
+  return c;
+}
+// Every entry point: the calling thread's context, made current on its device (HIP's current device is per thread and
+// starts at 0, so a call from a fresh thread on an engine bound to another GPU would otherwise allocate and launch on GPU 0).
+#define ENTER()                                                                                              \
+  Ctx* ctx_ = cur();                                                                                         \
+  if (ctx_ == nullptr || !ctx_->ready) return fail(KYB_E_NOT_INIT, "no initialised context: kyb_init / kyb_ctx_create has not succeeded"); \
+  Ctx& g = *ctx_;                                                                                            \
+  HIPCK(hipSetDevice(g.device))
+#define REQUIRE_TABLE() do { if (!g.table_ready.load()) return fail(KYB_E_NOT_INIT, "base table not built or imported"); } while (0)
+
+struct ProfScope {
+  Ctx& g; hipStream_t st; int slot;
+  ProfScope(Ctx& g_, hipStream_t s, int id) : g(g_), st(s), slot(-1) {
+    std::lock_guard<std::mutex> lk(g.prof.mu);
+    if (g.prof.on && g.prof.used < g.prof.cap) { slot = g.prof.used++; g.prof.recs[slot].id = id; (void)hipEventRecord(g.prof.recs[slot].a, st); }
+  }
+  ~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g.prof.mu);
+    if (slot < g.prof.cap) (void)hipEventRecord(g.prof.recs[slot].b, st);
+  }
+};
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline hipStream_t pick(Ctx& g, void* s) { return s ? reinterpret_cast<hipStream_t>(s) : g.stream; }
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// device buffers that held caller data (possibly private keys and nonces) are cleared before they go back to the runtime
+void wipe_free_dev(void* p, size_t bytes) {
+  if (!p) return;
+  (void)hipMemset(p, 0, bytes);
+  (void)hipFree(p);
+}
+
+int ensure_stage(Ctx& g, size_t bytes) {
+  if (bytes <= g.stage_bytes) return KYB_OK;
+  if (g.stage) { wipe_free_dev(g.stage, g.stage_bytes); g.stage = nullptr; g.stage_bytes = 0; }
+  size_t want = bytes + (bytes >> 2) + 4096;
+  hipError_t e = hipMalloc(&g.stage, want);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "staging allocation", e);
+  g.stage_bytes = want;
+  return KYB_OK;
+}
+int ensure_stage2(Ctx& g, size_t bytes) {
+  if (bytes <= g.stage2_bytes) return KYB_OK;
+  if (g.stage2) { wipe_free_dev(g.stage2, g.stage2_bytes); g.stage2 = nullptr; g.stage2_bytes = 0; }
+  size_t want = bytes + (bytes >> 2) + 4096;
+  hipError_t e = hipMalloc(&g.stage2, want);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "staging allocation", e);
+  g.stage2_bytes = want;
+  return KYB_OK;
+}
+int ensure_pin(Ctx& g, int lane, size_t bytes) {
+  if (bytes <= g.pin_bytes[lane]) return KYB_OK;
+  if (g.pin[lane]) { memset(g.pin[lane], 0, g.pin_bytes[lane]); HIPCK(hipHostFree(g.pin[lane])); g.pin[lane] = nullptr; g.pin_bytes[lane] = 0; }
+  size_t want = bytes + (bytes >> 2) + 4096;
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&g.pin[lane]), want, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "pinned bounce buffer allocation", e);
+  g.pin_bytes[lane] = want;
+  return KYB_OK;
+}
+
+int copy_threads(Ctx& g) {
+  if (g.opt_copy_threads > 0) return g.opt_copy_threads;
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int t = (int)(hw / 2);
+  return t < 1 ? 1 : (t > 8 ? 8 : t);
+}
+// page-locked (hipHostMalloc / hipHostRegister) memory is copied by the DMA engines directly
+bool is_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
+// Host-pointer batches of fixed-size records: the batch is cut into chunks that alternate between two
+// streams (each with its own staging and scratch) so that the H2D copy of chunk c+1 and the D2H copy
+// of chunk c-1 overlap the kernels of chunk c.  Page-locked caller buffers (kyb_host_alloc) are handed to
+// the DMA engines as they are.  Pageable ones would make every hipMemcpyAsync a blocking, single-threaded
+// staging copy inside the runtime (~7 GB/s); they go through the context's own page-locked bounce buffers
+// instead, filled and drained by CopyPool threads while the GPU works on the neighbouring chunk.
+// One host-pointer call at a time per CONTEXT (g.mu); callers that want several in flight use several contexts.
+struct HostArr { const void* in; void* out; size_t bytes; };    // per-item size; exactly one of in/out, or neither = absent
+constexpr size_t PIPE_MIN_ITEMS = (size_t)1 << 16;
+constexpr int PIPE_CHUNKS = 8;
+template <class Fn>
+int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
+  std::lock_guard<std::mutex> lk(g.mu);
+  const int nchunks = n >= PIPE_MIN_ITEMS ? PIPE_CHUNKS : 1;
+  const size_t cap = (((n + nchunks - 1) / nchunks) + 1023) & ~(size_t)1023;      // items per chunk
+  size_t off[8], total = 0;
+  for (int k = 0; k < na; ++k) { off[k] = total; total += up256(arrs[k].bytes * cap); }
+  int rc = ensure_stage(g, total);
+  if (rc) return rc;
+  if (nchunks > 1) { rc = ensure_stage2(g, total); if (rc) return rc; }
+  hipStream_t streams[2] = {g.stream, g.stream2};
+  uint8_t* stages[2] = {g.stage, g.stage2};
+  bool pinned = true;
+  for (int k = 0; k < na; ++k) {
+    if (arrs[k].in) pinned = pinned && is_pinned(arrs[k].in);
+    if (arrs[k].out) pinned = pinned && is_pinned(arrs[k].out);
+  }
+  if (nchunks > 1 && !pinned) {
+    rc = ensure_pin(g, 0, total); if (rc) return rc;
+    rc = ensure_pin(g, 1, total); if (rc) return rc;
+    const int threads = copy_threads(g);
+    kyb::CopyPool::Job jobs[8];
+    auto chunk_items = [&](int c) { const size_t lo = (size_t)c * cap; return lo >= n ? (size_t)0 : ((lo + cap <= n) ? cap : n - lo); };
+    auto copy_out = [&](int c) -> int {             // chunk c has been queued on its lane: wait for it, hand the results over
+      const int lane = c & 1;
+      HIPCK(hipStreamSynchronize(streams[lane]));
+      const size_t lo = (size_t)c * cap, cn = chunk_items(c);
+      int nj = 0;
+      for (int k = 0; k < na; ++k)
+        if (arrs[k].out) jobs[nj++] = kyb::CopyPool::Job{static_cast<uint8_t*>(arrs[k].out) + arrs[k].bytes * lo, g.pin[lane] + off[k], arrs[k].bytes * cn};
+      g.copy.run(jobs, nj, threads);
+      return KYB_OK;
+    };
+    int queued = -1;
+    for (int c = 0; c < nchunks && chunk_items(c) > 0; ++c) {
+      const int lane = c & 1;
+      const size_t lo = (size_t)c * cap, cn = chunk_items(c);
+      if (c >= 2) { rc = copy_out(c - 2); if (rc) return rc; }     // frees this lane's bounce and staging buffers
+      int nj = 0;
+      for (int k = 0; k < na; ++k)
+        if (arrs[k].in) jobs[nj++] = kyb::CopyPool::Job{g.pin[lane] + off[k], static_cast<const uint8_t*>(arrs[k].in) + arrs[k].bytes * lo, arrs[k].bytes * cn};
+      g.copy.run(jobs, nj, threads);
+      uint8_t* dptr[8];
+      for (int k = 0; k < na; ++k) {
+        dptr[k] = (arrs[k].in || arrs[k].out) ? stages[lane] + off[k] : nullptr;
+        if (arrs[k].in) HIPCK(hipMemcpyAsync(dptr[k], g.pin[lane] + off[k], arrs[k].bytes * cn, hipMemcpyHostToDevice, streams[lane]));
+      }
+      rc = launch(streams[lane], cn, dptr);
+      if (rc) return rc;
+      for (int k = 0; k < na; ++k)
+        if (arrs[k].out) HIPCK(hipMemcpyAsync(g.pin[lane] + off[k], stages[lane] + off[k], arrs[k].bytes * cn, hipMemcpyDeviceToHost, streams[lane]));
+      queued = c;
+    }
+    if (queued >= 1) { rc = copy_out(queued - 1); if (rc) return rc; }
+    if (queued >= 0) { rc = copy_out(queued); if (rc) return rc; }
+    return KYB_OK;
+  }
+  auto d2h = [&](int c) -> int {
+    const int lane = c & 1;
+    const size_t lo = (size_t)c * cap, cn = (lo + cap <= n) ? cap : n - lo;
+    for (int k = 0; k < na; ++k)
+      if (arrs[k].out) HIPCK(hipMemcpyAsync(static_cast<uint8_t*>(arrs[k].out) + arrs[k].bytes * lo, stages[lane] + off[k], arrs[k].bytes * cn, hipMemcpyDeviceToHost, streams[lane]));
+    return KYB_OK;
+  };
+  int last = -1;
+  for (int c = 0; c < nchunks; ++c) {
+    const size_t lo = (size_t)c * cap;
+    if (lo >= n) break;
+    const size_t cn = (lo + cap <= n) ? cap : n - lo;
+    const int lane = c & 1;
+    if (c >= 2) HIPCK(hipStreamSynchronize(streams[lane]));      // chunk c-2 has left this lane's staging
+    uint8_t* dptr[8];
+    for (int k = 0; k < na; ++k) {
+      dptr[k] = (arrs[k].in || arrs[k].out) ? stages[lane] + off[k] : nullptr;
+      if (arrs[k].in) HIPCK(hipMemcpyAsync(dptr[k], static_cast<const uint8_t*>(arrs[k].in) + arrs[k].bytes * lo, arrs[k].bytes * cn, hipMemcpyHostToDevice, streams[lane]));
+    }
+    rc = launch(streams[lane], cn, dptr);
+    if (rc) return rc;
+    if (c >= 1) { rc = d2h(c - 1); if (rc) return rc; }
+    last = c;
+  }
+  if (last >= 0) { rc = d2h(last); if (rc) return rc; }
+  HIPCK(hipStreamSynchronize(g.stream));
+  if (nchunks > 1) HIPCK(hipStreamSynchronize(g.stream2));
+  return KYB_OK;
+}
+
+static_assert(KYB_BASE_TABLE_BYTES == 4u * (KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS + KYB_BASE64_TABLE_WORDS), "table image layout");
+constexpr int KYB_CK_LO = KYB_BT_IDX(0, 0, 30), KYB_CK_HI = KYB_BT_IDX(0, 0, 31);   // where the image carries its own checksum
+
+// One synchronous host-pointer call of the small (non-pipelined) kind: the caller's arrays are laid out in the
+// context's device staging buffer, inputs copied in, `body` queues the kernels on the engine stream, outputs copied
+// back, stream synchronised.  An array whose host pointer is null takes no space and maps to a null device pointer.
+// secret(): the inputs include private keys / nonces — the staging region is cleared before the call returns.
+class HostCall {
+ public:
+  explicit HostCall(Ctx& g) : g_(g) {}
+  int in(const void* p, size_t bytes, size_t pad = 0) { return add(p, nullptr, bytes, pad); }
+  int out(void* p, size_t bytes) { return add(nullptr, p, bytes, 0); }
+  int inout(const void* p_in, void* p_out, size_t bytes) { return add(p_in, p_out, bytes, 0); }      // one device array, filled from p_in and/or returned to p_out
+  void secret() { secret_ = true; }
+  template <class T = uint8_t>
+  T* dev(int slot) const { return a_[slot].present ? reinterpret_cast<T*>(g_.stage + a_[slot].off) : nullptr; }
+  template <class Body>
+  int run(Body body) {
+    Ctx& g = g_;
+    std::lock_guard<std::mutex> lk(g.mu);
+    int rc = ensure_stage(g, total_);
+    if (rc) return rc;
+    for (int i = 0; i < n_; ++i)
+      if (a_[i].src && a_[i].bytes) HIPCK(hipMemcpyAsync(g.stage + a_[i].off, a_[i].src, a_[i].bytes, hipMemcpyHostToDevice, g.stream));
+    rc = body(g.stream);
+    if (rc) return rc;
+    for (int i = 0; i < n_; ++i)
+      if (a_[i].dst && a_[i].bytes) HIPCK(hipMemcpyAsync(a_[i].dst, g.stage + a_[i].off, a_[i].bytes, hipMemcpyDeviceToHost, g.stream));
+    if (secret_ && total_) HIPCK(hipMemsetAsync(g.stage, 0, total_, g.stream));
+    HIPCK(hipStreamSynchronize(g.stream));
+    return KYB_OK;
+  }
+
+ private:
+  struct Arr { const void* src; void* dst; size_t bytes, off; bool present; };
+  int add(const void* src, void* dst, size_t bytes, size_t pad) {
+    const bool present = src != nullptr || dst != nullptr;
+    a_[n_] = Arr{src, dst, bytes, total_, present};
+    if (present) total_ += up256(bytes + pad);
+    return n_++;
+  }
+  Ctx& g_;
+  Arr a_[12];
+  int n_ = 0;
+  size_t total_ = 0;
+  bool secret_ = false;
+};
+// message blobs: offsets must not decrease; returns the blob size through *mbytes
+int check_messages(const uint8_t* msgs, const uint32_t* msg_off, size_t n, size_t* mbytes) {
+  *mbytes = msg_off[n];
+  if (*mbytes && !msgs) return fail(KYB_E_BAD_ARG, "null message buffer");
+  for (size_t i = 0; i < n; ++i) if (msg_off[i + 1] < msg_off[i]) return fail(KYB_E_BAD_ARG, "msg_off must be non-decreasing");
+  return KYB_OK;
+}
+
+// ---- per-stream scratch slots ---------------------------------------------------------------------------
+void free_slot(StreamRes* r) {
+  if (r->ev_last && r->used) (void)hipEventSynchronize(r->ev_last);      // everything that used the scratch has finished
+  if (r->ws) (void)hipFree(r->ws);
+  if (r->proj) wipe_free_dev(r->proj, r->proj_items * 8 * sizeof(uint4));
+  if (r->enc) wipe_free_dev(r->enc, r->enc_bytes);
+  if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->ev_fork); (void)hipEventDestroy(r->ev_join); }
+  if (r->ev_last) (void)hipEventDestroy(r->ev_last);
+  delete r;
+}
+// scratch bound to a stream (allocated on first use).  Called with g.launch_mu held.  Up to MAX_STREAM_SLOTS streams are
+// registered at a time; beyond that the least recently used caller stream's slot is recycled (after its last launch).
+int res_for(Ctx& g, hipStream_t st, StreamRes** out) {
+  for (StreamRes* r : g.res) if (r->stream == st) { r->last_use = ++g.use_clock; *out = r; return KYB_OK; }
+  if (g.res.size() >= MAX_STREAM_SLOTS) {
+    size_t victim = g.res.size();
+    for (size_t i = 0; i < g.res.size(); ++i)
+      if (!g.res[i]->own && (victim == g.res.size() || g.res[i]->last_use < g.res[victim]->last_use)) victim = i;
+    if (victim == g.res.size()) return fail(KYB_E_NOMEM, "no stream scratch slot can be recycled");
+    free_slot(g.res[victim]);
+    g.res.erase(g.res.begin() + (long)victim);
+  }
+  StreamRes* r = new StreamRes();
+  r->stream = st;
+  r->own = (st == g.stream || st == g.stream2);
+  hipError_t e = hipEventCreateWithFlags(&r->ev_last, hipEventDisableTiming);
+  if (e != hipSuccess) { delete r; return fail(KYB_E_HIP, "hipEventCreateWithFlags", e); }
+  r->last_use = ++g.use_clock;
+  g.res.push_back(r);
+  *out = r;
+  return KYB_OK;
+}
+// Brackets one launch sequence on a slot: the stream first waits for the slot's previous user (a no-op when that was the
+// same stream; the protection when a destroyed stream's handle value comes back for a new stream), and the slot's
+// ev_last is re-recorded behind everything the sequence queued.
+struct SlotUse {
+  StreamRes* r; hipStream_t st;
+  SlotUse(StreamRes* r_, hipStream_t st_) : r(r_), st(st_) { if (r->used) (void)hipStreamWaitEvent(st, r->ev_last, 0); }
+  ~SlotUse() { (void)hipEventRecord(r->ev_last, st); r->used = true; }
+};
+// the windowed-table kernel's per-wave table slots (160 MiB): only allocated if that kernel is used
+int ensure_ws(Ctx& g, StreamRes* r) {
+  if (r->ws) return KYB_OK;
+  hipError_t e = hipMalloc(&r->ws, g.ws_bytes);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "table workspace allocation", e);
+  return KYB_OK;
+}
+// grow-only; growth synchronises the stream first because earlier launches may still use the old buffer
+int ensure_proj(Ctx& g, StreamRes* r, size_t items) {
+  (void)g;
+  if (items <= r->proj_items) return KYB_OK;
+  HIPCK(hipStreamSynchronize(r->stream));
+  if (r->proj) wipe_free_dev(r->proj, r->proj_items * 8 * sizeof(uint4));
+  r->proj = nullptr; r->proj_items = 0;
+  const size_t want = ((items + (items >> 3)) + 1023) & ~(size_t)1023;
+  hipError_t e = hipMalloc(&r->proj, want * 8 * sizeof(uint4));
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "projective staging allocation", e);
+  r->proj_items = want;
+  return KYB_OK;
+}
+int ensure_enc(Ctx& g, StreamRes* r, size_t bytes) {
+  (void)g;
+  if (bytes <= r->enc_bytes) return KYB_OK;
+  HIPCK(hipStreamSynchronize(r->stream));
+  if (r->enc) wipe_free_dev(r->enc, r->enc_bytes);
+  r->enc = nullptr; r->enc_bytes = 0;
+  const size_t want = bytes + (bytes >> 3) + 4096;
+  hipError_t e = hipMalloc(&r->enc, want);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "encoding staging allocation", e);
+  r->enc_bytes = want;
+  return KYB_OK;
+}
+int ensure_aux(Ctx& g, StreamRes* r) {
+  (void)g;
+  if (r->aux) return KYB_OK;
+  HIPCK(hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking));
+  HIPCK(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
+  HIPCK(hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming));
+  return KYB_OK;
+}
+inline bool use_split(Ctx& g, size_t n) { return g.opt_finish == 1 && n >= (size_t)g.opt_finish_min; }
+
+// ---- context life cycle ------------------------------------------------------------------------------------
+// image in g.table -> does the embedded checksum match?  (synchronous; used after an import)
+int table_validate(Ctx& g, hipStream_t st) {
+  uint64_t got = 0;
+  uint32_t emb[2] = {0, 0};
+  LAUNCHCK(launch::table_checksum(g.table, g.ck_dev, st));
+  HIPCK(hipMemcpyAsync(&got, g.ck_dev, sizeof(got), hipMemcpyDeviceToHost, st));
+  HIPCK(hipMemcpyAsync(emb, g.table + KYB_CK_LO, sizeof(emb), hipMemcpyDeviceToHost, st));
+  HIPCK(hipStreamSynchronize(st));
+  const uint64_t want = (uint64_t)emb[0] | ((uint64_t)emb[1] << 32);
+  if (got != want) return fail(KYB_E_BAD_ARG, "base table image failed its checksum (truncated or corrupted transfer): table not installed");
+  return KYB_OK;
+}
+
+void ctx_release(Ctx* c) {
+  if (c->device >= 0) (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  c->copy.stop();
+  for (StreamRes* r : c->res) free_slot(r);
+  c->res.clear();
+  wipe_free_dev(c->stage, c->stage_bytes);
+  wipe_free_dev(c->stage2, c->stage2_bytes);
+  for (int l = 0; l < 2; ++l) if (c->pin[l]) { memset(c->pin[l], 0, c->pin_bytes[l]); (void)hipHostFree(c->pin[l]); }
+  { std::lock_guard<std::mutex> lk(c->prof.mu);
+    for (int i = 0; i < c->prof.cap; ++i) { (void)hipEventDestroy(c->prof.recs[i].a); (void)hipEventDestroy(c->prof.recs[i].b); }
+    delete[] c->prof.recs; c->prof.recs = nullptr; c->prof.cap = c->prof.used = 0; c->prof.on = false; }
+  if (c->table) (void)hipFree(c->table);
+  if (c->ck_dev) (void)hipFree(c->ck_dev);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int ctx_new(int device, bool build_table, Ctx** out) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) return fail(KYB_E_NO_DEVICE, "no HIP device visible (this engine has no CPU path)", e);
+  if (device < 0 || device >= count) return fail(KYB_E_BAD_ARG, "device index out of range");
+  HIPCK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    char buf[200];
+    snprintf(buf, sizeof(buf), "device %d is %s; this library carries gfx950 code objects only", device, prop.gcnArchName);
+    return fail(KYB_E_NO_DEVICE, buf);
+  }
+  Ctx* c = new Ctx();
+  Ctx& g = *c;
+  g.device = device;
+  g.cus = prop.multiProcessorCount;
+  snprintf(g.name, sizeof(g.name), "%s", prop.name);
+#define CTXCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ctx_release(c); return fail(KYB_E_HIP, #x, e_); } } while (0)
+  CTXCK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  CTXCK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
+  CTXCK(hipMalloc(&g.table, KYB_BASE_TABLE_BYTES));
+  CTXCK(hipMalloc(&g.ck_dev, 16));
+  // persistent grids of the windowed kernel: 2 blocks of 256 threads per CU = 2 waves per SIMD (needed to saturate
+  // v_mad_u64_u32 issue, profiles/r01_valu_rates_mi355x.jsonl)
+  g.grid_mul = g.cus * 2;
+  g.ws_bytes = (size_t)g.grid_mul * (KYB_BLOCK / 64) * (8 * 10 * 64) * sizeof(uint4);
+  if (build_table) {
+    CTXCK(launch::build_tables(g.table, g.stream));
+    CTXCK(hipStreamSynchronize(g.stream));
+    g.table_ready = true;
+  }
+#undef CTXCK
+  g.ready = true;
+  { std::lock_guard<std::mutex> lk(g_reg_mu); g_all.push_back(c); }
+  *out = c;
+  return KYB_OK;
+}
+void ctx_delete(Ctx* c) {
+  { std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (size_t i = 0; i < g_all.size(); ++i) if (g_all[i] == c) { g_all.erase(g_all.begin() + (long)i); break; }
+    if (g_default == c) g_default = nullptr; }
+  if (tl_cur == c) tl_cur = nullptr;
+  c->ready = false;
+  ctx_release(c);
+}
+bool ctx_is_live(Ctx* c) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  for (Ctx* x : g_all) if (x == c) return true;
+  return false;
+}
+
+int do_init(int device, bool build_table) {
+  static std::mutex init_mu;
+  std::lock_guard<std::mutex> lk(init_mu);
+  if (g_default != nullptr) {
+    if (g_default->device != device)
+      return fail(KYB_E_BAD_ARG, "the default context is bound to another device (kyb_init is one context per process; use kyb_ctx_create / kyb_group_create for more GPUs)");
+    return KYB_OK;
+  }
+  Ctx* c = nullptr;
+  int rc = ctx_new(device, build_table, &c);
+  if (rc) return rc;
+  { std::lock_guard<std::mutex> lk2(g_reg_mu); g_default = c; }
+  return KYB_OK;
+}
+
+// ---- launch sequences ------------------------------------------------------------------------------------
+int launch_finish(Ctx& g, StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st, size_t src_mul = 1) {
+  ProfScope ps(g, st, KID_FINISH);
+  LAUNCHCK(launch::finish(st, r->proj, r->proj_items, n, oenc, oext, src_mul));
+  return KYB_OK;
+}
+
+// leaves the results projective in r->proj[0, n): prep (batched inversion) -> 256-step ladder.
+// npts == 0: item i multiplies point i.  npts > 0: the npts points are shared, item i multiplies point
+// i mod npts (their Montgomery images live in records [n, n + npts)).
+// skip_bits: leading zero bits every scalar of the launch has for public reasons (3 for values reduced mod L).
+int launch_ladder_core(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* ok, StreamRes* r, hipStream_t st,
+                       size_t npts = 0, int skip_bits = 0) {
+  const size_t np = npts ? npts : n;
+  int rc = ensure_proj(g, r, n + npts); if (rc) return rc;
+  if (penc != nullptr) {           // unmarshal_binary of the operands first (ok flags; failed decodes become the neutral element)
+    rc = ensure_enc(g, r, 160 * np + 256); if (rc) return rc;
+    int32_t* tmp = reinterpret_cast<int32_t*>(r->enc);
+    ProfScope ps(g, st, KID_DECODE);
+    LAUNCHCK(launch::decode_or_identity(st, penc, np, tmp, ok));
+    pext = tmp;
+  } else if (ok != nullptr) {
+    HIPCK(hipMemsetAsync(ok, 1, np, st));          // extended operands are taken as they are (k_mul does the same)
+  }
+  {
+    ProfScope ps(g, st, KID_MONT_PREP);
+    LAUNCHCK(launch::mont_prep(st, pext, np, r->proj + (npts ? n : 0), r->proj_items));
+  }
+  {
+    ProfScope ps(g, st, KID_MUL_LADDER);
+    LAUNCHCK(launch::mul_ladder(g.opt_ladder_waves, st, sc, n, r->proj, r->proj_items, n, npts, skip_bits));
+  }
+  return KYB_OK;
+}
+
+// the ceil(log2 t) halving passes that leave the sum of each group of t staging records in the group's first record
+int launch_pair_sums(Ctx& g, StreamRes* r, size_t m, size_t t, hipStream_t st) {
+  for (size_t len = t; len > 1;) {
+    const size_t half = (len + 1) / 2;
+    ProfScope ps(g, st, KID_PAIR_SUM);
+    LAUNCHCK(launch::pair_sum(st, r->proj, r->proj_items, m, t, len, half));
+    len = half;
+  }
+  return KYB_OK;
+}
+
+// out[g] = sum_j scalars[g*t + j] * P[g*t + j]  (shared == false)  or  * P[j]  (shared == true)
+int launch_lincomb(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pext, bool shared, size_t m, size_t t, uint8_t* ok,
+                   uint8_t* oenc, int32_t* oext, hipStream_t st) {
+  if (m == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  const size_t n = m * t;
+  { int rc = launch_ladder_core(g, sc, penc, pext, n, ok, r, st, shared ? t : 0); if (rc) return rc; }
+  { int rc = launch_pair_sums(g, r, m, t, st); if (rc) return rc; }
+  return launch_finish(g, r, m, oenc, oext, st, t);
+}
+
+// out[g] = sum_j P[g*t + j]: the halving passes of launch_lincomb on the points themselves
+int launch_sum(Ctx& g, const int32_t* pext, size_t m, size_t t, uint8_t* oenc, int32_t* oext, hipStream_t st) {
+  if (m == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  const size_t n = m * t;
+  { int rc = ensure_proj(g, r, n); if (rc) return rc; }
+  LAUNCHCK(launch::ext_to_proj(st, pext, n, r->proj, r->proj_items));
+  { int rc = launch_pair_sums(g, r, m, t, st); if (rc) return rc; }
+  return launch_finish(g, r, m, oenc, oext, st, t);
+}
+
+int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  if (g.opt_mul_algo == 1) {
+    int rc = launch_ladder_core(g, sc, penc, pext, n, ok, r, st); if (rc) return rc;
+    return launch_finish(g, r, n, oenc, oext, st);
+  }
+  { int rc = ensure_ws(g, r); if (rc) return rc; }
+  const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
+  const int grid = (int)(nchunks < (size_t)g.grid_mul ? nchunks : (size_t)g.grid_mul);
+  const bool split = use_split(g, n);
+  if (split) { int rc = ensure_proj(g, r, n); if (rc) return rc; }
+  {
+    ProfScope ps(g, st, KID_MUL);
+    LAUNCHCK(launch::mul_window(g.opt_mul_select, penc != nullptr, split, grid, st, sc, penc, pext, n, oenc, oext, ok, r->ws, r->proj, r->proj_items));
+  }
+  if (split) return launch_finish(g, r, n, oenc, oext, st);
+  return KYB_OK;
+}
+
+// fixed-base multiplication of n scalars; split leaves the points in r->proj at [offset, offset + n)
+// sc_b != nullptr: a second array of n_b scalars follows the first in the same launch (radix-64 kernel), their
+// results land behind the first n
+int launch_base(Ctx& g, bool split, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, StreamRes* r, size_t offset, hipStream_t st,
+                const uint8_t* sc_b = nullptr, size_t n_b = 0) {
+  const int radix = g.opt_base_radix, finish_min = g.opt_finish_min;
+  if (sc_b != nullptr && !(radix == 64 && n + n_b >= (size_t)finish_min)) {
+    int rc = launch_base(g, split, sc, n, oenc, oext, r, offset, st); if (rc) return rc;
+    return launch_base(g, split, sc_b, n_b, oenc ? oenc + 32 * n : nullptr, oext ? oext + 40 * n : nullptr, r, offset + n, st);
+  }
+  if (radix == 64 && n + n_b >= (size_t)finish_min) {
+    const size_t n_a = n;
+    n += n_b;
+    // one workgroup per CU (the table is its whole LDS); 256-thread workgroups while that leaves CUs idle
+    const uint4* img64 = reinterpret_cast<const uint4*>(g.table + KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS);
+    const bool small = n <= (size_t)256 * (size_t)g.cus * (size_t)g.opt_base_small_chunks;
+    const int block = small ? 256 : (g.opt_base_block64 == 512 ? 512 : 1024);
+    const size_t nchunks64 = (n + block - 1) / block;
+    const int grid64 = (int)(nchunks64 < (size_t)g.cus ? nchunks64 : (size_t)g.cus);
+    ProfScope ps(g, st, KID_MUL_BASE);
+    LAUNCHCK(launch::mul_base64(split, block, grid64, st, sc, sc_b, n_a, n, oenc, oext, img64, r->proj, r->proj_items, offset));
+    return KYB_OK;
+  }
+  if (radix == 32 && n >= (size_t)finish_min) {
+    const uint4* img32 = reinterpret_cast<const uint4*>(g.table + KYB_BASE_TABLE_WORDS);
+    const size_t nchunks32 = (n + KYB_BLOCK32 - 1) / KYB_BLOCK32;
+    const int grid32 = (int)(nchunks32 < (size_t)g.cus ? nchunks32 : (size_t)g.cus);     // one workgroup per CU: the table fills its LDS
+    ProfScope ps(g, st, KID_MUL_BASE);
+    LAUNCHCK(launch::mul_base32(split, grid32, st, sc, n, oenc, oext, img32, r->proj, r->proj_items, offset));
+    return KYB_OK;
+  }
+  const uint4* img = reinterpret_cast<const uint4*>(g.table);
+  const int block = g.opt_base_block;
+  const size_t nchunks = (n + block - 1) / block;
+  const size_t cap = (size_t)g.cus * 2;                       // 2 blocks per CU: LDS holds two 64 KiB tables
+  const int grid = (int)(nchunks < cap ? nchunks : cap);
+  ProfScope ps(g, st, KID_MUL_BASE);
+  LAUNCHCK(launch::mul_base16(g.opt_base_select, block, split, grid, st, sc, n, oenc, oext, img, r->proj, r->proj_items, offset));
+  return KYB_OK;
+}
+int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  if (use_split(g, n)) {
+    int rc = ensure_proj(g, r, n); if (rc) return rc;
+    rc = launch_base(g, true, sc, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
+    return launch_finish(g, r, n, oenc, oext, st);
+  }
+  return launch_base(g, false, sc, n, oenc, oext, r, 0, st);
+}
+// marshal_binary of n extended points: one shared inversion per FINISH_K points
+int launch_encode(Ctx& g, const int32_t* pext, size_t n, uint8_t* oenc, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  if (g.opt_encode_batched == 1) {
+    ProfScope ps(g, st, KID_ENCODE);
+    LAUNCHCK(launch::encode_batched(st, pext, n, oenc));
+  } else {
+    LAUNCHCK(launch::encode(st, pext, n, oenc));
+  }
+  return KYB_OK;
+}
+// schnorr::sign for n (x, k, msg) triples.  pub_in != nullptr: the callers' stored public keys enc(x*B) are
+// hashed as they are and A is not recomputed (EdDSA::sign, eddsa_sig.rs:132-137; DSS long-term keys);
+// pub_out != nullptr: receives enc(x*B).
+int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const uint8_t* pub_in, const uint8_t* msgs, const uint32_t* off, size_t n,
+                uint8_t* sig, uint8_t* pub_out, hipStream_t st) {
+  if (pub_in != nullptr) {
+    // R = k*B only
+    int rc = ensure_enc(g, r, 32 * n); if (rc) return rc;
+    if (use_split(g, n)) {
+      rc = ensure_proj(g, r, n); if (rc) return rc;
+      rc = launch_base(g, true, k, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
+      rc = launch_finish(g, r, n, r->enc, nullptr, st); if (rc) return rc;
+    } else {
+      rc = launch_base(g, false, k, n, r->enc, nullptr, r, 0, st); if (rc) return rc;
+    }
+    {
+      ProfScope ps(g, st, KID_SIGN_HASH);
+      LAUNCHCK(launch::sign_hash(st, x, k, msgs, off, n, r->enc, pub_in, sig));
+    }
+    if (pub_out != nullptr && pub_out != pub_in) HIPCK(hipMemcpyAsync(pub_out, pub_in, 32 * n, hipMemcpyDeviceToDevice, st));
+    return KYB_OK;
+  }
+  if (use_split(g, 2 * n)) {
+    // R = k*B -> proj[0, n), A = x*B -> proj[n, 2n); one batched finish; then hash + scalar arithmetic
+    int rc = ensure_proj(g, r, 2 * n); if (rc) return rc;
+    rc = ensure_enc(g, r, 64 * n); if (rc) return rc;
+    rc = launch_base(g, true, k, n, nullptr, nullptr, r, 0, st, x, n); if (rc) return rc;
+    rc = launch_finish(g, r, 2 * n, r->enc, nullptr, st); if (rc) return rc;
+    {
+      ProfScope ps(g, st, KID_SIGN_HASH);
+      LAUNCHCK(launch::sign_hash(st, x, k, msgs, off, n, r->enc, r->enc + 32 * n, sig));
+    }
+    if (pub_out != nullptr) HIPCK(hipMemcpyAsync(pub_out, r->enc + 32 * n, 32 * n, hipMemcpyDeviceToDevice, st));
+    return KYB_OK;
+  }
+  const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
+  const size_t cap = (size_t)g.cus * 2;
+  const int grid = (int)(nchunks < cap ? nchunks : cap);
+  const uint4* img = reinterpret_cast<const uint4*>(g.table);
+  {
+    ProfScope ps(g, st, KID_SIGN);
+    LAUNCHCK(launch::sign_fused(g.opt_base_select, grid, st, x, k, msgs, off, n, sig, img));
+  }
+  if (pub_out != nullptr) return launch_base(g, false, x, n, pub_out, nullptr, r, 0, st);
+  return KYB_OK;
+}
+int launch_sign(Ctx& g, const uint8_t* x, const uint8_t* k, const uint8_t* pub_in, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* sig, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  return sign_locked(g, r, x, k, pub_in, msgs, off, n, sig, nullptr, st);
+}
+
+// EdDSA::sign for n (seed, msg) pairs: expansion + nonce, then the Schnorr pipeline.  pub_in: the public keys
+// the EdDSA objects hold (eddsa_sig.rs:22-29), or nullptr = derive them here; pub_out: optional copy of them.
+int launch_eddsa_sign(Ctx& g, const uint8_t* seeds, const uint8_t* pub_in, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* sig, uint8_t* pub_out, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  int rc = res_for(g, st, &r); if (rc) return rc;
+  SlotUse use(r, st);
+  // the signing pipeline uses r->enc[0, 64n) for the encodings of R and A: keep x and k behind that
+  rc = ensure_enc(g, r, up256(64 * n) + 2 * up256(32 * n)); if (rc) return rc;
+  uint8_t* xbuf = r->enc + up256(64 * n);
+  uint8_t* kbuf = xbuf + up256(32 * n);
+  {
+    ProfScope ps(g, st, KID_EDDSA_PREP);
+    LAUNCHCK(launch::eddsa_prep(st, seeds, msgs, off, n, xbuf, kbuf));
+  }
+  rc = sign_locked(g, r, xbuf, kbuf, pub_in, msgs, off, n, sig, pub_out, st);
+  // the expanded secret scalars and the nonces do not outlive the call
+  HIPCK(hipMemsetAsync(xbuf, 0, 2 * up256(32 * n), st));
+  return rc;
+}
+
+// verification pipeline on one stream: prep -> ladder (h, A) -> fixed base (s) -> final
+int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, const uint8_t* sigs, size_t n, int flavor,
+                  uint8_t* status, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  int rc = ensure_proj(g, r, 3 * n); if (rc) return rc;
+  const size_t o_h = 0, o_s = up256(32 * n), o_a = o_s + up256(32 * n), o_fa = o_a + up256(160 * n), o_fr = o_fa + up256(n);
+  rc = ensure_enc(g, r, o_fr + up256(n)); if (rc) return rc;
+  uint8_t* hbuf = r->enc + o_h; uint8_t* sbuf = r->enc + o_s; int32_t* a_ext = reinterpret_cast<int32_t*>(r->enc + o_a);
+  uint8_t* flags_a = r->enc + o_fa; uint8_t* flags_r = r->enc + o_fr;
+  // the R half (decode of R, s*B) is independent of the A half (decode of A, hash, h*A): while the batch leaves most of
+  // the chip idle it runs on the side stream
+  const bool fork = g.opt_verify_overlap && n <= (size_t)64 * (size_t)g.cus;
+  hipStream_t side = st;
+  if (fork) {
+    rc = ensure_aux(g, r); if (rc) return rc;
+    side = r->aux;
+    HIPCK(hipEventRecord(r->ev_fork, st));                 // behind whatever the caller queued before this call
+    HIPCK(hipStreamWaitEvent(side, r->ev_fork, 0));
+  }
+  {
+    ProfScope ps(g, side, KID_VERIFY_PREP_R);
+    LAUNCHCK(launch::verify_prep_r(side, sigs, n, flags_r, r->proj, r->proj_items, 2 * n));
+  }
+  {
+    ProfScope ps(g, st, KID_VERIFY_PREP);
+    LAUNCHCK(launch::verify_prep(st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext));
+  }
+  if (fork) {
+    HIPCK(hipEventRecord(r->ev_fork, st));                 // s*B reads sbuf, which the A-half kernel has just been asked to write
+    HIPCK(hipStreamWaitEvent(side, r->ev_fork, 0));
+    rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side); if (rc) return rc;
+    HIPCK(hipEventRecord(r->ev_join, side));
+  }
+  if (g.opt_mul_algo == 1) {
+    rc = launch_ladder_core(g, hbuf, nullptr, a_ext, n, nullptr, r, st, 0, 3); if (rc) return rc;      // h < L < 2^253
+  } else {
+    rc = ensure_ws(g, r); if (rc) return rc;
+    const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
+    const int grid = (int)(nchunks < (size_t)g.grid_mul ? nchunks : (size_t)g.grid_mul);
+    ProfScope ps(g, st, KID_MUL);
+    LAUNCHCK(launch::mul_window(g.opt_mul_select, false, true, grid, st, hbuf, nullptr, a_ext, n, nullptr, nullptr, nullptr, r->ws, r->proj, r->proj_items));
+  }
+  if (fork) HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
+  else { rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, st); if (rc) return rc; }
+  {
+    ProfScope ps(g, st, KID_VERIFY_FINAL);
+    LAUNCHCK(launch::verify_final(st, r->proj, r->proj_items, n, flags_a, flags_r, flavor, status));
+  }
+  return KYB_OK;
+}
+
+int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* idx, size_t n, uint32_t max_index, uint8_t* oenc, int32_t* oext, hipStream_t st,
+                     size_t per_poly = 0) {
+  if (n == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  int nbits = 1;
+  while (nbits < 32 && ((uint64_t)max_index + 1) >> nbits) ++nbits;      // bit length of max x = max_index + 1
+  const bool split = use_split(g, n);
+  if (split) { int rc = ensure_proj(g, r, n); if (rc) return rc; }
+  {
+    ProfScope ps(g, st, KID_POLY_EVAL);
+    LAUNCHCK(launch::poly_eval(split, st, commits, (int)t, idx, n, nbits, per_poly, oenc, oext, r->proj, r->proj_items));
+  }
+  if (split) return launch_finish(g, r, n, oenc, oext, st);
+  return KYB_OK;
+}
+
+}  // namespace
+
+#include "c_abi.inc"
+#include "engine_group.inc"

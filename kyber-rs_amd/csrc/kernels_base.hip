@@ -1,0 +1,99 @@
+// Fixed-base kernels of the MI355X Ed25519 engine (one of the five translation units, see launch.h).
+//   k_base_table / 32 / 64   build the LDS table images on the GPU at init (role of constants.rs:89 BASE)
+//   k_table_checksum         checksum embedded in / checked against an image that travelled between GPUs
+//   k_mul_base64             Point::mul(s, None)  ge.rs:442-486   42x32+16 affine table = the whole LDS (163,200 B), batches
+#include <hip/hip_runtime.h>
+#include "launch.h"
+#include "ge_scalarmult.h"
+using namespace kyb;
+#include "device_tables.h"
+
+__global__ void __launch_bounds__(64) k_base_table(uint32_t* image) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // 0..511
+  if (e < 512) ge_base_table_entry(image, e >> 3, e & 7);
+}
+
+__global__ void __launch_bounds__(64) k_base_table32(uint32_t* image) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // 0..831
+  if (e < KYB_BASE32_POS * 16) ge_base32_table_entry(image, e >> 4, e & 15);
+}
+
+__global__ void __launch_bounds__(64) k_base_table64(uint32_t* image) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // 0..1359: 42 windows x 32 entries, then the top window's 16
+  if (e < 42 * 32) ge_base64_table_entry(image, e >> 5, e & 31);
+  else if (e < 42 * 32 + 16) ge_base64_table_entry(image, 42, e - 42 * 32);
+}
+
+// Fixed base, signed radix 64: one workgroup per CU owns the whole LDS (163,200 B table); 43 mixed additions
+// per item.  BLOCK = 1024 (4 waves/SIMD) when the batch fills the chip, 256 (1 wave/SIMD, four times as many
+// CUs busy) for batches that do not.
+// Two scalar arrays may be multiplied in one launch (signing: the nonces and the private keys): items
+// [0, n_a) come from `scalars`, items [n_a, n) from `scalars_b`.
+template <bool SPLIT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK, BLOCK / 256)
+k_mul_base64(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ scalars_b, size_t n_a, size_t n,
+             uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
+             const uint4* __restrict__ table_image, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
+  __shared__ uint4 lds_tbl[KYB_BASE64_TABLE_WORDS / 4];
+  for (int k = threadIdx.x; k < KYB_BASE64_TABLE_WORDS / 4; k += BLOCK) lds_tbl[k] = table_image[k];
+  __syncthreads();
+  tbl_lds64 tbl{reinterpret_cast<const uint32_t*>(lds_tbl)};
+  const size_t nchunks = (n + BLOCK - 1) / BLOCK;
+  for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const size_t i = chunk * BLOCK + threadIdx.x;
+    const bool live = i < n;
+    const size_t ii = live ? i : 0;
+    uint32_t a[8];
+    if (ii < n_a) load_words8(a, scalars, ii); else load_words8(a, scalars_b, ii - n_a);
+    ge_p3 h;
+    ge_scalarmult_base64(h, a, tbl);
+    if (SPLIT) { if (live) store_proj(proj, proj_stride, proj_offset + i, h.X, h.Y, h.Z); }
+    else finish_point(h.X, h.Y, h.Z, out_enc, out_ext, ii, live);
+  }
+}
+
+// ---- table image checksum ---------------------------------------------------------------------------
+// 64-bit position-weighted sum of the image's words, the two padding words of radix-16 entry (0, 0) excluded: that is
+// where the checksum itself travels (KYB_BT_IDX(0, 0, 30 / 31); no kernel reads those words as data).  A wrong or
+// truncated broadcast is caught at import instead of producing wrong points on 7 of 8 GPUs.
+constexpr int KYB_TABLE_WORDS_ALL = KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS + KYB_BASE64_TABLE_WORDS;
+constexpr int KYB_CK_LO = KYB_BT_IDX(0, 0, 30), KYB_CK_HI = KYB_BT_IDX(0, 0, 31);
+__global__ void __launch_bounds__(1024) k_table_checksum(const uint32_t* __restrict__ image, uint64_t* __restrict__ out, uint32_t* __restrict__ embed_into) {
+  __shared__ unsigned long long part[1024 / 64];
+  unsigned long long h = 0;
+  for (int i = threadIdx.x; i < KYB_TABLE_WORDS_ALL; i += 1024) {
+    if (i == KYB_CK_LO || i == KYB_CK_HI) continue;
+    h += ((unsigned long long)image[i] + 0x9e3779b97f4a7c15ull) * (2ull * (unsigned long long)i + 1ull);
+  }
+  for (int o = 32; o > 0; o >>= 1) h += __shfl_down(h, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < 1024 / 64; ++w) t += part[w];
+    if (out != nullptr) out[0] = t;
+    if (embed_into != nullptr) { embed_into[KYB_CK_LO] = (uint32_t)t; embed_into[KYB_CK_HI] = (uint32_t)(t >> 32); }
+  }
+}
+
+namespace kyb { namespace launch {
+hipError_t build_tables(uint32_t* table, hipStream_t st) {
+  hipLaunchKernelGGL(k_base_table, dim3(8), dim3(64), 0, st, table);
+  hipLaunchKernelGGL(k_base_table32, dim3(13), dim3(64), 0, st, table + KYB_BASE_TABLE_WORDS);
+  hipLaunchKernelGGL(k_base_table64, dim3(22), dim3(64), 0, st, table + KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS);
+  hipLaunchKernelGGL(k_table_checksum, dim3(1), dim3(1024), 0, st, table, (uint64_t*)nullptr, table);
+  return hipGetLastError();
+}
+hipError_t table_checksum(const uint32_t* table, uint64_t* out_dev, hipStream_t st) {
+  hipLaunchKernelGGL(k_table_checksum, dim3(1), dim3(1024), 0, st, table, out_dev, (uint32_t*)nullptr);
+  return hipGetLastError();
+}
+hipError_t mul_base64(bool split, int block, int grid, hipStream_t st, const uint8_t* sc, const uint8_t* sc_b, size_t n_a, size_t n,
+                      uint8_t* oenc, int32_t* oext, const uint4* img64, uint4* proj, size_t stride, size_t offset) {
+#define KYB_L(S_, B_) hipLaunchKernelGGL((k_mul_base64<S_, B_>), dim3(grid), dim3(B_), 0, st, sc, sc_b, n_a, n, oenc, oext, img64, proj, stride, offset)
+  if (split) { if (block == 256) KYB_L(true, 256); else if (block == 512) KYB_L(true, 512); else KYB_L(true, 1024); }
+  else       { if (block == 256) KYB_L(false, 256); else if (block == 512) KYB_L(false, 512); else KYB_L(false, 1024); }
+#undef KYB_L
+  return hipGetLastError();
+}
+}}  // namespace kyb::launch

@@ -1,0 +1,159 @@
+// Variable-base kernels of the MI355X Ed25519 engine (one of the five translation units, see launch.h).
+//   k_decode_or_identity   unmarshal_binary of the operands (ge.rs:124-179), failed decodes -> neutral element
+//   k_mont_prep            Montgomery images of the operands, one field inversion per FINISH_K items
+//   k_mul_ladder           Point::mul(s, Some(P))  ge.rs:508-568   Montgomery ladder + y-recovery (ge_ladder.h)
+//   k_pair_sum             one halving pass of the segmented sums behind kyb_lincomb_batch / kyb_sum_batch
+//   k_ext_to_proj          extended limbs -> projective staging records
+#include <hip/hip_runtime.h>
+#include "launch.h"
+#include "ge_scalarmult.h"
+#include "ge_ladder.h"
+#include "device_batch_invert.h"
+using namespace kyb;
+#include "device_tables.h"
+
+// unmarshal_binary for the ladder path: extended limbs out, failed decodes replaced by the neutral element
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_decode_or_identity(const uint8_t* __restrict__ enc, size_t n, int32_t* __restrict__ out_ext, uint8_t* __restrict__ ok_out) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words8(w, enc, i);
+  ge_p3 P, id;
+  const uint32_t ok = ge_decode(P, w);
+  ge_p3_0(id);
+  fe_cmov(P.X, id.X, 1u - ok); fe_cmov(P.Y, id.Y, 1u - ok); fe_cmov(P.Z, id.Z, 1u - ok); fe_cmov(P.T, id.T, 1u - ok);
+  store_ext(out_ext, i, P.X, P.Y, P.Z, P.T);
+  if (ok_out != nullptr) ok_out[i] = (uint8_t)ok;
+}
+
+// ---- table-free variable base (ge_ladder.h) -------------------------------------------------------
+// Montgomery images of the input points, one field inversion per FINISH_K items.  Output record of item
+// i in the staging buffer: quads 0..4 = u[10] v[10], quad 5.x = flags (the ladder kernel later overwrites
+// the same record with the projective result).
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_mont_prep(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ proj, size_t stride) {
+  const size_t M = (n + FINISH_K - 1) / FINISH_K;
+  const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (j >= M) return;
+  auto load = [&](int t, fe& d) {
+    const size_t i = j + (size_t)t * M;
+    if (i < n) { ge_p3 P; uint32_t fl; load_ext(P, pts_ext, i); mont_prep_den(d, fl, P); }
+    else fe_one(d);
+  };
+  auto emit = [&](int t, const fe& dinv) {
+    const size_t i = j + (size_t)t * M;
+    if (i >= n) return;
+    ge_p3 P;
+    load_ext(P, pts_ext, i);
+    fe d;
+    uint32_t fl;
+    mont_prep_den(d, fl, P);
+    mont_point m;
+    mont_prep_finish(m, P, dinv, fl);
+    uint32_t f[24];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { f[k] = m.u.v[k]; f[10 + k] = m.v.v[k]; }
+    f[20] = m.flags; f[21] = f[22] = f[23] = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) proj[q * stride + i] = make_uint4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+  };
+  fe unused_prefix, unused_inv;
+  fe_one(unused_prefix);
+  batch_invert<0, FINISH_K>(unused_prefix, unused_inv, load, emit);
+}
+#if defined(KYB_DIAG_STAMPS)
+// diagnostic build only: per-wave (cycles, 100 MHz ticks) of the ladder loop go to a buffer of their own
+__device__ uint64_t* kyb_diag_stamp_buf = nullptr;
+__device__ size_t kyb_diag_stamp_cap = 0;
+#endif
+template <int WAVES>
+__global__ void __launch_bounds__(KYB_BLOCK, WAVES)
+k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t a[8];
+  load_words8(a, scalars, i);
+  // Montgomery image of the operand: record i itself, or (shared operands) record img_offset + i mod img_mod
+  const size_t src = img_mod ? img_offset + i % img_mod : i;
+  uint32_t f[24];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) { const uint4 v = proj[q * stride + src]; f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w; }
+  mont_point m;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { m.u.v[k] = f[k]; m.v.v[k] = f[10 + k]; }
+  m.flags = f[20];
+  ge_p2 r;
+#if defined(KYB_DIAG_STAMPS)
+  uint64_t stamp[2];
+  ge_scalarmult_ladder_stamped(r, a, m, skip_bits, stamp);
+  const size_t wave = i >> 6;
+  if ((threadIdx.x & 63u) == 0 && kyb_diag_stamp_buf != nullptr && wave < kyb_diag_stamp_cap) { kyb_diag_stamp_buf[2 * wave] = stamp[0]; kyb_diag_stamp_buf[2 * wave + 1] = stamp[1]; }
+#else
+  ge_scalarmult_ladder(r, a, m, skip_bits);
+#endif
+  store_proj(proj, stride, i, r.X, r.Y, r.Z);
+}
+
+// One halving pass of the segmented sum behind kyb_lincomb_batch: in each of the m groups (group g
+// starts at record g * gstride and currently holds `len` partial sums) record j + half is added onto
+// record j for j < len - half.  ceil(log2 t) passes leave the group total in the group's first record.
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_pair_sum(uint4* __restrict__ proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half) {
+  const size_t cnt = len - half;
+  const size_t idx = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (idx >= m * cnt) return;
+  const size_t g = idx / cnt, j = idx - g * cnt;
+  const size_t ia = g * gstride + j, ib = ia + half;
+  ge_p2 a, b, r;
+  load_proj_xy(a.X, a.Y, proj, stride, ia); load_proj_z(a.Z, proj, stride, ia);
+  load_proj_xy(b.X, b.Y, proj, stride, ib); load_proj_z(b.Z, proj, stride, ib);
+  ge_p2_add(r, a, b);
+  store_proj(proj, stride, ia, r.X, r.Y, r.Z);
+}
+
+// extended limbs -> projective staging records (input of the k_pair_sum passes of kyb_sum_batch)
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_ext_to_proj(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ proj, size_t stride) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  ge_p3 P;
+  load_ext(P, pts_ext, i);
+  store_proj(proj, stride, i, P.X, P.Y, P.Z);
+}
+
+
+namespace kyb { namespace launch {
+static inline unsigned blocks_for(size_t n) { return (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK); }
+hipError_t decode_or_identity(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok) {
+  hipLaunchKernelGGL(k_decode_or_identity, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, enc, n, out_ext, ok);
+  return hipGetLastError();
+}
+hipError_t mont_prep(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride) {
+  const size_t M = (n + FINISH_K - 1) / FINISH_K;
+  hipLaunchKernelGGL(k_mont_prep, dim3(blocks_for(M)), dim3(KYB_BLOCK), 0, st, pext, n, proj, stride);
+  return hipGetLastError();
+}
+hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, uint4* proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits) {
+  if (waves >= 4)      hipLaunchKernelGGL((k_mul_ladder<4>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits);
+  else if (waves == 3) hipLaunchKernelGGL((k_mul_ladder<3>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits);
+  else                 hipLaunchKernelGGL((k_mul_ladder<2>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits);
+  return hipGetLastError();
+}
+hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half) {
+  const size_t lanes = m * (len - half);
+  hipLaunchKernelGGL(k_pair_sum, dim3(blocks_for(lanes)), dim3(KYB_BLOCK), 0, st, proj, stride, m, gstride, len, half);
+  return hipGetLastError();
+}
+hipError_t ext_to_proj(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride) {
+  hipLaunchKernelGGL(k_ext_to_proj, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, pext, n, proj, stride);
+  return hipGetLastError();
+}
+#if defined(KYB_DIAG_STAMPS)
+hipError_t diag_set_stamp_buffer(uint64_t* dev_buf, size_t waves) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(kyb_diag_stamp_buf), &dev_buf, sizeof(dev_buf));
+  if (e != hipSuccess) return e;
+  return hipMemcpyToSymbol(HIP_SYMBOL(kyb_diag_stamp_cap), &waves, sizeof(waves));
+}
+#endif
+}}  // namespace kyb::launch

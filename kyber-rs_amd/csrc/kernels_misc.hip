@@ -1,0 +1,209 @@
+// Remaining kernels of the MI355X Ed25519 engine (one of the five translation units, see launch.h).
+//   k_finish            batched inversion + encode of projective staging records (ge.rs:112-122)
+//   k_encode_batched    marshal_binary of extended points with the same shared inversion (point.rs:35-41)
+//   k_add / k_equal / k_encode / k_decode   point.rs:179-241 / 35-51
+//   k_poly_eval         share/poly.rs:457-469
+#include <hip/hip_runtime.h>
+#include "launch.h"
+#include "ge_scalarmult.h"
+#include "device_batch_invert.h"
+using namespace kyb;
+#include "device_tables.h"
+
+// Batched finish: lane j owns items j, j+M, ..., j+(K-1)M (M = ceil(n/K)) and inverts the product of
+// their Z's once (Montgomery's trick): 3(K-1) M + one inversion per K items instead of 254 S + 11 M
+// per item.  A zero Z (only reachable from invalid extended inputs) is replaced by 1 in the product
+// and gets the reference's own answer for it (0^(p-2) = 0 -> x = y = 0), so one bad item cannot
+// disturb its K-1 neighbours.  Item i is read from record i * src_mul (src_mul = group length after a
+// segmented sum, 1 otherwise).
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_finish(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, size_t src_mul) {
+  const size_t M = (n + FINISH_K - 1) / FINISH_K;
+  const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (j >= M) return;
+  auto load = [&](int t, fe& z) {
+    const size_t i = j + (size_t)t * M;
+    fe one;
+    fe_one(one);
+    if (i < n) load_proj_z(z, proj, stride, i * src_mul); else fe_one(z);
+    fe_cmov(z, one, 1u - fe_is_nonzero(z));
+  };
+  auto emit = [&](int t, const fe& zinv) {
+    const size_t i = j + (size_t)t * M;
+    if (i >= n) return;
+    fe z, zi, zero, one, X, Y, x, y;
+    fe_zero(zero); fe_one(one);
+    load_proj_z(z, proj, stride, i * src_mul);
+    fe_copy(zi, zinv);
+    fe_cmov(zi, zero, 1u - fe_is_nonzero(z));          // Z == 0: the reference's 0^(p-2) = 0
+    load_proj_xy(X, Y, proj, stride, i * src_mul);
+    fe_mul(x, X, zi);
+    fe_mul(y, Y, zi);
+    if (out_enc != nullptr) {
+      uint32_t w[8];
+      fe_to_words(w, y);
+      w[7] ^= fe_is_negative(x) << 31;
+      store_words8(out_enc, i, w);
+    }
+    if (out_ext != nullptr) {
+      fe tt;
+      fe_mul(tt, x, y);
+      store_ext(out_ext, i, x, y, one, tt);
+    }
+  };
+  fe unused_prefix, unused_inv;
+  fe_one(unused_prefix);
+  batch_invert<0, FINISH_K>(unused_prefix, unused_inv, load, emit);
+}
+
+
+// marshal_binary of n extended points (point.rs:35-41 -> ge.rs:112-122) with one field inversion per FINISH_K
+// points: lane j owns points j, j+M, ... exactly as k_finish does, reading X, Y, Z straight from the 160-byte records.
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_encode_batched(const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc) {
+  const size_t M = (n + FINISH_K - 1) / FINISH_K;
+  const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (j >= M) return;
+  auto load_fe = [&](fe& h, size_t i, int which) {
+    const uint4* p = reinterpret_cast<const uint4*>(pts_ext) + 10 * i;
+    int32_t s[12];
+    // limbs [10*which, 10*which + 10) of the record: quads (10*which)/4 .. cover them with three 16-byte loads
+    const int first = (10 * which) >> 2, skip = (10 * which) & 3;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const uint4 v = p[first + q]; s[4 * q] = (int32_t)v.x; s[4 * q + 1] = (int32_t)v.y; s[4 * q + 2] = (int32_t)v.z; s[4 * q + 3] = (int32_t)v.w; }
+    int32_t t[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) t[k] = s[skip + k];
+    fe_from_ref10(h, t);
+  };
+  auto load = [&](int t, fe& z) {
+    const size_t i = j + (size_t)t * M;
+    fe one;
+    fe_one(one);
+    if (i < n) load_fe(z, i, 2); else fe_one(z);
+    fe_cmov(z, one, 1u - fe_is_nonzero(z));
+  };
+  auto emit = [&](int t, const fe& zinv) {
+    const size_t i = j + (size_t)t * M;
+    if (i >= n) return;
+    fe z, zi, zero, X, Y, x, y;
+    fe_zero(zero);
+    load_fe(z, i, 2);
+    fe_copy(zi, zinv);
+    fe_cmov(zi, zero, 1u - fe_is_nonzero(z));          // Z == 0: the reference's 0^(p-2) = 0
+    load_fe(X, i, 0);
+    load_fe(Y, i, 1);
+    fe_mul(x, X, zi);
+    fe_mul(y, Y, zi);
+    uint32_t w[8];
+    fe_to_words(w, y);
+    w[7] ^= fe_is_negative(x) << 31;
+    store_words8(out_enc, i, w);
+  };
+  fe unused_prefix, unused_inv;
+  fe_one(unused_prefix);
+  batch_invert<0, FINISH_K>(unused_prefix, unused_inv, load, emit);
+}
+
+// PubPoly::eval (poly.rs:457-469, shares :472-478) at n share indices: of one polynomial (per_poly == 0) or of
+// polynomial i / per_poly for item i (a verifier checking the deals of many dealers at its own index)
+template <bool SPLIT>
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_poly_eval(const int32_t* __restrict__ commits_ext, int t, const uint32_t* __restrict__ indices, size_t n, int nbits, size_t per_poly,
+            uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, uint4* __restrict__ proj, size_t stride) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  const bool live = i < n;
+  const size_t ii = live ? i : 0;
+  const uint32_t x = indices[ii] + 1u;
+  const size_t first = per_poly ? (ii / per_poly) * (size_t)t : 0;      // first commitment of this item's polynomial
+  ge_p2 r;
+  ge_poly_eval(r, [&](int j, ge_p3& c) { load_ext(c, commits_ext, first + (size_t)j); }, t, x, nbits);
+  if (SPLIT) { if (live) store_proj(proj, stride, i, r.X, r.Y, r.Z); }
+  else finish_point(r.X, r.Y, r.Z, out_enc, out_ext, ii, live);
+}
+// batched Point::eq (point.rs:227-241) without inversions
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_equal(const int32_t* __restrict__ a_ext, const int32_t* __restrict__ b_ext, size_t n, uint8_t* __restrict__ eq_out) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  ge_p3 A, B;
+  load_ext(A, a_ext, i);
+  load_ext(B, b_ext, i);
+  eq_out[i] = (uint8_t)ge_equal(A, B);
+}
+
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_add(const int32_t* __restrict__ a_ext, const int32_t* __restrict__ b_ext, size_t n, int32_t* __restrict__ out_ext, int subtract) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  ge_p3 A, B, R;
+  load_ext(A, a_ext, i);
+  load_ext(B, b_ext, i);
+  ge_cached c;
+  ge_p3_to_cached(c, B);
+  ge_cached_cneg(c, subtract ? 1u : 0u);
+  ge_p1p1 r;
+  ge_add(r, A, c);
+  ge_p1p1_to_p3(R, r);
+  store_ext(out_ext, i, R.X, R.Y, R.Z, R.T);
+}
+
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_encode(const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  ge_p3 P;
+  load_ext(P, pts_ext, i);
+  uint32_t w[8];
+  ge_encode(w, P.X, P.Y, P.Z);
+  store_words8(out_enc, i, w);
+}
+
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_decode(const uint8_t* __restrict__ enc, size_t n, int32_t* __restrict__ out_ext, uint8_t* __restrict__ ok_out) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words8(w, enc, i);
+  ge_p3 P;
+  const uint32_t ok = ge_decode(P, w);
+  store_ext(out_ext, i, P.X, P.Y, P.Z, P.T);
+  if (ok_out != nullptr) ok_out[i] = (uint8_t)ok;
+}
+
+
+namespace kyb { namespace launch {
+static inline unsigned blocks_for(size_t n) { return (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK); }
+hipError_t finish(hipStream_t st, const uint4* proj, size_t stride, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul) {
+  const size_t M = (n + FINISH_K - 1) / FINISH_K;
+  hipLaunchKernelGGL(k_finish, dim3(blocks_for(M)), dim3(KYB_BLOCK), 0, st, proj, stride, n, oenc, oext, src_mul);
+  return hipGetLastError();
+}
+hipError_t encode_batched(hipStream_t st, const int32_t* pext, size_t n, uint8_t* oenc) {
+  const size_t M = (n + FINISH_K - 1) / FINISH_K;
+  hipLaunchKernelGGL(k_encode_batched, dim3(blocks_for(M)), dim3(KYB_BLOCK), 0, st, pext, n, oenc);
+  return hipGetLastError();
+}
+hipError_t add(hipStream_t st, const int32_t* a, const int32_t* b, size_t n, int32_t* out, int subtract) {
+  hipLaunchKernelGGL(k_add, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, a, b, n, out, subtract);
+  return hipGetLastError();
+}
+hipError_t equal(hipStream_t st, const int32_t* a, const int32_t* b, size_t n, uint8_t* eq) {
+  hipLaunchKernelGGL(k_equal, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, a, b, n, eq);
+  return hipGetLastError();
+}
+hipError_t encode(hipStream_t st, const int32_t* pext, size_t n, uint8_t* oenc) {
+  hipLaunchKernelGGL(k_encode, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, pext, n, oenc);
+  return hipGetLastError();
+}
+hipError_t decode(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok) {
+  hipLaunchKernelGGL(k_decode, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, enc, n, out_ext, ok);
+  return hipGetLastError();
+}
+hipError_t poly_eval(bool split, hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly,
+                     uint8_t* oenc, int32_t* oext, uint4* proj, size_t stride) {
+  if (split) hipLaunchKernelGGL((k_poly_eval<true>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, commits, t, idx, n, nbits, per_poly, oenc, oext, proj, stride);
+  else       hipLaunchKernelGGL((k_poly_eval<false>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, commits, t, idx, n, nbits, per_poly, oenc, oext, proj, stride);
+  return hipGetLastError();
+}
+}}  // namespace kyb::launch

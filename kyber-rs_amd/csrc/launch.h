@@ -1,0 +1,72 @@
+// Host-callable launchers of every kernel group.  The library is built from seven translation units that hipcc
+// compiles in parallel (csrc/Makefile):
+//
+//   kernels_base.hip      fixed base: table builders, table checksum, k_mul_base64 (the default fixed-base kernel)
+//   kernels_base_alt.hip  radix-32 / radix-16 fixed-base kernels and the fused k_sign (selectable cross-checks)
+//   kernels_ladder.hip    variable base: k_decode_or_identity, k_mont_prep, k_mul_ladder, k_pair_sum, k_ext_to_proj
+//   kernels_window.hip    windowed variable-base k_mul (mul.algo=0, cross-check of the ladder)
+//   kernels_verify.hip    SHA-512 users: k_verify_prep / _r / _final, k_sign_hash, k_eddsa_prep
+//   kernels_misc.hip      k_finish, k_encode_batched, k_add, k_equal, k_encode, k_decode, k_poly_eval
+//   engine.hip            contexts, per-stream scratch, launch sequences, host-pointer pipeline, multi-device groups, C ABI
+//
+// A kernel is defined in exactly one unit; the engine reaches it through the plain C++ function declared here
+// (arguments = the kernel's own, plus stream and launch geometry), so no template or __global__ symbol crosses a
+// unit boundary.  Every launcher returns hipGetLastError() of its launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace kyb {
+
+constexpr int KYB_BLOCK = 256;      // threads per workgroup of every one-item-per-lane kernel
+constexpr int KYB_BLOCK32 = 1024;   // radix-32 fixed-base kernel
+constexpr int FINISH_K = 8;         // items per shared field inversion (k_finish, k_mont_prep, k_encode_batched)
+
+namespace launch {
+
+// ---- kernels_base.hip / kernels_base_alt.hip ----
+hipError_t build_tables(uint32_t* table, hipStream_t st);                       // radix-16, -32 and -64 images, then the embedded checksum
+hipError_t table_checksum(const uint32_t* table, uint64_t* out_dev, hipStream_t st);   // out_dev[0] = checksum of the image (embed slot excluded)
+hipError_t mul_base64(bool split, int block, int grid, hipStream_t st, const uint8_t* sc, const uint8_t* sc_b, size_t n_a, size_t n,
+                      uint8_t* oenc, int32_t* oext, const uint4* img64, uint4* proj, size_t stride, size_t offset);
+hipError_t mul_base32(bool split, int grid, hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint4* img32,
+                      uint4* proj, size_t stride, size_t offset);
+hipError_t mul_base16(int mode, int block, bool split, int grid, hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext,
+                      const uint4* img, uint4* proj, size_t stride, size_t offset);
+hipError_t sign_fused(int mode, int grid, hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n,
+                      uint8_t* sig, const uint4* img);
+
+// ---- kernels_ladder.hip ----
+hipError_t decode_or_identity(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok);
+hipError_t mont_prep(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride);
+hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, uint4* proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits);
+hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half);
+hipError_t ext_to_proj(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride);
+#if defined(KYB_DIAG_STAMPS)
+hipError_t diag_set_stamp_buffer(uint64_t* dev_buf, size_t waves);
+#endif
+
+// ---- kernels_verify.hip ----
+hipError_t verify_prep(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,
+                       uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf, int32_t* a_ext);
+hipError_t verify_prep_r(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* flags_r, uint4* proj, size_t stride, size_t offset);
+hipError_t verify_final(hipStream_t st, const uint4* proj, size_t stride, size_t n, const uint8_t* flags_a, const uint8_t* flags_r, int flavor, uint8_t* status);
+hipError_t sign_hash(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n,
+                     const uint8_t* r_enc, const uint8_t* a_enc, uint8_t* sig);
+hipError_t eddsa_prep(hipStream_t st, const uint8_t* seeds, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* xbuf, uint8_t* kbuf);
+
+// ---- kernels_misc.hip / kernels_window.hip ----
+hipError_t finish(hipStream_t st, const uint4* proj, size_t stride, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul);
+hipError_t encode_batched(hipStream_t st, const int32_t* pext, size_t n, uint8_t* oenc);
+hipError_t mul_window(int masked, bool from_enc, bool split, int grid, hipStream_t st, const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n,
+                      uint8_t* oenc, int32_t* oext, uint8_t* ok, uint4* ws, uint4* proj, size_t stride);
+hipError_t add(hipStream_t st, const int32_t* a, const int32_t* b, size_t n, int32_t* out, int subtract);
+hipError_t equal(hipStream_t st, const int32_t* a, const int32_t* b, size_t n, uint8_t* eq);
+hipError_t encode(hipStream_t st, const int32_t* pext, size_t n, uint8_t* oenc);
+hipError_t decode(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok);
+hipError_t poly_eval(bool split, hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly,
+                     uint8_t* oenc, int32_t* oext, uint4* proj, size_t stride);
+
+}  // namespace launch
+}  // namespace kyb

@@ -27,17 +27,10 @@ MADS_PER_STEP = 5 * 100 + 4 * 55 + 10 + 9          # 5 M + 4 S + the a24 multipl
 
 
 def build_diag():
-    src = os.path.join(ROOT, "kyber-rs_amd", "csrc", "kernels.hip")
-    csrc = os.path.dirname(src)
-    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)]
-    if os.path.exists(DIAG_LIB) and os.path.getmtime(DIAG_LIB) >= max(os.path.getmtime(d) for d in deps):
-        return DIAG_LIB
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
     os.makedirs(os.path.dirname(DIAG_LIB), exist_ok=True)
-    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-DKYB_DIAG_STAMPS", "-o", DIAG_LIB, src]
-    print("[build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return DIAG_LIB
+    return __graft_entry__.build_hip(extra_flags=("-DKYB_DIAG_STAMPS",), out=DIAG_LIB, objdir="_obj_stamps")
 
 
 def main():
@@ -46,8 +39,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=2.5)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02", "ladder_clock.json"))
     ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--no-build", action="store_true", help="use the diagnostic library as it is (it was built before the snapshot left for the GPU box)")
     args = ap.parse_args()
-    build_diag()
+    if not (args.no_build and os.path.exists(DIAG_LIB)):
+        build_diag()
     if args.build_only:
         return
     os.environ["KYB_HIP_LIB"] = DIAG_LIB
@@ -75,7 +70,7 @@ def main():
     eng.mul_base_dev(psc, out_ext=pts, stream=st)
     waves = (n + 63) // 64
     stamps = torch.zeros((waves, 2), dtype=torch.int64, device=dev)
-    lib = eng.lib
+    lib = kyber_rs_amd.load_library()      # the raw ctypes library (the engine sees it through its context proxy)
     lib.kyb_diag_set_stamp_buffer.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     lib.kyb_diag_set_stamp_buffer.restype = ctypes.c_int
     assert lib.kyb_diag_set_stamp_buffer(ctypes.c_void_p(stamps.data_ptr()), waves) == 0
