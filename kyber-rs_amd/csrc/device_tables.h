@@ -151,8 +151,9 @@ struct tbl_lds32 {
 struct tbl_lds64 {
   const uint32_t* t;  // LDS
   template <int E, bool SIGNED>
-  __device__ __forceinline__ void fetch(ge_precomp& c, const uint32_t* win, uint32_t src_lane) {
-    const uint32_t lane = threadIdx.x & 63u;
+  __device__ __forceinline__ void fetch(ge_precomp& c, const uint32_t* win, uint32_t src_lane, bool once = false) {
+    uint32_t lane = threadIdx.x & 63u;
+    if (once) asm volatile("" : "+v"(lane));     // a fetch outside the window loop: recompute the lane terms there instead of keeping them live across it
     const uint32_t mine = lane & (uint32_t)(E - 1);
     const uint32_t s = SIGNED ? (lane >> 5) & 1u : 0u;                 // this lane holds the negated entry
     const uint32_t* pa = win + (s ? 8 * E : 0);                        // plane A (ypx 0..7) or B (ymx 0..7)
@@ -190,7 +191,12 @@ struct tbl_lds64 {
   }
   __device__ __forceinline__ void select_top(ge_precomp& c, uint32_t idx) {
     const uint32_t lane = threadIdx.x & 63u;
-    fetch<16, false>(c, t + KYB_BASE64_TOP_BASE, (lane & 48u) | idx);
+    // The top window sits 161,280 bytes into LDS, beyond the 16-bit offset field of ds_read: folded as constants its
+    // nine plane addresses become nine loop-invariant VGPRs (which then spill in the 128-register build).  Behind an
+    // opaque offset they are one base register + small immediate offsets.
+    uint32_t top = KYB_BASE64_TOP_BASE;
+    asm volatile("" : "+v"(top));
+    fetch<16, false>(c, t + top, (lane & 48u) | idx, true);
   }
 };
 

@@ -113,6 +113,36 @@ __device__ __forceinline__ uint64_t kyb_col10(uint64_t acc, const uint32_t* A, c
       : "vcc");
   return acc;
 }
+#define KYB_M0(a, b) "v_mad_u64_u32 %0, vcc, %" #a ", %" #b ", 0\n\t"
+// first column of a product: the accumulator starts at the literal 0 (no v_mov_b64 to clear a register pair)
+__device__ __forceinline__ uint64_t kyb_col10z(const uint32_t* A, const uint32_t* B) {
+  uint64_t acc;
+  asm(KYB_M0(1, 11) KYB_M1(2, 12) KYB_M1(3, 13) KYB_M1(4, 14) KYB_M1(5, 15) KYB_M1(6, 16) KYB_M1(7, 17) KYB_M1(8, 18) KYB_M1(9, 19) KYB_M1(10, 20)
+      : "=&v"(acc)
+      : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(A[6]), "v"(A[7]), "v"(A[8]), "v"(A[9]),
+        "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]), "v"(B[5]), "v"(B[6]), "v"(B[7]), "v"(B[8]), "v"(B[9])
+      : "vcc");
+  return acc;
+}
+__device__ __forceinline__ uint64_t kyb_col6z(const uint32_t* A, const uint32_t* B) {
+  uint64_t acc;
+  asm(KYB_M0(1, 7) KYB_M1(2, 8) KYB_M1(3, 9) KYB_M1(4, 10) KYB_M1(5, 11) KYB_M1(6, 12)
+      : "=&v"(acc)
+      : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]), "v"(B[5])
+      : "vcc");
+  return acc;
+}
+// 2*a as v_add_u32 a, a: LLVM canonicalises x + x into v_lshlrev_b32, which issues at 4.4 cycles per wave-instruction on
+// gfx950 against 2.45 for the add (tools/microbench/valu_rates.hip).  One asm statement per GROUP of doublings, so there
+// is one asm boundary, not one per limb.  Outputs are early-clobber: none may share a register with a later input.
+__device__ __forceinline__ void kyb_dbl5(uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3, uint32_t& o4,
+                                         uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4) {
+  asm("v_add_u32 %0, %5, %5\n\tv_add_u32 %1, %6, %6\n\tv_add_u32 %2, %7, %7\n\tv_add_u32 %3, %8, %8\n\tv_add_u32 %4, %9, %9"
+      : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(o4) : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4));
+}
+__device__ __forceinline__ void kyb_dbl3(uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t a0, uint32_t a1, uint32_t a2) {
+  asm("v_add_u32 %0, %3, %3\n\tv_add_u32 %1, %4, %4\n\tv_add_u32 %2, %5, %5" : "=&v"(o0), "=&v"(o1), "=&v"(o2) : "v"(a0), "v"(a1), "v"(a2));
+}
 __device__ __forceinline__ uint64_t kyb_col6(uint64_t acc, const uint32_t* A, const uint32_t* B) {
   asm(KYB_M1(1, 7) KYB_M1(2, 8) KYB_M1(3, 9) KYB_M1(4, 10) KYB_M1(5, 11) KYB_M1(6, 12)
       : "+v"(acc)
@@ -181,12 +211,42 @@ KYB_HD void fe_reduce_weak(fe& h, const fe& f) {
   KYB_UNROLL for (int i = 1; i < 10; ++i) h.v[i] = (f.v[i] & KYB_MASK(i)) + c[i - 1];
 }
 
-// h = f*g.  f <= 6T, g <= 3.3T.  100 v_mad_u64_u32 + ~50 VALU.  Output tight.
-KYB_HD void fe_mul(fe& h, const fe& f, const fe& g) {
-  uint32_t g19[10], f2[10];
+// Carry out of the top column folded back into limbs 0 and 1: h0 = (r0 + 19 c) mod 2^26, h1 = r1 + ((r0 + 19 c) >> 26).
+// C32 = the caller guarantees c < 2^32 (column 9 stays below 2^57): then 19 c + r0 is ONE v_mad_u64_u32 on c's low word;
+// otherwise c may have 34 bits and the high word is folded separately (v_lshrrev + v_mad_u32_u24 more per product).
+template <bool C32>
+KYB_HD void fe_fold(fe& h, const uint32_t r[10], uint64_t acc) {
+  uint64_t t;
+  if (C32) {
+#if defined(KYB_HOST_TEST)
+    if (acc >> 32) kyb_host_overflow("fold32: top carry needs more than 32 bits");
+#endif
+    t = kyb_mad((uint32_t)acc, 19u, (uint64_t)r[0]);
+  } else {
+    t = (uint64_t)r[0] + acc * 19u;       // acc < 2^39
+  }
+  h.v[0] = (uint32_t)t & KYB_MASK(0);
+  h.v[1] = r[1] + (uint32_t)(t >> 26);
+  KYB_UNROLL for (int i = 2; i < 10; ++i) h.v[i] = r[i];
+}
+
+// 19 * g, limbs 1..9 (limb 0 unused): the wrap-around multiples of a product's second operand.  Loop-invariant operands
+// (the ladder's u(P)) compute it once.
+KYB_HD void fe_x19(uint32_t g19[10], const fe& g) {
+  g19[0] = 0;
   KYB_UNROLL for (int i = 1; i < 10; ++i) g19[i] = kyb_x19(g.v[i]);
+}
+
+// h = f*g with 19*g supplied.  Bounds as fe_mul.
+template <bool C32>
+KYB_HD void fe_mul_g19(fe& h, const fe& f, const fe& g, const uint32_t g19[10]) {
+  uint32_t f2[10];
+  f2[0] = f2[2] = f2[4] = f2[6] = f2[8] = 0;
+#if defined(KYB_ASM_COLUMNS)
+  kyb_dbl5(f2[1], f2[3], f2[5], f2[7], f2[9], f.v[1], f.v[3], f.v[5], f.v[7], f.v[9]);
+#else
   KYB_UNROLL for (int i = 1; i < 10; i += 2) f2[i] = kyb_x2(f.v[i], "f2");
-  g19[0] = 0; f2[0] = f2[2] = f2[4] = f2[6] = f2[8] = 0;
+#endif
   uint64_t acc = 0;
   uint32_t r[10];
   KYB_UNROLL for (int k = 0; k < 10; ++k) {
@@ -197,7 +257,7 @@ KYB_HD void fe_mul(fe& h, const fe& f, const fe& g) {
       ca[i] = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
       cb[i] = (i > k) ? g19[j] : g.v[j];
     }
-    acc = kyb_col10(acc, ca, cb);
+    acc = (k == 0) ? kyb_col10z(ca, cb) : kyb_col10(acc, ca, cb);
 #else
     KYB_UNROLL for (int i = 0; i < 10; ++i) {
       const int j = (k - i + 10) % 10;
@@ -210,20 +270,37 @@ KYB_HD void fe_mul(fe& h, const fe& f, const fe& g) {
     r[k] = (uint32_t)acc & KYB_MASK(k);
     acc >>= KYB_BITS(k);
   }
-  // acc < 2^39: fold 19*acc into limb 0 and ripple once into limb 1
-  uint64_t t = (uint64_t)r[0] + acc * 19u;
-  h.v[0] = (uint32_t)t & KYB_MASK(0);
-  h.v[1] = r[1] + (uint32_t)(t >> 26);
-  KYB_UNROLL for (int i = 2; i < 10; ++i) h.v[i] = r[i];
+  fe_fold<C32>(h, r, acc);
 }
 
-// h = f^2.  f <= 3.3T.  55 v_mad_u64_u32.  Output tight.
-KYB_HD void fe_sq(fe& h, const fe& f) {
+// h = f*g.  f <= 6T, g <= 3.3T.  100 v_mad_u64_u32 + ~45 VALU.  Output tight.
+KYB_HD void fe_mul(fe& h, const fe& f, const fe& g) {
+  uint32_t g19[10];
+  fe_x19(g19, g);
+  fe_mul_g19<false>(h, f, g, g19);
+}
+// The same for operands with bound(f) * bound(g) <= 6.3 (e.g. 3T x 2T, 6T x tight, tight x tight): column 9 then stays
+// below 63 * 2^51 + 2^33 < 2^57, the top carry fits 32 bits and the fold is 3 instructions shorter.
+KYB_HD void fe_mul_b6(fe& h, const fe& f, const fe& g) {
+  uint32_t g19[10];
+  fe_x19(g19, g);
+  fe_mul_g19<true>(h, f, g, g19);
+}
+
+// h = f^2.  f <= 3.3T (C32: f <= 2.5T, column 9 <= 62.5 * 2^51).  55 v_mad_u64_u32.  Output tight.
+template <bool C32>
+KYB_HD void fe_sq_t(fe& h, const fe& f) {
   uint32_t f2[10], f19[10], f38[10];
-  KYB_UNROLL for (int i = 0; i < 10; ++i) f2[i] = kyb_x2(f.v[i], "sq f2");
   KYB_UNROLL for (int i = 0; i < 10; ++i) { f19[i] = 0; f38[i] = 0; }
   KYB_UNROLL for (int i = 5; i < 10; ++i) f19[i] = kyb_x19(f.v[i]);
+#if defined(KYB_ASM_COLUMNS)
+  kyb_dbl5(f2[0], f2[1], f2[2], f2[3], f2[4], f.v[0], f.v[1], f.v[2], f.v[3], f.v[4]);
+  kyb_dbl5(f2[5], f2[6], f2[7], f2[8], f2[9], f.v[5], f.v[6], f.v[7], f.v[8], f.v[9]);
+  kyb_dbl3(f38[5], f38[7], f38[9], f19[5], f19[7], f19[9]);
+#else
+  KYB_UNROLL for (int i = 0; i < 10; ++i) f2[i] = kyb_x2(f.v[i], "sq f2");
   KYB_UNROLL for (int i = 5; i < 10; i += 2) f38[i] = kyb_x2(f19[i], "sq f38");
+#endif
   uint64_t acc = 0;
   uint32_t r[10];
   KYB_UNROLL for (int k = 0; k < 10; ++k) {
@@ -248,63 +325,64 @@ KYB_HD void fe_sq(fe& h, const fe& f) {
 #endif
     }
 #if defined(KYB_ASM_COLUMNS)
-    if ((k & 1) == 0) acc = kyb_col6(acc, ca, cb); else acc = kyb_col5(acc, ca, cb);   // 6 pairs in even columns, 5 in odd ones
+    if (k == 0) acc = kyb_col6z(ca, cb);
+    else if ((k & 1) == 0) acc = kyb_col6(acc, ca, cb); else acc = kyb_col5(acc, ca, cb);   // 6 pairs in even columns, 5 in odd ones
 #endif
     r[k] = (uint32_t)acc & KYB_MASK(k);
     acc >>= KYB_BITS(k);
   }
-  uint64_t t = (uint64_t)r[0] + acc * 19u;
-  h.v[0] = (uint32_t)t & KYB_MASK(0);
-  h.v[1] = r[1] + (uint32_t)(t >> 26);
-  KYB_UNROLL for (int i = 2; i < 10; ++i) h.v[i] = r[i];
+  fe_fold<C32>(h, r, acc);
 }
+KYB_HD void fe_sq(fe& h, const fe& f) { fe_sq_t<false>(h, f); }
+// f <= 2.5T (tight operands, sums of two tight ones)
+KYB_HD void fe_sq_b2(fe& h, const fe& f) { fe_sq_t<true>(h, f); }
 
 // h = f^(2^n), n >= 1 (rolled loop: one copy of the squaring body per call site)
 KYB_HD void fe_sqn(fe& h, const fe& f, int n) {
-  fe_sq(h, f);
+  fe_sq_b2(h, f);
 #if defined(__HIPCC__)
 #pragma unroll 1
 #endif
-  for (int i = 1; i < n; ++i) fe_sq(h, h);
+  for (int i = 1; i < n; ++i) fe_sq_b2(h, h);
 }
 
-// z^(2^250-1) and z^11, the shared prefix of both exponentiations
+// z^(2^250-1) and z^11, the shared prefix of both exponentiations (z <= 2.5T; everything after the first squaring is tight)
 KYB_HD void fe_pow_250_1(fe& z250, fe& z11, const fe& z) {
   fe z2, z9, t, z5, z10, z20, z50, z100;
-  fe_sq(z2, z);               // 2
+  fe_sq_b2(z2, z);               // 2
   fe_sqn(t, z2, 2);           // 8
-  fe_mul(z9, t, z);           // 9
-  fe_mul(z11, z9, z2);        // 11
-  fe_sq(t, z11);              // 22
-  fe_mul(z5, t, z9);          // 2^5-1
+  fe_mul_b6(z9, t, z);           // 9
+  fe_mul_b6(z11, z9, z2);        // 11
+  fe_sq_b2(t, z11);              // 22
+  fe_mul_b6(z5, t, z9);          // 2^5-1
   fe_sqn(t, z5, 5);
-  fe_mul(z10, t, z5);         // 2^10-1
+  fe_mul_b6(z10, t, z5);         // 2^10-1
   fe_sqn(t, z10, 10);
-  fe_mul(z20, t, z10);        // 2^20-1
+  fe_mul_b6(z20, t, z10);        // 2^20-1
   fe_sqn(t, z20, 20);
-  fe_mul(t, t, z20);          // 2^40-1
+  fe_mul_b6(t, t, z20);          // 2^40-1
   fe_sqn(t, t, 10);
-  fe_mul(z50, t, z10);        // 2^50-1
+  fe_mul_b6(z50, t, z10);        // 2^50-1
   fe_sqn(t, z50, 50);
-  fe_mul(z100, t, z50);       // 2^100-1
+  fe_mul_b6(z100, t, z50);       // 2^100-1
   fe_sqn(t, z100, 100);
-  fe_mul(t, t, z100);         // 2^200-1
+  fe_mul_b6(t, t, z100);         // 2^200-1
   fe_sqn(t, t, 50);
-  fe_mul(z250, t, z50);       // 2^250-1
+  fe_mul_b6(z250, t, z50);       // 2^250-1
 }
 // h = z^(p-2) = z^(2^255-21): 254 squarings + 11 multiplications (same count as fe.rs:857-944)
 KYB_HD void fe_invert(fe& h, const fe& z) {
   fe z250, z11;
   fe_pow_250_1(z250, z11, z);
   fe_sqn(z250, z250, 5);
-  fe_mul(h, z250, z11);
+  fe_mul_b6(h, z250, z11);
 }
 // h = z^((p-5)/8) = z^(2^252-3)  (fe.rs:946-1035)
 KYB_HD void fe_pow22523(fe& h, const fe& z) {
   fe z250, z11;
   fe_pow_250_1(z250, z11, z);
   fe_sqn(z250, z250, 2);
-  fe_mul(h, z250, z);
+  fe_mul_b6(h, z250, z);
 }
 
 // Canonical limbs (value in [0,p), limb_i < 2^bits_i).  Input: any limbs <= 2^31.

@@ -28,26 +28,33 @@ KYB_HD void ge_p1p1_0(ge_p1p1& h) { fe_zero(h.X); fe_one(h.Y); fe_one(h.Z); fe_o
 
 // ge.rs:211-215  (3M)
 KYB_HD void ge_p1p1_to_p2(ge_p2& r, const ge_p1p1& p) {
-  fe_mul(r.X, p.X, p.T);
-  fe_mul(r.Y, p.Z, p.Y);
-  fe_mul(r.Z, p.Z, p.T);
+  fe_mul_b6(r.X, p.X, p.T);     // 5T x tight
+  fe_mul_b6(r.Y, p.Z, p.Y);     // 3T x 2T
+  fe_mul_b6(r.Z, p.Z, p.T);     // 3T x tight
 }
 // ge.rs:292-297  (4M)
 KYB_HD void ge_p1p1_to_p3(ge_p3& r, const ge_p1p1& p) {
-  fe_mul(r.X, p.X, p.T);
-  fe_mul(r.Y, p.Z, p.Y);
-  fe_mul(r.Z, p.Z, p.T);
-  fe_mul(r.T, p.X, p.Y);
+  fe_mul_b6(r.X, p.X, p.T);     // 5T x tight
+  fe_mul_b6(r.Y, p.Z, p.Y);     // 3T x 2T
+  fe_mul_b6(r.Z, p.Z, p.T);     // 3T x tight
+  fe_mul(r.T, p.X, p.Y);        // 5T x 2T after a doubling: general fold
+}
+// the same for a p1p1 that came out of ge_add / ge_madd (X <= 3T): every product is within the short fold's bound
+KYB_HD void ge_p1p1_to_p3_after_add(ge_p3& r, const ge_p1p1& p) {
+  fe_mul_b6(r.X, p.X, p.T);
+  fe_mul_b6(r.Y, p.Z, p.Y);
+  fe_mul_b6(r.Z, p.Z, p.T);
+  fe_mul_b6(r.T, p.X, p.Y);     // 3T x 2T
 }
 
 // ge.rs:35-49  (4S).  p tight.
 KYB_HD void ge_p2_dbl(ge_p1p1& r, const fe& X, const fe& Y, const fe& Z) {
   fe xx, yy, zz, a, aa;
-  fe_sq(xx, X);
-  fe_sq(yy, Y);
-  fe_sq(zz, Z);
+  fe_sq_b2(xx, X);
+  fe_sq_b2(yy, Y);
+  fe_sq_b2(zz, Z);
   fe_add(a, X, Y);              // 2T
-  fe_sq(aa, a);
+  fe_sq_b2(aa, a);
   fe_add(r.Y, yy, xx);          // 2T
   fe_sub(r.Z, yy, xx);          // 3T
   fe_sub(r.X, aa, yy);          // 3T
@@ -64,10 +71,10 @@ KYB_HD void ge_add(ge_p1p1& r, const ge_p3& p, const ge_cached& q) {
   fe a, b, A, B, C, D, t;
   fe_add(a, p.Y, p.X);          // 2T
   fe_sub(b, p.Y, p.X);          // 3T
-  fe_mul(A, a, q.YpX);
-  fe_mul(B, b, q.YmX);
-  fe_mul(C, q.T2d, p.T);
-  fe_mul(D, p.Z, q.Z);
+  fe_mul_b6(A, a, q.YpX);       // 2T x 2T
+  fe_mul(B, b, q.YmX);          // 3T x 3T: general fold
+  fe_mul_b6(C, q.T2d, p.T);     // 2T x tight
+  fe_mul_b6(D, p.Z, q.Z);       // tight x tight
   fe_add(D, D, D);              // 2T
   fe_sub(r.X, A, B);            // 3T
   fe_add(r.Y, A, B);            // 2T
@@ -81,9 +88,9 @@ KYB_HD void ge_madd(ge_p1p1& r, const ge_p3& p, const ge_precomp& q) {
   fe a, b, A, B, C, D, t;
   fe_add(a, p.Y, p.X);
   fe_sub(b, p.Y, p.X);
-  fe_mul(A, a, q.ypx);
-  fe_mul(B, b, q.ymx);
-  fe_mul(C, q.xy2d, p.T);
+  fe_mul_b6(A, a, q.ypx);       // 2T x tight
+  fe_mul_b6(B, b, q.ymx);       // 3T x tight
+  fe_mul_b6(C, q.xy2d, p.T);    // 2T x tight
   fe_add(D, p.Z, p.Z);
   fe_sub(r.X, A, B);
   fe_add(r.Y, A, B);

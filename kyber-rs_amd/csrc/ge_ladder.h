@@ -82,6 +82,8 @@ KYB_HD void mont_prep_finish(mont_point& m, const ge_p3& P, const fe& dinv, uint
 KYB_HD void mont_ladder(fe& x2, fe& z2, fe& x3, fe& z3, const fe& u1, const uint32_t mag[8], int skip = 0) {
   fe_one(x2); fe_zero(z2); fe_copy(x3, u1); fe_one(z3);
   uint32_t swap = 0;
+  uint32_t u1_19[10];                    // 19 * u(P): the same nine premultiplies in every one of the 256 steps
+  fe_x19(u1_19, u1);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
@@ -100,6 +102,8 @@ KYB_HD void mont_ladder(fe& x2, fe& z2, fe& x3, fe& z3, const fe& u1, const uint
       // RFC 7748 swaps (x2,z2) <-> (x3,z3) here.  The swap only exchanges (a,b) with (c,d): da + cb is
       // symmetric under it and da - cb merely changes sign before being squared, so the differential
       // addition does not see it; only the two operands of the doubling need the selection.
+      // Bounds: every product below is (<= 3T) x (<= 2T) or tighter, every square of a sum is of <= 2T: the short fold
+      // (fe_mul_b6 / fe_sq_b2) applies; the two squares of differences (3T) take the general one.
       fe a, aa, b, bb, e, c, d, da, cb, t, sa, sb;
       fe_add(a, x2, z2);                 // 2T
       fe_sub(b, x2, z2);                 // 3T
@@ -108,20 +112,20 @@ KYB_HD void mont_ladder(fe& x2, fe& z2, fe& x3, fe& z3, const fe& u1, const uint
       fe_select(sa, a, c, swap);
       fe_select(sb, b, d, swap);
       swap = bit;
-      fe_sq(aa, sa);
+      fe_sq_b2(aa, sa);
       fe_sq(bb, sb);
-      fe_mul(da, d, a);                  // f 3T, g 2T
-      fe_mul(cb, b, c);                  // f 3T, g 2T
+      fe_mul_b6(da, d, a);               // f 3T, g 2T
+      fe_mul_b6(cb, b, c);               // f 3T, g 2T
       fe_sub(e, aa, bb);                 // 3T
       fe_add(t, da, cb);                 // 2T
-      fe_sq(x3, t);
+      fe_sq_b2(x3, t);
       fe_sub(t, da, cb);                 // 3T
       fe_sq(t, t);
-      fe_mul(z3, t, u1);
-      fe_mul(x2, aa, bb);
+      fe_mul_g19<true>(z3, t, u1, u1_19);
+      fe_mul_b6(x2, aa, bb);
       fe_mul_small(t, e, 121665u);       // a24 * E
       fe_add(t, t, aa);                  // 2T
-      fe_mul(z2, e, t);                  // f 3T, g 2T
+      fe_mul_b6(z2, e, t);               // f 3T, g 2T
     }
   }
   fe_cswap(x2, x3, swap);

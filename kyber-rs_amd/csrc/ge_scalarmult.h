@@ -98,7 +98,7 @@ KYB_HD void ge_scalarmult_base(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
     ge_precomp_cneg(c, neg);
     ge_p1p1 t;
     ge_madd(t, h, c);                              // 3M
-    ge_p1p1_to_p3(h, t);                           // 4M
+    ge_p1p1_to_p3_after_add(h, t);                 // 4M
   }
 }
 
@@ -257,7 +257,7 @@ KYB_HD void ge_scalarmult_base32(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
     ge_precomp_cneg(c, neg);
     ge_p1p1 t;
     ge_madd(t, h, c);
-    ge_p1p1_to_p3(h, t);
+    ge_p1p1_to_p3_after_add(h, t);
   }
   // a' < 0: negate (x -> -x, t -> -t)
   fe nx, nt;
@@ -353,7 +353,7 @@ KYB_HD void ge_scalarmult_base64(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
     tbl.select(c, pos, mag, neg);
     ge_p1p1 t;
     ge_madd(t, h, c);
-    ge_p1p1_to_p3(h, t);
+    ge_p1p1_to_p3_after_add(h, t);
   }
   {
     uint32_t mag, neg;
@@ -362,7 +362,7 @@ KYB_HD void ge_scalarmult_base64(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
     tbl.select_top(c, mag);
     ge_p1p1 t;
     ge_madd(t, h, c);
-    ge_p1p1_to_p3(h, t);
+    ge_p1p1_to_p3_after_add(h, t);
   }
   fe nx, nt;
   fe_neg(nx, h.X); fe_reduce_weak(nx, nx);

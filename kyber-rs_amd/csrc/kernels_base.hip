@@ -39,16 +39,25 @@ k_mul_base64(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ sc
   __syncthreads();
   tbl_lds64 tbl{reinterpret_cast<const uint32_t*>(lds_tbl)};
   const size_t nchunks = (n + BLOCK - 1) / BLOCK;
+  // Addressing: everything the 43-window loop does not need stays out of VGPRs across it.  The chunk's first item i0 is
+  // wave-uniform, so record addresses are (uniform base in SGPRs) + (32-bit lane offset), not 64-bit per-lane pointers
+  // (which the compiler hoists out of the chunk loop as invariants and then has to spill in the 128-register build).
   for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const size_t i = chunk * BLOCK + threadIdx.x;
-    const bool live = i < n;
-    const size_t ii = live ? i : 0;
+    const size_t i0 = chunk * BLOCK;
+    const uint32_t cnt = (uint32_t)((n - i0 < (size_t)BLOCK) ? n - i0 : (size_t)BLOCK);       // items of this chunk (>= 1)
+    const bool live = threadIdx.x < cnt;
+    const uint32_t t = live ? threadIdx.x : 0u;                                                  // dead lanes redo the chunk's first item
     uint32_t a[8];
-    if (ii < n_a) load_words8(a, scalars, ii); else load_words8(a, scalars_b, ii - n_a);
+    if (scalars_b == nullptr || i0 + BLOCK <= n_a) load_words8(a, scalars + 32 * i0, t);       // the usual case: one array (uniform branch)
+    else if (i0 >= n_a) load_words8(a, scalars_b + 32 * (i0 - n_a), t);
+    else if (i0 + t < n_a) load_words8(a, scalars + 32 * i0, t);                               // the one chunk that straddles the two arrays
+    else load_words8(a, scalars_b, (size_t)(i0 + t - n_a));
     ge_p3 h;
     ge_scalarmult_base64(h, a, tbl);
-    if (SPLIT) { if (live) store_proj(proj, proj_stride, proj_offset + i, h.X, h.Y, h.Z); }
-    else finish_point(h.X, h.Y, h.Z, out_enc, out_ext, ii, live);
+    uint32_t tl = threadIdx.x;
+    asm volatile("" : "+v"(tl));         // the lane's store address is formed here, after the loop (not hoisted out of the chunk loop and spilled)
+    if (SPLIT) { if (live) store_proj(proj + (proj_offset + i0), proj_stride, tl, h.X, h.Y, h.Z); }
+    else finish_point(h.X, h.Y, h.Z, out_enc ? out_enc + 32 * i0 : nullptr, out_ext ? out_ext + 40 * i0 : nullptr, t, live);
   }
 }
 

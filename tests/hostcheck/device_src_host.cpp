@@ -119,6 +119,24 @@ void hd_fe_sq_bound_probe(int kf100) {
   }
   fe_sq(h, f);
 }
+// the short-fold variants: fe_mul_b6 needs bound(f) * bound(g) <= 6.3, fe_sq_b2 needs f <= 2.5T
+void hd_fe_mul_b6_bound_probe(int kf100, int kg100) {
+  fe f, g, h;
+  for (int i = 0; i < 10; ++i) {
+    uint64_t T = (i & 1) ? (1u << 25) : (1u << 26);
+    f.v[i] = (uint32_t)(T * kf100 / 100);
+    g.v[i] = (uint32_t)(T * kg100 / 100);
+  }
+  fe_mul_b6(h, f, g);
+}
+void hd_fe_sq_b2_bound_probe(int kf100) {
+  fe f, h;
+  for (int i = 0; i < 10; ++i) {
+    uint64_t T = (i & 1) ? (1u << 25) : (1u << 26);
+    f.v[i] = (uint32_t)(T * kf100 / 100);
+  }
+  fe_sq_b2(h, f);
+}
 void hd_sc_muladd(uint8_t out[32], const uint8_t a[32], const uint8_t b[32], const uint8_t c[32]) {
   uint32_t wa[8], wb[8], wc[8], w[8];
   load_words(wa, a); load_words(wb, b); load_words(wc, c);

@@ -74,6 +74,18 @@ def test_limb_bound_contract(hd):
     hd.hd_fe_mul_bound_probe(640, 337)
     hd.hd_fe_sq_bound_probe(340)
     assert hd.hd_overflows() > base
+    # short-fold variants (top carry must fit 32 bits): bound(f) * bound(g) <= 6.3 resp. f <= 2.5T
+    base = hd.hd_overflows()
+    for kf, kg in [(300, 200), (200, 300), (600, 101), (190, 330), (505, 101), (250, 250), (630, 100), (210, 300)]:
+        hd.hd_fe_mul_b6_bound_probe(kf, kg)
+    for k in (101, 202, 250):
+        hd.hd_fe_sq_b2_bound_probe(k)
+    assert hd.hd_overflows() == base
+    hd.hd_fe_mul_b6_bound_probe(330, 200)
+    assert hd.hd_overflows() > base
+    base = hd.hd_overflows()
+    hd.hd_fe_sq_b2_bound_probe(262)
+    assert hd.hd_overflows() > base
 
 
 def test_recoding_matches_reference_recode(hd):
