@@ -254,8 +254,9 @@ int kyb_sum_batch(const int32_t* pts_ext, size_t m, size_t t, uint8_t* out_enc, 
 int kyb_sum_batch_dev(const int32_t* pts_ext, size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext, void* stream);
 
 /* ---- Point::eq, point.rs:227-241 -------------------------------------------- */
-/* eq[i] = 1 iff a[i] and b[i] are the same point (the reference compares the two encodings = two
- * inversions; here a projective cross-multiplication).  Inputs must be curve points (Z != 0). */
+/* eq[i] = 1 iff a[i] and b[i] have the same encoding (the reference compares the two encodings = two
+ * inversions; here a projective cross-multiplication).  Records with Z = 0 (`Point::default()`) behave as in the
+ * reference, where they encode as x = y = 0. */
 int kyb_equal_batch(const int32_t* a_ext, const int32_t* b_ext, size_t n, uint8_t* eq);
 int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, uint8_t* eq, void* stream);
 

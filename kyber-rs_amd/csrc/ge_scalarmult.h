@@ -152,14 +152,20 @@ KYB_HD void ge_poly_eval(ge_p2& out, LoadCommit load_commit, int t, uint32_t x, 
 }
 
 // Point equality without inversions (the reference's eq encodes both sides, point.rs:227-241):
-// X1 Z2 == X2 Z1 and Y1 Z2 == Y2 Z1.  Valid curve points only (Z != 0).
+// X1 Z2 == X2 Z1 and Y1 Z2 == Y2 Z1.  Total like the reference's: a record with Z = 0 (e.g. `Point::default()`, all-zero
+// limbs) encodes as x = y = 0 there (0^(p-2) = 0, ge.rs:112-122), so it equals another Z = 0 record and a Z != 0 record
+// only if that one's X and Y are both 0.
 KYB_HD uint32_t ge_equal(const ge_p3& a, const ge_p3& b) {
   fe l, r, d;
   fe_mul(l, a.X, b.Z); fe_mul(r, b.X, a.Z); fe_sub(d, l, r);
   const uint32_t xne = fe_is_nonzero(d);
   fe_mul(l, a.Y, b.Z); fe_mul(r, b.Y, a.Z); fe_sub(d, l, r);
   const uint32_t yne = fe_is_nonzero(d);
-  return 1u - (xne | yne);
+  const uint32_t cross = 1u - (xne | yne);
+  const uint32_t za = 1u - fe_is_nonzero(a.Z), zb = 1u - fe_is_nonzero(b.Z);
+  const uint32_t a00 = (1u - fe_is_nonzero(a.X)) & (1u - fe_is_nonzero(a.Y)), b00 = (1u - fe_is_nonzero(b.X)) & (1u - fe_is_nonzero(b.Y));
+  // za & zb -> equal; za only -> b must be (0, 0); zb only -> a must be (0, 0); neither -> the cross-multiplication
+  return (za & zb) | (za & (1u - zb) & b00) | (zb & (1u - za) & a00) | ((1u - za) & (1u - zb) & cross);
 }
 
 // --- plain-array policies (host-test build, and the one-off device table generator) ---

@@ -262,7 +262,12 @@ class Point {
     std::memcpy(ge, out, sizeof(ge));
   }
   size_t marshal_size() const { return 32; }
-  bool operator==(const Point& o) const { return marshal_binary() == o.marshal_binary(); }      // point.rs:227-241
+  // point.rs:227-241 compares the two encodings (two field inversions); the engine compares projectively, same answer
+  bool operator==(const Point& o) const {
+    uint8_t eq = 0;
+    detail::engine_must(kyb_equal_batch(ge, o.ge, 1, &eq), "Point::eq");
+    return eq != 0;
+  }
   bool operator!=(const Point& o) const { return !(*this == o); }
   std::string hex() const {
     static const char* d = "0123456789abcdef";

@@ -1,0 +1,81 @@
+//! `extern "C"` block for include/kyber_ed25519.h (ABI version 2).  One line per entry point the Rust side binds.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+use std::sync::Once;
+
+pub type size_t = usize;
+/// opaque `kyb_ctx` / `kyb_group`
+#[repr(C)] pub struct kyb_ctx { _p: [u8; 0] }
+#[repr(C)] pub struct kyb_group { _p: [u8; 0] }
+
+pub const KYB_ABI_VERSION: c_int = 2;
+
+extern "C" {
+    pub fn kyb_abi_version() -> c_int;
+    pub fn kyb_init(device: c_int) -> c_int;
+    pub fn kyb_shutdown();
+    pub fn kyb_last_error() -> *const c_char;
+    pub fn kyb_sync(stream: *mut c_void) -> c_int;
+    pub fn kyb_stream_release(stream: *mut c_void) -> c_int;
+    // contexts and multi-device groups (one Rust process driving every GPU of a node)
+    pub fn kyb_ctx_create(device: c_int, build_table: c_int, out: *mut *mut kyb_ctx) -> c_int;
+    pub fn kyb_ctx_destroy(ctx: *mut kyb_ctx) -> c_int;
+    pub fn kyb_ctx_set_current(ctx: *mut kyb_ctx) -> c_int;
+    pub fn kyb_group_create(devices: *const c_int, n: c_int, out: *mut *mut kyb_group) -> c_int;
+    pub fn kyb_group_destroy(g: *mut kyb_group);
+    pub fn kyb_group_size(g: *const kyb_group) -> c_int;
+    pub fn kyb_group_ctx(g: *mut kyb_group, rank: c_int) -> *mut kyb_ctx;
+    pub fn kyb_group_table_transport(g: *const kyb_group) -> *const c_char;
+    pub fn kyb_group_mul_base_batch(g: *mut kyb_group, scalars: *const u8, n: size_t, out_enc: *mut u8, out_ext: *mut i32) -> c_int;
+    pub fn kyb_group_mul_batch(g: *mut kyb_group, scalars: *const u8, pts_enc: *const u8, pts_ext: *const i32, n: size_t,
+                               out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8) -> c_int;
+    pub fn kyb_group_schnorr_sign_batch(g: *mut kyb_group, x: *const u8, k: *const u8, msgs: *const u8, msg_off: *const u32, n: size_t, sig: *mut u8) -> c_int;
+    pub fn kyb_group_verify_batch(g: *mut kyb_group, pubs: *const u8, msgs: *const u8, msg_off: *const u32, sigs: *const u8, n: size_t,
+                                  flavor: c_int, status: *mut u8) -> c_int;
+    // Point::mul / add / sub / marshal / unmarshal / eq
+    pub fn kyb_mul_base_batch(scalars: *const u8, n: size_t, out_enc: *mut u8, out_ext: *mut i32) -> c_int;
+    pub fn kyb_mul_batch(scalars: *const u8, pts_enc: *const u8, pts_ext: *const i32, n: size_t,
+                         out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8) -> c_int;
+    pub fn kyb_mul_batch_dev(scalars: *const u8, pts_enc: *const u8, pts_ext: *const i32, n: size_t,
+                             out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8, stream: *mut c_void) -> c_int;
+    pub fn kyb_add_batch(a_ext: *const i32, b_ext: *const i32, n: size_t, out_ext: *mut i32, subtract: c_int) -> c_int;
+    pub fn kyb_encode_batch(pts_ext: *const i32, n: size_t, out_enc: *mut u8) -> c_int;
+    pub fn kyb_decode_batch(enc: *const u8, n: size_t, out_ext: *mut i32, ok: *mut u8) -> c_int;
+    pub fn kyb_equal_batch(a_ext: *const i32, b_ext: *const i32, n: size_t, eq: *mut u8) -> c_int;
+    // signing / verification
+    pub fn kyb_schnorr_sign_batch(x: *const u8, k: *const u8, msgs: *const u8, msg_off: *const u32, n: size_t, sig: *mut u8) -> c_int;
+    pub fn kyb_schnorr_sign_keyed_batch(x: *const u8, pubs: *const u8, k: *const u8, msgs: *const u8, msg_off: *const u32, n: size_t, sig: *mut u8) -> c_int;
+    pub fn kyb_eddsa_sign_batch(seeds: *const u8, msgs: *const u8, msg_off: *const u32, n: size_t, sig: *mut u8, pub_out: *mut u8) -> c_int;
+    pub fn kyb_eddsa_sign_keyed_batch(seeds: *const u8, pubs: *const u8, msgs: *const u8, msg_off: *const u32, n: size_t, sig: *mut u8) -> c_int;
+    pub fn kyb_verify_batch(pubs: *const u8, msgs: *const u8, msg_off: *const u32, sigs: *const u8, n: size_t, flavor: c_int, status: *mut u8) -> c_int;
+    // public polynomials
+    pub fn kyb_pubpoly_eval_batch(commits_ext: *const i32, t: size_t, indices: *const u32, n: size_t, out_enc: *mut u8, out_ext: *mut i32) -> c_int;
+    pub fn kyb_pubpoly_eval_multi_batch(commits_ext: *const i32, t: size_t, m: size_t, indices: *const u32, k: size_t, out_enc: *mut u8, out_ext: *mut i32) -> c_int;
+    pub fn kyb_lincomb_batch(scalars: *const u8, pts_enc: *const u8, pts_ext: *const i32, shared_points: c_int, m: size_t, t: size_t,
+                             out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8) -> c_int;
+    pub fn kyb_sum_batch(pts_ext: *const i32, m: size_t, t: size_t, out_enc: *mut u8, out_ext: *mut i32) -> c_int;
+    // page-locked batch buffers (optional: pageable slices work, through the engine's bounce buffers)
+    pub fn kyb_host_alloc(bytes: size_t) -> *mut c_void;
+    pub fn kyb_host_free(p: *mut c_void);
+}
+
+static INIT: Once = Once::new();
+
+/// `kyb_init(KYBER_HIP_DEVICE or 0)` once per process; every trait method calls it first (cheap after the first time).
+pub fn ensure_init() {
+    INIT.call_once(|| {
+        let dev = std::env::var("KYBER_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
+        unsafe {
+            assert_eq!(kyb_abi_version(), KYB_ABI_VERSION, "libkyber_ed25519_hip.so has another ABI version");
+        }
+        must(unsafe { kyb_init(dev) }, "kyb_init");
+    });
+}
+
+/// The trait methods are infallible (`mul` returns `Self`, group.rs:139): an engine failure cannot be reported and panics.
+pub fn must(rc: c_int, what: &str) {
+    if rc != 0 {
+        let msg = unsafe { std::ffi::CStr::from_ptr(kyb_last_error()) }.to_string_lossy().into_owned();
+        panic!("kyber edwards25519_hip: {what} failed ({rc}): {msg}");
+    }
+}

@@ -359,6 +359,15 @@ def test_pubpoly_eval_and_equal(engine, oracle):
     eq = engine.equal(a, b)
     assert eq.all()
     assert not engine.equal(a, np.roll(a, 1, axis=0)).any()
+    # records with Z = 0 (Point::default(): all-zero limbs) follow the reference's encode-and-compare: they encode as x = y = 0
+    zero = np.zeros(40, dtype=np.int32)
+    z_only = zero.copy(); z_only[0] = 5; z_only[10] = 7              # X, Y non-zero, Z = 0: still encodes as (0, 0)
+    xy0 = zero.copy(); xy0[20] = 3                                   # X = Y = 0, Z = 3: affine (0, 0)
+    pairs = [(zero, zero), (zero, z_only), (zero, xy0), (xy0, z_only), (zero, a[0]), (a[0], z_only), (xy0, a[0]), (a[0], a[0])]
+    pa, pb = np.stack([x for x, _ in pairs]), np.stack([y for _, y in pairs])
+    want_eq = [oracle.encode(x) == oracle.encode(y) for x, y in pairs]
+    assert want_eq == [True, True, True, True, False, False, False, True]
+    assert engine.equal(pa, pb).astype(bool).tolist() == want_eq
     # check (poly.rs:526-530): eval(i) == s_i * B for the matching private polynomial
     coeffs = [int.from_bytes(bytes(c), "little") for c in synth.scalars(t, 50)]
     shares = [sum(c * pow(int(i) + 1, j, synth.L) for j, c in enumerate(coeffs)) % synth.L for i in idx[:64]]

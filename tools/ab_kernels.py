@@ -18,9 +18,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(lib_path, workloads, steps, n):
+def child(lib_spec, workloads, steps, n):
     import numpy as np
     import torch
+    lib_path, *opts = lib_spec.split("@")          # path.so@key=value@key=value: engine options set after kyb_init
     lib = ctypes.CDLL(lib_path)
     vp, sz = ctypes.c_void_p, ctypes.c_size_t
     lib.kyb_init.argtypes = [ctypes.c_int]
@@ -29,6 +30,10 @@ def child(lib_path, workloads, steps, n):
     lib.kyb_schnorr_sign_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     lib.kyb_verify_batch_dev.argtypes = [vp, vp, vp, vp, sz, ctypes.c_int, vp, vp]
     assert lib.kyb_init(0) == 0
+    lib.kyb_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    for o in opts:
+        key, val = o.split("=")
+        assert lib.kyb_set_option(key.encode(), int(val)) == 0, o
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(11)
     sc_np = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
@@ -88,7 +93,7 @@ def main():
     acc = {lib: {w: [] for w in wl} for lib in a.libs}
     for r in range(a.rounds):
         for lib in a.libs:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), lib, "--child", os.path.abspath(lib), "--steps", str(a.steps), "--n", str(a.n),
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), lib, "--child", os.path.abspath(lib.split("@")[0]) + lib[len(lib.split("@")[0]):], "--steps", str(a.steps), "--n", str(a.n),
                                   "--workloads", a.workloads], capture_output=True, text=True)
             line = [ln for ln in out.stdout.split("\n") if ln.startswith("AB_RESULT ")]
             if not line:
