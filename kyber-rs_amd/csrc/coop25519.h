@@ -1,0 +1,163 @@
+// Lane-cooperative GF(2^255-19) arithmetic for SMALL batches (device only).
+//
+// The batch kernels give every item one lane: a variable-base multiplication is then a serial chain of ~330,000
+// instructions that ONE wavefront walks alone (0.9 ms), however few items the call carries — which is what unmodified
+// protocol code does (Point::mul one at a time: poly.rs:198, vss.rs:300-303, schnorr_sig.rs:32-35, key_pair.rs:66).
+// Here ONE ITEM OWNS A WAVEFRONT: a field element is spread over ten lanes (limb k in lane k of a 16-lane row), a
+// wavefront holds four rows, and the four independent multiplications of a ladder level / of a point addition run side by
+// side, so the dependent chain is ~60 instructions per level instead of ~140 per multiplication.
+//
+//   quad (`cq`)    one VGPR: row r = lanes 16r .. 16r+15 holds limbs 0..9 of element r in its first ten lanes, 0 in the rest
+//   cmul4(F, G)    four products F_r * G_r.  Lane k forms column k: sum_i f_i * g_{(k-i) mod 10} * m(i,k), with f_i broadcast and
+//                  g rotated inside the row by ds_bpermute_b32 and the 2x / 19x / 38x factors of the radix-2^25.5 product
+//                  (fe25519.h) as the per-lane constant m(i,k) applied to the broadcast f_i — so F must be TIGHT (<= 1.01T:
+//                  38 f_i < 2^32), G may be lazy (<= 4T).  Carries travel between lanes: a three-way split of the 64-bit
+//                  column (own limb / next limb / limb after that, x19 across the wrap) and one more light pass.
+//   cnorm(V)       that light pass alone: any limbs < 2^31 -> tight
+//   rows are moved with ds_bpermute_b32 and per-lane index constants; additions are ONE instruction for four elements.
+//
+// Same limb format and bounds notation as fe25519.h; results are bit-identical to the one-lane code (tests compare both
+// paths with the oracle).  Constant time: the instruction stream and every lane index are independent of secret data except
+// the row index of the ladder's conditional swap, which goes through the conflict-free ds_bpermute crossbar exactly like the
+// window selection of the fixed-base kernel.
+#pragma once
+#include "fe25519.h"
+
+namespace kyb {
+namespace coop {
+
+typedef uint32_t cq;      // one lane's share of a quad
+
+// per-lane constants of the cooperative arithmetic (computed once per kernel)
+struct lane_consts {
+  uint32_t lane, row, k;          // k = lane & 15
+  uint32_t active;                // k < 10
+  uint32_t mask, bits;            // of limb k
+  uint32_t mask_next;             // of limb k+1 (mod 10)
+  uint32_t p2;                    // limb k of 2p (0 in inactive lanes)
+  uint32_t c1, c2;                // 19 where the carry from lane k-1 / k-2 crosses the wrap (k == 0 / k < 2), else 1; 0 in inactive lanes
+  int prev1, prev2;               // byte index (4 * lane) of lanes k-1 and k-2 of the same row (mod 10); own lane when inactive
+  int bidx[10];                   // byte index of lane i of the same row
+  int ridx[10];                   // byte index of lane (k - i) mod 10 of the same row
+  uint32_t mfac[10];              // m(i, k) in {1, 2, 19, 38}; 0 in inactive lanes
+};
+
+__device__ __forceinline__ void lane_consts_init(lane_consts& c) {
+  const uint32_t p2v[10] = KYB_FE_2P;
+  c.lane = threadIdx.x & 63u;
+  c.row = c.lane >> 4;
+  c.k = c.lane & 15u;
+  c.active = c.k < 10u;
+  const uint32_t k = c.active ? c.k : 0u;
+  c.bits = (k & 1u) ? 25u : 26u;
+  c.mask = c.active ? ((1u << c.bits) - 1u) : 0u;
+  c.mask_next = c.active ? ((k & 1u) ? 0x3ffffffu : 0x1ffffffu) : 0u;      // limb k+1 has the other width
+  uint32_t p2 = 0;
+  KYB_UNROLL for (int j = 0; j < 10; ++j) p2 = (k == (uint32_t)j) ? p2v[j] : p2;
+  c.p2 = c.active ? p2 : 0u;
+  c.c1 = c.active ? (k == 0u ? 19u : 1u) : 0u;
+  c.c2 = c.active ? (k < 2u ? 19u : 1u) : 0u;
+  const uint32_t base = c.row << 4;
+  c.prev1 = c.active ? (int)((base + (k + 9u) % 10u) << 2) : (int)(c.lane << 2);
+  c.prev2 = c.active ? (int)((base + (k + 8u) % 10u) << 2) : (int)(c.lane << 2);
+  KYB_UNROLL for (int i = 0; i < 10; ++i) {
+    c.bidx[i] = (int)((base + (uint32_t)i) << 2);
+    const uint32_t j = (k + 10u - (uint32_t)i) % 10u;               // g index of term i in column k
+    c.ridx[i] = c.active ? (int)((base + j) << 2) : (int)(c.lane << 2);
+    const uint32_t wrap = (uint32_t)i > k;                              // i + j >= 10
+    const uint32_t oo = ((uint32_t)i & 1u) & (j & 1u);
+    c.mfac[i] = c.active ? ((wrap ? 19u : 1u) * (oo ? 2u : 1u)) : 0u;
+  }
+}
+
+__device__ __forceinline__ cq bperm(int idx, cq v) { return (cq)__builtin_amdgcn_ds_bpermute(idx, (int)v); }
+
+// byte-index vector that makes row r read row p_r (same limb position)
+__device__ __forceinline__ int rowperm_idx(const lane_consts& c, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3) {
+  const uint32_t src = c.row == 0 ? p0 : (c.row == 1 ? p1 : (c.row == 2 ? p2 : p3));
+  return (int)(((src << 4) | c.k) << 2);
+}
+
+// light carry pass: limbs < 2^31 in, tight (<= mask + 19 * 64) out.  4 instructions + one cross-lane move.
+__device__ __forceinline__ cq cnorm(const lane_consts& c, cq v) {
+  const uint32_t lo = v & c.mask;
+  const uint32_t cy = v >> c.bits;
+  const uint32_t cin = bperm(c.prev1, cy);
+  return lo + cin * c.c1;
+}
+
+// carry propagation of four 64-bit column vectors -> tight quad
+__device__ __forceinline__ cq ccarry(const lane_consts& c, uint64_t s) {
+  const uint32_t lo = (uint32_t)s & c.mask;
+  const uint64_t t = s >> c.bits;
+  const uint32_t mid = (uint32_t)t & c.mask_next;            // belongs to limb k+1
+  const uint32_t hi = (uint32_t)(s >> 51);                   // belongs to limb k+2 (26 + 25 bits up); < 2^13
+  const uint32_t mid_in = bperm(c.prev1, mid);
+  const uint32_t hi_in = bperm(c.prev2, hi);
+  const uint32_t v = lo + mid_in * c.c1 + hi_in * c.c2;      // < 2^26 + 19 * 2^26 + 19 * 2^13
+  return cnorm(c, v);
+}
+
+// four products; F tight, G <= 4T
+__device__ __forceinline__ cq cmul4(const lane_consts& c, cq F, cq G) {
+  uint32_t fb[10], gr[10];
+  KYB_UNROLL for (int i = 0; i < 10; ++i) fb[i] = bperm(c.bidx[i], F);
+  gr[0] = G;
+  KYB_UNROLL for (int i = 1; i < 10; ++i) gr[i] = bperm(c.ridx[i], G);
+  uint64_t acc = (uint64_t)(fb[0] * c.mfac[0]) * gr[0];
+  KYB_UNROLL for (int i = 1; i < 10; ++i) acc += (uint64_t)(fb[i] * c.mfac[i]) * gr[i];
+  return ccarry(c, acc);
+}
+__device__ __forceinline__ cq csq4(const lane_consts& c, cq F) { return cmul4(c, F, F); }
+
+// element-wise on four elements at once
+__device__ __forceinline__ cq cadd(cq a, cq b) { return a + b; }
+__device__ __forceinline__ cq csub(const lane_consts& c, cq a, cq b) { return a + (c.p2 - b); }      // b <= 2T; result <= bound(a) + 2T
+__device__ __forceinline__ cq csel(bool take_b, cq a, cq b) { return take_b ? b : a; }
+
+// ---- replicated one-lane form <-> quad ----------------------------------------------------------------------------
+// every lane holds the same `fe` (the irregular parts of a multiplication run replicated on all lanes)
+__device__ __forceinline__ cq quad_row_from_fe(const lane_consts& c, cq q, uint32_t r, const fe& f) {
+  uint32_t v = 0;
+  KYB_UNROLL for (int j = 0; j < 10; ++j) v = (c.k == (uint32_t)j) ? f.v[j] : v;
+  return (c.row == r && c.active) ? v : q;
+}
+__device__ __forceinline__ void fe_from_quad_row(const lane_consts& c, fe& f, cq q, uint32_t r) {
+  (void)c;
+  KYB_UNROLL for (int j = 0; j < 10; ++j) f.v[j] = bperm((int)(((r << 4) | (uint32_t)j) << 2), q);
+}
+
+// z^(p-2) of all four rows (fe_invert's chain, fe25519.h): 254 squarings + 11 products, each one cmul4.  Rows holding 0 stay 0.
+__device__ __forceinline__ cq csqn(const lane_consts& c, cq f, int n) {
+  cq h = csq4(c, f);
+#pragma unroll 1
+  for (int i = 1; i < n; ++i) h = csq4(c, h);
+  return h;
+}
+__device__ __forceinline__ cq cinv(const lane_consts& c, cq z) {
+  const cq z2 = csq4(c, z);
+  cq t = csqn(c, z2, 2);
+  const cq z9 = cmul4(c, t, z);
+  const cq z11 = cmul4(c, z9, z2);
+  t = csq4(c, z11);
+  const cq z5 = cmul4(c, t, z9);               // 2^5 - 1
+  t = csqn(c, z5, 5);
+  const cq z10 = cmul4(c, t, z5);              // 2^10 - 1
+  t = csqn(c, z10, 10);
+  const cq z20 = cmul4(c, t, z10);             // 2^20 - 1
+  t = csqn(c, z20, 20);
+  t = cmul4(c, t, z20);                        // 2^40 - 1
+  t = csqn(c, t, 10);
+  const cq z50 = cmul4(c, t, z10);             // 2^50 - 1
+  t = csqn(c, z50, 50);
+  const cq z100 = cmul4(c, t, z50);            // 2^100 - 1
+  t = csqn(c, z100, 100);
+  t = cmul4(c, t, z100);                       // 2^200 - 1
+  t = csqn(c, t, 50);
+  t = cmul4(c, t, z50);                        // 2^250 - 1
+  t = csqn(c, t, 5);
+  return cmul4(c, t, z11);                     // 2^255 - 21
+}
+
+}  // namespace coop
+}  // namespace kyb

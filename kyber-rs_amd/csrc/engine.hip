@@ -36,9 +36,9 @@ thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
 enum KernelId { KID_MUL, KID_MUL_BASE, KID_FINISH, KID_SIGN, KID_SIGN_HASH, KID_VERIFY_PREP, KID_VERIFY_FINAL, KID_POLY_EVAL, KID_MONT_PREP,
-                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_COUNT };
+                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_COUNT };
 const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval",
-                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched"};
+                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   std::mutex mu;                  // begin / read / every ProfScope: callable from any thread
@@ -97,6 +97,8 @@ struct Ctx {
   std::atomic<int> opt_ladder_waves{3};       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
   std::atomic<int> opt_finish{1};             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
   std::atomic<int> opt_finish_min{1};         // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size; cross-check)
+  std::atomic<int> opt_coop_max{2048};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured at 2048, profiles/r02/coop_kernel_times.log)
+  std::atomic<int> opt_coop_base_max{2048};      // fixed base: the same
   std::atomic<int> opt_encode_batched{1};     // kyb_encode_batch: 1 shared inversion per 8 points (k_encode_batched), 0 one inversion per point (k_encode)
   std::mutex mu;          // host-pointer API: staging buffers + engine streams of this context
   std::mutex launch_mu;   // every launch_* entry: per-stream scratch bookkeeping (calls from any thread, any stream)
@@ -207,6 +209,7 @@ bool is_pinned(const void* p) {
 // One host-pointer call at a time per CONTEXT (g.mu); callers that want several in flight use several contexts.
 struct HostArr { const void* in; void* out; size_t bytes; };    // per-item size; exactly one of in/out, or neither = absent
 constexpr size_t PIPE_MIN_ITEMS = (size_t)1 << 16;
+constexpr size_t ZERO_COPY_BYTES = (size_t)1 << 19;      // host-pointer calls up to this size skip the copies: kernels work on page-locked host memory
 constexpr int PIPE_CHUNKS = 8;
 template <class Fn>
 int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
@@ -215,6 +218,22 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
   const size_t cap = (((n + nchunks - 1) / nchunks) + 1023) & ~(size_t)1023;      // items per chunk
   size_t off[8], total = 0;
   for (int k = 0; k < na; ++k) { off[k] = total; total += up256(arrs[k].bytes * cap); }
+  if (nchunks == 1 && total <= ZERO_COPY_BYTES) {
+    // small batch: kernels on the page-locked buffer itself (see HostCall::run)
+    int rc = ensure_pin(g, 0, ZERO_COPY_BYTES);
+    if (rc) return rc;
+    uint8_t* dptr[8];
+    for (int k = 0; k < na; ++k) {
+      dptr[k] = (arrs[k].in || arrs[k].out) ? g.pin[0] + off[k] : nullptr;
+      if (arrs[k].in) memcpy(dptr[k], arrs[k].in, arrs[k].bytes * n);
+    }
+    rc = launch(g.stream, n, dptr);
+    if (rc) return rc;
+    HIPCK(hipStreamSynchronize(g.stream));
+    for (int k = 0; k < na; ++k)
+      if (arrs[k].out) memcpy(arrs[k].out, g.pin[0] + off[k], arrs[k].bytes * n);
+    return KYB_OK;
+  }
   int rc = ensure_stage(g, total);
   if (rc) return rc;
   if (nchunks > 1) { rc = ensure_stage2(g, total); if (rc) return rc; }
@@ -310,13 +329,30 @@ class HostCall {
   int inout(const void* p_in, void* p_out, size_t bytes) { return add(p_in, p_out, bytes, 0); }      // one device array, filled from p_in and/or returned to p_out
   void secret() { secret_ = true; }
   template <class T = uint8_t>
-  T* dev(int slot) const { return a_[slot].present ? reinterpret_cast<T*>(g_.stage + a_[slot].off) : nullptr; }
+  T* dev(int slot) const { return a_[slot].present ? reinterpret_cast<T*>(base_ + a_[slot].off) : nullptr; }
   template <class Body>
   int run(Body body) {
     Ctx& g = g_;
     std::lock_guard<std::mutex> lk(g.mu);
+    if (total_ <= ZERO_COPY_BYTES) {
+      // small call: the kernels read and write the context's page-locked buffer directly over PCIe — no hipMemcpy at all
+      // (each costs ~10 us of runtime work, more than the transfer), one launch sequence and one stream synchronisation
+      int rc = ensure_pin(g, 0, ZERO_COPY_BYTES);
+      if (rc) return rc;
+      base_ = g.pin[0];
+      for (int i = 0; i < n_; ++i)
+        if (a_[i].src && a_[i].bytes) memcpy(base_ + a_[i].off, a_[i].src, a_[i].bytes);
+      rc = body(g.stream);
+      if (rc) return rc;
+      HIPCK(hipStreamSynchronize(g.stream));
+      for (int i = 0; i < n_; ++i)
+        if (a_[i].dst && a_[i].bytes) memcpy(a_[i].dst, base_ + a_[i].off, a_[i].bytes);
+      if (secret_ && total_) memset(base_, 0, total_);
+      return KYB_OK;
+    }
     int rc = ensure_stage(g, total_);
     if (rc) return rc;
+    base_ = g.stage;
     for (int i = 0; i < n_; ++i)
       if (a_[i].src && a_[i].bytes) HIPCK(hipMemcpyAsync(g.stage + a_[i].off, a_[i].src, a_[i].bytes, hipMemcpyHostToDevice, g.stream));
     rc = body(g.stream);
@@ -337,6 +373,7 @@ class HostCall {
     return n_++;
   }
   Ctx& g_;
+  uint8_t* base_ = nullptr;
   Arr a_[12];
   int n_ = 0;
   size_t total_ = 0;
@@ -430,6 +467,7 @@ int ensure_aux(Ctx& g, StreamRes* r) {
   HIPCK(hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming));
   return KYB_OK;
 }
+inline const uint32_t* image64(Ctx& g) { return g.table + KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS; }
 inline bool use_split(Ctx& g, size_t n) { return g.opt_finish == 1 && n >= (size_t)g.opt_finish_min; }
 
 // ---- context life cycle ------------------------------------------------------------------------------------
@@ -613,6 +651,20 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
   StreamRes* r = nullptr;
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
+  if (n <= (size_t)g.opt_coop_max && g.opt_mul_algo == 1) {
+    // small batch: one item per wavefront, the whole multiplication in one launch (kernels_coop.hip)
+    if (penc != nullptr) {
+      int rc = ensure_enc(g, r, 160 * n + 256); if (rc) return rc;
+      int32_t* tmp = reinterpret_cast<int32_t*>(r->enc);
+      { ProfScope ps(g, st, KID_DECODE); LAUNCHCK(launch::decode_or_identity(st, penc, n, tmp, ok)); }
+      pext = tmp;
+    } else if (ok != nullptr) {
+      HIPCK(hipMemsetAsync(ok, 1, n, st));
+    }
+    ProfScope ps(g, st, KID_MUL_COOP);
+    LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, 0));
+    return KYB_OK;
+  }
   if (g.opt_mul_algo == 1) {
     int rc = launch_ladder_core(g, sc, penc, pext, n, ok, r, st); if (rc) return rc;
     return launch_finish(g, r, n, oenc, oext, st);
@@ -676,6 +728,11 @@ int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t*
   StreamRes* r = nullptr;
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
+  if (n <= (size_t)g.opt_coop_base_max) {
+    ProfScope ps(g, st, KID_MUL_BASE_COOP);
+    LAUNCHCK(launch::mul_base_coop(st, sc, n, oenc, oext, image64(g)));
+    return KYB_OK;
+  }
   if (use_split(g, n)) {
     int rc = ensure_proj(g, r, n); if (rc) return rc;
     rc = launch_base(g, true, sc, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
@@ -702,7 +759,10 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
   if (pub_in != nullptr) {
     // R = k*B only
     int rc = ensure_enc(g, r, 32 * n); if (rc) return rc;
-    if (use_split(g, n)) {
+    if (n <= (size_t)g.opt_coop_base_max) {
+      ProfScope ps(g, st, KID_MUL_BASE_COOP);
+      LAUNCHCK(launch::mul_base_coop(st, k, n, r->enc, nullptr, image64(g)));
+    } else if (use_split(g, n)) {
       rc = ensure_proj(g, r, n); if (rc) return rc;
       rc = launch_base(g, true, k, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
       rc = launch_finish(g, r, n, r->enc, nullptr, st); if (rc) return rc;
@@ -714,6 +774,21 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
       LAUNCHCK(launch::sign_hash(st, x, k, msgs, off, n, r->enc, pub_in, sig));
     }
     if (pub_out != nullptr && pub_out != pub_in) HIPCK(hipMemcpyAsync(pub_out, pub_in, 32 * n, hipMemcpyDeviceToDevice, st));
+    return KYB_OK;
+  }
+  if (2 * n <= (size_t)g.opt_coop_base_max) {
+    // small batch: the 2n fixed-base multiplications as 2n wavefronts of the cooperative kernel, encodings straight out
+    int rc = ensure_enc(g, r, 64 * n); if (rc) return rc;
+    {
+      ProfScope ps(g, st, KID_MUL_BASE_COOP);
+      LAUNCHCK(launch::mul_base_coop(st, k, n, r->enc, nullptr, image64(g)));
+      LAUNCHCK(launch::mul_base_coop(st, x, n, r->enc + 32 * n, nullptr, image64(g)));
+    }
+    {
+      ProfScope ps(g, st, KID_SIGN_HASH);
+      LAUNCHCK(launch::sign_hash(st, x, k, msgs, off, n, r->enc, r->enc + 32 * n, sig));
+    }
+    if (pub_out != nullptr) HIPCK(hipMemcpyAsync(pub_out, r->enc + 32 * n, 32 * n, hipMemcpyDeviceToDevice, st));
     return KYB_OK;
   }
   if (use_split(g, 2 * n)) {
@@ -787,6 +862,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   // the R half (decode of R, s*B) is independent of the A half (decode of A, hash, h*A): while the batch leaves most of
   // the chip idle it runs on the side stream
   const bool fork = g.opt_verify_overlap && n <= (size_t)64 * (size_t)g.cus;
+  const bool coop = g.opt_mul_algo == 1 && n <= (size_t)g.opt_coop_max && n <= (size_t)g.opt_coop_base_max;     // small batch: one item per wavefront
   hipStream_t side = st;
   if (fork) {
     rc = ensure_aux(g, r); if (rc) return rc;
@@ -805,10 +881,14 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   if (fork) {
     HIPCK(hipEventRecord(r->ev_fork, st));                 // s*B reads sbuf, which the A-half kernel has just been asked to write
     HIPCK(hipStreamWaitEvent(side, r->ev_fork, 0));
-    rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side); if (rc) return rc;
+    if (coop) { ProfScope ps(g, side, KID_MUL_BASE_COOP); LAUNCHCK(launch::mul_base_coop(side, sbuf, n, nullptr, nullptr, image64(g), r->proj, r->proj_items, n)); }
+    else { rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side); if (rc) return rc; }
     HIPCK(hipEventRecord(r->ev_join, side));
   }
-  if (g.opt_mul_algo == 1) {
+  if (coop) {
+    ProfScope ps(g, st, KID_MUL_COOP);
+    LAUNCHCK(launch::mul_coop(st, hbuf, a_ext, n, nullptr, nullptr, 3, r->proj, r->proj_items, 0));      // h < L < 2^253
+  } else if (g.opt_mul_algo == 1) {
     rc = launch_ladder_core(g, hbuf, nullptr, a_ext, n, nullptr, r, st, 0, 3); if (rc) return rc;      // h < L < 2^253
   } else {
     rc = ensure_ws(g, r); if (rc) return rc;
@@ -818,6 +898,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     LAUNCHCK(launch::mul_window(g.opt_mul_select, false, true, grid, st, hbuf, nullptr, a_ext, n, nullptr, nullptr, nullptr, r->ws, r->proj, r->proj_items));
   }
   if (fork) HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
+  else if (coop) { ProfScope ps(g, st, KID_MUL_BASE_COOP); LAUNCHCK(launch::mul_base_coop(st, sbuf, n, nullptr, nullptr, image64(g), r->proj, r->proj_items, n)); }
   else { rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, st); if (rc) return rc; }
   {
     ProfScope ps(g, st, KID_VERIFY_FINAL);

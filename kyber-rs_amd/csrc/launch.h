@@ -1,4 +1,4 @@
-// Host-callable launchers of every kernel group.  The library is built from seven translation units that hipcc
+// Host-callable launchers of every kernel group.  The library is built from eight translation units that hipcc
 // compiles in parallel (csrc/Makefile):
 //
 //   kernels_base.hip      fixed base: table builders, table checksum, k_mul_base64 (the default fixed-base kernel)
@@ -7,6 +7,7 @@
 //   kernels_window.hip    windowed variable-base k_mul (mul.algo=0, cross-check of the ladder)
 //   kernels_verify.hip    SHA-512 users: k_verify_prep / _r / _final, k_sign_hash, k_eddsa_prep
 //   kernels_misc.hip      k_finish, k_encode_batched, k_add, k_equal, k_encode, k_decode, k_poly_eval
+//   kernels_coop.hip      small batches: one item per wavefront, lane-cooperative field arithmetic (k_mul_coop, k_mul_base_coop)
 //   engine.hip            contexts, per-stream scratch, launch sequences, host-pointer pipeline, multi-device groups, C ABI
 //
 // A kernel is defined in exactly one unit; the engine reaches it through the plain C++ function declared here
@@ -46,6 +47,14 @@ hipError_t ext_to_proj(hipStream_t st, const int32_t* pext, size_t n, uint4* pro
 #if defined(KYB_DIAG_STAMPS)
 hipError_t diag_set_stamp_buffer(uint64_t* dev_buf, size_t waves);
 #endif
+
+// ---- kernels_coop.hip ----
+// proj != nullptr: the affine result is also written to staging record proj_offset + i (Z = 1), the input format of k_verify_final
+hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
+                    uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0);
+hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
+                         uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0);
+hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* image64);
 
 // ---- kernels_verify.hip ----
 hipError_t verify_prep(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,

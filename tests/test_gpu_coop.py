@@ -1,0 +1,152 @@
+"""Small-batch (one item per wavefront, lane-cooperative) kernels: bit-identical to the oracle and to the batch kernels
+on the quirk vectors (scalars >= 2^255, L, 8L, 0, 1; identity, small-order, mixed-order points), random inputs, ragged
+sizes; selected by batch size through `coop.max_items` / `coop.base_max_items`."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "kats.json")))
+
+
+@pytest.fixture()
+def coop_engine(engine):
+    old = (engine.get_option("coop.max_items"), engine.get_option("coop.base_max_items"))
+    engine.set_option("coop.max_items", 1 << 20)
+    engine.set_option("coop.base_max_items", 1 << 20)
+    yield engine
+    engine.set_option("coop.max_items", old[0])
+    engine.set_option("coop.base_max_items", old[1])
+
+
+def test_coop_fixed_base_matches_oracle(coop_engine, oracle):
+    eng = coop_engine
+    q = KATS["quirk_mul_base"]
+    sc = np.frombuffer(b"".join(bytes.fromhex(v["scalar"]) for v in q), dtype=np.uint8).reshape(-1, 32)
+    got = eng.mul_base(sc)
+    assert [bytes(r).hex() for r in got] == [v["out"] for v in q]
+    for n in (1, 2, 63, 64, 65, 300):
+        s = synth.raw256(n, 400 + n)
+        enc, ext = eng.mul_base(s, want_ext=True)
+        assert np.array_equal(enc, oracle.mul_base_batch(s, nthreads=8))
+        assert [oracle.encode(e) for e in ext[:8]] == [bytes(r) for r in enc[:8]]
+        assert all(list(e[20:30]) == [1] + [0] * 9 for e in ext[:8])
+    assert eng.mul_base(sc[:0]).shape == (0, 32)
+
+
+def test_coop_variable_base_matches_oracle(coop_engine, oracle):
+    eng = coop_engine
+    q = [v for v in KATS["quirk_mul"] if v["ok"]]
+    sc = np.frombuffer(b"".join(bytes.fromhex(v["scalar"]) for v in q), dtype=np.uint8).reshape(-1, 32)
+    pts = np.stack([oracle.decode(bytes.fromhex(v["point"]))[0] for v in q])
+    got = eng.mul(sc, pts_ext=pts)
+    assert [bytes(r).hex() for r in got] == [v["out"] for v in q]
+    # the same from the wire encodings (decode kernel in front), invalid encodings included
+    penc = np.frombuffer(b"".join(bytes.fromhex(v["point"]) for v in KATS["quirk_mul"]), dtype=np.uint8).reshape(-1, 32)
+    sc_all = np.frombuffer(b"".join(bytes.fromhex(v["scalar"]) for v in KATS["quirk_mul"]), dtype=np.uint8).reshape(-1, 32)
+    enc, ok = eng.mul(sc_all, pts_enc=penc, want_ok=True)
+    for v, e, o in zip(KATS["quirk_mul"], enc, ok):
+        assert bool(o) == bool(v["ok"])
+        if v["ok"]:
+            assert bytes(e).hex() == v["out"]
+    for n in (1, 3, 64, 65, 257):
+        s = synth.raw256(n, 500 + n)
+        p = oracle.mul_base_ext_batch(synth.scalars(n, 600 + n, b"point"))
+        enc, ext = eng.mul(s, pts_ext=p, want_ext=True)
+        assert np.array_equal(enc, oracle.mul_batch(s, p, nthreads=8)), n
+        assert [oracle.encode(e) for e in ext[:4]] == [bytes(r) for r in enc[:4]]
+    # projective inputs with Z != 1 (sums of points) and reduced scalars
+    a = oracle.mul_base_ext_batch(synth.scalars(40, 700, b"point"))
+    b = np.stack([oracle.add(x, y) for x, y in zip(a, np.roll(a, 1, axis=0))])
+    s = synth.scalars(40, 701)
+    assert np.array_equal(eng.mul(s, pts_ext=b), oracle.mul_batch(s, b, nthreads=8))
+
+
+def test_coop_and_batch_kernels_agree_at_the_threshold(engine, oracle):
+    """the routing by size: n <= coop.max_items -> cooperative kernel, above -> batch kernels; same bytes either way"""
+    s = synth.raw256(130, 800)
+    p = oracle.mul_base_ext_batch(synth.scalars(130, 801, b"point"))
+    engine.set_option("coop.max_items", 0)
+    engine.set_option("coop.base_max_items", 0)
+    ref_mul, ref_base = engine.mul(s, pts_ext=p), engine.mul_base(s)
+    try:
+        engine.set_option("coop.max_items", 64)
+        engine.set_option("coop.base_max_items", 64)
+        engine.profile_begin(64)
+        assert np.array_equal(engine.mul(s[:64], pts_ext=p[:64]), ref_mul[:64])
+        assert np.array_equal(engine.mul(s[:65], pts_ext=p[:65]), ref_mul[:65])
+        assert np.array_equal(engine.mul_base(s[:64]), ref_base[:64])
+        assert np.array_equal(engine.mul_base(s[:65]), ref_base[:65])
+        names = [k for k, _ in engine.profile_read(64)]
+        assert names.count("k_mul_coop") == 1 and names.count("k_mul_base_coop") == 1 and "k_mul_ladder" in names
+    finally:
+        engine.profile_begin(0)
+        engine.set_option("coop.max_items", 0)
+        engine.set_option("coop.base_max_items", 0)
+
+
+def test_coop_primitives_match_the_lane_model(engine):
+    """every cooperative primitive (cmul4, cnorm, csub, cinv, table entry, mixed addition, ladder step, layout round
+    trip) run by one wavefront through the library's test hook == the lane-level numpy model tools/coop_model.py"""
+    import ctypes
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import coop_model as M
+    import kyber_rs_amd
+    lib = kyber_rs_amd.load_library()
+    lib.kyb_diag_coop.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    engine.device_info()                       # makes the fixture's context current on this thread
+
+    def run(op, A, B=None):
+        A = np.ascontiguousarray(A, dtype=np.uint32)
+        B = np.zeros(64, np.uint32) if B is None else np.ascontiguousarray(B, dtype=np.uint32)
+        out = np.zeros(64, np.uint32)
+        assert lib.kyb_diag_coop(op, A.ctypes.data, B.ctypes.data, out.ctypes.data) == 0
+        return out.astype(np.uint64)
+
+    c = M.lane_consts()
+    rnd = random.Random(5)
+    for _ in range(4):
+        a = [rnd.randrange(M.P) for _ in range(4)]
+        b = [rnd.randrange(M.P) for _ in range(4)]
+        F, G = M.quad_from_ints(c, a), M.quad_from_ints(c, b)
+        assert np.array_equal(run(7, F), F)
+        assert np.array_equal(run(1, M.cadd(F, G)), M.cnorm(c, M.cadd(F, G)))
+        assert np.array_equal(run(5, F, G), M.csub(c, F, G))
+        G4 = M.cadd(M.cadd(G, G), M.cadd(G, G))
+        assert np.array_equal(run(0, F, G4), M.cmul4(c, F, G4))
+        assert M.ints_from_quad(run(0, F, G)) == [x * y % M.P for x, y in zip(a, b)]
+        assert M.ints_from_quad(run(2, F)) == [pow(x, M.P - 2, M.P) for x in a]
+        h = M.quad_from_ints(c, [rnd.randrange(M.P) for _ in range(4)])
+        E = M.quad_from_ints(c, [rnd.randrange(M.P), rnd.randrange(M.P), rnd.randrange(M.P), 0])
+        assert np.array_equal(run(3, h, E), M.madd(c, h, E))
+        for swap0 in (0, 1):
+            for bit in (0, 1):
+                S = M.quad_from_ints(c, [rnd.randrange(M.P) for _ in range(4)])
+                U1Q = M.quad_from_ints(c, [rnd.randrange(M.P), 0, 0, 0])
+                B = U1Q.copy(); B[16] = swap0; B[17] = bit
+                assert np.array_equal(run(6, S, B), M.ladder_step(c, S, U1Q, swap0, bit)[0])
+    assert M.ints_from_quad(run(2, M.quad_from_ints(c, [0, 1, M.P - 1, 2]))) == [0, 1, M.P - 1, pow(2, M.P - 2, M.P)]
+    img64 = engine.base_table().view(np.uint32)[(65536 + 106496) // 4:]
+    for pos, idx, neg in [(0, 0, 0), (0, 5, 0), (0, 31, 1), (7, 12, 1), (41, 8, 0), (42, 3, 0), (42, 15, 0)]:
+        B = np.zeros(64, np.uint32); B[0], B[1], B[2] = pos, idx, neg
+        n_e, base = (32, pos * 960) if pos < 42 else (16, 42 * 960)
+
+        def word(j, k):
+            g_, r_ = k // 10, k % 10
+            big = 0 if g_ == 0 else (8 * n_e if g_ == 1 else 20 * n_e)
+            small = 16 * n_e if g_ == 0 else (18 * n_e if g_ == 1 else 28 * n_e)
+            return base + (big + ((r_ >> 2) * n_e + j) * 4 + (r_ & 3) if r_ < 8 else small + j * 2 + (r_ - 8))
+        want = np.zeros(64, np.uint64)
+        for g_ in range(3):
+            ge = (g_ ^ neg) if g_ < 2 else g_
+            for k in range(10):
+                v = int(img64[word(idx, 10 * ge + k)])
+                want[16 * g_ + k] = (M.P2[k] - v) if (g_ == 2 and neg) else v
+        assert np.array_equal(run(4, np.zeros(64, np.uint32), B), want), (pos, idx, neg)

@@ -14,6 +14,13 @@ import oracle_lib
 import synth
 
 eng = kyber_rs_amd.Engine(0)
+# --opt key=value ...: engine options (e.g. coop.max_items=0 coop.base_max_items=0 to time the batch kernels alone)
+for kv in sys.argv[1:]:
+    if kv.startswith("--opt"):
+        continue
+    key, val = kv.split("=")
+    eng.set_option(key, int(val))
+    print(f"# option {key} = {val}")
 orc = oracle_lib.Oracle()
 N = 1 << 15
 s = synth.scalars(N, 3)
