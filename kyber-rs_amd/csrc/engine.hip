@@ -781,8 +781,7 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
     int rc = ensure_enc(g, r, 64 * n); if (rc) return rc;
     {
       ProfScope ps(g, st, KID_MUL_BASE_COOP);
-      LAUNCHCK(launch::mul_base_coop(st, k, n, r->enc, nullptr, image64(g)));
-      LAUNCHCK(launch::mul_base_coop(st, x, n, r->enc + 32 * n, nullptr, image64(g)));
+      LAUNCHCK(launch::mul_base_coop(st, k, n, r->enc, nullptr, image64(g), nullptr, 0, 0, x, n));      // R in [0, n), A in [n, 2n)
     }
     {
       ProfScope ps(g, st, KID_SIGN_HASH);

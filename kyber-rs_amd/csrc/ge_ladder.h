@@ -210,6 +210,142 @@ KYB_HD void ge_scalarmult_ladder(ge_p2& out, const uint32_t a[8], const mont_poi
   mont_recover_to_edwards(out, m, x2, z2, x3, z3, mag[0] & 1u, neg);
 }
 
+// ---- projective base point: no inversion before the ladder (small-batch kernel, kernels_coop.hip) --------------------------
+// The batch kernel normalises the image (u, v) with one shared inversion per eight points and saves a multiplication in each
+// of the 256 steps.  The one-item-per-wavefront kernel has idle rows in its third multiplication level, so there the extra
+// product is free and the inversion (a 265-multiplication dependent chain) is what costs: it keeps the image projective,
+//     u = U / W,  v = V / W   with   U = (Z+Y) X,  V = c (Z+Y) Z,  W = (Z-Y) X,
+// runs the ladder with x3' = W (da+cb)^2, z3' = U (da-cb)^2, and recovers y with every term of the Okeya-Sakurai formulas
+// scaled by W^2 (the result is projective anyway).  tools/ladder_proto.py (mul_via_ladder_proj) is the big-integer prototype.
+struct mont_point_proj {
+  fe U, V, W;        // (1, 1, 1) when flags != 0
+  uint32_t flags;    // as mont_point
+};
+KYB_HD void mont_prep_proj(mont_point_proj& m, const ge_p3& P) {
+  const fe c = {KYB_FE_MONT_C};
+  fe zmy, zpy, t, one;
+  fe_sub(zmy, P.Z, P.Y);                 // 3T
+  fe_add(zpy, P.Z, P.Y);                 // 2T
+  fe_mul(m.W, zmy, P.X);
+  fe_mul(m.U, zpy, P.X);
+  fe_mul(t, zpy, P.Z);
+  fe_mul(m.V, t, c);
+  const uint32_t x0 = 1u - fe_is_nonzero(P.X);
+  const uint32_t id = x0 & (1u - fe_is_nonzero(zmy));
+  const uint32_t o2 = x0 & (1u - fe_is_nonzero(zpy));
+  const uint32_t degenerate = 1u - fe_is_nonzero(m.W);          // X == 0, or Z == Y with X != 0 (not on the curve): neutral element
+  m.flags = (id | (degenerate & (1u - o2))) | (o2 << 1);
+  fe_one(one);
+  fe_cmov(m.U, one, degenerate); fe_cmov(m.V, one, degenerate); fe_cmov(m.W, one, degenerate);
+}
+// the same ladder with the base point's u as U1 / W1 (one-lane form: reference for the cooperative kernel and the host-test build)
+KYB_HD void mont_ladder_proj(fe& x2, fe& z2, fe& x3, fe& z3, const fe& U1, const fe& W1, const uint32_t mag[8], int skip = 0) {
+  fe_one(x2); fe_zero(z2); fe_copy(x3, U1); fe_copy(z3, W1);
+  uint32_t swap = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int i = 255 - skip; i >= 0; --i) {
+    uint32_t word = 0;
+    KYB_UNROLL for (int k = 0; k < 8; ++k) word = ((i >> 5) == k) ? mag[k] : word;
+    const uint32_t bit = (word >> (i & 31)) & 1u;
+    swap ^= bit;
+    fe a, aa, b, bb, e, c, d, da, cb, t, sa, sb;
+    fe_add(a, x2, z2); fe_sub(b, x2, z2); fe_add(c, x3, z3); fe_sub(d, x3, z3);
+    fe_select(sa, a, c, swap);
+    fe_select(sb, b, d, swap);
+    swap = bit;
+    fe_sq(aa, sa); fe_sq(bb, sb);
+    fe_mul(da, d, a); fe_mul(cb, b, c);
+    fe_sub(e, aa, bb);
+    fe_add(t, da, cb); fe_sq(t, t); fe_mul(x3, t, W1);
+    fe_sub(t, da, cb); fe_sq(t, t); fe_mul(z3, t, U1);
+    fe_mul(x2, aa, bb);
+    fe_mul_small(t, e, 121665u); fe_add(t, t, aa); fe_mul(z2, e, t);
+  }
+  fe_cswap(x2, x3, swap);
+  fe_cswap(z2, z3, swap);
+}
+KYB_HD void mont_recover_to_edwards_proj(ge_p2& out, const mont_point_proj& m, const fe& x2, const fe& z2, const fe& x3, const fe& z3,
+                                         uint32_t k_is_odd, uint32_t negate) {
+  const fe cc = {KYB_FE_MONT_C};
+  fe T1, Wx2, T2, T3, a_, T4, b_, W2, t, YP, TT, U, V, W;
+  fe_mul(T1, m.U, z2);
+  fe_mul(Wx2, m.W, x2);
+  fe_add(T2, Wx2, T1);                   // 2T   W t2
+  fe_sub(T3, Wx2, T1);                   // 3T
+  fe_sq(T3, T3);
+  fe_mul(T3, T3, x3);                    // W^2 t3
+  fe_mul_small(a_, z2, 2u * 486662u);    // 2A Z_Q
+  fe_mul(t, m.W, a_);
+  fe_add(T2, T2, t);                     // 3T   W (t2 + 2A z2)
+  fe_mul(T4, m.U, x2);
+  fe_mul(t, m.W, z2);
+  fe_add(T4, T4, t);                     // 2T   W t4
+  fe_mul(b_, a_, z2);
+  fe_sq(W2, m.W);
+  fe_mul(T2, T2, T4);                    // f 3T, g 2T
+  fe_mul(t, W2, b_);
+  fe_sub(T2, T2, t);                     // 3T
+  fe_mul(T2, T2, z3);
+  fe_sub(YP, T2, T3);                    // 3T   W^2 Yp
+  fe_add(TT, m.V, m.V);                  // 2T
+  fe_mul(TT, TT, z2);
+  fe_mul(TT, TT, z3);                    // W t1
+  fe_mul(t, m.W, TT);
+  fe_mul(U, t, x2);
+  fe_reduce_weak(V, YP);
+  fe_mul(W, t, z2);
+  // Edwards: x = c*u/v, y = (u-1)/(u+1)  ->  X = c*U*(U+W), Y = (U-W)*V, Z = V*(U+W)
+  fe upw, umw, X, Y, Z, t1;
+  fe_add(upw, U, W);                     // 2T
+  fe_sub(umw, U, W);                     // 3T
+  fe_mul(t1, U, cc);
+  fe_mul(X, t1, upw);
+  fe_mul(Y, umw, V);
+  fe_mul(Z, V, upw);
+  const uint32_t z2_zero = 1u - fe_is_nonzero(z2);
+  const uint32_t z3_zero = 1u - fe_is_nonzero(z3);
+  const uint32_t x2_zero = 1u - fe_is_nonzero(x2);
+  const uint32_t res_inf = z2_zero;
+  const uint32_t res_negp = z3_zero & (1u - z2_zero);
+  const uint32_t res_o2 = x2_zero & (1u - z2_zero);
+  const uint32_t p_id = m.flags & 1u, p_o2 = (m.flags >> 1) & 1u;
+  // -P from the projective image: (X:Y:Z) = (-c*U1*(U1+W1) : (U1-W1)*V1 : V1*(U1+W1))
+  fe one, zero, mone, up1, um1, nX, nY, nZ;
+  fe_one(one); fe_zero(zero); fe_neg(mone, one);
+  fe_add(up1, m.U, m.W);                 // 2T
+  fe_sub(um1, m.U, m.W);                 // 3T
+  fe_mul(t1, m.U, cc);
+  fe_mul(nX, t1, up1);
+  fe_neg(nX, nX);                        // 2T
+  fe_mul(nY, um1, m.V);
+  fe_mul(nZ, m.V, up1);
+  fe_cmov(X, nX, res_negp); fe_cmov(Y, nY, res_negp); fe_cmov(Z, nZ, res_negp);
+  fe_cmov(X, zero, res_o2); fe_cmov(Y, mone, res_o2); fe_cmov(Z, one, res_o2);
+  fe_cmov(X, zero, res_inf); fe_cmov(Y, one, res_inf); fe_cmov(Z, one, res_inf);
+  fe_cmov(X, zero, p_id); fe_cmov(Y, one, p_id); fe_cmov(Z, one, p_id);
+  fe yo2;
+  fe_select(yo2, one, mone, k_is_odd);
+  fe_cmov(X, zero, p_o2); fe_cmov(Y, yo2, p_o2); fe_cmov(Z, one, p_o2);
+  fe nx;
+  fe_reduce_weak(X, X);
+  fe_neg(nx, X);
+  fe_cmov(X, nx, negate);
+  fe_reduce_weak(out.X, X);
+  fe_reduce_weak(out.Y, Y);
+  fe_reduce_weak(out.Z, Z);
+}
+KYB_HD void ge_scalarmult_ladder_proj(ge_p2& out, const uint32_t a[8], const ge_p3& P, int skip = 0) {
+  uint32_t neg, mag[8];
+  sc_effective(neg, mag, a);
+  mont_point_proj m;
+  mont_prep_proj(m, P);
+  fe x2, z2, x3, z3;
+  mont_ladder_proj(x2, z2, x3, z3, m.U, m.W, mag, skip);
+  mont_recover_to_edwards_proj(out, m, x2, z2, x3, z3, mag[0] & 1u, neg);
+}
+
 #if defined(__HIPCC__) && defined(KYB_DIAG_STAMPS)
 // Diagnostic build only (tools/ladder_clock.py, -DKYB_DIAG_STAMPS; the product library contains no stamp):
 // the same multiplication with s_memtime (shader cycles) and s_memrealtime (100 MHz) read immediately before and

@@ -1,8 +1,9 @@
 // Small-batch (latency) kernels of the MI355X Ed25519 engine: ONE ITEM PER WAVEFRONT, field elements spread over lanes
 // (coop25519.h).  One of the translation units of the library (map: launch.h).
-//   k_mul_coop        Point::mul(s, Some(P))  ge.rs:508-568   the same Montgomery ladder as k_mul_ladder (ge_ladder.h), its 256
-//                     steps as three cooperative multiplication levels each; image, y-recovery and encoding replicated on all lanes
-//                     around it, the two field inversions cooperative.  One launch does the whole multiplication.
+//   k_mul_coop        Point::mul(s, Some(P))  ge.rs:508-568   the Montgomery ladder of k_mul_ladder with a PROJECTIVE base point
+//                     (mont_ladder_proj, ge_ladder.h: no inversion in front), its 256 steps as three cooperative multiplication
+//                     levels each; image, y-recovery and encoding replicated on all lanes around it, the one field inversion
+//                     cooperative.  One launch does the whole multiplication.
 //   k_mul_base_coop   Point::mul(s, None)     ge.rs:442-486   the radix-64 table of k_mul_base64 read from global memory (every
 //                     line of a limb's 32 entries is touched whatever the digit), 43 cooperative mixed additions, cooperative inversion.
 // Used for batches that leave the chip idle (engine.hip: `coop.max_items`); results are bit-identical to the batch kernels.
@@ -60,16 +61,17 @@ __device__ __forceinline__ void coop_finish(const lane_consts& c, const fe& X, c
 
 }  // namespace
 
-// One ladder step on the state S = (x2, z2, x3, z3) (rows 0..3), u(P) in row 0 of U1Q; `swap` = the pending conditional swap
-// XOR this step's scalar bit (mont_ladder, ge_ladder.h: the swap only exchanges (a, b) with (c, d)).  Three cooperative levels.
-struct ladder_idx { int I_0022, I_1133, I_F1, I_G1, I_2200, I_3311, I_1313, I_3333, I_0000, I_1100, x128; };
+// One ladder step on the state S = (x2, z2, x3, z3) (rows 0..3) with the base point's u = U1 / W1 kept projective
+// (mont_ladder_proj, ge_ladder.h): UWQ holds U1 in row 0 and W1 in row 2.  `swap` = the pending conditional swap XOR this
+// step's scalar bit (the swap only exchanges (a, b) with (c, d)).  Three cooperative multiplication levels.
+struct ladder_idx { int I_0022, I_1133, I_F1, I_G1, I_2200, I_3311, I_1300, I_3333, I_0000, I_1120, x128; };
 __device__ __forceinline__ ladder_idx ladder_idx_init(const lane_consts& c) {
   return ladder_idx{rowperm_idx(c, 0, 0, 2, 2), rowperm_idx(c, 1, 1, 3, 3), rowperm_idx(c, 0, 1, 3, 1), rowperm_idx(c, 0, 1, 0, 2), rowperm_idx(c, 2, 2, 0, 0),
-                    rowperm_idx(c, 3, 3, 1, 1), rowperm_idx(c, 1, 3, 1, 3), rowperm_idx(c, 3, 3, 3, 3), rowperm_idx(c, 0, 0, 0, 0), rowperm_idx(c, 1, 1, 0, 0),
+                    rowperm_idx(c, 3, 3, 1, 1), rowperm_idx(c, 1, 3, 0, 0), rowperm_idx(c, 3, 3, 3, 3), rowperm_idx(c, 0, 0, 0, 0), rowperm_idx(c, 1, 1, 2, 0),
                     c.row < 2 ? 128 : 0};             // x128: rows 0,1 read rows 2,3 of the source when the swap is set
 }
-__device__ __forceinline__ cq coop_ladder_step(const lane_consts& c, const ladder_idx& li, cq S, cq U1Q, uint32_t swap) {
-  const bool rodd = (c.row & 1u) != 0, r1 = c.row == 1, r2 = c.row == 2, r3 = c.row == 3;
+__device__ __forceinline__ cq coop_ladder_step(const lane_consts& c, const ladder_idx& li, cq S, cq UWQ, uint32_t swap) {
+  const bool rodd = (c.row & 1u) != 0, r0 = c.row == 0, r1 = c.row == 1, r2 = c.row == 2, r3 = c.row == 3;
   const cq A24Q = (r3 && c.k == 0) ? 121665u : 0u;
   // level 0: a = x2 + z2, b = x2 - z2, c = x3 + z3, d = x3 - z3
   const cq U = bperm(li.I_0022, S), V = bperm(li.I_1133, S);
@@ -77,20 +79,20 @@ __device__ __forceinline__ cq coop_ladder_step(const lane_consts& c, const ladde
   // level 1: (aa, bb, da, cb) = (sa^2, sb^2, d*a, b*c) with (sa, sb) = swap ? (c, d) : (a, b)
   const int sx = (0 - (int)swap) & li.x128;
   const cq L1 = cmul4(c, bperm(li.I_F1 ^ sx, AB), bperm(li.I_G1 ^ sx, AB));
-  // level 2: (x3', t', x2', a24*e) = ((da+cb)^2, (da-cb)^2, aa*bb, e*a24),  e = aa - bb
+  // level 2: (s, t', x2', a24*e) = ((da+cb)^2, (da-cb)^2, aa*bb, e*a24),  e = aa - bb
   const cq W = bperm(li.I_2200, L1), Z = bperm(li.I_3311, L1);                    // (da, da, aa, aa), (cb, cb, bb, bb)
   const cq F2 = cnorm(c, rodd ? csub(c, W, Z) : (r2 ? W : cadd(W, Z)));            // (da+cb, da-cb, aa, e), tight
   const cq G2 = r3 ? A24Q : (r2 ? Z : F2);
   const cq L2 = cmul4(c, F2, G2);
-  // level 3: (z3', z2') = (t' * u1, e * (a24*e + aa))
-  const cq T3 = bperm(li.I_1313, L2);                                              // (t', a24*e, ..)
+  // level 3: (z3', z2', x3') = (t' * U1, e * (a24*e + aa), s * W1)
+  const cq T3 = bperm(li.I_1300, L2);                                              // (t', a24*e, s, s)
   const cq E1 = bperm(li.I_3333, F2), A1 = bperm(li.I_0000, L1);                   // e, aa in every row
-  const cq L3 = cmul4(c, r1 ? E1 : T3, r1 ? cadd(T3, A1) : U1Q);                   // rows 2, 3: * 0
-  // new state (x2', z2', x3', z3') = (L2 row 2, L3 row 1, L2 row 0, L3 row 0)
+  const cq L3 = cmul4(c, r1 ? E1 : T3, r1 ? cadd(T3, A1) : UWQ);                   // row 3: * 0
+  // new state (x2', z2', x3', z3') = (L2 row 2, L3 row 1, L3 row 2, L3 row 0)
   // (both cross-lane reads are issued by EVERY lane before the select: `cond ? bperm() : bperm()` would run each under a
   // partial EXEC mask, and a ds_bpermute that reads a disabled lane gets 0)
-  const cq fromL3 = bperm(li.I_1100, L3), fromL2 = bperm(li.I_2200, L2);
-  return rodd ? fromL3 : fromL2;
+  const cq fromL3 = bperm(li.I_1120, L3), fromL2 = bperm(li.I_2200, L2);
+  return r0 ? fromL2 : fromL3;
 }
 
 __global__ void __launch_bounds__(64)
@@ -101,25 +103,20 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
   lane_consts c;
   lane_consts_init(c);
 
-  // ---- replicated on all lanes: operands, Montgomery image (ge_ladder.h) with the one inversion done cooperatively ----
+  // ---- replicated on all lanes: operands and their projective Montgomery image (ge_ladder.h) ----
   uint32_t a[8];
   load_words8(a, scalars, i);
   ge_p3 P;
   load_ext(P, pts_ext, i);
-  fe d;
-  uint32_t fl;
-  mont_prep_den(d, fl, P);
-  fe dinv;
-  fe_from_quad_row(c, dinv, cinv(c, quad_row_from_fe(c, 0, 0, d)), 0);
-  mont_point m;
-  mont_prep_finish(m, P, dinv, fl);
+  mont_point_proj m;
+  mont_prep_proj(m, P);                                                // u = U / W, v = V / W: no inversion in front of the ladder
   uint32_t neg, mag[8];
   sc_effective(neg, mag, a);
 
   // ---- the ladder: state S = (x2, z2, x3, z3) in rows 0..3 ----
-  const cq U1Q = quad_row_from_fe(c, 0, 0, m.u);                     // u(P) in row 0 (second operand of z3 = t' * u1)
+  const cq UWQ = quad_row_from_fe(c, quad_row_from_fe(c, 0, 0, m.U), 2, m.W);      // U1 in row 0, W1 in row 2 (second operands of level 3)
   const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
-  cq S = quad_row_from_fe(c, (c.row == 0 || c.row == 3) ? ONE0 : 0u, 2, m.u);      // (1, 0, u1, 1)
+  cq S = quad_row_from_fe(c, quad_row_from_fe(c, c.row == 0 ? ONE0 : 0u, 2, m.U), 3, m.W);      // (1, 0, U1, W1)
   const ladder_idx li = ladder_idx_init(c);
   const int I_own = (int)(c.lane << 2);
   uint32_t swap = 0;
@@ -135,7 +132,7 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
       const uint32_t bit = word >> 31;
       word <<= 1;
       swap ^= bit;
-      S = coop_ladder_step(c, li, S, U1Q, swap);
+      S = coop_ladder_step(c, li, S, UWQ, swap);
       swap = bit;
     }
   }
@@ -148,7 +145,7 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
   fe_from_quad_row(c, x3, S, 2);
   fe_from_quad_row(c, z3, S, 3);
   ge_p2 r;
-  mont_recover_to_edwards(r, m, x2, z2, x3, z3, mag[0] & 1u, neg);
+  mont_recover_to_edwards_proj(r, m, x2, z2, x3, z3, mag[0] & 1u, neg);
   coop_finish(c, r.X, r.Y, r.Z, 0u, out_enc, out_ext, i, proj, proj_stride, proj_offset);
 }
 
@@ -199,15 +196,15 @@ __device__ __forceinline__ cq coop_table_entry(const lane_consts& c, const uint3
 }
 
 __global__ void __launch_bounds__(64)
-k_mul_base_coop(const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, const uint32_t* __restrict__ image64,
-                uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
+k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ scalars_b, size_t n_a, size_t n, uint8_t* __restrict__ out_enc,
+                int32_t* __restrict__ out_ext, const uint32_t* __restrict__ image64, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
   lane_consts c;
   lane_consts_init(c);
   const bool r1 = c.row == 1, r2 = c.row == 2;
   uint32_t a[8];
-  load_words8(a, scalars, i);
+  if (i < n_a) load_words8(a, scalars, i); else load_words8(a, scalars_b, i - n_a);      // two arrays in one launch (signing: nonces, then keys)
   sc_digits64 dg;
   sc_recode64(dg, a);
   const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
@@ -235,7 +232,7 @@ k_mul_base_coop(const uint8_t* __restrict__ scalars, size_t n, uint8_t* __restri
 // Test hook (tests/test_gpu_coop.py, against the lane-level model tools/coop_model.py): one wavefront applies ONE
 // cooperative primitive to caller-supplied quads.  op: 0 cmul4(A, B), 1 cnorm(A), 2 cinv(A), 3 mixed addition h = A, entry = B,
 // 4 table entry (window, idx, negate) = (B[0], B[1], B[2]) of the radix-64 image, 5 csub(A, B), 6 one ladder step S = A,
-// u1 in row 0 of B, swap / bit in B lanes 16 / 17 (returns S'), 7 quad -> fe -> quad round trip of every row.
+// U1 / W1 in rows 0 / 2 of B, swap / bit in B lanes 16 / 17 (returns S'), 7 quad -> fe -> quad round trip of every row.
 __global__ void __launch_bounds__(64)
 k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, uint32_t* __restrict__ out, const uint32_t* __restrict__ image64) {
   lane_consts c;
@@ -253,7 +250,7 @@ k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restri
     r = coop_madd(c, madd_idx_init(c), a, b);
   } else if (op == 6) {
     const uint32_t swap = B[16] ^ B[17];                              // pending swap XOR this step's bit
-    r = coop_ladder_step(c, ladder_idx_init(c), a, (c.row == 0 && c.active) ? b : 0u, swap);
+    r = coop_ladder_step(c, ladder_idx_init(c), a, ((c.row == 0 || c.row == 2) && c.active) ? b : 0u, swap);
   } else if (op == 7) {
     fe f[4];
     for (uint32_t q = 0; q < 4; ++q) fe_from_quad_row(c, f[q], a, q);
@@ -273,8 +270,8 @@ hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size
   return hipGetLastError();
 }
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
-                         uint4* proj, size_t proj_stride, size_t proj_offset) {
-  hipLaunchKernelGGL(k_mul_base_coop, dim3((unsigned)n), dim3(64), 0, st, sc, n, oenc, oext, image64, proj, proj_stride, proj_offset);
+                         uint4* proj, size_t proj_stride, size_t proj_offset, const uint8_t* sc_b, size_t n_b) {
+  hipLaunchKernelGGL(k_mul_base_coop, dim3((unsigned)(n + n_b)), dim3(64), 0, st, sc, sc_b, n, n + n_b, oenc, oext, image64, proj, proj_stride, proj_offset);
   return hipGetLastError();
 }
 }}  // namespace kyb::launch

@@ -52,8 +52,9 @@ hipError_t diag_set_stamp_buffer(uint64_t* dev_buf, size_t waves);
 // proj != nullptr: the affine result is also written to staging record proj_offset + i (Z = 1), the input format of k_verify_final
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
                     uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0);
+// sc_b != nullptr: n_b more scalars follow the first n in the same launch (their results behind the first n)
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
-                         uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0);
+                         uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, const uint8_t* sc_b = nullptr, size_t n_b = 0);
 hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* image64);
 
 // ---- kernels_verify.hip ----

@@ -221,6 +221,17 @@ void hd_mul_ladder_skip(uint8_t out[32], const uint8_t scalar[32], const int32_t
   ge_encode(w, r.X, r.Y, r.Z);
   memcpy(out, w, 32);
 }
+// the projective-base variant of the same path (no inversion before the ladder): what the cooperative small-batch kernel computes
+void hd_mul_ladder_proj(uint8_t out[32], const uint8_t scalar[32], const int32_t pt[40], int skip) {
+  uint32_t a[8], w[8];
+  load_words(a, scalar);
+  ge_p3 P;
+  fe_from_ref10(P.X, pt); fe_from_ref10(P.Y, pt + 10); fe_from_ref10(P.Z, pt + 20); fe_from_ref10(P.T, pt + 30);
+  ge_p2 r;
+  ge_scalarmult_ladder_proj(r, a, P, skip);
+  ge_encode(w, r.X, r.Y, r.Z);
+  memcpy(out, w, 32);
+}
 // the flow of kyb_lincomb_batch for one group: t ladder multiplications, the halving passes of k_pair_sum, encode
 void hd_lincomb(uint8_t out[32], const uint8_t* scalars, const int32_t* pts, int t) {
   std::vector<ge_p2> v((size_t)t);

@@ -277,6 +277,8 @@ def test_ladder_path_matches_oracle(hd, oracle):
         ext, _ = oracle.decode(bytes.fromhex(q["point"]))
         o = B(32); hd.hd_mul_ladder(o, bytes.fromhex(q["scalar"]), p32(ext))
         assert o.raw.hex() == q["out"], q
+        o = B(32); hd.hd_mul_ladder_proj(o, bytes.fromhex(q["scalar"]), p32(ext), 0)      # projective-base variant (small-batch kernel)
+        assert o.raw.hex() == q["out"], q
     weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
     for i in range(120):
         s = bytes(rnd.getrandbits(8) for _ in range(32))
@@ -287,11 +289,17 @@ def test_ladder_path_matches_oracle(hd, oracle):
             s = ((rnd.choice([1, 2, 4, 8]) * M.L + rnd.choice([-1, 0, 1])) % 2**256).to_bytes(32, "little")
         o = B(32); hd.hd_mul_ladder(o, s, p32(pt))
         assert o.raw == oracle.mul(s, pt), (i, s.hex())
+        if i % 2 == 0:
+            pz = oracle.add(oracle.add(pt, weak[0]), weak[0], sub=True)                     # the same point with Z != 1
+            o = B(32); hd.hd_mul_ladder_proj(o, s, p32(pz), 0)
+            assert o.raw == oracle.mul(s, pt), (i, s.hex())
     # verification multiplies by h < L < 2^253: the ladder may start three bits lower
     for v in [0, 1, 2, M.L - 1, M.L - 2, 2**252, 2**252 - 1, 2**252 + 12345] + [rnd.randrange(M.L) for _ in range(40)]:
         s = v.to_bytes(32, "little")
         pt = oracle.add(oracle.mul_base_ext(bytes(rnd.getrandbits(8) for _ in range(32))), weak[rnd.choice([0, 2, 3, 4])])
         o = B(32); hd.hd_mul_ladder_skip(o, s, p32(pt), 3)
+        assert o.raw == oracle.mul(s, pt), v
+        o = B(32); hd.hd_mul_ladder_proj(o, s, p32(pt), 3)
         assert o.raw == oracle.mul(s, pt), v
     assert hd.hd_overflows() == base
 

@@ -129,9 +129,9 @@ def test_coop_primitives_match_the_lane_model(engine):
         for swap0 in (0, 1):
             for bit in (0, 1):
                 S = M.quad_from_ints(c, [rnd.randrange(M.P) for _ in range(4)])
-                U1Q = M.quad_from_ints(c, [rnd.randrange(M.P), 0, 0, 0])
-                B = U1Q.copy(); B[16] = swap0; B[17] = bit
-                assert np.array_equal(run(6, S, B), M.ladder_step(c, S, U1Q, swap0, bit)[0])
+                UWQ = M.quad_from_ints(c, [rnd.randrange(M.P), 0, rnd.randrange(M.P), 0])       # U1 in row 0, W1 in row 2
+                B = UWQ.copy(); B[16] = swap0; B[17] = bit
+                assert np.array_equal(run(6, S, B), M.ladder_step(c, S, UWQ, swap0, bit)[0])
     assert M.ints_from_quad(run(2, M.quad_from_ints(c, [0, 1, M.P - 1, 2]))) == [0, 1, M.P - 1, pow(2, M.P - 2, M.P)]
     img64 = engine.base_table().view(np.uint32)[(65536 + 106496) // 4:]
     for pos, idx, neg in [(0, 0, 0), (0, 5, 0), (0, 31, 1), (7, 12, 1), (41, 8, 0), (42, 3, 0), (42, 15, 0)]:

@@ -116,9 +116,9 @@ def cinv(c, z):
     return cmul4(c, t, z11)
 
 
-def ladder_step(c, S, U1Q, swap, bit):
-    """one step of k_mul_coop's loop; returns (S', swap')"""
-    rodd, r1, r2, r3 = (c.row & 1) == 1, c.row == 1, c.row == 2, c.row == 3
+def ladder_step(c, S, UWQ, swap, bit):
+    """one step of k_mul_coop's loop (projective base point: U1 in row 0, W1 in row 2 of UWQ); returns (S', swap')"""
+    rodd, r0, r1, r2, r3 = (c.row & 1) == 1, c.row == 0, c.row == 1, c.row == 2, c.row == 3
     A24Q = np.where(r3 & (c.k == 0), 121665, 0).astype(np.uint64)
     I = lambda *p: rowperm_idx(c, *p)
     x128 = np.where(c.row < 2, 32, 0)          # lane index units here (the HIP code works in bytes: 128)
@@ -132,10 +132,10 @@ def ladder_step(c, S, U1Q, swap, bit):
     F2 = cnorm(c, np.where(rodd, csub(c, W, Z), np.where(r2, W, cadd(W, Z))))
     G2 = np.where(r3, A24Q, np.where(r2, Z, F2))
     L2 = cmul4(c, F2, G2)
-    T3 = bperm(I(1, 3, 1, 3), L2)
+    T3 = bperm(I(1, 3, 0, 0), L2)
     E1, A1 = bperm(I(3, 3, 3, 3), F2), bperm(I(0, 0, 0, 0), L1)
-    L3 = cmul4(c, np.where(r1, E1, T3), np.where(r1, cadd(T3, A1), U1Q))
-    S = np.where(rodd, bperm(I(1, 1, 0, 0), L3), bperm(I(2, 2, 0, 0), L2))
+    L3 = cmul4(c, np.where(r1, E1, T3), np.where(r1, cadd(T3, A1), UWQ))
+    S = np.where(r0, bperm(I(2, 2, 0, 0), L2), bperm(I(1, 1, 2, 0), L3))
     return S, swap
 
 
@@ -194,19 +194,19 @@ def main():
         X, Y, Z, T = ints_from_quad(madd(c, h, E))
         zi = pow(Z, P - 2, P)
         assert (X * zi % P, Y * zi % P) == aff_add((x1, y1), (x2, y2)) and T * Z % P == X * Y % P
-    # ladder step against RFC 7748
+    # ladder step against RFC 7748 with the base point's u = U1 / W1
     for swap0 in (0, 1):
         for bit in (0, 1):
-            x2, z2, x3, z3, u1 = (rnd.randrange(P) for _ in range(5))
+            x2, z2, x3, z3, U1, W1 = (rnd.randrange(P) for _ in range(6))
             S = quad_from_ints(c, [x2, z2, x3, z3])
-            U1Q = quad_from_ints(c, [u1, 0, 0, 0])
-            S2, sw = ladder_step(c, S, U1Q, swap0, bit)
+            UWQ = quad_from_ints(c, [U1, 0, W1, 0])
+            S2, sw = ladder_step(c, S, UWQ, swap0, bit)
             s = swap0 ^ bit
             if s: x2, x3, z2, z3 = x3, x2, z3, z2
             A, B, Cc, D = (x2 + z2) % P, (x2 - z2) % P, (x3 + z3) % P, (x3 - z3) % P
             AA, BB, DA, CB = A * A % P, B * B % P, D * A % P, Cc * B % P
             E_ = (AA - BB) % P
-            want = [AA * BB % P, E_ * (AA + 121665 * E_) % P, (DA + CB) ** 2 % P, u1 * (DA - CB) ** 2 % P]
+            want = [AA * BB % P, E_ * (AA + 121665 * E_) % P, W1 * (DA + CB) ** 2 % P, U1 * (DA - CB) ** 2 % P]
             # the kernel leaves the swap pending: its (x2', z2', x3', z3') are RFC 7748's AFTER that step's own swap
             assert ints_from_quad(S2) == want and sw == bit, (swap0, bit)
     print("coop model: cmul4 / cnorm / cinv / madd / ladder step OK")

@@ -105,3 +105,91 @@ if __name__ == "__main__":
             n += 1
             if mul_via_ladder(s, pt) != M.point_mul(s, pt): bad += 1; print("MISMATCH mixed", t, k)
     print("cases", n, "bad", bad)
+
+
+# ---- projective base point (the cooperative small-batch kernel): no inversion before the ladder ----
+def ladder_proj(k, U1, W1, nbits=256):
+    """u(P) = U1 / W1: x3' = W1 (da+cb)^2, z3' = U1 (da-cb)^2 (the extra product rides in an idle row of level 3)"""
+    x2, z2, x3, z3 = 1, 0, U1, W1
+    swap = 0
+    for i in range(nbits - 1, -1, -1):
+        bit = (k >> i) & 1
+        swap ^= bit
+        if swap: x2, x3, z2, z3 = x3, x2, z3, z2
+        swap = bit
+        a = (x2 + z2) % P; aa = a * a % P; b = (x2 - z2) % P; bb = b * b % P; e = (aa - bb) % P
+        c = (x3 + z3) % P; d = (x3 - z3) % P; da = d * a % P; cb = c * b % P
+        x3 = W1 * (da + cb) ** 2 % P; z3 = U1 * (da - cb) ** 2 % P
+        x2 = aa * bb % P; z2 = e * (aa + A24 * e) % P
+    if swap: x2, x3, z2, z3 = x3, x2, z3, z2
+    return x2, z2, x3, z3
+
+
+def mul_via_ladder_proj(a_bytes, P3):
+    """P3 = projective Edwards (X : Y : Z) -> affine Edwards a' * P, image (U : V : W) without any inversion:
+    u = (Z+Y)/(Z-Y) = U/W, v = c u Z / X = V/W with U = (Z+Y) X, V = c (Z+Y) Z, W = (Z-Y) X"""
+    X, Y, Z = P3
+    sign, k = effective(a_bytes)
+    zmy, zpy = (Z - Y) % P, (Z + Y) % P
+    is_id = (X == 0 and zmy == 0)
+    is_o2 = (X == 0 and zpy == 0)
+    U1, V1, W1 = zpy * X % P, C * zpy % P * Z % P, zmy * X % P
+    degenerate = (W1 == 0)
+    if degenerate: U1, V1, W1 = 1, 1, 1               # any finite point: the result is replaced below
+    x2, z2, x3, z3 = ladder_proj(k, U1, W1)
+    # Okeya-Sakurai with u = U1/W1, v = V1/W1, everything scaled by W1^2 (the output is projective)
+    T1 = U1 * z2 % P
+    Wx2 = W1 * x2 % P
+    T2 = (Wx2 + T1) % P                               # W t2
+    T3 = (Wx2 - T1) ** 2 % P * x3 % P                 # W^2 t3
+    a_ = 2 * A * z2 % P
+    T2 = (T2 + W1 * a_) % P                           # W (t2 + 2A z2)
+    T4 = (U1 * x2 + W1 * z2) % P                      # W t4
+    b_ = a_ * z2 % P
+    W2 = W1 * W1 % P
+    YP = ((T2 * T4 - W2 * b_) % P * z3 - T3) % P      # W^2 Yp
+    TT = 2 * V1 * z2 % P * z3 % P                     # W t1
+    Uo, Vo, Wo = W1 * TT % P * x2 % P, YP, W1 * TT % P * z2 % P
+    Xe = C * Uo % P * (Uo + Wo) % P; Ye = (Uo - Wo) * Vo % P; Ze = Vo * (Uo + Wo) % P
+    res_inf = (z2 == 0)
+    res_negp = (z3 == 0) and not res_inf
+    res_o2 = (x2 == 0) and (z2 != 0)
+    # -P from the image: x = c u / v, y = (u - 1)/(u + 1) with (u, v) = (U1, V1)/W1
+    nX, nY, nZ = (-C * U1 % P * (U1 + W1)) % P, (U1 - W1) * V1 % P, V1 * (U1 + W1) % P
+    if res_negp: Xe, Ye, Ze = nX, nY, nZ
+    if res_o2: Xe, Ye, Ze = 0, P - 1, 1
+    if res_inf: Xe, Ye, Ze = 0, 1, 1
+    if is_id or (degenerate and not is_o2): Xe, Ye, Ze = 0, 1, 1
+    if is_o2: Xe, Ye, Ze = (0, P - 1, 1) if (k & 1) else (0, 1, 1)
+    zi = inv(Ze)
+    rx, ry = Xe * zi % P, Ye * zi % P
+    if sign: rx = (-rx) % P
+    return rx, ry
+
+
+if __name__ == "__main__":
+    bad = n = 0
+    rnd = random.Random(2)
+    def proj(pt):
+        z = rnd.randrange(1, P)
+        return pt[0] * z % P, pt[1] * z % P, z
+    for q in kats["quirk_mul"]:
+        if not q["ok"]: continue
+        pt = M.decode(bytes.fromhex(q["point"]))
+        n += 1
+        if M.encode(mul_via_ladder_proj(bytes.fromhex(q["scalar"]), proj(pt))).hex() != q["out"]:
+            bad += 1; print("MISMATCH proj", q["point"][:16], q["scalar"][-8:])
+    for _ in range(300):
+        s = bytes(rnd.getrandbits(8) for _ in range(32))
+        pt = M.point_mul(bytes(rnd.getrandbits(8) for _ in range(32)))
+        if rnd.random() < 0.3:
+            pt = M.add(pt, M.decode(bytes.fromhex(kats["weak_keys"][rnd.choice([0, 2, 3, 4])])))
+        n += 1
+        if mul_via_ladder_proj(s, proj(pt)) != M.point_mul(s, pt): bad += 1; print("MISMATCH proj random")
+    for t in [0, 2, 3, 4]:
+        t8 = M.decode(bytes.fromhex(kats["weak_keys"][t]))
+        pt = M.add(M.point_mul((7).to_bytes(32, "little")), t8)
+        for k in [0, 1, 2, L - 1, L, L + 1, 2 * L, 4 * L - 1, 4 * L, 8 * L - 1, 8 * L, 8 * L + 1]:
+            n += 1
+            if mul_via_ladder_proj(k.to_bytes(32, "little"), proj(pt)) != M.point_mul(k.to_bytes(32, "little"), pt): bad += 1; print("MISMATCH proj mixed", t, k)
+    print("projective-base cases", n, "bad", bad)
