@@ -358,8 +358,8 @@ KYB_HD void ge_scalarmult_base64(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
     ge_precomp c;
     tbl.select(c, pos, mag, neg);
     ge_p1p1 t;
-    ge_madd(t, h, c);
-    ge_p1p1_to_p3_after_add(h, t);
+    ge_madd_lazy_t(t, h, c);
+    ge_p1p1_to_p3_lazy_t(h, t);
   }
   {
     uint32_t mag, neg;
@@ -367,8 +367,8 @@ KYB_HD void ge_scalarmult_base64(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
     ge_precomp c;
     tbl.select_top(c, mag);
     ge_p1p1 t;
-    ge_madd(t, h, c);
-    ge_p1p1_to_p3_after_add(h, t);
+    ge_madd_lazy_t(t, h, c);
+    ge_p1p1_to_p3_lazy_t(h, t);
   }
   fe nx, nt;
   fe_neg(nx, h.X); fe_reduce_weak(nx, nx);

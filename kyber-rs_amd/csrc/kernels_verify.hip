@@ -5,16 +5,9 @@
 #include <hip/hip_runtime.h>
 #include "launch.h"
 #include "schnorr.h"
-namespace kyb {
-// one out-of-line copy of the decompression (255 S + 20 M): called twice per item by k_verify_prep
-__device__ __noinline__ uint32_t ge_decode_outlined(ge_p3& h, const uint32_t w[8]) { return ge_decode(h, w); }
-__host__ inline uint32_t ge_decode_outlined_host(ge_p3& h, const uint32_t w[8]) { return ge_decode(h, w); }
-}
-#if defined(__HIP_DEVICE_COMPILE__)
-#define KYB_GE_DECODE ge_decode_outlined
-#else
-#define KYB_GE_DECODE ge_decode_outlined_host
-#endif
+// (round 1 routed the point decompression through one out-of-line copy because a single kernel decoded both A and R; with
+// the two halves in kernels of their own each decodes once, inline — the call's stack frame was the kernels' 208 / 240 B
+// of scratch and the reason for their 248 VGPRs)
 #include "verify.h"
 using namespace kyb;
 #include "device_tables.h"
