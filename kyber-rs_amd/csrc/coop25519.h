@@ -7,12 +7,17 @@
 // wavefront holds four rows, and the four independent multiplications of a ladder level / of a point addition run side by
 // side, so the dependent chain is ~60 instructions per level instead of ~140 per multiplication.
 //
-//   quad (`cq`)    one VGPR: row r = lanes 16r .. 16r+15 holds limbs 0..9 of element r in its first ten lanes, 0 in the rest
-//   cmul4(F, G)    four products F_r * G_r.  Lane k forms column k: sum_i f_i * g_{(k-i) mod 10} * m(i,k), with f_i broadcast and
-//                  g rotated inside the row by ds_bpermute_b32 and the 2x / 19x / 38x factors of the radix-2^25.5 product
-//                  (fe25519.h) as the per-lane constant m(i,k) applied to the broadcast f_i — so F must be TIGHT (<= 1.01T:
-//                  38 f_i < 2^32), G may be lazy (<= 4T).  Carries travel between lanes: a three-way split of the 64-bit
-//                  column (own limb / next limb / limb after that, x19 across the wrap) and one more light pass.
+//   quad (`cq`)    one VGPR: row r = lanes 16r .. 16r+15 holds limbs 0..9 of element r in its first ten lanes; lanes 10..15 of a row
+//                  are DON'T-CARE (nothing an active lane computes ever depends on them)
+//   cmul4(F, G)    four products F_r * G_r.  Lane k forms column k: sum_i f_i * g_{(k-i) mod 10} * m(i,k), with f_i broadcast
+//                  inside the row by DPP (v_mov_b32 row_newbcast:i — no LDS round trip), g rotated inside the row by
+//                  ds_bpermute_b32 (a rotation mod 10 is not a DPP pattern; the nine of them are in flight while the VALU does
+//                  the broadcasts), and the 2x / 19x / 38x factors of the radix-2^25.5 product (fe25519.h) as the per-lane
+//                  constant m(i,k) applied to the broadcast f_i — so F must be TIGHT (<= 1.01T: 38 f_i < 2^32), G may be lazy
+//                  (<= 4T).  Carries travel between NEIGHBOURING lanes, i.e. by DPP row shifts (row_shr:1 / row_shr:2; the
+//                  wrap from limbs 8, 9 to limbs 0, 1 by row_shl:8 / row_shl:9 times 19): a three-way split of the 64-bit column
+//                  (own limb / next limb / limb after that) and one more light pass.  No LDS traffic in the carries at all —
+//                  round 2 measured the dependent ds_bpermute round trips (~64 cycles each) as most of a lone wavefront's time.
 //   cnorm(V)       that light pass alone: any limbs < 2^31 -> tight
 //   rows are moved with ds_bpermute_b32 and per-lane index constants; additions are ONE instruction for four elements.
 //
@@ -20,6 +25,8 @@
 // paths with the oracle).  Constant time: the instruction stream and every lane index are independent of secret data except
 // the row index of the ladder's conditional swap, which goes through the conflict-free ds_bpermute crossbar exactly like the
 // window selection of the fixed-base kernel.
+// All of this needs the FULL wavefront active: a DPP or ds_bpermute read of a lane that EXEC has switched off returns 0, so
+// no cross-lane operation may sit under a lane-dependent branch (`cond ? move(a) : move(b)` must be written move, move, select).
 #pragma once
 #include "fe25519.h"
 
@@ -35,9 +42,7 @@ struct lane_consts {
   uint32_t mask, bits;            // of limb k
   uint32_t mask_next;             // of limb k+1 (mod 10)
   uint32_t p2;                    // limb k of 2p (0 in inactive lanes)
-  uint32_t c1, c2;                // 19 where the carry from lane k-1 / k-2 crosses the wrap (k == 0 / k < 2), else 1; 0 in inactive lanes
-  int prev1, prev2;               // byte index (4 * lane) of lanes k-1 and k-2 of the same row (mod 10); own lane when inactive
-  int bidx[10];                   // byte index of lane i of the same row
+  uint32_t w19a, w19b;            // 19 where the carry from limb k-1 / k-2 crosses the wrap (k == 0 / k < 2), else 0
   int ridx[10];                   // byte index of lane (k - i) mod 10 of the same row
   uint32_t mfac[10];              // m(i, k) in {1, 2, 19, 38}; 0 in inactive lanes
 };
@@ -55,13 +60,10 @@ __device__ __forceinline__ void lane_consts_init(lane_consts& c) {
   uint32_t p2 = 0;
   KYB_UNROLL for (int j = 0; j < 10; ++j) p2 = (k == (uint32_t)j) ? p2v[j] : p2;
   c.p2 = c.active ? p2 : 0u;
-  c.c1 = c.active ? (k == 0u ? 19u : 1u) : 0u;
-  c.c2 = c.active ? (k < 2u ? 19u : 1u) : 0u;
+  c.w19a = c.k == 0u ? 19u : 0u;
+  c.w19b = c.k < 2u ? 19u : 0u;
   const uint32_t base = c.row << 4;
-  c.prev1 = c.active ? (int)((base + (k + 9u) % 10u) << 2) : (int)(c.lane << 2);
-  c.prev2 = c.active ? (int)((base + (k + 8u) % 10u) << 2) : (int)(c.lane << 2);
   KYB_UNROLL for (int i = 0; i < 10; ++i) {
-    c.bidx[i] = (int)((base + (uint32_t)i) << 2);
     const uint32_t j = (k + 10u - (uint32_t)i) % 10u;               // g index of term i in column k
     c.ridx[i] = c.active ? (int)((base + j) << 2) : (int)(c.lane << 2);
     const uint32_t wrap = (uint32_t)i > k;                              // i + j >= 10
@@ -72,18 +74,27 @@ __device__ __forceinline__ void lane_consts_init(lane_consts& c) {
 
 __device__ __forceinline__ cq bperm(int idx, cq v) { return (cq)__builtin_amdgcn_ds_bpermute(idx, (int)v); }
 
+// DPP moves inside a 16-lane row; a lane whose source falls outside the row gets 0.  Controls (ISA 'DPP_CTRL'):
+//   row_shl:n  lane k reads lane k+n      row_shr:n  lane k reads lane k-n      row_newbcast:n  every lane reads lane n of its row
+// (checked on the device by tools/microbench/dpp_probe.hip)
+#define KYB_DPP_ROW_SHL(n) (0x100 + (n))
+#define KYB_DPP_ROW_SHR(n) (0x110 + (n))
+#define KYB_DPP_ROW_BCAST(n) (0x150 + (n))
+template <int CTRL>
+__device__ __forceinline__ cq dpp0(cq v) { return (cq)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+
 // byte-index vector that makes row r read row p_r (same limb position)
 __device__ __forceinline__ int rowperm_idx(const lane_consts& c, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3) {
   const uint32_t src = c.row == 0 ? p0 : (c.row == 1 ? p1 : (c.row == 2 ? p2 : p3));
   return (int)(((src << 4) | c.k) << 2);
 }
 
-// light carry pass: limbs < 2^31 in, tight (<= mask + 19 * 64) out.  4 instructions + one cross-lane move.
+// light carry pass: limbs < 2^31 in, tight (<= mask + 19 * 64) out.  Five VALU instructions, no LDS.
 __device__ __forceinline__ cq cnorm(const lane_consts& c, cq v) {
   const uint32_t lo = v & c.mask;
-  const uint32_t cy = v >> c.bits;
-  const uint32_t cin = bperm(c.prev1, cy);
-  return lo + cin * c.c1;
+  const uint32_t cy = v >> c.bits;                                             // < 2^7
+  const uint32_t r = lo + dpp0<KYB_DPP_ROW_SHR(1)>(cy);                        // carry of limb k-1 (v_add_u32_dpp)
+  return r + __umul24(dpp0<KYB_DPP_ROW_SHL(9)>(cy), c.w19a);                   // limb 0: 19 x the carry of limb 9 (v_mad_u32_u24)
 }
 
 // carry propagation of four 64-bit column vectors -> tight quad
@@ -92,18 +103,22 @@ __device__ __forceinline__ cq ccarry(const lane_consts& c, uint64_t s) {
   const uint64_t t = s >> c.bits;
   const uint32_t mid = (uint32_t)t & c.mask_next;            // belongs to limb k+1
   const uint32_t hi = (uint32_t)(s >> 51);                   // belongs to limb k+2 (26 + 25 bits up); < 2^13
-  const uint32_t mid_in = bperm(c.prev1, mid);
-  const uint32_t hi_in = bperm(c.prev2, hi);
-  const uint32_t v = lo + mid_in * c.c1 + hi_in * c.c2;      // < 2^26 + 19 * 2^26 + 19 * 2^13
-  return cnorm(c, v);
+  uint32_t v = lo + dpp0<KYB_DPP_ROW_SHR(1)>(mid);
+  v += dpp0<KYB_DPP_ROW_SHR(2)>(hi);
+  v += dpp0<KYB_DPP_ROW_SHL(9)>(mid) * c.w19a;               // limb 0 <- 19 x mid of limb 9
+  v += __umul24(dpp0<KYB_DPP_ROW_SHL(8)>(hi), c.w19b);       // limbs 0, 1 <- 19 x hi of limbs 8, 9
+  return cnorm(c, v);                                        // v < 2^26 + 19 * 2^26 + 20 * 2^13
 }
 
 // four products; F tight, G <= 4T
 __device__ __forceinline__ cq cmul4(const lane_consts& c, cq F, cq G) {
   uint32_t fb[10], gr[10];
-  KYB_UNROLL for (int i = 0; i < 10; ++i) fb[i] = bperm(c.bidx[i], F);
   gr[0] = G;
   KYB_UNROLL for (int i = 1; i < 10; ++i) gr[i] = bperm(c.ridx[i], G);
+  fb[0] = dpp0<KYB_DPP_ROW_BCAST(0)>(F); fb[1] = dpp0<KYB_DPP_ROW_BCAST(1)>(F); fb[2] = dpp0<KYB_DPP_ROW_BCAST(2)>(F);
+  fb[3] = dpp0<KYB_DPP_ROW_BCAST(3)>(F); fb[4] = dpp0<KYB_DPP_ROW_BCAST(4)>(F); fb[5] = dpp0<KYB_DPP_ROW_BCAST(5)>(F);
+  fb[6] = dpp0<KYB_DPP_ROW_BCAST(6)>(F); fb[7] = dpp0<KYB_DPP_ROW_BCAST(7)>(F); fb[8] = dpp0<KYB_DPP_ROW_BCAST(8)>(F);
+  fb[9] = dpp0<KYB_DPP_ROW_BCAST(9)>(F);
   uint64_t acc = (uint64_t)(fb[0] * c.mfac[0]) * gr[0];
   KYB_UNROLL for (int i = 1; i < 10; ++i) acc += (uint64_t)(fb[i] * c.mfac[i]) * gr[i];
   return ccarry(c, acc);
@@ -123,7 +138,7 @@ __device__ __forceinline__ cq quad_row_from_fe(const lane_consts& c, cq q, uint3
   return (c.row == r && c.active) ? v : q;
 }
 __device__ __forceinline__ void fe_from_quad_row(const lane_consts& c, fe& f, cq q, uint32_t r) {
-  (void)c;
+  (void)c;                                                   // (ten readlane-style fetches; outside the loops)
   KYB_UNROLL for (int j = 0; j < 10; ++j) f.v[j] = bperm((int)(((r << 4) | (uint32_t)j) << 2), q);
 }
 

@@ -169,6 +169,11 @@ KYB_HD void fe_one(fe& h) {
 KYB_HD void fe_copy(fe& h, const fe& f) {
   KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = f.v[i];
 }
+// 2p - g, limb-wise (g <= 1.99T)
+KYB_HD void fe_neg_raw(fe& h, const fe& g) {
+  const uint32_t p2[10] = KYB_FE_2P;
+  KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = kyb_sub32(p2[i], g.v[i], "fe_sub");
+}
 // h = f + g, no carry: bound(h) = bound(f) + bound(g)
 KYB_HD void fe_add(fe& h, const fe& f, const fe& g) {
   KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = kyb_add32(f.v[i], g.v[i], "fe_add");
@@ -177,6 +182,35 @@ KYB_HD void fe_add(fe& h, const fe& f, const fe& g) {
 KYB_HD void fe_sub(fe& h, const fe& f, const fe& g) {
   const uint32_t p2[10] = KYB_FE_2P;
   KYB_UNROLL for (int i = 0; i < 10; ++i) h.v[i] = kyb_add32(f.v[i], kyb_sub32(p2[i], g.v[i], "fe_sub"), "fe_sub+");
+}
+// The same two for the INNER LOOPS (ladder step, point doubling / addition): on the device two limbs share one 64-bit
+// addition (no carry can cross a word: limb sums stay below 2^32), 5 v_lshl_add_u64 instead of 10 v_add_u32.  These kernels
+// are bound by instruction COUNT, not by what an instruction does: the ladder step goes from 1275 to
+// 1245 instructions and the same-box A/B gives -3.3 % (mul), -3.7 % (mul_base), -2.6 % (sign), -2.0 % (verify):
+// profiles/r02/ab_add64w.log.  Register pairs cost allocation freedom, so code outside the loops (where the register
+// peaks are) keeps the 32-bit forms, and so do the doublings inside fe_sq (measured: no gain there).
+// -DKYB_NO_ADD64 turns these into the 32-bit forms as well.
+KYB_HD void fe_addw(fe& h, const fe& f, const fe& g) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KYB_NO_ADD64)
+  KYB_UNROLL for (int j = 0; j < 5; ++j) {
+    const uint64_t x = (uint64_t)f.v[2 * j] | ((uint64_t)f.v[2 * j + 1] << 32), y = (uint64_t)g.v[2 * j] | ((uint64_t)g.v[2 * j + 1] << 32);
+    uint64_t s;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(s) : "v"(x), "v"(y));      // as asm: LLVM otherwise splits some of these back into 32-bit halves
+    h.v[2 * j] = (uint32_t)s; h.v[2 * j + 1] = (uint32_t)(s >> 32);
+  }
+#else
+  fe_add(h, f, g);
+#endif
+}
+KYB_HD void fe_subw(fe& h, const fe& f, const fe& g) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KYB_NO_ADD64)
+  fe t;
+  fe_neg_raw(t, g);
+  KYB_UNROLL for (int i = 0; i < 10; ++i) asm("" : "+v"(t.v[i]));      // keep 2p - g as ten 32-bit subtractions (LLVM would widen them into borrow chains)
+  fe_addw(h, f, t);
+#else
+  fe_sub(h, f, g);
+#endif
 }
 // h = f - g computed as f + 4p - g; requires g <= 3.99T; bound(h) = bound(f) + 4T
 KYB_HD void fe_sub4(fe& h, const fe& f, const fe& g) {

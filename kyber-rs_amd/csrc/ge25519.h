@@ -53,49 +53,49 @@ KYB_HD void ge_p2_dbl(ge_p1p1& r, const fe& X, const fe& Y, const fe& Z) {
   fe_sq_b2(xx, X);
   fe_sq_b2(yy, Y);
   fe_sq_b2(zz, Z);
-  fe_add(a, X, Y);              // 2T
+  fe_addw(a, X, Y);              // 2T
   fe_sq_b2(aa, a);
-  fe_add(r.Y, yy, xx);          // 2T
-  fe_sub(r.Z, yy, xx);          // 3T
-  fe_sub(r.X, aa, yy);          // 3T
-  fe_sub(r.X, r.X, xx);         // 5T   = (X+Y)^2 - Y^2 - X^2
+  fe_addw(r.Y, yy, xx);          // 2T
+  fe_subw(r.Z, yy, xx);          // 3T
+  fe_subw(r.X, aa, yy);          // 3T
+  fe_subw(r.X, r.X, xx);         // 5T   = (X+Y)^2 - Y^2 - X^2
   fe t;
-  fe_add(t, zz, zz);            // 2T
-  fe_add(t, t, xx);             // 3T
-  fe_sub(t, t, yy);             // 5T   = 2Z^2 - (Y^2 - X^2)
+  fe_addw(t, zz, zz);            // 2T
+  fe_addw(t, t, xx);             // 3T
+  fe_subw(t, t, yy);             // 5T   = 2Z^2 - (Y^2 - X^2)
   fe_reduce_weak(r.T, t);       // tight
 }
 
 // ge.rs:217-233  (4M).  p tight; q: YpX <= 2T, YmX <= 3T, Z tight, T2d <= 2T
 KYB_HD void ge_add(ge_p1p1& r, const ge_p3& p, const ge_cached& q) {
   fe a, b, A, B, C, D, t;
-  fe_add(a, p.Y, p.X);          // 2T
-  fe_sub(b, p.Y, p.X);          // 3T
+  fe_addw(a, p.Y, p.X);          // 2T
+  fe_subw(b, p.Y, p.X);          // 3T
   fe_mul_b6(A, a, q.YpX);       // 2T x 2T
   fe_mul(B, b, q.YmX);          // 3T x 3T: general fold
   fe_mul_b6(C, q.T2d, p.T);     // 2T x tight
   fe_mul_b6(D, p.Z, q.Z);       // tight x tight
-  fe_add(D, D, D);              // 2T
-  fe_sub(r.X, A, B);            // 3T
-  fe_add(r.Y, A, B);            // 2T
-  fe_add(r.Z, D, C);            // 3T
-  fe_sub(t, D, C);              // 4T
+  fe_addw(D, D, D);              // 2T
+  fe_subw(r.X, A, B);            // 3T
+  fe_addw(r.Y, A, B);            // 2T
+  fe_addw(r.Z, D, C);            // 3T
+  fe_subw(t, D, C);              // 4T
   fe_reduce_weak(r.T, t);
 }
 
 // ge.rs:274-290  (3M).  p tight; q: ypx, ymx tight, xy2d <= 2T
 KYB_HD void ge_madd(ge_p1p1& r, const ge_p3& p, const ge_precomp& q) {
   fe a, b, A, B, C, D, t;
-  fe_add(a, p.Y, p.X);
-  fe_sub(b, p.Y, p.X);
+  fe_addw(a, p.Y, p.X);
+  fe_subw(b, p.Y, p.X);
   fe_mul_b6(A, a, q.ypx);       // 2T x tight
   fe_mul_b6(B, b, q.ymx);       // 3T x tight
   fe_mul_b6(C, q.xy2d, p.T);    // 2T x tight
-  fe_add(D, p.Z, p.Z);
-  fe_sub(r.X, A, B);
-  fe_add(r.Y, A, B);
-  fe_add(r.Z, D, C);
-  fe_sub(t, D, C);
+  fe_addw(D, p.Z, p.Z);
+  fe_subw(r.X, A, B);
+  fe_addw(r.Y, A, B);
+  fe_addw(r.Z, D, C);
+  fe_subw(t, D, C);
   fe_reduce_weak(r.T, t);
 }
 
@@ -133,16 +133,16 @@ KYB_HD void ge_p2_add(ge_p2& r, const ge_p2& a, const ge_p2& b) {
 // for two general folds (6 instructions) more.
 KYB_HD void ge_madd_lazy_t(ge_p1p1& r, const ge_p3& p, const ge_precomp& q) {
   fe a, b, A, B, C, D;
-  fe_add(a, p.Y, p.X);
-  fe_sub(b, p.Y, p.X);
+  fe_addw(a, p.Y, p.X);
+  fe_subw(b, p.Y, p.X);
   fe_mul_b6(A, a, q.ypx);       // 2T x tight
   fe_mul_b6(B, b, q.ymx);       // 3T x tight
   fe_mul_b6(C, q.xy2d, p.T);    // 2T x tight
-  fe_add(D, p.Z, p.Z);          // 2T
-  fe_sub(r.X, A, B);            // 3T
-  fe_add(r.Y, A, B);            // 2T
-  fe_add(r.Z, D, C);            // 3T
-  fe_sub(r.T, D, C);            // 4T
+  fe_addw(D, p.Z, p.Z);          // 2T
+  fe_subw(r.X, A, B);            // 3T
+  fe_addw(r.Y, A, B);            // 2T
+  fe_addw(r.Z, D, C);            // 3T
+  fe_subw(r.T, D, C);            // 4T
 }
 KYB_HD void ge_p1p1_to_p3_lazy_t(ge_p3& r, const ge_p1p1& p) {
   fe_mul(r.X, p.T, p.X);        // 4T x 3T: general fold

@@ -105,10 +105,10 @@ KYB_HD void mont_ladder(fe& x2, fe& z2, fe& x3, fe& z3, const fe& u1, const uint
       // Bounds: every product below is (<= 3T) x (<= 2T) or tighter, every square of a sum is of <= 2T: the short fold
       // (fe_mul_b6 / fe_sq_b2) applies; the two squares of differences (3T) take the general one.
       fe a, aa, b, bb, e, c, d, da, cb, t, sa, sb;
-      fe_add(a, x2, z2);                 // 2T
-      fe_sub(b, x2, z2);                 // 3T
-      fe_add(c, x3, z3);                 // 2T
-      fe_sub(d, x3, z3);                 // 3T
+      fe_addw(a, x2, z2);                 // 2T
+      fe_subw(b, x2, z2);                 // 3T
+      fe_addw(c, x3, z3);                 // 2T
+      fe_subw(d, x3, z3);                 // 3T
       fe_select(sa, a, c, swap);
       fe_select(sb, b, d, swap);
       swap = bit;
@@ -116,15 +116,15 @@ KYB_HD void mont_ladder(fe& x2, fe& z2, fe& x3, fe& z3, const fe& u1, const uint
       fe_sq(bb, sb);
       fe_mul_b6(da, d, a);               // f 3T, g 2T
       fe_mul_b6(cb, b, c);               // f 3T, g 2T
-      fe_sub(e, aa, bb);                 // 3T
-      fe_add(t, da, cb);                 // 2T
+      fe_subw(e, aa, bb);                 // 3T
+      fe_addw(t, da, cb);                 // 2T
       fe_sq_b2(x3, t);
-      fe_sub(t, da, cb);                 // 3T
+      fe_subw(t, da, cb);                 // 3T
       fe_sq(t, t);
       fe_mul_g19<true>(z3, t, u1, u1_19);
       fe_mul_b6(x2, aa, bb);
       fe_mul_small(t, e, 121665u);       // a24 * E
-      fe_add(t, t, aa);                  // 2T
+      fe_addw(t, t, aa);                  // 2T
       fe_mul_b6(z2, e, t);               // f 3T, g 2T
     }
   }
@@ -251,17 +251,17 @@ KYB_HD void mont_ladder_proj(fe& x2, fe& z2, fe& x3, fe& z3, const fe& U1, const
     const uint32_t bit = (word >> (i & 31)) & 1u;
     swap ^= bit;
     fe a, aa, b, bb, e, c, d, da, cb, t, sa, sb;
-    fe_add(a, x2, z2); fe_sub(b, x2, z2); fe_add(c, x3, z3); fe_sub(d, x3, z3);
+    fe_addw(a, x2, z2); fe_subw(b, x2, z2); fe_addw(c, x3, z3); fe_subw(d, x3, z3);
     fe_select(sa, a, c, swap);
     fe_select(sb, b, d, swap);
     swap = bit;
     fe_sq(aa, sa); fe_sq(bb, sb);
     fe_mul(da, d, a); fe_mul(cb, b, c);
-    fe_sub(e, aa, bb);
-    fe_add(t, da, cb); fe_sq(t, t); fe_mul(x3, t, W1);
-    fe_sub(t, da, cb); fe_sq(t, t); fe_mul(z3, t, U1);
+    fe_subw(e, aa, bb);
+    fe_addw(t, da, cb); fe_sq(t, t); fe_mul(x3, t, W1);
+    fe_subw(t, da, cb); fe_sq(t, t); fe_mul(z3, t, U1);
     fe_mul(x2, aa, bb);
-    fe_mul_small(t, e, 121665u); fe_add(t, t, aa); fe_mul(z2, e, t);
+    fe_mul_small(t, e, 121665u); fe_addw(t, t, aa); fe_mul(z2, e, t);
   }
   fe_cswap(x2, x3, swap);
   fe_cswap(z2, z3, swap);

@@ -112,26 +112,28 @@ def test_coop_primitives_match_the_lane_model(engine):
 
     c = M.lane_consts()
     rnd = random.Random(5)
+    act = (np.arange(64) & 15) < 10            # lanes 10..15 of a row are don't-care (coop25519.h)
+    same = lambda got, want: np.array_equal(np.asarray(got)[act], np.asarray(want)[act])
     for _ in range(4):
         a = [rnd.randrange(M.P) for _ in range(4)]
         b = [rnd.randrange(M.P) for _ in range(4)]
         F, G = M.quad_from_ints(c, a), M.quad_from_ints(c, b)
-        assert np.array_equal(run(7, F), F)
-        assert np.array_equal(run(1, M.cadd(F, G)), M.cnorm(c, M.cadd(F, G)))
-        assert np.array_equal(run(5, F, G), M.csub(c, F, G))
+        assert same(run(7, F), F)
+        assert same(run(1, M.cadd(F, G)), M.cnorm(c, M.cadd(F, G)))
+        assert same(run(5, F, G), M.csub(c, F, G))
         G4 = M.cadd(M.cadd(G, G), M.cadd(G, G))
-        assert np.array_equal(run(0, F, G4), M.cmul4(c, F, G4))
+        assert same(run(0, F, G4), M.cmul4(c, F, G4))
         assert M.ints_from_quad(run(0, F, G)) == [x * y % M.P for x, y in zip(a, b)]
         assert M.ints_from_quad(run(2, F)) == [pow(x, M.P - 2, M.P) for x in a]
         h = M.quad_from_ints(c, [rnd.randrange(M.P) for _ in range(4)])
         E = M.quad_from_ints(c, [rnd.randrange(M.P), rnd.randrange(M.P), rnd.randrange(M.P), 0])
-        assert np.array_equal(run(3, h, E), M.madd(c, h, E))
+        assert same(run(3, h, E), M.madd(c, h, E))
         for swap0 in (0, 1):
             for bit in (0, 1):
                 S = M.quad_from_ints(c, [rnd.randrange(M.P) for _ in range(4)])
                 UWQ = M.quad_from_ints(c, [rnd.randrange(M.P), 0, rnd.randrange(M.P), 0])       # U1 in row 0, W1 in row 2
                 B = UWQ.copy(); B[16] = swap0; B[17] = bit
-                assert np.array_equal(run(6, S, B), M.ladder_step(c, S, UWQ, swap0, bit)[0])
+                assert same(run(6, S, B), M.ladder_step(c, S, UWQ, swap0, bit)[0])
     assert M.ints_from_quad(run(2, M.quad_from_ints(c, [0, 1, M.P - 1, 2]))) == [0, 1, M.P - 1, pow(2, M.P - 2, M.P)]
     img64 = engine.base_table().view(np.uint32)[(65536 + 106496) // 4:]
     for pos, idx, neg in [(0, 0, 0), (0, 5, 0), (0, 31, 1), (7, 12, 1), (41, 8, 0), (42, 3, 0), (42, 15, 0)]:
@@ -149,4 +151,4 @@ def test_coop_primitives_match_the_lane_model(engine):
             for k in range(10):
                 v = int(img64[word(idx, 10 * ge + k)])
                 want[16 * g_ + k] = (M.P2[k] - v) if (g_ == 2 and neg) else v
-        assert np.array_equal(run(4, np.zeros(64, np.uint32), B), want), (pos, idx, neg)
+        assert same(run(4, np.zeros(64, np.uint32), B), want), (pos, idx, neg)
