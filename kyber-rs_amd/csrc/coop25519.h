@@ -45,6 +45,8 @@ struct lane_consts {
   uint32_t w19a, w19b;            // 19 where the carry from limb k-1 / k-2 crosses the wrap (k == 0 / k < 2), else 0
   int ridx[10];                   // byte index of lane (k - i) mod 10 of the same row
   uint32_t mfac[10];              // m(i, k) in {1, 2, 19, 38}; 0 in inactive lanes
+  int sqa[6], sqb[6];             // csq4: byte indices of limbs a_t = ceil(k/2) + t and b_t = floor(k/2) - t (mod 10) of the same row
+  uint32_t sqfac[6];              // csq4: factor of term t on the a side (see csq4); 0 in inactive lanes and for the one duplicate
 };
 
 __device__ __forceinline__ void lane_consts_init(lane_consts& c) {
@@ -69,6 +71,15 @@ __device__ __forceinline__ void lane_consts_init(lane_consts& c) {
     const uint32_t wrap = (uint32_t)i > k;                              // i + j >= 10
     const uint32_t oo = ((uint32_t)i & 1u) & (j & 1u);
     c.mfac[i] = c.active ? ((wrap ? 19u : 1u) * (oo ? 2u : 1u)) : 0u;
+  }
+  KYB_UNROLL for (int t = 0; t < 6; ++t) {
+    const uint32_t a = ((k + 1u) / 2u + (uint32_t)t) % 10u, b = (k / 2u + 10u - (uint32_t)t) % 10u;       // a + b = k (mod 10)
+    c.sqa[t] = c.active ? (int)((base + a) << 2) : (int)(c.lane << 2);
+    c.sqb[t] = c.active ? (int)((base + b) << 2) : (int)(c.lane << 2);
+    const uint32_t wrap = a + b >= 10u, oo = (a & 1u) & (b & 1u);
+    const uint32_t dup = (t == 5) & (k & 1u);                         // odd k: {a_5, b_5} = {a_4, b_4}
+    const uint32_t twice0 = (t == 0) & (k & 1u);                      // t = 0, odd k: a proper pair, counted twice here (no wrap, never both odd)
+    c.sqfac[t] = (c.active && !dup) ? ((wrap ? 19u : 1u) * (oo ? 2u : 1u) * (twice0 ? 2u : 1u)) : 0u;
   }
 }
 
@@ -110,20 +121,45 @@ __device__ __forceinline__ cq ccarry(const lane_consts& c, uint64_t s) {
   return cnorm(c, v);                                        // v < 2^26 + 19 * 2^26 + 20 * 2^13
 }
 
-// four products; F tight, G <= 4T
-__device__ __forceinline__ cq cmul4(const lane_consts& c, cq F, cq G) {
-  uint32_t fb[10], gr[10];
-  gr[0] = G;
-  KYB_UNROLL for (int i = 1; i < 10; ++i) gr[i] = bperm(c.ridx[i], G);
+// The ten rotations of a second operand G (<= 4T): g[i] in lane k = limb (k - i) mod 10 of the same row.  Nine ds_bpermute; a
+// caller that has G early issues them early and hides the LDS round trip behind other work.
+struct crot { uint32_t g[10]; };
+__device__ __forceinline__ crot crot_make(const lane_consts& c, cq G) {
+  crot r;
+  r.g[0] = G;
+  KYB_UNROLL for (int i = 1; i < 10; ++i) r.g[i] = bperm(c.ridx[i], G);
+  return r;
+}
+// four products F_r * G_r; F tight, G given by its rotations
+__device__ __forceinline__ cq cmul4r(const lane_consts& c, cq F, const crot& G) {
+  uint32_t fb[10];
   fb[0] = dpp0<KYB_DPP_ROW_BCAST(0)>(F); fb[1] = dpp0<KYB_DPP_ROW_BCAST(1)>(F); fb[2] = dpp0<KYB_DPP_ROW_BCAST(2)>(F);
   fb[3] = dpp0<KYB_DPP_ROW_BCAST(3)>(F); fb[4] = dpp0<KYB_DPP_ROW_BCAST(4)>(F); fb[5] = dpp0<KYB_DPP_ROW_BCAST(5)>(F);
   fb[6] = dpp0<KYB_DPP_ROW_BCAST(6)>(F); fb[7] = dpp0<KYB_DPP_ROW_BCAST(7)>(F); fb[8] = dpp0<KYB_DPP_ROW_BCAST(8)>(F);
   fb[9] = dpp0<KYB_DPP_ROW_BCAST(9)>(F);
-  uint64_t acc = (uint64_t)(fb[0] * c.mfac[0]) * gr[0];
-  KYB_UNROLL for (int i = 1; i < 10; ++i) acc += (uint64_t)(fb[i] * c.mfac[i]) * gr[i];
+  uint64_t acc = (uint64_t)(fb[0] * c.mfac[0]) * G.g[0];
+  KYB_UNROLL for (int i = 1; i < 10; ++i) acc += (uint64_t)(fb[i] * c.mfac[i]) * G.g[i];
   return ccarry(c, acc);
 }
-__device__ __forceinline__ cq csq4(const lane_consts& c, cq F) { return cmul4(c, F, F); }
+// four products; F tight, G <= 4T
+__device__ __forceinline__ cq cmul4(const lane_consts& c, cq F, cq G) { return cmul4r(c, F, crot_make(c, G)); }
+// four squares F_r^2, F tight; bit-identical to cmul4(c, F, F) (the same column sums) with the symmetric terms taken once:
+// column k = sum over the unordered pairs {a, b}, a + b = k (mod 10), of f_a f_b m(a, b) x (2 if a != b).  Step t = 0..5 takes
+// a = ceil(k/2) + t, b = floor(k/2) - t: for even k the steps 0 and 5 are the two squares and 1..4 the four pairs; for odd k
+// 0..4 are the five pairs and step 5 repeats step 4 (factor 0).  The pair's 2 rides on b (read from 2F) in steps 1..4 and on
+// the a-side factor in step 0 (where nothing wraps), so every a-side factor stays <= 38.  6 + 6 multiplications instead of
+// 10 + 10 and no DPP broadcasts; the twelve operand fetches are ds_bpermutes, which cost LDS time, not VALU issue slots.
+__device__ __forceinline__ cq csq4(const lane_consts& c, cq F) {
+  const cq F2 = F + F;
+  uint32_t fa[6], fb[6];
+  KYB_UNROLL for (int t = 0; t < 6; ++t) fa[t] = bperm(c.sqa[t], F);
+  fb[0] = bperm(c.sqb[0], F);
+  KYB_UNROLL for (int t = 1; t < 5; ++t) fb[t] = bperm(c.sqb[t], F2);
+  fb[5] = bperm(c.sqb[5], F);
+  uint64_t acc = (uint64_t)(fa[0] * c.sqfac[0]) * fb[0];
+  KYB_UNROLL for (int t = 1; t < 6; ++t) acc += (uint64_t)(fa[t] * c.sqfac[t]) * fb[t];
+  return ccarry(c, acc);
+}
 
 // element-wise on four elements at once
 __device__ __forceinline__ cq cadd(cq a, cq b) { return a + b; }
@@ -142,18 +178,18 @@ __device__ __forceinline__ void fe_from_quad_row(const lane_consts& c, fe& f, cq
   KYB_UNROLL for (int j = 0; j < 10; ++j) f.v[j] = bperm((int)(((r << 4) | (uint32_t)j) << 2), q);
 }
 
-// z^(p-2) of all four rows (fe_invert's chain, fe25519.h): 254 squarings + 11 products, each one cmul4.  Rows holding 0 stay 0.
 __device__ __forceinline__ cq csqn(const lane_consts& c, cq f, int n) {
   cq h = csq4(c, f);
 #pragma unroll 1
   for (int i = 1; i < n; ++i) h = csq4(c, h);
   return h;
 }
-__device__ __forceinline__ cq cinv(const lane_consts& c, cq z) {
+// z^(2^250 - 1) and z^11 of all four rows: the shared prefix of both exponentiations (fe_pow_250_1, fe25519.h)
+__device__ __forceinline__ void cpow_250_1(const lane_consts& c, cq& z250, cq& z11, cq z) {
   const cq z2 = csq4(c, z);
   cq t = csqn(c, z2, 2);
   const cq z9 = cmul4(c, t, z);
-  const cq z11 = cmul4(c, z9, z2);
+  z11 = cmul4(c, z9, z2);
   t = csq4(c, z11);
   const cq z5 = cmul4(c, t, z9);               // 2^5 - 1
   t = csqn(c, z5, 5);
@@ -169,9 +205,19 @@ __device__ __forceinline__ cq cinv(const lane_consts& c, cq z) {
   t = csqn(c, z100, 100);
   t = cmul4(c, t, z100);                       // 2^200 - 1
   t = csqn(c, t, 50);
-  t = cmul4(c, t, z50);                        // 2^250 - 1
-  t = csqn(c, t, 5);
-  return cmul4(c, t, z11);                     // 2^255 - 21
+  z250 = cmul4(c, t, z50);                     // 2^250 - 1
+}
+// z^(p-2) of all four rows (fe_invert): 254 squarings + 11 products.  Rows holding 0 stay 0.
+__device__ __forceinline__ cq cinv(const lane_consts& c, cq z) {
+  cq z250, z11;
+  cpow_250_1(c, z250, z11, z);
+  return cmul4(c, csqn(c, z250, 5), z11);      // 2^255 - 21
+}
+// z^((p-5)/8) = z^(2^252 - 3) of all four rows (fe_pow22523): the square-root chain of the point decode
+__device__ __forceinline__ cq cpow22523(const lane_consts& c, cq z) {
+  cq z250, z11;
+  cpow_250_1(c, z250, z11, z);
+  return cmul4(c, csqn(c, z250, 2), z);
 }
 
 }  // namespace coop

@@ -247,6 +247,18 @@ __device__ __forceinline__ void finish_point(const fe& X, const fe& Y, const fe&
   }
 }
 
+// completion signal (launch.h, DoneFlag): called by the thread that has just stored an item's results
+__device__ __forceinline__ void signal_done(const kyb::launch::DoneFlag& df) {
+  if (df.flag == nullptr) return;
+  __threadfence_system();                                                  // this item's results first, system-wide
+  const uint32_t before = atomicAdd(df.counter, 1u);
+  if (before + 1u == df.total) {
+    atomicExch(df.counter, 0u);                                            // ready for the next call
+    __threadfence_system();
+    __hip_atomic_store(df.flag, df.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // projective staging buffer for the split finish: uint4 [8 quads][stride items]
 //   dwords 0..9 X, 10..19 Y, 20..29 Z (tight limbs), 30..31 unused.  Item-minor so that both the

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -36,9 +37,9 @@ thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
 enum KernelId { KID_MUL, KID_MUL_BASE, KID_FINISH, KID_SIGN, KID_SIGN_HASH, KID_VERIFY_PREP, KID_VERIFY_FINAL, KID_POLY_EVAL, KID_MONT_PREP,
-                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_COUNT };
+                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_COUNT };
 const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval",
-                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop"};
+                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   std::mutex mu;                  // begin / read / every ProfScope: callable from any thread
@@ -81,6 +82,9 @@ struct Ctx {
   size_t stage_bytes = 0;
   uint8_t* stage2 = nullptr;      // staging of the second pipeline lane
   size_t stage2_bytes = 0;
+  uint32_t* done_flag = nullptr;          // coherent page-locked word the last kernel of a small host-pointer call writes (launch.h, DoneFlag)
+  uint32_t* done_counter = nullptr;       // device word: finished items of that kernel
+  uint32_t done_seq = 0;                  // under mu
   uint8_t* pin[2] = {nullptr, nullptr};   // page-locked bounce buffers of the two lanes (pageable caller memory)
   size_t pin_bytes[2] = {0, 0};
   kyb::CopyPool copy;
@@ -97,8 +101,9 @@ struct Ctx {
   std::atomic<int> opt_ladder_waves{3};       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
   std::atomic<int> opt_finish{1};             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
   std::atomic<int> opt_finish_min{1};         // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size; cross-check)
-  std::atomic<int> opt_coop_max{2048};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured at 2048, profiles/r02/coop_kernel_times.log)
-  std::atomic<int> opt_coop_base_max{2048};      // fixed base: the same
+  std::atomic<int> opt_coop_max{4096};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 4096 and 6144, profiles/r02/coop_crossover.log)
+  std::atomic<int> opt_coop_decode_max{1024};    // unmarshal_binary alone: the same (crossover between 1024 and 2048)
+  std::atomic<int> opt_coop_base_max{3072};      // fixed base: the same (crossover between 3072 and 4096; signing counts its two multiplications per item)
   std::atomic<int> opt_encode_batched{1};     // kyb_encode_batch: 1 shared inversion per 8 points (k_encode_batched), 0 one inversion per point (k_encode)
   std::mutex mu;          // host-pointer API: staging buffers + engine streams of this context
   std::mutex launch_mu;   // every launch_* entry: per-stream scratch bookkeeping (calls from any thread, any stream)
@@ -181,7 +186,8 @@ int ensure_pin(Ctx& g, int lane, size_t bytes) {
   if (bytes <= g.pin_bytes[lane]) return KYB_OK;
   if (g.pin[lane]) { memset(g.pin[lane], 0, g.pin_bytes[lane]); HIPCK(hipHostFree(g.pin[lane])); g.pin[lane] = nullptr; g.pin_bytes[lane] = 0; }
   size_t want = bytes + (bytes >> 2) + 4096;
-  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&g.pin[lane]), want, hipHostMallocDefault);
+  // coherent: the zero-copy path reads results out of it as soon as the last kernel signals, before the runtime has seen the kernel end
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&g.pin[lane]), want, hipHostMallocCoherent);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "pinned bounce buffer allocation", e);
   g.pin_bytes[lane] = want;
   return KYB_OK;
@@ -199,6 +205,49 @@ bool is_pinned(const void* p) {
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
   return a.type == hipMemoryTypeHost;
 }
+
+// ---- completion flag of small host-pointer calls --------------------------------------------------------
+// A zero-copy host-pointer call (run_host_batch / HostCall::run) posts a request in this thread-local; the launch sequence it runs
+// on the engine stream hands the flag to its LAST kernel (take_done_flag, only where nothing is queued behind that kernel), and
+// the call then spins on the flag word instead of synchronising the stream.  Sequences that do not take it are synchronised
+// as before.  (Thread-local: a device-pointer call another thread makes on the same context must never pick the request up.)
+struct DoneReq { bool armed = false; uint32_t seq = 0; };
+thread_local DoneReq* tl_done = nullptr;
+launch::DoneFlag take_done_flag(Ctx& g, hipStream_t st, size_t total) {
+  if (tl_done == nullptr || tl_done->armed || st != g.stream || g.done_flag == nullptr || total == 0 || total > 0xffffffffu) return launch::DoneFlag{};
+  tl_done->armed = true;
+  tl_done->seq = ++g.done_seq;
+  return launch::DoneFlag{g.done_counter, g.done_flag, tl_done->seq, (uint32_t)total};
+}
+int ensure_done_flag(Ctx& g) {
+  if (g.done_flag != nullptr) return KYB_OK;
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&g.done_flag), 64, hipHostMallocCoherent);
+  if (e != hipSuccess) { g.done_flag = nullptr; return fail(KYB_E_NOMEM, "completion flag allocation", e); }
+  *g.done_flag = 0;
+  e = hipMalloc(reinterpret_cast<void**>(&g.done_counter), 64);
+  if (e != hipSuccess) { (void)hipHostFree(g.done_flag); g.done_flag = nullptr; return fail(KYB_E_NOMEM, "completion counter allocation", e); }
+  HIPCK(hipMemset(g.done_counter, 0, 64));
+  return KYB_OK;
+}
+// after the launch sequence of a zero-copy call: wait for its results
+int wait_done(Ctx& g, const DoneReq& req) {
+  if (req.armed) {
+    volatile uint32_t* f = g.done_flag;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 1; *f != req.seq; ++it) {
+      __builtin_ia32_pause();
+      if ((it & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;      // a long batch: let the runtime wait
+    }
+    if (*f == req.seq) { std::atomic_thread_fence(std::memory_order_acquire); return KYB_OK; }
+  }
+  HIPCK(hipStreamSynchronize(g.stream));
+  return KYB_OK;
+}
+struct DoneScope {          // posts / withdraws the request around the launch sequence
+  DoneReq req;
+  DoneScope() { tl_done = &req; }
+  ~DoneScope() { tl_done = nullptr; }
+};
 
 // Host-pointer batches of fixed-size records: the batch is cut into chunks that alternate between two
 // streams (each with its own staging and scratch) so that the H2D copy of chunk c+1 and the D2H copy
@@ -227,9 +276,16 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
       dptr[k] = (arrs[k].in || arrs[k].out) ? g.pin[0] + off[k] : nullptr;
       if (arrs[k].in) memcpy(dptr[k], arrs[k].in, arrs[k].bytes * n);
     }
-    rc = launch(g.stream, n, dptr);
+    rc = ensure_done_flag(g);
     if (rc) return rc;
-    HIPCK(hipStreamSynchronize(g.stream));
+    {
+      DoneScope ds;
+      rc = launch(g.stream, n, dptr);
+      tl_done = nullptr;
+      if (rc) { (void)hipStreamSynchronize(g.stream); return rc; }
+      rc = wait_done(g, ds.req);
+      if (rc) return rc;
+    }
     for (int k = 0; k < na; ++k)
       if (arrs[k].out) memcpy(arrs[k].out, g.pin[0] + off[k], arrs[k].bytes * n);
     return KYB_OK;
@@ -342,9 +398,16 @@ class HostCall {
       base_ = g.pin[0];
       for (int i = 0; i < n_; ++i)
         if (a_[i].src && a_[i].bytes) memcpy(base_ + a_[i].off, a_[i].src, a_[i].bytes);
-      rc = body(g.stream);
+      rc = ensure_done_flag(g);
       if (rc) return rc;
-      HIPCK(hipStreamSynchronize(g.stream));
+      {
+        DoneScope ds;
+        rc = body(g.stream);
+        tl_done = nullptr;
+        if (rc) { (void)hipStreamSynchronize(g.stream); if (secret_ && total_) memset(base_, 0, total_); return rc; }
+        rc = wait_done(g, ds.req);
+        if (rc) return rc;
+      }
       for (int i = 0; i < n_; ++i)
         if (a_[i].dst && a_[i].bytes) memcpy(a_[i].dst, base_ + a_[i].off, a_[i].bytes);
       if (secret_ && total_) memset(base_, 0, total_);
@@ -424,8 +487,9 @@ int res_for(Ctx& g, hipStream_t st, StreamRes** out) {
 // ev_last is re-recorded behind everything the sequence queued.
 struct SlotUse {
   StreamRes* r; hipStream_t st;
-  SlotUse(StreamRes* r_, hipStream_t st_) : r(r_), st(st_) { if (r->used) (void)hipStreamWaitEvent(st, r->ev_last, 0); }
-  ~SlotUse() { (void)hipEventRecord(r->ev_last, st); r->used = true; }
+  // (the context's own streams live as long as their slots: nothing to protect, and two runtime calls less per launch sequence)
+  SlotUse(StreamRes* r_, hipStream_t st_) : r(r_), st(st_) { if (r->used && !r->own) (void)hipStreamWaitEvent(st, r->ev_last, 0); }
+  ~SlotUse() { if (!r->own) { (void)hipEventRecord(r->ev_last, st); r->used = true; } }
 };
 // the windowed-table kernel's per-wave table slots (160 MiB): only allocated if that kernel is used
 int ensure_ws(Ctx& g, StreamRes* r) {
@@ -494,6 +558,8 @@ void ctx_release(Ctx* c) {
   wipe_free_dev(c->stage, c->stage_bytes);
   wipe_free_dev(c->stage2, c->stage2_bytes);
   for (int l = 0; l < 2; ++l) if (c->pin[l]) { memset(c->pin[l], 0, c->pin_bytes[l]); (void)hipHostFree(c->pin[l]); }
+  if (c->done_flag) (void)hipHostFree(c->done_flag);
+  if (c->done_counter) (void)hipFree(c->done_counter);
   { std::lock_guard<std::mutex> lk(c->prof.mu);
     for (int i = 0; i < c->prof.cap; ++i) { (void)hipEventDestroy(c->prof.recs[i].a); (void)hipEventDestroy(c->prof.recs[i].b); }
     delete[] c->prof.recs; c->prof.recs = nullptr; c->prof.cap = c->prof.used = 0; c->prof.on = false; }
@@ -656,13 +722,13 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
     if (penc != nullptr) {
       int rc = ensure_enc(g, r, 160 * n + 256); if (rc) return rc;
       int32_t* tmp = reinterpret_cast<int32_t*>(r->enc);
-      { ProfScope ps(g, st, KID_DECODE); LAUNCHCK(launch::decode_or_identity(st, penc, n, tmp, ok)); }
+      { ProfScope ps(g, st, KID_DECODE_COOP); LAUNCHCK(launch::decode_coop(st, penc, n, tmp, ok, true)); }
       pext = tmp;
     } else if (ok != nullptr) {
       HIPCK(hipMemsetAsync(ok, 1, n, st));
     }
     ProfScope ps(g, st, KID_MUL_COOP);
-    LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, 0));
+    LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, 0, nullptr, 0, 0, take_done_flag(g, st, n)));
     return KYB_OK;
   }
   if (g.opt_mul_algo == 1) {
@@ -730,7 +796,7 @@ int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t*
   SlotUse use(r, st);
   if (n <= (size_t)g.opt_coop_base_max) {
     ProfScope ps(g, st, KID_MUL_BASE_COOP);
-    LAUNCHCK(launch::mul_base_coop(st, sc, n, oenc, oext, image64(g)));
+    LAUNCHCK(launch::mul_base_coop(st, sc, n, oenc, oext, image64(g), nullptr, 0, 0, nullptr, 0, take_done_flag(g, st, n)));
     return KYB_OK;
   }
   if (use_split(g, n)) {
@@ -771,7 +837,8 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
     }
     {
       ProfScope ps(g, st, KID_SIGN_HASH);
-      LAUNCHCK(launch::sign_hash(st, x, k, msgs, off, n, r->enc, pub_in, sig));
+      const bool last = pub_out == nullptr || pub_out == pub_in;
+      LAUNCHCK(launch::sign_hash(st, x, k, msgs, off, n, r->enc, pub_in, sig, last ? take_done_flag(g, st, n) : launch::DoneFlag{}));
     }
     if (pub_out != nullptr && pub_out != pub_in) HIPCK(hipMemcpyAsync(pub_out, pub_in, 32 * n, hipMemcpyDeviceToDevice, st));
     return KYB_OK;
@@ -785,7 +852,7 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
     }
     {
       ProfScope ps(g, st, KID_SIGN_HASH);
-      LAUNCHCK(launch::sign_hash(st, x, k, msgs, off, n, r->enc, r->enc + 32 * n, sig));
+      LAUNCHCK(launch::sign_hash(st, x, k, msgs, off, n, r->enc, r->enc + 32 * n, sig, pub_out == nullptr ? take_done_flag(g, st, n) : launch::DoneFlag{}));
     }
     if (pub_out != nullptr) HIPCK(hipMemcpyAsync(pub_out, r->enc + 32 * n, 32 * n, hipMemcpyDeviceToDevice, st));
     return KYB_OK;
@@ -871,11 +938,13 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   }
   {
     ProfScope ps(g, side, KID_VERIFY_PREP_R);
-    LAUNCHCK(launch::verify_prep_r(side, sigs, n, flags_r, r->proj, r->proj_items, 2 * n));
+    if (coop) LAUNCHCK(launch::verify_prep_r_coop(side, sigs, n, flags_r, r->proj, r->proj_items, 2 * n));
+    else LAUNCHCK(launch::verify_prep_r(side, sigs, n, flags_r, r->proj, r->proj_items, 2 * n));
   }
   {
     ProfScope ps(g, st, KID_VERIFY_PREP);
-    LAUNCHCK(launch::verify_prep(st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext));
+    if (coop) LAUNCHCK(launch::verify_prep_coop(st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext));
+    else LAUNCHCK(launch::verify_prep(st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext));
   }
   if (fork) {
     HIPCK(hipEventRecord(r->ev_fork, st));                 // s*B reads sbuf, which the A-half kernel has just been asked to write
@@ -901,7 +970,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   else { rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, st); if (rc) return rc; }
   {
     ProfScope ps(g, st, KID_VERIFY_FINAL);
-    LAUNCHCK(launch::verify_final(st, r->proj, r->proj_items, n, flags_a, flags_r, flavor, status));
+    LAUNCHCK(launch::verify_final(st, r->proj, r->proj_items, n, flags_a, flags_r, flavor, status, take_done_flag(g, st, n)));
   }
   return KYB_OK;
 }

@@ -185,7 +185,10 @@ KYB_HD void ge_encode_with_recip(uint32_t w[8], const fe& X, const fe& Y, const 
 
 // Decode (ge.rs:124-179).  Returns 1 on success.  Quirks kept: bit 255 of y ignored by the field
 // load, y >= p accepted, x = 0 with sign bit set accepted (x stays 0), Z = 1, T = x*y.
-KYB_HD uint32_t ge_decode(ge_p3& h, const uint32_t w[8]) {
+// `pow22523(out, z)` computes z^((p-5)/8) for a tight z: fe_pow22523 in the batch kernels, the lane-cooperative chain in the
+// small-batch kernels (kernels_coop.hip) — 252 of the decode's ~270 dependent multiplications.
+template <class Pow>
+KYB_HD uint32_t ge_decode_with(ge_p3& h, const uint32_t w[8], Pow&& pow22523) {
   const fe d = {KYB_FE_D};
   const fe sqrtm1 = {KYB_FE_SQRTM1};
   fe u, v, v3, vxx, chk, x, xm;
@@ -200,7 +203,7 @@ KYB_HD uint32_t ge_decode(ge_p3& h, const uint32_t w[8]) {
   fe_sq(x, v3);
   fe_mul(x, x, v);
   fe_mul(x, x, u);              // u v^7
-  fe_pow22523(x, x);
+  pow22523(x, x);
   fe_mul(x, x, v3);
   fe_mul(x, x, u);              // u v^3 (u v^7)^((p-5)/8)
   fe_sq(vxx, x);
@@ -222,6 +225,8 @@ KYB_HD uint32_t ge_decode(ge_p3& h, const uint32_t w[8]) {
   fe_mul(h.T, h.X, h.Y);
   return ok;
 }
+struct fe_pow22523_fn { KYB_HD void operator()(fe& o, const fe& z) const { fe_pow22523(o, z); } };
+KYB_HD uint32_t ge_decode(ge_p3& h, const uint32_t w[8]) { return ge_decode_with(h, w, fe_pow22523_fn()); }
 
 // ---------------------------------------------------------------------------------------------
 // Scalar recoding (ge.rs:443-459 / 519-534).  The reference turns the 64 nibbles of the scalar into

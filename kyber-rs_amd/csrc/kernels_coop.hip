@@ -6,11 +6,15 @@
 //                     cooperative.  One launch does the whole multiplication.
 //   k_mul_base_coop   Point::mul(s, None)     ge.rs:442-486   the radix-64 table of k_mul_base64 read from global memory (every
 //                     line of a limb's 32 entries is touched whatever the digit), 43 cooperative mixed additions, cooperative inversion.
+//   k_decode_coop     unmarshal_binary          ge.rs:124-179   ge_decode replicated on all lanes, its square-root chain
+//                     (252 of ~270 dependent multiplications) cooperative
+//   k_verify_prep_coop / k_verify_prep_r_coop   the two front halves of a verification (verify.h) with that decode
 // Used for batches that leave the chip idle (engine.hip: `coop.max_items`); results are bit-identical to the batch kernels.
 #include <hip/hip_runtime.h>
 #include "launch.h"
 #include "ge_scalarmult.h"
 #include "ge_ladder.h"
+#include "verify.h"
 #include "coop25519.h"
 using namespace kyb;
 using namespace kyb::coop;
@@ -26,6 +30,15 @@ struct row_masks {
 // proj != nullptr: the affine point also goes to staging record proj_offset + i (X, Y, Z = 1) for k_verify_final
 __device__ __forceinline__ void coop_finish(const lane_consts& c, const fe& X, const fe& Y, const fe& Z, uint32_t negate_x,
                                             uint8_t* out_enc, int32_t* out_ext, size_t i, uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0) {
+  if (out_enc == nullptr && out_ext == nullptr) {                     // projective consumers (k_verify_final) take (X : Y : Z) as it is: no inversion
+    fe x, nx;
+    fe_copy(x, X);
+    fe_neg(nx, x);
+    fe_reduce_weak(nx, nx);
+    fe_cmov(x, nx, negate_x);
+    if (proj != nullptr && c.lane == 0) store_proj(proj, proj_stride, proj_offset + i, x, Y, Z);
+    return;
+  }
   cq q = 0;
   q = quad_row_from_fe(c, q, 0, X);
   q = quad_row_from_fe(c, q, 1, Y);
@@ -59,45 +72,64 @@ __device__ __forceinline__ void coop_finish(const lane_consts& c, const fe& X, c
   }
 }
 
+// ge_decode (ge25519.h) with z^((p-5)/8) computed cooperatively (row 0 of a quad)
+struct coop_decode_fn {
+  const lane_consts& c;
+  __device__ __forceinline__ uint32_t operator()(ge_p3& P, const uint32_t w[8]) const {
+    const lane_consts& lc = c;
+    return ge_decode_with(P, w, [&lc](fe& o, const fe& z) { fe_from_quad_row(lc, o, cpow22523(lc, quad_row_from_fe(lc, 0u, 0, z)), 0); });
+  }
+};
+
 }  // namespace
 
-// One ladder step on the state S = (x2, z2, x3, z3) (rows 0..3) with the base point's u = U1 / W1 kept projective
-// (mont_ladder_proj, ge_ladder.h): UWQ holds U1 in row 0 and W1 in row 2.  `swap` = the pending conditional swap XOR this
-// step's scalar bit (the swap only exchanges (a, b) with (c, d)).  Three cooperative multiplication levels.
-struct ladder_idx { int I_0022, I_1133, I_F1, I_G1, I_2200, I_3311, I_1300, I_3333, I_0000, I_1120, x128; };
+// One ladder step with the base point's u = U1 / W1 kept projective (mont_ladder_proj, ge_ladder.h).  The state is held as two
+// quads with every coordinate twice, SX = (x2, x2, x3, x3) and SZ = (z2, z2, z3, z3): the additions in front of the first
+// multiplication level then need no cross-row traffic.  UWQ holds U1 in row 0 and W1 in row 2.  `swap` = the pending
+// conditional swap XOR this step's scalar bit (the swap only exchanges (a, b) with (c, d)).  Three cooperative multiplication
+// levels, six dependent LDS round trips (two operand fetches and two rotations in levels 1 and 2, one fetch in level 3 — its
+// second operands are known before level 2 ends and are rotated early — and the new state).
+struct ladder_idx { int I_F1, I_G1, I_2200, I_3311, I_1300, I_3333, I_0000, I_2222, I_1100, x128; };
+struct ladder_state { cq SX, SZ; };
 __device__ __forceinline__ ladder_idx ladder_idx_init(const lane_consts& c) {
-  return ladder_idx{rowperm_idx(c, 0, 0, 2, 2), rowperm_idx(c, 1, 1, 3, 3), rowperm_idx(c, 0, 1, 3, 1), rowperm_idx(c, 0, 1, 0, 2), rowperm_idx(c, 2, 2, 0, 0),
-                    rowperm_idx(c, 3, 3, 1, 1), rowperm_idx(c, 1, 3, 0, 0), rowperm_idx(c, 3, 3, 3, 3), rowperm_idx(c, 0, 0, 0, 0), rowperm_idx(c, 1, 1, 2, 0),
+  return ladder_idx{rowperm_idx(c, 0, 1, 3, 1), rowperm_idx(c, 0, 1, 0, 2), rowperm_idx(c, 2, 2, 0, 0), rowperm_idx(c, 3, 3, 1, 1), rowperm_idx(c, 1, 3, 0, 0),
+                    rowperm_idx(c, 3, 3, 3, 3), rowperm_idx(c, 0, 0, 0, 0), rowperm_idx(c, 2, 2, 2, 2), rowperm_idx(c, 1, 1, 0, 0),
                     c.row < 2 ? 128 : 0};             // x128: rows 0,1 read rows 2,3 of the source when the swap is set
 }
-__device__ __forceinline__ cq coop_ladder_step(const lane_consts& c, const ladder_idx& li, cq S, cq UWQ, uint32_t swap) {
-  const bool rodd = (c.row & 1u) != 0, r0 = c.row == 0, r1 = c.row == 1, r2 = c.row == 2, r3 = c.row == 3;
+__device__ __forceinline__ ladder_state coop_ladder_step(const lane_consts& c, const ladder_idx& li, ladder_state st, cq UWQ, uint32_t swap) {
+  const bool rodd = (c.row & 1u) != 0, r1 = c.row == 1, r2 = c.row == 2, r3 = c.row == 3;
   const cq A24Q = (r3 && c.k == 0) ? 121665u : 0u;
-  // level 0: a = x2 + z2, b = x2 - z2, c = x3 + z3, d = x3 - z3
-  const cq U = bperm(li.I_0022, S), V = bperm(li.I_1133, S);
-  const cq AB = cnorm(c, rodd ? csub(c, U, V) : cadd(U, V));                      // (a, b, c, d), tight
+  // level 0: (a, b, c, d) = (x2 + z2, x2 - z2, x3 + z3, x3 - z3)
+  const cq ABraw = rodd ? csub(c, st.SX, st.SZ) : cadd(st.SX, st.SZ);              // <= 3T: good enough for a second operand
+  const cq AB = cnorm(c, ABraw);
   // level 1: (aa, bb, da, cb) = (sa^2, sb^2, d*a, b*c) with (sa, sb) = swap ? (c, d) : (a, b)
   const int sx = (0 - (int)swap) & li.x128;
-  const cq L1 = cmul4(c, bperm(li.I_F1 ^ sx, AB), bperm(li.I_G1 ^ sx, AB));
+  const crot G1 = crot_make(c, bperm(li.I_G1 ^ sx, ABraw));
+  const cq L1 = cmul4r(c, bperm(li.I_F1 ^ sx, AB), G1);
   // level 2: (s, t', x2', a24*e) = ((da+cb)^2, (da-cb)^2, aa*bb, e*a24),  e = aa - bb
   const cq W = bperm(li.I_2200, L1), Z = bperm(li.I_3311, L1);                    // (da, da, aa, aa), (cb, cb, bb, bb)
-  const cq F2 = cnorm(c, rodd ? csub(c, W, Z) : (r2 ? W : cadd(W, Z)));            // (da+cb, da-cb, aa, e), tight
-  const cq G2 = r3 ? A24Q : (r2 ? Z : F2);
-  const cq L2 = cmul4(c, F2, G2);
-  // level 3: (z3', z2', x3') = (t' * U1, e * (a24*e + aa), s * W1)
-  const cq T3 = bperm(li.I_1300, L2);                                              // (t', a24*e, s, s)
+  const cq F2raw = rodd ? csub(c, W, Z) : (r2 ? W : cadd(W, Z));                   // (da+cb, da-cb, aa, e), <= 3T
+  const crot G2 = crot_make(c, r3 ? A24Q : (r2 ? Z : F2raw));
+  const cq F2 = cnorm(c, F2raw);
+  // second operands of level 3, rotated while level 2 multiplies: (U1, e, W1, -)
   const cq E1 = bperm(li.I_3333, F2), A1 = bperm(li.I_0000, L1);                   // e, aa in every row
-  const cq L3 = cmul4(c, r1 ? E1 : T3, r1 ? cadd(T3, A1) : UWQ);                   // row 3: * 0
-  // new state (x2', z2', x3', z3') = (L2 row 2, L3 row 1, L3 row 2, L3 row 0)
-  // (both cross-lane reads are issued by EVERY lane before the select: `cond ? bperm() : bperm()` would run each under a
+  const crot G3 = crot_make(c, r1 ? E1 : UWQ);
+  const cq L2 = cmul4r(c, F2, G2);
+  // level 3: (z3', z2', x3') = (t' * U1, (a24*e + aa) * e, s * W1)
+  const cq T3 = bperm(li.I_1300, L2);                                              // (t', a24*e, s, s)
+  const cq X2 = bperm(li.I_2222, L2);                                              // x2' in every row
+  const cq F3 = r1 ? cnorm(c, cadd(T3, A1)) : T3;                                  // row 3: * 0
+  const cq L3 = cmul4r(c, F3, G3);
+  // new state: SX = (x2', x2', x3', x3') = (L2 row 2 twice, L3 row 2 twice), SZ = (z2', z2', z3', z3') = (L3 rows 1, 1, 0, 0)
+  // (all cross-lane reads are issued by EVERY lane before the select: `cond ? bperm() : bperm()` would run each under a
   // partial EXEC mask, and a ds_bpermute that reads a disabled lane gets 0)
-  const cq fromL3 = bperm(li.I_1120, L3), fromL2 = bperm(li.I_2200, L2);
-  return r0 ? fromL2 : fromL3;
+  const cq x3n = bperm(li.I_2222, L3), zn = bperm(li.I_1100, L3);
+  return ladder_state{c.row < 2 ? X2 : x3n, zn};
 }
 
 __global__ void __launch_bounds__(64)
 k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
-           int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
+           int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, kyb::launch::DoneFlag df) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
   lane_consts c;
@@ -116,9 +148,10 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
   // ---- the ladder: state S = (x2, z2, x3, z3) in rows 0..3 ----
   const cq UWQ = quad_row_from_fe(c, quad_row_from_fe(c, 0, 0, m.U), 2, m.W);      // U1 in row 0, W1 in row 2 (second operands of level 3)
   const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
-  cq S = quad_row_from_fe(c, quad_row_from_fe(c, c.row == 0 ? ONE0 : 0u, 2, m.U), 3, m.W);      // (1, 0, U1, W1)
+  ladder_state st;                                                                 // (x2, z2, x3, z3) = (1, 0, U1, W1)
+  st.SX = quad_row_from_fe(c, quad_row_from_fe(c, c.row < 2 ? ONE0 : 0u, 2, m.U), 3, m.U);
+  st.SZ = quad_row_from_fe(c, quad_row_from_fe(c, 0u, 2, m.W), 3, m.W);
   const ladder_idx li = ladder_idx_init(c);
-  const int I_own = (int)(c.lane << 2);
   uint32_t swap = 0;
 #pragma unroll 1
   for (int w = 7; w >= 0; --w) {
@@ -132,21 +165,23 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
       const uint32_t bit = word >> 31;
       word <<= 1;
       swap ^= bit;
-      S = coop_ladder_step(c, li, S, UWQ, swap);
+      st = coop_ladder_step(c, li, st, UWQ, swap);
       swap = bit;
     }
   }
-  S = bperm(I_own ^ ((0 - (int)swap) & 128), S);                       // final conditional swap (x2, z2) <-> (x3, z3)
 
   // ---- replicated: y-recovery and the exceptional cases (mont_recover_to_edwards), then the encoding ----
+  // the final conditional swap (x2, z2) <-> (x3, z3) is the choice of the rows read here
   fe x2, z2, x3, z3;
-  fe_from_quad_row(c, x2, S, 0);
-  fe_from_quad_row(c, z2, S, 1);
-  fe_from_quad_row(c, x3, S, 2);
-  fe_from_quad_row(c, z3, S, 3);
+  const uint32_t ra = swap ? 2u : 0u, rb = swap ? 0u : 2u;
+  fe_from_quad_row(c, x2, st.SX, ra);
+  fe_from_quad_row(c, z2, st.SZ, ra);
+  fe_from_quad_row(c, x3, st.SX, rb);
+  fe_from_quad_row(c, z3, st.SZ, rb);
   ge_p2 r;
   mont_recover_to_edwards_proj(r, m, x2, z2, x3, z3, mag[0] & 1u, neg);
   coop_finish(c, r.X, r.Y, r.Z, 0u, out_enc, out_ext, i, proj, proj_stride, proj_offset);
+  if (c.lane == 0) signal_done(df);
 }
 
 // h + E for h = (X : Y : Z : T) in rows 0..3 and an affine table entry E = (y+x, y-x, 2dxy, 0): ge_madd followed by
@@ -197,7 +232,8 @@ __device__ __forceinline__ cq coop_table_entry(const lane_consts& c, const uint3
 
 __global__ void __launch_bounds__(64)
 k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ scalars_b, size_t n_a, size_t n, uint8_t* __restrict__ out_enc,
-                int32_t* __restrict__ out_ext, const uint32_t* __restrict__ image64, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
+                int32_t* __restrict__ out_ext, const uint32_t* __restrict__ image64, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset,
+                kyb::launch::DoneFlag df) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
   lane_consts c;
@@ -227,12 +263,75 @@ k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__
   fe_from_quad_row(c, Y, h, 1);
   fe_from_quad_row(c, Z, h, 2);
   coop_finish(c, X, Y, Z, dg.neg, out_enc, out_ext, i, proj, proj_stride, proj_offset);
+  if (c.lane == 0) signal_done(df);
+}
+
+// unmarshal_binary of a small batch: extended limbs and the ok flag; or_identity: failed decodes become the neutral element
+__global__ void __launch_bounds__(64)
+k_decode_coop(const uint8_t* __restrict__ enc, size_t n, int32_t* __restrict__ out_ext, uint8_t* __restrict__ ok_out, int or_identity, kyb::launch::DoneFlag df) {
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  lane_consts c;
+  lane_consts_init(c);
+  uint32_t w[8];
+  load_words8(w, enc, i);
+  ge_p3 P, id;
+  const uint32_t ok = coop_decode_fn{c}(P, w);
+  const uint32_t repl = or_identity ? 1u - ok : 0u;
+  ge_p3_0(id);
+  fe_cmov(P.X, id.X, repl); fe_cmov(P.Y, id.Y, repl); fe_cmov(P.Z, id.Z, repl); fe_cmov(P.T, id.T, repl);
+  if (c.lane == 0) {
+    store_ext(out_ext, i, P.X, P.Y, P.Z, P.T);
+    if (ok_out != nullptr) ok_out[i] = (uint8_t)ok;
+    signal_done(df);
+  }
+}
+
+// the A half of a verification (k_verify_prep, kernels_verify.hip): checks, decode of A, h = SHA-512(R || A || msg) mod L
+__global__ void __launch_bounds__(64)
+k_verify_prep_coop(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ msgs,
+                   const uint32_t* __restrict__ msg_off, size_t n, uint8_t* __restrict__ flags_a,
+                   uint8_t* __restrict__ hbuf, uint8_t* __restrict__ sbuf, int32_t* __restrict__ a_ext) {
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  lane_consts c;
+  lane_consts_init(c);
+  uint32_t pub[8], sig[16], h[8];
+  load_words8(pub, pubs, i);
+  load_words8(sig, sigs, 2 * i);
+  load_words8(sig + 8, sigs, 2 * i + 1);
+  const uint32_t off = msg_off[i], len = msg_off[i + 1] - off;
+  ge_p3 A;
+  const uint32_t fl = verify_prep_a_with(h, A, pub, sig, msgs + off, len, coop_decode_fn{c});
+  if (c.lane == 0) {
+    flags_a[i] = (uint8_t)fl;
+    store_words8(hbuf, i, h);
+    store_words8(sbuf, i, sig + 8);
+    store_ext(a_ext, i, A.X, A.Y, A.Z, A.T);
+  }
+}
+// the R half (k_verify_prep_r)
+__global__ void __launch_bounds__(64)
+k_verify_prep_r_coop(const uint8_t* __restrict__ sigs, size_t n, uint8_t* __restrict__ flags_r, uint4* __restrict__ proj, size_t stride, size_t proj_offset) {
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  lane_consts c;
+  lane_consts_init(c);
+  uint32_t sig[16];
+  load_words8(sig, sigs, 2 * i);
+  load_words8(sig + 8, sigs, 2 * i + 1);
+  ge_p3 R;
+  const uint32_t fl = verify_prep_r_with(R, sig, coop_decode_fn{c});
+  if (c.lane == 0) {
+    flags_r[i] = (uint8_t)fl;
+    store_proj(proj, stride, proj_offset + i, R.X, R.Y, R.Z);
+  }
 }
 
 // Test hook (tests/test_gpu_coop.py, against the lane-level model tools/coop_model.py): one wavefront applies ONE
 // cooperative primitive to caller-supplied quads.  op: 0 cmul4(A, B), 1 cnorm(A), 2 cinv(A), 3 mixed addition h = A, entry = B,
 // 4 table entry (window, idx, negate) = (B[0], B[1], B[2]) of the radix-64 image, 5 csub(A, B), 6 one ladder step S = A,
-// U1 / W1 in rows 0 / 2 of B, swap / bit in B lanes 16 / 17 (returns S'), 7 quad -> fe -> quad round trip of every row.
+// U1 / W1 in rows 0 / 2 of B, swap / bit in B lanes 16 / 17 (returns S'), 7 quad -> fe -> quad round trip of every row, 8 csq4(A).
 __global__ void __launch_bounds__(64)
 k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, uint32_t* __restrict__ out, const uint32_t* __restrict__ image64) {
   lane_consts c;
@@ -243,6 +342,7 @@ k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restri
   else if (op == 1) r = cnorm(c, a);
   else if (op == 2) r = cinv(c, a);
   else if (op == 5) r = csub(c, a, b);
+  else if (op == 8) r = csq4(c, a);
   else if (op == 4) {
     const uint32_t pos = B[0], idx = B[1], neg = B[2];
     r = pos < 42 ? coop_table_entry<32>(c, image64 + pos * KYB_BASE64_WIN_WORDS, idx, neg) : coop_table_entry<16>(c, image64 + KYB_BASE64_TOP_BASE, idx, 0u);
@@ -250,7 +350,10 @@ k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restri
     r = coop_madd(c, madd_idx_init(c), a, b);
   } else if (op == 6) {
     const uint32_t swap = B[16] ^ B[17];                              // pending swap XOR this step's bit
-    r = coop_ladder_step(c, ladder_idx_init(c), a, ((c.row == 0 || c.row == 2) && c.active) ? b : 0u, swap);
+    ladder_state st{bperm(rowperm_idx(c, 0, 0, 2, 2), a), bperm(rowperm_idx(c, 1, 1, 3, 3), a)};
+    st = coop_ladder_step(c, ladder_idx_init(c), st, ((c.row == 0 || c.row == 2) && c.active) ? b : 0u, swap);
+    const cq fx = bperm(rowperm_idx(c, 0, 0, 2, 2), st.SX), fz = bperm(rowperm_idx(c, 0, 0, 2, 2), st.SZ);
+    r = (c.row & 1u) ? fz : fx;                                       // (x2', z2', x3', z3')
   } else if (op == 7) {
     fe f[4];
     for (uint32_t q = 0; q < 4; ++q) fe_from_quad_row(c, f[q], a, q);
@@ -264,14 +367,27 @@ hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32
   hipLaunchKernelGGL(k_coop_selftest, dim3(1), dim3(64), 0, st, op, A, B, out, image64);
   return hipGetLastError();
 }
+hipError_t decode_coop(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok, bool or_identity, DoneFlag df) {
+  hipLaunchKernelGGL(k_decode_coop, dim3((unsigned)n), dim3(64), 0, st, enc, n, out_ext, ok, or_identity ? 1 : 0, df);
+  return hipGetLastError();
+}
+hipError_t verify_prep_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,
+                            uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf, int32_t* a_ext) {
+  hipLaunchKernelGGL(k_verify_prep_coop, dim3((unsigned)n), dim3(64), 0, st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext);
+  return hipGetLastError();
+}
+hipError_t verify_prep_r_coop(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* flags_r, uint4* proj, size_t stride, size_t offset) {
+  hipLaunchKernelGGL(k_verify_prep_r_coop, dim3((unsigned)n), dim3(64), 0, st, sigs, n, flags_r, proj, stride, offset);
+  return hipGetLastError();
+}
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
-                    uint4* proj, size_t proj_stride, size_t proj_offset) {
-  hipLaunchKernelGGL(k_mul_coop, dim3((unsigned)n), dim3(64), 0, st, sc, pext, n, oenc, oext, skip_bits, proj, proj_stride, proj_offset);
+                    uint4* proj, size_t proj_stride, size_t proj_offset, DoneFlag df) {
+  hipLaunchKernelGGL(k_mul_coop, dim3((unsigned)n), dim3(64), 0, st, sc, pext, n, oenc, oext, skip_bits, proj, proj_stride, proj_offset, df);
   return hipGetLastError();
 }
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
-                         uint4* proj, size_t proj_stride, size_t proj_offset, const uint8_t* sc_b, size_t n_b) {
-  hipLaunchKernelGGL(k_mul_base_coop, dim3((unsigned)(n + n_b)), dim3(64), 0, st, sc, sc_b, n, n + n_b, oenc, oext, image64, proj, proj_stride, proj_offset);
+                         uint4* proj, size_t proj_stride, size_t proj_offset, const uint8_t* sc_b, size_t n_b, DoneFlag df) {
+  hipLaunchKernelGGL(k_mul_base_coop, dim3((unsigned)(n + n_b)), dim3(64), 0, st, sc, sc_b, n, n + n_b, oenc, oext, image64, proj, proj_stride, proj_offset, df);
   return hipGetLastError();
 }
 }}  // namespace kyb::launch

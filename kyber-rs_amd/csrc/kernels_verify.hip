@@ -32,7 +32,7 @@ k_eddsa_prep(const uint8_t* __restrict__ seeds, const uint8_t* __restrict__ msgs
 __global__ void __launch_bounds__(KYB_BLOCK)
 k_sign_hash(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const uint8_t* __restrict__ msgs,
             const uint32_t* __restrict__ msg_off, size_t n, const uint8_t* __restrict__ r_enc, const uint8_t* __restrict__ a_enc,
-            uint8_t* __restrict__ sig) {
+            uint8_t* __restrict__ sig, kyb::launch::DoneFlag df) {
   const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t wx[8], wk[8], ra[16];
@@ -51,6 +51,7 @@ k_sign_hash(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const 
   sc_muladd(s, wx, h, wk);
   store_words8(sig, 2 * i, ra);
   store_words8(sig, 2 * i + 1, s);
+  signal_done(df);
 }
 
 // verification, A half: s < L, checks and decode of the public key, h = SHA-512(R || A || msg) mod L.
@@ -87,7 +88,7 @@ k_verify_prep_r(const uint8_t* __restrict__ sigs, size_t n, uint8_t* __restrict_
 // verification, last stage: hA at proj[i], sB at proj[n + i], R at proj[2n + i]; status = first failing check, else the equation
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
 k_verify_final(const uint4* __restrict__ proj, size_t stride, size_t n, const uint8_t* __restrict__ flags_a, const uint8_t* __restrict__ flags_r,
-               int flavor, uint8_t* __restrict__ status) {
+               int flavor, uint8_t* __restrict__ status, kyb::launch::DoneFlag df) {
   const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (i >= n) return;
   ge_p2 hA, sB;
@@ -98,6 +99,7 @@ k_verify_final(const uint4* __restrict__ proj, size_t stride, size_t n, const ui
   const uint32_t eq = verify_final(RX, RY, hA, sB);
   const uint32_t st = verify_status(flags_a[i], flags_r[i], flavor);
   status[i] = (st == 0 && !eq) ? (uint8_t)9 : (uint8_t)st;
+  signal_done(df);
 }
 
 
@@ -112,13 +114,13 @@ hipError_t verify_prep_r(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t*
   hipLaunchKernelGGL(k_verify_prep_r, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sigs, n, flags_r, proj, stride, offset);
   return hipGetLastError();
 }
-hipError_t verify_final(hipStream_t st, const uint4* proj, size_t stride, size_t n, const uint8_t* flags_a, const uint8_t* flags_r, int flavor, uint8_t* status) {
-  hipLaunchKernelGGL(k_verify_final, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, proj, stride, n, flags_a, flags_r, flavor, status);
+hipError_t verify_final(hipStream_t st, const uint4* proj, size_t stride, size_t n, const uint8_t* flags_a, const uint8_t* flags_r, int flavor, uint8_t* status, DoneFlag df) {
+  hipLaunchKernelGGL(k_verify_final, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, proj, stride, n, flags_a, flags_r, flavor, status, df);
   return hipGetLastError();
 }
 hipError_t sign_hash(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n,
-                     const uint8_t* r_enc, const uint8_t* a_enc, uint8_t* sig) {
-  hipLaunchKernelGGL(k_sign_hash, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, r_enc, a_enc, sig);
+                     const uint8_t* r_enc, const uint8_t* a_enc, uint8_t* sig, DoneFlag df) {
+  hipLaunchKernelGGL(k_sign_hash, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, x, k, msgs, off, n, r_enc, a_enc, sig, df);
   return hipGetLastError();
 }
 hipError_t eddsa_prep(hipStream_t st, const uint8_t* seeds, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* xbuf, uint8_t* kbuf) {

@@ -48,22 +48,34 @@ hipError_t ext_to_proj(hipStream_t st, const int32_t* pext, size_t n, uint4* pro
 hipError_t diag_set_stamp_buffer(uint64_t* dev_buf, size_t waves);
 #endif
 
+// Completion signal of a small host-pointer call (engine.hip, HostCall): the LAST kernel of the call's launch sequence counts
+// its finished items (threads or wavefronts, `total` of them) in *counter; the one that completes the count resets the counter and
+// stores `seq` into *flag, a word of coherent page-locked host memory the calling thread is spinning on — ~6 us sooner than
+// hipStreamSynchronize notices the end of the kernel (tools/microbench/launch_latency.hip).  flag == nullptr: no signal.
+struct DoneFlag { uint32_t* counter; uint32_t* flag; uint32_t seq; uint32_t total; };
+
 // ---- kernels_coop.hip ----
 // proj != nullptr: the affine result is also written to staging record proj_offset + i (Z = 1), the input format of k_verify_final
+hipError_t decode_coop(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok, bool or_identity, DoneFlag df = DoneFlag{});
+hipError_t verify_prep_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,
+                            uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf, int32_t* a_ext);
+hipError_t verify_prep_r_coop(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* flags_r, uint4* proj, size_t stride, size_t offset);
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
-                    uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0);
+                    uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, DoneFlag df = DoneFlag{});
 // sc_b != nullptr: n_b more scalars follow the first n in the same launch (their results behind the first n)
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
-                         uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, const uint8_t* sc_b = nullptr, size_t n_b = 0);
+                         uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, const uint8_t* sc_b = nullptr, size_t n_b = 0,
+                         DoneFlag df = DoneFlag{});
 hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* image64);
 
 // ---- kernels_verify.hip ----
 hipError_t verify_prep(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,
                        uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf, int32_t* a_ext);
 hipError_t verify_prep_r(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* flags_r, uint4* proj, size_t stride, size_t offset);
-hipError_t verify_final(hipStream_t st, const uint4* proj, size_t stride, size_t n, const uint8_t* flags_a, const uint8_t* flags_r, int flavor, uint8_t* status);
+hipError_t verify_final(hipStream_t st, const uint4* proj, size_t stride, size_t n, const uint8_t* flags_a, const uint8_t* flags_r, int flavor, uint8_t* status,
+                        DoneFlag df = DoneFlag{});
 hipError_t sign_hash(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n,
-                     const uint8_t* r_enc, const uint8_t* a_enc, uint8_t* sig);
+                     const uint8_t* r_enc, const uint8_t* a_enc, uint8_t* sig, DoneFlag df = DoneFlag{});
 hipError_t eddsa_prep(hipStream_t st, const uint8_t* seeds, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* xbuf, uint8_t* kbuf);
 
 // ---- kernels_misc.hip / kernels_window.hip ----

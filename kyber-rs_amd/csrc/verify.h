@@ -63,10 +63,12 @@ KYB_HD uint32_t pt_has_small_order(const fe& Y) {
 // A failed decode is replaced by the neutral element so that the later stages stay well defined.
 //   flags_a: bit 0 s canonical, 1 A canonical, 2 A decodes, 3 A has small order
 //   flags_r: bit 0 R canonical, 1 R decodes, 2 R has small order
-KYB_HD uint32_t verify_prep_a(uint32_t h[8], ge_p3& A, const uint32_t pub[8], const uint32_t sig[16], const uint8_t* msg, uint32_t msg_len) {
+// (`decode(P, words)`: ge_decode, or the small-batch kernels' cooperative form of it)
+template <class Dec>
+KYB_HD uint32_t verify_prep_a_with(uint32_t h[8], ge_p3& A, const uint32_t pub[8], const uint32_t sig[16], const uint8_t* msg, uint32_t msg_len, Dec&& decode) {
   const uint32_t s_ok = sc_is_canonical_w(sig + 8);
   const uint32_t a_can = pt_is_canonical_w(pub);
-  const uint32_t a_dec = KYB_GE_DECODE(A, pub);
+  const uint32_t a_dec = decode(A, pub);
   const uint32_t a_small = pt_has_small_order(A.Y);
   ge_p3 id;
   ge_p3_0(id);
@@ -82,15 +84,21 @@ KYB_HD uint32_t verify_prep_a(uint32_t h[8], ge_p3& A, const uint32_t pub[8], co
   sc_reduce512(h, dig);
   return s_ok | (a_can << 1) | (a_dec << 2) | (a_small << 3);
 }
-KYB_HD uint32_t verify_prep_r(ge_p3& R, const uint32_t sig[16]) {
+template <class Dec>
+KYB_HD uint32_t verify_prep_r_with(ge_p3& R, const uint32_t sig[16], Dec&& decode) {
   const uint32_t r_can = pt_is_canonical_w(sig);
-  const uint32_t r_dec = KYB_GE_DECODE(R, sig);
+  const uint32_t r_dec = decode(R, sig);
   const uint32_t r_small = pt_has_small_order(R.Y);
   ge_p3 id;
   ge_p3_0(id);
   fe_cmov(R.X, id.X, 1u - r_dec); fe_cmov(R.Y, id.Y, 1u - r_dec); fe_cmov(R.Z, id.Z, 1u - r_dec); fe_cmov(R.T, id.T, 1u - r_dec);
   return r_can | (r_dec << 1) | (r_small << 2);
 }
+struct ge_decode_fn { KYB_HD uint32_t operator()(ge_p3& P, const uint32_t w[8]) const { return KYB_GE_DECODE(P, w); } };
+KYB_HD uint32_t verify_prep_a(uint32_t h[8], ge_p3& A, const uint32_t pub[8], const uint32_t sig[16], const uint8_t* msg, uint32_t msg_len) {
+  return verify_prep_a_with(h, A, pub, sig, msg, msg_len, ge_decode_fn());
+}
+KYB_HD uint32_t verify_prep_r(ge_p3& R, const uint32_t sig[16]) { return verify_prep_r_with(R, sig, ge_decode_fn()); }
 // status of the pre-equation checks: the FIRST failing one in the order of the flavour (evaluated last-to-first)
 KYB_HD uint32_t verify_status(uint32_t flags_a, uint32_t flags_r, int flavor) {
   const uint32_t s_ok = flags_a & 1u, a_can = (flags_a >> 1) & 1u, a_dec = (flags_a >> 2) & 1u, a_small = (flags_a >> 3) & 1u;

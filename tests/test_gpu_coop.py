@@ -67,6 +67,60 @@ def test_coop_variable_base_matches_oracle(coop_engine, oracle):
     assert np.array_equal(eng.mul(s, pts_ext=b), oracle.mul_batch(s, b, nthreads=8))
 
 
+def test_coop_decode_sign_verify_match_oracle(coop_engine, oracle):
+    """the small-batch forms of unmarshal_binary (cooperative square-root chain), Schnorr signing and both verification
+    flavours (cooperative decodes of A and R, both multiplications projective into the final comparison): weak keys, invalid
+    and non-canonical encodings, every reject reason, the 1024 golden EdDSA lines"""
+    import gzip
+    import hashlib
+    from test_device_source_on_host import verify_cases
+    eng = coop_engine
+    rng = np.random.default_rng(15)
+    encs = [bytes.fromhex(h) for h in KATS["weak_keys"] + KATS["invalid_encodings"] + [KATS["decode_kat"]]]
+    P = 2**255 - 19
+    encs += [(P + k).to_bytes(32, "little") for k in range(19)] + [bytes([1] + [0] * 30 + [0x80])]
+    encs += [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(300)]
+    ext, ok = eng.decode(np.frombuffer(b"".join(encs), dtype=np.uint8))
+    for i, e in enumerate(encs):
+        oext, ook = oracle.decode(e)
+        assert ok[i] == ook, e.hex()
+        if ook:
+            assert oracle.encode(ext[i]) == oracle.encode(oext)
+    cases = verify_cases(oracle)
+    pubs = np.frombuffer(b"".join(c[0] for c in cases), dtype=np.uint8)
+    sigs = np.frombuffer(b"".join(c[2] for c in cases), dtype=np.uint8)
+    msgs = [c[1] for c in cases]
+    for flavor in (0, 1):
+        want = np.array([oracle.verify(flavor, *c) for c in cases], dtype=np.uint8)
+        assert set(want.tolist()) >= {0, 2, 3, 4, 5, 6, 7, 8, 9}
+        for overlap in (1, 0):
+            eng.set_option("verify.overlap", overlap)
+            try:
+                eng.profile_begin(16)
+                assert np.array_equal(eng.verify(pubs, msgs, sigs, flavor), want)
+                names = [k for k, _ in eng.profile_read(16)]
+                assert "k_mul_coop" in names and "k_mul_base_coop" in names and "k_mul_ladder" not in names
+                assert np.array_equal(eng.verify(pubs[:32], msgs[:1], sigs[:64], flavor), want[:1])
+            finally:
+                eng.profile_begin(0)
+                eng.set_option("verify.overlap", 1)
+    xs, ks, ms, ss, ps = [], [], [], [], []
+    for ln in gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n"):
+        if not ln:
+            continue
+        p = ln.split(":")
+        seed, msg, sig = bytes.fromhex(p[0])[:32], bytes.fromhex(p[2]), bytes.fromhex(p[3])[:64]
+        d = bytearray(hashlib.sha512(seed).digest())
+        d[0] &= 0xF8; d[31] &= 0x7F; d[31] |= 0x40
+        r = int.from_bytes(hashlib.sha512(bytes(d[32:]) + msg).digest(), "little") % synth.L
+        xs.append(bytes(d[:32])); ks.append(r.to_bytes(32, "little")); ms.append(msg); ss.append(sig); ps.append(bytes.fromhex(p[1]))
+    u8 = lambda lst: np.frombuffer(b"".join(lst), dtype=np.uint8)
+    assert [bytes(r) for r in eng.schnorr_sign(u8(xs), u8(ks), ms)] == ss
+    assert not eng.verify(u8(ps), ms, u8(ss), 0).any()
+    bad = bytearray(b"".join(ss)); bad[40] ^= 1
+    assert eng.verify(u8(ps), ms, np.frombuffer(bytes(bad), dtype=np.uint8), 0)[0] == 9
+
+
 def test_coop_and_batch_kernels_agree_at_the_threshold(engine, oracle):
     """the routing by size: n <= coop.max_items -> cooperative kernel, above -> batch kernels; same bytes either way"""
     s = synth.raw256(130, 800)
@@ -123,6 +177,7 @@ def test_coop_primitives_match_the_lane_model(engine):
         assert same(run(5, F, G), M.csub(c, F, G))
         G4 = M.cadd(M.cadd(G, G), M.cadd(G, G))
         assert same(run(0, F, G4), M.cmul4(c, F, G4))
+        assert same(run(8, F), M.cmul4(c, F, F))                  # the symmetric squaring gives the very limbs of the product
         assert M.ints_from_quad(run(0, F, G)) == [x * y % M.P for x, y in zip(a, b)]
         assert M.ints_from_quad(run(2, F)) == [pow(x, M.P - 2, M.P) for x in a]
         h = M.quad_from_ints(c, [rnd.randrange(M.P) for _ in range(4)])

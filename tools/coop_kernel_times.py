@@ -8,12 +8,19 @@ import kyber_rs_amd, synth
 eng = kyber_rs_amd.Engine(0)
 s = synth.scalars(8192, 3)
 _, ext = eng.mul_base(s, want_ext=True)
+k = synth.scalars(8192, 4)
+msgs = [bytes([i & 255]) * 32 for i in range(1024)]
+pubs = eng.mul_base(s[:1024])
+sigs = eng.schnorr_sign(s[:1024], k[:1024], msgs)
 print("n, path, op, call_us, kernels")
 for coop in (1, 0):
     eng.set_option("coop.max_items", 1 << 20 if coop else 0)
     eng.set_option("coop.base_max_items", 1 << 20 if coop else 0)
     for n in (1, 64, 1024, 2048, 4096):
-        for op, fn in (("mul_base", lambda: eng.mul_base(s[:n])), ("mul", lambda: eng.mul(s[:n], pts_ext=ext[:n]))):
+        for op, fn in (("mul_base", lambda: eng.mul_base(s[:n])), ("mul", lambda: eng.mul(s[:n], pts_ext=ext[:n])),
+                       ("sign", lambda: eng.schnorr_sign(s[:n], k[:n], msgs[:n])), ("verify", lambda: eng.verify(pubs[:n], msgs[:n], sigs[:n], 1))):
+            if op in ("sign", "verify") and n > 1024:
+                continue
             fn(); fn()
             ts = []
             for _ in range(7):

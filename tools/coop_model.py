@@ -117,26 +117,38 @@ def cinv(c, z):
 
 
 def ladder_step(c, S, UWQ, swap, bit):
-    """one step of k_mul_coop's loop (projective base point: U1 in row 0, W1 in row 2 of UWQ); returns (S', swap')"""
+    """one step of k_mul_coop's loop (projective base point: U1 in row 0, W1 in row 2 of UWQ) on the state S = (x2, z2, x3,
+    z3); the kernel keeps it as SX = (x2, x2, x3, x3), SZ = (z2, z2, z3, z3).  Returns (S', swap')"""
+    I = lambda *p: rowperm_idx(c, *p)
+    SX, SZ = bperm(I(0, 0, 2, 2), S), bperm(I(1, 1, 3, 3), S)
+    SX, SZ, swap = ladder_step_xz(c, SX, SZ, UWQ, swap, bit)
+    fx, fz = bperm(I(0, 0, 2, 2), SX), bperm(I(0, 0, 2, 2), SZ)
+    return np.where((c.row & 1) == 1, fz, fx), swap
+
+
+def ladder_step_xz(c, SX, SZ, UWQ, swap, bit):
     rodd, r0, r1, r2, r3 = (c.row & 1) == 1, c.row == 0, c.row == 1, c.row == 2, c.row == 3
     A24Q = np.where(r3 & (c.k == 0), 121665, 0).astype(np.uint64)
     I = lambda *p: rowperm_idx(c, *p)
     x128 = np.where(c.row < 2, 32, 0)          # lane index units here (the HIP code works in bytes: 128)
     swap ^= bit
-    U, V = bperm(I(0, 0, 2, 2), S), bperm(I(1, 1, 3, 3), S)
-    AB = cnorm(c, np.where(rodd, csub(c, U, V), cadd(U, V)))
+    ABraw = np.where(rodd, csub(c, SX, SZ), cadd(SX, SZ))
+    AB = cnorm(c, ABraw)
     sx = x128 if swap else 0
-    L1 = cmul4(c, bperm(I(0, 1, 3, 1) ^ sx, AB), bperm(I(0, 1, 0, 2) ^ sx, AB))
+    L1 = cmul4(c, bperm(I(0, 1, 3, 1) ^ sx, AB), bperm(I(0, 1, 0, 2) ^ sx, ABraw))
     swap = bit
     W, Z = bperm(I(2, 2, 0, 0), L1), bperm(I(3, 3, 1, 1), L1)
-    F2 = cnorm(c, np.where(rodd, csub(c, W, Z), np.where(r2, W, cadd(W, Z))))
-    G2 = np.where(r3, A24Q, np.where(r2, Z, F2))
+    F2raw = np.where(rodd, csub(c, W, Z), np.where(r2, W, cadd(W, Z)))
+    G2 = np.where(r3, A24Q, np.where(r2, Z, F2raw))
+    F2 = cnorm(c, F2raw)
     L2 = cmul4(c, F2, G2)
     T3 = bperm(I(1, 3, 0, 0), L2)
     E1, A1 = bperm(I(3, 3, 3, 3), F2), bperm(I(0, 0, 0, 0), L1)
-    L3 = cmul4(c, np.where(r1, E1, T3), np.where(r1, cadd(T3, A1), UWQ))
-    S = np.where(r0, bperm(I(2, 2, 0, 0), L2), bperm(I(1, 1, 2, 0), L3))
-    return S, swap
+    F3 = np.where(r1, cnorm(c, cadd(T3, A1)), T3)
+    L3 = cmul4(c, F3, np.where(r1, E1, UWQ))
+    SXn = np.where(c.row < 2, bperm(I(2, 2, 2, 2), L2), bperm(I(2, 2, 2, 2), L3))
+    SZn = bperm(I(1, 1, 0, 0), L3)
+    return SXn, SZn, swap
 
 
 def madd(c, h, E):
