@@ -26,33 +26,27 @@ struct row_masks {
   bool odd, r0, r1, r2, r3;
 };
 
-// encode (and optionally affine limbs) from a point (X : Y : Z) held replicated; Z^-1 computed cooperatively
-// proj != nullptr: the affine point also goes to staging record proj_offset + i (X, Y, Z = 1) for k_verify_final
-__device__ __forceinline__ void coop_finish(const lane_consts& c, const fe& X, const fe& Y, const fe& Z, uint32_t negate_x,
+// encode (and optionally affine limbs) from a point (X : Y : Z) in rows 0..2 of a tight quad; Z^-1 computed cooperatively.
+// proj != nullptr: the point also goes to staging record proj_offset + i for k_verify_final — affine (Z = 1) next to an
+// encoding or limbs, as it is (projective, no inversion at all) when it is the only output.
+__device__ __forceinline__ void coop_finish(const lane_consts& c, cq q, uint32_t negate_x,
                                             uint8_t* out_enc, int32_t* out_ext, size_t i, uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0) {
-  if (out_enc == nullptr && out_ext == nullptr) {                     // projective consumers (k_verify_final) take (X : Y : Z) as it is: no inversion
-    fe x, nx;
-    fe_copy(x, X);
-    fe_neg(nx, x);
-    fe_reduce_weak(nx, nx);
-    fe_cmov(x, nx, negate_x);
-    if (proj != nullptr && c.lane == 0) store_proj(proj, proj_stride, proj_offset + i, x, Y, Z);
+  const cq nq = cnorm(c, c.p2 - q);                                    // row 0: -X
+  q = (c.row == 0 && negate_x) ? nq : q;
+  if (out_enc == nullptr && out_ext == nullptr) {
+    fe X, Y, Z;
+    fe_from_quad_row(c, X, q, 0);
+    fe_from_quad_row(c, Y, q, 1);
+    fe_from_quad_row(c, Z, q, 2);
+    if (proj != nullptr && c.lane == 0) store_proj(proj, proj_stride, proj_offset + i, X, Y, Z);
     return;
   }
-  cq q = 0;
-  q = quad_row_from_fe(c, q, 0, X);
-  q = quad_row_from_fe(c, q, 1, Y);
-  q = quad_row_from_fe(c, q, 2, Z);
   const cq inv = cinv(c, q);                                         // row 2 = 1/Z (0 when Z = 0: the reference's 0^(p-2))
   const cq zi = bperm(rowperm_idx(c, 2, 2, 2, 2), inv);
   const cq xy = cmul4(c, q, zi);                                     // rows 0, 1 = x, y
   fe x, y;
   fe_from_quad_row(c, x, xy, 0);
   fe_from_quad_row(c, y, xy, 1);
-  fe nx;
-  fe_neg(nx, x);
-  fe_reduce_weak(nx, nx);
-  fe_cmov(x, nx, negate_x);
   if (out_enc != nullptr) {
     uint32_t w[8];
     fe_to_words(w, y);
@@ -70,6 +64,12 @@ __device__ __forceinline__ void coop_finish(const lane_consts& c, const fe& X, c
     fe_one(one);
     if (c.lane == 0) store_proj(proj, proj_stride, proj_offset + i, x, y, one);
   }
+}
+// 1 iff row r of a tight quad is 0 mod p (the row fetched into every lane, then fe_is_nonzero's canonical test)
+__device__ __forceinline__ uint32_t coop_row_is_zero(const lane_consts& c, cq q, uint32_t r) {
+  fe f;
+  fe_from_quad_row(c, f, q, r);
+  return 1u - fe_is_nonzero(f);
 }
 
 // ge_decode (ge25519.h) with z^((p-5)/8) computed cooperatively (row 0 of a quad)
@@ -127,6 +127,90 @@ __device__ __forceinline__ ladder_state coop_ladder_step(const lane_consts& c, c
   return ladder_state{c.row < 2 ? X2 : x3n, zn};
 }
 
+// Head of k_mul_coop in quads (mont_prep_proj, ge_ladder.h): PQ = (X, Y, Z, T) -> M = (U, V, W, 0), the projective Montgomery
+// image u = U / W, v = V / W with U = (Z+Y) X, V = c (Z+Y) Z, W = (Z-Y) X; flags as mont_point.  Two multiplication levels.
+__device__ __forceinline__ cq coop_mont_prep(const lane_consts& c, cq PQ, uint32_t& flags) {
+  const bool r0 = c.row == 0, r1 = c.row == 1, r2 = c.row == 2, r3 = c.row == 3;
+  const uint32_t ccv[10] = KYB_FE_MONT_C;
+  uint32_t cck = 0;
+  KYB_UNROLL for (int j = 0; j < 10; ++j) cck = (c.k == (uint32_t)j) ? ccv[j] : cck;
+  const cq ZZ = bperm(rowperm_idx(c, 2, 2, 2, 2), PQ), YY = bperm(rowperm_idx(c, 1, 1, 1, 1), PQ), XX = bperm(rowperm_idx(c, 0, 0, 0, 0), PQ);
+  const cq Fp = cnorm(c, r0 ? csub(c, ZZ, YY) : cadd(ZZ, YY));           // (Z-Y, Z+Y, Z+Y, Z+Y)
+  const cq M1 = cmul4(c, Fp, r2 ? ZZ : XX);                                // (W, U, (Z+Y) Z, -)
+  const cq M2 = cmul4(c, M1, (r2 && c.active) ? cck : 0u);                 // row 2 = V
+  const cq a = bperm(rowperm_idx(c, 1, 1, 0, 0), M1), b = bperm(rowperm_idx(c, 2, 2, 2, 2), M2);
+  cq M = r1 ? b : (r3 ? 0u : a);                                           // (U, V, W, 0)
+  const uint32_t x0 = coop_row_is_zero(c, PQ, 0);
+  const uint32_t id = x0 & coop_row_is_zero(c, Fp, 0);
+  const uint32_t o2 = x0 & coop_row_is_zero(c, Fp, 1);
+  const uint32_t degenerate = coop_row_is_zero(c, M1, 0);                  // X == 0, or Z == Y with X != 0 (not on the curve): neutral element
+  flags = (id | (degenerate & (1u - o2))) | (o2 << 1);
+  const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
+  M = degenerate ? (r3 ? 0u : ONE0) : M;
+  return M;
+}
+
+// Tail of k_mul_coop in quads (mont_recover_to_edwards_proj, ge_ladder.h; lane-level model: tools/coop_model.py recover_quads):
+// M = (U, V, W, 0), SX = (x2, x2, x3, x3), SZ = (z2, z2, z3, z3) after the ladder's last swap.  Okeya-Sakurai y-recovery
+// scaled by W^2, the map back to Edwards and -P (for the result -P the formulas degenerate), eight multiplication levels
+// where the one-lane form has 27 dependent multiplications; then the exceptional cases by uniform selects.  Returns (X : Y : Z).
+__device__ __forceinline__ cq coop_mont_recover(const lane_consts& c, cq M, cq SX, cq SZ, uint32_t p_flags, uint32_t k_is_odd, uint32_t negate) {
+  const bool r0 = c.row == 0, r1 = c.row == 1, r2 = c.row == 2, r3 = c.row == 3;
+  const int I0 = rowperm_idx(c, 0, 0, 0, 0), I1 = rowperm_idx(c, 1, 1, 1, 1), I2 = rowperm_idx(c, 2, 2, 2, 2), I3 = rowperm_idx(c, 3, 3, 3, 3);
+  const uint32_t ccv[10] = KYB_FE_MONT_C;
+  uint32_t cck = 0;
+  KYB_UNROLL for (int j = 0; j < 10; ++j) cck = (c.k == (uint32_t)j) ? ccv[j] : cck;
+  const cq CCQ = c.active ? cck : 0u;
+  const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
+  const cq K2A = ONE0 * (2u * 486662u);
+  const cq z2a = bperm(I0, SZ), x2a = bperm(I0, SX);
+  const cq mu = bperm(I0, M), mv = bperm(I1, M), mw = bperm(I2, M);
+  const cq up1 = cadd(mu, mw), um1 = csub(c, mu, mw);
+  // level 1: (T1, Wx2, UX, Wz2) = (U z2, W x2, U x2, W z2)
+  const cq L1 = cmul4(c, (r0 || r2) ? mu : mw, (r0 || r3) ? z2a : x2a);
+  // level 2: (a_, TT1, t1n, W2) = (2A z2, 2V z2, U c, W^2)
+  const cq L2 = cmul4(c, (r0 || r1) ? z2a : (r2 ? mu : mw), r0 ? K2A : (r1 ? cadd(mv, mv) : (r2 ? CCQ : mw)));
+  // level 3: (T3s, Wa, b_, nXp) = ((Wx2 - T1)^2, W a_, a_ z2, t1n (U + W))
+  const cq T3d = cnorm(c, csub(c, bperm(I1, L1), L1));                    // row 0
+  const cq a_all = bperm(I0, L2), t1n_all = bperm(I2, L2);
+  const cq L3 = cmul4(c, r0 ? T3d : (r1 ? mw : (r2 ? a_all : t1n_all)), r0 ? T3d : (r1 ? a_all : (r2 ? z2a : up1)));
+  // level 4: (T3, T2T4, W2b, TT2) = (T3s x3, (Wx2 + T1 + Wa) (UX + Wz2), W2 b_, TT1 z3)
+  const cq T2p = cnorm(c, cadd(cadd(L1, bperm(I0, L1)), L3));             // row 1
+  const cq T4 = cadd(bperm(I2, L1), bperm(I3, L1));
+  const cq fromL2 = bperm(rowperm_idx(c, 0, 0, 3, 1), L2), x3a = bperm(I2, SX);
+  const cq L4 = cmul4(c, r0 ? L3 : (r1 ? T2p : fromL2), r0 ? x3a : (r1 ? T4 : (r2 ? L3 : SZ)));
+  // level 5: (T2z3, t, nY, nZ) = ((T2T4 - W2b) z3, W TT2, V (U - W), V (U + W))
+  const cq T2pp = cnorm(c, csub(c, bperm(I1, L4), bperm(I2, L4)));
+  const cq z3a = bperm(I2, SZ), tt2 = bperm(I3, L4);
+  const cq L5 = cmul4(c, r0 ? T2pp : (r1 ? mw : mv), r0 ? z3a : (r1 ? tt2 : (r2 ? um1 : up1)));
+  const cq YPn = cnorm(c, csub(c, L5, L4));                               // row 0: W^2 Yp
+  // level 6: (Uo, Wo) = (t x2, t z2)
+  const cq L6 = cmul4(c, bperm(I1, L5), r0 ? SX : SZ);
+  const cq uo = bperm(I0, L6), wo = bperm(I1, L6);
+  const cq upw = cadd(uo, wo), umw = csub(c, uo, wo);
+  // level 7: (t1, Y, Z) = (Uo c, (Uo - Wo) V', V' (Uo + Wo));  level 8: X = t1 (Uo + Wo)
+  const cq vq = bperm(I0, YPn);
+  const cq L7 = cmul4(c, r0 ? L6 : vq, r0 ? CCQ : (r1 ? umw : upw));
+  const cq L8 = cmul4(c, L7, upw);
+  cq RES = r0 ? L8 : L7;
+  // -P = (-t1n (U + W) : (U - W) V : V (U + W))
+  const cq nxp = bperm(I3, L3), nyz = bperm(rowperm_idx(c, 0, 2, 3, 3), L5);
+  const cq NEG = r0 ? cnorm(c, c.p2 - nxp) : nyz;
+  const cq ID = (r1 || r2) ? ONE0 : 0u;                                   // (0 : 1 : 1)
+  const cq O2 = r1 ? c.p2 - ONE0 : (r2 ? ONE0 : 0u);                      // (0 : -1 : 1)
+  const uint32_t z2_zero = coop_row_is_zero(c, SZ, 0), z3_zero = coop_row_is_zero(c, SZ, 2), x2_zero = coop_row_is_zero(c, SX, 0);
+  const uint32_t res_inf = z2_zero, res_negp = z3_zero & (1u - z2_zero), res_o2 = x2_zero & (1u - z2_zero);
+  const uint32_t p_id = p_flags & 1u, p_o2 = (p_flags >> 1) & 1u;
+  RES = res_negp ? NEG : RES;
+  RES = res_o2 ? O2 : RES;
+  RES = res_inf ? ID : RES;
+  RES = p_id ? ID : RES;
+  RES = p_o2 ? (k_is_odd ? O2 : ID) : RES;
+  RES = cnorm(c, RES);                                                    // (the constant -1 is 2p - 1 limb-wise)
+  const cq nres = cnorm(c, c.p2 - RES);
+  return (r0 && negate) ? nres : RES;
+}
+
 __global__ void __launch_bounds__(64)
 k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
            int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, kyb::launch::DoneFlag df) {
@@ -135,22 +219,24 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
   lane_consts c;
   lane_consts_init(c);
 
-  // ---- replicated on all lanes: operands and their projective Montgomery image (ge_ladder.h) ----
+  // ---- operands: the scalar replicated on all lanes, the point as a quad (X, Y, Z, T) straight from its 40 reference limbs ----
   uint32_t a[8];
   load_words8(a, scalars, i);
-  ge_p3 P;
-  load_ext(P, pts_ext, i);
-  mont_point_proj m;
-  mont_prep_proj(m, P);                                                // u = U / W, v = V / W: no inversion in front of the ladder
   uint32_t neg, mag[8];
   sc_effective(neg, mag, a);
+  const uint32_t word = c.active ? (uint32_t)pts_ext[40 * i + 10 * c.row + c.k] : 0u;
+  const cq PQ = cnorm(c, c.active ? word + (c.p2 << 3) : 0u);           // fe_from_ref10: signed limb + 16p, one carry pass
+  uint32_t p_flags;
+  const cq M = coop_mont_prep(c, PQ, p_flags);                           // u = U / W, v = V / W: no inversion in front of the ladder
 
-  // ---- the ladder: state S = (x2, z2, x3, z3) in rows 0..3 ----
-  const cq UWQ = quad_row_from_fe(c, quad_row_from_fe(c, 0, 0, m.U), 2, m.W);      // U1 in row 0, W1 in row 2 (second operands of level 3)
+  // ---- the ladder: state (x2, z2, x3, z3) = (1, 0, U1, W1) ----
   const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
-  ladder_state st;                                                                 // (x2, z2, x3, z3) = (1, 0, U1, W1)
-  st.SX = quad_row_from_fe(c, quad_row_from_fe(c, c.row < 2 ? ONE0 : 0u, 2, m.U), 3, m.U);
-  st.SZ = quad_row_from_fe(c, quad_row_from_fe(c, 0u, 2, m.W), 3, m.W);
+  ladder_state st;
+  {
+    const cq u1 = bperm(rowperm_idx(c, 0, 0, 0, 0), M), w1 = bperm(rowperm_idx(c, 2, 2, 2, 2), M);
+    st.SX = c.row < 2 ? ONE0 : u1;
+    st.SZ = c.row < 2 ? 0u : w1;
+  }
   const ladder_idx li = ladder_idx_init(c);
   uint32_t swap = 0;
 #pragma unroll 1
@@ -165,22 +251,17 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
       const uint32_t bit = word >> 31;
       word <<= 1;
       swap ^= bit;
-      st = coop_ladder_step(c, li, st, UWQ, swap);
+      st = coop_ladder_step(c, li, st, M, swap);                         // M: U1 in row 0, W1 in row 2 (rows 1, 3 are not read)
       swap = bit;
     }
   }
+  // the final conditional swap (x2, z2) <-> (x3, z3): rows 0, 1 <-> 2, 3
+  const int I_sw = (int)(c.lane << 2) ^ ((0 - (int)swap) & 128);
+  const cq SX = bperm(I_sw, st.SX), SZ = bperm(I_sw, st.SZ);
 
-  // ---- replicated: y-recovery and the exceptional cases (mont_recover_to_edwards), then the encoding ----
-  // the final conditional swap (x2, z2) <-> (x3, z3) is the choice of the rows read here
-  fe x2, z2, x3, z3;
-  const uint32_t ra = swap ? 2u : 0u, rb = swap ? 0u : 2u;
-  fe_from_quad_row(c, x2, st.SX, ra);
-  fe_from_quad_row(c, z2, st.SZ, ra);
-  fe_from_quad_row(c, x3, st.SX, rb);
-  fe_from_quad_row(c, z3, st.SZ, rb);
-  ge_p2 r;
-  mont_recover_to_edwards_proj(r, m, x2, z2, x3, z3, mag[0] & 1u, neg);
-  coop_finish(c, r.X, r.Y, r.Z, 0u, out_enc, out_ext, i, proj, proj_stride, proj_offset);
+  // ---- y-recovery, exceptional cases, encoding ----
+  const cq RES = coop_mont_recover(c, M, SX, SZ, p_flags, mag[0] & 1u, neg);
+  coop_finish(c, RES, 0u, out_enc, out_ext, i, proj, proj_stride, proj_offset);
   if (c.lane == 0) signal_done(df);
 }
 
@@ -258,11 +339,7 @@ k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__
     sc_next_digit64(idx, neg, dg, true);
     madd(coop_table_entry<16>(c, image64 + KYB_BASE64_TOP_BASE, idx, 0u));
   }
-  fe X, Y, Z;
-  fe_from_quad_row(c, X, h, 0);
-  fe_from_quad_row(c, Y, h, 1);
-  fe_from_quad_row(c, Z, h, 2);
-  coop_finish(c, X, Y, Z, dg.neg, out_enc, out_ext, i, proj, proj_stride, proj_offset);
+  coop_finish(c, h, dg.neg, out_enc, out_ext, i, proj, proj_stride, proj_offset);
   if (c.lane == 0) signal_done(df);
 }
 

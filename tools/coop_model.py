@@ -151,6 +151,85 @@ def ladder_step_xz(c, SX, SZ, UWQ, swap, bit):
     return SXn, SZn, swap
 
 
+MONT_C = None   # sqrt(-486664), set by main() from the big-integer prototype
+
+
+def const_quad(c, vals):
+    return quad_from_ints(c, vals)
+
+
+def prep_quads(c, PQ, cc):
+    """k_mul_coop's head: PQ = (X, Y, Z, T) tight -> M = (U, V, W, 0) with U = (Z+Y) X, V = c (Z+Y) Z, W = (Z-Y) X, and the
+    quads whose rows the flags are read from (X; Z-Y, Z+Y; W)"""
+    I = lambda *p: rowperm_idx(c, *p)
+    r0, r1, r2 = c.row == 0, c.row == 1, c.row == 2
+    ZZ, YY, XX = bperm(I(2, 2, 2, 2), PQ), bperm(I(1, 1, 1, 1), PQ), bperm(I(0, 0, 0, 0), PQ)
+    Fp = cnorm(c, np.where(r0, csub(c, ZZ, YY), cadd(ZZ, YY)))          # (zmy, zpy, zpy, zpy)
+    M1 = cmul4(c, Fp, np.where(r2, ZZ, XX))                             # (W, U, t, -)
+    M2 = cmul4(c, M1, const_quad(c, [0, 0, cc, 0]))                     # row 2 = V
+    a, b = bperm(I(1, 1, 0, 0), M1), bperm(I(2, 2, 2, 2), M2)
+    M = np.where(r1, b, np.where(c.row == 3, 0, a))                     # (U, V, W, 0)
+    return M, Fp, M1
+
+
+def recover_quads(c, M, SX, SZ, cc, flags):
+    """k_mul_coop's tail (mont_recover_to_edwards_proj in quads): M = (U, V, W, 0), SX = (x2, x2, x3, x3), SZ = (z2, z2, z3, z3)
+    after the final swap.  flags = dict(res_inf, res_negp, res_o2, p_id, p_o2, k_odd, negate).  Returns (X, Y, Z, -)."""
+    I = lambda *p: rowperm_idx(c, *p)
+    r0, r1, r2, r3 = c.row == 0, c.row == 1, c.row == 2, c.row == 3
+    one0 = np.where((c.k == 0) & c.active, 1, 0).astype(np.uint64)
+    K2A = np.where(r0, one0 * np.uint64(2 * 486662), 0).astype(np.uint64)
+    CCQ = const_quad(c, [cc, 0, cc, 0])
+    z2a, x2a = bperm(I(0, 0, 0, 0), SZ), bperm(I(0, 0, 0, 0), SX)
+    mu, mv, mw = bperm(I(0, 0, 0, 0), M), bperm(I(1, 1, 1, 1), M), bperm(I(2, 2, 2, 2), M)
+    up1, um1 = cadd(mu, mw), csub(c, mu, mw)
+    # R1: (T1, Wx2, UX, Wz2) = (U z2, W x2, U x2, W z2)
+    L1 = cmul4(c, np.where(r0 | r2, mu, mw), np.where(r0 | r3, z2a, x2a))
+    # R2: (a_, TT1, t1n, W2) = (2A z2, 2V z2, U c, W^2)
+    L2 = cmul4(c, np.where(r0 | r1, z2a, np.where(r2, mu, mw)), np.where(r0, K2A, np.where(r1, cadd(mv, mv), np.where(r2, CCQ, mw))))
+    # R3: (T3s, Wa, b_, nXp) = ((Wx2 - T1)^2, W a_, a_ z2, t1n (U + W))
+    T3d = cnorm(c, csub(c, bperm(I(1, 1, 1, 1), L1), L1))               # row 0
+    a_all = bperm(I(0, 0, 0, 0), L2)
+    F3 = np.where(r0, T3d, np.where(r1, mw, np.where(r2, a_all, bperm(I(2, 2, 2, 2), L2))))
+    G3 = np.where(r0, T3d, np.where(r1, a_all, np.where(r2, z2a, up1)))
+    L3 = cmul4(c, F3, G3)
+    # R4: (T3, T2T4, W2b, TT2) = (T3s x3, (Wx2 + T1 + Wa) (UX + Wz2), W2 b_, TT1 z3)
+    T2p = cnorm(c, cadd(cadd(L1, bperm(I(0, 0, 0, 0), L1)), L3))        # row 1
+    F4 = np.where(r0, L3, np.where(r1, T2p, bperm(I(0, 0, 3, 1), L2)))
+    T4 = cadd(bperm(I(2, 2, 2, 2), L1), bperm(I(3, 3, 3, 3), L1))
+    G4 = np.where(r0, bperm(I(2, 2, 2, 2), SX), np.where(r1, T4, np.where(r2, L3, SZ)))
+    L4 = cmul4(c, F4, G4)
+    # R5: (T2z3, t, nY, nZ) = ((T2T4 - W2b) z3, W TT2, V (U - W), V (U + W))
+    T2pp = cnorm(c, csub(c, bperm(I(1, 1, 1, 1), L4), bperm(I(2, 2, 2, 2), L4)))
+    F5 = np.where(r0, T2pp, np.where(r1, mw, mv))
+    G5 = np.where(r0, bperm(I(2, 2, 2, 2), SZ), np.where(r1, bperm(I(3, 3, 3, 3), L4), np.where(r2, um1, up1)))
+    L5 = cmul4(c, F5, G5)
+    YPn = cnorm(c, csub(c, L5, L4))                                     # row 0: W^2 Yp
+    # R6: (Uo, Wo) = (t x2, t z2)
+    L6 = cmul4(c, bperm(I(1, 1, 1, 1), L5), np.where(r0, SX, SZ))
+    uo, wo = bperm(I(0, 0, 0, 0), L6), bperm(I(1, 1, 1, 1), L6)
+    upw, umw = cadd(uo, wo), csub(c, uo, wo)
+    # R7: (t1, Y, Z) = (Uo c, (Uo - Wo) V', V' (Uo + Wo))
+    vq = bperm(I(0, 0, 0, 0), YPn)
+    L7 = cmul4(c, np.where(r0, L6, vq), np.where(r0, CCQ, np.where(r1, umw, upw)))
+    # R8: X = t1 (Uo + Wo)
+    L8 = cmul4(c, L7, upw)
+    RES = np.where(r0, L8, L7)
+    # -P = (-t1n (U + W) : (U - W) V : V (U + W))
+    NEG = np.where(r0, cnorm(c, csub(c, np.zeros(64, np.uint64), bperm(I(3, 3, 3, 3), L3))), bperm(I(0, 2, 3, 3), L5))
+    ID = np.where(r1 | r2, one0, 0).astype(np.uint64)
+    O2 = np.where(r1, c.p2 - one0, np.where(r2, one0, 0)).astype(np.uint64)
+    RES = np.where(flags["res_negp"], NEG, RES)
+    RES = np.where(flags["res_o2"], O2, RES)
+    RES = np.where(flags["res_inf"], ID, RES)
+    RES = np.where(flags["p_id"], ID, RES)
+    RES = np.where(flags["p_o2"], O2 if flags["k_odd"] else ID, RES)
+    RES = cnorm(c, RES)
+    if flags["negate"]:
+        RES = np.where(r0, cnorm(c, csub(c, np.zeros(64, np.uint64), RES)), RES)
+    return RES
+
+
 def madd(c, h, E):
     r0, r1, r2, r3 = c.row == 0, c.row == 1, c.row == 2, c.row == 3
     I = lambda *p: rowperm_idx(c, *p)
@@ -221,7 +300,41 @@ def main():
             want = [AA * BB % P, E_ * (AA + 121665 * E_) % P, W1 * (DA + CB) ** 2 % P, U1 * (DA - CB) ** 2 % P]
             # the kernel leaves the swap pending: its (x2', z2', x3', z3') are RFC 7748's AFTER that step's own swap
             assert ints_from_quad(S2) == want and sw == bit, (swap0, bit)
-    print("coop model: cmul4 / cnorm / cinv / madd / ladder step OK")
+    # head and tail of k_mul_coop in quads against the big-integer prototype (tools/ladder_proto.py)
+    import ladder_proto as LP
+    def proj_eq(a, b):
+        return all((a[i] * b[j] - a[j] * b[i]) % P == 0 for i in range(3) for j in range(i + 1, 3)) and any(v % P for v in a)
+    for trial in range(12):
+        X, Y, Z = (rnd.randrange(1, P) for _ in range(3))
+        M, Fp, M1 = prep_quads(c, quad_from_ints(c, [X, Y, Z, 0]), LP.C)
+        U1, V1, W1 = (Z + Y) * X % P, LP.C * (Z + Y) % P * Z % P, (Z - Y) * X % P
+        assert ints_from_quad(M)[:3] == [U1, V1, W1]
+        assert ints_from_quad(Fp)[:2] == [(Z - Y) % P, (Z + Y) % P] and ints_from_quad(M1)[0] == W1
+        k = rnd.getrandbits(255)
+        x2, z2, x3, z3 = LP.ladder_proj(k, U1, W1)
+        if trial in (3, 4): z3 = 0
+        if trial in (5, 6): z2 = 0
+        if trial in (7, 8): x2 = 0
+        res_inf = z2 == 0; res_negp = z3 == 0 and not res_inf; res_o2 = x2 == 0 and z2 != 0
+        for p_id, p_o2, neg in ((0, 0, trial & 1), (1, 0, 0), (0, 1, 1)):
+            fl = dict(res_inf=res_inf, res_negp=res_negp, res_o2=res_o2, p_id=p_id, p_o2=p_o2, k_odd=k & 1, negate=neg)
+            RES = recover_quads(c, M, quad_from_ints(c, [x2, x2, x3, x3]), quad_from_ints(c, [z2, z2, z3, z3]), LP.C, fl)
+            # the prototype's tail on the same values
+            T1 = U1 * z2 % P; Wx2 = W1 * x2 % P; T2 = (Wx2 + T1) % P; T3 = (Wx2 - T1) ** 2 % P * x3 % P
+            a_ = 2 * 486662 * z2 % P; T2 = (T2 + W1 * a_) % P; T4 = (U1 * x2 + W1 * z2) % P; b_ = a_ * z2 % P; W2 = W1 * W1 % P
+            YP = ((T2 * T4 - W2 * b_) % P * z3 - T3) % P; TT = 2 * V1 * z2 % P * z3 % P
+            Uo, Vo, Wo = W1 * TT % P * x2 % P, YP, W1 * TT % P * z2 % P
+            Xe, Ye, Ze = LP.C * Uo % P * (Uo + Wo) % P, (Uo - Wo) * Vo % P, Vo * (Uo + Wo) % P
+            nX, nY, nZ = (-LP.C * U1 % P * (U1 + W1)) % P, (U1 - W1) * V1 % P, V1 * (U1 + W1) % P
+            if res_negp: Xe, Ye, Ze = nX, nY, nZ
+            if res_o2: Xe, Ye, Ze = 0, P - 1, 1
+            if res_inf: Xe, Ye, Ze = 0, 1, 1
+            if p_id: Xe, Ye, Ze = 0, 1, 1
+            if p_o2: Xe, Ye, Ze = (0, P - 1, 1) if (k & 1) else (0, 1, 1)
+            if neg: Xe = (-Xe) % P
+            got = ints_from_quad(RES)[:3]
+            assert got == [Xe, Ye, Ze], (trial, p_id, p_o2, neg)
+    print("coop model: cmul4 / cnorm / cinv / madd / ladder step / prep + recovery in quads OK")
 
 
 if __name__ == "__main__":
