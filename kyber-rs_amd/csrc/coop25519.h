@@ -21,6 +21,10 @@
 //   cnorm(V)       that light pass alone: any limbs < 2^31 -> tight
 //   rows are moved with ds_bpermute_b32 and per-lane index constants; additions are ONE instruction for four elements.
 //
+// Measured for ONE wavefront on an idle chip (tools/coop_primitive_times.py, profiles/r02/coop_primitive_times.log): cmul4 368
+// cycles, csq4 309, cnorm 45, a ds_bpermute round trip 45, one ladder step (three levels) 1450, one mixed addition (two
+// levels) 1070 — about 6 cycles per instruction whatever its kind: a lone wavefront is bound by its instruction count.
+//
 // Same limb format and bounds notation as fe25519.h; results are bit-identical to the one-lane code (tests compare both
 // paths with the oracle).  Constant time: the instruction stream and every lane index are independent of secret data except
 // the row index of the ladder's conditional swap, which goes through the conflict-free ds_bpermute crossbar exactly like the
@@ -138,7 +142,7 @@ __device__ __forceinline__ cq cmul4r(const lane_consts& c, cq F, const crot& G) 
   fb[6] = dpp0<KYB_DPP_ROW_BCAST(6)>(F); fb[7] = dpp0<KYB_DPP_ROW_BCAST(7)>(F); fb[8] = dpp0<KYB_DPP_ROW_BCAST(8)>(F);
   fb[9] = dpp0<KYB_DPP_ROW_BCAST(9)>(F);
   uint64_t acc = (uint64_t)(fb[0] * c.mfac[0]) * G.g[0];
-  KYB_UNROLL for (int i = 1; i < 10; ++i) acc += (uint64_t)(fb[i] * c.mfac[i]) * G.g[i];
+  KYB_UNROLL for (int i = 1; i < 10; ++i) acc += (uint64_t)(fb[i] * c.mfac[i]) * G.g[i];      // (two interleaved chains measured no faster)
   return ccarry(c, acc);
 }
 // four products; F tight, G <= 4T

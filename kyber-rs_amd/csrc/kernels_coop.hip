@@ -431,6 +431,25 @@ k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restri
     st = coop_ladder_step(c, ladder_idx_init(c), st, ((c.row == 0 || c.row == 2) && c.active) ? b : 0u, swap);
     const cq fx = bperm(rowperm_idx(c, 0, 0, 2, 2), st.SX), fz = bperm(rowperm_idx(c, 0, 0, 2, 2), st.SZ);
     r = (c.row & 1u) ? fz : fx;                                       // (x2', z2', x3', z3')
+  } else if (op >= 16 && op < 24) {
+    // timing chains (tools/coop_primitive_times.py): B[3] dependent repetitions of one primitive
+    const uint32_t reps = B[3];
+    const ladder_idx li = ladder_idx_init(c);
+    const madd_idx mi = madd_idx_init(c);
+    const int Irot = rowperm_idx(c, 1, 2, 3, 0);
+    ladder_state st{a, b};
+    r = a;
+#define KYB_CHAIN(stmt) _Pragma("unroll 1") for (uint32_t t = 0; t < reps; ++t) { stmt; }
+    if (op == 16) { KYB_CHAIN(r = cmul4(c, r, b)) }
+    else if (op == 17) { KYB_CHAIN(r = csq4(c, r)) }
+    else if (op == 18) { KYB_CHAIN(r = cnorm(c, r + b)) }
+    else if (op == 19) { KYB_CHAIN(st = coop_ladder_step(c, li, st, b, t & 1u)) }
+    else if (op == 20) { KYB_CHAIN(r = bperm(Irot, r)) }
+    else if (op == 21) { KYB_CHAIN(r = dpp0<KYB_DPP_ROW_SHR(1)>(r) + b) }
+    else if (op == 22) { KYB_CHAIN(r = coop_madd(c, mi, r, b)) }
+    else { KYB_CHAIN(r = r * b + t) }                                    // 23: one dependent v_mul_lo + add
+#undef KYB_CHAIN
+    if (op == 19) r = st.SX ^ st.SZ;
   } else if (op == 7) {
     fe f[4];
     for (uint32_t q = 0; q < 4; ++q) fe_from_quad_row(c, f[q], a, q);
