@@ -37,9 +37,9 @@ thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
 enum KernelId { KID_MUL, KID_MUL_BASE, KID_FINISH, KID_SIGN, KID_SIGN_HASH, KID_VERIFY_PREP, KID_VERIFY_FINAL, KID_POLY_EVAL, KID_MONT_PREP,
-                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_COUNT };
+                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_COUNT };
 const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval",
-                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop"};
+                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   std::mutex mu;                  // begin / read / every ProfScope: callable from any thread
@@ -86,6 +86,7 @@ struct Ctx {
   uint32_t* done_counter = nullptr;       // device word: finished items of that kernel
   uint32_t done_seq = 0;                  // under mu
   uint8_t* pin[2] = {nullptr, nullptr};   // page-locked bounce buffers of the two lanes (pageable caller memory)
+  hipEvent_t ev_pin[2] = {nullptr, nullptr};   // h2d(): a bounce buffer's last copy to the device
   size_t pin_bytes[2] = {0, 0};
   kyb::CopyPool copy;
   // kernel variant selection (kyb_set_option): atomics, so a set_option from one thread and launches from others do not race
@@ -377,6 +378,39 @@ constexpr int KYB_CK_LO = KYB_BT_IDX(0, 0, 30), KYB_CK_HI = KYB_BT_IDX(0, 0, 31)
 // context's device staging buffer, inputs copied in, `body` queues the kernels on the engine stream, outputs copied
 // back, stream synchronised.  An array whose host pointer is null takes no space and maps to a null device pointer.
 // secret(): the inputs include private keys / nonces — the staging region is cleared before the call returns.
+// One input array of a host-pointer call to the device, queued on the engine stream.  A large PAGEABLE array handed to
+// hipMemcpyAsync is staged by the runtime on the calling thread (~5-15 GB/s, and the copy engine waits meanwhile); it is
+// cut into chunks instead that CopyPool threads move into the context's two page-locked bounce buffers while the DMA engine
+// drains the other one (the pipeline of run_host_batch, without kernels in between).
+constexpr size_t H2D_PIPE_MIN = (size_t)8 << 20, H2D_PIPE_CHUNK = (size_t)8 << 20;
+int h2d(Ctx& g, uint8_t* dst, const uint8_t* src, size_t bytes, bool secret) {
+  if (bytes < H2D_PIPE_MIN || is_pinned(src)) {
+    HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g.stream));
+    return KYB_OK;
+  }
+  int rc = ensure_pin(g, 0, H2D_PIPE_CHUNK); if (rc) return rc;
+  rc = ensure_pin(g, 1, H2D_PIPE_CHUNK); if (rc) return rc;
+  for (int l = 0; l < 2; ++l)
+    if (!g.ev_pin[l]) HIPCK(hipEventCreateWithFlags(&g.ev_pin[l], hipEventDisableTiming));
+  const int threads = copy_threads(g);
+  int c = 0;
+  for (size_t o = 0; o < bytes; o += H2D_PIPE_CHUNK, ++c) {
+    const int lane = c & 1;
+    const size_t nb = bytes - o < H2D_PIPE_CHUNK ? bytes - o : H2D_PIPE_CHUNK;
+    if (c >= 2) HIPCK(hipEventSynchronize(g.ev_pin[lane]));          // the DMA engine has drained this bounce buffer
+    kyb::CopyPool::Job job{g.pin[lane], src + o, nb};
+    g.copy.run(&job, 1, threads);
+    HIPCK(hipMemcpyAsync(dst + o, g.pin[lane], nb, hipMemcpyHostToDevice, g.stream));
+    HIPCK(hipEventRecord(g.ev_pin[lane], g.stream));
+  }
+  // the bounce buffers are reused by whatever comes next under g.mu: the copies out of them must have been issued AND finished
+  for (int l = 0; l < 2 && l < c; ++l) {
+    HIPCK(hipEventSynchronize(g.ev_pin[l]));
+    if (secret) memset(g.pin[l], 0, H2D_PIPE_CHUNK);                   // private keys / nonces do not stay in the bounce buffers
+  }
+  return KYB_OK;
+}
+
 class HostCall {
  public:
   explicit HostCall(Ctx& g) : g_(g) {}
@@ -417,7 +451,7 @@ class HostCall {
     if (rc) return rc;
     base_ = g.stage;
     for (int i = 0; i < n_; ++i)
-      if (a_[i].src && a_[i].bytes) HIPCK(hipMemcpyAsync(g.stage + a_[i].off, a_[i].src, a_[i].bytes, hipMemcpyHostToDevice, g.stream));
+      if (a_[i].src && a_[i].bytes) { rc = h2d(g, g.stage + a_[i].off, static_cast<const uint8_t*>(a_[i].src), a_[i].bytes, secret_); if (rc) return rc; }
     rc = body(g.stream);
     if (rc) return rc;
     for (int i = 0; i < n_; ++i)
@@ -558,6 +592,7 @@ void ctx_release(Ctx* c) {
   wipe_free_dev(c->stage, c->stage_bytes);
   wipe_free_dev(c->stage2, c->stage2_bytes);
   for (int l = 0; l < 2; ++l) if (c->pin[l]) { memset(c->pin[l], 0, c->pin_bytes[l]); (void)hipHostFree(c->pin[l]); }
+  for (int l = 0; l < 2; ++l) if (c->ev_pin[l]) (void)hipEventDestroy(c->ev_pin[l]);
   if (c->done_flag) (void)hipHostFree(c->done_flag);
   if (c->done_counter) (void)hipFree(c->done_counter);
   { std::lock_guard<std::mutex> lk(c->prof.mu);
@@ -984,6 +1019,12 @@ int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* i
   SlotUse use(r, st);
   int nbits = 1;
   while (nbits < 32 && ((uint64_t)max_index + 1) >> nbits) ++nbits;      // bit length of max x = max_index + 1
+  if (n <= (size_t)g.opt_coop_max) {
+    // few evaluations: one per wavefront (kernels_coop.hip)
+    ProfScope ps(g, st, KID_POLY_EVAL_COOP);
+    LAUNCHCK(launch::poly_eval_coop(st, commits, (int)t, idx, n, nbits, per_poly, oenc, oext, take_done_flag(g, st, n)));
+    return KYB_OK;
+  }
   const bool split = use_split(g, n);
   if (split) { int rc = ensure_proj(g, r, n); if (rc) return rc; }
   {

@@ -9,6 +9,7 @@
 //   k_decode_coop     unmarshal_binary          ge.rs:124-179   ge_decode replicated on all lanes, its square-root chain
 //                     (252 of ~270 dependent multiplications) cooperative
 //   k_verify_prep_coop / k_verify_prep_r_coop   the two front halves of a verification (verify.h) with that decode
+//   k_poly_eval_coop  PubPoly::eval             poly.rs:457-469 one evaluation per wavefront: Horner with cooperative doublings / additions
 // Used for batches that leave the chip idle (engine.hip: `coop.max_items`); results are bit-identical to the batch kernels.
 #include <hip/hip_runtime.h>
 #include "launch.h"
@@ -290,6 +291,86 @@ __device__ __forceinline__ cq coop_madd(const lane_consts& c, const madd_idx& mi
   return cmul4(c, FB, GB);
 }
 
+// ---- general point arithmetic in quads: PubPoly::eval for small batches (share/poly.rs:457-469) ----------------------------------
+// (X : Y : Z : T) -> the cached form (Y+X, Y-X, 2d T, Z) the addition below takes as its second operand.  One multiplication level.
+__device__ __forceinline__ cq coop_to_cached(const lane_consts& c, cq P) {
+  const bool r0 = c.row == 0, r1 = c.row == 1, r2 = c.row == 2;
+  const uint32_t d2v[10] = KYB_FE_D2;
+  uint32_t d2k = 0;
+  KYB_UNROLL for (int j = 0; j < 10; ++j) d2k = (c.k == (uint32_t)j) ? d2v[j] : d2k;
+  const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
+  const cq a = bperm(rowperm_idx(c, 1, 1, 3, 2), P), b = bperm(rowperm_idx(c, 0, 0, 0, 0), P);      // (Y, Y, T, Z), X
+  const cq F = cnorm(c, r0 ? cadd(a, b) : (r1 ? csub(c, a, b) : a));
+  return cmul4(c, F, r2 ? (c.active ? d2k : 0u) : ONE0);
+}
+// h + E for extended h and cached E: ge_add followed by ge_p1p1_to_p3 (ge25519.h).  Two multiplication levels.
+__device__ __forceinline__ cq coop_add(const lane_consts& c, cq h, cq E) {
+  const bool r0 = c.row == 0, r1 = c.row == 1, r2 = c.row == 2, r3 = c.row == 3;
+  const int I0 = rowperm_idx(c, 0, 0, 0, 0), I2 = rowperm_idx(c, 2, 2, 2, 2);
+  const cq U = bperm(rowperm_idx(c, 1, 1, 3, 2), h), V = bperm(I0, h);          // (Y, Y, T, Z), X
+  const cq FA = cnorm(c, r0 ? cadd(U, V) : (r1 ? csub(c, U, V) : U));
+  const cq LA = cmul4(c, FA, E);                                                  // (A, B, C, ZZ)
+  const cq H2 = cadd(LA, LA);
+  const cq qa = bperm(I0, LA), qd = bperm(rowperm_idx(c, 3, 3, 3, 3), H2);       // every lane issues both reads, then selects
+  const cq Q1 = (c.row < 2) ? qa : qd;                                            // (A, A, D, D), D = 2 ZZ
+  const cq Q2 = bperm(rowperm_idx(c, 1, 1, 2, 2), LA);                            // (B, B, C, C)
+  const cq SUM = cadd(Q1, Q2), DIF = csub(c, Q1, Q2);                             // (Y3, Y3, Z3, Z3), (X3, X3, T3, T3)
+  const cq x3 = bperm(I0, DIF), z3 = bperm(I2, SUM), t3 = bperm(I2, DIF), y3 = bperm(I0, SUM);
+  return cmul4(c, cnorm(c, (r0 || r3) ? x3 : z3), (r0 || r2) ? t3 : y3);          // (X3 T3, Z3 Y3, Z3 T3, X3 Y3)
+}
+// 2 h: ge_p2_dbl followed by ge_p1p1_to_p3.  One squaring level, one multiplication level.
+__device__ __forceinline__ cq coop_dbl(const lane_consts& c, cq h) {
+  const bool r0 = c.row == 0, r1 = c.row == 1, r2 = c.row == 2, r3 = c.row == 3;
+  const cq a = bperm(rowperm_idx(c, 0, 1, 2, 0), h), b = bperm(rowperm_idx(c, 1, 1, 1, 1), h);
+  const cq xpy = cnorm(c, cadd(a, b));
+  const cq Q = csq4(c, r3 ? xpy : a);                                             // (XX, YY, ZZ, (X+Y)^2)
+  const cq xx = bperm(rowperm_idx(c, 0, 0, 0, 0), Q), yy = bperm(rowperm_idx(c, 1, 1, 1, 1), Q);
+  const cq zz = bperm(rowperm_idx(c, 2, 2, 2, 2), Q), aa = bperm(rowperm_idx(c, 3, 3, 3, 3), Q);
+  const cq Y3 = cnorm(c, cadd(yy, xx)), Z3 = cnorm(c, csub(c, yy, xx));
+  const cq X3 = cnorm(c, csub(c, aa, Y3));
+  const cq T3 = csub(c, cadd(zz, zz), Z3);                                        // <= 4T: second operand only
+  return cmul4(c, (r0 || r3) ? X3 : (r1 ? Y3 : Z3), (r0 || r2) ? T3 : (r1 ? Z3 : Y3));      // (X3 T3, Y3 Z3, Z3 T3, X3 Y3)
+}
+
+// PubPoly::eval at one share index per wavefront: v = sum_j x^j C_j by Horner, x = index + 1 (public: the instruction stream
+// follows its bits), every point operation two cooperative levels.  The batch kernel (k_poly_eval, one evaluation per lane)
+// walks the same t (nbits + 1) point operations as ~150-instruction field multiplications of ONE lane; with a few thousand
+// evaluations or fewer this is what a DKG node's verify_deal pass looks like (vss.rs:904-909: n polynomials at its own index).
+__global__ void __launch_bounds__(64)
+k_poly_eval_coop(const int32_t* __restrict__ commits_ext, int t, const uint32_t* __restrict__ indices, size_t n, int nbits, size_t per_poly,
+                 uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, kyb::launch::DoneFlag df) {
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  lane_consts c;
+  lane_consts_init(c);
+  const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(indices[i] + 1u));      // wave-uniform: the branches on its bits are scalar
+  const size_t first = per_poly ? (i / per_poly) * (size_t)t : 0;      // first commitment of this item's polynomial
+  const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
+  cq v = (c.row == 1 || c.row == 2) ? ONE0 : 0u;                       // neutral element (0 : 1 : 1 : 0)
+  (void)nbits;
+  const int top = 31 - __builtin_clz(x | 1u);                           // x >= 1
+#pragma unroll 1
+  for (int j = t - 1; j >= 0; --j) {
+    // v <- x v  (binary, most significant bit first; x = 1 leaves v alone)
+    if (top > 0) {
+      const cq vc = coop_to_cached(c, v);
+      cq acc = v;
+#pragma unroll 1
+      for (int b = top - 1; b >= 0; --b) {
+        acc = coop_dbl(c, acc);
+        if ((x >> b) & 1u) acc = coop_add(c, acc, vc);
+      }
+      v = acc;
+    }
+    // v <- v + C_j
+    const uint32_t word = c.active ? (uint32_t)commits_ext[40 * (first + (size_t)j) + 10 * c.row + c.k] : 0u;
+    const cq C = cnorm(c, c.active ? word + (c.p2 << 3) : 0u);         // fe_from_ref10: signed limb + 16p, one carry pass
+    v = coop_add(c, v, coop_to_cached(c, C));
+  }
+  coop_finish(c, v, 0u, out_enc, out_ext, i);
+  if (c.lane == 0) signal_done(df);
+}
+
 // One entry of the radix-64 image for the cooperative layout: lane (row g < 3, limb r) gets word 10 g + r of entry idx of
 // the window at `win` (E entries).  All LINES of a limb's entries are read whatever idx is (four loads 8 entries apart, the
 // wanted one kept by a uniform select): the cache sees the same lines for every digit.
@@ -474,6 +555,11 @@ hipError_t verify_prep_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* 
 }
 hipError_t verify_prep_r_coop(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* flags_r, uint4* proj, size_t stride, size_t offset) {
   hipLaunchKernelGGL(k_verify_prep_r_coop, dim3((unsigned)n), dim3(64), 0, st, sigs, n, flags_r, proj, stride, offset);
+  return hipGetLastError();
+}
+hipError_t poly_eval_coop(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly,
+                          uint8_t* oenc, int32_t* oext, DoneFlag df) {
+  hipLaunchKernelGGL(k_poly_eval_coop, dim3((unsigned)n), dim3(64), 0, st, commits, t, idx, n, nbits, per_poly, oenc, oext, df);
   return hipGetLastError();
 }
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,

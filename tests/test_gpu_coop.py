@@ -121,6 +121,35 @@ def test_coop_decode_sign_verify_match_oracle(coop_engine, oracle):
     assert eng.verify(u8(ps), ms, np.frombuffer(bytes(bad), dtype=np.uint8), 0)[0] == 9
 
 
+def test_coop_pubpoly_eval_matches_oracle(coop_engine, oracle):
+    """PubPoly::eval one evaluation per wavefront (cooperative doubling / addition): indices of every bit length up to 2^32 - 2,
+    commitments with small-order components and the neutral element among them, the many-polynomials form"""
+    eng = coop_engine
+    t = 9
+    commits = oracle.mul_base_ext_batch(synth.scalars(t, 900, b"coef"))
+    weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"][:5]]
+    commits[2] = oracle.add(commits[2], weak[2])                   # a point of mixed order
+    commits[5] = weak[0]                                           # a small-order point
+    commits[7] = oracle.decode(bytes([1] + [0] * 31))[0]           # the neutral element
+    idx = np.array([0, 1, 2, 3, 6, 7, 254, 255, 256, 1023, 65534, 65535, (1 << 31) - 1, (1 << 32) - 2], dtype=np.uint32)
+    eng.profile_begin(4)
+    got = eng.pubpoly_eval(commits, idx)
+    assert [k for k, _ in eng.profile_read(4)] == ["k_poly_eval_coop"]
+    eng.profile_begin(0)
+    for g, i in zip(got, idx):
+        assert bytes(g) == oracle.pubpoly_eval(commits, int(i)), int(i)
+    enc, ext = eng.pubpoly_eval(commits, idx[:5], want_ext=True)
+    assert [oracle.encode(e) for e in ext] == [bytes(g) for g in got[:5]]
+    polys = np.stack([commits, np.roll(commits, 3, axis=0), commits[::-1].copy()])
+    ii = np.array([[4, 77], [0, 1000], [12345, 2]], dtype=np.uint32)
+    multi = eng.pubpoly_eval_multi(polys, ii)
+    for p in range(3):
+        for q in range(2):
+            assert bytes(multi[p, q]) == oracle.pubpoly_eval(polys[p], int(ii[p, q]))
+    one = eng.pubpoly_eval(commits[:1], idx[:3])                   # degree 0
+    assert all(bytes(o) == oracle.encode(commits[0]) for o in one)
+
+
 def test_coop_and_batch_kernels_agree_at_the_threshold(engine, oracle):
     """the routing by size: n <= coop.max_items -> cooperative kernel, above -> batch kernels; same bytes either way"""
     s = synth.raw256(130, 800)

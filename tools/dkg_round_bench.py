@@ -70,12 +70,19 @@ for n in args.n:
     assert not st.any()
     dh2, br["dh_in"] = timed(lambda: eng.mul(me, pts_enc=pubs))
     polys = np.tile(commit_ext[None, :, :], (n, 1, 1))
-    idx = np.zeros((n, 1), dtype=np.uint32)
-    fig, br["fig"] = timed(lambda: eng.mul_base(np.tile(shares[0], (n, 1))))
+    me_i = n // 2                                                            # this node's share index (x = me_i + 1: a log2(n)-bit multiplier per Horner step)
+    idx = np.full((n, 1), me_i, dtype=np.uint32)
+    fig, br["fig"] = timed(lambda: eng.mul_base(np.tile(shares[me_i], (n, 1))))
     ev, br["eval"] = timed(lambda: eng.pubpoly_eval_multi(polys, idx))
     assert np.array_equal(ev[:, 0], fig)
-    dist, br["dist_poly"] = timed(lambda: eng.sum_points(np.ascontiguousarray(polys.transpose(1, 0, 2))))
+    coop_was = eng.get_option("coop.max_items")
+    eng.set_option("coop.max_items", 0)                                       # the one-evaluation-per-lane kernel, for comparison (not part of the total)
+    ev_b, eval_batch_ms = timed(lambda: eng.pubpoly_eval_multi(polys, idx))
+    eng.set_option("coop.max_items", coop_was)
+    assert np.array_equal(ev_b, ev)
+    by_coeff = np.ascontiguousarray(polys.transpose(1, 0, 2))              # (the node accumulates the incoming polynomials coefficient by coefficient)
+    dist, br["dist_poly"] = timed(lambda: eng.sum_points(by_coeff))
     assert bytes(commit_enc[1]) == orc.mul(bytes(coeffs[1]), orc.base()) and bytes(dh[3]) == orc.mul(bytes(longterm[0]), orc.decode(bytes(pubs[3]))[0])
     gpu_ms = sum(br.values())
     cpu_ms = t * cpu["mul"] + n * (cpu["sign"] + cpu["mul"]) + n * (cpu["verify"] + cpu["mul"]) + n * (cpu["mul_base"] + t * cpu["eval_per_coeff"]) + n * t * 0.0005
-    print(f"{n}, {t}, {gpu_ms:.2f}, {cpu_ms:.0f}, {cpu_ms / gpu_ms:.0f}x, " + " ".join(f"{k}={v:.2f}" for k, v in br.items()), flush=True)
+    print(f"{n}, {t}, {gpu_ms:.2f}, {cpu_ms:.0f}, {cpu_ms / gpu_ms:.0f}x, " + " ".join(f"{k}={v:.2f}" for k, v in br.items()) + f" (eval with the batch kernel: {eval_batch_ms:.2f})", flush=True)
