@@ -276,7 +276,8 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *   encode.batched    1 (default): kyb_encode_batch shares one inversion between 8 points; 0: one per point
  *   coop.max_items    batches of at most this many items take the one-item-per-wavefront kernels (variable base, verification,
  *                     polynomial evaluation; default 4096, 0 = never); coop.base_max_items the same for the fixed base and signing
- *                     (default 3072), coop.decode_max_items for a bare decode (default 1024).  Same results either way.
+ *                     (default 3072), coop.decode_max_items for a bare decode (default 1024), coop.verify_max_items for the
+ *                     single-launch verification with three wavefronts per signature (default 512).  Same results either way.
  *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder
  *   host.copy_threads host threads that move pageable batches through the bounce buffers (0 = auto)
  * Options belong to the calling thread's context. */

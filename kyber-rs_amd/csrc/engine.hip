@@ -37,9 +37,9 @@ thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
 enum KernelId { KID_MUL, KID_MUL_BASE, KID_FINISH, KID_SIGN, KID_SIGN_HASH, KID_VERIFY_PREP, KID_VERIFY_FINAL, KID_POLY_EVAL, KID_MONT_PREP,
-                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_COUNT };
+                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_VERIFY_COOP, KID_COUNT };
 const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval",
-                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop"};
+                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop", "k_verify_coop"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   std::mutex mu;                  // begin / read / every ProfScope: callable from any thread
@@ -103,6 +103,7 @@ struct Ctx {
   std::atomic<int> opt_finish{1};             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
   std::atomic<int> opt_finish_min{1};         // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size; cross-check)
   std::atomic<int> opt_coop_max{4096};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 4096 and 6144, profiles/r02/coop_crossover.log)
+  std::atomic<int> opt_coop_verify_max{512};     // verification: up to this many signatures take the single-launch kernel (three wavefronts each)
   std::atomic<int> opt_coop_decode_max{1024};    // unmarshal_binary alone: the same (crossover between 1024 and 2048)
   std::atomic<int> opt_coop_base_max{3072};      // fixed base: the same (crossover between 3072 and 4096; signing counts its two multiplications per item)
   std::atomic<int> opt_encode_batched{1};     // kyb_encode_batch: 1 shared inversion per 8 points (k_encode_batched), 0 one inversion per point (k_encode)
@@ -952,6 +953,12 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
                   uint8_t* status, hipStream_t st) {
   if (n == 0) return KYB_OK;
   std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  if (g.opt_mul_algo == 1 && n <= (size_t)g.opt_coop_verify_max) {
+    // few signatures: the whole verification in one launch, three wavefronts per signature (kernels_coop.hip)
+    ProfScope ps(g, st, KID_VERIFY_COOP);
+    LAUNCHCK(launch::verify_coop(st, pubs, sigs, msgs, off, n, flavor, image64(g), status, take_done_flag(g, st, n)));
+    return KYB_OK;
+  }
   StreamRes* r = nullptr;
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);

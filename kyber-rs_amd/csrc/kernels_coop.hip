@@ -9,6 +9,7 @@
 //   k_decode_coop     unmarshal_binary          ge.rs:124-179   ge_decode replicated on all lanes, its square-root chain
 //                     (252 of ~270 dependent multiplications) cooperative
 //   k_verify_prep_coop / k_verify_prep_r_coop   the two front halves of a verification (verify.h) with that decode
+//   k_verify_coop     one verification per workgroup of three wavefronts: hash + ladder | both decodes | s B, one barrier, one launch
 //   k_poly_eval_coop  PubPoly::eval             poly.rs:457-469 one evaluation per wavefront: Horner with cooperative doublings / additions
 // Used for batches that leave the chip idle (engine.hip: `coop.max_items`); results are bit-identical to the batch kernels.
 #include <hip/hip_runtime.h>
@@ -212,6 +213,40 @@ __device__ __forceinline__ cq coop_mont_recover(const lane_consts& c, cq M, cq S
   return (r0 && negate) ? nres : RES;
 }
 
+// The whole ladder: UWQ = the base point's u as U1 (row 0) / W1 (row 2), tight; |scalar| = mag, its top skip_bits bits known to be 0.
+// Returns the state after the last conditional swap: SX = (x2, x2, x3, x3), SZ = (z2, z2, z3, z3).
+__device__ __forceinline__ void coop_ladder_run(const lane_consts& c, const uint32_t mag[8], int skip_bits, cq UWQ, cq& SX, cq& SZ) {
+  const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
+  ladder_state st;                                                       // (x2, z2, x3, z3) = (1, 0, U1, W1)
+  {
+    const cq u1 = bperm(rowperm_idx(c, 0, 0, 0, 0), UWQ), w1 = bperm(rowperm_idx(c, 2, 2, 2, 2), UWQ);
+    st.SX = c.row < 2 ? ONE0 : u1;
+    st.SZ = c.row < 2 ? 0u : w1;
+  }
+  const ladder_idx li = ladder_idx_init(c);
+  uint32_t swap = 0;
+#pragma unroll 1
+  for (int w = 7; w >= 0; --w) {
+    uint32_t word = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) word = (w == q) ? mag[q] : word;
+    const int first = (w == 7) ? skip_bits : 0;
+    word <<= first;
+#pragma unroll 1
+    for (int j = first; j < 32; ++j) {
+      const uint32_t bit = word >> 31;
+      word <<= 1;
+      swap ^= bit;
+      st = coop_ladder_step(c, li, st, UWQ, swap);                       // (rows 1, 3 of UWQ are not read)
+      swap = bit;
+    }
+  }
+  // the final conditional swap (x2, z2) <-> (x3, z3): rows 0, 1 <-> 2, 3
+  const int I_sw = (int)(c.lane << 2) ^ ((0 - (int)swap) & 128);
+  SX = bperm(I_sw, st.SX);
+  SZ = bperm(I_sw, st.SZ);
+}
+
 __global__ void __launch_bounds__(64)
 k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
            int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, kyb::launch::DoneFlag df) {
@@ -230,35 +265,8 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
   uint32_t p_flags;
   const cq M = coop_mont_prep(c, PQ, p_flags);                           // u = U / W, v = V / W: no inversion in front of the ladder
 
-  // ---- the ladder: state (x2, z2, x3, z3) = (1, 0, U1, W1) ----
-  const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
-  ladder_state st;
-  {
-    const cq u1 = bperm(rowperm_idx(c, 0, 0, 0, 0), M), w1 = bperm(rowperm_idx(c, 2, 2, 2, 2), M);
-    st.SX = c.row < 2 ? ONE0 : u1;
-    st.SZ = c.row < 2 ? 0u : w1;
-  }
-  const ladder_idx li = ladder_idx_init(c);
-  uint32_t swap = 0;
-#pragma unroll 1
-  for (int w = 7; w >= 0; --w) {
-    uint32_t word = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) word = (w == q) ? mag[q] : word;
-    const int first = (w == 7) ? skip_bits : 0;
-    word <<= first;
-#pragma unroll 1
-    for (int j = first; j < 32; ++j) {
-      const uint32_t bit = word >> 31;
-      word <<= 1;
-      swap ^= bit;
-      st = coop_ladder_step(c, li, st, M, swap);                         // M: U1 in row 0, W1 in row 2 (rows 1, 3 are not read)
-      swap = bit;
-    }
-  }
-  // the final conditional swap (x2, z2) <-> (x3, z3): rows 0, 1 <-> 2, 3
-  const int I_sw = (int)(c.lane << 2) ^ ((0 - (int)swap) & 128);
-  const cq SX = bperm(I_sw, st.SX), SZ = bperm(I_sw, st.SZ);
+  cq SX, SZ;
+  coop_ladder_run(c, mag, skip_bits, M, SX, SZ);
 
   // ---- y-recovery, exceptional cases, encoding ----
   const cq RES = coop_mont_recover(c, M, SX, SZ, p_flags, mag[0] & 1u, neg);
@@ -392,6 +400,29 @@ __device__ __forceinline__ cq coop_table_entry(const lane_consts& c, const uint3
   return (c.row == 2 && negate) ? nv : v;
 }
 
+// a' B for the scalar words a (sc_recode64's signed radix-64 digits): the point (X : Y : Z : T) before the sign of the top digit
+// (`neg`: negate X) is applied.  43 cooperative mixed additions.
+__device__ __forceinline__ cq coop_base_mul(const lane_consts& c, const uint32_t a[8], const uint32_t* __restrict__ image64, uint32_t& neg) {
+  sc_digits64 dg;
+  sc_recode64(dg, a);
+  const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
+  cq h = (c.row == 1 || c.row == 2) ? ONE0 : 0u;                         // neutral element (0 : 1 : 1 : 0)
+  const madd_idx mi = madd_idx_init(c);
+#pragma unroll 1
+  for (int pos = 0; pos < KYB_BASE64_POS - 1; ++pos) {
+    uint32_t idx, ng;
+    sc_next_digit64(idx, ng, dg, false);
+    h = coop_madd(c, mi, h, coop_table_entry<32>(c, image64 + pos * KYB_BASE64_WIN_WORDS, idx, ng));
+  }
+  {
+    uint32_t idx, ng;
+    sc_next_digit64(idx, ng, dg, true);
+    h = coop_madd(c, mi, h, coop_table_entry<16>(c, image64 + KYB_BASE64_TOP_BASE, idx, 0u));
+  }
+  neg = dg.neg;
+  return h;
+}
+
 __global__ void __launch_bounds__(64)
 k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ scalars_b, size_t n_a, size_t n, uint8_t* __restrict__ out_enc,
                 int32_t* __restrict__ out_ext, const uint32_t* __restrict__ image64, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset,
@@ -400,27 +431,11 @@ k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__
   if (i >= n) return;
   lane_consts c;
   lane_consts_init(c);
-  const bool r1 = c.row == 1, r2 = c.row == 2;
   uint32_t a[8];
   if (i < n_a) load_words8(a, scalars, i); else load_words8(a, scalars_b, i - n_a);      // two arrays in one launch (signing: nonces, then keys)
-  sc_digits64 dg;
-  sc_recode64(dg, a);
-  const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
-  cq h = (r1 || r2) ? ONE0 : 0u;                                       // neutral element (0 : 1 : 1 : 0)
-  const madd_idx mi = madd_idx_init(c);
-  auto madd = [&](cq E) { h = coop_madd(c, mi, h, E); };
-#pragma unroll 1
-  for (int pos = 0; pos < KYB_BASE64_POS - 1; ++pos) {
-    uint32_t idx, neg;
-    sc_next_digit64(idx, neg, dg, false);
-    madd(coop_table_entry<32>(c, image64 + pos * KYB_BASE64_WIN_WORDS, idx, neg));
-  }
-  {
-    uint32_t idx, neg;
-    sc_next_digit64(idx, neg, dg, true);
-    madd(coop_table_entry<16>(c, image64 + KYB_BASE64_TOP_BASE, idx, 0u));
-  }
-  coop_finish(c, h, dg.neg, out_enc, out_ext, i, proj, proj_stride, proj_offset);
+  uint32_t neg;
+  const cq h = coop_base_mul(c, a, image64, neg);
+  coop_finish(c, h, neg, out_enc, out_ext, i, proj, proj_stride, proj_offset);
   if (c.lane == 0) signal_done(df);
 }
 
@@ -483,6 +498,93 @@ k_verify_prep_r_coop(const uint8_t* __restrict__ sigs, size_t n, uint8_t* __rest
   if (c.lane == 0) {
     flags_r[i] = (uint8_t)fl;
     store_proj(proj, stride, proj_offset + i, R.X, R.Y, R.Z);
+  }
+}
+
+// One verification per WORKGROUP of three wavefronts (eddsa_sig.rs:159-212 / schnorr_sig.rs:53-110, verify.h), one launch:
+//   wavefront 0   s < L, canonical A, h = SHA-512(R || A || msg) mod L, the ladder for h A — which needs only A's y, since
+//                 u = (1 + y) / (1 - y): the x-only state it leaves is the same projective pair whatever common factor U1 and W1
+//                 carry, so it runs on (1 + y : 1 - y) while wavefront 1 is still extracting the square root for x;
+//   wavefront 1   decode of A (x, the small-order test), then decode and checks of R;
+//   wavefront 2   s B.
+// After one barrier wavefront 0 builds A's full image (U, V, W) with the x it was handed, recovers y(h A) and tests
+// R + h A == s B.  Critical path: hash + 253 ladder steps + recovery + comparison; the five-kernel sequence this replaces
+// for up to `coop.verify_max_items` signatures had the decode of A in front of the ladder and four launch gaps.
+__global__ void __launch_bounds__(192)
+k_verify_coop(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ msgs, const uint32_t* __restrict__ msg_off,
+              size_t n, int flavor, const uint32_t* __restrict__ image64, uint8_t* __restrict__ status, kyb::launch::DoneFlag df) {
+  __shared__ uint32_t sh_ax[10], sh_rx[10], sh_ry[10], sh_sb[30], sh_fl[4];
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  const uint32_t wave = threadIdx.x >> 6;
+  lane_consts c;
+  lane_consts_init(c);
+  uint32_t pub[8], sig[16];
+  load_words8(pub, pubs, i);
+  load_words8(sig, sigs, 2 * i);
+  load_words8(sig + 8, sigs, 2 * i + 1);
+  const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
+  cq SX = 0, SZ = 0;
+  uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  fe AY;
+  fe_from_words(AY, pub);
+  if (wave == 0) {
+    uint32_t ra[16];
+    for (int j = 0; j < 8; ++j) { ra[j] = sig[j]; ra[8 + j] = pub[j]; }
+    const uint32_t off = msg_off[i], len = msg_off[i + 1] - off;
+    sha512_ctx sc;
+    sha512_init(sc);
+    sha512_words64(sc, ra);
+    sha512_bytes(sc, msgs + off, len);
+    uint32_t dig[16];
+    sha512_final(dig, sc);
+    sc_reduce512(h, dig);
+    // (1 + y : 1 - y) in rows 0 / 2
+    const cq yq = quad_row_from_fe(c, quad_row_from_fe(c, 0u, 0, AY), 2, AY);
+    const cq UWQ = cnorm(c, c.row == 0 ? cadd(ONE0, yq) : (c.row == 2 ? csub(c, ONE0, yq) : 0u));
+    coop_ladder_run(c, h, 3, UWQ, SX, SZ);                               // h < L < 2^253
+  } else if (wave == 1) {
+    ge_p3 A, R;
+    const uint32_t a_dec = coop_decode_fn{c}(A, pub);
+    const uint32_t a_small = pt_has_small_order(A.Y);
+    const uint32_t r_can = pt_is_canonical_w(sig);
+    const uint32_t r_dec = coop_decode_fn{c}(R, sig);
+    const uint32_t r_small = pt_has_small_order(R.Y);
+    ge_p3 id;
+    ge_p3_0(id);
+    fe_cmov(R.X, id.X, 1u - r_dec); fe_cmov(R.Y, id.Y, 1u - r_dec);
+    if (c.lane == 0) {
+      for (int j = 0; j < 10; ++j) { sh_ax[j] = A.X.v[j]; sh_rx[j] = R.X.v[j]; sh_ry[j] = R.Y.v[j]; }
+      sh_fl[0] = a_dec | (a_small << 1);
+      sh_fl[1] = r_can | (r_dec << 1) | (r_small << 2);
+    }
+  } else {
+    uint32_t neg;
+    cq hq = coop_base_mul(c, sig + 8, image64, neg);
+    const cq nq = cnorm(c, c.p2 - hq);
+    hq = (c.row == 0 && neg) ? nq : hq;
+    if (c.active && c.row < 3) sh_sb[10 * c.row + c.k] = hq;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const uint32_t a_dec = sh_fl[0] & 1u, a_small = (sh_fl[0] >> 1) & 1u, fr = sh_fl[1];
+  // A = (x, y, 1) or, after a failed decode, the neutral element (verify_prep_a_with)
+  const uint32_t axk = c.active ? sh_ax[c.k] : 0u;
+  cq PQ = c.row == 0 ? axk : (c.row == 1 ? quad_row_from_fe(c, 0u, 1, AY) : (c.row == 2 ? ONE0 : 0u));
+  PQ = a_dec ? PQ : ((c.row == 1 || c.row == 2) ? ONE0 : 0u);
+  uint32_t p_flags;
+  const cq M = coop_mont_prep(c, PQ, p_flags);
+  const cq HA = coop_mont_recover(c, M, SX, SZ, p_flags, h[0] & 1u, 0u);
+  ge_p2 hA, sB;
+  fe RX, RY;
+  fe_from_quad_row(c, hA.X, HA, 0); fe_from_quad_row(c, hA.Y, HA, 1); fe_from_quad_row(c, hA.Z, HA, 2);
+  for (int j = 0; j < 10; ++j) { RX.v[j] = sh_rx[j]; RY.v[j] = sh_ry[j]; sB.X.v[j] = sh_sb[j]; sB.Y.v[j] = sh_sb[10 + j]; sB.Z.v[j] = sh_sb[20 + j]; }
+  const uint32_t eq = verify_final(RX, RY, hA, sB);
+  const uint32_t fa = sc_is_canonical_w(sig + 8) | (pt_is_canonical_w(pub) << 1) | (a_dec << 2) | (a_small << 3);
+  const uint32_t st = verify_status(fa, fr, flavor);
+  if (c.lane == 0) {
+    status[i] = (st == 0 && !eq) ? (uint8_t)9 : (uint8_t)st;
+    signal_done(df);
   }
 }
 
@@ -560,6 +662,11 @@ hipError_t verify_prep_r_coop(hipStream_t st, const uint8_t* sigs, size_t n, uin
 hipError_t poly_eval_coop(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly,
                           uint8_t* oenc, int32_t* oext, DoneFlag df) {
   hipLaunchKernelGGL(k_poly_eval_coop, dim3((unsigned)n), dim3(64), 0, st, commits, t, idx, n, nbits, per_poly, oenc, oext, df);
+  return hipGetLastError();
+}
+hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, int flavor,
+                       const uint32_t* image64, uint8_t* status, DoneFlag df) {
+  hipLaunchKernelGGL(k_verify_coop, dim3((unsigned)n), dim3(192), 0, st, pubs, sigs, msgs, off, n, flavor, image64, status, df);
   return hipGetLastError();
 }
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,

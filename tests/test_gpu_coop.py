@@ -90,20 +90,32 @@ def test_coop_decode_sign_verify_match_oracle(coop_engine, oracle):
     pubs = np.frombuffer(b"".join(c[0] for c in cases), dtype=np.uint8)
     sigs = np.frombuffer(b"".join(c[2] for c in cases), dtype=np.uint8)
     msgs = [c[1] for c in cases]
+    vmax = eng.get_option("coop.verify_max_items")
+    assert vmax >= 64
     for flavor in (0, 1):
         want = np.array([oracle.verify(flavor, *c) for c in cases], dtype=np.uint8)
         assert set(want.tolist()) >= {0, 2, 3, 4, 5, 6, 7, 8, 9}
-        for overlap in (1, 0):
-            eng.set_option("verify.overlap", overlap)
-            try:
+        # the single-launch kernel (three wavefronts per signature: hash + ladder on y alone | both decodes | s B)
+        eng.profile_begin(16)
+        assert np.array_equal(eng.verify(pubs, msgs, sigs, flavor), want)
+        assert [k for k, _ in eng.profile_read(16)] == ["k_verify_coop"]
+        eng.profile_begin(0)
+        for m in (1, 2, 5):
+            assert np.array_equal(eng.verify(pubs[:32 * m], msgs[:m], sigs[:64 * m], flavor), want[:m])
+        # the five-kernel sequence of the one-item-per-wavefront kernels (what larger small batches take)
+        eng.set_option("coop.verify_max_items", 0)
+        try:
+            for overlap in (1, 0):
+                eng.set_option("verify.overlap", overlap)
                 eng.profile_begin(16)
                 assert np.array_equal(eng.verify(pubs, msgs, sigs, flavor), want)
                 names = [k for k, _ in eng.profile_read(16)]
                 assert "k_mul_coop" in names and "k_mul_base_coop" in names and "k_mul_ladder" not in names
                 assert np.array_equal(eng.verify(pubs[:32], msgs[:1], sigs[:64], flavor), want[:1])
-            finally:
-                eng.profile_begin(0)
-                eng.set_option("verify.overlap", 1)
+        finally:
+            eng.profile_begin(0)
+            eng.set_option("verify.overlap", 1)
+            eng.set_option("coop.verify_max_items", vmax)
     xs, ks, ms, ss, ps = [], [], [], [], []
     for ln in gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n"):
         if not ln:
@@ -116,9 +128,11 @@ def test_coop_decode_sign_verify_match_oracle(coop_engine, oracle):
         xs.append(bytes(d[:32])); ks.append(r.to_bytes(32, "little")); ms.append(msg); ss.append(sig); ps.append(bytes.fromhex(p[1]))
     u8 = lambda lst: np.frombuffer(b"".join(lst), dtype=np.uint8)
     assert [bytes(r) for r in eng.schnorr_sign(u8(xs), u8(ks), ms)] == ss
-    assert not eng.verify(u8(ps), ms, u8(ss), 0).any()
+    assert not eng.verify(u8(ps), ms, u8(ss), 0).any()                   # 1024 > coop.verify_max_items: the kernel sequence
+    assert not eng.verify(u8(ps[:400]), ms[:400], u8(ss[:400]), 0).any()   # the single-launch kernel, messages of 0..399 bytes
     bad = bytearray(b"".join(ss)); bad[40] ^= 1
     assert eng.verify(u8(ps), ms, np.frombuffer(bytes(bad), dtype=np.uint8), 0)[0] == 9
+    assert eng.verify(u8(ps[:3]), ms[:3], np.frombuffer(bytes(bad[:192]), dtype=np.uint8), 0).tolist() == [9, 0, 0]
 
 
 def test_coop_pubpoly_eval_matches_oracle(coop_engine, oracle):
