@@ -755,6 +755,12 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
   SlotUse use(r, st);
   if (n <= (size_t)g.opt_coop_max && g.opt_mul_algo == 1) {
     // small batch: one item per wavefront, the whole multiplication in one launch (kernels_coop.hip)
+    if (penc != nullptr && 4 * n <= (size_t)g.opt_coop_max) {
+      // from the wire encoding, two wavefronts per item: the ladder starts on y while the decode is still looking for x
+      ProfScope ps(g, st, KID_MUL_COOP);
+      LAUNCHCK(launch::mul_enc_coop(st, sc, penc, n, oenc, oext, ok, take_done_flag(g, st, n)));
+      return KYB_OK;
+    }
     if (penc != nullptr) {
       int rc = ensure_enc(g, r, 160 * n + 256); if (rc) return rc;
       int32_t* tmp = reinterpret_cast<int32_t*>(r->enc);

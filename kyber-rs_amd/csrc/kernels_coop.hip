@@ -9,6 +9,7 @@
 //   k_decode_coop     unmarshal_binary          ge.rs:124-179   ge_decode replicated on all lanes, its square-root chain
 //                     (252 of ~270 dependent multiplications) cooperative
 //   k_verify_prep_coop / k_verify_prep_r_coop   the two front halves of a verification (verify.h) with that decode
+//   k_mul_enc_coop    Point::mul on a wire encoding, two wavefronts per item: ladder on y alone | square root for x
 //   k_verify_coop     one verification per workgroup of three wavefronts: hash + ladder | both decodes | s B, one barrier, one launch
 //   k_poly_eval_coop  PubPoly::eval             poly.rs:457-469 one evaluation per wavefront: Horner with cooperative doublings / additions
 // Used for batches that leave the chip idle (engine.hip: `coop.max_items`); results are bit-identical to the batch kernels.
@@ -501,6 +502,56 @@ k_verify_prep_r_coop(const uint8_t* __restrict__ sigs, size_t n, uint8_t* __rest
   }
 }
 
+// Point::mul on a WIRE ENCODING (the Diffie-Hellman batch: unmarshal_binary + mul), one workgroup of two wavefronts per item:
+// wavefront 0 runs the ladder on (1 + y : 1 - y) while wavefront 1 extracts the square root for x (see k_verify_coop below);
+// a failed decode gives ok = 0 and the neutral element, as k_decode_or_identity + k_mul_coop do in two launches.
+__global__ void __launch_bounds__(128)
+k_mul_enc_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ pts_enc, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
+               uint8_t* __restrict__ ok_out, kyb::launch::DoneFlag df) {
+  __shared__ uint32_t sh_x[10], sh_ok[1];
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  const uint32_t wave = threadIdx.x >> 6;
+  lane_consts c;
+  lane_consts_init(c);
+  uint32_t w[8];
+  load_words8(w, pts_enc, i);
+  const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
+  fe Y;
+  fe_from_words(Y, w);
+  cq SX = 0, SZ = 0;
+  uint32_t neg = 0, mag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (wave == 0) {
+    uint32_t a[8];
+    load_words8(a, scalars, i);
+    sc_effective(neg, mag, a);
+    const cq yq = quad_row_from_fe(c, quad_row_from_fe(c, 0u, 0, Y), 2, Y);
+    const cq UWQ = cnorm(c, c.row == 0 ? cadd(ONE0, yq) : (c.row == 2 ? csub(c, ONE0, yq) : 0u));
+    coop_ladder_run(c, mag, 0, UWQ, SX, SZ);
+  } else {
+    ge_p3 P;
+    const uint32_t ok = coop_decode_fn{c}(P, w);
+    if (c.lane == 0) {
+      for (int j = 0; j < 10; ++j) sh_x[j] = P.X.v[j];
+      sh_ok[0] = ok;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const uint32_t ok = sh_ok[0];
+  const uint32_t xk = c.active ? sh_x[c.k] : 0u;
+  cq PQ = c.row == 0 ? xk : (c.row == 1 ? quad_row_from_fe(c, 0u, 1, Y) : (c.row == 2 ? ONE0 : 0u));
+  PQ = ok ? PQ : ((c.row == 1 || c.row == 2) ? ONE0 : 0u);
+  uint32_t p_flags;
+  const cq M = coop_mont_prep(c, PQ, p_flags);
+  const cq RES = coop_mont_recover(c, M, SX, SZ, p_flags, mag[0] & 1u, neg);
+  coop_finish(c, RES, 0u, out_enc, out_ext, i);
+  if (c.lane == 0) {
+    if (ok_out != nullptr) ok_out[i] = (uint8_t)ok;
+    signal_done(df);
+  }
+}
+
 // One verification per WORKGROUP of three wavefronts (eddsa_sig.rs:159-212 / schnorr_sig.rs:53-110, verify.h), one launch:
 //   wavefront 0   s < L, canonical A, h = SHA-512(R || A || msg) mod L, the ladder for h A — which needs only A's y, since
 //                 u = (1 + y) / (1 - y): the x-only state it leaves is the same projective pair whatever common factor U1 and W1
@@ -662,6 +713,10 @@ hipError_t verify_prep_r_coop(hipStream_t st, const uint8_t* sigs, size_t n, uin
 hipError_t poly_eval_coop(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly,
                           uint8_t* oenc, int32_t* oext, DoneFlag df) {
   hipLaunchKernelGGL(k_poly_eval_coop, dim3((unsigned)n), dim3(64), 0, st, commits, t, idx, n, nbits, per_poly, oenc, oext, df);
+  return hipGetLastError();
+}
+hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, DoneFlag df) {
+  hipLaunchKernelGGL(k_mul_enc_coop, dim3((unsigned)n), dim3(128), 0, st, sc, penc, n, oenc, oext, ok, df);
   return hipGetLastError();
 }
 hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, int flavor,
