@@ -37,9 +37,9 @@ thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
 enum KernelId { KID_MUL, KID_MUL_BASE, KID_FINISH, KID_SIGN, KID_SIGN_HASH, KID_VERIFY_PREP, KID_VERIFY_FINAL, KID_POLY_EVAL, KID_MONT_PREP,
-                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_VERIFY_COOP, KID_COUNT };
+                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_VERIFY_COOP, KID_FINISH_COOP, KID_COUNT };
 const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval",
-                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop", "k_verify_coop"};
+                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop", "k_verify_coop", "k_finish_coop"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   std::mutex mu;                  // begin / read / every ProfScope: callable from any thread
@@ -674,7 +674,13 @@ int do_init(int device, bool build_table) {
 }
 
 // ---- launch sequences ------------------------------------------------------------------------------------
-int launch_finish(Ctx& g, StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st, size_t src_mul = 1) {
+// last: nothing is queued behind this launch in its call (it may carry the completion flag)
+int launch_finish(Ctx& g, StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st, size_t src_mul = 1, bool last = false) {
+  if (n <= (size_t)g.opt_coop_decode_max) {          // few points: one per wavefront
+    ProfScope ps(g, st, KID_FINISH_COOP);
+    LAUNCHCK(launch::finish_coop(st, r->proj, r->proj_items, nullptr, n, oenc, oext, src_mul, last ? take_done_flag(g, st, n) : launch::DoneFlag{}));
+    return KYB_OK;
+  }
   ProfScope ps(g, st, KID_FINISH);
   LAUNCHCK(launch::finish(st, r->proj, r->proj_items, n, oenc, oext, src_mul));
   return KYB_OK;
@@ -728,9 +734,25 @@ int launch_lincomb(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
   const size_t n = m * t;
-  { int rc = launch_ladder_core(g, sc, penc, pext, n, ok, r, st, shared ? t : 0); if (rc) return rc; }
+  if (n <= (size_t)g.opt_coop_max && g.opt_mul_algo == 1) {
+    // few products: one per wavefront, handed over projective (no inversion) to the halving passes
+    const size_t np = shared ? t : n;
+    int rc = ensure_proj(g, r, n); if (rc) return rc;
+    if (penc != nullptr) {
+      rc = ensure_enc(g, r, 160 * np + 256); if (rc) return rc;
+      int32_t* tmp = reinterpret_cast<int32_t*>(r->enc);
+      { ProfScope ps(g, st, KID_DECODE_COOP); LAUNCHCK(launch::decode_coop(st, penc, np, tmp, ok, true)); }
+      pext = tmp;
+    } else if (ok != nullptr) {
+      HIPCK(hipMemsetAsync(ok, 1, np, st));
+    }
+    ProfScope ps(g, st, KID_MUL_COOP);
+    LAUNCHCK(launch::mul_coop(st, sc, pext, n, nullptr, nullptr, 0, r->proj, r->proj_items, 0, launch::DoneFlag{}, shared ? t : 0));
+  } else {
+    int rc = launch_ladder_core(g, sc, penc, pext, n, ok, r, st, shared ? t : 0); if (rc) return rc;
+  }
   { int rc = launch_pair_sums(g, r, m, t, st); if (rc) return rc; }
-  return launch_finish(g, r, m, oenc, oext, st, t);
+  return launch_finish(g, r, m, oenc, oext, st, t, true);
 }
 
 // out[g] = sum_j P[g*t + j]: the halving passes of launch_lincomb on the points themselves
@@ -744,7 +766,7 @@ int launch_sum(Ctx& g, const int32_t* pext, size_t m, size_t t, uint8_t* oenc, i
   { int rc = ensure_proj(g, r, n); if (rc) return rc; }
   LAUNCHCK(launch::ext_to_proj(st, pext, n, r->proj, r->proj_items));
   { int rc = launch_pair_sums(g, r, m, t, st); if (rc) return rc; }
-  return launch_finish(g, r, m, oenc, oext, st, t);
+  return launch_finish(g, r, m, oenc, oext, st, t, true);
 }
 
 int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, hipStream_t st) {
@@ -775,7 +797,7 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
   }
   if (g.opt_mul_algo == 1) {
     int rc = launch_ladder_core(g, sc, penc, pext, n, ok, r, st); if (rc) return rc;
-    return launch_finish(g, r, n, oenc, oext, st);
+    return launch_finish(g, r, n, oenc, oext, st, 1, true);
   }
   { int rc = ensure_ws(g, r); if (rc) return rc; }
   const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
@@ -786,7 +808,7 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
     ProfScope ps(g, st, KID_MUL);
     LAUNCHCK(launch::mul_window(g.opt_mul_select, penc != nullptr, split, grid, st, sc, penc, pext, n, oenc, oext, ok, r->ws, r->proj, r->proj_items));
   }
-  if (split) return launch_finish(g, r, n, oenc, oext, st);
+  if (split) return launch_finish(g, r, n, oenc, oext, st, 1, true);
   return KYB_OK;
 }
 
@@ -844,13 +866,18 @@ int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t*
   if (use_split(g, n)) {
     int rc = ensure_proj(g, r, n); if (rc) return rc;
     rc = launch_base(g, true, sc, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
-    return launch_finish(g, r, n, oenc, oext, st);
+    return launch_finish(g, r, n, oenc, oext, st, 1, true);
   }
   return launch_base(g, false, sc, n, oenc, oext, r, 0, st);
 }
 // marshal_binary of n extended points: one shared inversion per FINISH_K points
 int launch_encode(Ctx& g, const int32_t* pext, size_t n, uint8_t* oenc, hipStream_t st) {
   if (n == 0) return KYB_OK;
+  if (n <= (size_t)g.opt_coop_decode_max) {
+    ProfScope ps(g, st, KID_FINISH_COOP);
+    LAUNCHCK(launch::finish_coop(st, nullptr, 0, pext, n, oenc, nullptr, 1, take_done_flag(g, st, n)));
+    return KYB_OK;
+  }
   if (g.opt_encode_batched == 1) {
     ProfScope ps(g, st, KID_ENCODE);
     LAUNCHCK(launch::encode_batched(st, pext, n, oenc));
@@ -1044,7 +1071,7 @@ int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* i
     ProfScope ps(g, st, KID_POLY_EVAL);
     LAUNCHCK(launch::poly_eval(split, st, commits, (int)t, idx, n, nbits, per_poly, oenc, oext, r->proj, r->proj_items));
   }
-  if (split) return launch_finish(g, r, n, oenc, oext, st);
+  if (split) return launch_finish(g, r, n, oenc, oext, st, 1, true);
   return KYB_OK;
 }
 

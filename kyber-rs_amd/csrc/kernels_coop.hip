@@ -6,6 +6,7 @@
 //                     cooperative.  One launch does the whole multiplication.
 //   k_mul_base_coop   Point::mul(s, None)     ge.rs:442-486   the radix-64 table of k_mul_base64 read from global memory (every
 //                     line of a limb's 32 entries is touched whatever the digit), 43 cooperative mixed additions, cooperative inversion.
+//   k_finish_coop     marshal_binary / the finish of a projective staging record, one point per wavefront (cooperative inversion)
 //   k_decode_coop     unmarshal_binary          ge.rs:124-179   ge_decode replicated on all lanes, its square-root chain
 //                     (252 of ~270 dependent multiplications) cooperative
 //   k_verify_prep_coop / k_verify_prep_r_coop   the two front halves of a verification (verify.h) with that decode
@@ -250,18 +251,19 @@ __device__ __forceinline__ void coop_ladder_run(const lane_consts& c, const uint
 
 __global__ void __launch_bounds__(64)
 k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
-           int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, kyb::launch::DoneFlag df) {
+           int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, size_t pt_mod, kyb::launch::DoneFlag df) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
   lane_consts c;
   lane_consts_init(c);
+  const size_t ip = pt_mod ? i % pt_mod : i;                             // shared operands: item i multiplies point i mod pt_mod
 
   // ---- operands: the scalar replicated on all lanes, the point as a quad (X, Y, Z, T) straight from its 40 reference limbs ----
   uint32_t a[8];
   load_words8(a, scalars, i);
   uint32_t neg, mag[8];
   sc_effective(neg, mag, a);
-  const uint32_t word = c.active ? (uint32_t)pts_ext[40 * i + 10 * c.row + c.k] : 0u;
+  const uint32_t word = c.active ? (uint32_t)pts_ext[40 * ip + 10 * c.row + c.k] : 0u;
   const cq PQ = cnorm(c, c.active ? word + (c.p2 << 3) : 0u);           // fe_from_ref10: signed limb + 16p, one carry pass
   uint32_t p_flags;
   const cq M = coop_mont_prep(c, PQ, p_flags);                           // u = U / W, v = V / W: no inversion in front of the ladder
@@ -437,6 +439,29 @@ k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__
   uint32_t neg;
   const cq h = coop_base_mul(c, a, image64, neg);
   coop_finish(c, h, neg, out_enc, out_ext, i, proj, proj_stride, proj_offset);
+  if (c.lane == 0) signal_done(df);
+}
+
+// k_finish / k_encode for a small batch: one point per wavefront, the inversion cooperative (csrc/kernels_misc.hip has the batch forms,
+// one inversion per 8 points of ONE lane: 70 us however few the points).  Source: projective staging record i * src_mul, or the 40
+// reference limbs of point i.
+__global__ void __launch_bounds__(64)
+k_finish_coop(const uint4* __restrict__ proj, size_t stride, const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc,
+              int32_t* __restrict__ out_ext, size_t src_mul, kyb::launch::DoneFlag df) {
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  lane_consts c;
+  lane_consts_init(c);
+  cq q;
+  if (pts_ext != nullptr) {
+    const uint32_t word = c.active ? (uint32_t)pts_ext[40 * i + 10 * c.row + c.k] : 0u;
+    q = cnorm(c, c.active ? word + (c.p2 << 3) : 0u);
+  } else {
+    const uint32_t w = 10u * (c.row < 3 ? c.row : 0u) + (c.active ? c.k : 0u);
+    const uint32_t v = reinterpret_cast<const uint32_t*>(proj)[((size_t)(w >> 2) * stride + i * src_mul) * 4 + (w & 3u)];
+    q = (c.active && c.row < 3) ? v : 0u;                                // staging records hold tight limbs
+  }
+  coop_finish(c, q, 0u, out_enc, out_ext, i);
   if (c.lane == 0) signal_done(df);
 }
 
@@ -697,6 +722,10 @@ hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32
   hipLaunchKernelGGL(k_coop_selftest, dim3(1), dim3(64), 0, st, op, A, B, out, image64);
   return hipGetLastError();
 }
+hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul, DoneFlag df) {
+  hipLaunchKernelGGL(k_finish_coop, dim3((unsigned)n), dim3(64), 0, st, proj, stride, pts_ext, n, oenc, oext, src_mul, df);
+  return hipGetLastError();
+}
 hipError_t decode_coop(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok, bool or_identity, DoneFlag df) {
   hipLaunchKernelGGL(k_decode_coop, dim3((unsigned)n), dim3(64), 0, st, enc, n, out_ext, ok, or_identity ? 1 : 0, df);
   return hipGetLastError();
@@ -725,8 +754,8 @@ hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs,
   return hipGetLastError();
 }
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
-                    uint4* proj, size_t proj_stride, size_t proj_offset, DoneFlag df) {
-  hipLaunchKernelGGL(k_mul_coop, dim3((unsigned)n), dim3(64), 0, st, sc, pext, n, oenc, oext, skip_bits, proj, proj_stride, proj_offset, df);
+                    uint4* proj, size_t proj_stride, size_t proj_offset, DoneFlag df, size_t pt_mod) {
+  hipLaunchKernelGGL(k_mul_coop, dim3((unsigned)n), dim3(64), 0, st, sc, pext, n, oenc, oext, skip_bits, proj, proj_stride, proj_offset, pt_mod, df);
   return hipGetLastError();
 }
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,

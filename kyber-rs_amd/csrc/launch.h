@@ -66,7 +66,10 @@ hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, 
 hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, int flavor,
                        const uint32_t* image64, uint8_t* status, DoneFlag df = DoneFlag{});
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
-                    uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, DoneFlag df = DoneFlag{});
+                    uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, DoneFlag df = DoneFlag{}, size_t pt_mod = 0);
+// proj != nullptr: projective staging record i * src_mul, else the 40 reference limbs of point i
+hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul,
+                       DoneFlag df = DoneFlag{});
 // sc_b != nullptr: n_b more scalars follow the first n in the same launch (their results behind the first n)
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
                          uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, const uint8_t* sc_b = nullptr, size_t n_b = 0,

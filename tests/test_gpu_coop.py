@@ -164,6 +164,25 @@ def test_coop_pubpoly_eval_matches_oracle(coop_engine, oracle):
     assert all(bytes(o) == oracle.encode(commits[0]) for o in one)
 
 
+def test_parity_suites_again_on_the_small_batch_kernels(coop_engine, oracle):
+    """the parity tests of linear combinations, decode / encode / add / sub and polynomial evaluation (tests/test_gpu_parity.py,
+    which the session runs with the one-item-per-wavefront kernels switched off) once more with them switched on:
+    products of a linear combination one per wavefront and handed over projective, cooperative finish and encode"""
+    import test_gpu_parity as P
+    eng = coop_engine
+    sc = synth.scalars(12, 61).reshape(3, 4, 32)
+    pts = oracle.mul_base_ext_batch(synth.scalars(12, 62)).reshape(3, 4, 40)
+    eng.profile_begin(8)
+    got = eng.lincomb(sc, pts_ext=pts)
+    names = [k for k, _ in eng.profile_read(8)]
+    eng.profile_begin(0)
+    assert names[0] == "k_mul_coop" and names[-1] == "k_finish_coop" and "k_mul_ladder" not in names
+    assert [bytes(g) for g in got] == [oracle.lincomb(sc[g], pts[g]) for g in range(3)]
+    P.test_lincomb_matches_oracle(eng, oracle)
+    P.test_decode_encode_add_sub(eng, oracle)
+    P.test_pubpoly_eval_and_equal(eng, oracle)
+
+
 def test_coop_and_batch_kernels_agree_at_the_threshold(engine, oracle):
     """the routing by size: n <= coop.max_items -> cooperative kernel, above -> batch kernels; same bytes either way"""
     s = synth.raw256(130, 800)
