@@ -168,7 +168,6 @@ __device__ __forceinline__ cq csq4(const lane_consts& c, cq F) {
 // element-wise on four elements at once
 __device__ __forceinline__ cq cadd(cq a, cq b) { return a + b; }
 __device__ __forceinline__ cq csub(const lane_consts& c, cq a, cq b) { return a + (c.p2 - b); }      // b <= 2T; result <= bound(a) + 2T
-__device__ __forceinline__ cq csel(bool take_b, cq a, cq b) { return take_b ? b : a; }
 
 // ---- replicated one-lane form <-> quad ----------------------------------------------------------------------------
 // every lane holds the same `fe` (the irregular parts of a multiplication run replicated on all lanes)

@@ -2,8 +2,8 @@
 // (coop25519.h).  One of the translation units of the library (map: launch.h).
 //   k_mul_coop        Point::mul(s, Some(P))  ge.rs:508-568   the Montgomery ladder of k_mul_ladder with a PROJECTIVE base point
 //                     (mont_ladder_proj, ge_ladder.h: no inversion in front), its 256 steps as three cooperative multiplication
-//                     levels each; image, y-recovery and encoding replicated on all lanes around it, the one field inversion
-//                     cooperative.  One launch does the whole multiplication.
+//                     levels each; operand image, y-recovery with its exceptional cases and the field inversion of the encoding
+//                     cooperative as well (only the canonical byte encoding runs replicated).  One launch does the whole multiplication.
 //   k_mul_base_coop   Point::mul(s, None)     ge.rs:442-486   the radix-64 table of k_mul_base64 read from global memory (every
 //                     line of a limb's 32 entries is touched whatever the digit), 43 cooperative mixed additions, cooperative inversion.
 //   k_finish_coop     marshal_binary / the finish of a projective staging record, one point per wavefront (cooperative inversion)
@@ -25,10 +25,6 @@ using namespace kyb::coop;
 #include "device_tables.h"
 
 namespace {
-
-struct row_masks {
-  bool odd, r0, r1, r2, r3;
-};
 
 // encode (and optionally affine limbs) from a point (X : Y : Z) in rows 0..2 of a tight quad; Z^-1 computed cooperatively.
 // proj != nullptr: the point also goes to staging record proj_offset + i for k_verify_final — affine (Z = 1) next to an

@@ -7,7 +7,8 @@
 //   kernels_window.hip    windowed variable-base k_mul (mul.algo=0, cross-check of the ladder)
 //   kernels_verify.hip    SHA-512 users: k_verify_prep / _r / _final, k_sign_hash, k_eddsa_prep
 //   kernels_misc.hip      k_finish, k_encode_batched, k_add, k_equal, k_encode, k_decode, k_poly_eval
-//   kernels_coop.hip      small batches: one item per wavefront, lane-cooperative field arithmetic (k_mul_coop, k_mul_base_coop)
+//   kernels_coop.hip      small batches: one item per wavefront (or two / three wavefronts per item), lane-cooperative field arithmetic:
+//                         k_mul_coop, k_mul_enc_coop, k_mul_base_coop, k_decode_coop, k_finish_coop, k_verify_coop, k_verify_prep(_r)_coop, k_poly_eval_coop
 //   engine.hip            contexts, per-stream scratch, launch sequences, host-pointer pipeline, multi-device groups, C ABI
 //
 // A kernel is defined in exactly one unit; the engine reaches it through the plain C++ function declared here
@@ -55,7 +56,7 @@ hipError_t diag_set_stamp_buffer(uint64_t* dev_buf, size_t waves);
 struct DoneFlag { uint32_t* counter; uint32_t* flag; uint32_t seq; uint32_t total; };
 
 // ---- kernels_coop.hip ----
-// proj != nullptr: the affine result is also written to staging record proj_offset + i (Z = 1), the input format of k_verify_final
+// proj != nullptr: the result is also written to staging record proj_offset + i (projective when it is the only output)
 hipError_t decode_coop(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok, bool or_identity, DoneFlag df = DoneFlag{});
 hipError_t verify_prep_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,
                             uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf, int32_t* a_ext);
