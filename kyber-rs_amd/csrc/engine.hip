@@ -37,9 +37,9 @@ thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
 enum KernelId { KID_MUL, KID_MUL_BASE, KID_FINISH, KID_SIGN, KID_SIGN_HASH, KID_VERIFY_PREP, KID_VERIFY_FINAL, KID_POLY_EVAL, KID_MONT_PREP,
-                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_VERIFY_COOP, KID_FINISH_COOP, KID_COUNT };
+                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_VERIFY_COOP, KID_FINISH_COOP, KID_SIGN_COOP, KID_COUNT };
 const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval",
-                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop", "k_verify_coop", "k_finish_coop"};
+                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop", "k_verify_coop", "k_finish_coop", "k_sign_coop"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   std::mutex mu;                  // begin / read / every ProfScope: callable from any thread
@@ -891,6 +891,12 @@ int launch_encode(Ctx& g, const int32_t* pext, size_t n, uint8_t* oenc, hipStrea
 // pub_out != nullptr: receives enc(x*B).
 int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const uint8_t* pub_in, const uint8_t* msgs, const uint32_t* off, size_t n,
                 uint8_t* sig, uint8_t* pub_out, hipStream_t st) {
+  if (n <= (size_t)g.opt_coop_verify_max && 2 * n <= (size_t)g.opt_coop_base_max) {
+    // few signatures: one launch, two wavefronts each (kernels_coop.hip)
+    ProfScope ps(g, st, KID_SIGN_COOP);
+    LAUNCHCK(launch::sign_coop(st, x, k, pub_in, msgs, off, n, sig, pub_out, image64(g), take_done_flag(g, st, n)));
+    return KYB_OK;
+  }
   if (pub_in != nullptr) {
     // R = k*B only
     int rc = ensure_enc(g, r, 32 * n); if (rc) return rc;

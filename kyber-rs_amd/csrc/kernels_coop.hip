@@ -10,6 +10,7 @@
 //   k_decode_coop     unmarshal_binary          ge.rs:124-179   ge_decode replicated on all lanes, its square-root chain
 //                     (252 of ~270 dependent multiplications) cooperative
 //   k_verify_prep_coop / k_verify_prep_r_coop   the two front halves of a verification (verify.h) with that decode
+//   k_sign_coop       schnorr::sign in one launch, two wavefronts per signature: k B | x B, then hash and s = k + x h
 //   k_mul_enc_coop    Point::mul on a wire encoding, two wavefronts per item: ladder on y alone | square root for x
 //   k_verify_coop     one verification per workgroup of three wavefronts: hash + ladder | both decodes | s B, one barrier, one launch
 //   k_poly_eval_coop  PubPoly::eval             poly.rs:457-469 one evaluation per wavefront: Horner with cooperative doublings / additions
@@ -26,6 +27,14 @@ using namespace kyb::coop;
 
 namespace {
 
+// affine (x, y) of the point (X : Y : Z) in rows 0..2 of a tight quad, in every lane; Z^-1 cooperative (0 when Z = 0: the reference's 0^(p-2))
+__device__ __forceinline__ void coop_affine(const lane_consts& c, cq q, fe& x, fe& y) {
+  const cq inv = cinv(c, q);
+  const cq zi = bperm(rowperm_idx(c, 2, 2, 2, 2), inv);
+  const cq xy = cmul4(c, q, zi);                                     // rows 0, 1 = x, y
+  fe_from_quad_row(c, x, xy, 0);
+  fe_from_quad_row(c, y, xy, 1);
+}
 // encode (and optionally affine limbs) from a point (X : Y : Z) in rows 0..2 of a tight quad; Z^-1 computed cooperatively.
 // proj != nullptr: the point also goes to staging record proj_offset + i for k_verify_final — affine (Z = 1) next to an
 // encoding or limbs, as it is (projective, no inversion at all) when it is the only output.
@@ -41,12 +50,8 @@ __device__ __forceinline__ void coop_finish(const lane_consts& c, cq q, uint32_t
     if (proj != nullptr && c.lane == 0) store_proj(proj, proj_stride, proj_offset + i, X, Y, Z);
     return;
   }
-  const cq inv = cinv(c, q);                                         // row 2 = 1/Z (0 when Z = 0: the reference's 0^(p-2))
-  const cq zi = bperm(rowperm_idx(c, 2, 2, 2, 2), inv);
-  const cq xy = cmul4(c, q, zi);                                     // rows 0, 1 = x, y
   fe x, y;
-  fe_from_quad_row(c, x, xy, 0);
-  fe_from_quad_row(c, y, xy, 1);
+  coop_affine(c, q, x, y);
   if (out_enc != nullptr) {
     uint32_t w[8];
     fe_to_words(w, y);
@@ -523,6 +528,55 @@ k_verify_prep_r_coop(const uint8_t* __restrict__ sigs, size_t n, uint8_t* __rest
   }
 }
 
+// schnorr::sign (schnorr_sig.rs:25-47) in one launch, two wavefronts per signature: R = k B in wavefront 0, A = x B in wavefront 1
+// (idle when the signer's stored public key is given), then wavefront 0 hashes and forms s = k + x h (k_sign_hash's work).
+__global__ void __launch_bounds__(128)
+k_sign_coop(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ msgs,
+            const uint32_t* __restrict__ msg_off, size_t n, uint8_t* __restrict__ sig, uint8_t* __restrict__ pub_out,
+            const uint32_t* __restrict__ image64, kyb::launch::DoneFlag df) {
+  __shared__ uint32_t sh_a[8];
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  const uint32_t wave = threadIdx.x >> 6;
+  lane_consts c;
+  lane_consts_init(c);
+  uint32_t ra[16];
+  if (wave == 0 || pubs == nullptr) {
+    uint32_t a[8], neg;
+    load_words8(a, wave == 0 ? k : x, i);
+    cq h = coop_base_mul(c, a, image64, neg);
+    const cq nq = cnorm(c, c.p2 - h);
+    h = (c.row == 0 && neg) ? nq : h;
+    fe ax, ay;
+    coop_affine(c, h, ax, ay);
+    fe_to_words(ra, ay);
+    ra[7] ^= fe_is_negative(ax) << 31;
+    if (wave == 1 && c.lane == 0) for (int j = 0; j < 8; ++j) sh_a[j] = ra[j];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  if (pubs != nullptr) load_words8(ra + 8, pubs, i);
+  else for (int j = 0; j < 8; ++j) ra[8 + j] = sh_a[j];
+  uint32_t wx[8], wk[8];
+  load_words8(wx, x, i);
+  load_words8(wk, k, i);
+  sha512_ctx sc;
+  sha512_init(sc);
+  sha512_words64(sc, ra);
+  const uint32_t off = msg_off[i], len = msg_off[i + 1] - off;
+  sha512_bytes(sc, msgs + off, len);
+  uint32_t dig[16], hh[8], ss[8];
+  sha512_final(dig, sc);
+  sc_reduce512(hh, dig);
+  sc_muladd(ss, wx, hh, wk);
+  if (c.lane == 0) {
+    store_words8(sig, 2 * i, ra);
+    store_words8(sig, 2 * i + 1, ss);
+    if (pub_out != nullptr) store_words8(pub_out, i, ra + 8);
+    signal_done(df);
+  }
+}
+
 // Point::mul on a WIRE ENCODING (the Diffie-Hellman batch: unmarshal_binary + mul), one workgroup of two wavefronts per item:
 // wavefront 0 runs the ladder on (1 + y : 1 - y) while wavefront 1 extracts the square root for x (see k_verify_coop below);
 // a failed decode gives ok = 0 and the neutral element, as k_decode_or_identity + k_mul_coop do in two launches.
@@ -738,6 +792,11 @@ hipError_t verify_prep_r_coop(hipStream_t st, const uint8_t* sigs, size_t n, uin
 hipError_t poly_eval_coop(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly,
                           uint8_t* oenc, int32_t* oext, DoneFlag df) {
   hipLaunchKernelGGL(k_poly_eval_coop, dim3((unsigned)n), dim3(64), 0, st, commits, t, idx, n, nbits, per_poly, oenc, oext, df);
+  return hipGetLastError();
+}
+hipError_t sign_coop(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, size_t n,
+                     uint8_t* sig, uint8_t* pub_out, const uint32_t* image64, DoneFlag df) {
+  hipLaunchKernelGGL(k_sign_coop, dim3((unsigned)n), dim3(128), 0, st, x, k, pubs, msgs, off, n, sig, pub_out, image64, df);
   return hipGetLastError();
 }
 hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, DoneFlag df) {

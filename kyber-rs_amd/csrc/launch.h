@@ -63,6 +63,8 @@ hipError_t verify_prep_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* 
 hipError_t verify_prep_r_coop(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* flags_r, uint4* proj, size_t stride, size_t offset);
 hipError_t poly_eval_coop(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly,
                           uint8_t* oenc, int32_t* oext, DoneFlag df = DoneFlag{});
+hipError_t sign_coop(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, size_t n,
+                     uint8_t* sig, uint8_t* pub_out, const uint32_t* image64, DoneFlag df = DoneFlag{});
 hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, DoneFlag df = DoneFlag{});
 hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, int flavor,
                        const uint32_t* image64, uint8_t* status, DoneFlag df = DoneFlag{});

@@ -164,6 +164,37 @@ def test_coop_pubpoly_eval_matches_oracle(coop_engine, oracle):
     assert all(bytes(o) == oracle.encode(commits[0]) for o in one)
 
 
+def test_coop_single_launch_signing(coop_engine, oracle):
+    """schnorr::sign / EdDSA::sign for up to 512 signatures in one launch (two wavefronts per signature), with and without the
+    signer's stored public key: the reference's golden EdDSA lines (ragged messages), random triples, unreduced secrets"""
+    import gzip
+    eng = coop_engine
+    seeds, pubs, msgs, sigs = [], [], [], []
+    for ln in gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n")[:400]:
+        if ln:
+            p = ln.split(":")
+            seeds.append(bytes.fromhex(p[0])[:32]); pubs.append(bytes.fromhex(p[1])); msgs.append(bytes.fromhex(p[2])); sigs.append(bytes.fromhex(p[3])[:64])
+    for v in KATS["rfc8032"]:
+        seeds.append(bytes.fromhex(v["private"])); pubs.append(bytes.fromhex(v["public"])); msgs.append(bytes.fromhex(v["message"])); sigs.append(bytes.fromhex(v["signature"]))
+    u8 = lambda lst: np.frombuffer(b"".join(lst), dtype=np.uint8)
+    eng.profile_begin(8)
+    sig, pub = eng.eddsa_sign(u8(seeds), msgs, want_pub=True)
+    assert [k for k, _ in eng.profile_read(8)] == ["k_eddsa_prep", "k_sign_coop"]
+    eng.profile_begin(0)
+    assert [bytes(r) for r in pub] == pubs and [bytes(r) for r in sig] == sigs
+    assert [bytes(r) for r in eng.eddsa_sign(u8(seeds), msgs, pubs=pub)] == sigs
+    assert [bytes(r) for r in eng.eddsa_sign(u8(seeds[:1]), msgs[:1])] == sigs[:1]
+    n = 300
+    x, k = synth.raw256(n, 41), synth.scalars(n, 42, b"k")                 # secrets as the clamped EdDSA ones: not reduced mod L
+    x[:, 31] &= 0x7f
+    ms = synth.messages(n, 43)
+    want = oracle.schnorr_sign_batch(x, k, ms, nthreads=8)
+    assert np.array_equal(eng.schnorr_sign(x, k, ms), want)
+    assert np.array_equal(eng.schnorr_sign(x, k, ms, pubs=eng.mul_base(x)), want)
+    for m in (1, 2, 63, 65):
+        assert np.array_equal(eng.schnorr_sign(x[:m], k[:m], ms[:m]), want[:m])
+
+
 def test_parity_suites_again_on_the_small_batch_kernels(coop_engine, oracle):
     """the parity tests of linear combinations, decode / encode / add / sub and polynomial evaluation (tests/test_gpu_parity.py,
     which the session runs with the one-item-per-wavefront kernels switched off) once more with them switched on:
