@@ -103,6 +103,7 @@ struct Ctx {
   std::atomic<int> opt_finish{1};             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
   std::atomic<int> opt_finish_min{1};         // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size; cross-check)
   std::atomic<int> opt_coop_max{4096};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 4096 and 6144, profiles/r02/coop_crossover.log)
+  std::atomic<int> opt_verify_by_enc{1};         // large verification batches: compare the encoding of s*B - h*A with R's bytes, decode R only on a mismatch
   std::atomic<int> opt_coop_verify_max{512};     // verification: up to this many signatures take the single-launch kernel (three wavefronts each)
   std::atomic<int> opt_coop_decode_max{1024};    // unmarshal_binary alone: the same (crossover between 1024 and 2048)
   std::atomic<int> opt_coop_base_max{3072};      // fixed base: the same (crossover between 3072 and 4096; signing counts its two multiplications per item)
@@ -1017,7 +1018,9 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     HIPCK(hipEventRecord(r->ev_fork, st));                 // behind whatever the caller queued before this call
     HIPCK(hipStreamWaitEvent(side, r->ev_fork, 0));
   }
-  {
+  // large batches compare encodings (kernels_verify.hip, k_verify_final_enc): R is only decoded for signatures that fail
+  const bool by_enc = !coop && g.opt_verify_by_enc != 0;
+  if (!by_enc) {
     ProfScope ps(g, side, KID_VERIFY_PREP_R);
     if (coop) LAUNCHCK(launch::verify_prep_r_coop(side, sigs, n, flags_r, r->proj, r->proj_items, 2 * n));
     else LAUNCHCK(launch::verify_prep_r(side, sigs, n, flags_r, r->proj, r->proj_items, 2 * n));
@@ -1051,7 +1054,8 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   else { rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, st); if (rc) return rc; }
   {
     ProfScope ps(g, st, KID_VERIFY_FINAL);
-    LAUNCHCK(launch::verify_final(st, r->proj, r->proj_items, n, flags_a, flags_r, flavor, status, take_done_flag(g, st, n)));
+    if (by_enc) LAUNCHCK(launch::verify_tail_enc(st, r->proj, r->proj_items, n, sigs, flags_a, flavor, status, take_done_flag(g, st, n)));
+    else LAUNCHCK(launch::verify_final(st, r->proj, r->proj_items, n, flags_a, flags_r, flavor, status, take_done_flag(g, st, n)));
   }
   return KYB_OK;
 }

@@ -1,5 +1,6 @@
 // SHA-512 users of the MI355X Ed25519 engine (one of the five translation units, see launch.h).
 //   k_verify_prep / k_verify_prep_r / k_verify_final   eddsa_sig.rs:159-212, schnorr_sig.rs:53-110 (verify.h)
+//   k_verify_diff / k_verify_final_enc / k_verify_fixup   the same equation checked on encodings: R is decoded only when it fails
 //   k_sign_hash                                        last stage of the split signing path (schnorr_sig.rs:25-47)
 //   k_eddsa_prep                                       key expansion + deterministic nonce (curve.rs:74-87, eddsa_sig.rs:120-131)
 #include <hip/hip_runtime.h>
@@ -9,6 +10,7 @@
 // the two halves in kernels of their own each decodes once, inline — the call's stack frame was the kernels' 208 / 240 B
 // of scratch and the reason for their 248 VGPRs)
 #include "verify.h"
+#include "device_batch_invert.h"
 using namespace kyb;
 #include "device_tables.h"
 
@@ -102,6 +104,87 @@ k_verify_final(const uint4* __restrict__ proj, size_t stride, size_t n, const ui
   signal_done(df);
 }
 
+// ---- the equation without decoding R (large batches) ----------------------------------------------------------------------------
+// R + h A == s B holds iff the encoding of D = s B - h A is the 32 bytes of R: in both check orders a non-canonical R is rejected
+// before the equation is looked at, and the encoding of a curve point decodes.  So the 252-squaring square root of R's
+// decompression is only needed for signatures whose bytes do NOT match — to tell "R is not a point" (status 4) from "the equation
+// fails" (9) — and k_verify_fixup does it for exactly those; k_verify_prep_r (0.8 ms per 2^20) drops out of the common path.
+// D goes through the projective staging buffer: k_verify_diff overwrites record i (h A) with D, k_verify_final_enc encodes with one
+// field inversion per FINISH_K items (k_finish's scheme) and compares.
+constexpr uint8_t KYB_VERIFY_TODO = 0xff;
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_verify_diff(uint4* __restrict__ proj, size_t stride, size_t n) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  ge_p2 hA, sB, D;
+  load_proj_xy(hA.X, hA.Y, proj, stride, i);           load_proj_z(hA.Z, proj, stride, i);
+  load_proj_xy(sB.X, sB.Y, proj, stride, n + i);       load_proj_z(sB.Z, proj, stride, n + i);
+  ge_p3 H, S;
+  ge_p2_to_p3(H, hA);
+  ge_p2_to_p3(S, sB);
+  ge_cached c;
+  ge_p3_to_cached(c, H);
+  ge_cached_cneg(c, 1u);
+  ge_p1p1 t;
+  ge_add(t, S, c);
+  ge_p1p1_to_p2(D, t);
+  store_proj(proj, stride, i, D.X, D.Y, D.Z);
+}
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_verify_final_enc(const uint4* __restrict__ proj, size_t stride, size_t n, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ flags_a,
+                   int flavor, uint8_t* __restrict__ status) {
+  const size_t M = (n + FINISH_K - 1) / FINISH_K;
+  const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (j >= M) return;
+  auto load = [&](int t, fe& z) {
+    const size_t i = j + (size_t)t * M;
+    fe one;
+    fe_one(one);
+    if (i < n) load_proj_z(z, proj, stride, i); else fe_one(z);
+    fe_cmov(z, one, 1u - fe_is_nonzero(z));
+  };
+  auto emit = [&](int t, const fe& zinv) {
+    const size_t i = j + (size_t)t * M;
+    if (i >= n) return;
+    fe z, zi, zero, X, Y, x, y;
+    fe_zero(zero);
+    load_proj_z(z, proj, stride, i);
+    fe_copy(zi, zinv);
+    fe_cmov(zi, zero, 1u - fe_is_nonzero(z));
+    load_proj_xy(X, Y, proj, stride, i);
+    fe_mul(x, X, zi);
+    fe_mul(y, Y, zi);
+    uint32_t w[8], r[8];
+    fe_to_words(w, y);
+    w[7] ^= fe_is_negative(x) << 31;
+    load_words8(r, sigs, 2 * i);
+    uint32_t diff = 0;
+    for (int q = 0; q < 8; ++q) diff |= w[q] ^ r[q];
+    if (diff != 0) { status[i] = KYB_VERIFY_TODO; return; }
+    fe RY;
+    fe_from_words(RY, r);
+    const uint32_t fr = pt_is_canonical_w(r) | (1u << 1) | (pt_has_small_order(RY) << 2);      // R decodes: it is the encoding of D
+    status[i] = (uint8_t)verify_status(flags_a[i], fr, flavor);
+  };
+  fe unused_prefix, unused_inv;
+  fe_one(unused_prefix);
+  batch_invert<0, FINISH_K>(unused_prefix, unused_inv, load, emit);
+}
+// the signatures whose R bytes are not the encoding of s B - h A: the reference's first failing check, else 9 (equation)
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_verify_fixup(const uint8_t* __restrict__ sigs, size_t n, const uint8_t* __restrict__ flags_a, int flavor, uint8_t* __restrict__ status, kyb::launch::DoneFlag df) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  if (status[i] == KYB_VERIFY_TODO) {
+    uint32_t sig[16];
+    load_words8(sig, sigs, 2 * i);
+    load_words8(sig + 8, sigs, 2 * i + 1);
+    ge_p3 R;
+    const uint32_t st = verify_status(flags_a[i], verify_prep_r(R, sig), flavor);
+    status[i] = st == 0 ? (uint8_t)9 : (uint8_t)st;
+  }
+  signal_done(df);
+}
 
 namespace kyb { namespace launch {
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK); }
@@ -116,6 +199,17 @@ hipError_t verify_prep_r(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t*
 }
 hipError_t verify_final(hipStream_t st, const uint4* proj, size_t stride, size_t n, const uint8_t* flags_a, const uint8_t* flags_r, int flavor, uint8_t* status, DoneFlag df) {
   hipLaunchKernelGGL(k_verify_final, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, proj, stride, n, flags_a, flags_r, flavor, status, df);
+  return hipGetLastError();
+}
+hipError_t verify_tail_enc(hipStream_t st, uint4* proj, size_t stride, size_t n, const uint8_t* sigs, const uint8_t* flags_a, int flavor, uint8_t* status, DoneFlag df) {
+  const size_t M = (n + FINISH_K - 1) / FINISH_K;
+  hipLaunchKernelGGL(k_verify_diff, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, proj, stride, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_verify_final_enc, dim3(blocks_for(M)), dim3(KYB_BLOCK), 0, st, proj, stride, n, sigs, flags_a, flavor, status);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_verify_fixup, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sigs, n, flags_a, flavor, status, df);
   return hipGetLastError();
 }
 hipError_t sign_hash(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n,

@@ -85,6 +85,9 @@ hipError_t verify_prep(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs,
 hipError_t verify_prep_r(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* flags_r, uint4* proj, size_t stride, size_t offset);
 hipError_t verify_final(hipStream_t st, const uint4* proj, size_t stride, size_t n, const uint8_t* flags_a, const uint8_t* flags_r, int flavor, uint8_t* status,
                         DoneFlag df = DoneFlag{});
+// the equation of n verifications on encodings (h A at proj[i], s B at proj[n + i]; record i is overwritten): three launches
+hipError_t verify_tail_enc(hipStream_t st, uint4* proj, size_t stride, size_t n, const uint8_t* sigs, const uint8_t* flags_a, int flavor, uint8_t* status,
+                           DoneFlag df = DoneFlag{});
 hipError_t sign_hash(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n,
                      const uint8_t* r_enc, const uint8_t* a_enc, uint8_t* sig, DoneFlag df = DoneFlag{});
 hipError_t eddsa_prep(hipStream_t st, const uint8_t* seeds, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* xbuf, uint8_t* kbuf);

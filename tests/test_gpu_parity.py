@@ -306,13 +306,15 @@ def test_verify_matches_oracle(engine, oracle):
     for flavor in (0, 1):
         want = np.array([oracle.verify(flavor, *c) for c in cases], dtype=np.uint8)
         assert set(want.tolist()) >= {0, 2, 3, 4, 5, 6, 7, 8, 9}      # every reject reason is exercised
-        for overlap in (1, 0):                                         # s*B on the side stream / in line
+        for overlap, by_enc in ((1, 1), (0, 1), (1, 0), (0, 0)):       # s*B on the side stream / in line; equation on encodings / on points
             engine.set_option("verify.overlap", overlap)
+            engine.set_option("verify.by_encoding", by_enc)
             try:
                 for _ in range(3):                                     # back-to-back calls reuse the scratch of the one before
                     assert np.array_equal(engine.verify(pubs, msgs, sigs, flavor), want)
             finally:
                 engine.set_option("verify.overlap", 1)
+                engine.set_option("verify.by_encoding", 1)
     # all 1024 golden signatures verify; their messages are 0..1023 bytes long
     ps, ms, ss = [], [], []
     for ln in gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n"):
