@@ -212,6 +212,16 @@ def test_parity_suites_again_on_the_small_batch_kernels(coop_engine, oracle):
     P.test_lincomb_matches_oracle(eng, oracle)
     P.test_decode_encode_add_sub(eng, oracle)
     P.test_pubpoly_eval_and_equal(eng, oracle)
+    P.test_quirk_vectors(eng, oracle)
+    P.test_mul_from_encodings_and_invalid_points(eng, oracle)
+
+
+def test_structured_fuzz_on_the_small_batch_kernels(coop_engine, oracle):
+    """the 2^16 structured (scalar, point) pairs of tests/test_gpu_parity.py (bit runs, recoding extremes, multiples of L, torsion and
+    small-order points, the neutral element) through k_mul_base_coop and k_mul_coop: image, ladder, y-recovery and exceptional cases
+    in quads, every output against the oracle"""
+    import test_gpu_parity as P
+    P.test_structured_fuzz_against_oracle(coop_engine, oracle)
 
 
 def test_coop_and_batch_kernels_agree_at_the_threshold(engine, oracle):
