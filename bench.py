@@ -15,7 +15,8 @@ collective is the one-time RCCL broadcast of the base-point table image built on
 Rank 0 prints ONE JSON line.  `value` is whole-job items/s of the PRIMARY workload over the timed K steps
 (barrier + synchronize on both sides, max over ranks).  At N = 1 the other single-GPU configurations of
 BASELINE.json are then timed the same way, each in its own timed region OUTSIDE the primary one, and
-reported under `workloads` (value, ms_per_step, roofline, cpu_baseline, parity_checked_items each).
+reported under `workloads` (value, ms_per_step, roofline, cpu_baseline, parity_checked_items each), and `small_calls` gives the
+wall time of ONE synchronous host-pointer call with 1 / 64 items (what unmodified protocol code sees; a latency, not a throughput).
 
 `roofline` prices the dominant kernel against the v_mad_u64_u32 issue peak: the path is integer-VALU bound
 by construction (BASELINE.json north_star), not HBM or MFMA bound, so the object carries
@@ -270,6 +271,34 @@ def device_identity(torch, local):
     return ident
 
 
+def small_call_latency(eng, orc):
+    """What unmodified protocol code sees: ONE synchronous host-pointer call with 1 / 64 items (the one-item-per-wavefront kernels,
+    DESIGN.md section 4 "Small batches"), median wall time in microseconds, outputs checked against the oracle.  Not a throughput figure."""
+    import numpy as np
+    import synth as _s
+    s = _s.scalars(64, 71)
+    k = _s.scalars(64, 72, b"k")
+    enc, ext = eng.mul_base(s, want_ext=True)
+    msgs = _s.messages(64, 73)
+    sigs = eng.schnorr_sign(s, k, msgs)
+    assert np.array_equal(enc, orc.mul_base_batch(s)) and np.array_equal(sigs, orc.schnorr_sign_batch(s, k, msgs))
+    assert np.array_equal(eng.mul(k, pts_ext=ext), orc.mul_batch(k, ext)) and not eng.verify(enc, msgs, sigs, 1).any()
+
+    def med(fn, reps=100):
+        fn(); fn()
+        ts = []
+        for _ in range(reps):
+            a = time.perf_counter(); fn(); ts.append(time.perf_counter() - a)
+        return round(sorted(ts)[len(ts) // 2] * 1e6, 1)
+
+    out = {"unit": "us per host-pointer call (median of 100)", "checked_against_oracle": True}
+    for n in (1, 64):
+        out[f"n={n}"] = {"mul_base": med(lambda: eng.mul_base(s[:n])), "mul": med(lambda: eng.mul(k[:n], pts_ext=ext[:n])),
+                         "sign": med(lambda: eng.schnorr_sign(s[:n], k[:n], msgs[:n])), "verify": med(lambda: eng.verify(enc[:n], msgs[:n], sigs[:n], 1)),
+                         "decode": med(lambda: eng.decode(enc[:n])), "encode": med(lambda: eng.encode(ext[:n]))}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -382,6 +411,7 @@ def main():
                                "parity_checked_items": ochk}
                 del ow
             line["workloads"] = others
+            line["small_calls"] = small_call_latency(eng, orc)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
