@@ -719,6 +719,23 @@ def test_host_pointer_paths_agree(engine, oracle):
     assert np.array_equal(enc_m[idx], oracle.mul_batch(t[idx], ext[idx], nthreads=8))
 
 
+def test_large_pageable_input_of_an_unchunked_call(engine, oracle):
+    """kyb_sum_batch with 21.6 MB of pageable points: the input travels through the two page-locked bounce buffers in 8 MiB pieces
+    (engine.hip h2d: three pieces, both buffers reused).  sum_j s_j B == (sum_j s_j mod L) B ties the result to the fixed-base kernel."""
+    m, t = 3, 45000
+    s = synth.scalars(m * t, 123)
+    _, pts = engine.mul_base(s, want_ext=True)
+    ints = [int.from_bytes(bytes(r), "little") for r in s]
+    tot = np.frombuffer(b"".join((sum(ints[g * t:(g + 1) * t]) % synth.L).to_bytes(32, "little") for g in range(m)), dtype=np.uint8).reshape(m, 32)
+    want = engine.mul_base(tot)
+    assert want.tolist() == [list(oracle.mul_base_batch(tot[g:g + 1])[0]) for g in range(m)]
+    for _ in range(2):                                                     # twice: the bounce buffers and their events are reused
+        assert np.array_equal(engine.sum_points(pts.reshape(m, t, 40)), want)
+    # and a pinned caller buffer takes the direct path
+    pp = engine.pinned_array((m, t, 40), np.int32); pp[:] = pts.reshape(m, t, 40)
+    assert np.array_equal(engine.sum_points(pp), want)
+
+
 def test_bad_arguments_are_rejected(engine, oracle):
     """error behaviour of the C ABI (INTEGRATION.md §3): a bad call returns a negative code with a message and
     leaves the engine usable; nothing is written on error"""
