@@ -278,6 +278,8 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *                     polynomial evaluation; default 4096, 0 = never); coop.base_max_items the same for the fixed base and signing
  *                     (default 3072), coop.decode_max_items for a bare decode (default 1024), coop.verify_max_items for the
  *                     single-launch verification with three wavefronts per signature (default 512).  Same results either way.
+ *   poly.segments     PubPoly::eval of few evaluations: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never
+ *                     split the Horner chain, 2..32)
  *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder
  *   verify.by_encoding 1 (default): large batches test the equation as enc(s*B - h*A) == R bytes and decode R only on a mismatch
  *   host.copy_threads host threads that move pageable batches through the bounce buffers (0 = auto)

@@ -103,6 +103,7 @@ struct Ctx {
   std::atomic<int> opt_finish{1};             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
   std::atomic<int> opt_finish_min{1};         // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size; cross-check)
   std::atomic<int> opt_coop_max{4096};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 4096 and 6144, profiles/r02/coop_crossover.log)
+  std::atomic<int> opt_poly_segments{0};         // PubPoly::eval, small batches: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never split, 2..32)
   std::atomic<int> opt_verify_by_enc{1};         // large verification batches: compare the encoding of s*B - h*A with R's bytes, decode R only on a mismatch
   std::atomic<int> opt_coop_verify_max{512};     // verification: up to this many signatures take the single-launch kernel (three wavefronts each)
   std::atomic<int> opt_coop_decode_max{1024};    // unmarshal_binary alone: the same (crossover between 1024 and 2048)
@@ -1070,7 +1071,23 @@ int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* i
   int nbits = 1;
   while (nbits < 32 && ((uint64_t)max_index + 1) >> nbits) ++nbits;      // bit length of max x = max_index + 1
   if (n <= (size_t)g.opt_coop_max) {
-    // few evaluations: one per wavefront (kernels_coop.hip)
+    // few evaluations: one per wavefront (kernels_coop.hip); a long polynomial at very few indices: several wavefronts per evaluation.
+    // A segment costs its wavefront one 255-step multiplication (~26 Horner steps of a 10-bit index) on top of its share of the chain,
+    // and the segments of all evaluations should find idle SIMDs (2,048 wavefronts).
+    int segs = g.opt_poly_segments;
+    if (segs == 0) {
+      const size_t by_len = t / 24, by_room = 2048 / n;         // at most two wavefronts per SIMD: both still run near single-wavefront speed
+      segs = (int)(by_len < by_room ? by_len : by_room);
+      if (nbits <= 1) segs = 1;                              // x = 1: the chain is t additions, nothing to gain
+    }
+    if (segs > 32) segs = 32;
+    if (segs >= 2 && (size_t)segs <= t) {
+      const int len = (int)((t + (size_t)segs - 1) / (size_t)segs);
+      int rc = ensure_enc(g, r, 160 * n * (size_t)segs + 256); if (rc) return rc;
+      ProfScope ps(g, st, KID_POLY_EVAL_COOP);
+      LAUNCHCK(launch::poly_eval_seg(st, commits, (int)t, idx, n, per_poly, len, segs, reinterpret_cast<uint32_t*>(r->enc), oenc, oext, take_done_flag(g, st, n)));
+      return KYB_OK;
+    }
     ProfScope ps(g, st, KID_POLY_EVAL_COOP);
     LAUNCHCK(launch::poly_eval_coop(st, commits, (int)t, idx, n, nbits, per_poly, oenc, oext, take_done_flag(g, st, n)));
     return KYB_OK;

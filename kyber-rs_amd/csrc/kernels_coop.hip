@@ -13,6 +13,7 @@
 //   k_sign_coop       schnorr::sign in one launch, two wavefronts per signature: k B | x B, then hash and s = k + x h
 //   k_mul_enc_coop    Point::mul on a wire encoding, two wavefronts per item: ladder on y alone | square root for x
 //   k_verify_coop     one verification per workgroup of three wavefronts: hash + ladder | both decodes | s B, one barrier, one launch
+//   k_poly_eval_seg / k_poly_eval_sum   the same for a long polynomial: up to 32 wavefronts per evaluation, segments combined by x^(s len) mod 8L
 //   k_poly_eval_coop  PubPoly::eval             poly.rs:457-469 one evaluation per wavefront: Horner with cooperative doublings / additions
 // Used for batches that leave the chip idle (engine.hip: `coop.max_items`); results are bit-identical to the batch kernels.
 #include <hip/hip_runtime.h>
@@ -20,6 +21,7 @@
 #include "ge_scalarmult.h"
 #include "ge_ladder.h"
 #include "verify.h"
+#include "sc25519.h"
 #include "coop25519.h"
 using namespace kyb;
 using namespace kyb::coop;
@@ -344,25 +346,19 @@ __device__ __forceinline__ cq coop_dbl(const lane_consts& c, cq h) {
   return cmul4(c, (r0 || r3) ? X3 : (r1 ? Y3 : Z3), (r0 || r2) ? T3 : (r1 ? Z3 : Y3));      // (X3 T3, Y3 Z3, Z3 T3, X3 Y3)
 }
 
-// PubPoly::eval at one share index per wavefront: v = sum_j x^j C_j by Horner, x = index + 1 (public: the instruction stream
-// follows its bits), every point operation two cooperative levels.  The batch kernel (k_poly_eval, one evaluation per lane)
-// walks the same t (nbits + 1) point operations as ~150-instruction field multiplications of ONE lane; with a few thousand
-// evaluations or fewer this is what a DKG node's verify_deal pass looks like (vss.rs:904-909: n polynomials at its own index).
-__global__ void __launch_bounds__(64)
-k_poly_eval_coop(const int32_t* __restrict__ commits_ext, int t, const uint32_t* __restrict__ indices, size_t n, int nbits, size_t per_poly,
-                 uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, kyb::launch::DoneFlag df) {
-  const size_t i = blockIdx.x;
-  if (i >= n) return;
-  lane_consts c;
-  lane_consts_init(c);
-  const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(indices[i] + 1u));      // wave-uniform: the branches on its bits are scalar
-  const size_t first = per_poly ? (i / per_poly) * (size_t)t : 0;      // first commitment of this item's polynomial
+// sum_{j < count} x^j C_{first + j} by Horner (x >= 1 public and wave-uniform: the instruction stream follows its bits), every
+// point operation two cooperative levels.  Returns the extended point (X : Y : Z : T).
+__device__ __forceinline__ cq coop_horner(const lane_consts& c, const int32_t* __restrict__ commits_ext, size_t first, int count, uint32_t x) {
   const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
   cq v = (c.row == 1 || c.row == 2) ? ONE0 : 0u;                       // neutral element (0 : 1 : 1 : 0)
-  (void)nbits;
-  const int top = 31 - __builtin_clz(x | 1u);                           // x >= 1
+  const int top = 31 - __builtin_clz(x | 1u);
+  // coefficient j - 1 is fetched while step j computes (the operands of a small host-pointer call sit in page-locked HOST memory:
+  // ~1.5 us per dependent read over PCIe)
+  auto fetch = [&](int j) { return (c.active && j >= 0) ? (uint32_t)commits_ext[40 * (first + (size_t)j) + 10 * c.row + c.k] : 0u; };
+  uint32_t word = fetch(count - 1);
 #pragma unroll 1
-  for (int j = t - 1; j >= 0; --j) {
+  for (int j = count - 1; j >= 0; --j) {
+    const uint32_t word_next = fetch(j - 1);
     // v <- x v  (binary, most significant bit first; x = 1 leaves v alone)
     if (top > 0) {
       const cq vc = coop_to_cached(c, v);
@@ -375,11 +371,77 @@ k_poly_eval_coop(const int32_t* __restrict__ commits_ext, int t, const uint32_t*
       v = acc;
     }
     // v <- v + C_j
-    const uint32_t word = c.active ? (uint32_t)commits_ext[40 * (first + (size_t)j) + 10 * c.row + c.k] : 0u;
     const cq C = cnorm(c, c.active ? word + (c.p2 << 3) : 0u);         // fe_from_ref10: signed limb + 16p, one carry pass
     v = coop_add(c, v, coop_to_cached(c, C));
+    word = word_next;
   }
+  return v;
+}
+
+// PubPoly::eval at one share index per wavefront: v = sum_j x^j C_j, x = index + 1.  The batch kernel (k_poly_eval, one evaluation
+// per lane) walks the same t (nbits + 1) point operations as ~150-instruction field multiplications of ONE lane; with a few thousand
+// evaluations or fewer this is what a DKG node's verify_deal pass looks like (vss.rs:904-909: n polynomials at its own index).
+__global__ void __launch_bounds__(64)
+k_poly_eval_coop(const int32_t* __restrict__ commits_ext, int t, const uint32_t* __restrict__ indices, size_t n, int nbits, size_t per_poly,
+                 uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, kyb::launch::DoneFlag df) {
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  lane_consts c;
+  lane_consts_init(c);
+  const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(indices[i] + 1u));      // wave-uniform: the branches on its bits are scalar
+  const size_t first = per_poly ? (i / per_poly) * (size_t)t : 0;      // first commitment of this item's polynomial
+  (void)nbits;
+  const cq v = coop_horner(c, commits_ext, first, t, x);
   coop_finish(c, v, 0u, out_enc, out_ext, i);
+  if (c.lane == 0) signal_done(df);
+}
+
+// The same for ONE long polynomial and few evaluations: the Horner chain of t steps is cut into `segs` segments of `len`
+// coefficients, one wavefront (and workgroup: the wavefronts of one workgroup would share a CU's four SIMDs) each:
+//     P(x) = sum_s x^(s len) Q_s(x),   Q_s(x) = sum_{j < len} x^j C_{s len + j}.
+// Wavefront s evaluates Q_s by Horner with the small multiplier x and then multiplies it by x^(s len), reduced mod 8L
+// (sc_pow_mod8L_signed: the commitments may carry small-order components, mod L alone would not be exact) — the variable-base
+// ladder of k_mul_coop with its image and recovery in quads — and leaves the extended point in `part`; k_poly_eval_sum adds an
+// evaluation's partial results up and encodes.  The chain per wavefront is len (bits(x) + 1) point operations + one
+// multiplication (~26 Horner steps of a 10-bit index) instead of t (bits(x) + 1).
+__global__ void __launch_bounds__(64)
+k_poly_eval_seg(const int32_t* __restrict__ commits_ext, int t, const uint32_t* __restrict__ indices, size_t n, size_t per_poly, int len, int segs,
+                uint32_t* __restrict__ part) {
+  const size_t b = blockIdx.x;
+  if (b >= n * (size_t)segs) return;
+  const size_t i = b / (size_t)segs;
+  const int sg = (int)(b % (size_t)segs);
+  lane_consts c;
+  lane_consts_init(c);
+  const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(indices[i] + 1u));
+  const size_t first = per_poly ? (i / per_poly) * (size_t)t : 0;
+  const int lo = sg * len, cnt = lo >= t ? 0 : (t - lo < len ? t - lo : len);
+  cq q = coop_horner(c, commits_ext, first + (size_t)lo, cnt, x);       // (cnt == 0: the neutral element)
+  if (sg > 0 && cnt > 0) {
+    uint32_t mag[8], neg;
+    sc_pow_mod8L_signed(mag, neg, x, (uint32_t)lo);
+    uint32_t p_flags;
+    const cq M = coop_mont_prep(c, q, p_flags);
+    cq SX, SZ;
+    coop_ladder_run(c, mag, 1, M, SX, SZ);                               // |multiplier| < 4L < 2^255
+    const cq R = coop_mont_recover(c, M, SX, SZ, p_flags, mag[0] & 1u, neg);
+    // (X : Y : Z) -> extended (X Z : Y Z : Z^2 : X Y)
+    const cq zz = bperm(rowperm_idx(c, 2, 2, 2, 2), R), xy = bperm(rowperm_idx(c, 0, 1, 2, 0), R), yy = bperm(rowperm_idx(c, 1, 1, 1, 1), R);
+    q = cmul4(c, xy, c.row == 3 ? yy : zz);
+  }
+  if (c.active) part[b * 40 + 10 * c.row + c.k] = q;
+}
+__global__ void __launch_bounds__(64)
+k_poly_eval_sum(const uint32_t* __restrict__ part, size_t n, int segs, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, kyb::launch::DoneFlag df) {
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  lane_consts c;
+  lane_consts_init(c);
+  auto load = [&](int sg) { return c.active ? part[(i * (size_t)segs + (size_t)sg) * 40 + 10 * c.row + c.k] : 0u; };
+  cq q = load(0);
+#pragma unroll 1
+  for (int sg = 1; sg < segs; ++sg) q = coop_add(c, q, coop_to_cached(c, load(sg)));
+  coop_finish(c, q, 0u, out_enc, out_ext, i);
   if (c.lane == 0) signal_done(df);
 }
 
@@ -806,6 +868,14 @@ hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, 
 hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, int flavor,
                        const uint32_t* image64, uint8_t* status, DoneFlag df) {
   hipLaunchKernelGGL(k_verify_coop, dim3((unsigned)n), dim3(192), 0, st, pubs, sigs, msgs, off, n, flavor, image64, status, df);
+  return hipGetLastError();
+}
+hipError_t poly_eval_seg(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, size_t per_poly, int len, int segs,
+                         uint32_t* part, uint8_t* oenc, int32_t* oext, DoneFlag df) {
+  hipLaunchKernelGGL(k_poly_eval_seg, dim3((unsigned)(n * (size_t)segs)), dim3(64), 0, st, commits, t, idx, n, per_poly, len, segs, part);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_poly_eval_sum, dim3((unsigned)n), dim3(64), 0, st, part, n, segs, oenc, oext, df);
   return hipGetLastError();
 }
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,

@@ -68,6 +68,9 @@ hipError_t sign_coop(hipStream_t st, const uint8_t* x, const uint8_t* k, const u
 hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, DoneFlag df = DoneFlag{});
 hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, int flavor,
                        const uint32_t* image64, uint8_t* status, DoneFlag df = DoneFlag{});
+// segs wavefronts (2..32) per evaluation, len coefficients each (segs * len >= t); part: n * segs * 40 words of device scratch
+hipError_t poly_eval_seg(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, size_t per_poly, int len, int segs,
+                         uint32_t* part, uint8_t* oenc, int32_t* oext, DoneFlag df = DoneFlag{});
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
                     uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, DoneFlag df = DoneFlag{}, size_t pt_mod = 0);
 // proj != nullptr: projective staging record i * src_mul, else the 40 reference limbs of point i

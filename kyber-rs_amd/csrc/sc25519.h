@@ -113,6 +113,50 @@ KYB_HD void sc_muladd(uint32_t out[8], const uint32_t a[8], const uint32_t b[8],
   }
   sc_reduce544(out, x);
 }
+// x^e as a multiplier of curve points: a point's order divides 8L (cofactor 8), so the integer x^e may be replaced by any
+// representative of x^e mod 8L — mod L alone would change the result on points with a small-order component, which the reference's
+// exact Horner evaluation (poly.rs:457-469) treats like any other.  Returns the representative of smallest magnitude, |v| < 4L
+// < 2^255 (below the top-digit quirk of the multiplication routines), as (mag, neg).  x^e mod L by square-and-multiply on
+// sc_muladd, x^e mod 8 in machine arithmetic, recombined with L^-1 = 5 (mod 8).
+KYB_HD void sc_pow_mod8L_signed(uint32_t mag[8], uint32_t& neg, uint32_t x, uint32_t e) {
+  const uint32_t Lw[8] = {0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0u, 0u, 0u, 0x10000000u};
+  uint32_t a[8] = {1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, xs[8] = {x, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  const uint32_t zero[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  uint32_t b = 1u;
+  int top = 31;
+  while (top > 0 && !((e >> top) & 1u)) --top;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int i = top; i >= 0; --i) {
+    uint32_t t[8];
+    sc_muladd(t, a, a, zero);
+    KYB_UNROLL for (int j = 0; j < 8; ++j) a[j] = t[j];
+    b = (b * b) & 7u;
+    if ((e >> i) & 1u) {
+      sc_muladd(t, a, xs, zero);
+      KYB_UNROLL for (int j = 0; j < 8; ++j) a[j] = t[j];
+      b = (b * x) & 7u;
+    }
+  }
+  // v = a + k L with v = b (mod 8):  k = 5 (b - a) mod 8
+  const uint32_t k = (5u * ((b - a[0]) & 7u)) & 7u;
+  uint32_t v[8], kl[8];
+  {
+    uint64_t c = 0;
+    KYB_UNROLL for (int j = 0; j < 8; ++j) { c += (uint64_t)Lw[j] * k; kl[j] = (uint32_t)c; c >>= 32; }      // k L < 8L < 2^256
+  }
+  mw_add<8>(v, a, kl);
+  uint32_t l4[8], l8[8], d[8];
+  KYB_UNROLL for (int j = 7; j >= 0; --j) {
+    l4[j] = (Lw[j] << 2) | (j ? Lw[j - 1] >> 30 : 0u);
+    l8[j] = (Lw[j] << 3) | (j ? Lw[j - 1] >> 29 : 0u);
+  }
+  const uint32_t below = mw_sub<8>(d, v, l4);          // borrow: v < 4L
+  mw_sub<8>(d, l8, v);                                  // 8L - v
+  neg = 1u - below;
+  KYB_UNROLL for (int j = 0; j < 8; ++j) mag[j] = below ? v[j] : d[j];
+}
 // out = x mod L for a 512-bit little-endian x (Scalar::set_bytes on a SHA-512 digest)
 KYB_HD void sc_reduce512(uint32_t out[8], const uint32_t x16[16]) {
   uint32_t x[17];

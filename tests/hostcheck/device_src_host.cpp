@@ -28,6 +28,12 @@ static void load_words(uint32_t w[8], const uint8_t* b) { memcpy(w, b, 32); }
 
 extern "C" {
 long hd_overflows() { return g_overflows.load(); }
+void hd_sc_pow_mod8L(uint32_t x, uint32_t e, uint8_t mag_out[32], uint32_t* neg_out) {
+  uint32_t mag[8], neg;
+  sc_pow_mod8L_signed(mag, neg, x, e);
+  memcpy(mag_out, mag, 32);
+  *neg_out = neg;
+}
 const uint32_t* hd_base_table() { ensure_table(); return g_base_table.data(); }
 
 void hd_mul_base(uint8_t out[32], const uint8_t scalar[32]) {

@@ -157,6 +157,24 @@ def test_decode_encode_add(hd, oracle):
     assert hd.hd_overflows() == base
 
 
+def test_power_of_a_share_index_mod_8L(hd):
+    """sc_pow_mod8L_signed (the multipliers of the segmented polynomial evaluation): x^e mod 8L as the signed representative of
+    smallest magnitude, against Python integers; even and odd x, exponents 0 .. 2^24"""
+    import ctypes
+    import random
+    L = 2**252 + 27742317777372353535851937790883648493
+    rnd = random.Random(8)
+    cases = [(1, 0), (1, 5), (2, 1), (2, 2), (2, 3), (2, 300), (4, 2), (6, 3), (3, 1), (7, 682), (1024, 683), (513, 341), (0xffffffff, 1), (0xffffffff, 0xffffff)]
+    cases += [(rnd.randrange(1, 1 << 32), rnd.randrange(0, 1 << 24)) for _ in range(60)] + [(rnd.randrange(1, 2000), rnd.randrange(0, 2000)) for _ in range(60)]
+    for x, e in cases:
+        mag = ctypes.create_string_buffer(32)
+        neg = ctypes.c_uint32(7)
+        hd.hd_sc_pow_mod8L(ctypes.c_uint32(x), ctypes.c_uint32(e), mag, ctypes.byref(neg))
+        v = int.from_bytes(mag.raw, "little")
+        assert v < 4 * L + 1 and neg.value in (0, 1), (x, e)
+        assert ((-v if neg.value else v) - pow(x, e, 8 * L)) % (8 * L) == 0, (x, e)
+
+
 def test_scalar_mod_l_and_sha512(hd):
     rnd = random.Random(5)
     edge = [bytes(32), bytes([255] * 32), M.L.to_bytes(32, "little"), (M.L - 1).to_bytes(32, "little")]

@@ -162,6 +162,29 @@ def test_coop_pubpoly_eval_matches_oracle(coop_engine, oracle):
             assert bytes(multi[p, q]) == oracle.pubpoly_eval(polys[p], int(ii[p, q]))
     one = eng.pubpoly_eval(commits[:1], idx[:3])                   # degree 0
     assert all(bytes(o) == oracle.encode(commits[0]) for o in one)
+    # several wavefronts per evaluation: the chain cut into segments, recombined with x^(s len) mod 8L — exact on the commitments with
+    # small-order components too (mod L would not be)
+    want = [oracle.pubpoly_eval(commits, int(i)) for i in idx]
+    try:
+        for segs in (2, 3, 4, 8, 9):
+            eng.set_option("poly.segments", segs)
+            assert [bytes(g) for g in eng.pubpoly_eval(commits, idx)] == want, segs
+            multi = eng.pubpoly_eval_multi(polys, ii)
+            assert all(bytes(multi[p, q]) == oracle.pubpoly_eval(polys[p], int(ii[p, q])) for p in range(3) for q in range(2))
+    finally:
+        eng.set_option("poly.segments", 0)
+    # a longer polynomial, segments chosen by the engine (t = 150 -> 6 wavefronts per evaluation), and the maximum of 32
+    t2 = 150
+    long_c = oracle.mul_base_ext_batch(synth.scalars(t2, 901, b"coef"))
+    long_c[17] = oracle.add(long_c[17], weak[3]); long_c[149] = oracle.add(long_c[149], weak[4]); long_c[75] = weak[1]
+    for i in (1, 6, 1000, 65535):
+        assert bytes(eng.pubpoly_eval(long_c, np.array([i], dtype=np.uint32))[0]) == oracle.pubpoly_eval(long_c, i), i
+    eng.set_option("poly.segments", 32)
+    try:
+        i3 = np.array([5, 77, 4000], dtype=np.uint32)
+        assert [bytes(g) for g in eng.pubpoly_eval(long_c, i3)] == [oracle.pubpoly_eval(long_c, int(i)) for i in i3]
+    finally:
+        eng.set_option("poly.segments", 0)
 
 
 def test_coop_single_launch_signing(coop_engine, oracle):

@@ -12,7 +12,7 @@ msgs = [b"m" * 32] * 64
 sigs = eng.schnorr_sign(s, np.roll(s, 1, axis=0).copy(), msgs)
 
 
-def t(fn, reps=200):
+def t(fn, reps=60):
     fn(); fn()
     ts = []
     for _ in range(reps):
@@ -26,6 +26,7 @@ for name, fn in (("encode", lambda n: eng.encode(ext[:n])), ("decode", lambda n:
                  ("mul(ext)", lambda n: eng.mul(s[:n], pts_ext=ext[:n])), ("mul(enc)", lambda n: eng.mul(s[:n], pts_enc=enc[:n])),
                  ("sign", lambda n: eng.schnorr_sign(s[:n], s[:n], msgs[:n])), ("verify", lambda n: eng.verify(enc[:n], msgs[:n], sigs[:n], 1)),
                  ("pubpoly_eval(t=8)", lambda n: eng.pubpoly_eval(ext[:8], np.arange(n, dtype=np.uint32))),
+                 ("pubpoly_eval(t=683, index 512)", lambda n: eng.pubpoly_eval(np.tile(ext, (11, 1))[:683], np.full(n, 512, dtype=np.uint32))),
                  ("sum(t=8)", lambda n: eng.sum_points(np.tile(ext[None, :8], (n, 1, 1)))),
                  ("lincomb(t=8)", lambda n: eng.lincomb(np.tile(s[None, :8], (n, 1, 1)), pts_ext=np.tile(ext[None, :8], (n, 1, 1))))):
     print(f"{name}, {t(lambda: fn(1)):.1f}, {t(lambda: fn(64)):.1f}", flush=True)
