@@ -1,4 +1,4 @@
-// Fixed-base kernels of the MI355X Ed25519 engine (one of the five translation units, see launch.h).
+// Fixed-base kernels of the MI355X Ed25519 engine (one of the translation units mapped in launch.h).
 //   k_base_table / 32 / 64   build the LDS table images on the GPU at init (role of constants.rs:89 BASE)
 //   k_table_checksum         checksum embedded in / checked against an image that travelled between GPUs
 //   k_mul_base64             Point::mul(s, None)  ge.rs:442-486   42x32+16 affine table = the whole LDS (163,200 B), batches

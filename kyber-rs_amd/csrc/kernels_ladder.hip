@@ -1,4 +1,4 @@
-// Variable-base kernels of the MI355X Ed25519 engine (one of the five translation units, see launch.h).
+// Variable-base kernels of the MI355X Ed25519 engine (one of the translation units mapped in launch.h).
 //   k_decode_or_identity   unmarshal_binary of the operands (ge.rs:124-179), failed decodes -> neutral element
 //   k_mont_prep            Montgomery images of the operands, one field inversion per FINISH_K items
 //   k_mul_ladder           Point::mul(s, Some(P))  ge.rs:508-568   Montgomery ladder + y-recovery (ge_ladder.h)

@@ -1,4 +1,4 @@
-// Remaining kernels of the MI355X Ed25519 engine (one of the five translation units, see launch.h).
+// Remaining kernels of the MI355X Ed25519 engine (one of the translation units mapped in launch.h).
 //   k_finish            batched inversion + encode of projective staging records (ge.rs:112-122)
 //   k_encode_batched    marshal_binary of extended points with the same shared inversion (point.rs:35-41)
 //   k_add / k_equal / k_encode / k_decode   point.rs:179-241 / 35-51

@@ -1,4 +1,4 @@
-// SHA-512 users of the MI355X Ed25519 engine (one of the five translation units, see launch.h).
+// SHA-512 users of the MI355X Ed25519 engine (one of the translation units mapped in launch.h).
 //   k_verify_prep / k_verify_prep_r / k_verify_final   eddsa_sig.rs:159-212, schnorr_sig.rs:53-110 (verify.h)
 //   k_verify_diff / k_verify_final_enc / k_verify_fixup   the same equation checked on encodings: R is decoded only when it fails
 //   k_sign_hash                                        last stage of the split signing path (schnorr_sig.rs:25-47)
