@@ -9,21 +9,23 @@
 //
 //   quad (`cq`)    one VGPR: row r = lanes 16r .. 16r+15 holds limbs 0..9 of element r in its first ten lanes; lanes 10..15 of a row
 //                  are DON'T-CARE (nothing an active lane computes ever depends on them)
-//   cmul4(F, G)    four products F_r * G_r.  Lane k forms column k: sum_i f_i * g_{(k-i) mod 10} * m(i,k), with f_i broadcast
-//                  inside the row by DPP (v_mov_b32 row_newbcast:i — no LDS round trip), g rotated inside the row by
-//                  ds_bpermute_b32 (a rotation mod 10 is not a DPP pattern; the nine of them are in flight while the VALU does
-//                  the broadcasts), and the 2x / 19x / 38x factors of the radix-2^25.5 product (fe25519.h) as the per-lane
-//                  constant m(i,k) applied to the broadcast f_i — so F must be TIGHT (<= 1.01T: 38 f_i < 2^32), G may be lazy
-//                  (<= 4T).  Carries travel between NEIGHBOURING lanes, i.e. by DPP row shifts (row_shr:1 / row_shr:2; the
-//                  wrap from limbs 8, 9 to limbs 0, 1 by row_shl:8 / row_shl:9 times 19): a three-way split of the 64-bit column
-//                  (own limb / next limb / limb after that) and one more light pass.  No LDS traffic in the carries at all —
-//                  round 2 measured the dependent ds_bpermute round trips (~64 cycles each) as most of a lone wavefront's time.
+//   cmul4(F, G)    four products F_r * G_r.  Lane k forms column k: sum_i f_i * g_{(k-i) mod 10} * m(i,k) with the 2x / 19x / 38x factors
+//                  m(i,k) of the radix-2^25.5 product (fe25519.h).  Both operands travel through a per-wavefront scratch in LDS MEMORY
+//                  (320 words): F is stored in four scaled copies (x1, x2, x19, x38 — so F must be TIGHT, <= 1.01T: 38 f < 2^32; G may be
+//                  lazy, <= 4T), lane k reads term i's f from the copy that carries m(i,k) at a per-lane constant address, and g_i by a
+//                  broadcast read of its row.  That is 5 ds_write + 20 ds_read and, in the VALU stream, 3 instructions for the copies,
+//                  10 multiply-adds and the carries.  LDS instructions of one wavefront execute in order, so no barrier is needed; a lone
+//                  wavefront pays ~6 cycles per VALU instruction and far less per LDS instruction (tools/coop_primitive_times.py: 277
+//                  cycles against 383 for the version that broadcast by DPP, rotated by ds_bpermute and multiplied the factors in).
+//                  Carries travel between NEIGHBOURING lanes, i.e. by DPP row shifts (row_shr:1 / row_shr:2; the wrap from limbs 8, 9 to
+//                  limbs 0, 1 by row_shl:8 / row_shl:9 times 19): a three-way split of the 64-bit column (own limb / next limb / limb
+//                  after that) and one more light pass.
 //   cnorm(V)       that light pass alone: any limbs < 2^31 -> tight
 //   rows are moved with ds_bpermute_b32 and per-lane index constants; additions are ONE instruction for four elements.
 //
-// Measured for ONE wavefront on an idle chip (tools/coop_primitive_times.py, profiles/r02/coop_primitive_times.log): cmul4 368
-// cycles, csq4 309, cnorm 45, a ds_bpermute round trip 45, one ladder step (three levels) 1450, one mixed addition (two
-// levels) 1070 — about 6 cycles per instruction whatever its kind: a lone wavefront is bound by its instruction count.
+// Measured for ONE wavefront on an idle chip (tools/coop_primitive_times.py, profiles/r02/coop_primitive_times.log): a lone wavefront
+// pays ~6 cycles per VALU instruction whatever it does, ~45 for a dependent ds_bpermute round trip, and little for LDS reads and
+// writes that are issued in a block — which is why the operands of the products live in LDS memory.
 //
 // Same limb format and bounds notation as fe25519.h; results are bit-identical to the one-lane code (tests compare both
 // paths with the oracle).  Constant time: the instruction stream and every lane index are independent of secret data except
@@ -47,13 +49,14 @@ struct lane_consts {
   uint32_t mask_next;             // of limb k+1 (mod 10)
   uint32_t p2;                    // limb k of 2p (0 in inactive lanes)
   uint32_t w19a, w19b;            // 19 where the carry from limb k-1 / k-2 crosses the wrap (k == 0 / k < 2), else 0
-  int ridx[10];                   // byte index of lane (k - i) mod 10 of the same row
-  uint32_t mfac[10];              // m(i, k) in {1, 2, 19, 38}; 0 in inactive lanes
-  int sqa[6], sqb[6];             // csq4: byte indices of limbs a_t = ceil(k/2) + t and b_t = floor(k/2) - t (mod 10) of the same row
-  uint32_t sqfac[6];              // csq4: factor of term t on the a side (see csq4); 0 in inactive lanes and for the one duplicate
+  uint32_t* wlds;                 // this wavefront's 384-word scratch in LDS (KYB_COOP_LDS_WORDS)
+  int mf[10];                     // cmul4: word index of term i's first-operand limb, in the copy carrying m(i, k) (copies at 0 / 64 / 128 / 192)
+  int mg;                         // cmul4: word index of limb 0 of this row's second operand (slot at 256)
+  int sqa[6], sqb[6];             // csq4: word indices of limbs a_t = ceil(k/2) + t (in the copy carrying its factor) and b_t = floor(k/2) - t (x1 or x2)
 };
 
-__device__ __forceinline__ void lane_consts_init(lane_consts& c) {
+constexpr int KYB_COOP_LDS_WORDS = 384;
+__device__ __forceinline__ void lane_consts_init(lane_consts& c, uint32_t* wlds) {
   const uint32_t p2v[10] = KYB_FE_2P;
   c.lane = threadIdx.x & 63u;
   c.row = c.lane >> 4;
@@ -69,22 +72,25 @@ __device__ __forceinline__ void lane_consts_init(lane_consts& c) {
   c.w19a = c.k == 0u ? 19u : 0u;
   c.w19b = c.k < 2u ? 19u : 0u;
   const uint32_t base = c.row << 4;
+  c.wlds = wlds;
+  auto copy_of = [](uint32_t factor) { return factor == 1u ? 0u : (factor == 2u ? 64u : (factor == 19u ? 128u : (factor == 38u ? 192u : 320u))); };      // 320: zeros
   KYB_UNROLL for (int i = 0; i < 10; ++i) {
-    const uint32_t j = (k + 10u - (uint32_t)i) % 10u;               // g index of term i in column k
-    c.ridx[i] = c.active ? (int)((base + j) << 2) : (int)(c.lane << 2);
-    const uint32_t wrap = (uint32_t)i > k;                              // i + j >= 10
-    const uint32_t oo = ((uint32_t)i & 1u) & (j & 1u);
-    c.mfac[i] = c.active ? ((wrap ? 19u : 1u) * (oo ? 2u : 1u)) : 0u;
+    // column k, term i: g_i (broadcast) times f_j, j = (k - i) mod 10, times m = 19 if i + j >= 10, 2 if i and j odd
+    const uint32_t j = (k + 10u - (uint32_t)i) % 10u;
+    const uint32_t wrap = (uint32_t)i > k, oo = ((uint32_t)i & 1u) & (j & 1u);
+    c.mf[i] = (int)(copy_of((wrap ? 19u : 1u) * (oo ? 2u : 1u)) + base + j);
   }
+  c.mg = (int)(256u + base);
   KYB_UNROLL for (int t = 0; t < 6; ++t) {
     const uint32_t a = ((k + 1u) / 2u + (uint32_t)t) % 10u, b = (k / 2u + 10u - (uint32_t)t) % 10u;       // a + b = k (mod 10)
-    c.sqa[t] = c.active ? (int)((base + a) << 2) : (int)(c.lane << 2);
-    c.sqb[t] = c.active ? (int)((base + b) << 2) : (int)(c.lane << 2);
     const uint32_t wrap = a + b >= 10u, oo = (a & 1u) & (b & 1u);
     const uint32_t dup = (t == 5) & (k & 1u);                         // odd k: {a_5, b_5} = {a_4, b_4}
-    const uint32_t twice0 = (t == 0) & (k & 1u);                      // t = 0, odd k: a proper pair, counted twice here (no wrap, never both odd)
-    c.sqfac[t] = (c.active && !dup) ? ((wrap ? 19u : 1u) * (oo ? 2u : 1u) * (twice0 ? 2u : 1u)) : 0u;
+    const uint32_t twice0 = (t == 0) & (k & 1u);                      // t = 0, odd k: a proper pair, counted twice on the a side (no wrap, never both odd)
+    const uint32_t fac = (c.active && !dup) ? ((wrap ? 19u : 1u) * (oo ? 2u : 1u) * (twice0 ? 2u : 1u)) : 0u;
+    c.sqa[t] = (int)(copy_of(fac) + base + a);
+    c.sqb[t] = (int)(((t >= 1 && t <= 4) ? 64u : 0u) + base + b);    // the pair's 2 rides on b in steps 1..4
   }
+  if (c.lane < 64u) wlds[320 + c.lane] = 0u;                            // the zero words a duplicate term reads
 }
 
 __device__ __forceinline__ cq bperm(int idx, cq v) { return (cq)__builtin_amdgcn_ds_bpermute(idx, (int)v); }
@@ -125,44 +131,43 @@ __device__ __forceinline__ cq ccarry(const lane_consts& c, uint64_t s) {
   return cnorm(c, v);                                        // v < 2^26 + 19 * 2^26 + 20 * 2^13
 }
 
-// The ten rotations of a second operand G (<= 4T): g[i] in lane k = limb (k - i) mod 10 of the same row.  Nine ds_bpermute; a
-// caller that has G early issues them early and hides the LDS round trip behind other work.
-struct crot { uint32_t g[10]; };
-__device__ __forceinline__ crot crot_make(const lane_consts& c, cq G) {
-  crot r;
-  r.g[0] = G;
-  KYB_UNROLL for (int i = 1; i < 10; ++i) r.g[i] = bperm(c.ridx[i], G);
-  return r;
+// four products F_r * G_r; F tight, G <= 4T
+__device__ __forceinline__ cq cmul4(const lane_consts& c, cq F, cq G) {
+  uint32_t* w = c.wlds;
+  const uint32_t f19 = F * 19u;
+  w[c.lane] = F;
+  w[64 + c.lane] = F + F;
+  w[128 + c.lane] = f19;
+  w[192 + c.lane] = f19 + f19;
+  w[256 + c.lane] = G;
+  __builtin_amdgcn_wave_barrier();                          // (compiler ordering only: the LDS queue of a wavefront is in order)
+  uint32_t fm[10], gb[10];
+  KYB_UNROLL for (int i = 0; i < 10; ++i) { gb[i] = w[c.mg + i]; fm[i] = w[c.mf[i]]; }
+  __builtin_amdgcn_wave_barrier();
+  uint64_t acc = (uint64_t)gb[0] * fm[0];
+  KYB_UNROLL for (int i = 1; i < 10; ++i) acc += (uint64_t)gb[i] * fm[i];
+  return ccarry(c, c.active ? acc : 0ull);
 }
-// four products F_r * G_r; F tight, G given by its rotations
-__device__ __forceinline__ cq cmul4r(const lane_consts& c, cq F, const crot& G) {
-  uint32_t fb[10];
-  fb[0] = dpp0<KYB_DPP_ROW_BCAST(0)>(F); fb[1] = dpp0<KYB_DPP_ROW_BCAST(1)>(F); fb[2] = dpp0<KYB_DPP_ROW_BCAST(2)>(F);
-  fb[3] = dpp0<KYB_DPP_ROW_BCAST(3)>(F); fb[4] = dpp0<KYB_DPP_ROW_BCAST(4)>(F); fb[5] = dpp0<KYB_DPP_ROW_BCAST(5)>(F);
-  fb[6] = dpp0<KYB_DPP_ROW_BCAST(6)>(F); fb[7] = dpp0<KYB_DPP_ROW_BCAST(7)>(F); fb[8] = dpp0<KYB_DPP_ROW_BCAST(8)>(F);
-  fb[9] = dpp0<KYB_DPP_ROW_BCAST(9)>(F);
-  uint64_t acc = (uint64_t)(fb[0] * c.mfac[0]) * G.g[0];
-  KYB_UNROLL for (int i = 1; i < 10; ++i) acc += (uint64_t)(fb[i] * c.mfac[i]) * G.g[i];      // (two interleaved chains measured no faster)
-  return ccarry(c, acc);
-}
-// four products; F tight, G <= 4T
-__device__ __forceinline__ cq cmul4(const lane_consts& c, cq F, cq G) { return cmul4r(c, F, crot_make(c, G)); }
 // four squares F_r^2, F tight; bit-identical to cmul4(c, F, F) (the same column sums) with the symmetric terms taken once:
 // column k = sum over the unordered pairs {a, b}, a + b = k (mod 10), of f_a f_b m(a, b) x (2 if a != b).  Step t = 0..5 takes
 // a = ceil(k/2) + t, b = floor(k/2) - t: for even k the steps 0 and 5 are the two squares and 1..4 the four pairs; for odd k
-// 0..4 are the five pairs and step 5 repeats step 4 (factor 0).  The pair's 2 rides on b (read from 2F) in steps 1..4 and on
-// the a-side factor in step 0 (where nothing wraps), so every a-side factor stays <= 38.  6 + 6 multiplications instead of
-// 10 + 10 and no DPP broadcasts; the twelve operand fetches are ds_bpermutes, which cost LDS time, not VALU issue slots.
+// 0..4 are the five pairs and step 5 repeats step 4 (read from the zero words).  The pair's 2 rides on b (read from the x2 copy)
+// in steps 1..4 and on the a side in step 0 (where nothing wraps), so every a-side factor is one of 1, 2, 19, 38: 6
+// multiply-adds instead of 10, 4 ds_write + 12 ds_read.
 __device__ __forceinline__ cq csq4(const lane_consts& c, cq F) {
-  const cq F2 = F + F;
+  uint32_t* w = c.wlds;
+  const uint32_t f19 = F * 19u;
+  w[c.lane] = F;
+  w[64 + c.lane] = F + F;
+  w[128 + c.lane] = f19;
+  w[192 + c.lane] = f19 + f19;
+  __builtin_amdgcn_wave_barrier();
   uint32_t fa[6], fb[6];
-  KYB_UNROLL for (int t = 0; t < 6; ++t) fa[t] = bperm(c.sqa[t], F);
-  fb[0] = bperm(c.sqb[0], F);
-  KYB_UNROLL for (int t = 1; t < 5; ++t) fb[t] = bperm(c.sqb[t], F2);
-  fb[5] = bperm(c.sqb[5], F);
-  uint64_t acc = (uint64_t)(fa[0] * c.sqfac[0]) * fb[0];
-  KYB_UNROLL for (int t = 1; t < 6; ++t) acc += (uint64_t)(fa[t] * c.sqfac[t]) * fb[t];
-  return ccarry(c, acc);
+  KYB_UNROLL for (int t = 0; t < 6; ++t) { fa[t] = w[c.sqa[t]]; fb[t] = w[c.sqb[t]]; }
+  __builtin_amdgcn_wave_barrier();
+  uint64_t acc = (uint64_t)fa[0] * fb[0];
+  KYB_UNROLL for (int t = 1; t < 6; ++t) acc += (uint64_t)fa[t] * fb[t];
+  return ccarry(c, c.active ? acc : 0ull);
 }
 
 // element-wise on four elements at once

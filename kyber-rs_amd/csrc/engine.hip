@@ -102,12 +102,12 @@ struct Ctx {
   std::atomic<int> opt_ladder_waves{3};       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
   std::atomic<int> opt_finish{1};             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
   std::atomic<int> opt_finish_min{1};         // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size; cross-check)
-  std::atomic<int> opt_coop_max{4096};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 4096 and 6144, profiles/r02/coop_crossover.log)
+  std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_poly_segments{0};         // PubPoly::eval, small batches: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never split, 2..32)
   std::atomic<int> opt_verify_by_enc{1};         // large verification batches: compare the encoding of s*B - h*A with R's bytes, decode R only on a mismatch
   std::atomic<int> opt_coop_verify_max{512};     // verification: up to this many signatures take the single-launch kernel (three wavefronts each)
   std::atomic<int> opt_coop_decode_max{1024};    // unmarshal_binary alone: the same (crossover between 1024 and 2048)
-  std::atomic<int> opt_coop_base_max{3072};      // fixed base: the same (crossover between 3072 and 4096; signing counts its two multiplications per item)
+  std::atomic<int> opt_coop_base_max{4096};      // fixed base: the same (crossover just above 4096; signing counts its two multiplications per item)
   std::atomic<int> opt_encode_batched{1};     // kyb_encode_batch: 1 shared inversion per 8 points (k_encode_batched), 0 one inversion per point (k_encode)
   std::mutex mu;          // host-pointer API: staging buffers + engine streams of this context
   std::mutex launch_mu;   // every launch_* entry: per-stream scratch bookkeeping (calls from any thread, any stream)

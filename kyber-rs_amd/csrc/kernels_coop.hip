@@ -27,6 +27,12 @@ using namespace kyb;
 using namespace kyb::coop;
 #include "device_tables.h"
 
+// per-lane constants and this wavefront's LDS scratch (NW = wavefronts per workgroup of the kernel)
+#define KYB_COOP_CONSTS(c, NW) \
+  __shared__ uint32_t coop_lds_[(NW) * KYB_COOP_LDS_WORDS]; \
+  lane_consts c; \
+  lane_consts_init(c, coop_lds_ + (threadIdx.x >> 6) * KYB_COOP_LDS_WORDS)
+
 namespace {
 
 // affine (x, y) of the point (X : Y : Z) in rows 0..2 of a tight quad, in every lane; Z^-1 cooperative (0 when Z = 0: the reference's 0^(p-2))
@@ -94,8 +100,7 @@ struct coop_decode_fn {
 // quads with every coordinate twice, SX = (x2, x2, x3, x3) and SZ = (z2, z2, z3, z3): the additions in front of the first
 // multiplication level then need no cross-row traffic.  UWQ holds U1 in row 0 and W1 in row 2.  `swap` = the pending
 // conditional swap XOR this step's scalar bit (the swap only exchanges (a, b) with (c, d)).  Three cooperative multiplication
-// levels, six dependent LDS round trips (two operand fetches and two rotations in levels 1 and 2, one fetch in level 3 — its
-// second operands are known before level 2 ends and are rotated early — and the new state).
+// levels.
 struct ladder_idx { int I_F1, I_G1, I_2200, I_3311, I_1300, I_3333, I_0000, I_2222, I_1100, x128; };
 struct ladder_state { cq SX, SZ; };
 __device__ __forceinline__ ladder_idx ladder_idx_init(const lane_consts& c) {
@@ -111,22 +116,18 @@ __device__ __forceinline__ ladder_state coop_ladder_step(const lane_consts& c, c
   const cq AB = cnorm(c, ABraw);
   // level 1: (aa, bb, da, cb) = (sa^2, sb^2, d*a, b*c) with (sa, sb) = swap ? (c, d) : (a, b)
   const int sx = (0 - (int)swap) & li.x128;
-  const crot G1 = crot_make(c, bperm(li.I_G1 ^ sx, ABraw));
-  const cq L1 = cmul4r(c, bperm(li.I_F1 ^ sx, AB), G1);
+  const cq L1 = cmul4(c, bperm(li.I_F1 ^ sx, AB), bperm(li.I_G1 ^ sx, ABraw));
   // level 2: (s, t', x2', a24*e) = ((da+cb)^2, (da-cb)^2, aa*bb, e*a24),  e = aa - bb
   const cq W = bperm(li.I_2200, L1), Z = bperm(li.I_3311, L1);                    // (da, da, aa, aa), (cb, cb, bb, bb)
   const cq F2raw = rodd ? csub(c, W, Z) : (r2 ? W : cadd(W, Z));                   // (da+cb, da-cb, aa, e), <= 3T
-  const crot G2 = crot_make(c, r3 ? A24Q : (r2 ? Z : F2raw));
   const cq F2 = cnorm(c, F2raw);
-  // second operands of level 3, rotated while level 2 multiplies: (U1, e, W1, -)
   const cq E1 = bperm(li.I_3333, F2), A1 = bperm(li.I_0000, L1);                   // e, aa in every row
-  const crot G3 = crot_make(c, r1 ? E1 : UWQ);
-  const cq L2 = cmul4r(c, F2, G2);
+  const cq L2 = cmul4(c, F2, r3 ? A24Q : (r2 ? Z : F2raw));
   // level 3: (z3', z2', x3') = (t' * U1, (a24*e + aa) * e, s * W1)
   const cq T3 = bperm(li.I_1300, L2);                                              // (t', a24*e, s, s)
   const cq X2 = bperm(li.I_2222, L2);                                              // x2' in every row
   const cq F3 = r1 ? cnorm(c, cadd(T3, A1)) : T3;                                  // row 3: * 0
-  const cq L3 = cmul4r(c, F3, G3);
+  const cq L3 = cmul4(c, F3, r1 ? E1 : UWQ);
   // new state: SX = (x2', x2', x3', x3') = (L2 row 2 twice, L3 row 2 twice), SZ = (z2', z2', z3', z3') = (L3 rows 1, 1, 0, 0)
   // (all cross-lane reads are issued by EVERY lane before the select: `cond ? bperm() : bperm()` would run each under a
   // partial EXEC mask, and a ds_bpermute that reads a disabled lane gets 0)
@@ -257,8 +258,7 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
            int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, size_t pt_mod, kyb::launch::DoneFlag df) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  lane_consts c;
-  lane_consts_init(c);
+  KYB_COOP_CONSTS(c, 1);
   const size_t ip = pt_mod ? i % pt_mod : i;                             // shared operands: item i multiplies point i mod pt_mod
 
   // ---- operands: the scalar replicated on all lanes, the point as a quad (X, Y, Z, T) straight from its 40 reference limbs ----
@@ -386,8 +386,7 @@ k_poly_eval_coop(const int32_t* __restrict__ commits_ext, int t, const uint32_t*
                  uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, kyb::launch::DoneFlag df) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  lane_consts c;
-  lane_consts_init(c);
+  KYB_COOP_CONSTS(c, 1);
   const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(indices[i] + 1u));      // wave-uniform: the branches on its bits are scalar
   const size_t first = per_poly ? (i / per_poly) * (size_t)t : 0;      // first commitment of this item's polynomial
   (void)nbits;
@@ -411,8 +410,7 @@ k_poly_eval_seg(const int32_t* __restrict__ commits_ext, int t, const uint32_t* 
   if (b >= n * (size_t)segs) return;
   const size_t i = b / (size_t)segs;
   const int sg = (int)(b % (size_t)segs);
-  lane_consts c;
-  lane_consts_init(c);
+  KYB_COOP_CONSTS(c, 1);
   const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(indices[i] + 1u));
   const size_t first = per_poly ? (i / per_poly) * (size_t)t : 0;
   const int lo = sg * len, cnt = lo >= t ? 0 : (t - lo < len ? t - lo : len);
@@ -435,8 +433,7 @@ __global__ void __launch_bounds__(64)
 k_poly_eval_sum(const uint32_t* __restrict__ part, size_t n, int segs, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, kyb::launch::DoneFlag df) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  lane_consts c;
-  lane_consts_init(c);
+  KYB_COOP_CONSTS(c, 1);
   auto load = [&](int sg) { return c.active ? part[(i * (size_t)segs + (size_t)sg) * 40 + 10 * c.row + c.k] : 0u; };
   cq q = load(0);
 #pragma unroll 1
@@ -495,8 +492,7 @@ k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__
                 kyb::launch::DoneFlag df) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  lane_consts c;
-  lane_consts_init(c);
+  KYB_COOP_CONSTS(c, 1);
   uint32_t a[8];
   if (i < n_a) load_words8(a, scalars, i); else load_words8(a, scalars_b, i - n_a);      // two arrays in one launch (signing: nonces, then keys)
   uint32_t neg;
@@ -513,8 +509,7 @@ k_finish_coop(const uint4* __restrict__ proj, size_t stride, const int32_t* __re
               int32_t* __restrict__ out_ext, size_t src_mul, kyb::launch::DoneFlag df) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  lane_consts c;
-  lane_consts_init(c);
+  KYB_COOP_CONSTS(c, 1);
   cq q;
   if (pts_ext != nullptr) {
     const uint32_t word = c.active ? (uint32_t)pts_ext[40 * i + 10 * c.row + c.k] : 0u;
@@ -533,8 +528,7 @@ __global__ void __launch_bounds__(64)
 k_decode_coop(const uint8_t* __restrict__ enc, size_t n, int32_t* __restrict__ out_ext, uint8_t* __restrict__ ok_out, int or_identity, kyb::launch::DoneFlag df) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  lane_consts c;
-  lane_consts_init(c);
+  KYB_COOP_CONSTS(c, 1);
   uint32_t w[8];
   load_words8(w, enc, i);
   ge_p3 P, id;
@@ -556,8 +550,7 @@ k_verify_prep_coop(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__
                    uint8_t* __restrict__ hbuf, uint8_t* __restrict__ sbuf, int32_t* __restrict__ a_ext) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  lane_consts c;
-  lane_consts_init(c);
+  KYB_COOP_CONSTS(c, 1);
   uint32_t pub[8], sig[16], h[8];
   load_words8(pub, pubs, i);
   load_words8(sig, sigs, 2 * i);
@@ -577,8 +570,7 @@ __global__ void __launch_bounds__(64)
 k_verify_prep_r_coop(const uint8_t* __restrict__ sigs, size_t n, uint8_t* __restrict__ flags_r, uint4* __restrict__ proj, size_t stride, size_t proj_offset) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  lane_consts c;
-  lane_consts_init(c);
+  KYB_COOP_CONSTS(c, 1);
   uint32_t sig[16];
   load_words8(sig, sigs, 2 * i);
   load_words8(sig + 8, sigs, 2 * i + 1);
@@ -600,8 +592,7 @@ k_sign_coop(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const 
   const size_t i = blockIdx.x;
   if (i >= n) return;
   const uint32_t wave = threadIdx.x >> 6;
-  lane_consts c;
-  lane_consts_init(c);
+  KYB_COOP_CONSTS(c, 2);
   uint32_t ra[16];
   if (wave == 0 || pubs == nullptr) {
     uint32_t a[8], neg;
@@ -649,8 +640,7 @@ k_mul_enc_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ 
   const size_t i = blockIdx.x;
   if (i >= n) return;
   const uint32_t wave = threadIdx.x >> 6;
-  lane_consts c;
-  lane_consts_init(c);
+  KYB_COOP_CONSTS(c, 2);
   uint32_t w[8];
   load_words8(w, pts_enc, i);
   const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
@@ -705,8 +695,7 @@ k_verify_coop(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs
   const size_t i = blockIdx.x;
   if (i >= n) return;
   const uint32_t wave = threadIdx.x >> 6;
-  lane_consts c;
-  lane_consts_init(c);
+  KYB_COOP_CONSTS(c, 3);
   uint32_t pub[8], sig[16];
   load_words8(pub, pubs, i);
   load_words8(sig, sigs, 2 * i);
@@ -782,8 +771,7 @@ k_verify_coop(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs
 // U1 / W1 in rows 0 / 2 of B, swap / bit in B lanes 16 / 17 (returns S'), 7 quad -> fe -> quad round trip of every row, 8 csq4(A).
 __global__ void __launch_bounds__(64)
 k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, uint32_t* __restrict__ out, const uint32_t* __restrict__ image64) {
-  lane_consts c;
-  lane_consts_init(c);
+  KYB_COOP_CONSTS(c, 1);
   const cq a = A[c.lane], b = B[c.lane];
   cq r = 0;
   if (op == 0) r = cmul4(c, a, b);
