@@ -78,7 +78,7 @@ __device__ __forceinline__ void lane_consts_init(lane_consts& c, uint32_t* wlds)
     // column k, term i: g_i (broadcast) times f_j, j = (k - i) mod 10, times m = 19 if i + j >= 10, 2 if i and j odd
     const uint32_t j = (k + 10u - (uint32_t)i) % 10u;
     const uint32_t wrap = (uint32_t)i > k, oo = ((uint32_t)i & 1u) & (j & 1u);
-    c.mf[i] = (int)(copy_of((wrap ? 19u : 1u) * (oo ? 2u : 1u)) + base + j);
+    c.mf[i] = c.active ? (int)(copy_of((wrap ? 19u : 1u) * (oo ? 2u : 1u)) + base + j) : 320;      // lanes 10..15 multiply by the zero words
   }
   c.mg = (int)(256u + base);
   KYB_UNROLL for (int t = 0; t < 6; ++t) {
@@ -146,7 +146,7 @@ __device__ __forceinline__ cq cmul4(const lane_consts& c, cq F, cq G) {
   __builtin_amdgcn_wave_barrier();
   uint64_t acc = (uint64_t)gb[0] * fm[0];
   KYB_UNROLL for (int i = 1; i < 10; ++i) acc += (uint64_t)gb[i] * fm[i];
-  return ccarry(c, c.active ? acc : 0ull);
+  return ccarry(c, acc);
 }
 // four squares F_r^2, F tight; bit-identical to cmul4(c, F, F) (the same column sums) with the symmetric terms taken once:
 // column k = sum over the unordered pairs {a, b}, a + b = k (mod 10), of f_a f_b m(a, b) x (2 if a != b).  Step t = 0..5 takes
@@ -167,7 +167,7 @@ __device__ __forceinline__ cq csq4(const lane_consts& c, cq F) {
   __builtin_amdgcn_wave_barrier();
   uint64_t acc = (uint64_t)fa[0] * fb[0];
   KYB_UNROLL for (int t = 1; t < 6; ++t) acc += (uint64_t)fa[t] * fb[t];
-  return ccarry(c, c.active ? acc : 0ull);
+  return ccarry(c, acc);
 }
 
 // element-wise on four elements at once
