@@ -862,7 +862,8 @@ int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t*
   SlotUse use(r, st);
   if (n <= (size_t)g.opt_coop_base_max) {
     ProfScope ps(g, st, KID_MUL_BASE_COOP);
-    LAUNCHCK(launch::mul_base_coop(st, sc, n, oenc, oext, image64(g), nullptr, 0, 0, nullptr, 0, take_done_flag(g, st, n)));
+    LAUNCHCK(launch::mul_base_coop(st, sc, n, oenc, oext, image64(g), nullptr, 0, 0, nullptr, 0, take_done_flag(g, st, n),
+                                   n <= (size_t)g.opt_coop_verify_max ? 4 : 1));      // very few items: four wavefronts share an item's 43 windows
     return KYB_OK;
   }
   if (use_split(g, n)) {

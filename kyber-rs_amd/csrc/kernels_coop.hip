@@ -10,7 +10,7 @@
 //   k_decode_coop     unmarshal_binary          ge.rs:124-179   ge_decode replicated on all lanes, its square-root chain
 //                     (252 of ~270 dependent multiplications) cooperative
 //   k_verify_prep_coop / k_verify_prep_r_coop   the two front halves of a verification (verify.h) with that decode
-//   k_sign_coop       schnorr::sign in one launch, two wavefronts per signature: k B | x B, then hash and s = k + x h
+//   k_sign_coop       schnorr::sign in one launch, eight wavefronts per signature: k B | x B (a quarter of the windows each), then hash and s = k + x h
 //   k_mul_enc_coop    Point::mul on a wire encoding, two wavefronts per item: ladder on y alone | square root for x
 //   k_verify_coop     one verification per workgroup of three wavefronts: hash + ladder | both decodes | s B, one barrier, one launch
 //   k_poly_eval_seg / k_poly_eval_sum   the same for a long polynomial: up to 32 wavefronts per evaluation, segments combined by x^(s len) mod 8L
@@ -464,20 +464,35 @@ __device__ __forceinline__ cq coop_table_entry(const lane_consts& c, const uint3
 }
 
 // a' B for the scalar words a (sc_recode64's signed radix-64 digits): the point (X : Y : Z : T) before the sign of the top digit
-// (`neg`: negate X) is applied.  43 cooperative mixed additions.
-__device__ __forceinline__ cq coop_base_mul(const lane_consts& c, const uint32_t a[8], const uint32_t* __restrict__ image64, uint32_t& neg) {
+// (`neg`: negate X) is applied.  43 cooperative mixed additions — or the share [pos_lo, pos_hi) of the 43 windows (window 42 is the
+// top one) when several wavefronts divide them between themselves.
+__device__ __forceinline__ cq coop_base_mul(const lane_consts& c, const uint32_t a[8], const uint32_t* __restrict__ image64, uint32_t& neg,
+                                            int pos_lo = 0, int pos_hi = KYB_BASE64_POS) {
   sc_digits64 dg;
   sc_recode64(dg, a);
+  // drop the digits below pos_lo: whole words, then the remaining bits (pos_lo is wave-uniform)
+  const int skip = 6 * pos_lo;
+#pragma unroll 1
+  for (int wd = 0; wd < (skip >> 5); ++wd) {
+    KYB_UNROLL for (int q = 0; q < 7; ++q) dg.w[q] = dg.w[q + 1];
+    dg.w[7] = 0;
+  }
+  if (skip & 31) {
+    const uint32_t r = (uint32_t)(skip & 31);
+    KYB_UNROLL for (int q = 0; q < 7; ++q) dg.w[q] = (dg.w[q] >> r) | (dg.w[q + 1] << (32u - r));
+    dg.w[7] >>= r;
+  }
   const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
   cq h = (c.row == 1 || c.row == 2) ? ONE0 : 0u;                         // neutral element (0 : 1 : 1 : 0)
   const madd_idx mi = madd_idx_init(c);
+  const int last = pos_hi < KYB_BASE64_POS - 1 ? pos_hi : KYB_BASE64_POS - 1;
 #pragma unroll 1
-  for (int pos = 0; pos < KYB_BASE64_POS - 1; ++pos) {
+  for (int pos = pos_lo; pos < last; ++pos) {
     uint32_t idx, ng;
     sc_next_digit64(idx, ng, dg, false);
     h = coop_madd(c, mi, h, coop_table_entry<32>(c, image64 + pos * KYB_BASE64_WIN_WORDS, idx, ng));
   }
-  {
+  if (pos_hi == KYB_BASE64_POS) {
     uint32_t idx, ng;
     sc_next_digit64(idx, ng, dg, true);
     h = coop_madd(c, mi, h, coop_table_entry<16>(c, image64 + KYB_BASE64_TOP_BASE, idx, 0u));
@@ -486,17 +501,34 @@ __device__ __forceinline__ cq coop_base_mul(const lane_consts& c, const uint32_t
   return h;
 }
 
-__global__ void __launch_bounds__(64)
+// One item per workgroup of `waves` wavefronts (1 or 4): with four, each adds up a quarter of the 43 windows and wavefront 0 adds the
+// four partial sums (three general additions) before it encodes — the dependent chain of a one-item call is 11 + 3 additions
+// instead of 43.
+__global__ void __launch_bounds__(256)
 k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ scalars_b, size_t n_a, size_t n, uint8_t* __restrict__ out_enc,
                 int32_t* __restrict__ out_ext, const uint32_t* __restrict__ image64, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset,
-                kyb::launch::DoneFlag df) {
+                int waves, kyb::launch::DoneFlag df) {
+  __shared__ uint32_t sh_part[3 * 40];
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  KYB_COOP_CONSTS(c, 1);
+  const int wave = (int)(threadIdx.x >> 6);
+  KYB_COOP_CONSTS(c, 4);
   uint32_t a[8];
   if (i < n_a) load_words8(a, scalars, i); else load_words8(a, scalars_b, i - n_a);      // two arrays in one launch (signing: nonces, then keys)
   uint32_t neg;
-  const cq h = coop_base_mul(c, a, image64, neg);
+  const int per = (KYB_BASE64_POS + waves - 1) / waves;
+  const int lo = wave * per, hi = (wave + 1) * per < KYB_BASE64_POS ? (wave + 1) * per : KYB_BASE64_POS;
+  cq h = coop_base_mul(c, a, image64, neg, lo, hi);
+  if (waves > 1) {
+    if (wave > 0 && c.active) sh_part[(wave - 1) * 40 + 10 * c.row + c.k] = h;
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll 1
+    for (int w = 1; w < waves; ++w) {
+      const cq o = c.active ? sh_part[(w - 1) * 40 + 10 * c.row + c.k] : 0u;
+      h = coop_add(c, h, coop_to_cached(c, o));
+    }
+  }
   coop_finish(c, h, neg, out_enc, out_ext, i, proj, proj_stride, proj_offset);
   if (c.lane == 0) signal_done(df);
 }
@@ -582,29 +614,43 @@ k_verify_prep_r_coop(const uint8_t* __restrict__ sigs, size_t n, uint8_t* __rest
   }
 }
 
-// schnorr::sign (schnorr_sig.rs:25-47) in one launch, two wavefronts per signature: R = k B in wavefront 0, A = x B in wavefront 1
-// (idle when the signer's stored public key is given), then wavefront 0 hashes and forms s = k + x h (k_sign_hash's work).
-__global__ void __launch_bounds__(128)
+// schnorr::sign (schnorr_sig.rs:25-47) in one launch, eight wavefronts per signature: R = k B in wavefronts 0..3 and A = x B in
+// wavefronts 4..7 (idle when the signer's stored public key is given), each a quarter of the 43 windows as in k_mul_base_coop; then
+// wavefront 0 hashes and forms s = k + x h (k_sign_hash's work).
+__global__ void __launch_bounds__(512)
 k_sign_coop(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ msgs,
             const uint32_t* __restrict__ msg_off, size_t n, uint8_t* __restrict__ sig, uint8_t* __restrict__ pub_out,
             const uint32_t* __restrict__ image64, kyb::launch::DoneFlag df) {
-  __shared__ uint32_t sh_a[8];
+  __shared__ uint32_t sh_a[8], sh_part[6 * 40];
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  const uint32_t wave = threadIdx.x >> 6;
-  KYB_COOP_CONSTS(c, 2);
-  uint32_t ra[16];
-  if (wave == 0 || pubs == nullptr) {
-    uint32_t a[8], neg;
-    load_words8(a, wave == 0 ? k : x, i);
-    cq h = coop_base_mul(c, a, image64, neg);
+  const int wave = (int)(threadIdx.x >> 6), grp = wave >> 2, sub = wave & 3;
+  KYB_COOP_CONSTS(c, 8);
+  const bool works = grp == 0 || pubs == nullptr;
+  uint32_t ra[16], neg = 0;
+  cq h = 0;
+  if (works) {
+    uint32_t a[8];
+    load_words8(a, grp == 0 ? k : x, i);
+    const int per = (KYB_BASE64_POS + 3) / 4;
+    const int lo = sub * per, hi = (sub + 1) * per < KYB_BASE64_POS ? (sub + 1) * per : KYB_BASE64_POS;
+    h = coop_base_mul(c, a, image64, neg, lo, hi);
+    if (sub > 0 && c.active) sh_part[(grp * 3 + sub - 1) * 40 + 10 * c.row + c.k] = h;
+  }
+  __syncthreads();
+  if (works && sub == 0) {
+#pragma unroll 1
+    for (int w = 1; w < 4; ++w) {
+      const cq o = c.active ? sh_part[(grp * 3 + w - 1) * 40 + 10 * c.row + c.k] : 0u;
+      h = coop_add(c, h, coop_to_cached(c, o));
+    }
     const cq nq = cnorm(c, c.p2 - h);
     h = (c.row == 0 && neg) ? nq : h;
     fe ax, ay;
     coop_affine(c, h, ax, ay);
     fe_to_words(ra, ay);
     ra[7] ^= fe_is_negative(ax) << 31;
-    if (wave == 1 && c.lane == 0) for (int j = 0; j < 8; ++j) sh_a[j] = ra[j];
+    if (grp == 1 && c.lane == 0) for (int j = 0; j < 8; ++j) sh_a[j] = ra[j];
   }
   __syncthreads();
   if (wave != 0) return;
@@ -846,7 +892,7 @@ hipError_t poly_eval_coop(hipStream_t st, const int32_t* commits, int t, const u
 }
 hipError_t sign_coop(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, size_t n,
                      uint8_t* sig, uint8_t* pub_out, const uint32_t* image64, DoneFlag df) {
-  hipLaunchKernelGGL(k_sign_coop, dim3((unsigned)n), dim3(128), 0, st, x, k, pubs, msgs, off, n, sig, pub_out, image64, df);
+  hipLaunchKernelGGL(k_sign_coop, dim3((unsigned)n), dim3(512), 0, st, x, k, pubs, msgs, off, n, sig, pub_out, image64, df);
   return hipGetLastError();
 }
 hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, DoneFlag df) {
@@ -872,8 +918,9 @@ hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size
   return hipGetLastError();
 }
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
-                         uint4* proj, size_t proj_stride, size_t proj_offset, const uint8_t* sc_b, size_t n_b, DoneFlag df) {
-  hipLaunchKernelGGL(k_mul_base_coop, dim3((unsigned)(n + n_b)), dim3(64), 0, st, sc, sc_b, n, n + n_b, oenc, oext, image64, proj, proj_stride, proj_offset, df);
+                         uint4* proj, size_t proj_stride, size_t proj_offset, const uint8_t* sc_b, size_t n_b, DoneFlag df, int waves) {
+  hipLaunchKernelGGL(k_mul_base_coop, dim3((unsigned)(n + n_b)), dim3(64u * (unsigned)waves), 0, st, sc, sc_b, n, n + n_b, oenc, oext, image64, proj, proj_stride, proj_offset,
+                     waves, df);
   return hipGetLastError();
 }
 }}  // namespace kyb::launch

@@ -79,7 +79,7 @@ hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const i
 // sc_b != nullptr: n_b more scalars follow the first n in the same launch (their results behind the first n)
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
                          uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, const uint8_t* sc_b = nullptr, size_t n_b = 0,
-                         DoneFlag df = DoneFlag{});
+                         DoneFlag df = DoneFlag{}, int waves = 1);      // waves: 1, or 4 wavefronts per item sharing the 43 windows
 hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* image64);
 
 // ---- kernels_verify.hip ----
