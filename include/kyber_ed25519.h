@@ -277,7 +277,8 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *   coop.max_items    batches of at most this many items take the one-item-per-wavefront kernels (variable base, verification,
  *                     polynomial evaluation; default 6144, 0 = never); coop.base_max_items the same for the fixed base and signing
  *                     (default 4096), coop.decode_max_items for a bare decode (default 1024), coop.verify_max_items for the
- *                     single-launch verification with three wavefronts per signature (default 512).  Same results either way.
+ *                     kernels that give ONE item several wavefronts (verification in one launch, signing in one launch, the fixed
+ *                     base with four wavefronts per item; default 512).  Same results either way.
  *   poly.segments     PubPoly::eval of few evaluations: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never
  *                     split the Horner chain, 2..32)
  *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder
