@@ -794,7 +794,8 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
       HIPCK(hipMemsetAsync(ok, 1, n, st));
     }
     ProfScope ps(g, st, KID_MUL_COOP);
-    LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, 0, nullptr, 0, 0, take_done_flag(g, st, n)));
+    LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, 0, nullptr, 0, 0, take_done_flag(g, st, n), 0,
+                              n <= (size_t)g.opt_coop_verify_max ? 4 : 1));      // very few items: four wavefronts share an item's scalar
     return KYB_OK;
   }
   if (g.opt_mul_algo == 1) {

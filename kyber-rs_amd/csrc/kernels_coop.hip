@@ -219,92 +219,6 @@ __device__ __forceinline__ cq coop_mont_recover(const lane_consts& c, cq M, cq S
   return (r0 && negate) ? nres : RES;
 }
 
-// The whole ladder: UWQ = the base point's u as U1 (row 0) / W1 (row 2), tight; |scalar| = mag, its top skip_bits bits known to be 0.
-// Returns the state after the last conditional swap: SX = (x2, x2, x3, x3), SZ = (z2, z2, z3, z3).
-__device__ __forceinline__ void coop_ladder_run(const lane_consts& c, const uint32_t mag[8], int skip_bits, cq UWQ, cq& SX, cq& SZ) {
-  const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
-  ladder_state st;                                                       // (x2, z2, x3, z3) = (1, 0, U1, W1)
-  {
-    const cq u1 = bperm(rowperm_idx(c, 0, 0, 0, 0), UWQ), w1 = bperm(rowperm_idx(c, 2, 2, 2, 2), UWQ);
-    st.SX = c.row < 2 ? ONE0 : u1;
-    st.SZ = c.row < 2 ? 0u : w1;
-  }
-  const ladder_idx li = ladder_idx_init(c);
-  uint32_t swap = 0;
-#pragma unroll 1
-  for (int w = 7; w >= 0; --w) {
-    uint32_t word = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) word = (w == q) ? mag[q] : word;
-    const int first = (w == 7) ? skip_bits : 0;
-    word <<= first;
-#pragma unroll 1
-    for (int j = first; j < 32; ++j) {
-      const uint32_t bit = word >> 31;
-      word <<= 1;
-      swap ^= bit;
-      st = coop_ladder_step(c, li, st, UWQ, swap);                       // (rows 1, 3 of UWQ are not read)
-      swap = bit;
-    }
-  }
-  // the final conditional swap (x2, z2) <-> (x3, z3): rows 0, 1 <-> 2, 3
-  const int I_sw = (int)(c.lane << 2) ^ ((0 - (int)swap) & 128);
-  SX = bperm(I_sw, st.SX);
-  SZ = bperm(I_sw, st.SZ);
-}
-
-__global__ void __launch_bounds__(64)
-k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
-           int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, size_t pt_mod, kyb::launch::DoneFlag df) {
-  const size_t i = blockIdx.x;
-  if (i >= n) return;
-  KYB_COOP_CONSTS(c, 1);
-  const size_t ip = pt_mod ? i % pt_mod : i;                             // shared operands: item i multiplies point i mod pt_mod
-
-  // ---- operands: the scalar replicated on all lanes, the point as a quad (X, Y, Z, T) straight from its 40 reference limbs ----
-  uint32_t a[8];
-  load_words8(a, scalars, i);
-  uint32_t neg, mag[8];
-  sc_effective(neg, mag, a);
-  const uint32_t word = c.active ? (uint32_t)pts_ext[40 * ip + 10 * c.row + c.k] : 0u;
-  const cq PQ = cnorm(c, c.active ? word + (c.p2 << 3) : 0u);           // fe_from_ref10: signed limb + 16p, one carry pass
-  uint32_t p_flags;
-  const cq M = coop_mont_prep(c, PQ, p_flags);                           // u = U / W, v = V / W: no inversion in front of the ladder
-
-  cq SX, SZ;
-  coop_ladder_run(c, mag, skip_bits, M, SX, SZ);
-
-  // ---- y-recovery, exceptional cases, encoding ----
-  const cq RES = coop_mont_recover(c, M, SX, SZ, p_flags, mag[0] & 1u, neg);
-  coop_finish(c, RES, 0u, out_enc, out_ext, i, proj, proj_stride, proj_offset);
-  if (c.lane == 0) signal_done(df);
-}
-
-// h + E for h = (X : Y : Z : T) in rows 0..3 and an affine table entry E = (y+x, y-x, 2dxy, 0): ge_madd followed by
-// ge_p1p1_to_p3 (ge25519.h), two cooperative multiplication levels.
-struct madd_idx { int I_1133, I_0000, I_2222, I_1122; };
-__device__ __forceinline__ madd_idx madd_idx_init(const lane_consts& c) {
-  return madd_idx{rowperm_idx(c, 1, 1, 3, 3), rowperm_idx(c, 0, 0, 0, 0), rowperm_idx(c, 2, 2, 2, 2), rowperm_idx(c, 1, 1, 2, 2)};
-}
-__device__ __forceinline__ cq coop_madd(const lane_consts& c, const madd_idx& mi, cq h, cq E) {
-  const bool r0 = c.row == 0, r1 = c.row == 1, r2 = c.row == 2, r3 = c.row == 3;
-  // a = Y + X, b = Y - X; A = a ypx, B = b ymx, C = xy2d T
-  const cq U = bperm(mi.I_1133, h), V = bperm(mi.I_0000, h);         // (Y, Y, T, T), (X, X, X, X)
-  const cq FA = cnorm(c, r0 ? cadd(U, V) : (r1 ? csub(c, U, V) : (r2 ? U : 0u)));
-  const cq LA = cmul4(c, FA, E);                                       // (A, B, C, 0)
-  // X3 = A - B, Y3 = A + B, Z3 = D + C, T3 = D - C with D = 2Z
-  const cq H2 = cadd(h, h);
-  const cq qa = bperm(mi.I_0000, LA), qd = bperm(mi.I_2222, H2);       // every lane issues both reads, then selects
-  const cq Q1 = (c.row < 2) ? qa : qd;                                 // (A, A, D, D)
-  const cq Q2 = bperm(mi.I_1122, LA);                                  // (B, B, C, C)
-  const cq SUM = cadd(Q1, Q2), DIF = csub(c, Q1, Q2);                  // (Y3, Y3, Z3, Z3), (X3, X3, T3, T3)
-  // (X3 T3, Z3 Y3, Z3 T3, X3 Y3)
-  const cq x3 = bperm(mi.I_0000, DIF), z3 = bperm(mi.I_2222, SUM), t3 = bperm(mi.I_2222, DIF), y3 = bperm(mi.I_0000, SUM);
-  const cq FB = cnorm(c, (r0 || r3) ? x3 : z3);                        // (X3, Z3, Z3, X3)
-  const cq GB = (r0 || r2) ? t3 : y3;                                  // (T3, Y3, T3, Y3)
-  return cmul4(c, FB, GB);
-}
-
 // ---- general point arithmetic in quads: PubPoly::eval for small batches (share/poly.rs:457-469) ----------------------------------
 // (X : Y : Z : T) -> the cached form (Y+X, Y-X, 2d T, Z) the addition below takes as its second operand.  One multiplication level.
 __device__ __forceinline__ cq coop_to_cached(const lane_consts& c, cq P) {
@@ -340,10 +254,130 @@ __device__ __forceinline__ cq coop_dbl(const lane_consts& c, cq h) {
   const cq Q = csq4(c, r3 ? xpy : a);                                             // (XX, YY, ZZ, (X+Y)^2)
   const cq xx = bperm(rowperm_idx(c, 0, 0, 0, 0), Q), yy = bperm(rowperm_idx(c, 1, 1, 1, 1), Q);
   const cq zz = bperm(rowperm_idx(c, 2, 2, 2, 2), Q), aa = bperm(rowperm_idx(c, 3, 3, 3, 3), Q);
-  const cq Y3 = cnorm(c, cadd(yy, xx)), Z3 = cnorm(c, csub(c, yy, xx));
-  const cq X3 = cnorm(c, csub(c, aa, Y3));
-  const cq T3 = csub(c, cadd(zz, zz), Z3);                                        // <= 4T: second operand only
+  // the four combinations side by side (no carry pass waits for another): 4p - (yy + xx) >= 0 limb-wise; T3 stays lazy (<= 5T, a
+  // second operand: columns stay below 2^63)
+  const cq ypx = cadd(yy, xx);
+  const cq Y3 = cnorm(c, ypx), Z3 = cnorm(c, csub(c, yy, xx));
+  const cq X3 = cnorm(c, cadd(aa, (c.p2 << 1) - ypx));
+  const cq T3 = csub(c, cadd(cadd(zz, zz), xx), yy);
   return cmul4(c, (r0 || r3) ? X3 : (r1 ? Y3 : Z3), (r0 || r2) ? T3 : (r1 ? Z3 : Y3));      // (X3 T3, Y3 Z3, Z3 T3, X3 Y3)
+}
+
+// The whole ladder: UWQ = the base point's u as U1 (row 0) / W1 (row 2), tight; |scalar| = mag (or its words w_hi .. w_lo taken as a
+// number of their own), the top skip_bits bits of word 7 known to be 0.
+// Returns the state after the last conditional swap: SX = (x2, x2, x3, x3), SZ = (z2, z2, z3, z3).
+__device__ __forceinline__ void coop_ladder_run(const lane_consts& c, const uint32_t mag[8], int skip_bits, cq UWQ, cq& SX, cq& SZ, int w_hi = 7, int w_lo = 0) {
+  const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
+  ladder_state st;                                                       // (x2, z2, x3, z3) = (1, 0, U1, W1)
+  {
+    const cq u1 = bperm(rowperm_idx(c, 0, 0, 0, 0), UWQ), w1 = bperm(rowperm_idx(c, 2, 2, 2, 2), UWQ);
+    st.SX = c.row < 2 ? ONE0 : u1;
+    st.SZ = c.row < 2 ? 0u : w1;
+  }
+  const ladder_idx li = ladder_idx_init(c);
+  uint32_t swap = 0;
+#pragma unroll 1
+  for (int w = w_hi; w >= w_lo; --w) {                                     // the scalar's words w_hi .. w_lo (a piece of it, or all eight)
+    uint32_t word = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) word = (w == q) ? mag[q] : word;
+    const int first = (w == 7) ? skip_bits : 0;
+    word <<= first;
+#pragma unroll 1
+    for (int j = first; j < 32; ++j) {
+      const uint32_t bit = word >> 31;
+      word <<= 1;
+      swap ^= bit;
+      st = coop_ladder_step(c, li, st, UWQ, swap);                       // (rows 1, 3 of UWQ are not read)
+      swap = bit;
+    }
+  }
+  // the final conditional swap (x2, z2) <-> (x3, z3): rows 0, 1 <-> 2, 3
+  const int I_sw = (int)(c.lane << 2) ^ ((0 - (int)swap) & 128);
+  SX = bperm(I_sw, st.SX);
+  SZ = bperm(I_sw, st.SZ);
+}
+
+// One item per workgroup of `waves` wavefronts (1 or 4).  With four the scalar is cut into 64-bit pieces k = sum_j k_j 2^(64 j):
+// wavefront j doubles P 64 j times (Edwards doublings, 0.3 us each), runs a 64-step ladder for k_j on that point and recovers the full
+// point; wavefront 0 adds the four results and encodes.  The dependent chain of a one-item call is 192 doublings + 64 ladder steps +
+// 3 additions instead of 256 ladder steps (a doubling is half a step).  Same instruction stream for every scalar.
+__global__ void __launch_bounds__(256)
+k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
+           int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, size_t pt_mod, int waves, kyb::launch::DoneFlag df) {
+  __shared__ uint32_t sh_part[3 * 40];
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  const int wave = (int)(threadIdx.x >> 6);
+  KYB_COOP_CONSTS(c, 4);
+  const size_t ip = pt_mod ? i % pt_mod : i;                             // shared operands: item i multiplies point i mod pt_mod
+
+  // ---- operands: the scalar replicated on all lanes, the point as a quad (X, Y, Z, T) straight from its 40 reference limbs ----
+  uint32_t a[8];
+  load_words8(a, scalars, i);
+  uint32_t neg, mag[8];
+  sc_effective(neg, mag, a);
+  const uint32_t word = c.active ? (uint32_t)pts_ext[40 * ip + 10 * c.row + c.k] : 0u;
+  cq PQ = cnorm(c, c.active ? word + (c.p2 << 3) : 0u);                 // fe_from_ref10: signed limb + 16p, one carry pass
+  if (waves == 1) {
+    uint32_t p_flags;
+    const cq M = coop_mont_prep(c, PQ, p_flags);                         // u = U / W, v = V / W: no inversion in front of the ladder
+    cq SX, SZ;
+    coop_ladder_run(c, mag, skip_bits, M, SX, SZ);
+    // y-recovery, exceptional cases, encoding
+    const cq RES = coop_mont_recover(c, M, SX, SZ, p_flags, mag[0] & 1u, neg);
+    coop_finish(c, RES, 0u, out_enc, out_ext, i, proj, proj_stride, proj_offset);
+    if (c.lane == 0) signal_done(df);
+    return;
+  }
+  // ---- four wavefronts: piece `wave` of the scalar on 2^(64 wave) P ----
+#pragma unroll 1
+  for (int d = 0; d < 64 * wave; ++d) PQ = coop_dbl(c, PQ);
+  uint32_t p_flags;
+  const cq M = coop_mont_prep(c, PQ, p_flags);
+  cq SX, SZ;
+  coop_ladder_run(c, mag, wave == 3 ? skip_bits : 0, M, SX, SZ, 2 * wave + 1, 2 * wave);
+  uint32_t lowbit = 0;
+  KYB_UNROLL for (int q = 0; q < 8; q += 2) lowbit = (2 * wave == q) ? (mag[q] & 1u) : lowbit;
+  const cq R = coop_mont_recover(c, M, SX, SZ, p_flags, lowbit, 0u);
+  // (X : Y : Z) -> extended (X Z : Y Z : Z^2 : X Y)
+  const cq zz = bperm(rowperm_idx(c, 2, 2, 2, 2), R), xy = bperm(rowperm_idx(c, 0, 1, 2, 0), R), yy = bperm(rowperm_idx(c, 1, 1, 1, 1), R);
+  cq q = cmul4(c, xy, c.row == 3 ? yy : zz);
+  if (wave > 0 && c.active) sh_part[(wave - 1) * 40 + 10 * c.row + c.k] = q;
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll 1
+  for (int w = 1; w < 4; ++w) {
+    const cq o = c.active ? sh_part[(w - 1) * 40 + 10 * c.row + c.k] : 0u;
+    q = coop_add(c, q, coop_to_cached(c, o));
+  }
+  coop_finish(c, q, neg, out_enc, out_ext, i, proj, proj_stride, proj_offset);
+  if (c.lane == 0) signal_done(df);
+}
+
+// h + E for h = (X : Y : Z : T) in rows 0..3 and an affine table entry E = (y+x, y-x, 2dxy, 0): ge_madd followed by
+// ge_p1p1_to_p3 (ge25519.h), two cooperative multiplication levels.
+struct madd_idx { int I_1133, I_0000, I_2222, I_1122; };
+__device__ __forceinline__ madd_idx madd_idx_init(const lane_consts& c) {
+  return madd_idx{rowperm_idx(c, 1, 1, 3, 3), rowperm_idx(c, 0, 0, 0, 0), rowperm_idx(c, 2, 2, 2, 2), rowperm_idx(c, 1, 1, 2, 2)};
+}
+__device__ __forceinline__ cq coop_madd(const lane_consts& c, const madd_idx& mi, cq h, cq E) {
+  const bool r0 = c.row == 0, r1 = c.row == 1, r2 = c.row == 2, r3 = c.row == 3;
+  // a = Y + X, b = Y - X; A = a ypx, B = b ymx, C = xy2d T
+  const cq U = bperm(mi.I_1133, h), V = bperm(mi.I_0000, h);         // (Y, Y, T, T), (X, X, X, X)
+  const cq FA = cnorm(c, r0 ? cadd(U, V) : (r1 ? csub(c, U, V) : (r2 ? U : 0u)));
+  const cq LA = cmul4(c, FA, E);                                       // (A, B, C, 0)
+  // X3 = A - B, Y3 = A + B, Z3 = D + C, T3 = D - C with D = 2Z
+  const cq H2 = cadd(h, h);
+  const cq qa = bperm(mi.I_0000, LA), qd = bperm(mi.I_2222, H2);       // every lane issues both reads, then selects
+  const cq Q1 = (c.row < 2) ? qa : qd;                                 // (A, A, D, D)
+  const cq Q2 = bperm(mi.I_1122, LA);                                  // (B, B, C, C)
+  const cq SUM = cadd(Q1, Q2), DIF = csub(c, Q1, Q2);                  // (Y3, Y3, Z3, Z3), (X3, X3, T3, T3)
+  // (X3 T3, Z3 Y3, Z3 T3, X3 Y3)
+  const cq x3 = bperm(mi.I_0000, DIF), z3 = bperm(mi.I_2222, SUM), t3 = bperm(mi.I_2222, DIF), y3 = bperm(mi.I_0000, SUM);
+  const cq FB = cnorm(c, (r0 || r3) ? x3 : z3);                        // (X3, Z3, Z3, X3)
+  const cq GB = (r0 || r2) ? t3 : y3;                                  // (T3, Y3, T3, Y3)
+  return cmul4(c, FB, GB);
 }
 
 // sum_{j < count} x^j C_{first + j} by Horner (x >= 1 public and wave-uniform: the instruction stream follows its bits), every
@@ -913,8 +947,9 @@ hipError_t poly_eval_seg(hipStream_t st, const int32_t* commits, int t, const ui
   return hipGetLastError();
 }
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
-                    uint4* proj, size_t proj_stride, size_t proj_offset, DoneFlag df, size_t pt_mod) {
-  hipLaunchKernelGGL(k_mul_coop, dim3((unsigned)n), dim3(64), 0, st, sc, pext, n, oenc, oext, skip_bits, proj, proj_stride, proj_offset, pt_mod, df);
+                    uint4* proj, size_t proj_stride, size_t proj_offset, DoneFlag df, size_t pt_mod, int waves) {
+  hipLaunchKernelGGL(k_mul_coop, dim3((unsigned)n), dim3(64u * (unsigned)waves), 0, st, sc, pext, n, oenc, oext, skip_bits, proj, proj_stride, proj_offset, pt_mod,
+                     waves, df);
   return hipGetLastError();
 }
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,

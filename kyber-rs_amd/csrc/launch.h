@@ -72,7 +72,8 @@ hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs,
 hipError_t poly_eval_seg(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, size_t per_poly, int len, int segs,
                          uint32_t* part, uint8_t* oenc, int32_t* oext, DoneFlag df = DoneFlag{});
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
-                    uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, DoneFlag df = DoneFlag{}, size_t pt_mod = 0);
+                    uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, DoneFlag df = DoneFlag{}, size_t pt_mod = 0,
+                    int waves = 1);      // waves: 1, or 4 wavefronts per item (64-bit pieces of the scalar)
 // proj != nullptr: projective staging record i * src_mul, else the 40 reference limbs of point i
 hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul,
                        DoneFlag df = DoneFlag{});
