@@ -795,7 +795,7 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
     }
     ProfScope ps(g, st, KID_MUL_COOP);
     LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, 0, nullptr, 0, 0, take_done_flag(g, st, n), 0,
-                              n <= (size_t)g.opt_coop_verify_max ? 4 : 1));      // very few items: four wavefronts share an item's scalar
+                              2 * n <= (size_t)g.opt_coop_verify_max ? 4 : 1));      // very few items (measured: up to 256): four wavefronts share an item's scalar
     return KYB_OK;
   }
   if (g.opt_mul_algo == 1) {
@@ -864,7 +864,7 @@ int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t*
   if (n <= (size_t)g.opt_coop_base_max) {
     ProfScope ps(g, st, KID_MUL_BASE_COOP);
     LAUNCHCK(launch::mul_base_coop(st, sc, n, oenc, oext, image64(g), nullptr, 0, 0, nullptr, 0, take_done_flag(g, st, n),
-                                   n <= (size_t)g.opt_coop_verify_max ? 4 : 1));      // very few items: four wavefronts share an item's 43 windows
+                                   n <= 2 * (size_t)g.opt_coop_verify_max ? 4 : 1));      // few items (measured: up to 1,024): four wavefronts share an item's 43 windows
     return KYB_OK;
   }
   if (use_split(g, n)) {
