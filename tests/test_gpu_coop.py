@@ -247,6 +247,38 @@ def test_structured_fuzz_on_the_small_batch_kernels(coop_engine, oracle):
     P.test_structured_fuzz_against_oracle(coop_engine, oracle)
 
 
+def test_every_routing_boundary_with_default_options(oracle):
+    """a fresh context with the DEFAULT thresholds: batch sizes on both sides of every routing boundary (multi-wavefront kernels up to
+    256 / 512 / 1,024 items, mul from encodings up to 1,536, cooperative kernels up to 4,096 / 6,144, batch kernels above), all four
+    operations against the oracle"""
+    import kyber_rs_amd
+    eng = kyber_rs_amd.Engine(0, private=True)
+    try:
+        sizes = (255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1535, 1536, 1537, 2047, 2048, 2049, 4095, 4096, 4097, 6143, 6144, 6145)
+        nmax = max(sizes)
+        s = synth.raw256(nmax, 31); s[::7] = synth.scalars(len(s[::7]), 32)
+        k = synth.scalars(nmax, 33, b"k")
+        pts = oracle.mul_base_ext_batch(synth.scalars(nmax, 34, b"point"))
+        enc = np.stack([np.frombuffer(oracle.encode(p), dtype=np.uint8) for p in pts[:1600]])
+        msgs = synth.messages(nmax, 35)
+        want_base = oracle.mul_base_batch(s, nthreads=8)
+        want_mul = oracle.mul_batch(s, pts, nthreads=8)
+        x = s.copy(); x[:, 31] &= 0x7f
+        want_sig = oracle.schnorr_sign_batch(x, k, msgs, nthreads=8)
+        pubs = oracle.mul_base_batch(x, nthreads=8)
+        bad = want_sig.copy(); bad[::5, 40] ^= 1
+        want_st = np.array([0 if i % 5 else 9 for i in range(nmax)], dtype=np.uint8)
+        for n in sizes:
+            assert np.array_equal(eng.mul_base(s[:n]), want_base[:n]), n
+            assert np.array_equal(eng.mul(s[:n], pts_ext=pts[:n]), want_mul[:n]), n
+            if n <= 1600:
+                assert np.array_equal(eng.mul(s[:n], pts_enc=enc[:n]), want_mul[:n]), n
+            assert np.array_equal(eng.schnorr_sign(x[:n], k[:n], msgs[:n]), want_sig[:n]), n
+            assert np.array_equal(eng.verify(pubs[:n], msgs[:n], bad[:n], 1), want_st[:n]), n
+    finally:
+        eng.close()
+
+
 def test_coop_and_batch_kernels_agree_at_the_threshold(engine, oracle):
     """the routing by size: n <= coop.max_items -> cooperative kernel, above -> batch kernels; same bytes either way"""
     s = synth.raw256(130, 800)
