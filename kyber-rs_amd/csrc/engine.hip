@@ -239,7 +239,11 @@ int wait_done(Ctx& g, const DoneReq& req) {
     volatile uint32_t* f = g.done_flag;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned it = 1; *f != req.seq; ++it) {
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
+#else
+      std::this_thread::yield();
+#endif
       if ((it & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;      // a long batch: let the runtime wait
     }
     if (*f == req.seq) { std::atomic_thread_fence(std::memory_order_acquire); return KYB_OK; }
