@@ -64,6 +64,7 @@ struct StreamRes {
 };
 constexpr size_t MAX_STREAM_SLOTS = 32;
 
+constexpr int PIPE_CHUNKS_DEFAULT = 8;
 struct Ctx {
   bool ready = false;
   int device = -1;
@@ -103,6 +104,7 @@ struct Ctx {
   std::atomic<int> opt_finish{1};             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
   std::atomic<int> opt_finish_min{1};         // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size; cross-check)
   std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
+  std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: chunks that alternate between the two lanes
   std::atomic<int> opt_poly_segments{0};         // PubPoly::eval, small batches: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never split, 2..32)
   std::atomic<int> opt_verify_by_enc{1};         // large verification batches: compare the encoding of s*B - h*A with R's bytes, decode R only on a mismatch
   std::atomic<int> opt_coop_verify_max{512};     // verification: up to this many signatures take the single-launch kernel (three wavefronts each)
@@ -267,11 +269,11 @@ struct DoneScope {          // posts / withdraws the request around the launch s
 struct HostArr { const void* in; void* out; size_t bytes; };    // per-item size; exactly one of in/out, or neither = absent
 constexpr size_t PIPE_MIN_ITEMS = (size_t)1 << 16;
 constexpr size_t ZERO_COPY_BYTES = (size_t)1 << 19;      // host-pointer calls up to this size skip the copies: kernels work on page-locked host memory
-constexpr int PIPE_CHUNKS = 8;
+
 template <class Fn>
 int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
   std::lock_guard<std::mutex> lk(g.mu);
-  const int nchunks = n >= PIPE_MIN_ITEMS ? PIPE_CHUNKS : 1;
+  const int nchunks = n >= PIPE_MIN_ITEMS ? (int)g.opt_pipe_chunks : 1;
   const size_t cap = (((n + nchunks - 1) / nchunks) + 1023) & ~(size_t)1023;      // items per chunk
   size_t off[8], total = 0;
   for (int k = 0; k < na; ++k) { off[k] = total; total += up256(arrs[k].bytes * cap); }
