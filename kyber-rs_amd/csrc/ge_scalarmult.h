@@ -120,9 +120,14 @@ KYB_HD void ge_small_mul(ge_p3& out, const ge_p3& in, uint32_t x, int nbits) {
     ge_p3 d, a;
     ge_p2_dbl(t, acc.X, acc.Y, acc.Z);
     ge_p1p1_to_p3(d, t);
+    const uint32_t bit = (x >> b) & 1u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // share indices are public: when no lane of the wavefront has this bit set (a verifier evaluates every dealer's polynomial at
+    // its OWN index, so the lanes usually agree) the addition is skipped for the whole wavefront
+    if (__builtin_amdgcn_ballot_w64(bit != 0u) == 0ull) { acc = d; continue; }
+#endif
     ge_add(t, d, cin);
     ge_p1p1_to_p3(a, t);
-    const uint32_t bit = (x >> b) & 1u;
     fe_select(acc.X, d.X, a.X, bit); fe_select(acc.Y, d.Y, a.Y, bit);
     fe_select(acc.Z, d.Z, a.Z, bit); fe_select(acc.T, d.T, a.T, bit);
   }
