@@ -139,7 +139,7 @@ int kyb_base_table_export(uint8_t* dst_host);                      /* engine tab
 int kyb_base_table_import(const uint8_t* src_host);                /* host buffer -> engine table   */
 
 /* ---- Point::mul(s, None): fixed base — ge_scalar_mult_base, ge.rs:442-486 --------------------- */
-/* out_enc (n x 32) and/or out_ext (n x 40 int32, Z = 1) may be NULL, not both. */
+/* out_enc (n x 32) and/or out_ext (n x 40 int32, Z = 1 unless the option ext.projective is set) may be NULL, not both. */
 int kyb_mul_base_batch(const uint8_t* scalars, size_t n, uint8_t* out_enc, int32_t* out_ext);
 int kyb_mul_base_batch_dev(const uint8_t* scalars, size_t n, uint8_t* out_enc, int32_t* out_ext, void* stream);
 
@@ -279,6 +279,10 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *                     (default 4096), coop.decode_max_items for a bare decode (default 1024), coop.verify_max_items for the
  *                     kernels that give ONE item several wavefronts (verification in one launch, signing in one launch, the fixed
  *                     base with four wavefronts per item; default 512).  Same results either way.
+ *   ext.projective    0 (default): out_ext always has Z = 1.  1: a small-batch kyb_mul_batch / kyb_mul_base_batch call that asks for
+ *                     out_ext ONLY (out_enc == NULL) gets the point as (X : Y : Z : T) with Z != 1 — what the reference's own Point
+ *                     holds after a multiplication — and skips the field inversion (one fixed-base call: 55 -> 27 us); every entry
+ *                     point accepts such points, kyb_encode_batch pays the inversion when an encoding is wanted
  *   poly.segments     PubPoly::eval of few evaluations: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never
  *                     split the Horner chain, 2..32)
  *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder

@@ -291,15 +291,25 @@ class Engine:
         self.lib.kyb_shutdown()
 
     # ---- host-buffer API (numpy in, numpy out) ---------------------------------------------------
-    def mul_base(self, scalars, want_ext: bool = False):
+    def mul_base(self, scalars, want_ext: bool = False, ext_only: bool = False):
+        """ext_only: extended limbs only (what a trait-level Point::mul keeps); with the option ext.projective they may have Z != 1"""
         s = _u8(scalars, 32, "scalars")
         n = s.shape[0]
-        enc = np.empty((n, 32), dtype=np.uint8)
-        ext = np.empty((n, 40), dtype=np.int32) if want_ext else None
+        enc = None if ext_only else np.empty((n, 32), dtype=np.uint8)
+        ext = np.empty((n, 40), dtype=np.int32) if (want_ext or ext_only) else None
         _check(self.lib.kyb_mul_base_batch(_ptr(s), n, _ptr(enc), _ptr(ext)), "kyb_mul_base_batch")
+        if ext_only:
+            return ext
         return (enc, ext) if want_ext else enc
 
-    def mul(self, scalars, pts_ext=None, pts_enc=None, want_ext: bool = False, want_ok: bool = False):
+    def mul(self, scalars, pts_ext=None, pts_enc=None, want_ext: bool = False, want_ok: bool = False, ext_only: bool = False):
+        if ext_only:
+            s = _u8(scalars, 32, "scalars")
+            px = np.ascontiguousarray(pts_ext, dtype=np.int32).reshape(-1, 40)
+            _rows(px, s.shape[0], "pts_ext")
+            ext = np.empty((s.shape[0], 40), dtype=np.int32)
+            _check(self.lib.kyb_mul_batch(_ptr(s), None, _ptr(px), s.shape[0], None, _ptr(ext), None), "kyb_mul_batch")
+            return ext
         s = _u8(scalars, 32, "scalars")
         n = s.shape[0]
         pe = None if pts_enc is None else _u8(pts_enc, 32, "pts_enc")

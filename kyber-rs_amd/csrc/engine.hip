@@ -105,6 +105,7 @@ struct Ctx {
   std::atomic<int> opt_finish_min{1};         // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size; cross-check)
   std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: chunks that alternate between the two lanes
+  std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
   std::atomic<int> opt_poly_segments{0};         // PubPoly::eval, small batches: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never split, 2..32)
   std::atomic<int> opt_verify_by_enc{1};         // large verification batches: compare the encoding of s*B - h*A with R's bytes, decode R only on a mismatch
   std::atomic<int> opt_coop_verify_max{512};     // verification: up to this many signatures take the single-launch kernel (three wavefronts each)
@@ -801,7 +802,8 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
     }
     ProfScope ps(g, st, KID_MUL_COOP);
     LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, 0, nullptr, 0, 0, take_done_flag(g, st, n), 0,
-                              2 * n <= (size_t)g.opt_coop_verify_max ? 4 : 1));      // very few items (measured: up to 256): four wavefronts share an item's scalar
+                              2 * n <= (size_t)g.opt_coop_verify_max ? 4 : 1,      // very few items (measured: up to 256): four wavefronts share an item's scalar
+                              g.opt_ext_projective != 0));
     return KYB_OK;
   }
   if (g.opt_mul_algo == 1) {
@@ -870,7 +872,8 @@ int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t*
   if (n <= (size_t)g.opt_coop_base_max) {
     ProfScope ps(g, st, KID_MUL_BASE_COOP);
     LAUNCHCK(launch::mul_base_coop(st, sc, n, oenc, oext, image64(g), nullptr, 0, 0, nullptr, 0, take_done_flag(g, st, n),
-                                   n <= 2 * (size_t)g.opt_coop_verify_max ? 4 : 1));      // few items (measured: up to 1,024): four wavefronts share an item's 43 windows
+                                   n <= 2 * (size_t)g.opt_coop_verify_max ? 4 : 1,      // few items (measured: up to 1,024): four wavefronts share an item's 43 windows
+                                   g.opt_ext_projective != 0));
     return KYB_OK;
   }
   if (use_split(g, n)) {

@@ -46,8 +46,24 @@ __device__ __forceinline__ void coop_affine(const lane_consts& c, cq q, fe& x, f
 // encode (and optionally affine limbs) from a point (X : Y : Z) in rows 0..2 of a tight quad; Z^-1 computed cooperatively.
 // proj != nullptr: the point also goes to staging record proj_offset + i for k_verify_final — affine (Z = 1) next to an
 // encoding or limbs, as it is (projective, no inversion at all) when it is the only output.
+// ext_proj (option ext.projective): a call that only asks for extended limbs gets the point as it is, (X : Y : Z : T) with Z != 1 —
+// what the reference's own Point holds after a multiplication — and the 265-multiplication inversion waits for a marshal_binary;
+// has_t: row 3 of q already holds T = X Y / Z.
 __device__ __forceinline__ void coop_finish(const lane_consts& c, cq q, uint32_t negate_x,
-                                            uint8_t* out_enc, int32_t* out_ext, size_t i, uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0) {
+                                            uint8_t* out_enc, int32_t* out_ext, size_t i, uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0,
+                                            bool ext_proj = false, bool has_t = false) {
+  if (ext_proj && out_enc == nullptr && out_ext != nullptr && proj == nullptr) {
+    if (!has_t) {                                                        // (X : Y : Z) -> (X Z : Y Z : Z^2 : X Y)
+      const cq zz = bperm(rowperm_idx(c, 2, 2, 2, 2), q), xy = bperm(rowperm_idx(c, 0, 1, 2, 0), q), yy = bperm(rowperm_idx(c, 1, 1, 1, 1), q);
+      q = cmul4(c, xy, c.row == 3 ? yy : zz);
+    }
+    const cq ng = cnorm(c, c.p2 - q);                                    // rows 0, 3: -X, -T
+    q = ((c.row == 0 || c.row == 3) && negate_x) ? ng : q;
+    fe X, Y, Z, T;
+    fe_from_quad_row(c, X, q, 0); fe_from_quad_row(c, Y, q, 1); fe_from_quad_row(c, Z, q, 2); fe_from_quad_row(c, T, q, 3);
+    if (c.lane == 0) store_ext(out_ext, i, X, Y, Z, T);
+    return;
+  }
   const cq nq = cnorm(c, c.p2 - q);                                    // row 0: -X
   q = (c.row == 0 && negate_x) ? nq : q;
   if (out_enc == nullptr && out_ext == nullptr) {
@@ -304,7 +320,7 @@ __device__ __forceinline__ void coop_ladder_run(const lane_consts& c, const uint
 // 3 additions instead of 256 ladder steps (a doubling is half a step).  Same instruction stream for every scalar.
 __global__ void __launch_bounds__(256)
 k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
-           int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, size_t pt_mod, int waves, kyb::launch::DoneFlag df) {
+           int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, size_t pt_mod, int waves, int ext_proj, kyb::launch::DoneFlag df) {
   __shared__ uint32_t sh_part[3 * 40];
   const size_t i = blockIdx.x;
   if (i >= n) return;
@@ -326,7 +342,7 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
     coop_ladder_run(c, mag, skip_bits, M, SX, SZ);
     // y-recovery, exceptional cases, encoding
     const cq RES = coop_mont_recover(c, M, SX, SZ, p_flags, mag[0] & 1u, neg);
-    coop_finish(c, RES, 0u, out_enc, out_ext, i, proj, proj_stride, proj_offset);
+    coop_finish(c, RES, 0u, out_enc, out_ext, i, proj, proj_stride, proj_offset, ext_proj != 0, false);
     if (c.lane == 0) signal_done(df);
     return;
   }
@@ -351,7 +367,7 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
     const cq o = c.active ? sh_part[(w - 1) * 40 + 10 * c.row + c.k] : 0u;
     q = coop_add(c, q, coop_to_cached(c, o));
   }
-  coop_finish(c, q, neg, out_enc, out_ext, i, proj, proj_stride, proj_offset);
+  coop_finish(c, q, neg, out_enc, out_ext, i, proj, proj_stride, proj_offset, ext_proj != 0, true);
   if (c.lane == 0) signal_done(df);
 }
 
@@ -541,7 +557,7 @@ __device__ __forceinline__ cq coop_base_mul(const lane_consts& c, const uint32_t
 __global__ void __launch_bounds__(256)
 k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ scalars_b, size_t n_a, size_t n, uint8_t* __restrict__ out_enc,
                 int32_t* __restrict__ out_ext, const uint32_t* __restrict__ image64, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset,
-                int waves, kyb::launch::DoneFlag df) {
+                int waves, int ext_proj, kyb::launch::DoneFlag df) {
   __shared__ uint32_t sh_part[3 * 40];
   const size_t i = blockIdx.x;
   if (i >= n) return;
@@ -563,7 +579,7 @@ k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__
       h = coop_add(c, h, coop_to_cached(c, o));
     }
   }
-  coop_finish(c, h, neg, out_enc, out_ext, i, proj, proj_stride, proj_offset);
+  coop_finish(c, h, neg, out_enc, out_ext, i, proj, proj_stride, proj_offset, ext_proj != 0, true);
   if (c.lane == 0) signal_done(df);
 }
 
@@ -947,15 +963,15 @@ hipError_t poly_eval_seg(hipStream_t st, const int32_t* commits, int t, const ui
   return hipGetLastError();
 }
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
-                    uint4* proj, size_t proj_stride, size_t proj_offset, DoneFlag df, size_t pt_mod, int waves) {
+                    uint4* proj, size_t proj_stride, size_t proj_offset, DoneFlag df, size_t pt_mod, int waves, bool ext_proj) {
   hipLaunchKernelGGL(k_mul_coop, dim3((unsigned)n), dim3(64u * (unsigned)waves), 0, st, sc, pext, n, oenc, oext, skip_bits, proj, proj_stride, proj_offset, pt_mod,
-                     waves, df);
+                     waves, ext_proj ? 1 : 0, df);
   return hipGetLastError();
 }
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
-                         uint4* proj, size_t proj_stride, size_t proj_offset, const uint8_t* sc_b, size_t n_b, DoneFlag df, int waves) {
+                         uint4* proj, size_t proj_stride, size_t proj_offset, const uint8_t* sc_b, size_t n_b, DoneFlag df, int waves, bool ext_proj) {
   hipLaunchKernelGGL(k_mul_base_coop, dim3((unsigned)(n + n_b)), dim3(64u * (unsigned)waves), 0, st, sc, sc_b, n, n + n_b, oenc, oext, image64, proj, proj_stride, proj_offset,
-                     waves, df);
+                     waves, ext_proj ? 1 : 0, df);
   return hipGetLastError();
 }
 }}  // namespace kyb::launch

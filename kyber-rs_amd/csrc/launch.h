@@ -73,14 +73,14 @@ hipError_t poly_eval_seg(hipStream_t st, const int32_t* commits, int t, const ui
                          uint32_t* part, uint8_t* oenc, int32_t* oext, DoneFlag df = DoneFlag{});
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
                     uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, DoneFlag df = DoneFlag{}, size_t pt_mod = 0,
-                    int waves = 1);      // waves: 1, or 4 wavefronts per item (64-bit pieces of the scalar)
+                    int waves = 1, bool ext_proj = false);      // waves: 1, or 4 wavefronts per item (64-bit pieces of the scalar); ext_proj: option ext.projective
 // proj != nullptr: projective staging record i * src_mul, else the 40 reference limbs of point i
 hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul,
                        DoneFlag df = DoneFlag{});
 // sc_b != nullptr: n_b more scalars follow the first n in the same launch (their results behind the first n)
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
                          uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, const uint8_t* sc_b = nullptr, size_t n_b = 0,
-                         DoneFlag df = DoneFlag{}, int waves = 1);      // waves: 1, or 4 wavefronts per item sharing the 43 windows
+                         DoneFlag df = DoneFlag{}, int waves = 1, bool ext_proj = false);      // waves: 1, or 4 wavefronts per item sharing the 43 windows
 hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* image64);
 
 // ---- kernels_verify.hip ----

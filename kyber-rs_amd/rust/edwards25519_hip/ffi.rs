@@ -13,6 +13,7 @@ pub const KYB_ABI_VERSION: c_int = 2;
 extern "C" {
     pub fn kyb_abi_version() -> c_int;
     pub fn kyb_init(device: c_int) -> c_int;
+    pub fn kyb_set_option(key: *const c_char, value: c_int) -> c_int;
     pub fn kyb_shutdown();
     pub fn kyb_last_error() -> *const c_char;
     pub fn kyb_sync(stream: *mut c_void) -> c_int;
@@ -69,6 +70,9 @@ pub fn ensure_init() {
             assert_eq!(kyb_abi_version(), KYB_ABI_VERSION, "libkyber_ed25519_hip.so has another ABI version");
         }
         must(unsafe { kyb_init(dev) }, "kyb_init");
+        // a Point keeps extended coordinates, as the reference's does: take them projective (no inversion per multiplication;
+        // marshal_binary pays it when an encoding is wanted)
+        must(unsafe { kyb_set_option(b"ext.projective\0".as_ptr() as *const c_char, 1) }, "kyb_set_option(ext.projective)");
     });
 }
 

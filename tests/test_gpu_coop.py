@@ -247,6 +247,37 @@ def test_structured_fuzz_on_the_small_batch_kernels(coop_engine, oracle):
     P.test_structured_fuzz_against_oracle(coop_engine, oracle)
 
 
+def test_projective_extended_results_on_request(oracle):
+    """option ext.projective: a small-batch multiplication asked for extended limbs ONLY hands the point over as (X : Y : Z : T) with
+    Z != 1 (no inversion) — the encodings of those points, and everything computed from them, are unchanged"""
+    import kyber_rs_amd
+    eng = kyber_rs_amd.Engine(0, private=True)
+    try:
+        eng.set_option("ext.projective", 1)
+        for n in (1, 5, 300, 700, 2000):                                   # four wavefronts per item / one
+            s, k = synth.raw256(n, 51), synth.scalars(n, 52)
+            want_b = oracle.mul_base_batch(s, nthreads=8)
+            eb = eng.mul_base(s, ext_only=True)
+            assert [oracle.encode(e) for e in eb[:40]] == [bytes(w) for w in want_b[:40]]
+            assert any(list(e[20:30]) != [1] + [0] * 9 for e in eb[:8])   # really projective
+            assert np.array_equal(eng.encode(eb), want_b)
+            em = eng.mul(k, pts_ext=eb, ext_only=True)                     # projective points in, projective points out
+            want_m = oracle.mul_batch(k, oracle.mul_base_ext_batch(s), nthreads=8)
+            assert np.array_equal(eng.encode(em), want_m)
+            assert np.array_equal(eng.mul(k, pts_ext=eb), want_m)          # with an encoding asked for: the affine path
+            enc, ext = eng.mul(k, pts_ext=eb, want_ext=True)
+            assert all(list(e[20:30]) == [1] + [0] * 9 for e in ext[:8])
+            assert eng.equal(em, ext).all()
+            sums = eng.add(em, eb)
+            assert [oracle.encode(x) for x in sums[:20]] == [oracle.encode(oracle.add(oracle.decode(bytes(a))[0], oracle.decode(bytes(b))[0])) for a, b in zip(want_m[:20], want_b[:20])]
+        q = [v for v in KATS["quirk_mul"] if v["ok"]]
+        sc = np.frombuffer(b"".join(bytes.fromhex(v["scalar"]) for v in q), dtype=np.uint8).reshape(-1, 32)
+        pts = np.stack([oracle.decode(bytes.fromhex(v["point"]))[0] for v in q])
+        assert [bytes(r).hex() for r in eng.encode(eng.mul(sc, pts_ext=pts, ext_only=True))] == [v["out"] for v in q]
+    finally:
+        eng.close()
+
+
 def test_every_routing_boundary_with_default_options(oracle):
     """a fresh context with the DEFAULT thresholds: batch sizes on both sides of every routing boundary (multi-wavefront kernels up to
     256 / 512 / 1,024 items, mul from encodings up to 1,536, cooperative kernels up to 4,096 / 6,144, batch kernels above), all four

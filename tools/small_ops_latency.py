@@ -20,6 +20,14 @@ def t(fn, reps=60):
     return sorted(ts)[len(ts) // 2] * 1e6
 
 
+def ext_only_rows():
+    eng.set_option("ext.projective", 1)
+    for name, fn in (("mul_base -> ext only, projective", lambda n: eng.mul_base(s[:n], ext_only=True)),
+                     ("mul(ext) -> ext only, projective", lambda n: eng.mul(s[:n], pts_ext=ext[:n], ext_only=True))):
+        print(f"{name}, {t(lambda: fn(1)):.1f}, {t(lambda: fn(64)):.1f}", flush=True)
+    eng.set_option("ext.projective", 0)
+
+
 print("op, n=1 us, n=64 us")
 for name, fn in (("encode", lambda n: eng.encode(ext[:n])), ("decode", lambda n: eng.decode(enc[:n])), ("add", lambda n: eng.add(ext[:n], ext2[:n])),
                  ("equal", lambda n: eng.equal(ext[:n], ext2[:n])), ("mul_base", lambda n: eng.mul_base(s[:n])),
@@ -30,3 +38,4 @@ for name, fn in (("encode", lambda n: eng.encode(ext[:n])), ("decode", lambda n:
                  ("sum(t=8)", lambda n: eng.sum_points(np.tile(ext[None, :8], (n, 1, 1)))),
                  ("lincomb(t=8)", lambda n: eng.lincomb(np.tile(s[None, :8], (n, 1, 1)), pts_ext=np.tile(ext[None, :8], (n, 1, 1))))):
     print(f"{name}, {t(lambda: fn(1)):.1f}, {t(lambda: fn(64)):.1f}", flush=True)
+ext_only_rows()
