@@ -392,14 +392,16 @@ class Engine:
         n = pubs.numel() // 32
         _check(self.lib.kyb_verify_batch_dev(self._dp(pubs), self._dp(msgs), self._dp(msg_off), self._dp(sigs), n, flavor, self._dp(status), ctypes.c_void_p(stream)), "kyb_verify_batch_dev")
 
-    def pubpoly_eval(self, commits_ext, indices, want_ext: bool = False):
+    def pubpoly_eval(self, commits_ext, indices, want_ext: bool = False, ext_only: bool = False):
         """PubPoly::eval of one polynomial (t x 40 limbs) at every index of `indices` (x = index + 1)"""
         c = np.ascontiguousarray(commits_ext, dtype=np.int32).reshape(-1, 40)
         idx = np.ascontiguousarray(indices, dtype=np.uint32)
         n = idx.shape[0]
-        enc = np.empty((n, 32), dtype=np.uint8)
-        ext = np.empty((n, 40), dtype=np.int32) if want_ext else None
+        enc = None if ext_only else np.empty((n, 32), dtype=np.uint8)
+        ext = np.empty((n, 40), dtype=np.int32) if (want_ext or ext_only) else None
         _check(self.lib.kyb_pubpoly_eval_batch(_ptr(c), c.shape[0], _ptr(idx), n, _ptr(enc), _ptr(ext)), "kyb_pubpoly_eval_batch")
+        if ext_only:
+            return ext
         return (enc, ext) if want_ext else enc
 
     def pubpoly_eval_multi(self, commits_ext, indices, want_ext: bool = False):
@@ -415,15 +417,17 @@ class Engine:
         _check(self.lib.kyb_pubpoly_eval_multi_batch(_ptr(c), t, m, _ptr(idx), k, _ptr(enc), _ptr(ext)), "kyb_pubpoly_eval_multi_batch")
         return (enc, ext) if want_ext else enc
 
-    def sum_points(self, pts_ext, want_ext: bool = False):
+    def sum_points(self, pts_ext, want_ext: bool = False, ext_only: bool = False):
         """out[g] = sum_j pts[g, j] for points of shape (m, t, 40)"""
         p = np.ascontiguousarray(pts_ext, dtype=np.int32)
         if p.ndim != 3 or p.shape[2] != 40:
             raise ValueError("pts_ext must have shape (m, t, 40)")
         m, t = p.shape[0], p.shape[1]
-        enc = np.empty((m, 32), dtype=np.uint8)
-        ext = np.empty((m, 40), dtype=np.int32) if want_ext else None
+        enc = None if ext_only else np.empty((m, 32), dtype=np.uint8)
+        ext = np.empty((m, 40), dtype=np.int32) if (want_ext or ext_only) else None
         _check(self.lib.kyb_sum_batch(_ptr(p), m, t, _ptr(enc), _ptr(ext)), "kyb_sum_batch")
+        if ext_only:
+            return ext
         return (enc, ext) if want_ext else enc
 
     def lincomb(self, scalars, pts_ext=None, pts_enc=None, want_ext: bool = False, want_ok: bool = False):

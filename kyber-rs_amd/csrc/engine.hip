@@ -687,7 +687,8 @@ int do_init(int device, bool build_table) {
 int launch_finish(Ctx& g, StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st, size_t src_mul = 1, bool last = false) {
   if (n <= (size_t)g.opt_coop_decode_max) {          // few points: one per wavefront
     ProfScope ps(g, st, KID_FINISH_COOP);
-    LAUNCHCK(launch::finish_coop(st, r->proj, r->proj_items, nullptr, n, oenc, oext, src_mul, last ? take_done_flag(g, st, n) : launch::DoneFlag{}));
+    LAUNCHCK(launch::finish_coop(st, r->proj, r->proj_items, nullptr, n, oenc, oext, src_mul, last ? take_done_flag(g, st, n) : launch::DoneFlag{},
+                                 g.opt_ext_projective != 0));
     return KYB_OK;
   }
   ProfScope ps(g, st, KID_FINISH);
@@ -1096,11 +1097,12 @@ int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* i
       const int len = (int)((t + (size_t)segs - 1) / (size_t)segs);
       int rc = ensure_enc(g, r, 160 * n * (size_t)segs + 256); if (rc) return rc;
       ProfScope ps(g, st, KID_POLY_EVAL_COOP);
-      LAUNCHCK(launch::poly_eval_seg(st, commits, (int)t, idx, n, per_poly, len, segs, reinterpret_cast<uint32_t*>(r->enc), oenc, oext, take_done_flag(g, st, n)));
+      LAUNCHCK(launch::poly_eval_seg(st, commits, (int)t, idx, n, per_poly, len, segs, reinterpret_cast<uint32_t*>(r->enc), oenc, oext, take_done_flag(g, st, n),
+                                     g.opt_ext_projective != 0));
       return KYB_OK;
     }
     ProfScope ps(g, st, KID_POLY_EVAL_COOP);
-    LAUNCHCK(launch::poly_eval_coop(st, commits, (int)t, idx, n, nbits, per_poly, oenc, oext, take_done_flag(g, st, n)));
+    LAUNCHCK(launch::poly_eval_coop(st, commits, (int)t, idx, n, nbits, per_poly, oenc, oext, take_done_flag(g, st, n), g.opt_ext_projective != 0));
     return KYB_OK;
   }
   const bool split = use_split(g, n);

@@ -433,7 +433,7 @@ __device__ __forceinline__ cq coop_horner(const lane_consts& c, const int32_t* _
 // evaluations or fewer this is what a DKG node's verify_deal pass looks like (vss.rs:904-909: n polynomials at its own index).
 __global__ void __launch_bounds__(64)
 k_poly_eval_coop(const int32_t* __restrict__ commits_ext, int t, const uint32_t* __restrict__ indices, size_t n, int nbits, size_t per_poly,
-                 uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, kyb::launch::DoneFlag df) {
+                 uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, int ext_proj, kyb::launch::DoneFlag df) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
   KYB_COOP_CONSTS(c, 1);
@@ -441,7 +441,7 @@ k_poly_eval_coop(const int32_t* __restrict__ commits_ext, int t, const uint32_t*
   const size_t first = per_poly ? (i / per_poly) * (size_t)t : 0;      // first commitment of this item's polynomial
   (void)nbits;
   const cq v = coop_horner(c, commits_ext, first, t, x);
-  coop_finish(c, v, 0u, out_enc, out_ext, i);
+  coop_finish(c, v, 0u, out_enc, out_ext, i, nullptr, 0, 0, ext_proj != 0, true);
   if (c.lane == 0) signal_done(df);
 }
 
@@ -480,7 +480,8 @@ k_poly_eval_seg(const int32_t* __restrict__ commits_ext, int t, const uint32_t* 
   if (c.active) part[b * 40 + 10 * c.row + c.k] = q;
 }
 __global__ void __launch_bounds__(64)
-k_poly_eval_sum(const uint32_t* __restrict__ part, size_t n, int segs, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, kyb::launch::DoneFlag df) {
+k_poly_eval_sum(const uint32_t* __restrict__ part, size_t n, int segs, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, int ext_proj,
+                kyb::launch::DoneFlag df) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
   KYB_COOP_CONSTS(c, 1);
@@ -488,7 +489,7 @@ k_poly_eval_sum(const uint32_t* __restrict__ part, size_t n, int segs, uint8_t* 
   cq q = load(0);
 #pragma unroll 1
   for (int sg = 1; sg < segs; ++sg) q = coop_add(c, q, coop_to_cached(c, load(sg)));
-  coop_finish(c, q, 0u, out_enc, out_ext, i);
+  coop_finish(c, q, 0u, out_enc, out_ext, i, nullptr, 0, 0, ext_proj != 0, true);
   if (c.lane == 0) signal_done(df);
 }
 
@@ -588,7 +589,7 @@ k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__
 // reference limbs of point i.
 __global__ void __launch_bounds__(64)
 k_finish_coop(const uint4* __restrict__ proj, size_t stride, const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc,
-              int32_t* __restrict__ out_ext, size_t src_mul, kyb::launch::DoneFlag df) {
+              int32_t* __restrict__ out_ext, size_t src_mul, int ext_proj, kyb::launch::DoneFlag df) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
   KYB_COOP_CONSTS(c, 1);
@@ -601,7 +602,7 @@ k_finish_coop(const uint4* __restrict__ proj, size_t stride, const int32_t* __re
     const uint32_t v = reinterpret_cast<const uint32_t*>(proj)[((size_t)(w >> 2) * stride + i * src_mul) * 4 + (w & 3u)];
     q = (c.active && c.row < 3) ? v : 0u;                                // staging records hold tight limbs
   }
-  coop_finish(c, q, 0u, out_enc, out_ext, i);
+  coop_finish(c, q, 0u, out_enc, out_ext, i, nullptr, 0, 0, ext_proj != 0, false);
   if (c.lane == 0) signal_done(df);
 }
 
@@ -918,8 +919,9 @@ hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32
   hipLaunchKernelGGL(k_coop_selftest, dim3(1), dim3(64), 0, st, op, A, B, out, image64);
   return hipGetLastError();
 }
-hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul, DoneFlag df) {
-  hipLaunchKernelGGL(k_finish_coop, dim3((unsigned)n), dim3(64), 0, st, proj, stride, pts_ext, n, oenc, oext, src_mul, df);
+hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul, DoneFlag df,
+                       bool ext_proj) {
+  hipLaunchKernelGGL(k_finish_coop, dim3((unsigned)n), dim3(64), 0, st, proj, stride, pts_ext, n, oenc, oext, src_mul, ext_proj ? 1 : 0, df);
   return hipGetLastError();
 }
 hipError_t decode_coop(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok, bool or_identity, DoneFlag df) {
@@ -936,8 +938,8 @@ hipError_t verify_prep_r_coop(hipStream_t st, const uint8_t* sigs, size_t n, uin
   return hipGetLastError();
 }
 hipError_t poly_eval_coop(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly,
-                          uint8_t* oenc, int32_t* oext, DoneFlag df) {
-  hipLaunchKernelGGL(k_poly_eval_coop, dim3((unsigned)n), dim3(64), 0, st, commits, t, idx, n, nbits, per_poly, oenc, oext, df);
+                          uint8_t* oenc, int32_t* oext, DoneFlag df, bool ext_proj) {
+  hipLaunchKernelGGL(k_poly_eval_coop, dim3((unsigned)n), dim3(64), 0, st, commits, t, idx, n, nbits, per_poly, oenc, oext, ext_proj ? 1 : 0, df);
   return hipGetLastError();
 }
 hipError_t sign_coop(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, size_t n,
@@ -955,11 +957,11 @@ hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs,
   return hipGetLastError();
 }
 hipError_t poly_eval_seg(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, size_t per_poly, int len, int segs,
-                         uint32_t* part, uint8_t* oenc, int32_t* oext, DoneFlag df) {
+                         uint32_t* part, uint8_t* oenc, int32_t* oext, DoneFlag df, bool ext_proj) {
   hipLaunchKernelGGL(k_poly_eval_seg, dim3((unsigned)(n * (size_t)segs)), dim3(64), 0, st, commits, t, idx, n, per_poly, len, segs, part);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_poly_eval_sum, dim3((unsigned)n), dim3(64), 0, st, part, n, segs, oenc, oext, df);
+  hipLaunchKernelGGL(k_poly_eval_sum, dim3((unsigned)n), dim3(64), 0, st, part, n, segs, oenc, oext, ext_proj ? 1 : 0, df);
   return hipGetLastError();
 }
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,

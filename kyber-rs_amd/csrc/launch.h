@@ -62,7 +62,7 @@ hipError_t verify_prep_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* 
                             uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf, int32_t* a_ext);
 hipError_t verify_prep_r_coop(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* flags_r, uint4* proj, size_t stride, size_t offset);
 hipError_t poly_eval_coop(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly,
-                          uint8_t* oenc, int32_t* oext, DoneFlag df = DoneFlag{});
+                          uint8_t* oenc, int32_t* oext, DoneFlag df = DoneFlag{}, bool ext_proj = false);
 hipError_t sign_coop(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, size_t n,
                      uint8_t* sig, uint8_t* pub_out, const uint32_t* image64, DoneFlag df = DoneFlag{});
 hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, DoneFlag df = DoneFlag{});
@@ -70,13 +70,13 @@ hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs,
                        const uint32_t* image64, uint8_t* status, DoneFlag df = DoneFlag{});
 // segs wavefronts (2..32) per evaluation, len coefficients each (segs * len >= t); part: n * segs * 40 words of device scratch
 hipError_t poly_eval_seg(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, size_t per_poly, int len, int segs,
-                         uint32_t* part, uint8_t* oenc, int32_t* oext, DoneFlag df = DoneFlag{});
+                         uint32_t* part, uint8_t* oenc, int32_t* oext, DoneFlag df = DoneFlag{}, bool ext_proj = false);
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
                     uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, DoneFlag df = DoneFlag{}, size_t pt_mod = 0,
                     int waves = 1, bool ext_proj = false);      // waves: 1, or 4 wavefronts per item (64-bit pieces of the scalar); ext_proj: option ext.projective
 // proj != nullptr: projective staging record i * src_mul, else the 40 reference limbs of point i
 hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul,
-                       DoneFlag df = DoneFlag{});
+                       DoneFlag df = DoneFlag{}, bool ext_proj = false);
 // sc_b != nullptr: n_b more scalars follow the first n in the same launch (their results behind the first n)
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
                          uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, const uint8_t* sc_b = nullptr, size_t n_b = 0,

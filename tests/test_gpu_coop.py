@@ -274,6 +274,15 @@ def test_projective_extended_results_on_request(oracle):
         sc = np.frombuffer(b"".join(bytes.fromhex(v["scalar"]) for v in q), dtype=np.uint8).reshape(-1, 32)
         pts = np.stack([oracle.decode(bytes.fromhex(v["point"]))[0] for v in q])
         assert [bytes(r).hex() for r in eng.encode(eng.mul(sc, pts_ext=pts, ext_only=True))] == [v["out"] for v in q]
+        # polynomial evaluation (one wavefront per evaluation, and segmented) and sums hand over projective as well
+        commits = eng.mul_base(synth.scalars(150, 53), ext_only=True)
+        idx = np.array([0, 5, 1000], dtype=np.uint32)
+        ref_commits = oracle.mul_base_ext_batch(synth.scalars(150, 53))
+        for t in (9, 150):
+            ev = eng.pubpoly_eval(commits[:t], idx, ext_only=True)
+            assert [bytes(r) for r in eng.encode(ev)] == [oracle.pubpoly_eval(ref_commits[:t], int(i)) for i in idx], t
+        sm = eng.sum_points(commits[:12].reshape(3, 4, 40), ext_only=True)
+        assert np.array_equal(eng.encode(sm), eng.sum_points(commits[:12].reshape(3, 4, 40)))
     finally:
         eng.close()
 
