@@ -58,6 +58,7 @@ struct Prof {
 struct StreamRes {
   hipStream_t stream = nullptr;
   uint4* ws = nullptr; uint4* proj = nullptr; size_t proj_items = 0; uint8_t* enc = nullptr; size_t enc_bytes = 0;
+  uint32_t* part = nullptr; size_t part_items = 0;      // extended quads of a small linear combination's products
   hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_last = nullptr;
   bool used = false, own = false;
   uint64_t last_use = 0;
@@ -500,6 +501,7 @@ void free_slot(StreamRes* r) {
   if (r->ws) (void)hipFree(r->ws);
   if (r->proj) wipe_free_dev(r->proj, r->proj_items * 8 * sizeof(uint4));
   if (r->enc) wipe_free_dev(r->enc, r->enc_bytes);
+  if (r->part) wipe_free_dev(r->part, r->part_items * 160);
   if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->ev_fork); (void)hipEventDestroy(r->ev_join); }
   if (r->ev_last) (void)hipEventDestroy(r->ev_last);
   delete r;
@@ -553,6 +555,19 @@ int ensure_proj(Ctx& g, StreamRes* r, size_t items) {
   hipError_t e = hipMalloc(&r->proj, want * 8 * sizeof(uint4));
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "projective staging allocation", e);
   r->proj_items = want;
+  return KYB_OK;
+}
+// extended quads of k_mul_coop's products for k_sum_coop (40 words per item)
+int ensure_ws_part(Ctx& g, StreamRes* r, size_t items) {
+  (void)g;
+  if (items <= r->part_items) return KYB_OK;
+  HIPCK(hipStreamSynchronize(r->stream));
+  if (r->part) wipe_free_dev(r->part, r->part_items * 160);
+  r->part = nullptr; r->part_items = 0;
+  const size_t want = ((items + (items >> 3)) + 1023) & ~(size_t)1023;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->part), want * 160);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "product staging allocation", e);
+  r->part_items = want;
   return KYB_OK;
 }
 int ensure_enc(Ctx& g, StreamRes* r, size_t bytes) {
@@ -756,6 +771,15 @@ int launch_lincomb(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t
     } else if (ok != nullptr) {
       HIPCK(hipMemsetAsync(ok, 1, np, st));
     }
+    if (t <= 32) {
+      // short sums: the products as extended quads, one wavefront adds a group up and finishes (two launches in all)
+      rc = ensure_ws_part(g, r, n); if (rc) return rc;
+      { ProfScope ps(g, st, KID_MUL_COOP);
+        LAUNCHCK(launch::mul_coop(st, sc, pext, n, nullptr, nullptr, 0, nullptr, 0, 0, launch::DoneFlag{}, shared ? t : 0, 1, false, r->part)); }
+      ProfScope ps(g, st, KID_FINISH_COOP);
+      LAUNCHCK(launch::sum_coop(st, r->part, nullptr, m, t, oenc, oext, g.opt_ext_projective != 0, take_done_flag(g, st, m)));
+      return KYB_OK;
+    }
     ProfScope ps(g, st, KID_MUL_COOP);
     LAUNCHCK(launch::mul_coop(st, sc, pext, n, nullptr, nullptr, 0, r->proj, r->proj_items, 0, launch::DoneFlag{}, shared ? t : 0));
   } else {
@@ -773,6 +797,12 @@ int launch_sum(Ctx& g, const int32_t* pext, size_t m, size_t t, uint8_t* oenc, i
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
   const size_t n = m * t;
+  if (t <= 32 && m <= (size_t)g.opt_coop_base_max) {
+    // short sums of few groups: one group per wavefront, one launch
+    ProfScope ps(g, st, KID_FINISH_COOP);
+    LAUNCHCK(launch::sum_coop(st, nullptr, pext, m, t, oenc, oext, g.opt_ext_projective != 0, take_done_flag(g, st, m)));
+    return KYB_OK;
+  }
   { int rc = ensure_proj(g, r, n); if (rc) return rc; }
   LAUNCHCK(launch::ext_to_proj(st, pext, n, r->proj, r->proj_items));
   { int rc = launch_pair_sums(g, r, m, t, st); if (rc) return rc; }

@@ -6,6 +6,7 @@
 //                     cooperative as well (only the canonical byte encoding runs replicated).  One launch does the whole multiplication.
 //   k_mul_base_coop   Point::mul(s, None)     ge.rs:442-486   the radix-64 table of k_mul_base64 read from global memory (every
 //                     line of a limb's 32 entries is touched whatever the digit), 43 cooperative mixed additions, cooperative inversion.
+//   k_sum_coop        short sums of points (kyb_sum_batch, the tail of a linear combination), one group per wavefront
 //   k_finish_coop     marshal_binary / the finish of a projective staging record, one point per wavefront (cooperative inversion)
 //   k_decode_coop     unmarshal_binary          ge.rs:124-179   ge_decode replicated on all lanes, its square-root chain
 //                     (252 of ~270 dependent multiplications) cooperative
@@ -320,7 +321,8 @@ __device__ __forceinline__ void coop_ladder_run(const lane_consts& c, const uint
 // 3 additions instead of 256 ladder steps (a doubling is half a step).  Same instruction stream for every scalar.
 __global__ void __launch_bounds__(256)
 k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
-           int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, size_t pt_mod, int waves, int ext_proj, kyb::launch::DoneFlag df) {
+           int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, size_t pt_mod, int waves, int ext_proj, uint32_t* __restrict__ part,
+           kyb::launch::DoneFlag df) {
   __shared__ uint32_t sh_part[3 * 40];
   const size_t i = blockIdx.x;
   if (i >= n) return;
@@ -342,6 +344,12 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
     coop_ladder_run(c, mag, skip_bits, M, SX, SZ);
     // y-recovery, exceptional cases, encoding
     const cq RES = coop_mont_recover(c, M, SX, SZ, p_flags, mag[0] & 1u, neg);
+    if (part != nullptr) {                                               // a term of a linear combination: the extended point for k_sum_coop
+      const cq zz = bperm(rowperm_idx(c, 2, 2, 2, 2), RES), xy = bperm(rowperm_idx(c, 0, 1, 2, 0), RES), yy = bperm(rowperm_idx(c, 1, 1, 1, 1), RES);
+      const cq e = cmul4(c, xy, c.row == 3 ? yy : zz);
+      if (c.active) part[i * 40 + 10 * c.row + c.k] = e;
+      return;
+    }
     coop_finish(c, RES, 0u, out_enc, out_ext, i, proj, proj_stride, proj_offset, ext_proj != 0, false);
     if (c.lane == 0) signal_done(df);
     return;
@@ -603,6 +611,27 @@ k_finish_coop(const uint4* __restrict__ proj, size_t stride, const int32_t* __re
     q = (c.active && c.row < 3) ? v : 0u;                                // staging records hold tight limbs
   }
   coop_finish(c, q, 0u, out_enc, out_ext, i, nullptr, 0, 0, ext_proj != 0, false);
+  if (c.lane == 0) signal_done(df);
+}
+
+// out[g] = sum_j P[g t + j] for short sums (kyb_sum_batch, the tail of kyb_lincomb_batch), one group per wavefront: t - 1 cooperative
+// additions, then the finish.  Source: extended quads in `part` (k_mul_coop's products) or the 40 reference limbs per point.
+__global__ void __launch_bounds__(64)
+k_sum_coop(const uint32_t* __restrict__ part, const int32_t* __restrict__ pts_ext, size_t m, size_t t, uint8_t* __restrict__ out_enc,
+           int32_t* __restrict__ out_ext, int ext_proj, kyb::launch::DoneFlag df) {
+  const size_t g = blockIdx.x;
+  if (g >= m) return;
+  KYB_COOP_CONSTS(c, 1);
+  auto load = [&](size_t j) -> cq {
+    const size_t i = g * t + j;
+    if (part != nullptr) return c.active ? part[i * 40 + 10 * c.row + c.k] : 0u;
+    const uint32_t word = c.active ? (uint32_t)pts_ext[40 * i + 10 * c.row + c.k] : 0u;
+    return cnorm(c, c.active ? word + (c.p2 << 3) : 0u);
+  };
+  cq q = load(0);
+#pragma unroll 1
+  for (size_t j = 1; j < t; ++j) q = coop_add(c, q, coop_to_cached(c, load(j)));
+  coop_finish(c, q, 0u, out_enc, out_ext, g, nullptr, 0, 0, ext_proj != 0, true);
   if (c.lane == 0) signal_done(df);
 }
 
@@ -924,6 +953,10 @@ hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const i
   hipLaunchKernelGGL(k_finish_coop, dim3((unsigned)n), dim3(64), 0, st, proj, stride, pts_ext, n, oenc, oext, src_mul, ext_proj ? 1 : 0, df);
   return hipGetLastError();
 }
+hipError_t sum_coop(hipStream_t st, const uint32_t* part, const int32_t* pts_ext, size_t m, size_t t, uint8_t* oenc, int32_t* oext, bool ext_proj, DoneFlag df) {
+  hipLaunchKernelGGL(k_sum_coop, dim3((unsigned)m), dim3(64), 0, st, part, pts_ext, m, t, oenc, oext, ext_proj ? 1 : 0, df);
+  return hipGetLastError();
+}
 hipError_t decode_coop(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok, bool or_identity, DoneFlag df) {
   hipLaunchKernelGGL(k_decode_coop, dim3((unsigned)n), dim3(64), 0, st, enc, n, out_ext, ok, or_identity ? 1 : 0, df);
   return hipGetLastError();
@@ -965,9 +998,9 @@ hipError_t poly_eval_seg(hipStream_t st, const int32_t* commits, int t, const ui
   return hipGetLastError();
 }
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
-                    uint4* proj, size_t proj_stride, size_t proj_offset, DoneFlag df, size_t pt_mod, int waves, bool ext_proj) {
+                    uint4* proj, size_t proj_stride, size_t proj_offset, DoneFlag df, size_t pt_mod, int waves, bool ext_proj, uint32_t* part) {
   hipLaunchKernelGGL(k_mul_coop, dim3((unsigned)n), dim3(64u * (unsigned)waves), 0, st, sc, pext, n, oenc, oext, skip_bits, proj, proj_stride, proj_offset, pt_mod,
-                     waves, ext_proj ? 1 : 0, df);
+                     waves, ext_proj ? 1 : 0, part, df);
   return hipGetLastError();
 }
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
