@@ -75,8 +75,12 @@ def set_random_options():
 
 counts = {}
 t_end = time.time() + budget
+t_note = time.time() + 60
 cases = 0
 while time.time() < t_end:
+    if time.time() > t_note:                 # a long run shows that it is alive
+        print(f"... {cases} cases so far", flush=True)
+        t_note = time.time() + 60
     opts = set_random_options()
     n = int(rng.choice(SIZES)) if rng.integers(0, 3) else int(rng.integers(1, 900))
     lo = int(rng.integers(0, NMAX - n + 1))
