@@ -24,6 +24,8 @@
  *              slot (up to 32 streams registered at a time; kyb_stream_release frees one, beyond 32 the least recently
  *              used slot is recycled after its last launch); their launch bookkeeping is serialised per context.
  *              kyb_set_option / kyb_profile_* are safe against concurrent launches.
+ *              Concurrent small calls of several contexts need hardware queues: kyb_init / kyb_ctx_create set GPU_MAX_HW_QUEUES=16
+ *              (the ROCm default is 4) when the variable is unset and the HIP runtime has not been started by the host program.
  *   memory     the caller owns every buffer; the library keeps no pointer after return.
  *
  * Two flavours of every batch call:
