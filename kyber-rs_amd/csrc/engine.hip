@@ -249,6 +249,7 @@ int wait_done(Ctx& g, const DoneReq& req) {
 #else
       std::this_thread::yield();
 #endif
+      if (it > 4096 && (it & 63) == 0) std::this_thread::yield();           // more waiting threads than cores: let the others run
       if ((it & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;      // a long batch: let the runtime wait
     }
     if (*f == req.seq) { std::atomic_thread_fence(std::memory_order_acquire); return KYB_OK; }
