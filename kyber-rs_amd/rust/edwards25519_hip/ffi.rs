@@ -62,18 +62,47 @@ extern "C" {
 
 static INIT: Once = Once::new();
 
-/// `kyb_init(KYBER_HIP_DEVICE or 0)` once per process; every trait method calls it first (cheap after the first time).
-pub fn ensure_init() {
-    INIT.call_once(|| {
-        let dev = std::env::var("KYBER_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
-        unsafe {
-            assert_eq!(kyb_abi_version(), KYB_ABI_VERSION, "libkyber_ed25519_hip.so has another ABI version");
-        }
-        must(unsafe { kyb_init(dev) }, "kyb_init");
+fn device() -> c_int {
+    std::env::var("KYBER_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0)
+}
+
+/// Host-pointer calls of ONE context are serialised (its staging buffers and streams are one set), so every thread of the
+/// process gets a context of its own on first use: N threads then run N small calls on the GPU at the same time
+/// (`profiles/r02/concurrent_small_calls.log`: 16 threads, 175,000 `mul(s, None)` per second).  Options belong to a context.
+struct ThreadCtx(*mut kyb_ctx);
+impl ThreadCtx {
+    fn new() -> Self {
+        let mut c: *mut kyb_ctx = std::ptr::null_mut();
+        must(unsafe { kyb_ctx_create(device(), 1, &mut c) }, "kyb_ctx_create");
+        must(unsafe { kyb_ctx_set_current(c) }, "kyb_ctx_set_current");
         // a Point keeps extended coordinates, as the reference's does: take them projective (no inversion per multiplication;
         // marshal_binary pays it when an encoding is wanted)
         must(unsafe { kyb_set_option(b"ext.projective\0".as_ptr() as *const c_char, 1) }, "kyb_set_option(ext.projective)");
+        ThreadCtx(c)
+    }
+}
+impl Drop for ThreadCtx {
+    fn drop(&mut self) {
+        unsafe {
+            kyb_ctx_set_current(std::ptr::null_mut());
+            kyb_ctx_destroy(self.0);
+        }
+    }
+}
+thread_local! {
+    static TL_CTX: ThreadCtx = ThreadCtx::new();
+}
+
+/// `kyb_init(KYBER_HIP_DEVICE or 0)` once per process and a context per thread; every trait method calls it first (cheap after the
+/// first time).
+pub fn ensure_init() {
+    INIT.call_once(|| {
+        unsafe {
+            assert_eq!(kyb_abi_version(), KYB_ABI_VERSION, "libkyber_ed25519_hip.so has another ABI version");
+        }
+        must(unsafe { kyb_init(device()) }, "kyb_init");
     });
+    TL_CTX.with(|_| ());
 }
 
 /// The trait methods are infallible (`mul` returns `Self`, group.rs:139): an engine failure cannot be reported and panics.
