@@ -255,6 +255,23 @@ int kyb_lincomb_batch_dev(const uint8_t* scalars, const uint8_t* pts_enc, const 
 int kyb_sum_batch(const int32_t* pts_ext, size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext);
 int kyb_sum_batch_dev(const int32_t* pts_ext, size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext, void* stream);
 
+/* ---- the same two, from the wire format (the data format on the caller's side of N1) ---- */
+/* A Deal carries its dealer's commitments as 32-byte encodings (vss/pedersen/vss.rs:113-124, Deal.commitments; the
+ * reference unmarshals them one by one, point.rs:43-51, before PubPoly::eval / PubPoly::add see them).  These entry
+ * points take the encodings as they arrive and decode on the GPU: 32 instead of 160 bytes per commitment over PCIe
+ * and no host-side decode.  ok (may be NULL) gets one flag per encoding; one that does not decode counts as the
+ * neutral element, as in kyb_lincomb_batch — the caller rejects that dealer, as the reference's unmarshal error does.
+ *   kyb_pubpoly_eval_multi_enc_batch: commits_enc = m x t x 32 bytes, polynomial g = encodings [g*t, (g+1)*t).
+ *   kyb_sum_enc_batch: item_major == 0: out[g] = sum_j pts[g*t + j]  (as kyb_sum_batch)
+ *                      item_major != 0: out[g] = sum_j pts[j*m + g]  — t dealers' polynomials of m coefficients each, in
+ *                      the order they were received; no transposition on the host. */
+int kyb_pubpoly_eval_multi_enc_batch(const uint8_t* commits_enc, size_t t, size_t m, const uint32_t* indices, size_t k,
+                                     uint8_t* out_enc, int32_t* out_ext, uint8_t* ok);
+int kyb_pubpoly_eval_multi_enc_batch_dev(const uint8_t* commits_enc, size_t t, size_t m, const uint32_t* indices, size_t k, uint32_t max_index,
+                                         uint8_t* out_enc, int32_t* out_ext, uint8_t* ok, void* stream);
+int kyb_sum_enc_batch(const uint8_t* pts_enc, size_t m, size_t t, int item_major, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok);
+int kyb_sum_enc_batch_dev(const uint8_t* pts_enc, size_t m, size_t t, int item_major, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok, void* stream);
+
 /* ---- Point::eq, point.rs:227-241 -------------------------------------------- */
 /* eq[i] = 1 iff a[i] and b[i] have the same encoding (the reference compares the two encodings = two
  * inversions; here a projective cross-multiplication).  Records with Z = 0 (`Point::default()`) behave as in the

@@ -42,6 +42,7 @@ ABI_SYMBOLS = [
     "kyb_pubpoly_eval_multi_batch", "kyb_pubpoly_eval_multi_batch_dev",
     "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev",
     "kyb_sum_batch", "kyb_sum_batch_dev",
+    "kyb_pubpoly_eval_multi_enc_batch", "kyb_pubpoly_eval_multi_enc_batch_dev", "kyb_sum_enc_batch", "kyb_sum_enc_batch_dev",
     "kyb_host_alloc", "kyb_host_free",
     "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
 ]
@@ -126,6 +127,10 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_pubpoly_eval_multi_batch_dev.argtypes = [vp, sz, sz, vp, sz, ctypes.c_uint32, vp, vp, vp]
     lib.kyb_sum_batch.argtypes = [vp, sz, sz, vp, vp]
     lib.kyb_sum_batch_dev.argtypes = [vp, sz, sz, vp, vp, vp]
+    lib.kyb_pubpoly_eval_multi_enc_batch.argtypes = [vp, sz, sz, vp, sz, vp, vp, vp]
+    lib.kyb_pubpoly_eval_multi_enc_batch_dev.argtypes = [vp, sz, sz, vp, sz, ctypes.c_uint32, vp, vp, vp, vp]
+    lib.kyb_sum_enc_batch.argtypes = [vp, sz, sz, i32, vp, vp, vp]
+    lib.kyb_sum_enc_batch_dev.argtypes = [vp, sz, sz, i32, vp, vp, vp, vp]
     lib.kyb_equal_batch.argtypes = [vp, vp, sz, vp]
     lib.kyb_equal_batch_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.kyb_lincomb_batch.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp]
@@ -416,6 +421,33 @@ class Engine:
         ext = np.empty((m, k, 40), dtype=np.int32) if want_ext else None
         _check(self.lib.kyb_pubpoly_eval_multi_batch(_ptr(c), t, m, _ptr(idx), k, _ptr(enc), _ptr(ext)), "kyb_pubpoly_eval_multi_batch")
         return (enc, ext) if want_ext else enc
+
+    def pubpoly_eval_multi_enc(self, commits_enc, indices, want_ext: bool = False):
+        """as pubpoly_eval_multi, the commitments as wire encodings (m, t, 32) -> (encodings (m, k, 32)[, ext], ok (m, t))"""
+        c = np.ascontiguousarray(commits_enc, dtype=np.uint8)
+        if c.ndim != 3 or c.shape[2] != 32:
+            raise ValueError("commits_enc must have shape (m, t, 32)")
+        m, t = c.shape[0], c.shape[1]
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(m, -1)
+        k = idx.shape[1]
+        enc = np.empty((m, k, 32), dtype=np.uint8)
+        ext = np.empty((m, k, 40), dtype=np.int32) if want_ext else None
+        ok = np.empty((m, t), dtype=np.uint8)
+        _check(self.lib.kyb_pubpoly_eval_multi_enc_batch(_ptr(c), t, m, _ptr(idx), k, _ptr(enc), _ptr(ext), _ptr(ok)), "kyb_pubpoly_eval_multi_enc_batch")
+        return (enc, ext, ok) if want_ext else (enc, ok)
+
+    def sum_points_enc(self, pts_enc, item_major: bool = False, want_ext: bool = False):
+        """sums of wire encodings: pts_enc (m, t, 32) -> out[g] = sum_j pts[g, j]; item_major: pts_enc (t, m, 32) -> out[g] = sum_j pts[j, g]
+        (t dealers' polynomials of m coefficients, as received).  Returns (encodings (m, 32)[, ext], ok in the shape of the input)."""
+        p = np.ascontiguousarray(pts_enc, dtype=np.uint8)
+        if p.ndim != 3 or p.shape[2] != 32:
+            raise ValueError("pts_enc must have shape (m, t, 32) or, item_major, (t, m, 32)")
+        m, t = (p.shape[1], p.shape[0]) if item_major else (p.shape[0], p.shape[1])
+        enc = np.empty((m, 32), dtype=np.uint8)
+        ext = np.empty((m, 40), dtype=np.int32) if want_ext else None
+        ok = np.empty(p.shape[:2], dtype=np.uint8)
+        _check(self.lib.kyb_sum_enc_batch(_ptr(p), m, t, int(item_major), _ptr(enc), _ptr(ext), _ptr(ok)), "kyb_sum_enc_batch")
+        return (enc, ext, ok) if want_ext else (enc, ok)
 
     def sum_points(self, pts_ext, want_ext: bool = False, ext_only: bool = False):
         """out[g] = sum_j pts[g, j] for points of shape (m, t, 40)"""

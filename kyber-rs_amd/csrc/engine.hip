@@ -801,22 +801,37 @@ int launch_lincomb(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t
   return launch_finish(g, r, m, oenc, oext, st, t, true);
 }
 
-// out[g] = sum_j P[g*t + j]: the halving passes of launch_lincomb on the points themselves
-int launch_sum(Ctx& g, const int32_t* pext, size_t m, size_t t, uint8_t* oenc, int32_t* oext, hipStream_t st) {
+// out[g] = sum_j P[g*t + j]: the halving passes of launch_lincomb on the points themselves.
+// penc != nullptr: the points come as wire encodings (decoded here, ok[i] per encoding, failed decodes = neutral element);
+// item_major (encodings only): point j of group g is encoding j*m + g — t dealers' polynomials of m coefficients each, as received.
+int launch_sum(Ctx& g, const int32_t* pext, const uint8_t* penc, uint8_t* ok, bool item_major, size_t m, size_t t, uint8_t* oenc, int32_t* oext, hipStream_t st) {
   if (m == 0) return KYB_OK;
   std::lock_guard<std::mutex> launch_lock(g.launch_mu);
   StreamRes* r = nullptr;
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
   const size_t n = m * t;
-  if (t <= 32 && m <= (size_t)g.opt_coop_base_max) {
+  const bool small = t <= 32 && m <= (size_t)g.opt_coop_base_max;
+  if (penc != nullptr && small && !item_major) {
+    int rc = ensure_ws_part(g, r, n); if (rc) return rc;
+    ProfScope ps(g, st, KID_DECODE_COOP);
+    LAUNCHCK(launch::decode_coop(st, penc, n, reinterpret_cast<int32_t*>(r->part), ok, true));
+    pext = reinterpret_cast<const int32_t*>(r->part);
+    penc = nullptr;
+  }
+  if (penc == nullptr && small) {
     // short sums of few groups: one group per wavefront, one launch
     ProfScope ps(g, st, KID_FINISH_COOP);
     LAUNCHCK(launch::sum_coop(st, nullptr, pext, m, t, oenc, oext, g.opt_ext_projective != 0, take_done_flag(g, st, m)));
     return KYB_OK;
   }
   { int rc = ensure_proj(g, r, n); if (rc) return rc; }
-  LAUNCHCK(launch::ext_to_proj(st, pext, n, r->proj, r->proj_items));
+  if (penc != nullptr) {
+    ProfScope ps(g, st, KID_DECODE);
+    LAUNCHCK(launch::decode_to_proj(st, penc, n, r->proj, r->proj_items, ok, item_major ? t : 0, item_major ? m : 0));
+  } else {
+    LAUNCHCK(launch::ext_to_proj(st, pext, n, r->proj, r->proj_items));
+  }
   { int rc = launch_pair_sums(g, r, m, t, st); if (rc) return rc; }
   return launch_finish(g, r, m, oenc, oext, st, t, true);
 }
@@ -1115,13 +1130,28 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   return KYB_OK;
 }
 
+// commits_enc != nullptr: the commitments as wire encodings (what a Deal carries), decoded here first; ok[i] per commitment,
+// a failed decode counts as the neutral element
 int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* idx, size_t n, uint32_t max_index, uint8_t* oenc, int32_t* oext, hipStream_t st,
-                     size_t per_poly = 0) {
+                     size_t per_poly = 0, const uint8_t* commits_enc = nullptr, uint8_t* ok = nullptr) {
   if (n == 0) return KYB_OK;
   std::lock_guard<std::mutex> launch_lock(g.launch_mu);
   StreamRes* r = nullptr;
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
+  if (commits_enc != nullptr) {
+    const size_t np = t * (per_poly ? (n + per_poly - 1) / per_poly : 1);
+    int rc = ensure_ws_part(g, r, np); if (rc) return rc;
+    int32_t* dec = reinterpret_cast<int32_t*>(r->part);
+    if (np <= (size_t)g.opt_coop_decode_max) {
+      ProfScope ps(g, st, KID_DECODE_COOP);
+      LAUNCHCK(launch::decode_coop(st, commits_enc, np, dec, ok, true));
+    } else {
+      ProfScope ps(g, st, KID_DECODE);
+      LAUNCHCK(launch::decode_or_identity(st, commits_enc, np, dec, ok));
+    }
+    commits = dec;
+  }
   int nbits = 1;
   while (nbits < 32 && ((uint64_t)max_index + 1) >> nbits) ++nbits;      // bit length of max x = max_index + 1
   if (n <= (size_t)g.opt_coop_max) {

@@ -2,6 +2,7 @@
 //   k_decode_or_identity   unmarshal_binary of the operands (ge.rs:124-179), failed decodes -> neutral element
 //   k_mont_prep            Montgomery images of the operands, one field inversion per FINISH_K items
 //   k_mul_ladder           Point::mul(s, Some(P))  ge.rs:508-568   Montgomery ladder + y-recovery (ge_ladder.h)
+//   k_decode_to_proj       unmarshal_binary into projective staging records, optionally transposed (kyb_sum_enc_batch)
 //   k_pair_sum             one halving pass of the segmented sums behind kyb_lincomb_batch / kyb_sum_batch
 //   k_ext_to_proj          extended limbs -> projective staging records
 #include <hip/hip_runtime.h>
@@ -24,6 +25,25 @@ k_decode_or_identity(const uint8_t* __restrict__ enc, size_t n, int32_t* __restr
   ge_p3_0(id);
   fe_cmov(P.X, id.X, 1u - ok); fe_cmov(P.Y, id.Y, 1u - ok); fe_cmov(P.Z, id.Z, 1u - ok); fe_cmov(P.T, id.T, 1u - ok);
   store_ext(out_ext, i, P.X, P.Y, P.Z, P.T);
+  if (ok_out != nullptr) ok_out[i] = (uint8_t)ok;
+}
+
+// unmarshal_binary straight into projective staging records (kyb_sum_enc_batch): no extended-limb copy in between.
+// rows > 0: the encodings form a rows x cols matrix (row-major) and the records its transpose, so that the sums over the
+// COLUMNS of the source (coefficient g of every dealer's polynomial) become sums over contiguous records.
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_decode_to_proj(const uint8_t* __restrict__ enc, size_t n, uint4* __restrict__ proj, size_t stride, uint8_t* __restrict__ ok_out, size_t rows, size_t cols) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words8(w, enc, i);
+  ge_p3 P, id;
+  const uint32_t ok = ge_decode(P, w);
+  ge_p3_0(id);
+  fe_cmov(P.X, id.X, 1u - ok); fe_cmov(P.Y, id.Y, 1u - ok); fe_cmov(P.Z, id.Z, 1u - ok);
+  size_t d = i;
+  if (rows != 0) { const size_t rr = i / cols, cc = i - rr * cols; d = cc * rows + rr; }
+  store_proj(proj, stride, d, P.X, P.Y, P.Z);
   if (ok_out != nullptr) ok_out[i] = (uint8_t)ok;
 }
 
@@ -127,6 +147,10 @@ namespace kyb { namespace launch {
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK); }
 hipError_t decode_or_identity(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok) {
   hipLaunchKernelGGL(k_decode_or_identity, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, enc, n, out_ext, ok);
+  return hipGetLastError();
+}
+hipError_t decode_to_proj(hipStream_t st, const uint8_t* enc, size_t n, uint4* proj, size_t stride, uint8_t* ok, size_t rows, size_t cols) {
+  hipLaunchKernelGGL(k_decode_to_proj, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, enc, n, proj, stride, ok, rows, cols);
   return hipGetLastError();
 }
 hipError_t mont_prep(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride) {

@@ -3,7 +3,7 @@
 //
 //   kernels_base.hip      fixed base: table builders, table checksum, k_mul_base64 (the default fixed-base kernel)
 //   kernels_base_alt.hip  radix-32 / radix-16 fixed-base kernels and the fused k_sign (selectable cross-checks)
-//   kernels_ladder.hip    variable base: k_decode_or_identity, k_mont_prep, k_mul_ladder, k_pair_sum, k_ext_to_proj
+//   kernels_ladder.hip    variable base: k_decode_or_identity, k_decode_to_proj, k_mont_prep, k_mul_ladder, k_pair_sum, k_ext_to_proj
 //   kernels_window.hip    windowed variable-base k_mul (mul.algo=0, cross-check of the ladder)
 //   kernels_verify.hip    SHA-512 users: k_verify_prep / _r / _final, k_sign_hash, k_eddsa_prep
 //   kernels_misc.hip      k_finish, k_encode_batched, k_add, k_equal, k_encode, k_decode, k_poly_eval
@@ -41,6 +41,8 @@ hipError_t sign_fused(int mode, int grid, hipStream_t st, const uint8_t* x, cons
 
 // ---- kernels_ladder.hip ----
 hipError_t decode_or_identity(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok);
+// rows != 0: encoding i = (r, c) of a rows x cols matrix lands in record c * rows + r
+hipError_t decode_to_proj(hipStream_t st, const uint8_t* enc, size_t n, uint4* proj, size_t stride, uint8_t* ok, size_t rows, size_t cols);
 hipError_t mont_prep(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride);
 hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, uint4* proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits);
 hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half);

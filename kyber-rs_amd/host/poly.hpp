@@ -158,6 +158,41 @@ inline PubPoly sum_polys(const std::vector<PubPoly>& polys) {
   return r;
 }
 
+// The same two from the wire: the commitments of m deals as they arrive (Deal.commitments, vss/pedersen/vss.rs:113-124: t
+// 32-byte encodings per dealer, dealer after dealer).  The reference unmarshals every one on the CPU (point.rs:43-51) before
+// it can evaluate or add; here the encodings go to the GPU as they are.  A commitment that does not decode raises the
+// reference's unmarshal error for its dealer.
+inline void wire_check(const std::vector<uint8_t>& commits_enc, size_t t) {
+  if (t == 0 || commits_enc.size() % (32 * t) != 0) throw std::invalid_argument("wire commitments: t encodings of 32 bytes per dealer");
+}
+inline std::vector<PubShare> eval_each_wire(const std::vector<uint8_t>& commits_enc, size_t t, const std::vector<uint32_t>& idx) {
+  wire_check(commits_enc, t);
+  const size_t m = commits_enc.size() / (32 * t);
+  if (idx.size() != m) throw std::invalid_argument("eval_each_wire: one index per dealer");
+  if (m == 0) return {};
+  std::vector<int32_t> out(40 * m);
+  std::vector<uint8_t> ok(m * t);
+  group::edwards25519::detail::engine_must(kyb_pubpoly_eval_multi_enc_batch(commits_enc.data(), t, m, idx.data(), 1, nullptr, out.data(), ok.data()), "eval_each_wire");
+  for (uint8_t f : ok) if (!f) throw MarshallingError("invalid Ed25519 curve point");
+  std::vector<PubShare> r(m);
+  for (size_t g = 0; g < m; ++g) { r[g].i = idx[g]; std::memcpy(r[g].v.ge, &out[40 * g], 160); }
+  return r;
+}
+inline PubPoly sum_polys_wire(const std::vector<uint8_t>& commits_enc, size_t t, const std::optional<Point>& base) {
+  wire_check(commits_enc, t);
+  const size_t n = commits_enc.size() / (32 * t);
+  if (n == 0) throw std::invalid_argument("sum_polys_wire: no polynomial");
+  std::vector<int32_t> out(40 * t);
+  std::vector<uint8_t> ok(n * t);
+  group::edwards25519::detail::engine_must(kyb_sum_enc_batch(commits_enc.data(), t, n, 1, nullptr, out.data(), ok.data()), "sum_polys_wire");
+  for (uint8_t f : ok) if (!f) throw MarshallingError("invalid Ed25519 curve point");
+  PubPoly r;
+  r.b = base;
+  r.commits.resize(t);
+  for (size_t j = 0; j < t; ++j) std::memcpy(r.commits[j].ge, &out[40 * j], 160);
+  return r;
+}
+
 // poly.rs:534-563: the first t shares by index; x_i = i + 1
 struct XYCommit { std::vector<size_t> idx; std::vector<Scalar> x; std::vector<Point> y; };
 inline XYCommit xy_commit(const std::vector<std::optional<PubShare>>& shares, size_t t, size_t /*n*/) {

@@ -55,6 +55,10 @@ extern "C" {
     pub fn kyb_lincomb_batch(scalars: *const u8, pts_enc: *const u8, pts_ext: *const i32, shared_points: c_int, m: size_t, t: size_t,
                              out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8) -> c_int;
     pub fn kyb_sum_batch(pts_ext: *const i32, m: size_t, t: size_t, out_enc: *mut u8, out_ext: *mut i32) -> c_int;
+    // the same two on wire encodings (Deal.commitments as received)
+    pub fn kyb_pubpoly_eval_multi_enc_batch(commits_enc: *const u8, t: size_t, m: size_t, indices: *const u32, k: size_t, out_enc: *mut u8,
+                                            out_ext: *mut i32, ok: *mut u8) -> c_int;
+    pub fn kyb_sum_enc_batch(pts_enc: *const u8, m: size_t, t: size_t, item_major: c_int, out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8) -> c_int;
     // page-locked batch buffers (optional: pageable slices work, through the engine's bounce buffers)
     pub fn kyb_host_alloc(bytes: size_t) -> *mut c_void;
     pub fn kyb_host_free(p: *mut c_void);

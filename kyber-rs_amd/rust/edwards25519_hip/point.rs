@@ -132,6 +132,47 @@ pub fn recover_commit_accumulate(lagrange: &[Scalar], shares: &[Point]) -> Point
     out
 }
 
+/// The verifier's side of a DKG round on the deals as they arrive: `commits_enc` holds the `t` 32-byte commitments of every
+/// dealer, dealer after dealer (`Deal.commitments`, vss/pedersen/vss.rs:113-124, before any `unmarshal_binary`), `idx[g]` is the
+/// index dealer g's polynomial is evaluated at (vss.rs:904-909: the verifier's own).  One engine call decodes the m·t points
+/// on the GPU and returns the m evaluations; an encoding that is not a point is the reference's unmarshal error.
+pub fn eval_each_wire(commits_enc: &[u8], t: usize, idx: &[u32]) -> Result<Vec<Point>, MarshallingError> {
+    ensure_init();
+    let m = idx.len();
+    assert!(t > 0 && commits_enc.len() == 32 * t * m);
+    let mut staged = vec![[[0i32; 10]; 4]; m];
+    let mut ok = vec![0u8; m * t];
+    must(
+        unsafe {
+            ffi::kyb_pubpoly_eval_multi_enc_batch(commits_enc.as_ptr(), t, m, idx.as_ptr(), 1, std::ptr::null_mut(), staged.as_mut_ptr() as *mut i32,
+                                                  ok.as_mut_ptr())
+        },
+        "pubpoly_eval_multi_enc",
+    );
+    if ok.iter().any(|&f| f == 0) {
+        return Err(MarshallingError::InvalidInput("invalid Ed25519 curve point".to_owned()));
+    }
+    Ok(staged.into_iter().map(|ge| Point { ge, var_time: false }).collect())
+}
+
+/// The distributed public polynomial (dkg.rs:905-953 folds `PubPoly::add`, poly.rs:486-507, over the dealers) from the same
+/// buffer: coefficient j of the result = sum over the dealers of their commitment j.
+pub fn sum_polys_wire(commits_enc: &[u8], t: usize) -> Result<Vec<Point>, MarshallingError> {
+    ensure_init();
+    assert!(t > 0 && commits_enc.len() % (32 * t) == 0 && !commits_enc.is_empty());
+    let dealers = commits_enc.len() / (32 * t);
+    let mut staged = vec![[[0i32; 10]; 4]; t];
+    let mut ok = vec![0u8; dealers * t];
+    must(
+        unsafe { ffi::kyb_sum_enc_batch(commits_enc.as_ptr(), t, dealers, 1, std::ptr::null_mut(), staged.as_mut_ptr() as *mut i32, ok.as_mut_ptr()) },
+        "sum_enc",
+    );
+    if ok.iter().any(|&f| f == 0) {
+        return Err(MarshallingError::InvalidInput("invalid Ed25519 curve point".to_owned()));
+    }
+    Ok(staged.into_iter().map(|ge| Point { ge, var_time: false }).collect())
+}
+
 /// `schnorr::verify_with_checks` / `eddsa::verify_with_checks` for a batch (every DKG deal / response / DSS partial
 /// signature is verified by every peer).  Returns the per-item status: 0 = valid, else the reference's FIRST failing
 /// check in the order of the chosen flavour (codes in include/kyber_ed25519.h).

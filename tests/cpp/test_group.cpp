@@ -328,6 +328,16 @@ int main() {
       at[4] = 9;
       std::vector<PubShare> got = eval_each(polys, at);
       for (int k = 0; k < 6; ++k) CHECK(got[k].v == Point().mul(pris[k].eval(at[k]).v, nullptr), "eval_each == commit of the private share");
+      // the same deals as they come off the wire: t encodings per dealer
+      std::vector<uint8_t> wire;
+      for (const PubPoly& q : polys) for (const Point& c : q.commits) { std::vector<uint8_t> b = c.marshal_binary(); wire.insert(wire.end(), b.begin(), b.end()); }
+      std::vector<PubShare> gw = eval_each_wire(wire, t, at);
+      for (int k = 0; k < 6; ++k) CHECK(gw[k].v == got[k].v && gw[k].i == got[k].i, "eval_each_wire == eval_each");
+      CHECK(sum_polys_wire(wire, t, polys[0].b).equal(sum_polys(polys)), "sum_polys_wire == sum_polys");
+      std::string werr;
+      wire[32 * 7] = 2; for (int b = 1; b < 32; ++b) wire[32 * 7 + b] = 0;          // y = 2 is not on the curve
+      try { (void)eval_each_wire(wire, t, at); } catch (const MarshallingError& e) { werr = e.what(); }
+      CHECK(werr == "invalid Ed25519 curve point", "eval_each_wire: a commitment that does not decode is the reference's unmarshal error");
     }
     // test_public_add
     Point gp = points[5], h = points[6];

@@ -47,8 +47,13 @@ t0 = time.perf_counter()
 for i in range(8):
     orc.pubpoly_eval(p256[:32], i)
 cpu["eval_per_coeff"] = (time.perf_counter() - t0) / 8 / 32 * 1e3
+t0 = time.perf_counter()
+for e in pub256:
+    orc.decode(bytes(e))
+cpu["unmarshal"] = (time.perf_counter() - t0) / 256 * 1e3                     # incl. the ctypes call (~2 us)
 print("CPU port, 1 thread, ms per op:", {k: round(v, 4) for k, v in cpu.items()})
-print("n, t, gpu_ms_total, cpu_ms_estimate, speedup, breakdown_ms")
+print("n, t, gpu_ms_total, cpu_ms_estimate, speedup, breakdown_ms   [wire: the n*t commitments arrive as 32-byte encodings; GPU total with "
+      "kyb_pubpoly_eval_multi_enc_batch / kyb_sum_enc_batch, CPU estimate with the n*t unmarshal_binary calls the reference makes]")
 for n in args.n:
     t = n * 2 // 3 + 1
     coeffs = synth.scalars(t, 100 + n)
@@ -82,7 +87,13 @@ for n in args.n:
     assert np.array_equal(ev_b, ev)
     by_coeff = np.ascontiguousarray(polys.transpose(1, 0, 2))              # (the node accumulates the incoming polynomials coefficient by coefficient)
     dist, br["dist_poly"] = timed(lambda: eng.sum_points(by_coeff))
+    polys_enc = np.tile(commit_enc[None, :, :], (n, 1, 1))                  # as received: dealer-major, 32 bytes per commitment
+    (ev_w, ok_w), eval_wire_ms = timed(lambda: eng.pubpoly_eval_multi_enc(polys_enc, idx))
+    assert np.array_equal(ev_w, ev) and ok_w.all()
+    (dist_w, ok_w), dist_wire_ms = timed(lambda: eng.sum_points_enc(polys_enc, item_major=True))
+    assert np.array_equal(dist_w, dist) and ok_w.all()
     assert bytes(commit_enc[1]) == orc.mul(bytes(coeffs[1]), orc.base()) and bytes(dh[3]) == orc.mul(bytes(longterm[0]), orc.decode(bytes(pubs[3]))[0])
     gpu_ms = sum(br.values())
     cpu_ms = t * cpu["mul"] + n * (cpu["sign"] + cpu["mul"]) + n * (cpu["verify"] + cpu["mul"]) + n * (cpu["mul_base"] + t * cpu["eval_per_coeff"]) + n * t * 0.0005
-    print(f"{n}, {t}, {gpu_ms:.2f}, {cpu_ms:.0f}, {cpu_ms / gpu_ms:.0f}x, " + " ".join(f"{k}={v:.2f}" for k, v in br.items()) + f" (eval with the batch kernel: {eval_batch_ms:.2f})", flush=True)
+    print(f"{n}, {t}, {gpu_ms:.2f}, {cpu_ms:.0f}, {cpu_ms / gpu_ms:.0f}x, " + " ".join(f"{k}={v:.2f}" for k, v in br.items()) + f" (eval with the batch kernel: {eval_batch_ms:.2f})"
+          + f"   [wire: {gpu_ms - br['eval'] - br['dist_poly'] + eval_wire_ms + dist_wire_ms:.2f} ms, eval={eval_wire_ms:.2f} dist_poly={dist_wire_ms:.2f}; CPU {cpu_ms + n * t * cpu['unmarshal']:.0f} ms]", flush=True)
