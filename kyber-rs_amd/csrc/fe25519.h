@@ -105,8 +105,13 @@ KYB_HD uint32_t kyb_x2(uint32_t a, const char* what) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(KYB_NO_ASM_COLUMNS)
 #define KYB_ASM_COLUMNS 1
 #define KYB_M1(a, b) "v_mad_u64_u32 %0, vcc, %" #a ", %" #b ", %0\n\t"
+#if defined(KYB_EXPERIMENT_EXTRA_NOPS)      // what does an s_nop cost?  (tools/ab_kernels.py, profiles/r02/ab_extra_nops.log)
+#define KYB_COL_TAIL "s_nop 0\n\t"
+#else
+#define KYB_COL_TAIL
+#endif
 __device__ __forceinline__ uint64_t kyb_col10(uint64_t acc, const uint32_t* A, const uint32_t* B) {
-  asm(KYB_M1(1, 11) KYB_M1(2, 12) KYB_M1(3, 13) KYB_M1(4, 14) KYB_M1(5, 15) KYB_M1(6, 16) KYB_M1(7, 17) KYB_M1(8, 18) KYB_M1(9, 19) KYB_M1(10, 20)
+  asm(KYB_M1(1, 11) KYB_M1(2, 12) KYB_M1(3, 13) KYB_M1(4, 14) KYB_M1(5, 15) KYB_M1(6, 16) KYB_M1(7, 17) KYB_M1(8, 18) KYB_M1(9, 19) KYB_M1(10, 20) KYB_COL_TAIL
       : "+v"(acc)
       : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(A[6]), "v"(A[7]), "v"(A[8]), "v"(A[9]),
         "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]), "v"(B[5]), "v"(B[6]), "v"(B[7]), "v"(B[8]), "v"(B[9])
@@ -117,7 +122,7 @@ __device__ __forceinline__ uint64_t kyb_col10(uint64_t acc, const uint32_t* A, c
 // first column of a product: the accumulator starts at the literal 0 (no v_mov_b64 to clear a register pair)
 __device__ __forceinline__ uint64_t kyb_col10z(const uint32_t* A, const uint32_t* B) {
   uint64_t acc;
-  asm(KYB_M0(1, 11) KYB_M1(2, 12) KYB_M1(3, 13) KYB_M1(4, 14) KYB_M1(5, 15) KYB_M1(6, 16) KYB_M1(7, 17) KYB_M1(8, 18) KYB_M1(9, 19) KYB_M1(10, 20)
+  asm(KYB_M0(1, 11) KYB_M1(2, 12) KYB_M1(3, 13) KYB_M1(4, 14) KYB_M1(5, 15) KYB_M1(6, 16) KYB_M1(7, 17) KYB_M1(8, 18) KYB_M1(9, 19) KYB_M1(10, 20) KYB_COL_TAIL
       : "=&v"(acc)
       : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(A[6]), "v"(A[7]), "v"(A[8]), "v"(A[9]),
         "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]), "v"(B[5]), "v"(B[6]), "v"(B[7]), "v"(B[8]), "v"(B[9])
