@@ -298,6 +298,9 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *                     (default 4096), coop.decode_max_items for a bare decode (default 1024), coop.verify_max_items for the
  *                     kernels that give ONE item several wavefronts (verification in one launch, signing in one launch, the fixed
  *                     base with four wavefronts per item; default 512).  Same results either way.
+ *   poly.batch_segments  kyb_pubpoly_eval*_batch, long polynomials at 10^3..6x10^4 evaluations: the Horner chain of an evaluation is cut into
+ *                     this many segments, one per lane, recombined with x^(s len) mod 8L by the variable-base ladder (0 = chosen by a cost
+ *                     model from t, the batch size and the bit length of the largest index; 1 = never; 2..256).  Same results either way.
  *   ext.projective    0 (default): out_ext always has Z = 1.  1: a small-batch kyb_mul_batch / kyb_mul_base_batch / kyb_pubpoly_eval*_batch /
  *                     kyb_sum_batch / kyb_lincomb_batch call that asks for out_ext ONLY (out_enc == NULL) gets the point as (X : Y : Z : T) with Z != 1 — what the reference's own Point
  *                     holds after a multiplication — and skips the field inversion (one fixed-base call: 55 -> 27 us); every entry

@@ -108,6 +108,7 @@ struct Ctx {
   std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: chunks that alternate between the two lanes
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
+  std::atomic<int> opt_poly_batch_segments{0};   // PubPoly::eval, long polynomials at 10^3..10^4 evaluations: lanes per evaluation of the batch kernels (0 = cost model, 1 = never, 2..256)
   std::atomic<int> opt_poly_segments{0};         // PubPoly::eval, small batches: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never split, 2..32)
   std::atomic<int> opt_verify_by_enc{1};         // large verification batches: compare the encoding of s*B - h*A with R's bytes, decode R only on a mismatch
   std::atomic<int> opt_coop_verify_max{512};     // verification: up to this many signatures take the single-launch kernel (three wavefronts each)
@@ -1154,6 +1155,54 @@ int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* i
   }
   int nbits = 1;
   while (nbits < 32 && ((uint64_t)max_index + 1) >> nbits) ++nbits;      // bit length of max x = max_index + 1
+  // Three shapes (times: kernel time on an MI355X, profiles/r02/poly_eval_multi_probe.log, poly_eval_batch_segments.log):
+  //   one evaluation per wavefront (kernels_coop.hip), its chain optionally cut over several wavefronts   — few evaluations
+  //   one evaluation per lane (k_poly_eval)                                                               — >= 10^5 evaluations
+  //   one SEGMENT per lane, recombined by the variable-base ladder (k_poly_eval_part)                      — long polynomials between the two
+  // Cost model in microseconds; a Horner step of the small multiplier x costs (nbits + 1) point operations.
+  {
+    const double f = (double)(nbits + 1) / 11.0;                       // measured with 10-bit indices
+    int bsegs = g.opt_poly_batch_segments;
+    double cost_other;
+    if (n <= (size_t)g.opt_coop_max) {
+      int cs = g.opt_poly_segments;
+      if (cs == 0) { const size_t by_len = t / 24, by_room = 2048 / n; cs = (int)(by_len < by_room ? by_len : by_room); if (cs > 32) cs = 32; if (cs < 1 || nbits <= 1) cs = 1; }
+      const double waves = (double)n * cs, crowd = waves > 1536.0 ? waves / 1536.0 : 1.0;
+      cost_other = ((double)((t + cs - 1) / cs) * 6.2 * f + (cs > 1 ? 160.0 : 0.0)) * crowd + 40.0;
+    } else {
+      const double crowd = n > 65536 ? (double)n / 65536.0 : 1.0;
+      cost_other = (double)t * 31.0 * f * crowd + 100.0;
+    }
+    if (bsegs == 0) {
+      // lanes up to ~one wavefront per SIMD keep the per-lane latency; at least four coefficients per segment
+      size_t sgs = 65536 / n;
+      if (sgs > t / 4) sgs = t / 4;
+      if (sgs > 256) sgs = 256;
+      bsegs = 1;
+      if (sgs >= 2 && nbits > 1) {
+        const size_t len = (t + sgs - 1) / sgs;
+        const double cost_seg = (double)len * 35.0 * f + 1000.0;       // + Montgomery images, the 255-step ladder, sums, finish (0.95-1.0 ms measured)
+        if (cost_seg * 1.05 < cost_other) bsegs = (int)sgs;
+      }
+    }
+    if (bsegs >= 2 && (size_t)bsegs <= t && g.opt_mul_algo == 1) {
+      const int len = (int)((t + (size_t)bsegs - 1) / (size_t)bsegs);
+      const int segs = (int)((t + (size_t)len - 1) / (size_t)len);     // no empty segment
+      const size_t N = n * (size_t)segs;
+      if (segs >= 2 && N <= (size_t(1) << 26)) {
+        int rc = ensure_enc(g, r, 192 * N + 256); if (rc) return rc;
+        int32_t* part_ext = reinterpret_cast<int32_t*>(r->enc);
+        uint8_t* part_sc = r->enc + 160 * N;
+        {
+          ProfScope ps(g, st, KID_POLY_EVAL);
+          LAUNCHCK(launch::poly_eval_part(st, commits, (int)t, idx, n, nbits, per_poly, len, segs, part_ext, part_sc));
+        }
+        rc = launch_ladder_core(g, part_sc, nullptr, part_ext, N, nullptr, r, st, 0, 1); if (rc) return rc;      // |multiplier| < 4L < 2^255
+        rc = launch_pair_sums(g, r, n, (size_t)segs, st); if (rc) return rc;
+        return launch_finish(g, r, n, oenc, oext, st, (size_t)segs, true);
+      }
+    }
+  }
   if (n <= (size_t)g.opt_coop_max) {
     // few evaluations: one per wavefront (kernels_coop.hip); a long polynomial at very few indices: several wavefronts per evaluation.
     // A segment costs its wavefront one 255-step multiplication (~26 Horner steps of a 10-bit index) on top of its share of the chain,

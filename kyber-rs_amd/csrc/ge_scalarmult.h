@@ -137,8 +137,7 @@ KYB_HD void ge_small_mul(ge_p3& out, const ge_p3& in, uint32_t x, int nbits) {
 // PubPoly::eval (poly.rs:457-469): v = sum_j commit_j * x^j by Horner, x = index + 1.
 // `load_commit(j, P)` supplies commitment j as an extended point.
 template <class LoadCommit>
-KYB_HD void ge_poly_eval(ge_p2& out, LoadCommit load_commit, int t, uint32_t x, int nbits) {
-  ge_p3 v;
+KYB_HD void ge_poly_eval_p3(ge_p3& v, LoadCommit load_commit, int t, uint32_t x, int nbits) {
   ge_p3_0(v);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
@@ -153,6 +152,11 @@ KYB_HD void ge_poly_eval(ge_p2& out, LoadCommit load_commit, int t, uint32_t x, 
     ge_add(r, m, cc);
     ge_p1p1_to_p3(v, r);
   }
+}
+template <class LoadCommit>
+KYB_HD void ge_poly_eval(ge_p2& out, LoadCommit load_commit, int t, uint32_t x, int nbits) {
+  ge_p3 v;
+  ge_poly_eval_p3(v, load_commit, t, x, nbits);
   fe_copy(out.X, v.X); fe_copy(out.Y, v.Y); fe_copy(out.Z, v.Z);
 }
 

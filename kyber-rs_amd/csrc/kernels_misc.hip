@@ -3,9 +3,11 @@
 //   k_encode_batched    marshal_binary of extended points with the same shared inversion (point.rs:35-41)
 //   k_add / k_equal / k_encode / k_decode   point.rs:179-241 / 35-51
 //   k_poly_eval         share/poly.rs:457-469
+//   k_poly_eval_part    the same for long polynomials at 10^3..10^4 evaluations: partial Horner chains, recombined by the ladder
 #include <hip/hip_runtime.h>
 #include "launch.h"
 #include "ge_scalarmult.h"
+#include "sc25519.h"
 #include "device_batch_invert.h"
 using namespace kyb;
 #include "device_tables.h"
@@ -121,6 +123,38 @@ k_poly_eval(const int32_t* __restrict__ commits_ext, int t, const uint32_t* __re
   if (SPLIT) { if (live) store_proj(proj, stride, i, r.X, r.Y, r.Z); }
   else finish_point(r.X, r.Y, r.Z, out_enc, out_ext, ii, live);
 }
+// Long polynomials at a middling number of evaluations (about 10^3 .. 6x10^4: more than one wavefront each can serve, fewer than
+// one lane each needs to fill the chip, whose t-step Horner chain would then run at one lane's latency).  The chain is cut as in
+// k_poly_eval_seg:  P(x) = sum_s x^(s len) Q_s(x),  Q_s(x) = sum_{j < len} x^j C_{s len + j}.
+// Lane (evaluation e, segment s) evaluates Q_s by Horner and leaves it as extended limbs — negated when the representative of the
+// multiplier is negative — next to |x^(s len) mod 8L| (sc_pow_mod8L_signed: exact on points with small-order components); the
+// variable-base ladder multiplies, k_pair_sum adds an evaluation's segs products up, k_finish encodes.  segs * len >= t and
+// (segs - 1) * len < t: no segment is empty.
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_poly_eval_part(const int32_t* __restrict__ commits_ext, int t, const uint32_t* __restrict__ indices, size_t n, int nbits, size_t per_poly, int len, int segs,
+                 int32_t* __restrict__ part_ext, uint8_t* __restrict__ part_sc) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  const bool live = i < n * (size_t)segs;
+  const size_t ii = live ? i : 0;
+  const size_t e = ii / (size_t)segs;
+  const int sg = (int)(ii - e * (size_t)segs);
+  const uint32_t x = indices[e] + 1u;
+  const int lo = sg * len, cnt = t - lo < len ? t - lo : len;
+  const size_t first = (per_poly ? (e / per_poly) * (size_t)t : 0) + (size_t)lo;
+  ge_p3 v;
+  ge_poly_eval_p3(v, [&](int j, ge_p3& c) { load_ext(c, commits_ext, first + (size_t)j); }, cnt, x, nbits);
+  uint32_t mag[8], neg;
+  sc_pow_mod8L_signed(mag, neg, x, (uint32_t)lo);
+  fe nx, nt;
+  fe_reduce_weak(v.X, v.X); fe_reduce_weak(v.T, v.T);
+  fe_neg(nx, v.X); fe_neg(nt, v.T);
+  fe_reduce_weak(nx, nx); fe_reduce_weak(nt, nt);
+  fe_cmov(v.X, nx, neg); fe_cmov(v.T, nt, neg);
+  if (live) {
+    store_ext(part_ext, i, v.X, v.Y, v.Z, v.T);
+    store_words8(part_sc, i, mag);
+  }
+}
 // batched Point::eq (point.rs:227-241) without inversions
 __global__ void __launch_bounds__(KYB_BLOCK)
 k_equal(const int32_t* __restrict__ a_ext, const int32_t* __restrict__ b_ext, size_t n, uint8_t* __restrict__ eq_out) {
@@ -204,6 +238,11 @@ hipError_t poly_eval(bool split, hipStream_t st, const int32_t* commits, int t, 
                      uint8_t* oenc, int32_t* oext, uint4* proj, size_t stride) {
   if (split) hipLaunchKernelGGL((k_poly_eval<true>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, commits, t, idx, n, nbits, per_poly, oenc, oext, proj, stride);
   else       hipLaunchKernelGGL((k_poly_eval<false>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, commits, t, idx, n, nbits, per_poly, oenc, oext, proj, stride);
+  return hipGetLastError();
+}
+hipError_t poly_eval_part(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly, int len, int segs,
+                          int32_t* part_ext, uint8_t* part_sc) {
+  hipLaunchKernelGGL(k_poly_eval_part, dim3(blocks_for(n * (size_t)segs)), dim3(KYB_BLOCK), 0, st, commits, t, idx, n, nbits, per_poly, len, segs, part_ext, part_sc);
   return hipGetLastError();
 }
 }}  // namespace kyb::launch

@@ -114,5 +114,9 @@ hipError_t decode(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext
 hipError_t poly_eval(bool split, hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly,
                      uint8_t* oenc, int32_t* oext, uint4* proj, size_t stride);
 
+// segs lanes per evaluation (len coefficients each): partial results as extended limbs in part_ext[n * segs], multipliers in part_sc
+hipError_t poly_eval_part(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly, int len, int segs,
+                          int32_t* part_ext, uint8_t* part_sc);
+
 }  // namespace launch
 }  // namespace kyb

@@ -61,7 +61,7 @@ COMMITS = POOL_P[:200].copy()
 
 
 def set_random_options():
-    o = {"ext.projective": int(rng.integers(0, 2)), "poly.segments": int(rng.choice([0, 0, 1, 2, 5, 32])),
+    o = {"ext.projective": int(rng.integers(0, 2)), "poly.segments": int(rng.choice([0, 0, 1, 2, 5, 32])), "poly.batch_segments": int(rng.choice([0, 0, 1, 1, 2, 3, 16, 200])),
          "coop.verify_max_items": int(rng.choice([512, 512, 0, 4096])), "verify.by_encoding": int(rng.integers(0, 2)),
          "verify.overlap": int(rng.integers(0, 2))}
     if rng.integers(0, 8) == 0:
@@ -85,7 +85,7 @@ while time.time() < t_end:
     n = int(rng.choice(SIZES)) if rng.integers(0, 3) else int(rng.integers(1, 900))
     lo = int(rng.integers(0, NMAX - n + 1))
     sl = slice(lo, lo + n)
-    op = str(rng.choice(["mul_base", "mul_ext", "mul_enc", "sign", "verify", "decode", "encode", "eval", "lincomb", "sum"]))
+    op = str(rng.choice(["mul_base", "mul_ext", "mul_enc", "sign", "verify", "decode", "encode", "eval", "eval_wire", "lincomb", "sum", "sum_wire"]))
     counts[op] = counts.get(op, 0) + 1
     cases += 1
     ctx = (op, n, lo, opts)
@@ -129,6 +129,34 @@ while time.time() < t_end:
             got = eng.pubpoly_eval(COMMITS[:t], idx)
             for i in range(0, m, max(1, m // 6)):
                 assert bytes(got[i]) == orc.pubpoly_eval(COMMITS[:t], int(idx[i]))
+        elif op == "eval_wire":
+            t = int(rng.choice([1, 3, 20, 60]))
+            m = max(1, min(n, 1200) // t)
+            k_ = int(rng.choice([1, 2]))
+            enc_in = POOL_E_BAD[lo:lo + m * t] if lo + m * t <= NMAX else POOL_E_BAD[:m * t]
+            base_i = lo if lo + m * t <= NMAX else 0
+            idx = rng.integers(0, 1 << int(rng.choice([1, 4, 10, 16])), (m, k_), dtype=np.uint64).astype(np.uint32)
+            got, ok = eng.pubpoly_eval_multi_enc(enc_in.reshape(m, t, 32), idx)
+            for g_ in range(0, m, max(1, m // 6)):
+                pts = [orc.null() if ((base_i + g_ * t + j) % 53) == 0 else POOL_P[base_i + g_ * t + j] for j in range(t)]
+                assert [bool(v) for v in ok[g_]] == [((base_i + g_ * t + j) % 53) != 0 for j in range(t)]
+                assert bytes(got[g_, k_ - 1]) == orc.pubpoly_eval(np.stack(pts), int(idx[g_, k_ - 1]))
+        elif op == "sum_wire":
+            t = int(rng.choice([1, 2, 5, 16, 40]))
+            m = max(1, min(n, 1200) // t)
+            major = bool(rng.integers(0, 2))
+            enc_in = POOL_E_BAD[:m * t].reshape(m, t, 32)
+            arg = np.ascontiguousarray(enc_in.transpose(1, 0, 2)) if major else enc_in
+            got, ok = eng.sum_points_enc(arg, item_major=major)
+            okm = ok.T if major else ok
+            for g_ in range(0, m, max(1, m // 8)):
+                acc = orc.null()
+                for j in range(t):
+                    bad_ = ((g_ * t + j) % 53) == 0
+                    assert bool(okm[g_, j]) == (not bad_)
+                    if not bad_:
+                        acc = orc.add(acc, POOL_P[g_ * t + j])
+                assert bytes(got[g_]) == orc.encode(acc)
         elif op == "lincomb":
             t = int(rng.choice([1, 2, 3, 8, 33]))
             m = max(1, min(n, 2000) // t)
