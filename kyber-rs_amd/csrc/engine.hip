@@ -1159,9 +1159,12 @@ int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* i
   //   one evaluation per wavefront (kernels_coop.hip), its chain optionally cut over several wavefronts   — few evaluations
   //   one evaluation per lane (k_poly_eval)                                                               — >= 10^5 evaluations
   //   one SEGMENT per lane, recombined by the variable-base ladder (k_poly_eval_part)                      — long polynomials between the two
-  // Cost model in microseconds; a Horner step of the small multiplier x costs (nbits + 1) point operations.
+  // Cost model in microseconds.  A Horner step with an nbits-bit multiplier is nbits doublings, one addition per set bit (all of them
+  // when the lanes of a wavefront disagree, none for the bits no lane has set) and the coefficient's addition: ~1.5 nbits + 1 point
+  // operations; the constants below were measured with 10-bit indices (16 operations).  The lane-per-item kernels keep a lane's latency
+  // up to one wavefront per SIMD (65,536 lanes) and take one more "round" for every further 65,536.
   {
-    const double f = (double)(nbits + 1) / 11.0;                       // measured with 10-bit indices
+    const double f = (1.5 * (double)nbits + 1.0) / 16.0;
     int bsegs = g.opt_poly_batch_segments;
     double cost_other;
     if (n <= (size_t)g.opt_coop_max) {
@@ -1170,19 +1173,18 @@ int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* i
       const double waves = (double)n * cs, crowd = waves > 1536.0 ? waves / 1536.0 : 1.0;
       cost_other = ((double)((t + cs - 1) / cs) * 6.2 * f + (cs > 1 ? 160.0 : 0.0)) * crowd + 40.0;
     } else {
-      const double crowd = n > 65536 ? (double)n / 65536.0 : 1.0;
-      cost_other = (double)t * 31.0 * f * crowd + 100.0;
+      cost_other = (double)((n + 65535) / 65536) * (double)t * 31.0 * f + 100.0;
     }
     if (bsegs == 0) {
-      // lanes up to ~one wavefront per SIMD keep the per-lane latency; at least four coefficients per segment
-      size_t sgs = 65536 / n;
-      if (sgs > t / 4) sgs = t / 4;
-      if (sgs > 256) sgs = 256;
       bsegs = 1;
-      if (sgs >= 2 && nbits > 1) {
+      double best = cost_other;
+      const size_t cand[] = {65536 / n, (65536 + n - 1) / n, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
+      for (size_t sgs : cand) {
+        if (sgs < 2 || sgs > 256 || sgs > t / 4 || nbits <= 1) continue;       // at least four coefficients per segment
         const size_t len = (t + sgs - 1) / sgs;
-        const double cost_seg = (double)len * 35.0 * f + 1000.0;       // + Montgomery images, the 255-step ladder, sums, finish (0.95-1.0 ms measured)
-        if (cost_seg * 1.05 < cost_other) bsegs = (int)sgs;
+        const double rounds = (double)((n * sgs + 65535) / 65536);
+        const double cost_seg = rounds * ((double)len * 35.0 * f + 700.0) + 300.0;      // Horner chain + the 255-step ladder per round; images, sums, finish
+        if (cost_seg * 1.05 < best) { best = cost_seg * 1.05; bsegs = (int)sgs; }
       }
     }
     if (bsegs >= 2 && (size_t)bsegs <= t && g.opt_mul_algo == 1) {
