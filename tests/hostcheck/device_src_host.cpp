@@ -264,6 +264,47 @@ void hd_lincomb(uint8_t out[32], const uint8_t* scalars, const int32_t* pts, int
   ge_encode(w, v[0].X, v[0].Y, v[0].Z);
   memcpy(out, w, 32);
 }
+// the flow of k_poly_eval_part + ladder + k_pair_sum for ONE evaluation: the Horner chain cut into segments of `len` coefficients,
+// every partial result (negated when the multiplier's representative is) multiplied by |x^(s len) mod 8L| on the ladder, summed, encoded
+void hd_pubpoly_eval_segments(uint8_t out[32], const int32_t* commits, int t, uint32_t index, int nbits, int len) {
+  const uint32_t x = index + 1u;
+  const int segs = (t + len - 1) / len;
+  std::vector<ge_p2> v((size_t)segs);
+  for (int sg = 0; sg < segs; ++sg) {
+    const int lo = sg * len, cnt = t - lo < len ? t - lo : len;
+    ge_p3 q;
+    ge_poly_eval_p3(q, [&](int j, ge_p3& c) {
+      const int32_t* p = commits + 40 * (lo + j);
+      fe_from_ref10(c.X, p); fe_from_ref10(c.Y, p + 10); fe_from_ref10(c.Z, p + 20); fe_from_ref10(c.T, p + 30);
+    }, cnt, x, nbits);
+    uint32_t mag[8], neg;
+    sc_pow_mod8L_signed(mag, neg, x, (uint32_t)lo);
+    fe nx, nt;
+    fe_reduce_weak(q.X, q.X); fe_reduce_weak(q.T, q.T);
+    fe_neg(nx, q.X); fe_neg(nt, q.T);
+    fe_reduce_weak(nx, nx); fe_reduce_weak(nt, nt);
+    fe_cmov(q.X, nx, neg); fe_cmov(q.T, nt, neg);
+    int32_t ext[40];                                   // through the reference-limb record, as the kernel hands it to k_mont_prep
+    fe_to_ref10(ext, q.X); fe_to_ref10(ext + 10, q.Y); fe_to_ref10(ext + 20, q.Z); fe_to_ref10(ext + 30, q.T);
+    ge_p3 P;
+    fe_from_ref10(P.X, ext); fe_from_ref10(P.Y, ext + 10); fe_from_ref10(P.Z, ext + 20); fe_from_ref10(P.T, ext + 30);
+    fe d, dinv;
+    uint32_t flags;
+    mont_prep_den(d, flags, P);
+    fe_invert(dinv, d);
+    mont_point m;
+    mont_prep_finish(m, P, dinv, flags);
+    ge_scalarmult_ladder(v[sg], mag, m, 1);
+  }
+  for (size_t n = (size_t)segs; n > 1;) {
+    const size_t half = (n + 1) / 2;
+    for (size_t j = 0; j < n - half; ++j) { ge_p2 r; ge_p2_add(r, v[j], v[j + half]); v[j] = r; }
+    n = half;
+  }
+  uint32_t w[8];
+  ge_encode(w, v[0].X, v[0].Y, v[0].Z);
+  memcpy(out, w, 32);
+}
 void hd_effective(uint8_t mag[32], int* neg, const uint8_t scalar[32]) {
   uint32_t a[8], m[8], n;
   load_words(a, scalar);

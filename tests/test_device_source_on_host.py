@@ -276,6 +276,29 @@ def test_pubpoly_eval_and_equal(hd, oracle):
     assert hd.hd_overflows() == base
 
 
+def test_pubpoly_eval_cut_into_segments(hd, oracle):
+    """k_poly_eval_part's flow restated on the host with the device's own field / group / scalar code under the overflow shadow: partial Horner
+    chains, multiplier x^(s len) mod 8L as a signed representative, ladder, pairwise sums == the reference's eval (poly.rs:457-469) — also
+    when commitments have small-order components, where a multiplier reduced mod L would give another point"""
+    base = hd.hd_overflows()
+    rnd = random.Random(21)
+    weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
+    t = 11
+    commits = np.stack([oracle.mul_base_ext(bytes(rnd.getrandbits(8) for _ in range(32))) for _ in range(t)])
+    commits[2] = oracle.add(commits[2], weak[2])           # mixed order
+    commits[5] = weak[3]                                     # small order
+    commits[7] = oracle.null()
+    commits[10] = oracle.add(commits[10], weak[4])
+    for idx in (0, 1, 6, 513, 65534, 2**32 - 2):
+        want = oracle.pubpoly_eval(commits, idx)
+        nbits = (idx + 1).bit_length()
+        for ln in (1, 2, 3, 4, 6, 10, 11):
+            o = B(32)
+            hd.hd_pubpoly_eval_segments(o, p32(commits), t, ctypes.c_uint32(idx), nbits, ln)
+            assert o.raw == want, (idx, ln)
+    assert hd.hd_overflows() == base
+
+
 def test_ladder_path_matches_oracle(hd, oracle):
     """table-free variable-base path (ge_ladder.h) == the reference's windowed multiplication on every
     quirk vector (small-order / mixed-order / non-canonical points; scalars 0, L, 8L, >= 2^255) and on
