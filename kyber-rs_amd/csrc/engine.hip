@@ -1131,6 +1131,42 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   return KYB_OK;
 }
 
+// PubPoly::eval has three launch shapes (kernel times on an MI355X: profiles/r02/poly_eval_multi_probe.log, poly_eval_batch_segments.log,
+// poly_eval_shares_probe.log):
+//   one evaluation per wavefront (kernels_coop.hip), its chain optionally cut over several wavefronts   — few evaluations
+//   one evaluation per lane (k_poly_eval)                                                               — >= 10^5 evaluations
+//   one SEGMENT per lane, recombined by the variable-base ladder (k_poly_eval_part)                      — long polynomials between the two
+// Returns the number of segments per evaluation for the third shape, or 1 when one of the other two is expected to be faster.
+// Cost model in microseconds.  A Horner step with an nbits-bit multiplier is nbits doublings, one addition per set bit (all of them
+// when the lanes of a wavefront disagree, none for the bits no lane has set) and the coefficient's addition: ~1.5 nbits + 1 point
+// operations; the constants were measured with 10-bit indices (16 operations).  The lane-per-item kernels keep a lane's latency
+// up to one wavefront per SIMD (65,536 lanes) and take one more "round" for every further 65,536.
+int poly_batch_segments(const Ctx& g, size_t n, size_t t, int nbits) {
+  const int forced = g.opt_poly_batch_segments;
+  if (forced != 0) return forced;
+  if (nbits <= 1) return 1;                                            // x = 1: the chain is t additions
+  const double f = (1.5 * (double)nbits + 1.0) / 16.0;
+  double best;
+  if (n <= (size_t)g.opt_coop_max) {
+    int cs = g.opt_poly_segments;
+    if (cs == 0) { const size_t by_len = t / 24, by_room = 2048 / n; cs = (int)(by_len < by_room ? by_len : by_room); if (cs > 32) cs = 32; if (cs < 1) cs = 1; }
+    const double waves = (double)n * cs, crowd = waves > 1536.0 ? waves / 1536.0 : 1.0;
+    best = ((double)((t + cs - 1) / cs) * 6.2 * f + (cs > 1 ? 160.0 : 0.0)) * crowd + 40.0;
+  } else {
+    best = (double)((n + 65535) / 65536) * (double)t * 31.0 * f + 100.0;
+  }
+  int segs = 1;
+  const size_t cand[] = {65536 / n, (65536 + n - 1) / n, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
+  for (size_t sgs : cand) {
+    if (sgs < 2 || sgs > 256 || sgs > t / 4) continue;                // at least four coefficients per segment
+    const size_t len = (t + sgs - 1) / sgs;
+    const double rounds = (double)((n * sgs + 65535) / 65536);
+    const double cost = (rounds * ((double)len * 35.0 * f + 700.0) + 300.0) * 1.05;      // Horner chain + 255-step ladder per round; images, sums, finish
+    if (cost < best) { best = cost; segs = (int)sgs; }
+  }
+  return segs;
+}
+
 // commits_enc != nullptr: the commitments as wire encodings (what a Deal carries), decoded here first; ok[i] per commitment,
 // a failed decode counts as the neutral element
 int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* idx, size_t n, uint32_t max_index, uint8_t* oenc, int32_t* oext, hipStream_t st,
@@ -1155,38 +1191,8 @@ int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* i
   }
   int nbits = 1;
   while (nbits < 32 && ((uint64_t)max_index + 1) >> nbits) ++nbits;      // bit length of max x = max_index + 1
-  // Three shapes (times: kernel time on an MI355X, profiles/r02/poly_eval_multi_probe.log, poly_eval_batch_segments.log):
-  //   one evaluation per wavefront (kernels_coop.hip), its chain optionally cut over several wavefronts   — few evaluations
-  //   one evaluation per lane (k_poly_eval)                                                               — >= 10^5 evaluations
-  //   one SEGMENT per lane, recombined by the variable-base ladder (k_poly_eval_part)                      — long polynomials between the two
-  // Cost model in microseconds.  A Horner step with an nbits-bit multiplier is nbits doublings, one addition per set bit (all of them
-  // when the lanes of a wavefront disagree, none for the bits no lane has set) and the coefficient's addition: ~1.5 nbits + 1 point
-  // operations; the constants below were measured with 10-bit indices (16 operations).  The lane-per-item kernels keep a lane's latency
-  // up to one wavefront per SIMD (65,536 lanes) and take one more "round" for every further 65,536.
   {
-    const double f = (1.5 * (double)nbits + 1.0) / 16.0;
-    int bsegs = g.opt_poly_batch_segments;
-    double cost_other;
-    if (n <= (size_t)g.opt_coop_max) {
-      int cs = g.opt_poly_segments;
-      if (cs == 0) { const size_t by_len = t / 24, by_room = 2048 / n; cs = (int)(by_len < by_room ? by_len : by_room); if (cs > 32) cs = 32; if (cs < 1 || nbits <= 1) cs = 1; }
-      const double waves = (double)n * cs, crowd = waves > 1536.0 ? waves / 1536.0 : 1.0;
-      cost_other = ((double)((t + cs - 1) / cs) * 6.2 * f + (cs > 1 ? 160.0 : 0.0)) * crowd + 40.0;
-    } else {
-      cost_other = (double)((n + 65535) / 65536) * (double)t * 31.0 * f + 100.0;
-    }
-    if (bsegs == 0) {
-      bsegs = 1;
-      double best = cost_other;
-      const size_t cand[] = {65536 / n, (65536 + n - 1) / n, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
-      for (size_t sgs : cand) {
-        if (sgs < 2 || sgs > 256 || sgs > t / 4 || nbits <= 1) continue;       // at least four coefficients per segment
-        const size_t len = (t + sgs - 1) / sgs;
-        const double rounds = (double)((n * sgs + 65535) / 65536);
-        const double cost_seg = rounds * ((double)len * 35.0 * f + 700.0) + 300.0;      // Horner chain + the 255-step ladder per round; images, sums, finish
-        if (cost_seg * 1.05 < best) { best = cost_seg * 1.05; bsegs = (int)sgs; }
-      }
-    }
+    const int bsegs = poly_batch_segments(g, n, t, nbits);
     if (bsegs >= 2 && (size_t)bsegs <= t && g.opt_mul_algo == 1) {
       const int len = (int)((t + (size_t)bsegs - 1) / (size_t)bsegs);
       const int segs = (int)((t + (size_t)len - 1) / (size_t)len);     // no empty segment
