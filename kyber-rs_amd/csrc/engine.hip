@@ -815,9 +815,15 @@ int launch_sum(Ctx& g, const int32_t* pext, const uint8_t* penc, uint8_t* ok, bo
   const bool small = t <= 32 && m <= (size_t)g.opt_coop_base_max;
   if (penc != nullptr && small && !item_major) {
     int rc = ensure_ws_part(g, r, n); if (rc) return rc;
-    ProfScope ps(g, st, KID_DECODE_COOP);
-    LAUNCHCK(launch::decode_coop(st, penc, n, reinterpret_cast<int32_t*>(r->part), ok, true));
-    pext = reinterpret_cast<const int32_t*>(r->part);
+    int32_t* dec = reinterpret_cast<int32_t*>(r->part);
+    if (n <= (size_t)g.opt_coop_decode_max) {
+      ProfScope ps(g, st, KID_DECODE_COOP);
+      LAUNCHCK(launch::decode_coop(st, penc, n, dec, ok, true));
+    } else {
+      ProfScope ps(g, st, KID_DECODE);
+      LAUNCHCK(launch::decode_or_identity(st, penc, n, dec, ok));
+    }
+    pext = dec;
     penc = nullptr;
   }
   if (penc == nullptr && small) {

@@ -65,7 +65,7 @@ def test_eval_from_wire_encodings(engine, oracle, m, t, k):
     assert np.array_equal(engine.encode(ext2.reshape(-1, 40)), got.reshape(-1, 32))
 
 
-@pytest.mark.parametrize("m,t", [(1, 1), (1, 2), (17, 24), (3, 32), (4, 33), (40, 50), (683, 64), (5000, 3)])
+@pytest.mark.parametrize("m,t", [(1, 1), (1, 2), (17, 24), (3, 32), (4, 33), (40, 50), (200, 16), (683, 64), (5000, 3)])
 def test_sums_from_wire_encodings(engine, oracle, m, t):
     ext, enc = _points(oracle, m * t, 800 + t)
     enc, ext, want_ok = _spoil(oracle, enc, ext)
