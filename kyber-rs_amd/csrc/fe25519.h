@@ -327,18 +327,19 @@ KYB_HD void fe_mul_b6(fe& h, const fe& f, const fe& g) {
 }
 
 // h = f^2.  f <= 3.3T (C32: f <= 2.5T, column 9 <= 62.5 * 2^51).  55 v_mad_u64_u32.  Output tight.
+// Operand multiples as the reference chooses them (fe.rs:544-688): 2 f_i for i <= 7, 38 f_j for the odd j >= 5, 19 f_j for
+// j = 6, 8 — 8 doublings and 5 multiplications.  A wrapped term with odd j takes its whole factor (2 for the cross term or for
+// odd-odd, times 19) from 38 f_j, and only the 76 of an odd-odd cross term also doubles f_i.
 template <bool C32>
 KYB_HD void fe_sq_t(fe& h, const fe& f) {
-  uint32_t f2[10], f19[10], f38[10];
-  KYB_UNROLL for (int i = 0; i < 10; ++i) { f19[i] = 0; f38[i] = 0; }
-  KYB_UNROLL for (int i = 5; i < 10; ++i) f19[i] = kyb_x19(f.v[i]);
+  uint32_t f2[10], fw[10];                    // fw[j]: the wrap-around multiple of f_j (38 f_j for odd j, 19 f_j for even j), j >= 5
+  KYB_UNROLL for (int i = 0; i < 10; ++i) { f2[i] = 0; fw[i] = 0; }
+  KYB_UNROLL for (int i = 5; i < 10; ++i) fw[i] = kyb_mul32(f.v[i], (i & 1) ? 38u : 19u, "sq fw");
 #if defined(KYB_ASM_COLUMNS)
   kyb_dbl5(f2[0], f2[1], f2[2], f2[3], f2[4], f.v[0], f.v[1], f.v[2], f.v[3], f.v[4]);
-  kyb_dbl5(f2[5], f2[6], f2[7], f2[8], f2[9], f.v[5], f.v[6], f.v[7], f.v[8], f.v[9]);
-  kyb_dbl3(f38[5], f38[7], f38[9], f19[5], f19[7], f19[9]);
+  kyb_dbl3(f2[5], f2[6], f2[7], f.v[5], f.v[6], f.v[7]);
 #else
-  KYB_UNROLL for (int i = 0; i < 10; ++i) f2[i] = kyb_x2(f.v[i], "sq f2");
-  KYB_UNROLL for (int i = 5; i < 10; i += 2) f38[i] = kyb_x2(f19[i], "sq f38");
+  KYB_UNROLL for (int i = 0; i < 8; ++i) f2[i] = kyb_x2(f.v[i], "sq f2");
 #endif
   uint64_t acc = 0;
   uint32_t r[10];
@@ -355,8 +356,9 @@ KYB_HD void fe_sq_t(fe& h, const fe& f) {
       const bool oo = (i & 1) && (j & 1);
       // multiplier = (cross?2:1) * (oo?2:1) * (wrap?19:1), split between the two operands
       uint32_t a, b;
-      if (!wrap) { a = cross ? f2[i] : f.v[i]; b = oo ? f2[j] : f.v[j]; }
-      else       { a = cross ? f2[i] : f.v[i]; b = oo ? f38[j] : f19[j]; }
+      if (!wrap)      { a = cross ? f2[i] : f.v[i]; b = oo ? f2[j] : f.v[j]; }
+      else if (j & 1) { a = (cross && oo) ? f2[i] : f.v[i]; b = fw[j]; }      // 38 f_j carries the 2 of a cross term with even i, or of f_j f_j
+      else            { a = cross ? f2[i] : f.v[i]; b = fw[j]; }
 #if defined(KYB_ASM_COLUMNS)
       ca[nt] = a; cb[nt] = b; ++nt;
 #else
