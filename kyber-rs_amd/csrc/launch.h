@@ -6,7 +6,7 @@
 //   kernels_ladder.hip    variable base: k_decode_or_identity, k_decode_to_proj, k_mont_prep, k_mul_ladder, k_pair_sum, k_ext_to_proj
 //   kernels_window.hip    windowed variable-base k_mul (mul.algo=0, cross-check of the ladder)
 //   kernels_verify.hip    SHA-512 users: k_verify_prep / _r / _final, k_sign_hash, k_eddsa_prep
-//   kernels_misc.hip      k_finish, k_encode_batched, k_add, k_equal, k_encode, k_decode, k_poly_eval
+//   kernels_misc.hip      k_finish, k_encode_batched, k_add, k_equal, k_encode, k_decode, k_poly_eval, k_poly_eval_part
 //   kernels_coop.hip      small batches: one item per wavefront (or two / three wavefronts per item), lane-cooperative field arithmetic:
 //                         k_mul_coop, k_mul_enc_coop, k_mul_base_coop, k_decode_coop, k_finish_coop, k_verify_coop, k_verify_prep(_r)_coop, k_poly_eval_coop
 //   engine.hip            contexts, per-stream scratch, launch sequences, host-pointer pipeline, multi-device groups, C ABI
