@@ -6,7 +6,10 @@
 //!   1. copy this directory to `src/group/edwards25519_hip/`,
 //!   2. add `pub mod edwards25519_hip;` next to `pub mod edwards25519;` in `src/group/mod.rs`,
 //!   3. add the two `cargo:` lines of `build.rs.snippet` to the crate's `build.rs`
-//!      (links `libkyber_ed25519_hip.so`, built by `python __graft_entry__.py build`).
+//!      (links `libkyber_ed25519_hip.so`, built by `python __graft_entry__.py build`),
+//!   4. make the CPU group's element arithmetic visible inside the crate: `mod ge;` -> `pub(crate) mod ge;` in
+//!      `src/group/edwards25519/mod.rs` (`Point::add` / `sub` of a single pair stay on the CPU, with the reference's own
+//!      formulas: nine field multiplications are not worth a round trip to the GPU).
 //!
 //! In-crate because the reference keeps what a drop-in needs behind crate-private paths
 //! (`group::edwards25519::constants` is `pub(crate)`, `group::internal::marshalling` is reached through
@@ -28,7 +31,7 @@ mod point;
 mod suite;
 
 pub use curve::CurveHip;
-pub use point::{recover_commit_accumulate, verify_batch, Point};
+pub use point::{eval_each_wire, recover_commit_accumulate, sum_polys_wire, verify_batch, Point};
 pub use suite::SuiteEd25519Hip;
 
 /// the scalar type is shared with the CPU group
