@@ -269,12 +269,17 @@ impl group::Point for Point {
         self
     }
 
-    /// point.rs:85-88 — the reference copies the literal BASEEXT; here 1 * B from the engine (the same point, Z = 1)
+    /// point.rs:85-88 — the reference copies the literal BASEEXT; here 1 * B from the engine, once per process (the same point, Z = 1)
     fn base(mut self) -> Self {
-        ensure_init();
-        let mut one = [0u8; 32];
-        one[0] = 1;
-        must(unsafe { ffi::kyb_mul_base_batch(one.as_ptr(), 1, std::ptr::null_mut(), self.ext_mut()) }, "base");
+        static BASE_EXT: std::sync::OnceLock<[[i32; 10]; 4]> = std::sync::OnceLock::new();
+        self.ge = *BASE_EXT.get_or_init(|| {
+            ensure_init();
+            let mut one = [0u8; 32];
+            one[0] = 1;
+            let mut b = [[0i32; 10]; 4];
+            must(unsafe { ffi::kyb_mul_base_batch(one.as_ptr(), 1, std::ptr::null_mut(), b.as_mut_ptr() as *mut i32) }, "base");
+            b
+        });
         self
     }
 
