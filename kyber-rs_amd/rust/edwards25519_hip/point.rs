@@ -269,7 +269,7 @@ impl group::Point for Point {
         self
     }
 
-    /// point.rs:85-88 — the reference copies the literal BASEEXT; here 1 * B from the engine, once per process (the same point, Z = 1)
+    /// point.rs:85-88 — the reference copies the literal BASEEXT; here 1 * B from the engine, once per process (the same point; like BASEEXT not normalised to Z = 1 when ext.projective is on)
     fn base(mut self) -> Self {
         static BASE_EXT: std::sync::OnceLock<[[i32; 10]; 4]> = std::sync::OnceLock::new();
         self.ge = *BASE_EXT.get_or_init(|| {
