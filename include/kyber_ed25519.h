@@ -298,6 +298,10 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *                     (default 4096), coop.decode_max_items for a bare decode (default 1024), coop.verify_max_items for the
  *                     kernels that give ONE item several wavefronts (verification in one launch, signing in one launch, the fixed
  *                     base with four wavefronts per item; default 512).  Same results either way.
+ *   mul.short_scalars  1 (default): a host-pointer kyb_mul_batch of at most 64 items (pts_ext) whose scalars are ALL below 2^64 — share indices
+ *                     (PubPoly::eval, poly.rs:461-464), the cofactor (Point::pick, point.rs:148): public multipliers; a uniformly random
+ *                     secret is that small with probability 2^-188 — starts its ladder below the leading zero bits: 29 us instead of 158 for a
+ *                     10-bit index (57 instead of 186 with the encoding).  0: always the full 255 steps.  Same results either way.
  *   poly.batch_segments  kyb_pubpoly_eval*_batch, long polynomials at 10^3..6x10^4 evaluations: the Horner chain of an evaluation is cut into
  *                     this many segments, one per lane, recombined with x^(s len) mod 8L by the variable-base ladder (0 = chosen by a cost
  *                     model from t, the batch size and the bit length of the largest index; 1 = never; 2..256).  Same results either way.

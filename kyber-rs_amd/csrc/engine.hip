@@ -108,6 +108,7 @@ struct Ctx {
   std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: chunks that alternate between the two lanes
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
+  std::atomic<int> opt_mul_short_scalars{1};     // host-pointer kyb_mul_batch of <= 64 items whose scalars are ALL below 2^64: the ladder skips the leading zeros
   std::atomic<int> opt_poly_batch_segments{0};   // PubPoly::eval, long polynomials at 10^3..10^4 evaluations: lanes per evaluation of the batch kernels (0 = cost model, 1 = never, 2..256)
   std::atomic<int> opt_poly_segments{0};         // PubPoly::eval, small batches: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never split, 2..32)
   std::atomic<int> opt_verify_by_enc{1};         // large verification batches: compare the encoding of s*B - h*A with R's bytes, decode R only on a mismatch
@@ -843,7 +844,11 @@ int launch_sum(Ctx& g, const int32_t* pext, const uint8_t* penc, uint8_t* ok, bo
   return launch_finish(g, r, m, oenc, oext, st, t, true);
 }
 
-int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, hipStream_t st) {
+// skip_hint: leading zero bits EVERY scalar of the call has (host-pointer calls of a few items look; 0 = unknown).  When all of them are below
+// 2^64 — share indices, the cofactor: public multipliers; a uniformly random secret is that small with probability 2^-188 — the ladder of the
+// one-item-per-wavefront kernel starts below the zeros: Point::mul(x_i, Some(v)) of an unmodified PubPoly::eval takes 10 steps, not 255.
+int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, hipStream_t st,
+               int skip_hint = 0) {
   if (n == 0) return KYB_OK;
   std::lock_guard<std::mutex> launch_lock(g.launch_mu);
   StreamRes* r = nullptr;
@@ -866,8 +871,9 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
       HIPCK(hipMemsetAsync(ok, 1, n, st));
     }
     ProfScope ps(g, st, KID_MUL_COOP);
-    LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, 0, nullptr, 0, 0, take_done_flag(g, st, n), 0,
-                              2 * n <= (size_t)g.opt_coop_verify_max ? 4 : 1,      // very few items (measured: up to 256): four wavefronts share an item's scalar
+    const bool short_scalars = skip_hint >= 192 && g.opt_mul_short_scalars != 0;
+    LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, short_scalars ? (skip_hint > 255 ? 255 : skip_hint) : 0, nullptr, 0, 0, take_done_flag(g, st, n), 0,
+                              (!short_scalars && 2 * n <= (size_t)g.opt_coop_verify_max) ? 4 : 1,   // very few items (measured: up to 256): four wavefronts share an item's scalar
                               g.opt_ext_projective != 0));
     return KYB_OK;
   }

@@ -281,7 +281,7 @@ __device__ __forceinline__ cq coop_dbl(const lane_consts& c, cq h) {
 }
 
 // The whole ladder: UWQ = the base point's u as U1 (row 0) / W1 (row 2), tight; |scalar| = mag (or its words w_hi .. w_lo taken as a
-// number of their own), the top skip_bits bits of word 7 known to be 0.
+// number of their own), the top skip_bits bits of the words from w_hi downwards known to be 0 (any number up to the piece's length).
 // Returns the state after the last conditional swap: SX = (x2, x2, x3, x3), SZ = (z2, z2, z3, z3).
 __device__ __forceinline__ void coop_ladder_run(const lane_consts& c, const uint32_t mag[8], int skip_bits, cq UWQ, cq& SX, cq& SZ, int w_hi = 7, int w_lo = 0) {
   const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
@@ -293,12 +293,13 @@ __device__ __forceinline__ void coop_ladder_run(const lane_consts& c, const uint
   }
   const ladder_idx li = ladder_idx_init(c);
   uint32_t swap = 0;
+  const int w_top = w_hi - (skip_bits >> 5);                               // whole leading words known to be zero are not walked at all
 #pragma unroll 1
-  for (int w = w_hi; w >= w_lo; --w) {                                     // the scalar's words w_hi .. w_lo (a piece of it, or all eight)
+  for (int w = w_top; w >= w_lo; --w) {                                    // the scalar's words w_hi .. w_lo (a piece of it, or all eight)
     uint32_t word = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) word = (w == q) ? mag[q] : word;
-    const int first = (w == 7) ? skip_bits : 0;
+    const int first = (w == w_top) ? (skip_bits & 31) : 0;
     word <<= first;
 #pragma unroll 1
     for (int j = first; j < 32; ++j) {

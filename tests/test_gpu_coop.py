@@ -405,3 +405,42 @@ def test_coop_primitives_match_the_lane_model(engine):
                 v = int(img64[word(idx, 10 * ge + k)])
                 want[16 * g_ + k] = (M.P2[k] - v) if (g_ == 2 and neg) else v
         assert same(run(4, np.zeros(64, np.uint32), B), want), (pos, idx, neg)
+
+
+def test_short_public_scalars_take_a_short_ladder(engine, oracle):
+    """A host-pointer mul of a few items whose scalars are ALL below 2^64 (share indices, the cofactor: what PubPoly::eval and
+    Point::pick multiply by, poly.rs:464, point.rs:148) starts its ladder below the leading zeros; same points as the full ladder and
+    as the reference's 64-window routine, also on small-order and mixed-order operands."""
+    weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
+    pts = list(oracle.mul_base_ext_batch(synth.scalars(6, 501, b"short")))
+    pts[1] = oracle.add(pts[1], weak[2])
+    pts[2] = weak[3]
+    pts[3] = oracle.null()
+    small = [0, 1, 2, 3, 8, 513, 65535, 65536, (1 << 32) - 1, 1 << 32, (1 << 63) + 5, (1 << 64) - 1]
+    for v in small:
+        for p in pts:
+            s = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8)[None, :]
+            got, ext = engine.mul(s, pts_ext=p[None, :], want_ext=True)
+            assert bytes(got[0]) == oracle.mul(bytes(s[0]), p), (v, "enc")
+            assert oracle.encode(ext[0]) == bytes(got[0])
+    # several items in one call: short only when every scalar is short
+    sc = np.stack([np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8) for v in small[:6]])
+    P = np.stack(pts)
+    want = oracle.mul_batch(sc, P)
+    assert np.array_equal(engine.mul(sc, pts_ext=P), want)
+    mixed = sc.copy(); mixed[4] = synth.scalars(1, 9)[0]
+    assert np.array_equal(engine.mul(mixed, pts_ext=P), oracle.mul_batch(mixed, P))
+    big = np.frombuffer((1 << 64).to_bytes(32, "little"), dtype=np.uint8)[None, :]
+    assert bytes(engine.mul(big, pts_ext=P[:1])[0]) == oracle.mul(bytes(big[0]), P[0])
+    engine.set_option("mul.short_scalars", 0)
+    try:
+        assert np.array_equal(engine.mul(sc, pts_ext=P), want)
+    finally:
+        engine.set_option("mul.short_scalars", 1)
+    # projective hand-over keeps working on the short path
+    engine.set_option("ext.projective", 1)
+    try:
+        ext = engine.mul(sc, pts_ext=P, ext_only=True)
+        assert np.array_equal(engine.encode(ext), want)
+    finally:
+        engine.set_option("ext.projective", 0)

@@ -20,10 +20,15 @@ def t(fn, reps=60):
     return sorted(ts)[len(ts) // 2] * 1e6
 
 
+small = np.zeros((64, 32), dtype=np.uint8)      # x = index + 1 of PubPoly::eval (poly.rs:461-464): 513, 514, ...
+small[:, 0] = np.arange(1, 65, dtype=np.uint8); small[:, 1] = 2
+
+
 def ext_only_rows():
     eng.set_option("ext.projective", 1)
     for name, fn in (("mul_base -> ext only, projective", lambda n: eng.mul_base(s[:n], ext_only=True)),
-                     ("mul(ext) -> ext only, projective", lambda n: eng.mul(s[:n], pts_ext=ext[:n], ext_only=True))):
+                     ("mul(ext) -> ext only, projective", lambda n: eng.mul(s[:n], pts_ext=ext[:n], ext_only=True)),
+                     ("mul(ext) by a 10-bit share index -> ext only, projective", lambda n: eng.mul(small[:n], pts_ext=ext[:n], ext_only=True))):
         print(f"{name}, {t(lambda: fn(1)):.1f}, {t(lambda: fn(64)):.1f}", flush=True)
     eng.set_option("ext.projective", 0)
 
@@ -31,7 +36,7 @@ def ext_only_rows():
 print("op, n=1 us, n=64 us")
 for name, fn in (("encode", lambda n: eng.encode(ext[:n])), ("decode", lambda n: eng.decode(enc[:n])), ("add", lambda n: eng.add(ext[:n], ext2[:n])),
                  ("equal", lambda n: eng.equal(ext[:n], ext2[:n])), ("mul_base", lambda n: eng.mul_base(s[:n])),
-                 ("mul(ext)", lambda n: eng.mul(s[:n], pts_ext=ext[:n])), ("mul(enc)", lambda n: eng.mul(s[:n], pts_enc=enc[:n])),
+                 ("mul(ext)", lambda n: eng.mul(s[:n], pts_ext=ext[:n])), ("mul(ext) by a 10-bit share index", lambda n: eng.mul(small[:n], pts_ext=ext[:n])), ("mul(enc)", lambda n: eng.mul(s[:n], pts_enc=enc[:n])),
                  ("sign", lambda n: eng.schnorr_sign(s[:n], s[:n], msgs[:n])), ("verify", lambda n: eng.verify(enc[:n], msgs[:n], sigs[:n], 1)),
                  ("pubpoly_eval(t=8)", lambda n: eng.pubpoly_eval(ext[:8], np.arange(n, dtype=np.uint32))),
                  ("pubpoly_eval(t=683, index 512)", lambda n: eng.pubpoly_eval(np.tile(ext, (11, 1))[:683], np.full(n, 512, dtype=np.uint32))),
