@@ -95,6 +95,21 @@ while time.time() < t_end:
                 assert np.array_equal(eng.mul_base(POOL_S[sl]), WANT_BASE[sl])
             else:
                 assert np.array_equal(eng.encode(eng.mul_base(POOL_S[sl], ext_only=True)), WANT_BASE[sl])
+        elif op == "mul_ext" and n <= 64 and rng.integers(0, 2):
+            # short public multipliers (share indices, the cofactor): the ladder skips the leading zeros when every scalar of the call is below 2^64
+            bits = int(rng.choice([1, 4, 10, 32, 63, 64, 65]))
+            sc = np.zeros((n, 32), dtype=np.uint8)
+            sc[:, :9] = rng.integers(0, 256, (n, 9), dtype=np.uint8)
+            for i in range(n):
+                v = int.from_bytes(bytes(sc[i]), "little") & ((1 << bits) - 1)
+                sc[i] = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8)
+            eng.set_option("mul.short_scalars", int(rng.integers(0, 4) != 0))
+            want = orc.mul_batch(sc, POOL_P[sl])
+            if opts["ext.projective"]:
+                assert np.array_equal(eng.encode(eng.mul(sc, pts_ext=POOL_P[sl], ext_only=True)), want)
+            else:
+                assert np.array_equal(eng.mul(sc, pts_ext=POOL_P[sl]), want)
+            eng.set_option("mul.short_scalars", 1)
         elif op == "mul_ext":
             if rng.integers(0, 2):
                 assert np.array_equal(eng.mul(K2[sl], pts_ext=POOL_P[sl]), WANT_MUL[sl])
