@@ -348,9 +348,16 @@ impl group::Point for Point {
         Ok(b[1..1 + dl].to_vec())
     }
 
-    /// point.rs:179-188, on the CPU with the reference's own formulas (ge.rs:99-110, 217-234, 292-297): nine field multiplications
-    /// take 0.3 us there, a batch-of-1 round trip to the GPU 26 us.  (`Point::add_batch` is the engine's `kyb_add_batch`.)
+    /// point.rs:179-188.  A single pair is added on the CPU with the reference's own formulas (ge.rs:99-110, 217-234, 292-297): nine field
+    /// multiplications take 0.3 us there, a batch-of-1 round trip to the GPU 26 us, and the ABI's ext record IS the reference's limb
+    /// layout, so nothing is converted.  Cargo feature `hip-single-add` sends it to the engine instead (`kyb_add_batch`, n = 1: the same
+    /// point); vectors go there in any case (`Point::add_batch`).
     fn add(mut self, p1: &Self, p2: &Self) -> Self {
+        if cfg!(feature = "hip-single-add") {
+            ensure_init();
+            must(unsafe { ffi::kyb_add_batch(p1.ext(), p2.ext(), 1, self.ext_mut(), 0) }, "add");
+            return self;
+        }
         let mut t2 = CachedGroupElement::default();
         let mut r = CompletedGroupElement::default();
         p2.to_ref().write_cached(&mut t2);
@@ -363,6 +370,11 @@ impl group::Point for Point {
 
     /// point.rs:190-199, as `add`
     fn sub(mut self, p1: &Self, p2: &Self) -> Self {
+        if cfg!(feature = "hip-single-add") {
+            ensure_init();
+            must(unsafe { ffi::kyb_add_batch(p1.ext(), p2.ext(), 1, self.ext_mut(), 1) }, "sub");
+            return self;
+        }
         let mut t2 = CachedGroupElement::default();
         let mut r = CompletedGroupElement::default();
         p2.to_ref().write_cached(&mut t2);
