@@ -23,6 +23,19 @@ use std::os::raw::c_int;
 
 use super::ffi::{self, ensure_init, must};
 
+/// 1 * B from the engine, asked for once per process
+fn base_ext() -> &'static [[i32; 10]; 4] {
+    static BASE_EXT: std::sync::OnceLock<[[i32; 10]; 4]> = std::sync::OnceLock::new();
+    BASE_EXT.get_or_init(|| {
+        ensure_init();
+        let mut one = [0u8; 32];
+        one[0] = 1;
+        let mut b = [[0i32; 10]; 4];
+        must(unsafe { ffi::kyb_mul_base_batch(one.as_ptr(), 1, std::ptr::null_mut(), b.as_mut_ptr() as *mut i32) }, "base");
+        b
+    })
+}
+
 const MARSHAL_POINT_ID: [u8; 8] = [b'e', b'd', b'.', b'p', b'o', b'i', b'n', b't'];
 
 /// Same data as the reference's `Point { ge: ExtendedGroupElement, var_time: bool }` (point.rs:23-27):
@@ -271,15 +284,7 @@ impl group::Point for Point {
 
     /// point.rs:85-88 — the reference copies the literal BASEEXT; here 1 * B from the engine, once per process (the same point; like BASEEXT not normalised to Z = 1 when ext.projective is on)
     fn base(mut self) -> Self {
-        static BASE_EXT: std::sync::OnceLock<[[i32; 10]; 4]> = std::sync::OnceLock::new();
-        self.ge = *BASE_EXT.get_or_init(|| {
-            ensure_init();
-            let mut one = [0u8; 32];
-            one[0] = 1;
-            let mut b = [[0i32; 10]; 4];
-            must(unsafe { ffi::kyb_mul_base_batch(one.as_ptr(), 1, std::ptr::null_mut(), b.as_mut_ptr() as *mut i32) }, "base");
-            b
-        });
+        self.ge = *base_ext();
         self
     }
 
@@ -402,6 +407,12 @@ impl group::Point for Point {
         ensure_init();
         match p {
             None => must(unsafe { ffi::kyb_mul_base_batch(s.v.as_ptr(), 1, std::ptr::null_mut(), self.ext_mut()) }, "mul(None)"),
+            // Every in-tree caller passes the generator as Some(base) (PriPoly::commit, poly.rs:195-206; vss.rs:303): when the operand is,
+            // limb for limb, what `base()` hands out and the scalar is below 2^255 (no top-digit quirk in either routine), the fixed-base
+            // kernel gives the same point in a sixth of the time.
+            Some(a_p) if a_p.ge == *base_ext() && s.v[31] & 0x80 == 0 => {
+                must(unsafe { ffi::kyb_mul_base_batch(s.v.as_ptr(), 1, std::ptr::null_mut(), self.ext_mut()) }, "mul(Some(base))")
+            }
             Some(a_p) => must(
                 unsafe {
                     ffi::kyb_mul_batch(s.v.as_ptr(), std::ptr::null(), a_p.ext(), 1, std::ptr::null_mut(), self.ext_mut(), std::ptr::null_mut())
