@@ -27,6 +27,7 @@
 
 #include "../../include/kyber_ed25519.h"
 #include "launch.h"
+#include "scalar_scan.h"
 #include "ge_scalarmult.h"      // table image geometry (KYB_BASE*_TABLE_WORDS, KYB_BT_IDX); plain C++ on the host
 #include "host_copy_pool.h"
 

@@ -5,6 +5,7 @@
 // This library is never loaded by the product (kyber-rs_amd/ loads only libkyber_ed25519_hip.so and
 // fails without a GPU); it is not a CPU fallback.
 #define KYB_HOST_TEST 1
+#include "../../kyber-rs_amd/csrc/scalar_scan.h"
 #include <atomic>
 #include <cstring>
 #include <vector>
@@ -305,6 +306,7 @@ void hd_pubpoly_eval_segments(uint8_t out[32], const int32_t* commits, int t, ui
   ge_encode(w, v[0].X, v[0].Y, v[0].Z);
   memcpy(out, w, 32);
 }
+int hd_common_leading_zero_bits(const uint8_t* scalars, uint32_t n) { return kyb::common_leading_zero_bits(scalars, n); }
 void hd_effective(uint8_t mag[32], int* neg, const uint8_t scalar[32]) {
   uint32_t a[8], m[8], n;
   load_words(a, scalar);

@@ -299,6 +299,22 @@ def test_pubpoly_eval_cut_into_segments(hd, oracle):
     assert hd.hd_overflows() == base
 
 
+def test_common_leading_zero_bits_of_a_small_call(hd):
+    """the host-side scan behind the short-multiplier path of kyb_mul_batch (scalar_scan.h)"""
+    rnd = random.Random(3)
+    for _ in range(300):
+        n = rnd.randrange(1, 9)
+        bits = [rnd.choice([0, 1, 2, 7, 8, 9, 31, 32, 33, 63, 64]) for _ in range(n)]
+        vals = [(rnd.getrandbits(b) | (1 << (b - 1))) if b else 0 for b in bits]
+        buf = b"".join(v.to_bytes(32, "little") for v in vals)
+        got = hd.hd_common_leading_zero_bits(buf, n)
+        assert got == 256 - max(bits)
+    # a long scalar anywhere ends the short path: the result only has to be below 192
+    buf = (5).to_bytes(32, "little") + (1 << 200).to_bytes(32, "little") + (7).to_bytes(32, "little")
+    assert hd.hd_common_leading_zero_bits(buf, 3) < 192
+    assert hd.hd_common_leading_zero_bits(((1 << 256) - 1).to_bytes(32, "little"), 1) == 0
+
+
 def test_ladder_path_matches_oracle(hd, oracle):
     """table-free variable-base path (ge_ladder.h) == the reference's windowed multiplication on every
     quirk vector (small-order / mixed-order / non-canonical points; scalars 0, L, 8L, >= 2^255) and on
