@@ -291,9 +291,14 @@ def small_call_latency(eng, orc):
             a = time.perf_counter(); fn(); ts.append(time.perf_counter() - a)
         return round(sorted(ts)[len(ts) // 2] * 1e6, 1)
 
+    # x = index + 1 of PubPoly::eval (poly.rs:461-464): a call whose multipliers are all below 2^64 starts its ladder below the leading zeros
+    idx = np.zeros((64, 32), dtype=np.uint8)
+    idx[:, 0] = np.arange(1, 65, dtype=np.uint8); idx[:, 1] = 2
+    assert np.array_equal(eng.mul(idx, pts_ext=ext), orc.mul_batch(idx, ext))
     out = {"unit": "us per host-pointer call (median of 100)", "checked_against_oracle": True}
     for n in (1, 64):
         out[f"n={n}"] = {"mul_base": med(lambda: eng.mul_base(s[:n])), "mul": med(lambda: eng.mul(k[:n], pts_ext=ext[:n])),
+                         "mul_by_10bit_index": med(lambda: eng.mul(idx[:n], pts_ext=ext[:n])),
                          "sign": med(lambda: eng.schnorr_sign(s[:n], k[:n], msgs[:n])), "verify": med(lambda: eng.verify(enc[:n], msgs[:n], sigs[:n], 1)),
                          "decode": med(lambda: eng.decode(enc[:n])), "encode": med(lambda: eng.encode(ext[:n]))}
     return out
