@@ -61,6 +61,7 @@ struct StreamRes {
   hipStream_t stream = nullptr;
   uint4* ws = nullptr; uint4* proj = nullptr; size_t proj_items = 0; uint8_t* enc = nullptr; size_t enc_bytes = 0;
   uint32_t* part = nullptr; size_t part_items = 0;      // extended quads of a small linear combination's products
+  uint32_t* top_or = nullptr; unsigned top_seq = 0;     // two alternating words behind the projective staging records (k_mont_prep / k_mul_ladder)
   hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_last = nullptr;
   bool used = false, own = false;
   uint64_t last_use = 0;
@@ -109,6 +110,7 @@ struct Ctx {
   std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: chunks that alternate between the two lanes
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
+  std::atomic<int> opt_ladder_skip_canonical{1};  // the batch ladder skips the three leading bits when no scalar of the launch has one set (canonical scalars)
   std::atomic<int> opt_mul_short_scalars{1};     // host-pointer kyb_mul_batch of <= 64 items whose scalars are ALL below 2^64: the ladder skips the leading zeros
   std::atomic<int> opt_poly_batch_segments{0};   // PubPoly::eval, long polynomials at 10^3..10^4 evaluations: lanes per evaluation of the batch kernels (0 = cost model, 1 = never, 2..256)
   std::atomic<int> opt_poly_segments{0};         // PubPoly::eval, small batches: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never split, 2..32)
@@ -555,11 +557,13 @@ int ensure_proj(Ctx& g, StreamRes* r, size_t items) {
   if (items <= r->proj_items) return KYB_OK;
   HIPCK(hipStreamSynchronize(r->stream));
   if (r->proj) wipe_free_dev(r->proj, r->proj_items * 8 * sizeof(uint4));
-  r->proj = nullptr; r->proj_items = 0;
+  r->proj = nullptr; r->proj_items = 0; r->top_or = nullptr;
   const size_t want = ((items + (items >> 3)) + 1023) & ~(size_t)1023;
-  hipError_t e = hipMalloc(&r->proj, want * 8 * sizeof(uint4));
+  hipError_t e = hipMalloc(&r->proj, want * 8 * sizeof(uint4) + 256);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "projective staging allocation", e);
   r->proj_items = want;
+  r->top_or = reinterpret_cast<uint32_t*>(r->proj + want * 8);
+  HIPCK(hipMemsetAsync(r->top_or, 0, 256, r->stream));
   return KYB_OK;
 }
 // extended quads of k_mul_coop's products for k_sum_coop (40 words per item)
@@ -743,13 +747,22 @@ int launch_ladder_core(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int
   } else if (ok != nullptr) {
     HIPCK(hipMemsetAsync(ok, 1, np, st));          // extended operands are taken as they are (k_mul does the same)
   }
+  // Are all scalars canonical (below 2^253)?  k_mont_prep ORs their top three bits into one of two alternating words on the way (one scalar
+  // per point only), the ladder starts three bits lower when the word stayed 0 and clears the other word for the next call on this stream.
+  uint32_t* top_or = nullptr;
+  uint32_t* zero_next = nullptr;
+  if (skip_bits == 0 && npts == 0 && g.opt_ladder_skip_canonical != 0) {
+    top_or = r->top_or + (r->top_seq & 1u);
+    zero_next = r->top_or + ((r->top_seq & 1u) ^ 1u);
+    ++r->top_seq;
+  }
   {
     ProfScope ps(g, st, KID_MONT_PREP);
-    LAUNCHCK(launch::mont_prep(st, pext, np, r->proj + (npts ? n : 0), r->proj_items));
+    LAUNCHCK(launch::mont_prep(st, pext, np, r->proj + (npts ? n : 0), r->proj_items, top_or ? sc : nullptr, top_or));
   }
   {
     ProfScope ps(g, st, KID_MUL_LADDER);
-    LAUNCHCK(launch::mul_ladder(g.opt_ladder_waves, st, sc, n, r->proj, r->proj_items, n, npts, skip_bits));
+    LAUNCHCK(launch::mul_ladder(g.opt_ladder_waves, st, sc, n, r->proj, r->proj_items, n, npts, skip_bits, top_or, zero_next));
   }
   return KYB_OK;
 }

@@ -52,10 +52,23 @@ k_decode_to_proj(const uint8_t* __restrict__ enc, size_t n, uint4* __restrict__ 
 // i in the staging buffer: quads 0..4 = u[10] v[10], quad 5.x = flags (the ladder kernel later overwrites
 // the same record with the projective result).
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
-k_mont_prep(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ proj, size_t stride) {
+k_mont_prep(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ proj, size_t stride, const uint8_t* __restrict__ scalars,
+            uint32_t* __restrict__ top_or) {
   const size_t M = (n + FINISH_K - 1) / FINISH_K;
   const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (j >= M) return;
+  if (top_or != nullptr) {
+    // On the way: the OR of the top three bits of this lane's scalars.  The word stays 0 iff every scalar of the launch is below 2^253, as
+    // every value reduced mod L is (L < 2^253); the ladder kernel then skips those three steps (1.2 % of its time).  The test says
+    // nothing about a canonical scalar; for the unreduced inputs the reference also accepts (clamped keys, quirk vectors) the word
+    // becomes non-zero and all 256 bits are walked.
+    uint32_t top = 0;
+    KYB_UNROLL for (int t = 0; t < FINISH_K; ++t) {
+      const size_t i = j + (size_t)t * M;
+      if (i < n) top |= reinterpret_cast<const uint32_t*>(scalars)[8 * i + 7] >> 29;
+    }
+    if (top != 0u) atomicOr(top_or, top);
+  }
   auto load = [&](int t, fe& d) {
     const size_t i = j + (size_t)t * M;
     if (i < n) { ge_p3 P; uint32_t fl; load_ext(P, pts_ext, i); mont_prep_den(d, fl, P); }
@@ -89,7 +102,12 @@ __device__ size_t kyb_diag_stamp_cap = 0;
 #endif
 template <int WAVES>
 __global__ void __launch_bounds__(KYB_BLOCK, WAVES)
-k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits) {
+k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits_arg,
+             const uint32_t* __restrict__ top_or, uint32_t* __restrict__ zero_next) {
+  // top_or (written by k_mont_prep of this call): 0 iff every scalar of the launch is below 2^253 — the ladder then starts below the three
+  // leading zeros.  zero_next: the word the NEXT call on this stream will collect into (the two alternate), cleared here.
+  const int skip_bits = top_or != nullptr ? ((*top_or == 0u) ? 3 : 0) : skip_bits_arg;
+  if (zero_next != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0u;
   const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (i >= n) return;
   uint32_t a[8];
@@ -153,15 +171,16 @@ hipError_t decode_to_proj(hipStream_t st, const uint8_t* enc, size_t n, uint4* p
   hipLaunchKernelGGL(k_decode_to_proj, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, enc, n, proj, stride, ok, rows, cols);
   return hipGetLastError();
 }
-hipError_t mont_prep(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride) {
+hipError_t mont_prep(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride, const uint8_t* scalars, uint32_t* top_or) {
   const size_t M = (n + FINISH_K - 1) / FINISH_K;
-  hipLaunchKernelGGL(k_mont_prep, dim3(blocks_for(M)), dim3(KYB_BLOCK), 0, st, pext, n, proj, stride);
+  hipLaunchKernelGGL(k_mont_prep, dim3(blocks_for(M)), dim3(KYB_BLOCK), 0, st, pext, n, proj, stride, scalars, top_or);
   return hipGetLastError();
 }
-hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, uint4* proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits) {
-  if (waves >= 4)      hipLaunchKernelGGL((k_mul_ladder<4>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits);
-  else if (waves == 3) hipLaunchKernelGGL((k_mul_ladder<3>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits);
-  else                 hipLaunchKernelGGL((k_mul_ladder<2>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits);
+hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, uint4* proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits,
+                      const uint32_t* top_or, uint32_t* zero_next) {
+  if (waves >= 4)      hipLaunchKernelGGL((k_mul_ladder<4>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits, top_or, zero_next);
+  else if (waves == 3) hipLaunchKernelGGL((k_mul_ladder<3>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits, top_or, zero_next);
+  else                 hipLaunchKernelGGL((k_mul_ladder<2>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits, top_or, zero_next);
   return hipGetLastError();
 }
 hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half) {

@@ -43,8 +43,11 @@ hipError_t sign_fused(int mode, int grid, hipStream_t st, const uint8_t* x, cons
 hipError_t decode_or_identity(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok);
 // rows != 0: encoding i = (r, c) of a rows x cols matrix lands in record c * rows + r
 hipError_t decode_to_proj(hipStream_t st, const uint8_t* enc, size_t n, uint4* proj, size_t stride, uint8_t* ok, size_t rows, size_t cols);
-hipError_t mont_prep(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride);
-hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, uint4* proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits);
+// scalars / top_or != nullptr (one scalar per point): the OR of the scalars' top three bits is collected into *top_or on the way
+hipError_t mont_prep(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride, const uint8_t* scalars = nullptr, uint32_t* top_or = nullptr);
+// top_or != nullptr: the word mont_prep collected into — the kernel takes skip_bits = 3 when it is 0, else 0; zero_next: cleared for the next call
+hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, uint4* proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits,
+                      const uint32_t* top_or = nullptr, uint32_t* zero_next = nullptr);
 hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half);
 hipError_t ext_to_proj(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride);
 #if defined(KYB_DIAG_STAMPS)

@@ -959,3 +959,32 @@ def test_verify_equation_on_raw_kernels_all_golden_lines(engine):
     # and from the wire encodings of A (the decode runs inside kyb_mul_batch)
     _, ha2 = engine.mul(as_u8(hs), pts_enc=as_u8(pubs), want_ext=True)
     assert np.array_equal(engine.encode(engine.add(r_ext, ha2)), rhs)
+
+
+def test_ladder_skips_the_leading_zeros_only_when_every_scalar_is_canonical(engine, oracle):
+    """The batch ladder starts three bits lower when no scalar of the launch reaches 2^253 (k_mont_prep ORs their top bits on the way, two
+    alternating words per stream): one unreduced scalar anywhere in the batch must switch the whole launch back to 256 steps, and the
+    launches before and after it must not see its flag."""
+    n = 8192
+    s = synth.scalars(n, 61)
+    pts = oracle.mul_base_ext_batch(synth.scalars(n, 62, b"p"))
+    want = oracle.mul_batch(s, pts, nthreads=8)
+    assert np.array_equal(engine.mul(s, pts_ext=pts), want)
+    for pos, top in ((n - 3, 0x20), (5, 0x80), (4097, 0xff)):
+        t = s.copy()
+        t[pos, 31] |= top                                   # bit 253, bit 255, everything
+        w = want.copy()
+        w[pos] = np.frombuffer(oracle.mul(bytes(t[pos]), pts[pos]), dtype=np.uint8)
+        assert np.array_equal(engine.mul(t, pts_ext=pts), w), (pos, top)
+        assert np.array_equal(engine.mul(s, pts_ext=pts), want)      # the next launch is canonical again
+    engine.set_option("ladder.skip_canonical", 0)
+    try:
+        assert np.array_equal(engine.mul(s, pts_ext=pts), want)
+    finally:
+        engine.set_option("ladder.skip_canonical", 1)
+    # linear combinations with private points go through the same launch sequence
+    lam = synth.scalars(40 * 200, 63).reshape(200, 40, 32)
+    pp = pts[: 40 * 200].reshape(200, 40, 40)
+    got = engine.lincomb(lam, pts_ext=pp)
+    for g in (0, 99, 199):
+        assert bytes(got[g]) == oracle.lincomb(lam[g], pp[g])
