@@ -886,7 +886,9 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
     }
     ProfScope ps(g, st, KID_MUL_COOP);
     const bool short_scalars = skip_hint >= 192 && g.opt_mul_short_scalars != 0;
-    LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, short_scalars ? (skip_hint > 255 ? 255 : skip_hint) : 0, nullptr, 0, 0, take_done_flag(g, st, n), 0,
+    // (canonical scalars, all below 2^253: the top wavefront's piece starts three bits lower, as the batch ladder does)
+    const int canon_skip = (skip_hint >= 3 && g.opt_ladder_skip_canonical != 0) ? 3 : 0;
+    LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, short_scalars ? (skip_hint > 255 ? 255 : skip_hint) : canon_skip, nullptr, 0, 0, take_done_flag(g, st, n), 0,
                               (!short_scalars && 2 * n <= (size_t)g.opt_coop_verify_max) ? 4 : 1,   // very few items (measured: up to 256): four wavefronts share an item's scalar
                               g.opt_ext_projective != 0));
     return KYB_OK;

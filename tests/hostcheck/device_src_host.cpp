@@ -307,6 +307,7 @@ void hd_pubpoly_eval_segments(uint8_t out[32], const int32_t* commits, int t, ui
   memcpy(out, w, 32);
 }
 int hd_common_leading_zero_bits(const uint8_t* scalars, uint32_t n) { return kyb::common_leading_zero_bits(scalars, n); }
+int hd_common_leading_zero_bits_exact(const uint8_t* scalars, uint32_t n) { return kyb::common_leading_zero_bits(scalars, n, 256); }
 void hd_effective(uint8_t mag[32], int* neg, const uint8_t scalar[32]) {
   uint32_t a[8], m[8], n;
   load_words(a, scalar);

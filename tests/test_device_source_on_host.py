@@ -313,6 +313,10 @@ def test_common_leading_zero_bits_of_a_small_call(hd):
     buf = (5).to_bytes(32, "little") + (1 << 200).to_bytes(32, "little") + (7).to_bytes(32, "little")
     assert hd.hd_common_leading_zero_bits(buf, 3) < 192
     assert hd.hd_common_leading_zero_bits(((1 << 256) - 1).to_bytes(32, "little"), 1) == 0
+    # exact mode (what kyb_mul_batch uses: the canonical test must see a long scalar behind a shorter long one)
+    buf = (1 << 250).to_bytes(32, "little") + (1 << 255).to_bytes(32, "little")
+    assert hd.hd_common_leading_zero_bits_exact(buf, 2) == 0
+    assert hd.hd_common_leading_zero_bits_exact((1 << 250).to_bytes(32, "little") * 2, 2) == 5
 
 
 def test_ladder_path_matches_oracle(hd, oracle):
