@@ -231,10 +231,12 @@ def roofline(w, eng, steps):
     executed = EXECUTED.get(dom, dom_products)
     if isinstance(executed, dict):
         executed = executed[eng.get_option("mul_base.radix") if n >= eng.get_option("finish.min_items") else 16]
-    if dom == "k_mul_ladder" and (wl == "verify" or eng.get_option("ladder.skip_canonical")):
-        # the ladder starts three bits lower: the challenge h of a verification is < L < 2^253 by construction, and the bench's scalars are
-        # reduced mod L (every scalar of the launch below 2^253: ladder.skip_canonical, checked on the device per launch)
-        executed -= 3 * (5 * 100 + 4 * 55 + 10)
+    if dom == "k_mul_ladder" and wl == "verify":
+        executed -= 3 * (5 * 100 + 4 * 55 + 10)      # the challenge h is < L < 2^253 by construction: the ladder starts three bits lower
+    elif dom == "k_mul_ladder" and eng.get_option("ladder.skip_canonical"):
+        # the bench's scalars are reduced mod L: every scalar of the launch is below 2^252 (checked on the device per launch) and the
+        # ladder starts four bits lower
+        executed -= 4 * (5 * 100 + 4 * 55 + 10)
     exec_rate = executed * items_per_launch / (dom_ms * 1e-3)
     avg_step_ms = sum(w["step_ms"]) / len(w["step_ms"])
     # HBM/fabric bytes per launch of the dominant kernel: NOT measured in this run — replayed from the PMC passes of the

@@ -298,9 +298,10 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *                     (default 4096), coop.decode_max_items for a bare decode (default 1024), coop.verify_max_items for the
  *                     kernels that give ONE item several wavefronts (verification in one launch, signing in one launch, the fixed
  *                     base with four wavefronts per item; default 512).  Same results either way.
- *   ladder.skip_canonical  1 (default): the batch ladder starts three bits lower when no scalar of the launch reaches 2^253 — true of every
- *                     scalar reduced mod L, so the test (an OR over the batch, taken on the way by the kernel that prepares the points) says
- *                     nothing about a canonical secret; one unreduced scalar anywhere and the launch walks all 256 bits.  0: always 256.
+ *   ladder.skip_canonical  1 (default): the batch ladder starts four bits lower when no scalar of the launch reaches 2^252 — true of a scalar
+ *                     reduced mod L (L = 2^252 + 2.8e37) except for 2^-127 of them, so the test (an OR over the batch, taken on the way by the
+ *                     kernel that prepares the points) says nothing about a canonical secret; one unreduced scalar anywhere and the launch
+ *                     walks all 256 bits.  0: always 256.
  *   mul.short_scalars  1 (default): a host-pointer kyb_mul_batch of at most 64 items (pts_ext) whose scalars are ALL below 2^64 — share indices
  *                     (PubPoly::eval, poly.rs:461-464), the cofactor (Point::pick, point.rs:148): public multipliers; a uniformly random
  *                     secret is that small with probability 2^-188 — starts its ladder below the leading zero bits: 29 us instead of 158 for a

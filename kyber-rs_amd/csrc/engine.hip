@@ -110,7 +110,7 @@ struct Ctx {
   std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: chunks that alternate between the two lanes
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
-  std::atomic<int> opt_ladder_skip_canonical{1};  // the batch ladder skips the three leading bits when no scalar of the launch has one set (canonical scalars)
+  std::atomic<int> opt_ladder_skip_canonical{1};  // the batch ladder skips the four leading bits when no scalar of the launch has one set (canonical scalars)
   std::atomic<int> opt_mul_short_scalars{1};     // host-pointer kyb_mul_batch of <= 64 items whose scalars are ALL below 2^64: the ladder skips the leading zeros
   std::atomic<int> opt_poly_batch_segments{0};   // PubPoly::eval, long polynomials at 10^3..10^4 evaluations: lanes per evaluation of the batch kernels (0 = cost model, 1 = never, 2..256)
   std::atomic<int> opt_poly_segments{0};         // PubPoly::eval, small batches: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never split, 2..32)
@@ -747,8 +747,8 @@ int launch_ladder_core(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int
   } else if (ok != nullptr) {
     HIPCK(hipMemsetAsync(ok, 1, np, st));          // extended operands are taken as they are (k_mul does the same)
   }
-  // Are all scalars canonical (below 2^253)?  k_mont_prep ORs their top three bits into one of two alternating words on the way (one scalar
-  // per point only), the ladder starts three bits lower when the word stayed 0 and clears the other word for the next call on this stream.
+  // Are all scalars canonical (below 2^252)?  k_mont_prep ORs their top four bits into one of two alternating words on the way (one scalar
+  // per point only), the ladder starts four bits lower when the word stayed 0 and clears the other word for the next call on this stream.
   uint32_t* top_or = nullptr;
   uint32_t* zero_next = nullptr;
   if (skip_bits == 0 && npts == 0 && g.opt_ladder_skip_canonical != 0) {
@@ -886,8 +886,8 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
     }
     ProfScope ps(g, st, KID_MUL_COOP);
     const bool short_scalars = skip_hint >= 192 && g.opt_mul_short_scalars != 0;
-    // (canonical scalars, all below 2^253: the top wavefront's piece starts three bits lower, as the batch ladder does)
-    const int canon_skip = (skip_hint >= 3 && g.opt_ladder_skip_canonical != 0) ? 3 : 0;
+    // (canonical scalars, all below 2^252: the top wavefront's piece starts four bits lower, as the batch ladder does)
+    const int canon_skip = (skip_hint >= 4 && g.opt_ladder_skip_canonical != 0) ? 4 : 0;
     LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, short_scalars ? (skip_hint > 255 ? 255 : skip_hint) : canon_skip, nullptr, 0, 0, take_done_flag(g, st, n), 0,
                               (!short_scalars && 2 * n <= (size_t)g.opt_coop_verify_max) ? 4 : 1,   // very few items (measured: up to 256): four wavefronts share an item's scalar
                               g.opt_ext_projective != 0));

@@ -58,14 +58,14 @@ k_mont_prep(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ p
   const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (j >= M) return;
   if (top_or != nullptr) {
-    // On the way: the OR of the top three bits of this lane's scalars.  The word stays 0 iff every scalar of the launch is below 2^253, as
-    // every value reduced mod L is (L < 2^253); the ladder kernel then skips those three steps (1.2 % of its time).  The test says
-    // nothing about a canonical scalar; for the unreduced inputs the reference also accepts (clamped keys, quirk vectors) the word
-    // becomes non-zero and all 256 bits are walked.
+    // On the way: the OR of the top four bits of this lane's scalars.  The word stays 0 iff every scalar of the launch is below 2^252, as
+    // a value reduced mod L is (L = 2^252 + 2.8 x 10^37: all but 2^-127 of them); the ladder kernel then skips those four steps (1.6 % of
+    // its time).  The test says nothing about a canonical scalar; for the unreduced inputs the reference also accepts (clamped keys,
+    // quirk vectors) the word becomes non-zero and all 256 bits are walked.
     uint32_t top = 0;
     KYB_UNROLL for (int t = 0; t < FINISH_K; ++t) {
       const size_t i = j + (size_t)t * M;
-      if (i < n) top |= reinterpret_cast<const uint32_t*>(scalars)[8 * i + 7] >> 29;
+      if (i < n) top |= reinterpret_cast<const uint32_t*>(scalars)[8 * i + 7] >> 28;
     }
     if (top != 0u) atomicOr(top_or, top);
   }
@@ -104,9 +104,9 @@ template <int WAVES>
 __global__ void __launch_bounds__(KYB_BLOCK, WAVES)
 k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits_arg,
              const uint32_t* __restrict__ top_or, uint32_t* __restrict__ zero_next) {
-  // top_or (written by k_mont_prep of this call): 0 iff every scalar of the launch is below 2^253 — the ladder then starts below the three
+  // top_or (written by k_mont_prep of this call): 0 iff every scalar of the launch is below 2^252 — the ladder then starts below the four
   // leading zeros.  zero_next: the word the NEXT call on this stream will collect into (the two alternate), cleared here.
-  const int skip_bits = top_or != nullptr ? ((*top_or == 0u) ? 3 : 0) : skip_bits_arg;
+  const int skip_bits = top_or != nullptr ? ((*top_or == 0u) ? 4 : 0) : skip_bits_arg;
   if (zero_next != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *zero_next = 0u;
   const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (i >= n) return;

@@ -962,7 +962,7 @@ def test_verify_equation_on_raw_kernels_all_golden_lines(engine):
 
 
 def test_ladder_skips_the_leading_zeros_only_when_every_scalar_is_canonical(engine, oracle):
-    """The batch ladder starts three bits lower when no scalar of the launch reaches 2^253 (k_mont_prep ORs their top bits on the way, two
+    """The batch ladder starts four bits lower when no scalar of the launch reaches 2^252 (k_mont_prep ORs their top bits on the way, two
     alternating words per stream): one unreduced scalar anywhere in the batch must switch the whole launch back to 256 steps, and the
     launches before and after it must not see its flag."""
     n = 8192
@@ -970,9 +970,9 @@ def test_ladder_skips_the_leading_zeros_only_when_every_scalar_is_canonical(engi
     pts = oracle.mul_base_ext_batch(synth.scalars(n, 62, b"p"))
     want = oracle.mul_batch(s, pts, nthreads=8)
     assert np.array_equal(engine.mul(s, pts_ext=pts), want)
-    for pos, top in ((n - 3, 0x20), (5, 0x80), (4097, 0xff)):
+    for pos, top in ((n - 3, 0x10), (17, 0x20), (5, 0x80), (4097, 0xff)):
         t = s.copy()
-        t[pos, 31] |= top                                   # bit 253, bit 255, everything
+        t[pos, 31] |= top                                   # bit 252, bit 253, bit 255, everything
         w = want.copy()
         w[pos] = np.frombuffer(oracle.mul(bytes(t[pos]), pts[pos]), dtype=np.uint8)
         assert np.array_equal(engine.mul(t, pts_ext=pts), w), (pos, top)
