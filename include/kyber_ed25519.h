@@ -285,6 +285,7 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *   mul.algo          1 Montgomery ladder + y-recovery (table-free, default), 0 windowed table 1P..8P per lane
  *   mul.ladder_waves  2..4 (default 3): waves per SIMD the ladder kernel's register allocation must allow
  *   mul.select        0 v_cndmask merge, 1 and/or merge of the windowed kernel's table scan
+ *   mul.grid_per_cu   1 | 2 workgroups per CU of the windowed kernel (its table workspace is sized for 2)                [mul.algo=0 only]
  *   mul_base.radix    64 (default): 43-window kernel, the table fills a CU's LDS; 32: 52 windows; 16: 64 windows
  *   mul_base.select   0 LDS broadcast scan, 1 ds_bpermute selection                       [radix-16 kernel]
  *   mul_base.block    256 | 512 threads per workgroup                                     [radix-16 kernel]

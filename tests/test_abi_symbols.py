@@ -63,3 +63,17 @@ def test_header_is_plain_c(tmp_path):
     txt = open(os.path.join(ROOT, "include", "kyber_ed25519.h")).read()
     code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     assert not re.search(r"hipStream_t|hipError_t|torch|at::|std::|#include\s*<hip", code)
+
+
+def test_every_engine_option_is_documented_in_the_header():
+    """kyb_set_option keys (c_abi.inc) and the option list of include/kyber_ed25519.h name the same options (the round-1 review
+    found the two drifting apart)"""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "kyber_ed25519.h")).read()
+    src = open(os.path.join(ROOT, "kyber-rs_amd", "csrc", "c_abi.inc")).read()
+    keys = set(re.findall(r'strcmp\(key, "([a-z_0-9.]+)"\)', src))
+    assert len(keys) > 20
+    listed = set(re.findall(r"^ \*\s+([a-z_]+\.[a-z_0-9]+)\b", hdr, re.M))
+    mentioned = set(re.findall(r"\b([a-z_]+\.[a-z_0-9]+)\b", hdr))
+    assert not (keys - mentioned), f"options without a word in the header: {sorted(keys - mentioned)}"
+    assert not {k for k in listed if k not in keys and not k.endswith(".h") and not k.endswith(".rs")}, "the header lists an option the engine does not know"
