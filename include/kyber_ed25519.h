@@ -24,8 +24,17 @@
  *              slot (up to 32 streams registered at a time; kyb_stream_release frees one, beyond 32 the least recently
  *              used slot is recycled after its last launch); their launch bookkeeping is serialised per context.
  *              kyb_set_option / kyb_profile_* are safe against concurrent launches.
- *              Concurrent small calls of several contexts need hardware queues: kyb_init / kyb_ctx_create set GPU_MAX_HW_QUEUES=16
- *              (the ROCm default is 4) when the variable is unset and the HIP runtime has not been started by the host program.
+ *              Concurrent small calls of several contexts need hardware queues: the ROCm runtime maps all streams of a process onto
+ *              GPU_MAX_HW_QUEUES queues (default 4).  The variable is read when the HIP runtime starts and belongs to the host
+ *              program: this library never touches the environment; a host that issues one-item calls from many threads sets
+ *              GPU_MAX_HW_QUEUES=16 before its first HIP call (16 threads: 16k -> 72k variable-base calls/s).
+ *   timing     The instruction stream, the LDS / memory addresses and the launch geometry of every kernel are independent of scalar
+ *              VALUES, with two documented exceptions, both launch SHAPES chosen from a public property of a whole batch:
+ *                ladder.skip_canonical (default 1): a launch whose scalars are ALL below 2^252 walks 252 bits instead of 256 — "is
+ *                  reduced mod L", which holds for every scalar kyber-rs's Scalar type produces; set the option to 0 for 256 always;
+ *                kyb_mul_public_batch / mul.short_scalars (default 0): multipliers DECLARED public by the caller skip their common
+ *                  leading zero bits when all are below 2^64.  kyb_mul_batch itself never does.
+ *              tools/ct_check.py checks the claim on the compiled kernels (no branch on, and no address from, scalar words).
  *   memory     the caller owns every buffer; the library keeps no pointer after return.
  *
  * Two flavours of every batch call:
@@ -122,6 +131,14 @@ int kyb_group_schnorr_sign_batch(kyb_group* g, const uint8_t* x, const uint8_t* 
                                  size_t n, uint8_t* sig);
 int kyb_group_verify_batch(kyb_group* g, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* msg_off, const uint8_t* sigs,
                            size_t n, int flavor, uint8_t* status);
+/* Device-resident shards: argument r of every array is rank r's pointer / item count, the memory on rank r's GPU (16-byte aligned,
+ * as for the kyb_*_dev calls).  The launches are asynchronous on each context's own stream — one calling thread queues the work of
+ * all GPUs — and kyb_group_sync waits for everything queued on every rank.  Arrays that are NULL as a whole are absent for all
+ * ranks (out_ext, ok; exactly one of pts_enc / pts_ext). */
+int kyb_group_mul_base_batch_dev(kyb_group* g, const uint8_t* const* scalars, const size_t* n, uint8_t* const* out_enc, int32_t* const* out_ext);
+int kyb_group_mul_batch_dev(kyb_group* g, const uint8_t* const* scalars, const uint8_t* const* pts_enc, const int32_t* const* pts_ext,
+                            const size_t* n, uint8_t* const* out_enc, int32_t* const* out_ext, uint8_t* const* ok);
+int kyb_group_sync(kyb_group* g);
 
 /* ---- pinned host memory for the host-pointer API ------------------------------------------------ */
 /* The host-pointer calls accept any host memory.  From pageable memory the copies run at ~7 GB/s and
@@ -157,6 +174,12 @@ int kyb_mul_batch(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t*
                   uint8_t* out_enc, int32_t* out_ext, uint8_t* ok);
 int kyb_mul_batch_dev(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, size_t n,
                       uint8_t* out_enc, int32_t* out_ext, uint8_t* ok, void* stream);
+/* The same multiplication for multipliers the caller DECLARES public — share indices x = i + 1 of PubPoly::eval (poly.rs:461-464),
+ * the cofactor of Point::pick (point.rs:148), Lagrange coefficients of public indices.  A call of at most 64 items (pts_ext) whose
+ * scalars are ALL below 2^64 starts its ladder below their common leading zero bits: 29 us instead of 158 for a 10-bit index.  The
+ * run time therefore depends on the scalars' bit length: never pass a secret here.  Same results as kyb_mul_batch. */
+int kyb_mul_public_batch(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, size_t n,
+                         uint8_t* out_enc, int32_t* out_ext, uint8_t* ok);
 
 /* ---- Point::add / Point::sub, point.rs:179-197 (out = a +/- b, extended limbs, Z arbitrary) ---- */
 int kyb_add_batch(const int32_t* a_ext, const int32_t* b_ext, size_t n, int32_t* out_ext, int subtract);
@@ -303,10 +326,10 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *                     reduced mod L (L = 2^252 + 2.8e37) except for 2^-127 of them, so the test (an OR over the batch, taken on the way by the
  *                     kernel that prepares the points) says nothing about a canonical secret; one unreduced scalar anywhere and the launch
  *                     walks all 256 bits.  0: always 256.
- *   mul.short_scalars  1 (default): a host-pointer kyb_mul_batch of at most 64 items (pts_ext) whose scalars are ALL below 2^64 — share indices
- *                     (PubPoly::eval, poly.rs:461-464), the cofactor (Point::pick, point.rs:148): public multipliers; a uniformly random
- *                     secret is that small with probability 2^-188 — starts its ladder below the leading zero bits: 29 us instead of 158 for a
- *                     10-bit index (57 instead of 186 with the encoding).  0: always the full 255 steps.  Same results either way.
+ *   mul.short_scalars  0 (default): kyb_mul_batch never looks at the size of its scalars.  1: every host-pointer kyb_mul_batch of this context
+ *                     behaves like kyb_mul_public_batch (above) — for hosts whose unmodified protocol code cannot say which multipliers are
+ *                     public (PubPoly::eval calls Point::mul with x = i + 1): a deployment decision, since a secret below 2^64 (probability
+ *                     2^-188 for a uniformly random one) would then be visible in the call's run time.  Same results either way.
  *   poly.batch_segments  kyb_pubpoly_eval*_batch, long polynomials at 10^3..6x10^4 evaluations: the Horner chain of an evaluation is cut into
  *                     this many segments, one per lane, recombined with x^(s len) mod 8L by the variable-base ladder (0 = chosen by a cost
  *                     model from t, the batch size and the bit length of the largest index; 1 = never; 2..256).  Same results either way.
@@ -331,6 +354,19 @@ int kyb_get_option(const char* key, int* value);
 int kyb_profile_begin(int max_launches);
 int kyb_profile_read(int* kernel_ids, float* ms, int cap, int* count);
 const char* kyb_kernel_name(int kernel_id);
+/* Benchmark diagnostics (bench.py: the roofline is quoted against a peak and a clock measured in the same run; no product call
+ * depends on them).
+ *   kyb_diag_mad_peak: every SIMD of the context's GPU issues nothing but v_mad_u64_u32 (8 wavefronts per SIMD, eight independent
+ *     accumulator chains each) for at least min_ms milliseconds.  *mads_per_s = 32x32+64 multiply-adds per second of the whole chip,
+ *     *clock_ghz = the shader clock the chip held under that load (s_memtime / s_memrealtime), *simd_cycles_per_mad = SIMD cycles per
+ *     wavefront-wide multiply-add (4.0 = one quarter-rate issue every 4 cycles), *kernel_ms = duration of the measured launch.  Any
+ *     pointer may be NULL.  Synchronous.
+ *   kyb_diag_wave_stamps(dev_buf): dev_buf = 5 x uint64 of device memory, zeroed by the caller; while set, every wavefront of
+ *     k_mul_ladder / k_mul_base64 launched on the context's DEVICE adds (shader cycles, 100 MHz ticks) at its start into words 0, 1
+ *     and at its end into words 2, 3, and counts itself in word 4: (w2 - w0) / (w3 - w1) x 100 MHz is the in-kernel clock.  NULL
+ *     switches it off (the default: the kernels then execute one extra scalar load and branch at each end).  Waits for the device. */
+int kyb_diag_mad_peak(double min_ms, double* mads_per_s, double* clock_ghz, double* simd_cycles_per_mad, double* kernel_ms);
+int kyb_diag_wave_stamps(void* dev_buf);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,8 @@ ABI_SYMBOLS = [
     "kyb_group_create", "kyb_group_destroy", "kyb_group_size", "kyb_group_ctx", "kyb_group_table_transport",
     "kyb_group_mul_base_batch", "kyb_group_mul_batch", "kyb_group_schnorr_sign_batch", "kyb_group_verify_batch",
     "kyb_base_table_export_dev", "kyb_base_table_import_dev", "kyb_base_table_export", "kyb_base_table_import",
-    "kyb_mul_base_batch", "kyb_mul_base_batch_dev", "kyb_mul_batch", "kyb_mul_batch_dev",
+    "kyb_group_mul_base_batch_dev", "kyb_group_mul_batch_dev", "kyb_group_sync",
+    "kyb_mul_base_batch", "kyb_mul_base_batch_dev", "kyb_mul_batch", "kyb_mul_batch_dev", "kyb_mul_public_batch",
     "kyb_add_batch", "kyb_add_batch_dev", "kyb_encode_batch", "kyb_encode_batch_dev",
     "kyb_decode_batch", "kyb_decode_batch_dev", "kyb_schnorr_sign_batch", "kyb_schnorr_sign_batch_dev",
     "kyb_eddsa_sign_batch", "kyb_eddsa_sign_batch_dev",
@@ -45,6 +46,7 @@ ABI_SYMBOLS = [
     "kyb_pubpoly_eval_multi_enc_batch", "kyb_pubpoly_eval_multi_enc_batch_dev", "kyb_sum_enc_batch", "kyb_sum_enc_batch_dev",
     "kyb_host_alloc", "kyb_host_free",
     "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
+    "kyb_diag_mad_peak", "kyb_diag_wave_stamps",
 ]
 
 
@@ -105,6 +107,13 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_mul_base_batch_dev.argtypes = [vp, sz, vp, vp, vp]
     lib.kyb_mul_batch.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     lib.kyb_mul_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp]
+    lib.kyb_mul_public_batch.argtypes = [vp, vp, vp, sz, vp, vp, vp]
+    lib.kyb_group_mul_base_batch_dev.argtypes = [vp, vp, vp, vp, vp]
+    lib.kyb_group_mul_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.kyb_group_sync.argtypes = [vp]
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.kyb_diag_mad_peak.argtypes = [ctypes.c_double, dp, dp, dp, dp]
+    lib.kyb_diag_wave_stamps.argtypes = [vp]
     lib.kyb_add_batch.argtypes = [vp, vp, sz, vp, i32]
     lib.kyb_add_batch_dev.argtypes = [vp, vp, sz, vp, i32, vp]
     lib.kyb_encode_batch.argtypes = [vp, sz, vp]
@@ -278,6 +287,16 @@ class Engine:
     def mul_base_into(self, scalars, out_enc) -> None:
         _check(self.lib.kyb_mul_base_batch(_ptr(scalars), scalars.shape[0], _ptr(out_enc), None), "kyb_mul_base_batch")
 
+    def mad_peak(self, min_ms: float = 50.0):
+        """kyb_diag_mad_peak: the chip's v_mad_u64_u32 rate, clock and issue cycles, measured now (a benchmark diagnostic)"""
+        r, c, y, k = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        _check(self.lib.kyb_diag_mad_peak(float(min_ms), ctypes.byref(r), ctypes.byref(c), ctypes.byref(y), ctypes.byref(k)), "kyb_diag_mad_peak")
+        return {"mads_per_s": r.value, "clock_ghz": c.value, "simd_cycles_per_mad": y.value, "kernel_ms": k.value}
+
+    def wave_stamps(self, buf) -> None:
+        """kyb_diag_wave_stamps: buf = zeroed torch int64 tensor of 5 words on this engine's device, or None = off"""
+        _check(self.lib.kyb_diag_wave_stamps(None if buf is None else ctypes.c_void_p(buf.data_ptr())), "kyb_diag_wave_stamps")
+
     def profile_begin(self, max_launches: int) -> None:
         _check(self.lib.kyb_profile_begin(max_launches), "kyb_profile_begin")
 
@@ -307,13 +326,15 @@ class Engine:
             return ext
         return (enc, ext) if want_ext else enc
 
-    def mul(self, scalars, pts_ext=None, pts_enc=None, want_ext: bool = False, want_ok: bool = False, ext_only: bool = False):
+    def mul(self, scalars, pts_ext=None, pts_enc=None, want_ext: bool = False, want_ok: bool = False, ext_only: bool = False, public: bool = False):
+        """public: the multipliers are declared public (kyb_mul_public_batch: short ones take a short ladder)"""
+        fn = self.lib.kyb_mul_public_batch if public else self.lib.kyb_mul_batch
         if ext_only:
             s = _u8(scalars, 32, "scalars")
             px = np.ascontiguousarray(pts_ext, dtype=np.int32).reshape(-1, 40)
             _rows(px, s.shape[0], "pts_ext")
             ext = np.empty((s.shape[0], 40), dtype=np.int32)
-            _check(self.lib.kyb_mul_batch(_ptr(s), None, _ptr(px), s.shape[0], None, _ptr(ext), None), "kyb_mul_batch")
+            _check(fn(_ptr(s), None, _ptr(px), s.shape[0], None, _ptr(ext), None), "kyb_mul_batch")
             return ext
         s = _u8(scalars, 32, "scalars")
         n = s.shape[0]
@@ -323,7 +344,7 @@ class Engine:
         enc = np.empty((n, 32), dtype=np.uint8)
         ext = np.empty((n, 40), dtype=np.int32) if want_ext else None
         ok = np.empty((n,), dtype=np.uint8) if (want_ok or pe is not None) else None
-        _check(self.lib.kyb_mul_batch(_ptr(s), _ptr(pe), _ptr(px), n, _ptr(enc), _ptr(ext), _ptr(ok)), "kyb_mul_batch")
+        _check(fn(_ptr(s), _ptr(pe), _ptr(px), n, _ptr(enc), _ptr(ext), _ptr(ok)), "kyb_mul_batch")
         out = [enc]
         if want_ext:
             out.append(ext)
@@ -583,6 +604,27 @@ class Group:
         if self.handle is not None:
             self.lib.kyb_group_destroy(self.handle)
             self.handle = None
+
+    @staticmethod
+    def _ptr_array(tensors):
+        """per-rank device pointers (torch tensors, one per rank, each on its rank's GPU) -> void*[size], or None"""
+        if tensors is None:
+            return None
+        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def mul_dev(self, scalars, pts_ext=None, pts_enc=None, out_enc=None, out_ext=None, ok=None) -> None:
+        """kyb_group_mul_batch_dev: device-resident shards, asynchronous on every rank's own stream (sync() waits)"""
+        n = (ctypes.c_size_t * self.size)(*[t.numel() // 32 for t in scalars])
+        _check(self.lib.kyb_group_mul_batch_dev(self.handle, self._ptr_array(scalars), self._ptr_array(pts_enc), self._ptr_array(pts_ext), n,
+                                                self._ptr_array(out_enc), self._ptr_array(out_ext), self._ptr_array(ok)), "kyb_group_mul_batch_dev")
+
+    def mul_base_dev(self, scalars, out_enc=None, out_ext=None) -> None:
+        n = (ctypes.c_size_t * self.size)(*[t.numel() // 32 for t in scalars])
+        _check(self.lib.kyb_group_mul_base_batch_dev(self.handle, self._ptr_array(scalars), n, self._ptr_array(out_enc), self._ptr_array(out_ext)),
+               "kyb_group_mul_base_batch_dev")
+
+    def sync(self) -> None:
+        _check(self.lib.kyb_group_sync(self.handle), "kyb_group_sync")
 
     def mul_base(self, scalars):
         s = _u8(scalars, 32, "scalars")

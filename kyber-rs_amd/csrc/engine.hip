@@ -20,6 +20,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -111,7 +112,8 @@ struct Ctx {
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: chunks that alternate between the two lanes
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
   std::atomic<int> opt_ladder_skip_canonical{1};  // the batch ladder skips the four leading bits when no scalar of the launch has one set (canonical scalars)
-  std::atomic<int> opt_mul_short_scalars{1};     // host-pointer kyb_mul_batch of <= 64 items whose scalars are ALL below 2^64: the ladder skips the leading zeros
+  std::atomic<int> opt_mul_short_scalars{0};     // 1: EVERY host-pointer kyb_mul_batch of <= 64 items is treated like kyb_mul_public_batch (multipliers declared public:
+                                                 // when all are below 2^64 the ladder skips the leading zeros).  Off by default: the ABI cannot know that a multiplier is public.
   std::atomic<int> opt_poly_batch_segments{0};   // PubPoly::eval, long polynomials at 10^3..10^4 evaluations: lanes per evaluation of the batch kernels (0 = cost model, 1 = never, 2..256)
   std::atomic<int> opt_poly_segments{0};         // PubPoly::eval, small batches: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never split, 2..32)
   std::atomic<int> opt_verify_by_enc{1};         // large verification batches: compare the encoding of s*B - h*A with R's bytes, decode R only on a mismatch
@@ -275,7 +277,10 @@ struct DoneScope {          // posts / withdraws the request around the launch s
 // staging copy inside the runtime (~7 GB/s); they go through the context's own page-locked bounce buffers
 // instead, filled and drained by CopyPool threads while the GPU works on the neighbouring chunk.
 // One host-pointer call at a time per CONTEXT (g.mu); callers that want several in flight use several contexts.
-struct HostArr { const void* in; void* out; size_t bytes; };    // per-item size; exactly one of in/out, or neither = absent
+struct HostArr { const void* in; void* out; size_t bytes; bool secret = false; };    // per-item size; exactly one of in/out, or neither = absent;
+                                                                                     // secret: private keys / nonces / DH secrets — every copy the engine made is cleared before the call returns
+template <class F> struct ScopeExit { F f; ~ScopeExit() { f(); } };
+template <class F> ScopeExit<F> on_scope_exit(F f) { return ScopeExit<F>{f}; }
 constexpr size_t PIPE_MIN_ITEMS = (size_t)1 << 16;
 constexpr size_t ZERO_COPY_BYTES = (size_t)1 << 19;      // host-pointer calls up to this size skip the copies: kernels work on page-locked host memory
 
@@ -295,6 +300,9 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
       dptr[k] = (arrs[k].in || arrs[k].out) ? g.pin[0] + off[k] : nullptr;
       if (arrs[k].in) memcpy(dptr[k], arrs[k].in, arrs[k].bytes * n);
     }
+    // whatever way the call ends, the secret operands do not stay behind in the page-locked buffer (the kernels have finished by then:
+    // every return below is behind a completed wait or a stream synchronisation)
+    auto wipe = on_scope_exit([&] { for (int k = 0; k < na; ++k) if (arrs[k].secret && arrs[k].in) memset(g.pin[0] + off[k], 0, arrs[k].bytes * n); });
     rc = ensure_done_flag(g);
     if (rc) return rc;
     {
@@ -303,7 +311,7 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
       tl_done = nullptr;
       if (rc) { (void)hipStreamSynchronize(g.stream); return rc; }
       rc = wait_done(g, ds.req);
-      if (rc) return rc;
+      if (rc) { (void)hipStreamSynchronize(g.stream); return rc; }
     }
     for (int k = 0; k < na; ++k)
       if (arrs[k].out) memcpy(arrs[k].out, g.pin[0] + off[k], arrs[k].bytes * n);
@@ -314,6 +322,22 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
   if (nchunks > 1) { rc = ensure_stage2(g, total); if (rc) return rc; }
   hipStream_t streams[2] = {g.stream, g.stream2};
   uint8_t* stages[2] = {g.stage, g.stage2};
+  bool bounce = false;
+  // secret operands: their device staging slots (and bounce-buffer slots) are cleared on every way out of the call
+  auto wipe = on_scope_exit([&] {
+    bool any = false;
+    for (int k = 0; k < na; ++k) any = any || (arrs[k].secret && arrs[k].in);
+    if (!any) return;
+    const int lanes = nchunks > 1 ? 2 : 1;
+    for (int l = 0; l < lanes; ++l) (void)hipStreamSynchronize(streams[l]);        // an error return may have left work in flight
+    for (int l = 0; l < lanes; ++l)
+      for (int k = 0; k < na; ++k)
+        if (arrs[k].secret && arrs[k].in) {
+          (void)hipMemsetAsync(stages[l] + off[k], 0, arrs[k].bytes * cap, streams[l]);
+          if (bounce && g.pin[l]) memset(g.pin[l] + off[k], 0, arrs[k].bytes * cap);
+        }
+    for (int l = 0; l < lanes; ++l) (void)hipStreamSynchronize(streams[l]);
+  });
   bool pinned = true;
   for (int k = 0; k < na; ++k) {
     if (arrs[k].in) pinned = pinned && is_pinned(arrs[k].in);
@@ -322,6 +346,7 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
   if (nchunks > 1 && !pinned) {
     rc = ensure_pin(g, 0, total); if (rc) return rc;
     rc = ensure_pin(g, 1, total); if (rc) return rc;
+    bounce = true;
     const int threads = copy_threads(g);
     kyb::CopyPool::Job jobs[8];
     auto chunk_items = [&](int c) { const size_t lo = (size_t)c * cap; return lo >= n ? (size_t)0 : ((lo + cap <= n) ? cap : n - lo); };
@@ -401,13 +426,14 @@ constexpr int KYB_CK_LO = KYB_BT_IDX(0, 0, 30), KYB_CK_HI = KYB_BT_IDX(0, 0, 31)
 // cut into chunks instead that CopyPool threads move into the context's two page-locked bounce buffers while the DMA engine
 // drains the other one (the pipeline of run_host_batch, without kernels in between).
 constexpr size_t H2D_PIPE_MIN = (size_t)8 << 20, H2D_PIPE_CHUNK = (size_t)8 << 20;
-int h2d(Ctx& g, uint8_t* dst, const uint8_t* src, size_t bytes, bool secret) {
+int h2d(Ctx& g, uint8_t* dst, const uint8_t* src, size_t bytes, bool* bounced) {
   if (bytes < H2D_PIPE_MIN || is_pinned(src)) {
     HIPCK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g.stream));
     return KYB_OK;
   }
   int rc = ensure_pin(g, 0, H2D_PIPE_CHUNK); if (rc) return rc;
   rc = ensure_pin(g, 1, H2D_PIPE_CHUNK); if (rc) return rc;
+  *bounced = true;                 // (a secret call's HostCall clears the bounce buffers on its way out)
   for (int l = 0; l < 2; ++l)
     if (!g.ev_pin[l]) HIPCK(hipEventCreateWithFlags(&g.ev_pin[l], hipEventDisableTiming));
   const int threads = copy_threads(g);
@@ -422,10 +448,7 @@ int h2d(Ctx& g, uint8_t* dst, const uint8_t* src, size_t bytes, bool secret) {
     HIPCK(hipEventRecord(g.ev_pin[lane], g.stream));
   }
   // the bounce buffers are reused by whatever comes next under g.mu: the copies out of them must have been issued AND finished
-  for (int l = 0; l < 2 && l < c; ++l) {
-    HIPCK(hipEventSynchronize(g.ev_pin[l]));
-    if (secret) memset(g.pin[l], 0, H2D_PIPE_CHUNK);                   // private keys / nonces do not stay in the bounce buffers
-  }
+  for (int l = 0; l < 2 && l < c; ++l) HIPCK(hipEventSynchronize(g.ev_pin[l]));
   return KYB_OK;
 }
 
@@ -448,6 +471,8 @@ class HostCall {
       int rc = ensure_pin(g, 0, ZERO_COPY_BYTES);
       if (rc) return rc;
       base_ = g.pin[0];
+      // secret(): cleared on EVERY way out (each return below is behind a completed wait or a stream synchronisation)
+      auto wipe = on_scope_exit([&] { if (secret_ && total_) memset(base_, 0, total_); });
       for (int i = 0; i < n_; ++i)
         if (a_[i].src && a_[i].bytes) memcpy(base_ + a_[i].off, a_[i].src, a_[i].bytes);
       rc = ensure_done_flag(g);
@@ -456,25 +481,31 @@ class HostCall {
         DoneScope ds;
         rc = body(g.stream);
         tl_done = nullptr;
-        if (rc) { (void)hipStreamSynchronize(g.stream); if (secret_ && total_) memset(base_, 0, total_); return rc; }
+        if (rc) { (void)hipStreamSynchronize(g.stream); return rc; }
         rc = wait_done(g, ds.req);
-        if (rc) return rc;
+        if (rc) { (void)hipStreamSynchronize(g.stream); return rc; }
       }
       for (int i = 0; i < n_; ++i)
         if (a_[i].dst && a_[i].bytes) memcpy(a_[i].dst, base_ + a_[i].off, a_[i].bytes);
-      if (secret_ && total_) memset(base_, 0, total_);
       return KYB_OK;
     }
     int rc = ensure_stage(g, total_);
     if (rc) return rc;
     base_ = g.stage;
+    bool bounced = false;
+    auto wipe = on_scope_exit([&] {
+      if (!secret_ || !total_) return;
+      (void)hipStreamSynchronize(g.stream);                  // an error return may have left copies or kernels in flight
+      (void)hipMemsetAsync(g.stage, 0, total_, g.stream);
+      if (bounced) for (int l = 0; l < 2; ++l) if (g.pin[l]) memset(g.pin[l], 0, g.pin_bytes[l] < H2D_PIPE_CHUNK ? g.pin_bytes[l] : H2D_PIPE_CHUNK);
+      (void)hipStreamSynchronize(g.stream);
+    });
     for (int i = 0; i < n_; ++i)
-      if (a_[i].src && a_[i].bytes) { rc = h2d(g, g.stage + a_[i].off, static_cast<const uint8_t*>(a_[i].src), a_[i].bytes, secret_); if (rc) return rc; }
+      if (a_[i].src && a_[i].bytes) { rc = h2d(g, g.stage + a_[i].off, static_cast<const uint8_t*>(a_[i].src), a_[i].bytes, &bounced); if (rc) return rc; }
     rc = body(g.stream);
     if (rc) return rc;
     for (int i = 0; i < n_; ++i)
       if (a_[i].dst && a_[i].bytes) HIPCK(hipMemcpyAsync(a_[i].dst, g.stage + a_[i].off, a_[i].bytes, hipMemcpyDeviceToHost, g.stream));
-    if (secret_ && total_) HIPCK(hipMemsetAsync(g.stage, 0, total_, g.stream));
     HIPCK(hipStreamSynchronize(g.stream));
     return KYB_OK;
   }
@@ -639,17 +670,10 @@ void ctx_release(Ctx* c) {
   delete c;
 }
 
-// The ROCm runtime maps all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4): with the default, at most four
-// of the small kernels that concurrent one-item calls of several contexts launch run at a time (tools/microbench/concurrent_calls.cpp:
-// 16 threads reach 16k variable-base calls/s with 4 queues, 72k with 16).  The variable is read when the runtime starts, so this only
-// has an effect when this library makes the process's first HIP call; a value the user has set is left alone.
-void default_hw_queues() {
-  static std::once_flag once;
-  std::call_once(once, [] { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); });
-}
-
+// (The ROCm runtime maps all streams of a process onto GPU_MAX_HW_QUEUES hardware queues, 4 by default: concurrent one-item calls of
+// many contexts want 16 — tools/microbench/concurrent_calls.cpp: 16k -> 72k variable-base calls/s with 16 threads.  The variable is read
+// when the HIP runtime starts and belongs to the host program: this library never touches the environment; INTEGRATION.md says where to set it.)
 int ctx_new(int device, bool build_table, Ctx** out) {
-  default_hw_queues();
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) return fail(KYB_E_NO_DEVICE, "no HIP device visible (this engine has no CPU path)", e);
@@ -858,11 +882,12 @@ int launch_sum(Ctx& g, const int32_t* pext, const uint8_t* penc, uint8_t* ok, bo
   return launch_finish(g, r, m, oenc, oext, st, t, true);
 }
 
-// skip_hint: leading zero bits EVERY scalar of the call has (host-pointer calls of a few items look; 0 = unknown).  When all of them are below
-// 2^64 — share indices, the cofactor: public multipliers; a uniformly random secret is that small with probability 2^-188 — the ladder of the
-// one-item-per-wavefront kernel starts below the zeros: Point::mul(x_i, Some(v)) of an unmodified PubPoly::eval takes 10 steps, not 255.
+// skip_hint: leading zero bits EVERY scalar of the call has (host-pointer calls of a few items look; 0 = unknown).  multipliers_public
+// (kyb_mul_public_batch, or the option mul.short_scalars for callers that cannot say): when all of them are below 2^64 — share indices, the
+// cofactor — the ladder of the one-item-per-wavefront kernel starts below the zeros: Point::mul(x_i, Some(v)) of PubPoly::eval takes 10 steps,
+// not 255.  Without that declaration the step count never depends on the scalars' values beyond the canonical-range test (ladder.skip_canonical).
 int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, hipStream_t st,
-               int skip_hint = 0) {
+               int skip_hint = 0, bool multipliers_public = false) {
   if (n == 0) return KYB_OK;
   std::lock_guard<std::mutex> launch_lock(g.launch_mu);
   StreamRes* r = nullptr;
@@ -885,7 +910,7 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
       HIPCK(hipMemsetAsync(ok, 1, n, st));
     }
     ProfScope ps(g, st, KID_MUL_COOP);
-    const bool short_scalars = skip_hint >= 192 && g.opt_mul_short_scalars != 0;
+    const bool short_scalars = skip_hint >= 192 && (multipliers_public || g.opt_mul_short_scalars != 0);
     // (canonical scalars, all below 2^252: the top wavefront's piece starts four bits lower, as the batch ladder does)
     const int canon_skip = (skip_hint >= 4 && g.opt_ladder_skip_canonical != 0) ? 4 : 0;
     LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, short_scalars ? (skip_hint > 255 ? 255 : skip_hint) : canon_skip, nullptr, 0, 0, take_done_flag(g, st, n), 0,

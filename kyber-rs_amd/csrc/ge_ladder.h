@@ -346,30 +346,5 @@ KYB_HD void ge_scalarmult_ladder_proj(ge_p2& out, const uint32_t a[8], const ge_
   mont_recover_to_edwards_proj(out, m, x2, z2, x3, z3, mag[0] & 1u, neg);
 }
 
-#if defined(__HIPCC__) && defined(KYB_DIAG_STAMPS)
-// Diagnostic build only (tools/ladder_clock.py, -DKYB_DIAG_STAMPS; the product library contains no stamp):
-// the same multiplication with s_memtime (shader cycles) and s_memrealtime (100 MHz) read immediately before and
-// after the 256-step loop.  The stamp asm takes a limb of the loop's input / output as a "+v" operand, so the
-// compiler can move no ladder arithmetic across it.  stamp[0..1] = cycles, 100 MHz ticks spent in the loop.
-__device__ __forceinline__ void kyb_stamp(uint64_t& cyc, uint64_t& rt, uint32_t& dep) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(cyc), "=s"(rt), "+v"(dep) :: "memory");
-#else
-  cyc = rt = 0; (void)dep;      // host pass of hipcc only parses this
-#endif
-}
-__device__ __forceinline__ void ge_scalarmult_ladder_stamped(ge_p2& out, const uint32_t a[8], const mont_point& m, int skip, uint64_t stamp[2]) {
-  uint32_t neg, mag[8];
-  sc_effective(neg, mag, a);
-  fe x2, z2, x3, z3, u1;
-  fe_copy(u1, m.u);
-  uint64_t c0, r0, c1, r1;
-  kyb_stamp(c0, r0, u1.v[0]);
-  mont_ladder(x2, z2, x3, z3, u1, mag, skip);
-  kyb_stamp(c1, r1, x2.v[0]);
-  stamp[0] = c1 - c0; stamp[1] = r1 - r0;
-  mont_recover_to_edwards(out, m, x2, z2, x3, z3, mag[0] & 1u, neg);
-}
-#endif
 
 }  // namespace kyb

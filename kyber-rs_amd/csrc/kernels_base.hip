@@ -5,8 +5,10 @@
 #include <hip/hip_runtime.h>
 #include "launch.h"
 #include "ge_scalarmult.h"
+#include "diag_stamp.h"
 using namespace kyb;
 #include "device_tables.h"
+KYB_DEFINE_STAMP_SLOT()
 
 __global__ void __launch_bounds__(64) k_base_table(uint32_t* image) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;   // 0..511
@@ -34,6 +36,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK / 256)
 k_mul_base64(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ scalars_b, size_t n_a, size_t n,
              uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
              const uint4* __restrict__ table_image, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
+  // kyb_diag_wave_stamps (diag_stamp.h): off unless a benchmark asked for the in-kernel clock
+  KYB_STAMP_BEGIN();
   __shared__ uint4 lds_tbl[KYB_BASE64_TABLE_WORDS / 4];
   for (int k = threadIdx.x; k < KYB_BASE64_TABLE_WORDS / 4; k += BLOCK) lds_tbl[k] = table_image[k];
   __syncthreads();
@@ -59,6 +63,7 @@ k_mul_base64(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ sc
     if (SPLIT) { if (live) store_proj(proj + (proj_offset + i0), proj_stride, tl, h.X, h.Y, h.Z); }
     else finish_point(h.X, h.Y, h.Z, out_enc ? out_enc + 32 * i0 : nullptr, out_ext ? out_ext + 40 * i0 : nullptr, t, live);
   }
+  KYB_STAMP_END();
 }
 
 // ---- table image checksum ---------------------------------------------------------------------------
@@ -105,4 +110,5 @@ hipError_t mul_base64(bool split, int block, int grid, hipStream_t st, const uin
 #undef KYB_L
   return hipGetLastError();
 }
+hipError_t diag_stamps_base(uint64_t* buf) { return kyb_set_stamp_slot(buf); }
 }}  // namespace kyb::launch

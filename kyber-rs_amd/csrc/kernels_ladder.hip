@@ -10,8 +10,10 @@
 #include "ge_scalarmult.h"
 #include "ge_ladder.h"
 #include "device_batch_invert.h"
+#include "diag_stamp.h"
 using namespace kyb;
 #include "device_tables.h"
+KYB_DEFINE_STAMP_SLOT()
 
 // unmarshal_binary for the ladder path: extended limbs out, failed decodes replaced by the neutral element
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
@@ -95,15 +97,12 @@ k_mont_prep(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ p
   fe_one(unused_prefix);
   batch_invert<0, FINISH_K>(unused_prefix, unused_inv, load, emit);
 }
-#if defined(KYB_DIAG_STAMPS)
-// diagnostic build only: per-wave (cycles, 100 MHz ticks) of the ladder loop go to a buffer of their own
-__device__ uint64_t* kyb_diag_stamp_buf = nullptr;
-__device__ size_t kyb_diag_stamp_cap = 0;
-#endif
 template <int WAVES>
 __global__ void __launch_bounds__(KYB_BLOCK, WAVES)
 k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits_arg,
              const uint32_t* __restrict__ top_or, uint32_t* __restrict__ zero_next) {
+  // kyb_diag_wave_stamps (diag_stamp.h): off unless a benchmark asked for the in-kernel clock
+  KYB_STAMP_BEGIN();
   // top_or (written by k_mont_prep of this call): 0 iff every scalar of the launch is below 2^252 — the ladder then starts below the four
   // leading zeros.  zero_next: the word the NEXT call on this stream will collect into (the two alternate), cleared here.
   const int skip_bits = top_or != nullptr ? ((*top_or == 0u) ? 4 : 0) : skip_bits_arg;
@@ -122,15 +121,9 @@ k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ 
   for (int k = 0; k < 10; ++k) { m.u.v[k] = f[k]; m.v.v[k] = f[10 + k]; }
   m.flags = f[20];
   ge_p2 r;
-#if defined(KYB_DIAG_STAMPS)
-  uint64_t stamp[2];
-  ge_scalarmult_ladder_stamped(r, a, m, skip_bits, stamp);
-  const size_t wave = i >> 6;
-  if ((threadIdx.x & 63u) == 0 && kyb_diag_stamp_buf != nullptr && wave < kyb_diag_stamp_cap) { kyb_diag_stamp_buf[2 * wave] = stamp[0]; kyb_diag_stamp_buf[2 * wave + 1] = stamp[1]; }
-#else
   ge_scalarmult_ladder(r, a, m, skip_bits);
-#endif
   store_proj(proj, stride, i, r.X, r.Y, r.Z);
+  KYB_STAMP_END();
 }
 
 // One halving pass of the segmented sum behind kyb_lincomb_batch: in each of the m groups (group g
@@ -192,11 +185,5 @@ hipError_t ext_to_proj(hipStream_t st, const int32_t* pext, size_t n, uint4* pro
   hipLaunchKernelGGL(k_ext_to_proj, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, pext, n, proj, stride);
   return hipGetLastError();
 }
-#if defined(KYB_DIAG_STAMPS)
-hipError_t diag_set_stamp_buffer(uint64_t* dev_buf, size_t waves) {
-  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(kyb_diag_stamp_buf), &dev_buf, sizeof(dev_buf));
-  if (e != hipSuccess) return e;
-  return hipMemcpyToSymbol(HIP_SYMBOL(kyb_diag_stamp_cap), &waves, sizeof(waves));
-}
-#endif
+hipError_t diag_stamps_ladder(uint64_t* buf) { return kyb_set_stamp_slot(buf); }
 }}  // namespace kyb::launch

@@ -9,6 +9,7 @@
 #include "ge_scalarmult.h"
 #include "sc25519.h"
 #include "device_batch_invert.h"
+#include "diag_stamp.h"
 using namespace kyb;
 #include "device_tables.h"
 
@@ -206,7 +207,37 @@ k_decode(const uint8_t* __restrict__ enc, size_t n, int32_t* __restrict__ out_ex
 }
 
 
+// Benchmark diagnostic (kyb_diag_mad_peak): the integer-multiply roofline of THIS chip, measured in the run that quotes it.
+// Every wavefront issues nothing but v_mad_u64_u32 — eight independent accumulator chains, so the 4-cycle issue of a
+// quarter-rate instruction is never waiting on a result — and stamps its own lifetime (diag_stamp.h).  Two 1024-thread
+// workgroups per CU = 8 wavefronts per SIMD.
+constexpr int MAD_PEAK_CHAINS = launch::MAD_PEAK_CHAINS_HOST, MAD_PEAK_UNROLL = launch::MAD_PEAK_UNROLL_HOST;
+__global__ void __launch_bounds__(1024)
+k_diag_mad_peak(int iters, uint64_t* stamps, uint32_t* __restrict__ sink) {
+  uint64_t acc[MAD_PEAK_CHAINS];
+  const uint32_t a = threadIdx.x * 2654435761u + 12345u + blockIdx.x, b = threadIdx.x * 40503u + 977u;
+#pragma unroll
+  for (int c = 0; c < MAD_PEAK_CHAINS; ++c) acc[c] = a + c * 7919u;
+  WaveClock::stamp(stamps, 0);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < MAD_PEAK_UNROLL; ++u) {
+#pragma unroll
+      for (int c = 0; c < MAD_PEAK_CHAINS; ++c) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[c]) : "v"(a), "v"(b) : "vcc");
+    }
+  }
+  WaveClock::stamp(stamps, 1);
+  uint64_t s = 0;
+#pragma unroll
+  for (int c = 0; c < MAD_PEAK_CHAINS; ++c) s += acc[c];
+  if (s == 0x1234567u) sink[0] = (uint32_t)s;      // keeps the chains alive; practically never true
+}
+
 namespace kyb { namespace launch {
+hipError_t diag_mad_peak(hipStream_t st, int grid, int iters, uint64_t* stamps, uint32_t* sink) {
+  hipLaunchKernelGGL(k_diag_mad_peak, dim3(grid), dim3(1024), 0, st, iters, stamps, sink);
+  return hipGetLastError();
+}
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK); }
 hipError_t finish(hipStream_t st, const uint4* proj, size_t stride, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul) {
   const size_t M = (n + FINISH_K - 1) / FINISH_K;

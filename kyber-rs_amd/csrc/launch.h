@@ -43,16 +43,13 @@ hipError_t sign_fused(int mode, int grid, hipStream_t st, const uint8_t* x, cons
 hipError_t decode_or_identity(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok);
 // rows != 0: encoding i = (r, c) of a rows x cols matrix lands in record c * rows + r
 hipError_t decode_to_proj(hipStream_t st, const uint8_t* enc, size_t n, uint4* proj, size_t stride, uint8_t* ok, size_t rows, size_t cols);
-// scalars / top_or != nullptr (one scalar per point): the OR of the scalars' top three bits is collected into *top_or on the way
+// scalars / top_or != nullptr (one scalar per point): the OR of the scalars' top four bits is collected into *top_or on the way
 hipError_t mont_prep(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride, const uint8_t* scalars = nullptr, uint32_t* top_or = nullptr);
-// top_or != nullptr: the word mont_prep collected into — the kernel takes skip_bits = 3 when it is 0, else 0; zero_next: cleared for the next call
+// top_or != nullptr: the word mont_prep collected into — the kernel takes skip_bits = 4 when it is 0, else 0; zero_next: cleared for the next call
 hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, uint4* proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits,
                       const uint32_t* top_or = nullptr, uint32_t* zero_next = nullptr);
 hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half);
 hipError_t ext_to_proj(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride);
-#if defined(KYB_DIAG_STAMPS)
-hipError_t diag_set_stamp_buffer(uint64_t* dev_buf, size_t waves);
-#endif
 
 // Completion signal of a small host-pointer call (engine.hip, HostCall): the LAST kernel of the call's launch sequence counts
 // its finished items (threads or wavefronts, `total` of them) in *counter; the one that completes the count resets the counter and
@@ -116,6 +113,15 @@ hipError_t encode(hipStream_t st, const int32_t* pext, size_t n, uint8_t* oenc);
 hipError_t decode(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok);
 hipError_t poly_eval(bool split, hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly,
                      uint8_t* oenc, int32_t* oext, uint4* proj, size_t stride);
+
+// benchmark diagnostic (kyb_diag_wave_stamps, diag_stamp.h): the five 64-bit sums into which the wavefronts of k_mul_ladder /
+// k_mul_base64 on the CURRENT device add their start / end (shader cycles, 100 MHz ticks); nullptr = off.  Synchronous.
+hipError_t diag_stamps_ladder(uint64_t* buf);
+hipError_t diag_stamps_base(uint64_t* buf);
+// benchmark diagnostic (kyb_diag_mad_peak): `grid` workgroups of 1024 threads issue nothing but v_mad_u64_u32, iters x 32 per wavefront;
+// stamps[0..4] = the sums of diag_stamp.h
+hipError_t diag_mad_peak(hipStream_t st, int grid, int iters, uint64_t* stamps, uint32_t* sink);
+constexpr int MAD_PEAK_CHAINS_HOST = 8, MAD_PEAK_UNROLL_HOST = 4;      // = the kernel's chains x unroll (kernels_misc.hip)
 
 // segs lanes per evaluation (len coefficients each): partial results as extended limbs in part_ext[n * segs], multipliers in part_sc
 hipError_t poly_eval_part(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly, int len, int segs,

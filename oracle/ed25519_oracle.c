@@ -751,7 +751,15 @@ static void* worker(void* arg) {
     if (j->kind == 0) orc_mul_base(j->out + 32 * i, NULL, j->sc + 32 * i);
     else if (j->kind == 1) orc_mul(j->out + 32 * i, NULL, j->sc + 32 * i, j->pts + 40 * i);
     else if (j->kind == 2) orc_schnorr_sign(j->out + 64 * i, j->sc + 32 * i, j->k + 32 * i, j->msgs + j->off[i], j->off[i + 1] - j->off[i]);
-    else j->out[i] = (uint8_t)orc_verify(j->flavor, j->sc + 32 * i, j->msgs + j->off[i], j->off[i + 1] - j->off[i], j->k + 64 * i, 64);
+    else if (j->kind == 3) j->out[i] = (uint8_t)orc_verify(j->flavor, j->sc + 32 * i, j->msgs + j->off[i], j->off[i + 1] - j->off[i], j->k + 64 * i, 64);
+    else if (j->kind == 4) {      /* a received point: unmarshal_binary (point.rs:43-51), then mul; an encoding that does not decode -> ok = 0, neutral element out */
+      int32_t ext[40];
+      int ok = orc_decode(ext, j->k + 32 * i);
+      if (!ok) orc_null(ext);
+      orc_mul(j->out + 32 * i, NULL, j->sc + 32 * i, ext);
+      if (j->msgs) ((uint8_t*)j->msgs)[i] = (uint8_t)ok;
+    }
+    else orc_encode(j->out + 32 * i, j->pts + 40 * i);      /* kind 5: marshal_binary */
   }
   return NULL;
 }
@@ -773,6 +781,12 @@ void orc_mul_base_batch(uint8_t* out_enc, const uint8_t* scalars, size_t n, int 
 }
 void orc_mul_batch(uint8_t* out_enc, const uint8_t* scalars, const int32_t* pts_ext, size_t n, int nthreads) {
   job_t j; memset(&j, 0, sizeof(j)); j.kind = 1; j.sc = scalars; j.pts = pts_ext; j.out = out_enc; run_batch(j, n, nthreads);
+}
+void orc_mul_enc_batch(uint8_t* out_enc, uint8_t* ok, const uint8_t* scalars, const uint8_t* pts_enc, size_t n, int nthreads) {
+  job_t j; memset(&j, 0, sizeof(j)); j.kind = 4; j.sc = scalars; j.k = pts_enc; j.msgs = ok; j.out = out_enc; run_batch(j, n, nthreads);
+}
+void orc_encode_batch(uint8_t* out_enc, const int32_t* pts_ext, size_t n, int nthreads) {
+  job_t j; memset(&j, 0, sizeof(j)); j.kind = 5; j.pts = pts_ext; j.out = out_enc; run_batch(j, n, nthreads);
 }
 void orc_schnorr_sign_batch(uint8_t* sigs, const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n, int nthreads) {
   job_t j; memset(&j, 0, sizeof(j)); j.kind = 2; j.sc = x; j.k = k; j.msgs = msgs; j.off = off; j.out = sigs; run_batch(j, n, nthreads);

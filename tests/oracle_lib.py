@@ -153,6 +153,22 @@ class Oracle:
         self.lib.orc_mul_batch(_p(out), _p(s), _p(p), ctypes.c_size_t(s.shape[0]), nthreads)
         return out
 
+    def mul_enc_batch(self, scalars, pts_enc, nthreads: int = 1):
+        """unmarshal_binary of every operand, then mul -> (encodings, ok); an encoding that does not decode gives ok = 0 and the neutral element"""
+        s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+        e = np.ascontiguousarray(pts_enc, dtype=np.uint8).reshape(-1, 32)
+        assert e.shape[0] == s.shape[0]
+        out = np.empty_like(s)
+        ok = np.empty((s.shape[0],), dtype=np.uint8)
+        self.lib.orc_mul_enc_batch(_p(out), _p(ok), _p(s), _p(e), ctypes.c_size_t(s.shape[0]), nthreads)
+        return out, ok
+
+    def encode_batch(self, pts_ext, nthreads: int = 1) -> np.ndarray:
+        p = _i32(pts_ext).reshape(-1, 40)
+        out = np.empty((p.shape[0], 32), dtype=np.uint8)
+        self.lib.orc_encode_batch(_p(out), _p(p), ctypes.c_size_t(p.shape[0]), nthreads)
+        return out
+
     def mul_base_ext_batch(self, scalars) -> np.ndarray:
         s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
         if s.shape[0] == 0:

@@ -193,3 +193,120 @@ def test_encode_batched_matches_per_item_encode(engine, oracle):
         assert np.array_equal(a, b)
         idx = list(range(min(n, 40)))
         assert [bytes(a[i]) for i in idx] == [oracle.encode(pts[i]) for i in idx]
+
+
+def test_group_device_resident_shards_and_pool_reuse(oracle):
+    """kyb_group_mul(_base)_batch_dev: per-rank device pointers, launches queued on every rank's own stream by ONE thread, kyb_group_sync;
+    and the group's persistent worker threads serve many sharded host-pointer calls in a row (nothing is spawned per call)."""
+    import torch
+    import kyber_rs_amd
+    grp = kyber_rs_amd.Group([0, 0, 0])
+    try:
+        dev = torch.device("cuda", 0)
+        sizes = [70000, 1, 4097]                    # batch kernels, one-item kernels, in between
+        sc_np = [synth.scalars(m, 50 + r) for r, m in enumerate(sizes)]
+        pt_np = [oracle.mul_base_ext_batch(synth.scalars(min(m, 64), 60 + r, b"point")) for r, m in enumerate(sizes)]
+        pt_np = [np.tile(p, ((m + len(p) - 1) // len(p), 1))[:m].copy() for p, m in zip(pt_np, sizes)]
+        sc = [torch.from_numpy(a).to(dev) for a in sc_np]
+        pts = [torch.from_numpy(a).to(dev) for a in pt_np]
+        out = [torch.empty((m, 32), dtype=torch.uint8, device=dev) for m in sizes]
+        outb = [torch.empty((m, 32), dtype=torch.uint8, device=dev) for m in sizes]
+        torch.cuda.synchronize()
+        for _ in range(2):
+            grp.mul_dev(sc, pts_ext=pts, out_enc=out)
+            grp.mul_base_dev(sc, out_enc=outb)
+        grp.sync()
+        for r in range(3):
+            assert np.array_equal(out[r].cpu().numpy(), oracle.mul_batch(sc_np[r], pt_np[r], nthreads=8)), r
+            assert np.array_equal(outb[r].cpu().numpy(), oracle.mul_base_batch(sc_np[r], nthreads=8)), r
+        # wire encodings in, decode flags out
+        penc = [torch.from_numpy(oracle.encode_batch(a)).to(dev) for a in pt_np]
+        ok = [torch.zeros((m,), dtype=torch.uint8, device=dev) for m in sizes]
+        for t in out:
+            t.zero_()
+        grp.mul_dev(sc, pts_enc=penc, out_enc=out, ok=ok)
+        grp.sync()
+        for r in range(3):
+            assert bool(ok[r].all()) and np.array_equal(out[r].cpu().numpy(), oracle.mul_batch(sc_np[r], pt_np[r], nthreads=8)), r
+        # 200 sharded host-pointer calls through the same three worker threads
+        s = synth.scalars(9, 77)
+        want = oracle.mul_base_batch(s)
+        before = threading.active_count()
+        for _ in range(200):
+            assert np.array_equal(grp.mul_base(s), want)
+        assert threading.active_count() == before
+    finally:
+        grp.close()
+
+
+def test_group_rejects_decreasing_message_offsets(oracle):
+    """a decrease in msg_off wrapped in the unsigned shard offsets and passed the per-shard check; the group entry points now
+    validate the whole array first, like the single-device calls."""
+    import kyber_rs_amd
+    lib = kyber_rs_amd.load_library()
+    grp = kyber_rs_amd.Group([0, 0])
+    try:
+        n = 6
+        x, k = synth.scalars(n, 81, b"x"), synth.scalars(n, 81, b"k")
+        blob = np.zeros(1024, dtype=np.uint8)
+        off = np.array([0, 10, 100, 40, 50, 60, 70], dtype=np.uint32)          # 100 -> 40: inside rank 0's shard ... and across shards below
+        sig = np.zeros((n, 64), dtype=np.uint8)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        assert lib.kyb_group_schnorr_sign_batch(grp.handle, p(x), p(k), p(blob), p(off), n, p(sig)) == -2
+        assert b"non-decreasing" in lib.kyb_last_error()
+        off2 = np.array([0, 10, 20, 30, 5, 6, 7], dtype=np.uint32)             # the decrease sits exactly on the shard boundary
+        assert lib.kyb_group_schnorr_sign_batch(grp.handle, p(x), p(k), p(blob), p(off2), n, p(sig)) == -2
+        pub = np.zeros((n, 32), dtype=np.uint8)
+        st = np.zeros(n, dtype=np.uint8)
+        assert lib.kyb_group_verify_batch(grp.handle, p(pub), p(blob), p(off), p(sig), n, 1, p(st)) == -2
+        assert not sig.any()                                                   # nothing was written
+        good = np.arange(0, 8 * (n + 1), 8, dtype=np.uint32)
+        assert lib.kyb_group_schnorr_sign_batch(grp.handle, p(x), p(k), p(blob), p(good), n, p(sig)) == 0
+        assert np.array_equal(sig, oracle.schnorr_sign_batch(x, k, [bytes(8)] * n))
+    finally:
+        grp.close()
+
+
+def test_benchmark_diagnostics(engine, oracle):
+    """kyb_diag_mad_peak and kyb_diag_wave_stamps: plausible figures, and the stamped kernels still produce the oracle's bytes"""
+    import torch
+    pk = engine.mad_peak(20.0)
+    cus = engine.device_info()["compute_units"]
+    assert pk["kernel_ms"] >= 20.0 and 1.2 < pk["clock_ghz"] < 2.7, pk
+    assert 3.9 < pk["simd_cycles_per_mad"] < 6.0, pk                         # quarter rate: never below 4 cycles per wavefront instruction
+    nominal = cus * 4 * 64 / 4 * 2.4e9
+    assert 0.5 * nominal < pk["mads_per_s"] <= 1.001 * nominal, pk
+    dev = torch.device("cuda", 0)
+    n = 1 << 17
+    s_np = synth.scalars(n, 91)
+    sc = torch.from_numpy(s_np).to(dev)
+    pts = torch.empty((n, 40), dtype=torch.int32, device=dev)
+    out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    outb = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+    engine.mul_base_dev(sc, out_ext=pts)
+    engine.sync()
+    buf = torch.zeros(8, dtype=torch.int64, device=dev)
+    engine.wave_stamps(buf)
+    try:
+        engine.mul_dev(sc, pts_ext=pts, out_enc=out)
+        engine.sync()
+        a = [int(v) % (1 << 64) for v in buf.cpu().tolist()]
+        assert a[4] == n // 64                                                # every wavefront of k_mul_ladder stamped once
+        ghz = ((a[2] - a[0]) % (1 << 64)) / ((a[3] - a[1]) % (1 << 64)) * 0.1
+        assert 1.2 < ghz < 2.7, ghz
+        buf.zero_()
+        torch.cuda.synchronize()
+        engine.mul_base_dev(sc, out_enc=outb)
+        engine.sync()
+        b = [int(v) % (1 << 64) for v in buf.cpu().tolist()]
+        assert b[4] > 0 and b[4] % 16 == 0                                    # k_mul_base64: whole 1024-thread workgroups
+    finally:
+        engine.wave_stamps(None)
+    idx = np.arange(0, n, 257)
+    assert np.array_equal(out.cpu().numpy()[idx], oracle.mul_batch(s_np[idx], pts.cpu().numpy()[idx], nthreads=8))
+    assert np.array_equal(outb.cpu().numpy()[idx], oracle.mul_base_batch(s_np[idx], nthreads=8))
+    buf.zero_()
+    torch.cuda.synchronize()
+    engine.mul_dev(sc, pts_ext=pts, out_enc=out)
+    engine.sync()
+    assert not buf.cpu().any()                                                # switched off: nothing is written any more

@@ -408,9 +408,11 @@ def test_coop_primitives_match_the_lane_model(engine):
 
 
 def test_short_public_scalars_take_a_short_ladder(engine, oracle):
-    """A host-pointer mul of a few items whose scalars are ALL below 2^64 (share indices, the cofactor: what PubPoly::eval and
-    Point::pick multiply by, poly.rs:464, point.rs:148) starts its ladder below the leading zeros; same points as the full ladder and
-    as the reference's 64-window routine, also on small-order and mixed-order operands."""
+    """kyb_mul_public_batch: a host-pointer mul of a few items whose multipliers the caller DECLARES public and which are ALL below 2^64
+    (share indices, the cofactor: what PubPoly::eval and Point::pick multiply by, poly.rs:464, point.rs:148) starts its ladder below the
+    leading zeros; same points as the full ladder and as the reference's 64-window routine, also on small-order and mixed-order operands.
+    kyb_mul_batch itself never shortens (mul.short_scalars defaults to 0); with the option set it behaves like the public call."""
+    assert engine.get_option("mul.short_scalars") == 0
     weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
     pts = list(oracle.mul_base_ext_batch(synth.scalars(6, 501, b"short")))
     pts[1] = oracle.add(pts[1], weak[2])
@@ -420,27 +422,39 @@ def test_short_public_scalars_take_a_short_ladder(engine, oracle):
     for v in small:
         for p in pts:
             s = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8)[None, :]
-            got, ext = engine.mul(s, pts_ext=p[None, :], want_ext=True)
+            got, ext = engine.mul(s, pts_ext=p[None, :], want_ext=True, public=True)
             assert bytes(got[0]) == oracle.mul(bytes(s[0]), p), (v, "enc")
             assert oracle.encode(ext[0]) == bytes(got[0])
     # several items in one call: short only when every scalar is short
     sc = np.stack([np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8) for v in small[:6]])
     P = np.stack(pts)
     want = oracle.mul_batch(sc, P)
-    assert np.array_equal(engine.mul(sc, pts_ext=P), want)
+    assert np.array_equal(engine.mul(sc, pts_ext=P, public=True), want)
     mixed = sc.copy(); mixed[4] = synth.scalars(1, 9)[0]
-    assert np.array_equal(engine.mul(mixed, pts_ext=P), oracle.mul_batch(mixed, P))
+    assert np.array_equal(engine.mul(mixed, pts_ext=P, public=True), oracle.mul_batch(mixed, P))
     big = np.frombuffer((1 << 64).to_bytes(32, "little"), dtype=np.uint8)[None, :]
-    assert bytes(engine.mul(big, pts_ext=P[:1])[0]) == oracle.mul(bytes(big[0]), P[0])
-    engine.set_option("mul.short_scalars", 0)
+    assert bytes(engine.mul(big, pts_ext=P[:1], public=True)[0]) == oracle.mul(bytes(big[0]), P[0])
+    # the plain call (full ladder), then the plain call with the option that treats every call as public
+    assert np.array_equal(engine.mul(sc, pts_ext=P), want)
+    engine.set_option("mul.short_scalars", 1)
     try:
         assert np.array_equal(engine.mul(sc, pts_ext=P), want)
     finally:
-        engine.set_option("mul.short_scalars", 1)
+        engine.set_option("mul.short_scalars", 0)
+    # the declaration is what shortens the ladder: a 10-bit multiplier is several times faster through the public call
+    import time
+    one = np.frombuffer((513).to_bytes(32, "little"), dtype=np.uint8)[None, :]
+    def med(fn):
+        fn(); ts = []
+        for _ in range(30):
+            a = time.perf_counter(); fn(); ts.append(time.perf_counter() - a)
+        return sorted(ts)[len(ts) // 2]
+    t_pub, t_plain = med(lambda: engine.mul(one, pts_ext=P[:1], ext_only=True, public=True)), med(lambda: engine.mul(one, pts_ext=P[:1], ext_only=True))
+    assert t_pub < 0.7 * t_plain, (t_pub, t_plain)
     # projective hand-over keeps working on the short path
     engine.set_option("ext.projective", 1)
     try:
-        ext = engine.mul(sc, pts_ext=P, ext_only=True)
+        ext = engine.mul(sc, pts_ext=P, ext_only=True, public=True)
         assert np.array_equal(engine.encode(ext), want)
     finally:
         engine.set_option("ext.projective", 0)

@@ -77,3 +77,43 @@ def test_shard_properties():
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
     with pytest.raises(ValueError):
         multi_gpu.shard(10, 2, 2)
+
+
+def test_bench_spawns_its_own_ranks_and_prints_one_line():
+    """`python bench.py --gpus 2` WITHOUT a launcher (the shape of the driver's N = 1 command): the parent spawns the two ranks before
+    any GPU call, they rendezvous over gloo with the stand-in engine (tests/standin_engine.py: no GPU, no arithmetic), rank 1 receives
+    rank 0's table image, and the parent relays exactly one JSON line — marked as a plumbing run, not a measurement."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "4096", "--standin"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["dist_backend"] == "gloo" and line["launched_by"] == "self-spawned ranks" and line["scaling"] == "weak"
+    assert line["metric"].startswith("STANDIN") and line["roofline"] is None            # cannot be mistaken for a measurement
+    assert line["standin_calls"] == {"mul_base_dev": 1, "mul_dev": 4}                     # input generation, 1 warm-up + 3 timed steps
+    assert [d["rank"] for d in line["devices"]] == [0, 1]
+    assert line["table_identical_on_all_ranks"] and len({d["table_sha256_16"] for d in line["devices"]}) == 1
+    assert abs(line["value"] - 2 * 4096 * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-3 * line["value"]      # whole-job rate over the max-over-ranks time
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--standin"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_a_failing_rank_fails_the_self_spawned_job():
+    """one rank dying must end the whole job with a non-zero status (the parent stops the others instead of hanging in the rendezvous)"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["KYB_BENCH_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--n", "256", "--standin"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]

@@ -103,13 +103,14 @@ while time.time() < t_end:
             for i in range(n):
                 v = int.from_bytes(bytes(sc[i]), "little") & ((1 << bits) - 1)
                 sc[i] = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8)
-            eng.set_option("mul.short_scalars", int(rng.integers(0, 4) != 0))
+            eng.set_option("mul.short_scalars", int(rng.integers(0, 4) == 0))      # the option, or (mostly) the explicit public call
+            pub = bool(rng.integers(0, 4) != 0)
             want = orc.mul_batch(sc, POOL_P[sl])
             if opts["ext.projective"]:
-                assert np.array_equal(eng.encode(eng.mul(sc, pts_ext=POOL_P[sl], ext_only=True)), want)
+                assert np.array_equal(eng.encode(eng.mul(sc, pts_ext=POOL_P[sl], ext_only=True, public=pub)), want)
             else:
-                assert np.array_equal(eng.mul(sc, pts_ext=POOL_P[sl]), want)
-            eng.set_option("mul.short_scalars", 1)
+                assert np.array_equal(eng.mul(sc, pts_ext=POOL_P[sl], public=pub), want)
+            eng.set_option("mul.short_scalars", 0)
         elif op == "mul_ext":
             if rng.integers(0, 2):
                 assert np.array_equal(eng.mul(K2[sl], pts_ext=POOL_P[sl]), WANT_MUL[sl])

@@ -5,7 +5,7 @@
 
 Compiles each kernel translation unit to gfx950 assembly (hipcc -S --cuda-device-only; no GPU needed) and reads the
 `.amdhsa_*` directives and the `; ScratchSize` / `; Occupancy` comments of every kernel.  Used to keep "0 bytes of scratch" a
-checked property (tests/test_build_resources.py) and to compare builds.
+checked property (tests/test_build_resources.py: default-path kernels 0 scratch and within their VGPR caps, spilling variants listed) and to compare builds.
 """
 import argparse, concurrent.futures, json, os, re, subprocess, sys, tempfile
 

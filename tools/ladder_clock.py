@@ -1,51 +1,33 @@
 #!/usr/bin/env python3
-"""In-kernel clock of the ladder kernel (MI355X_MICROARCH.md 'DVFS give-back' item 6).
+"""In-kernel clock of the ladder kernel (MI355X_MICROARCH.md 'DVFS give-back').
 
-Runs a DIAGNOSTIC build of the library (-DKYB_DIAG_STAMPS: k_mul_ladder reads s_memtime / s_memrealtime right
-before and after its 256-step loop and writes the two differences per wave to a buffer of their own; the product
-library executes no stamp) back to back for >= 2.5 s on random data, then reports from the LAST launch:
+The PRODUCT library carries optional wave stamps (csrc/diag_stamp.h, kyb_diag_wave_stamps): while a buffer is set every wavefront of
+k_mul_ladder adds s_memtime / s_memrealtime at its start and end into five 64-bit sums.  This tool runs the 2^20-item step back to
+back for >= 2.5 s, then reports from the LAST launch:
 
-  in_kernel_ghz              median over waves of  d(s_memtime) / d(s_memrealtime) x 100 MHz
-  cycles_per_wave_step       median over waves of  d(s_memtime) / steps           (a wave shares its SIMD with others)
+  in_kernel_ghz              (sum of cycle differences) / (sum of 100 MHz tick differences) x 100 MHz
   simd_cycles_per_wave_step  kernel time (HIP events) x in-kernel clock / (wave-steps one SIMD executes)
-  mad_issue_share_*          739 v_mad_u64_u32 per step x {4.0 nominal half-rate cycles, 4.63 measured in
-                             tools/microbench/valu_rates.hip} / simd_cycles_per_wave_step
+  mad_issue_share_*          739 v_mad_u64_u32 per step x {4.0 nominal quarter-rate cycles, the cycles kyb_diag_mad_peak measures in
+                             this run} / simd_cycles_per_wave_step
 
-  python tools/ladder_clock.py [--n 1048576] [--seconds 2.5] [--out profiles/r02/ladder_clock.json]
+  python tools/ladder_clock.py [--n 1048576] [--seconds 2.5] [--out profiles/r03/ladder_clock.json]
 """
 import argparse
-import ctypes
 import json
 import os
-import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DIAG_LIB = os.path.join(ROOT, "tools", "_build", "libkyber_ed25519_hip_stamps.so")
 MADS_PER_STEP = 5 * 100 + 4 * 55 + 10 + 9          # 5 M + 4 S + the a24 multiplication + 9 carry folds
-
-
-def build_diag():
-    sys.path.insert(0, ROOT)
-    import __graft_entry__
-    os.makedirs(os.path.dirname(DIAG_LIB), exist_ok=True)
-    return __graft_entry__.build_hip(extra_flags=("-DKYB_DIAG_STAMPS",), out=DIAG_LIB, objdir="_obj_stamps")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=1 << 20)
     ap.add_argument("--seconds", type=float, default=2.5)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02", "ladder_clock.json"))
-    ap.add_argument("--build-only", action="store_true")
-    ap.add_argument("--no-build", action="store_true", help="use the diagnostic library as it is (it was built before the snapshot left for the GPU box)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03", "ladder_clock.json"))
     args = ap.parse_args()
-    if not (args.no_build and os.path.exists(DIAG_LIB)):
-        build_diag()
-    if args.build_only:
-        return
-    os.environ["KYB_HIP_LIB"] = DIAG_LIB
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
@@ -69,12 +51,9 @@ def main():
     st = tstream.cuda_stream
     eng.mul_base_dev(psc, out_ext=pts, stream=st)
     waves = (n + 63) // 64
-    stamps = torch.zeros((waves, 2), dtype=torch.int64, device=dev)
-    lib = kyber_rs_amd.load_library()      # the raw ctypes library (the engine sees it through its context proxy)
-    lib.kyb_diag_set_stamp_buffer.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-    lib.kyb_diag_set_stamp_buffer.restype = ctypes.c_int
-    assert lib.kyb_diag_set_stamp_buffer(ctypes.c_void_p(stamps.data_ptr()), waves) == 0
+    stamps = torch.zeros(8, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
+    peak = eng.mad_peak(50.0)
     t0 = time.time()
     launches = 0
     while time.time() - t0 < args.seconds:
@@ -82,36 +61,38 @@ def main():
             eng.mul_dev(sc, pts_ext=pts, out_enc=out, stream=st)
         launches += 16
         torch.cuda.synchronize()
+    eng.wave_stamps(stamps)
     eng.profile_begin(8)
     eng.mul_dev(sc, pts_ext=pts, out_enc=out, stream=st)
     torch.cuda.synchronize()
     prof = dict(eng.profile_read(8))
     eng.profile_begin(0)
-    s = stamps.cpu().numpy().astype(np.float64)
-    cyc, rt = s[:, 0], s[:, 1]
-    ok = rt > 0
-    ghz = np.median(cyc[ok] / rt[ok] * 0.1)
-    steps = 256
+    eng.wave_stamps(None)
+    s = [int(v) & ((1 << 64) - 1) for v in stamps.cpu().tolist()]
+    cyc, rt, seen = (s[2] - s[0]) % (1 << 64), (s[3] - s[1]) % (1 << 64), s[4]
+    assert seen == waves, (seen, waves)
+    ghz = cyc / rt * 0.1
+    steps = 256 - (4 if eng.get_option("ladder.skip_canonical") else 0)      # the scalars above are below 2^252
     cu = eng.device_info()["compute_units"]
     simds = cu * 4
     ladder_ms = prof["k_mul_ladder"]
     wave_steps_per_simd = waves * steps / simds
     simd_cyc = ladder_ms * 1e-3 * ghz * 1e9 / wave_steps_per_simd
     res = {
-        "what": "k_mul_ladder, diagnostic build with s_memtime/s_memrealtime stamps around the 256-step loop (tools/ladder_clock.py)",
+        "what": "k_mul_ladder of the product library, wave stamps on (kyb_diag_wave_stamps: s_memtime / s_memrealtime at wavefront start and end; tools/ladder_clock.py)",
         "items": n, "waves": waves, "back_to_back_launches_before_sample": launches, "seconds_of_load": round(time.time() - t0, 2),
         "in_kernel_ghz": round(float(ghz), 4),
-        "in_kernel_ghz_p05_p95": [round(float(np.percentile(cyc[ok] / rt[ok] * 0.1, q)), 4) for q in (5, 95)],
-        "wave_loop_cycles_median": float(np.median(cyc)), "wave_loop_cycles_min_max": [float(cyc.min()), float(cyc.max())],
-        "cycles_per_wave_step_median": round(float(np.median(cyc)) / steps, 1),
+        "wave_lifetime_cycles_mean": round(cyc / waves, 1), "ladder_steps": steps,
+        "cycles_per_wave_step_mean": round(cyc / waves / steps, 1),
         "k_mul_ladder_ms_this_launch_hip_events": round(ladder_ms, 4),
         "simd_cycles_per_wave_step": round(float(simd_cyc), 1),
         "mads_per_step": MADS_PER_STEP,
         "mad_issue_share_at_4.00_cyc": round(MADS_PER_STEP * 4.0 / simd_cyc, 4),
-        "mad_issue_share_at_4.63_cyc": round(MADS_PER_STEP * 4.63 / simd_cyc, 4),
+        "mad_peak_this_run": {k_: round(v_, 4) if k_ != "mads_per_s" else round(v_ / 1e12, 3) for k_, v_ in peak.items()},
+        "mad_issue_share_at_measured_cyc": round(MADS_PER_STEP * peak["simd_cycles_per_mad"] / simd_cyc, 4),
         "mad_rate_T_per_s": round(MADS_PER_STEP * steps * n / (ladder_ms * 1e-3) / 1e12, 3),
         "mad_peak_at_in_kernel_clock_T_per_s_4.00_cyc": round(simds * 64 / 4.0 * ghz * 1e9 / 1e12, 2),
-        "note": "stamped build: the stamps themselves and the extra fe_copy cost < 0.1 % of the loop; never compare its wall time with the product build's",
+        "note": "the stamps span the whole wavefront (operand load, ladder, y-recovery, store): the ladder loop is 97 % of it",
     }
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
