@@ -29,8 +29,37 @@ def oracle():
     return oracle_lib.Oracle()
 
 
+_SESSION_ENGINE = []
+
+
+def _option_keys():
+    import re
+    src = open(os.path.join(ROOT, "kyber-rs_amd", "csrc", "c_abi.inc")).read()
+    return sorted(set(re.findall(r'strcmp\(key, "([a-z_0-9.]+)"\)', src)))
+
+
 @pytest.fixture(scope="session")
 def engine():
     import kyber_rs_amd
     eng = kyber_rs_amd.Engine(0)
+    _SESSION_ENGINE.append(eng)
     yield eng
+
+
+@pytest.fixture(autouse=True)
+def _engine_options_are_left_as_found():
+    """the session's engine is shared: a test that changes a kernel-selection option and does not put it back silently changes which
+    kernels every later test runs (one did: the small-batch kernels stayed switched off for the rest of the session)"""
+    eng = _SESSION_ENGINE[0] if _SESSION_ENGINE else None
+    before = {k: eng.get_option(k) for k in _option_keys()} if eng else None
+    yield
+    eng = _SESSION_ENGINE[0] if _SESSION_ENGINE else None
+    if eng is None:
+        return
+    after = {k: eng.get_option(k) for k in _option_keys()}
+    if before is None:
+        return
+    changed = {k: (before[k], after[k]) for k in before if before[k] != after[k]}
+    for k, (was, _now) in changed.items():
+        eng.set_option(k, was)
+    assert not changed, f"engine options left changed by this test (restored now): {changed}"

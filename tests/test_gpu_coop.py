@@ -323,6 +323,7 @@ def test_coop_and_batch_kernels_agree_at_the_threshold(engine, oracle):
     """the routing by size: n <= coop.max_items -> cooperative kernel, above -> batch kernels; same bytes either way"""
     s = synth.raw256(130, 800)
     p = oracle.mul_base_ext_batch(synth.scalars(130, 801, b"point"))
+    old = (engine.get_option("coop.max_items"), engine.get_option("coop.base_max_items"))
     engine.set_option("coop.max_items", 0)
     engine.set_option("coop.base_max_items", 0)
     ref_mul, ref_base = engine.mul(s, pts_ext=p), engine.mul_base(s)
@@ -338,8 +339,8 @@ def test_coop_and_batch_kernels_agree_at_the_threshold(engine, oracle):
         assert names.count("k_mul_coop") == 1 and names.count("k_mul_base_coop") == 1 and "k_mul_ladder" in names
     finally:
         engine.profile_begin(0)
-        engine.set_option("coop.max_items", 0)
-        engine.set_option("coop.base_max_items", 0)
+        engine.set_option("coop.max_items", old[0])          # (this used to leave the session's engine with the small-batch kernels switched off)
+        engine.set_option("coop.base_max_items", old[1])
 
 
 def test_coop_primitives_match_the_lane_model(engine):
