@@ -1,7 +1,7 @@
 //! `extern "C"` block for include/kyber_ed25519.h (ABI version 2).  One line per entry point the Rust side binds.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
-use std::sync::Once;
+use std::sync::OnceLock;
 
 pub type size_t = usize;
 /// opaque `kyb_ctx` / `kyb_group`
@@ -12,9 +12,7 @@ pub const KYB_ABI_VERSION: c_int = 2;
 
 extern "C" {
     pub fn kyb_abi_version() -> c_int;
-    pub fn kyb_init(device: c_int) -> c_int;
     pub fn kyb_set_option(key: *const c_char, value: c_int) -> c_int;
-    pub fn kyb_shutdown();
     pub fn kyb_last_error() -> *const c_char;
     pub fn kyb_sync(stream: *mut c_void) -> c_int;
     pub fn kyb_stream_release(stream: *mut c_void) -> c_int;
@@ -22,6 +20,8 @@ extern "C" {
     pub fn kyb_ctx_create(device: c_int, build_table: c_int, out: *mut *mut kyb_ctx) -> c_int;
     pub fn kyb_ctx_destroy(ctx: *mut kyb_ctx) -> c_int;
     pub fn kyb_ctx_set_current(ctx: *mut kyb_ctx) -> c_int;
+    pub fn kyb_base_table_export(dst_host: *mut u8) -> c_int;
+    pub fn kyb_base_table_import(src_host: *const u8) -> c_int;
     pub fn kyb_group_create(devices: *const c_int, n: c_int, out: *mut *mut kyb_group) -> c_int;
     pub fn kyb_group_destroy(g: *mut kyb_group);
     pub fn kyb_group_size(g: *const kyb_group) -> c_int;
@@ -37,6 +37,8 @@ extern "C" {
     pub fn kyb_mul_base_batch(scalars: *const u8, n: size_t, out_enc: *mut u8, out_ext: *mut i32) -> c_int;
     pub fn kyb_mul_batch(scalars: *const u8, pts_enc: *const u8, pts_ext: *const i32, n: size_t,
                          out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8) -> c_int;
+    pub fn kyb_mul_public_batch(scalars: *const u8, pts_enc: *const u8, pts_ext: *const i32, n: size_t,
+                                out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8) -> c_int;
     pub fn kyb_mul_batch_dev(scalars: *const u8, pts_enc: *const u8, pts_ext: *const i32, n: size_t,
                              out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8, stream: *mut c_void) -> c_int;
     pub fn kyb_add_batch(a_ext: *const i32, b_ext: *const i32, n: size_t, out_ext: *mut i32, subtract: c_int) -> c_int;
@@ -64,32 +66,63 @@ extern "C" {
     pub fn kyb_host_free(p: *mut c_void);
 }
 
-static INIT: Once = Once::new();
+pub const KYB_BASE_TABLE_BYTES: usize = 335232;
 
 fn device() -> c_int {
     std::env::var("KYBER_HIP_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0)
 }
 
-/// Host-pointer calls of ONE context are serialised (its staging buffers and streams are one set), so every thread of the
-/// process gets a context of its own on first use: N threads then run N small calls on the GPU at the same time
-/// (`profiles/r02/concurrent_small_calls.log`: 16 threads, 175,000 `mul(s, None)` per second).  Options belong to a context.
-struct ThreadCtx(*mut kyb_ctx);
-impl ThreadCtx {
-    fn new() -> Self {
+/// The base-point table image, built ONCE per process (on the GPU, by a short-lived context) and kept on the host: every thread's
+/// context imports it (a 327 KiB copy and a checksum) instead of rebuilding it.
+fn table_image() -> &'static [u8] {
+    static IMAGE: OnceLock<Vec<u8>> = OnceLock::new();
+    IMAGE.get_or_init(|| {
+        unsafe {
+            assert_eq!(kyb_abi_version(), KYB_ABI_VERSION, "libkyber_ed25519_hip.so has another ABI version");
+        }
         let mut c: *mut kyb_ctx = std::ptr::null_mut();
         must(unsafe { kyb_ctx_create(device(), 1, &mut c) }, "kyb_ctx_create");
         must(unsafe { kyb_ctx_set_current(c) }, "kyb_ctx_set_current");
+        let mut img = vec![0u8; KYB_BASE_TABLE_BYTES];
+        must(unsafe { kyb_base_table_export(img.as_mut_ptr()) }, "kyb_base_table_export");
+        unsafe {
+            kyb_ctx_set_current(std::ptr::null_mut());
+            kyb_ctx_destroy(c);
+        }
+        img
+    })
+}
+
+/// Host-pointer calls of ONE context are serialised (its staging buffers and streams are one set), so every thread that touches a
+/// `Point` gets a context of its own on first use: N threads then run N small calls on the GPU at the same time
+/// (`profiles/r02/concurrent_small_calls.log`: 16 threads, 175,000 `mul(s, None)` per second; start the process with
+/// GPU_MAX_HW_QUEUES=16 for that — the library leaves the environment alone).  Options belong to a context.
+struct ThreadCtx(*mut kyb_ctx);
+impl ThreadCtx {
+    fn new() -> Self {
+        let img = table_image();
+        let mut c: *mut kyb_ctx = std::ptr::null_mut();
+        must(unsafe { kyb_ctx_create(device(), 0, &mut c) }, "kyb_ctx_create");
+        must(unsafe { kyb_ctx_set_current(c) }, "kyb_ctx_set_current");
+        must(unsafe { kyb_base_table_import(img.as_ptr()) }, "kyb_base_table_import");
         // a Point keeps extended coordinates, as the reference's does: take them projective (no inversion per multiplication;
         // marshal_binary pays it when an encoding is wanted)
         must(unsafe { kyb_set_option(b"ext.projective\0".as_ptr() as *const c_char, 1) }, "kyb_set_option(ext.projective)");
+        // A deployment that accepts it (include/kyber_ed25519.h, mul.short_scalars) lets every small host-pointer mul whose scalars are all
+        // below 2^64 take a short ladder: the Horner step `mul(x_i, Some(v))` of an unmodified PubPoly::eval then costs 29 us, not 158.
+        if std::env::var_os("KYBER_HIP_SHORT_PUBLIC_SCALARS").is_some() {
+            must(unsafe { kyb_set_option(b"mul.short_scalars\0".as_ptr() as *const c_char, 1) }, "kyb_set_option(mul.short_scalars)");
+        }
         ThreadCtx(c)
     }
 }
 impl Drop for ThreadCtx {
+    /// Runs at thread exit — for the main thread possibly while the process is already tearing the HIP runtime down: both calls
+    /// return an error code in that case and nothing here looks at it.
     fn drop(&mut self) {
         unsafe {
-            kyb_ctx_set_current(std::ptr::null_mut());
-            kyb_ctx_destroy(self.0);
+            let _ = kyb_ctx_set_current(std::ptr::null_mut());
+            let _ = kyb_ctx_destroy(self.0);
         }
     }
 }
@@ -97,15 +130,9 @@ thread_local! {
     static TL_CTX: ThreadCtx = ThreadCtx::new();
 }
 
-/// `kyb_init(KYBER_HIP_DEVICE or 0)` once per process and a context per thread; every trait method calls it first (cheap after the
-/// first time).
+/// A context for the calling thread on first use (table image built once per process, imported per thread); every method that
+/// reaches the engine calls it first (a thread-local access afterwards).  There is no process-wide default context.
 pub fn ensure_init() {
-    INIT.call_once(|| {
-        unsafe {
-            assert_eq!(kyb_abi_version(), KYB_ABI_VERSION, "libkyber_ed25519_hip.so has another ABI version");
-        }
-        must(unsafe { kyb_init(device()) }, "kyb_init");
-    });
     TL_CTX.with(|_| ());
 }
 

@@ -1,7 +1,15 @@
-//! `Point` of the HIP group: every method of `impl group::Point for Point` in
-//! src/group/edwards25519/point.rs:75-225 (and the marshaling / comparison / formatting impls around it), with the
-//! curve arithmetic forwarded to the engine as batch-of-1 calls.  Host-side logic (the `embed` rejection loop, `data`,
-//! `has_small_order`, `is_canonical`) is the reference's own, expression for expression.
+//! `Point` of the HIP group: the type behind `group::edwards25519::Point` when kyber-rs is built with the `hip` feature.
+//!
+//! Two kinds of methods, and only two:
+//!   * curve arithmetic — `mul`, `eq`, `marshal_binary`, `unmarshal_binary`, the batch helpers — is FORWARDED to the engine
+//!     (include/kyber_ed25519.h) as batch-of-1 or batch-of-n calls on the 160-byte `ext` record, which is the reference's
+//!     own limb layout;
+//!   * everything that is host logic in the reference — the `embed` / `pick` rejection loop, `data`, `has_small_order`,
+//!     `is_canonical`, the three formatters — is DELEGATED to the reference's own CPU `Point` (`CpuPoint` below, reached through
+//!     the 32-byte encoding).  This module carries no second copy of it.
+//! `add` / `sub` of a single pair call the reference's group-element formulas (`ge.rs`) on the same limbs: nine field
+//! multiplications are not worth a round trip to the GPU; vectors of pairs go to the engine (`add_batch`).
+//! Which reference method each one stands for: INTEGRATION.md §3.
 use core::fmt::{Debug, Display, Formatter, LowerHex, UpperHex};
 
 use serde::{Deserialize, Serialize};
@@ -11,8 +19,8 @@ use crate::{
     encoding::{BinaryMarshaler, BinaryUnmarshaler, Marshaling, MarshallingError},
     group::{
         self,
-        edwards25519::constants::{COFACTOR_SCALAR, PRIME_ORDER_SCALAR, WEAK_KEYS},
         edwards25519::ge::{CachedGroupElement, CompletedGroupElement, ExtendedGroupElement},
+        edwards25519::point::Point as CpuPoint,
         edwards25519::Scalar,
         internal::marshalling,
         PointCanCheckCanonicalAndSmallOrder, PointError,
@@ -23,31 +31,35 @@ use std::os::raw::c_int;
 
 use super::ffi::{self, ensure_init, must};
 
-/// 1 * B from the engine, asked for once per process
-fn base_ext() -> &'static [[i32; 10]; 4] {
-    static BASE_EXT: std::sync::OnceLock<[[i32; 10]; 4]> = std::sync::OnceLock::new();
+type Limbs = [[i32; 10]; 4];
+
+/// 1 * B as the engine hands it out, asked for once per process
+fn base_ext() -> &'static Limbs {
+    static BASE_EXT: std::sync::OnceLock<Limbs> = std::sync::OnceLock::new();
     BASE_EXT.get_or_init(|| {
         ensure_init();
         let mut one = [0u8; 32];
         one[0] = 1;
-        let mut b = [[0i32; 10]; 4];
+        let mut b: Limbs = [[0; 10]; 4];
         must(unsafe { ffi::kyb_mul_base_batch(one.as_ptr(), 1, std::ptr::null_mut(), b.as_mut_ptr() as *mut i32) }, "base");
         b
     })
 }
 
-const MARSHAL_POINT_ID: [u8; 8] = [b'e', b'd', b'.', b'p', b'o', b'i', b'n', b't'];
+fn invalid_point() -> MarshallingError {
+    MarshallingError::InvalidInput("invalid Ed25519 curve point".to_owned())
+}
 
-/// Same data as the reference's `Point { ge: ExtendedGroupElement, var_time: bool }` (point.rs:23-27):
-/// `ge` = X, Y, Z, T as 4 x [i32; 10] radix-2^25.5 limbs — the layout of the ABI's `ext` records.
+/// X, Y, Z, T as 4 x [i32; 10] radix-2^25.5 limbs — the ABI's `ext` record, which is also what the reference's `Point`
+/// keeps in its `ge` field (point.rs:23-27) — plus the reference's `var_time` flag (carried, never acted on: SURVEY.md §2).
 #[derive(Copy, Clone, Eq, Ord, PartialOrd, Debug, Serialize, Deserialize)]
 pub struct Point {
-    ge: [[i32; 10]; 4],
+    ge: Limbs,
     var_time: bool,
 }
 
 impl Default for Point {
-    /// `ExtendedGroupElement::default()` is all-zero limbs (ge.rs:78-83 derives Default); kept as is
+    /// all-zero limbs, like the derived default of the reference's element
     fn default() -> Self {
         Point { ge: [[0; 10]; 4], var_time: false }
     }
@@ -57,10 +69,8 @@ impl Point {
     pub fn new() -> Self {
         Self::default()
     }
-    /// the same limbs as the reference's element: the ABI's `ext` record IS X, Y, Z, T in fe_from_bytes' normal form (or the
-    /// tight limbs of a product), so the CPU formulas of ge.rs accept it as it is
-    fn to_ref(&self) -> ExtendedGroupElement {
-        ExtendedGroupElement { x: self.ge[0], y: self.ge[1], z: self.ge[2], t: self.ge[3] }
+    fn from_limbs(ge: Limbs) -> Self {
+        Point { ge, var_time: false }
     }
     fn ext(&self) -> *const i32 {
         self.ge.as_ptr() as *const i32
@@ -68,25 +78,70 @@ impl Point {
     fn ext_mut(&mut self) -> *mut i32 {
         self.ge.as_mut_ptr() as *mut i32
     }
-    /// `ExtendedGroupElement::write_bytes` (ge.rs:112-122)
-    fn write_bytes(&self, b: &mut [u8; 32]) {
-        ensure_init();
-        must(unsafe { ffi::kyb_encode_batch(self.ext(), 1, b.as_mut_ptr()) }, "encode");
+    /// the reference's element on the same limbs (no conversion: the layouts are one)
+    fn element(&self) -> ExtendedGroupElement {
+        let [x, y, z, t] = self.ge;
+        ExtendedGroupElement { x, y, z, t }
     }
-    /// `ExtendedGroupElement::set_bytes` (ge.rs:124-179): false iff the length is not 32 or no square root exists
-    fn set_bytes(&mut self, data: &[u8]) -> bool {
+
+    /// the 32 bytes of `marshal_binary`, from the engine (one field inversion on the GPU)
+    fn encoding(&self) -> [u8; 32] {
+        ensure_init();
+        let mut b = [0u8; 32];
+        must(unsafe { ffi::kyb_encode_batch(self.ext(), 1, b.as_mut_ptr()) }, "encode");
+        b
+    }
+    /// `unmarshal_binary` on the engine: None iff the bytes are not 32 or do not decode
+    fn decode(data: &[u8]) -> Option<Limbs> {
         if data.len() != 32 {
-            return false;
+            return None;
         }
         ensure_init();
-        let mut ok = 0u8;
-        let mut out = [[0i32; 10]; 4];
+        let (mut ok, mut out) = (0u8, [[0i32; 10]; 4]);
         must(unsafe { ffi::kyb_decode_batch(data.as_ptr(), 1, out.as_mut_ptr() as *mut i32, &mut ok) }, "decode");
-        if ok == 0 {
-            return false;
+        (ok != 0).then_some(out)
+    }
+
+    /// This point as the reference's CPU type, through the wire encoding: how the host-only methods are delegated.
+    fn to_cpu(&self) -> CpuPoint {
+        let mut q = CpuPoint::default();
+        q.unmarshal_binary(&self.encoding()).expect("an encoding produced by the engine decodes");
+        q
+    }
+    /// ... and back
+    fn from_cpu(q: &CpuPoint) -> Self {
+        let bytes = q.marshal_binary().expect("marshal_binary of the CPU point");
+        Self::from_limbs(Self::decode(&bytes).expect("an encoding produced by the reference decodes"))
+    }
+
+    /// p1 + p2 or p1 - p2 for ONE pair, by the reference's own element formulas on the CPU
+    fn pair_on_cpu(p1: &Self, p2: &Self, subtract: bool) -> Limbs {
+        let (mut cached, mut sum, mut out) = (CachedGroupElement::default(), CompletedGroupElement::default(), ExtendedGroupElement::default());
+        p2.element().write_cached(&mut cached);
+        if subtract {
+            sum.sub(&p1.element(), &cached);
+        } else {
+            sum.add(&p1.element(), &cached);
         }
-        self.ge = out;
-        true
+        sum.to_extended(&mut out);
+        [out.x, out.y, out.z, out.t]
+    }
+    fn pair_on_gpu(p1: &Self, p2: &Self, subtract: bool) -> Limbs {
+        ensure_init();
+        let mut out: Limbs = [[0; 10]; 4];
+        must(unsafe { ffi::kyb_add_batch(p1.ext(), p2.ext(), 1, out.as_mut_ptr() as *mut i32, subtract as c_int) }, "add");
+        out
+    }
+
+    /// `mul` for a multiplier the caller KNOWS to be public (a share index, the cofactor): the engine may then skip its leading
+    /// zero bits (`kyb_mul_public_batch`; 29 us instead of 158 for a 10-bit index).  Never for a secret.
+    pub fn mul_public(mut self, s: &Scalar, p: &Self) -> Self {
+        ensure_init();
+        must(
+            unsafe { ffi::kyb_mul_public_batch(s.v.as_ptr(), std::ptr::null(), p.ext(), 1, std::ptr::null_mut(), self.ext_mut(), std::ptr::null_mut()) },
+            "mul_public",
+        );
+        self
     }
 
     // ---- throughput entry points for callers that own a batch (PriPoly::commit, poly.rs:195-206) ----
@@ -111,7 +166,7 @@ impl Point {
                 )
             }
         }
-        staged.into_iter().map(|ge| Point { ge, var_time: false }).collect()
+        staged.into_iter().map(Point::from_limbs).collect()
     }
 
     /// 32-byte encodings of many points with one shared inversion per 8 (marshal_binary of each, point.rs:35-41)
@@ -134,7 +189,7 @@ impl Point {
             unsafe { ffi::kyb_add_batch(ia.as_ptr() as *const i32, ib.as_ptr() as *const i32, a.len(), staged.as_mut_ptr() as *mut i32, subtract as c_int) },
             "add_batch",
         );
-        staged.into_iter().map(|ge| Point { ge, var_time: false }).collect()
+        staged.into_iter().map(Point::from_limbs).collect()
     }
 
     /// a[i] == b[i] for many pairs without any inversion (Point::eq pays two per pair, point.rs:227-241)
@@ -185,9 +240,9 @@ pub fn eval_each_wire(commits_enc: &[u8], t: usize, idx: &[u32]) -> Result<Vec<P
         "pubpoly_eval_multi_enc",
     );
     if ok.iter().any(|&f| f == 0) {
-        return Err(MarshallingError::InvalidInput("invalid Ed25519 curve point".to_owned()));
+        return Err(invalid_point());
     }
-    Ok(staged.into_iter().map(|ge| Point { ge, var_time: false }).collect())
+    Ok(staged.into_iter().map(Point::from_limbs).collect())
 }
 
 /// The distributed public polynomial (dkg.rs:905-953 folds `PubPoly::add`, poly.rs:486-507, over the dealers) from the same
@@ -203,9 +258,9 @@ pub fn sum_polys_wire(commits_enc: &[u8], t: usize) -> Result<Vec<Point>, Marsha
         "sum_enc",
     );
     if ok.iter().any(|&f| f == 0) {
-        return Err(MarshallingError::InvalidInput("invalid Ed25519 curve point".to_owned()));
+        return Err(invalid_point());
     }
-    Ok(staged.into_iter().map(|ge| Point { ge, var_time: false }).collect())
+    Ok(staged.into_iter().map(Point::from_limbs).collect())
 }
 
 /// `schnorr::verify_with_checks` / `eddsa::verify_with_checks` for a batch (every DKG deal / response / DSS partial
@@ -235,30 +290,24 @@ pub fn verify_batch(pubs: &[[u8; 32]], msgs: &[&[u8]], sigs: &[[u8; 64]], eddsa_
 }
 
 impl BinaryMarshaler for Point {
-    // point.rs:35-41
     fn marshal_binary(&self) -> Result<Vec<u8>, MarshallingError> {
-        let mut b = [0_u8; 32];
-        self.write_bytes(&mut b);
-        Ok(b.to_vec())
+        Ok(self.encoding().to_vec())
     }
 }
 impl BinaryUnmarshaler for Point {
-    // point.rs:43-50
     fn unmarshal_binary(&mut self, data: &[u8]) -> Result<(), MarshallingError> {
-        if !self.set_bytes(data) {
-            return Err(MarshallingError::InvalidInput("invalid Ed25519 curve point".to_owned()));
-        }
+        self.ge = Self::decode(data).ok_or_else(invalid_point)?;
         Ok(())
     }
 }
 
 impl Marshaling for Point {
-    // point.rs:53-73
+    // the crate's generic point (un)marshalling helpers, as every group's Point uses them
     fn marshal_to(&self, w: &mut impl std::io::Write) -> Result<(), MarshallingError> {
         marshalling::point_marshal_to(self, w)
     }
     fn marshal_size(&self) -> usize {
-        32
+        CpuPoint::default().marshal_size()
     }
     fn unmarshal_from(&mut self, r: &mut impl std::io::Read) -> Result<(), MarshallingError> {
         marshalling::point_unmarshal_from(self, r)
@@ -267,165 +316,91 @@ impl Marshaling for Point {
         marshalling::point_unmarshal_from_random(self, r);
     }
     fn marshal_id(&self) -> [u8; 8] {
-        MARSHAL_POINT_ID
+        CpuPoint::default().marshal_id()
     }
 }
 
 impl group::Point for Point {
     type SCALAR = Scalar;
 
-    /// point.rs:79-82 — `ge.zero()`: (0 : 1 : 1 : 0)
-    fn null(mut self) -> Self {
-        self.ge = [[0; 10]; 4];
-        self.ge[1][0] = 1;
-        self.ge[2][0] = 1;
-        self
+    /// the neutral element (0 : 1 : 1 : 0)
+    fn null(self) -> Self {
+        let mut ge: Limbs = [[0; 10]; 4];
+        ge[1][0] = 1;
+        ge[2][0] = 1;
+        Point { ge, ..self }
     }
 
-    /// point.rs:85-88 — the reference copies the literal BASEEXT; here 1 * B from the engine, once per process (the same point; like BASEEXT not normalised to Z = 1 when ext.projective is on)
-    fn base(mut self) -> Self {
-        self.ge = *base_ext();
-        self
+    /// 1 * B from the engine (the reference copies a literal; the same point)
+    fn base(self) -> Self {
+        Point { ge: *base_ext(), ..self }
     }
 
-    /// point.rs:90-92
+    /// delegated: the reference's rejection loop on its CPU point, the accepted point brought over by its encoding
     fn pick<S: Stream>(self, rand: &mut S) -> Self {
-        self.embed(None, rand)
+        Self::from_cpu(&CpuPoint::default().pick(rand))
     }
 
-    /// point.rs:94-97
     fn set(&mut self, p: &Self) -> Self {
         self.ge = p.ge;
         *self
     }
 
-    /// point.rs:99-104
     fn embed_len(&self) -> usize {
-        (255 - 8 - 8) / 8
+        CpuPoint::default().embed_len()
     }
 
-    /// point.rs:106-167 — the rejection loop is host logic; decode, the cofactor / order multiplications and the
-    /// comparisons with the neutral element go to the engine.
-    fn embed<S: Stream>(mut self, data: Option<&[u8]>, rand: &mut S) -> Self {
-        let mut dl = self.embed_len();
-        let data_len = match data {
-            Some(d) => d.len(),
-            None => 0,
-        };
-        if dl > data_len {
-            dl = data_len;
-        }
-        let null_point = Point::default().null();
-        loop {
-            let mut b = [0_u8; 32];
-            rand.xor_key_stream(&mut b, &[0_u8; 32]).unwrap();
-            if let Some(d) = data {
-                b[0] = dl as u8;
-                b[1..1 + dl].copy_from_slice(&d[0..dl]);
-            }
-            if !self.set_bytes(&b) {
-                continue;
-            }
-            if data.is_none() {
-                let old_self = &self.clone();
-                self = self.mul(&COFACTOR_SCALAR, Some(old_self));
-                if self.eq(&null_point) {
-                    continue;
-                }
-                return self;
-            }
-            let mut q = Point::default();
-            q = q.mul(&PRIME_ORDER_SCALAR, Some(&self));
-            if q.eq(&null_point) {
-                return self;
-            }
-        }
+    /// delegated, as `pick`
+    fn embed<S: Stream>(self, data: Option<&[u8]>, rand: &mut S) -> Self {
+        Self::from_cpu(&CpuPoint::default().embed(data, rand))
     }
 
-    /// point.rs:169-177
+    /// delegated
     fn data(&self) -> Result<Vec<u8>, PointError> {
-        let mut b = [0u8; 32];
-        self.write_bytes(&mut b);
-        let dl = b[0] as usize;
-        if dl > self.embed_len() {
-            return Err(PointError::EmbedDataLength);
-        }
-        Ok(b[1..1 + dl].to_vec())
+        self.to_cpu().data()
     }
 
-    /// point.rs:179-188.  A single pair is added on the CPU with the reference's own formulas (ge.rs:99-110, 217-234, 292-297): nine field
-    /// multiplications take 0.3 us there, a batch-of-1 round trip to the GPU 26 us, and the ABI's ext record IS the reference's limb
-    /// layout, so nothing is converted.  Cargo feature `hip-single-add` sends it to the engine instead (`kyb_add_batch`, n = 1: the same
-    /// point); vectors go there in any case (`Point::add_batch`).
-    fn add(mut self, p1: &Self, p2: &Self) -> Self {
-        if cfg!(feature = "hip-single-add") {
-            ensure_init();
-            must(unsafe { ffi::kyb_add_batch(p1.ext(), p2.ext(), 1, self.ext_mut(), 0) }, "add");
-            return self;
-        }
-        let mut t2 = CachedGroupElement::default();
-        let mut r = CompletedGroupElement::default();
-        p2.to_ref().write_cached(&mut t2);
-        r.add(&p1.to_ref(), &t2);
-        let mut out = ExtendedGroupElement::default();
-        r.to_extended(&mut out);
-        self.ge = [out.x, out.y, out.z, out.t];
-        self
+    /// One pair: the reference's own formulas on the CPU (0.3 us; a batch-of-1 round trip to the GPU is 26 us).  Cargo feature
+    /// `hip-single-add` sends it to the engine instead (the same point); vectors go there in any case (`Point::add_batch`).
+    fn add(self, p1: &Self, p2: &Self) -> Self {
+        let ge = if cfg!(feature = "hip-single-add") { Self::pair_on_gpu(p1, p2, false) } else { Self::pair_on_cpu(p1, p2, false) };
+        Point { ge, ..self }
     }
 
-    /// point.rs:190-199, as `add`
-    fn sub(mut self, p1: &Self, p2: &Self) -> Self {
-        if cfg!(feature = "hip-single-add") {
-            ensure_init();
-            must(unsafe { ffi::kyb_add_batch(p1.ext(), p2.ext(), 1, self.ext_mut(), 1) }, "sub");
-            return self;
-        }
-        let mut t2 = CachedGroupElement::default();
-        let mut r = CompletedGroupElement::default();
-        p2.to_ref().write_cached(&mut t2);
-        r.sub(&p1.to_ref(), &t2);
-        let mut out = ExtendedGroupElement::default();
-        r.to_extended(&mut out);
-        self.ge = [out.x, out.y, out.z, out.t];
-        self
+    fn sub(self, p1: &Self, p2: &Self) -> Self {
+        let ge = if cfg!(feature = "hip-single-add") { Self::pair_on_gpu(p1, p2, true) } else { Self::pair_on_cpu(p1, p2, true) };
+        Point { ge, ..self }
     }
 
-    /// point.rs:201-204 — `ge.neg`: X and T negated limb by limb (ge.rs:86-91), no engine call
+    /// -(X : Y : Z : T) = (-X : Y : Z : -T), limb by limb; no engine call
     fn neg(&mut self, a: &Self) -> Self {
-        for i in 0..10 {
-            self.ge[0][i] = -a.ge[0][i];
-            self.ge[1][i] = a.ge[1][i];
-            self.ge[2][i] = a.ge[2][i];
-            self.ge[3][i] = -a.ge[3][i];
-        }
+        let flip = |f: &[i32; 10]| f.map(|limb| -limb);
+        self.ge = [flip(&a.ge[0]), a.ge[1], a.ge[2], flip(&a.ge[3])];
         *self
     }
 
-    /// point.rs:207-224 — None -> fixed base (ge_scalar_mult_base), Some(P) -> variable base (ge_scalar_mult; the
-    /// reference's var_time branch is unreachable).  The scalar is used as stored (`s.v`, no reduction).
+    /// None -> fixed base, Some(P) -> variable base; the scalar is used as stored (`s.v`, no reduction).
+    /// Every in-tree caller passes the generator as Some(base) (PriPoly::commit; vss): when the operand is, limb for limb, what
+    /// `base()` hands out and the scalar is below 2^255 (no top-digit quirk in either routine), the fixed-base kernel gives the
+    /// same point in a sixth of the time.
     fn mul(mut self, s: &Scalar, p: Option<&Self>) -> Self {
         ensure_init();
-        match p {
-            None => must(unsafe { ffi::kyb_mul_base_batch(s.v.as_ptr(), 1, std::ptr::null_mut(), self.ext_mut()) }, "mul(None)"),
-            // Every in-tree caller passes the generator as Some(base) (PriPoly::commit, poly.rs:195-206; vss.rs:303): when the operand is,
-            // limb for limb, what `base()` hands out and the scalar is below 2^255 (no top-digit quirk in either routine), the fixed-base
-            // kernel gives the same point in a sixth of the time.
-            Some(a_p) if a_p.ge == *base_ext() && s.v[31] & 0x80 == 0 => {
-                must(unsafe { ffi::kyb_mul_base_batch(s.v.as_ptr(), 1, std::ptr::null_mut(), self.ext_mut()) }, "mul(Some(base))")
-            }
-            Some(a_p) => must(
-                unsafe {
-                    ffi::kyb_mul_batch(s.v.as_ptr(), std::ptr::null(), a_p.ext(), 1, std::ptr::null_mut(), self.ext_mut(), std::ptr::null_mut())
-                },
-                "mul(Some)",
-            ),
-        }
+        let fixed = match p {
+            None => true,
+            Some(q) => q.ge == *base_ext() && s.v[31] & 0x80 == 0,
+        };
+        let rc = if fixed {
+            unsafe { ffi::kyb_mul_base_batch(s.v.as_ptr(), 1, std::ptr::null_mut(), self.ext_mut()) }
+        } else {
+            unsafe { ffi::kyb_mul_batch(s.v.as_ptr(), std::ptr::null(), p.unwrap().ext(), 1, std::ptr::null_mut(), self.ext_mut(), std::ptr::null_mut()) }
+        };
+        must(rc, "mul");
         self
     }
 }
 
 impl PartialEq for Point {
-    /// point.rs:227-241 compares the two encodings; the engine compares projectively (no inversion), same answer
+    /// the reference compares the two encodings (two inversions); the engine compares projectively, same answer
     fn eq(&self, p2: &Self) -> bool {
         ensure_init();
         let mut e = 0u8;
@@ -435,70 +410,34 @@ impl PartialEq for Point {
 }
 
 impl core::hash::Hash for Point {
-    // point.rs:243-249
     fn hash<H: std::hash::Hasher>(&self, state: &mut H) {
-        let mut b = [0_u8; 32];
-        self.write_bytes(&mut b);
-        b.hash(state);
+        self.encoding().hash(state);
     }
 }
 
+// formatting: delegated to the reference's own impls
 impl Display for Point {
     fn fmt(&self, f: &mut Formatter<'_>) -> core::fmt::Result {
-        write!(f, "Ed25519Point({self:#x})")
+        Display::fmt(&self.to_cpu(), f)
     }
 }
 impl LowerHex for Point {
     fn fmt(&self, f: &mut Formatter<'_>) -> core::fmt::Result {
-        let prefix = if f.alternate() { "0x" } else { "" };
-        let mut b = [0u8; 32];
-        self.write_bytes(&mut b);
-        write!(f, "{prefix}{}", hex::encode(b))
+        LowerHex::fmt(&self.to_cpu(), f)
     }
 }
 impl UpperHex for Point {
     fn fmt(&self, f: &mut Formatter<'_>) -> core::fmt::Result {
-        let prefix = if f.alternate() { "0X" } else { "" };
-        let mut b = [0u8; 32];
-        self.write_bytes(&mut b);
-        write!(f, "{prefix}{}", hex::encode_upper(b))
+        UpperHex::fmt(&self.to_cpu(), f)
     }
 }
 
+// the two checks of verify_with_checks: delegated (the batch entry point `verify_batch` runs them on the GPU for whole batches)
 impl PointCanCheckCanonicalAndSmallOrder for Point {
-    /// point.rs:286-313
     fn has_small_order(&self) -> bool {
-        let s = match self.marshal_binary() {
-            Ok(v) => v,
-            Err(_) => return false,
-        };
-        let mut c = [0u8; 5];
-        (0..31).for_each(|j| {
-            for i in 0..5 {
-                c[i] |= s[j] ^ WEAK_KEYS[i][j];
-            }
-        });
-        for i in 0..5 {
-            c[i] |= (s[31] & 0x7f) ^ WEAK_KEYS[i][31];
-        }
-        let mut k = 0;
-        (0..5).for_each(|i| {
-            k |= (c[i] as u16).wrapping_sub(1);
-        });
-        (k >> 8) & 1 > 0
+        self.to_cpu().has_small_order()
     }
-
-    /// point.rs:315-337, expression for expression (including its `0xED - (1 - b0)`; csrc/verify.h has the analysis)
     fn is_canonical(&self, b: &[u8]) -> bool {
-        if b.len() != 32 {
-            return false;
-        }
-        let mut c = (b[31] & 0x7f) ^ 0x7f;
-        for i in (1..=30).rev() {
-            c |= b[i] ^ 0xff;
-        }
-        c = ((c as u16).wrapping_sub(1) >> 8) as u8;
-        let d = ((0xEDu16.wrapping_sub(1u16.wrapping_sub(b[0] as u16))) >> 8) as u8;
-        1 - (c & d & 1) == 1
+        CpuPoint::default().is_canonical(b)
     }
 }
