@@ -357,7 +357,8 @@ const char* kyb_kernel_name(int kernel_id);
 /* Benchmark diagnostics (bench.py: the roofline is quoted against a peak and a clock measured in the same run; no product call
  * depends on them).
  *   kyb_diag_mad_peak: every SIMD of the context's GPU issues nothing but v_mad_u64_u32 (8 wavefronts per SIMD, eight independent
- *     accumulator chains each) for at least min_ms milliseconds.  *mads_per_s = 32x32+64 multiply-adds per second of the whole chip,
+ *     accumulator chains each) for at least min_ms milliseconds, once with the unused carry-out written to VCC (as the product kernels do)
+ *     and once to an SGPR pair (a few per cent faster in a pure stream); the FASTER run is reported.  *mads_per_s = 32x32+64 multiply-adds per second of the whole chip,
  *     *clock_ghz = the shader clock the chip held under that load (s_memtime / s_memrealtime), *simd_cycles_per_mad = SIMD cycles per
  *     wavefront-wide multiply-add (4.0 = one quarter-rate issue every 4 cycles), *kernel_ms = duration of the measured launch.  Any
  *     pointer may be NULL.  Synchronous.

@@ -150,8 +150,12 @@ struct tbl_lds32 {
 // case.  The top window (16 entries, digit always positive) has no negated copies.
 struct tbl_lds64 {
   const uint32_t* t;  // LDS
+  // The selection in two halves, so that a caller can put arithmetic between them:
+  //   rows():    this lane's own entry of the window (entry lane mod E, lanes 32..63 the negated one) — nine LDS reads whose addresses depend
+  //              on nothing but the window and the lane
+  //   permute(): the wanted entry pulled from the lane that holds it — thirty ds_bpermute_b32, in place
   template <int E, bool SIGNED>
-  __device__ __forceinline__ void fetch(ge_precomp& c, const uint32_t* win, uint32_t src_lane, bool once = false) {
+  __device__ __forceinline__ void rows(uint32_t own[30], const uint32_t* win, bool once = false) {
     uint32_t lane = threadIdx.x & 63u;
     if (once) asm volatile("" : "+v"(lane));     // a fetch outside the window loop: recompute the lane terms there instead of keeping them live across it
     const uint32_t mine = lane & (uint32_t)(E - 1);
@@ -160,7 +164,6 @@ struct tbl_lds64 {
     const uint32_t* pb = win + (s ? 0 : 8 * E);
     const uint32_t* qa = win + (s ? 18 * E : 16 * E);                  // plane a (ypx 8, 9) or b
     const uint32_t* qb = win + (s ? 16 * E : 18 * E);
-    uint32_t own[30], f[30];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const uint4 va = *reinterpret_cast<const uint4*>(pa + (q * E + mine) * 4);
@@ -174,18 +177,38 @@ struct tbl_lds64 {
     const uint2 wb = *reinterpret_cast<const uint2*>(qb + mine * 2);
     const uint2 wc = *reinterpret_cast<const uint2*>(win + 28 * E + mine * 2);
     own[8] = wa.x; own[9] = wa.y; own[18] = wb.x; own[19] = wb.y; own[28] = wc.x; own[29] = wc.y;
+  }
+  template <bool SIGNED>
+  __device__ __forceinline__ void permute(ge_precomp& c, uint32_t own[30], uint32_t src_lane) {
+    const uint32_t lane = threadIdx.x & 63u;
     if (SIGNED) {
       const uint32_t p2[10] = KYB_FE_2P;
-      const uint32_t m = 0u - s;
+      const uint32_t m = 0u - ((lane >> 5) & 1u);
 #pragma unroll
-      for (int i = 0; i < 10; ++i) own[20 + i] = (own[20 + i] ^ m) + (m & (p2[i] + 1u));        // s ? 2p - x : x
+      for (int i = 0; i < 10; ++i) own[20 + i] = (own[20 + i] ^ m) + (m & (p2[i] + 1u));        // this lane holds the negated entry ? 2p - x : x
     }
     const int src = (int)(((lane & ~63u) | src_lane) << 2);
+    uint32_t f[30];
 #pragma unroll
     for (int i = 0; i < 30; ++i) f[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own[i]);
 #pragma unroll
     for (int i = 0; i < 10; ++i) { c.ypx.v[i] = f[i]; c.ymx.v[i] = f[10 + i]; c.xy2d.v[i] = f[20 + i]; }
   }
+  template <int E, bool SIGNED>
+  __device__ __forceinline__ void fetch(ge_precomp& c, const uint32_t* win, uint32_t src_lane, bool once = false) {
+    uint32_t own[30];
+    rows<E, SIGNED>(own, win, once);
+    permute<SIGNED>(c, own, src_lane);
+  }
+  // split form for the pipelined loop of ge_scalarmult_base64 (pos < 42: signed digits; the top window: 16 entries, no negatives)
+  __device__ __forceinline__ void rows_of(uint32_t own[30], int pos) { rows<32, true>(own, t + pos * KYB_BASE64_WIN_WORDS); }
+  __device__ __forceinline__ void pick(ge_precomp& c, uint32_t own[30], uint32_t idx, uint32_t neg) { permute<true>(c, own, (neg << 5) | idx); }
+  __device__ __forceinline__ void rows_of_top(uint32_t own[30]) {
+    uint32_t top = KYB_BASE64_TOP_BASE;
+    asm volatile("" : "+v"(top));
+    rows<16, false>(own, t + top, true);
+  }
+  __device__ __forceinline__ void pick_top(ge_precomp& c, uint32_t own[30], uint32_t idx) { permute<false>(c, own, ((threadIdx.x & 63u) & 48u) | idx); }
   __device__ __forceinline__ void select(ge_precomp& c, int pos, uint32_t idx, uint32_t neg) {
     fetch<32, true>(c, t + pos * KYB_BASE64_WIN_WORDS, (neg << 5) | idx);
   }
@@ -199,6 +222,59 @@ struct tbl_lds64 {
     fetch<16, false>(c, t + top, (lane & 48u) | idx, true);
   }
 };
+
+// Fixed base, software-pipelined (kernels_base.hip): the SAME additions in the same order as ge_scalarmult_base64, with the table traffic
+// of window pos + 1 placed inside the arithmetic of window pos —
+//     A, B of the mixed addition   |  the lane's nine LDS row reads of window pos + 1 are issued here ...
+//     C and the sums               |  ... and land under this product;  then the thirty ds_bpermute of the selection are issued ...
+//     conversion p1p1 -> p3        |  ... and land under its four products
+// — instead of in front of the window's first product, where every wavefront of a SIMD used to wait for two dependent LDS round trips
+// at the same point of the loop.  Order of issue is pinned with scheduling barriers; the rows cost 30 more live registers during C.
+__device__ __forceinline__ void ge_scalarmult_base64_pipelined(ge_p3& h, const uint32_t a[8], tbl_lds64& tbl) {
+  sc_digits64 dg;
+  sc_recode64(dg, a);
+  ge_p3_0(h);
+  ge_precomp c;
+  {
+    uint32_t mag, neg;
+    sc_next_digit64(mag, neg, dg, false);
+    tbl.select(c, 0, mag, neg);
+  }
+#pragma unroll 1
+  for (int pos = 1; pos < KYB_BASE64_POS - 1; ++pos) {
+    fe A, B;
+    ge_p1p1 t;
+    uint32_t own[30], mag, neg;
+    ge_madd_lazy_t_ab(A, B, h, c);                // window pos - 1 ...
+    __builtin_amdgcn_sched_barrier(0);
+    tbl.rows_of(own, pos);
+    __builtin_amdgcn_sched_barrier(0);
+    ge_madd_lazy_t_c(t, A, B, h, c);              // ... its last product hides the row reads
+    sc_next_digit64(mag, neg, dg, false);
+    __builtin_amdgcn_sched_barrier(0);
+    tbl.pick(c, own, mag, neg);
+    __builtin_amdgcn_sched_barrier(0);
+    ge_p1p1_to_p3_lazy_t(h, t);                   // ... and the conversion hides the selection
+  }
+  {
+    fe A, B;
+    ge_p1p1 t;
+    uint32_t own[30], mag, neg;
+    ge_madd_lazy_t_ab(A, B, h, c);                // window 41
+    tbl.rows_of_top(own);
+    ge_madd_lazy_t_c(t, A, B, h, c);
+    sc_next_digit64(mag, neg, dg, true);
+    tbl.pick_top(c, own, mag);
+    ge_p1p1_to_p3_lazy_t(h, t);
+    ge_madd_lazy_t(t, h, c);                      // top window
+    ge_p1p1_to_p3_lazy_t(h, t);
+  }
+  fe nx, nt;
+  fe_neg(nx, h.X); fe_reduce_weak(nx, nx);
+  fe_neg(nt, h.T); fe_reduce_weak(nt, nt);
+  fe_cmov(h.X, nx, dg.neg);
+  fe_cmov(h.T, nt, dg.neg);
+}
 
 // ------------------------------------------------------------------------------------------------
 // load / store helpers (16-byte vector accesses; batches are arrays of 32- or 160-byte records)

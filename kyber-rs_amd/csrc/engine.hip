@@ -951,8 +951,9 @@ int launch_base(Ctx& g, bool split, const uint8_t* sc, size_t n, uint8_t* oenc, 
     // one workgroup per CU (the table is its whole LDS); 256-thread workgroups while that leaves CUs idle
     const uint4* img64 = reinterpret_cast<const uint4*>(g.table + KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS);
     const bool small = n <= (size_t)256 * (size_t)g.cus * (size_t)g.opt_base_small_chunks;
-    const int block = small ? 256 : (g.opt_base_block64 == 512 ? 512 : 1024);
-    const size_t nchunks64 = (n + block - 1) / block;
+    const int b64 = g.opt_base_block64;
+    const int block = small ? 256 : ((b64 == 512 || b64 == 768) ? b64 : 1024);
+    const size_t nchunks64 = (n + block - 1) / block;                   // workgroups' worth of items (the kernel deals them out per wavefront)
     const int grid64 = (int)(nchunks64 < (size_t)g.cus ? nchunks64 : (size_t)g.cus);
     ProfScope ps(g, st, KID_MUL_BASE);
     LAUNCHCK(launch::mul_base64(split, block, grid64, st, sc, sc_b, n_a, n, oenc, oext, img64, r->proj, r->proj_items, offset));

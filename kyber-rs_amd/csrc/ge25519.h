@@ -144,6 +144,23 @@ KYB_HD void ge_madd_lazy_t(ge_p1p1& r, const ge_p3& p, const ge_precomp& q) {
   fe_addw(r.Z, D, C);            // 3T
   fe_subw(r.T, D, C);            // 4T
 }
+// the same mixed addition in two halves (A, B first; then C and the sums) for callers that start the next window's table reads in between
+KYB_HD void ge_madd_lazy_t_ab(fe& A, fe& B, const ge_p3& p, const ge_precomp& q) {
+  fe a, b;
+  fe_addw(a, p.Y, p.X);
+  fe_subw(b, p.Y, p.X);
+  fe_mul_b6(A, a, q.ypx);
+  fe_mul_b6(B, b, q.ymx);
+}
+KYB_HD void ge_madd_lazy_t_c(ge_p1p1& r, const fe& A, const fe& B, const ge_p3& p, const ge_precomp& q) {
+  fe C, D;
+  fe_mul_b6(C, q.xy2d, p.T);
+  fe_addw(D, p.Z, p.Z);
+  fe_subw(r.X, A, B);
+  fe_addw(r.Y, A, B);
+  fe_addw(r.Z, D, C);
+  fe_subw(r.T, D, C);
+}
 KYB_HD void ge_p1p1_to_p3_lazy_t(ge_p3& r, const ge_p1p1& p) {
   fe_mul(r.X, p.T, p.X);        // 4T x 3T: general fold
   fe_mul_b6(r.Y, p.Z, p.Y);     // 3T x 2T

@@ -353,6 +353,8 @@ KYB_HD void sc_next_digit64(uint32_t& idx, uint32_t& neg, sc_digits64& d, bool t
 }
 // Tbl: void select(ge_precomp& c, int pos, uint32_t idx, uint32_t neg) for pos < 42: entry idx in 0..31, negated when neg
 //      void select_top(ge_precomp& c, uint32_t idx) for the top window (idx in 0..15, never negative)
+// (One loop for all 43 windows, the top window's 16-entry selection behind a uniform branch: with the top window peeled off behind the
+// loop, as it was, the 1024-thread kernel of this round needs 12 bytes of scratch; this form needs none — tests/test_build_resources.py.)
 template <class Tbl>
 KYB_HD void ge_scalarmult_base64(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
   sc_digits64 dg;
@@ -361,20 +363,11 @@ KYB_HD void ge_scalarmult_base64(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
 #if defined(__HIPCC__)
 #pragma unroll 1
 #endif
-  for (int pos = 0; pos < KYB_BASE64_POS - 1; ++pos) {
+  for (int pos = 0; pos < KYB_BASE64_POS; ++pos) {
     uint32_t mag, neg;
-    sc_next_digit64(mag, neg, dg, false);
+    sc_next_digit64(mag, neg, dg, pos == KYB_BASE64_POS - 1);
     ge_precomp c;
-    tbl.select(c, pos, mag, neg);
-    ge_p1p1 t;
-    ge_madd_lazy_t(t, h, c);
-    ge_p1p1_to_p3_lazy_t(h, t);
-  }
-  {
-    uint32_t mag, neg;
-    sc_next_digit64(mag, neg, dg, true);
-    ge_precomp c;
-    tbl.select_top(c, mag);
+    if (pos < KYB_BASE64_POS - 1) tbl.select(c, pos, mag, neg); else tbl.select_top(c, mag);
     ge_p1p1 t;
     ge_madd_lazy_t(t, h, c);
     ge_p1p1_to_p3_lazy_t(h, t);

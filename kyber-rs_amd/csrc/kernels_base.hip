@@ -27,12 +27,16 @@ __global__ void __launch_bounds__(64) k_base_table64(uint32_t* image) {
 }
 
 // Fixed base, signed radix 64: one workgroup per CU owns the whole LDS (163,200 B table); 43 mixed additions
-// per item.  BLOCK = 1024 (4 waves/SIMD) when the batch fills the chip, 256 (1 wave/SIMD, four times as many
-// CUs busy) for batches that do not.
+// per item.  BLOCK = 1024 / 768 / 512 (4 / 3 / 2 waves per SIMD; the register budget is 128 / 168 / 256 VGPRs) when the batch fills
+// the chip, 256 (1 wave/SIMD, four times as many CUs busy) for batches that do not.
+// Work is dealt out per WAVEFRONT in chunks of 64 items — chunk (round, wave, workgroup) = round * waves_in_grid + wave * gridDim.x +
+// blockIdx.x — not per workgroup: a batch that is not a whole number of rounds leaves its last chunks with the LOW wave numbers of
+// every workgroup, i.e. spread evenly over all CUs and over the four SIMDs of each (2^20 items on 256 CUs x 12 waves: 16 chunks per
+// SIMD, as 6 + 5 + 5; dealt per workgroup the same batch would leave a third of the CUs with a round more than the others).
 // Two scalar arrays may be multiplied in one launch (signing: the nonces and the private keys): items
 // [0, n_a) come from `scalars`, items [n_a, n) from `scalars_b`.
 template <bool SPLIT, int BLOCK>
-__global__ void __launch_bounds__(BLOCK, BLOCK / 256)
+__global__ void __launch_bounds__(BLOCK, (BLOCK + 255) / 256)
 k_mul_base64(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ scalars_b, size_t n_a, size_t n,
              uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
              const uint4* __restrict__ table_image, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
@@ -42,25 +46,33 @@ k_mul_base64(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ sc
   for (int k = threadIdx.x; k < KYB_BASE64_TABLE_WORDS / 4; k += BLOCK) lds_tbl[k] = table_image[k];
   __syncthreads();
   tbl_lds64 tbl{reinterpret_cast<const uint32_t*>(lds_tbl)};
-  const size_t nchunks = (n + BLOCK - 1) / BLOCK;
+  const size_t nchunks = (n + 63) / 64;
+  const size_t per_round = (size_t)gridDim.x * (BLOCK / 64);
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform, and the compiler knows it
   // Addressing: everything the 43-window loop does not need stays out of VGPRs across it.  The chunk's first item i0 is
   // wave-uniform, so record addresses are (uniform base in SGPRs) + (32-bit lane offset), not 64-bit per-lane pointers
   // (which the compiler hoists out of the chunk loop as invariants and then has to spill in the 128-register build).
-  for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-    const size_t i0 = chunk * BLOCK;
-    const uint32_t cnt = (uint32_t)((n - i0 < (size_t)BLOCK) ? n - i0 : (size_t)BLOCK);       // items of this chunk (>= 1)
-    const bool live = threadIdx.x < cnt;
-    const uint32_t t = live ? threadIdx.x : 0u;                                                  // dead lanes redo the chunk's first item
+  for (size_t chunk = (size_t)wave * gridDim.x + blockIdx.x; chunk < nchunks; chunk += per_round) {
+    const size_t i0 = chunk * 64;
+    const uint32_t cnt = (uint32_t)((n - i0 < (size_t)64) ? n - i0 : (size_t)64);             // items of this chunk (>= 1)
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool live = lane < cnt;
+    const uint32_t t = live ? lane : 0u;                                                        // dead lanes redo the chunk's first item
     uint32_t a[8];
-    if (scalars_b == nullptr || i0 + BLOCK <= n_a) load_words8(a, scalars + 32 * i0, t);       // the usual case: one array (uniform branch)
+    if (scalars_b == nullptr || i0 + 64 <= n_a) load_words8(a, scalars + 32 * i0, t);          // the usual case: one array (uniform branch)
     else if (i0 >= n_a) load_words8(a, scalars_b + 32 * (i0 - n_a), t);
     else if (i0 + t < n_a) load_words8(a, scalars + 32 * i0, t);                               // the one chunk that straddles the two arrays
     else load_words8(a, scalars_b, (size_t)(i0 + t - n_a));
     ge_p3 h;
+#if !defined(KYB_BASE64_PIPELINE_768)      // the pipelined form is an A/B leftover (profiles/r03/ab_base_pipeline.log: no gain)
     ge_scalarmult_base64(h, a, tbl);
-    uint32_t tl = threadIdx.x;
+#else
+    if (BLOCK == 768) ge_scalarmult_base64_pipelined(h, a, tbl);      // 168 registers: room for the next window's rows under the current one's arithmetic
+    else ge_scalarmult_base64(h, a, tbl);
+#endif
+    uint32_t tl = threadIdx.x & 63u;
     asm volatile("" : "+v"(tl));         // the lane's store address is formed here, after the loop (not hoisted out of the chunk loop and spilled)
-    if (SPLIT) { if (live) store_proj(proj + (proj_offset + i0), proj_stride, tl, h.X, h.Y, h.Z); }
+    if (SPLIT) { if (tl < cnt) store_proj(proj + (proj_offset + i0), proj_stride, tl, h.X, h.Y, h.Z); }
     else finish_point(h.X, h.Y, h.Z, out_enc ? out_enc + 32 * i0 : nullptr, out_ext ? out_ext + 40 * i0 : nullptr, t, live);
   }
   KYB_STAMP_END();
@@ -105,8 +117,8 @@ hipError_t table_checksum(const uint32_t* table, uint64_t* out_dev, hipStream_t 
 hipError_t mul_base64(bool split, int block, int grid, hipStream_t st, const uint8_t* sc, const uint8_t* sc_b, size_t n_a, size_t n,
                       uint8_t* oenc, int32_t* oext, const uint4* img64, uint4* proj, size_t stride, size_t offset) {
 #define KYB_L(S_, B_) hipLaunchKernelGGL((k_mul_base64<S_, B_>), dim3(grid), dim3(B_), 0, st, sc, sc_b, n_a, n, oenc, oext, img64, proj, stride, offset)
-  if (split) { if (block == 256) KYB_L(true, 256); else if (block == 512) KYB_L(true, 512); else KYB_L(true, 1024); }
-  else       { if (block == 256) KYB_L(false, 256); else if (block == 512) KYB_L(false, 512); else KYB_L(false, 1024); }
+  if (split) { if (block == 256) KYB_L(true, 256); else if (block == 512) KYB_L(true, 512); else if (block == 768) KYB_L(true, 768); else KYB_L(true, 1024); }
+  else       { if (block == 256) KYB_L(false, 256); else if (block == 512) KYB_L(false, 512); else if (block == 768) KYB_L(false, 768); else KYB_L(false, 1024); }
 #undef KYB_L
   return hipGetLastError();
 }

@@ -212,6 +212,9 @@ k_decode(const uint8_t* __restrict__ enc, size_t n, int32_t* __restrict__ out_ex
 // quarter-rate instruction is never waiting on a result — and stamps its own lifetime (diag_stamp.h).  Two 1024-thread
 // workgroups per CU = 8 wavefronts per SIMD.
 constexpr int MAD_PEAK_CHAINS = launch::MAD_PEAK_CHAINS_HOST, MAD_PEAK_UNROLL = launch::MAD_PEAK_UNROLL_HOST;
+// SGPR_CARRY: the (unused) carry-out goes to an SGPR pair instead of VCC — in a pure stream that form issues a few per cent faster; the
+// roofline takes the faster of the two, whichever the product kernels use.
+template <bool SGPR_CARRY>
 __global__ void __launch_bounds__(1024)
 k_diag_mad_peak(int iters, uint64_t* stamps, uint32_t* __restrict__ sink) {
   uint64_t acc[MAD_PEAK_CHAINS];
@@ -223,7 +226,10 @@ k_diag_mad_peak(int iters, uint64_t* stamps, uint32_t* __restrict__ sink) {
 #pragma unroll
     for (int u = 0; u < MAD_PEAK_UNROLL; ++u) {
 #pragma unroll
-      for (int c = 0; c < MAD_PEAK_CHAINS; ++c) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[c]) : "v"(a), "v"(b) : "vcc");
+      for (int c = 0; c < MAD_PEAK_CHAINS; ++c) {
+        if (SGPR_CARRY) { uint64_t cy; asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc[c]), "=&s"(cy) : "v"(a), "v"(b)); }
+        else asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[c]) : "v"(a), "v"(b) : "vcc");
+      }
     }
   }
   WaveClock::stamp(stamps, 1);
@@ -234,8 +240,9 @@ k_diag_mad_peak(int iters, uint64_t* stamps, uint32_t* __restrict__ sink) {
 }
 
 namespace kyb { namespace launch {
-hipError_t diag_mad_peak(hipStream_t st, int grid, int iters, uint64_t* stamps, uint32_t* sink) {
-  hipLaunchKernelGGL(k_diag_mad_peak, dim3(grid), dim3(1024), 0, st, iters, stamps, sink);
+hipError_t diag_mad_peak(hipStream_t st, int grid, int iters, uint64_t* stamps, uint32_t* sink, bool sgpr_carry) {
+  if (sgpr_carry) hipLaunchKernelGGL((k_diag_mad_peak<true>), dim3(grid), dim3(1024), 0, st, iters, stamps, sink);
+  else            hipLaunchKernelGGL((k_diag_mad_peak<false>), dim3(grid), dim3(1024), 0, st, iters, stamps, sink);
   return hipGetLastError();
 }
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK); }

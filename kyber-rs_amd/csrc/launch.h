@@ -120,7 +120,7 @@ hipError_t diag_stamps_ladder(uint64_t* buf);
 hipError_t diag_stamps_base(uint64_t* buf);
 // benchmark diagnostic (kyb_diag_mad_peak): `grid` workgroups of 1024 threads issue nothing but v_mad_u64_u32, iters x 32 per wavefront;
 // stamps[0..4] = the sums of diag_stamp.h
-hipError_t diag_mad_peak(hipStream_t st, int grid, int iters, uint64_t* stamps, uint32_t* sink);
+hipError_t diag_mad_peak(hipStream_t st, int grid, int iters, uint64_t* stamps, uint32_t* sink, bool sgpr_carry);
 constexpr int MAD_PEAK_CHAINS_HOST = 8, MAD_PEAK_UNROLL_HOST = 4;      // = the kernel's chains x unroll (kernels_misc.hip)
 
 // segs lanes per evaluation (len coefficients each): partial results as extended limbs in part_ext[n * segs], multipliers in part_sc

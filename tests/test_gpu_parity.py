@@ -988,3 +988,27 @@ def test_ladder_skips_the_leading_zeros_only_when_every_scalar_is_canonical(engi
     got = engine.lincomb(lam, pts_ext=pp)
     for g in (0, 99, 199):
         assert bytes(got[g]) == oracle.lincomb(lam[g], pp[g])
+
+
+@pytest.mark.parametrize("block64", [512, 768, 1024])
+def test_fixed_base_workgroup_sizes_and_wave_chunks(engine, oracle, block64):
+    """k_mul_base64 deals its items out per wavefront (chunks of 64, low wave numbers take the leftovers): every workgroup size gives the
+    oracle's bytes on batches that end inside a chunk, inside a workgroup round and on a round boundary, and when signing puts two scalar
+    arrays into one launch (the chunk that straddles them)."""
+    cus = engine.device_info()["compute_units"]
+    old = (engine.get_option("mul_base.block64"), engine.get_option("mul_base.small_chunks"), engine.get_option("coop.base_max_items"))
+    engine.set_option("mul_base.block64", block64)
+    engine.set_option("mul_base.small_chunks", 0)        # always the full-size workgroups, however small the batch
+    engine.set_option("coop.base_max_items", 0)
+    try:
+        for n in (1, 63, 64, 65, block64 - 1, block64 + 1, 2 * block64 + 77, cus * block64 + 64 * 5 + 3, 300001):
+            s = np.concatenate([synth.scalars(n - n // 3, 900 + n), synth.raw256(n // 3, 900 + n)])
+            assert np.array_equal(engine.mul_base(s), oracle.mul_base_batch(s, nthreads=16)), (block64, n)
+        for n in (1, 31, 97, 1000, 5003):                  # signing: k*B and x*B in one launch of 2n items
+            x, k = synth.scalars(n, 910 + n, b"x"), synth.scalars(n, 911 + n, b"k")
+            msgs = synth.messages(n, 912, length=9)
+            assert np.array_equal(engine.schnorr_sign(x, k, msgs), oracle.schnorr_sign_batch(x, k, msgs, nthreads=16)), (block64, n)
+    finally:
+        engine.set_option("mul_base.block64", old[0])
+        engine.set_option("mul_base.small_chunks", old[1])
+        engine.set_option("coop.base_max_items", old[2])

@@ -30,16 +30,20 @@ def main():
     body = m.group(2)
     meta = re.search(r"\.amdhsa_next_free_vgpr (\d+)", txt[m.end():m.end() + 4000])
     scratch = re.search(r"; ScratchSize: (\d+)", txt[m.start():m.end() + 6000])
-    blocks = re.split(r"\n(?=\.LBB\d+_\d+:)", body)
-    def self_loop(b):
-        lab = re.match(r"\s*(\.LBB\d+_\d+):", b)
-        return bool(lab) and re.search(r"s_cbranch_\w+ " + re.escape(lab.group(1)) + r"\b", b) is not None
-    def cut(b):      # a self-looping block ends at its backward branch (what follows is the fall-through code up to the next label)
-        lab = re.match(r"\s*(\.LBB\d+_\d+):", b).group(1)
-        m_ = re.search(r"s_cbranch_\w+ " + re.escape(lab) + r"\b.*", b)
-        return b[:m_.end()]
-    loops = [cut(b) for b in blocks if self_loop(b)] or blocks
-    best = max(loops, key=lambda b: b.count("v_mad_u64_u32") + b.count("v_mad_i64_i32"))
+    # loops = regions from a label to a LATER branch back to it; among those with the most multiply-adds per pass take the smallest
+    # (the innermost loop around the arithmetic: a loop body may span several basic blocks, e.g. a uniform branch inside it)
+    lines = body.split("\n")
+    label_at = {m_.group(1): i for i, ln in enumerate(lines) for m_ in [re.match(r"\s*(\.LBB\d+_\d+):", ln)] if m_}
+    regions = []
+    for i, ln in enumerate(lines):
+        m_ = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)\b", ln)
+        if m_ and m_.group(1) in label_at and label_at[m_.group(1)] <= i:
+            regions.append("\n".join(lines[label_at[m_.group(1)]:i + 1]))
+    regions = regions or [body]
+    most = max(r.count("v_mad_u64_u32") + r.count("v_mad_i64_i32") for r in regions)
+    inner = [r for r in regions if r.count("v_mad_u64_u32") + r.count("v_mad_i64_i32") >= 0.9 * most]
+    # an outer loop around the arithmetic loop carries the same multiply-adds: the inner one is the shortest of them
+    best = min(inner, key=len)
     hist = collections.Counter()
     for ln in best.split("\n"):
         ln = ln.strip()
