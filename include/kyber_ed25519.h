@@ -341,8 +341,8 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *                     split the Horner chain, 2..32)
  *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder
  *   verify.by_encoding 1 (default): large batches test the equation as enc(s*B - h*A) == R bytes and decode R only on a mismatch
- *   host.pipe_chunks  host-pointer batches of 2^16 items or more are cut into this many chunks (default 8, 2..64) that alternate
- *                     between two streams so that copies and kernels overlap
+ *   host.pipe_chunks  host-pointer batches of 2^16 items or more are pipelined (one copy-in lane, two compute lanes, one copy-out lane)
+ *                     over chunks of 1 1 2 4 4 2 2 .. units; the unit is 1/value of the batch (default 16, 2..64)
  *   host.copy_threads host threads that move pageable batches through the bounce buffers (0 = auto)
  * Options belong to the calling thread's context. */
 int kyb_set_option(const char* key, int value);

@@ -8,7 +8,8 @@
 //   * contexts: one per (process, device) by default (kyb_init), any number through kyb_ctx_create — each with its own
 //     streams, per-stream scratch, staging buffers, table image, options and profiling state;
 //   * the launch sequences (which kernels a batch call runs, in which scratch);
-//   * the host-pointer pipeline (chunked two-stream H2D / kernels / D2H with page-locked bounce buffers);
+//   * the host-pointer pipeline (large batches: one copy-in lane, two compute lanes, one copy-out lane over chunks that ramp up and down;
+//     pageable caller memory through a page-locked bounce ring filled by copy threads);
 //   * multi-device groups: one context and one host thread per GPU, shards [rN/G, (r+1)N/G), the table image moved
 //     with ncclBroadcast (librccl, loaded on demand) — engine_group.inc;
 //   * the extern "C" entry points of include/kyber_ed25519.h — c_abi.inc.
@@ -69,14 +70,18 @@ struct StreamRes {
 };
 constexpr size_t MAX_STREAM_SLOTS = 32;
 
-constexpr int PIPE_CHUNKS_DEFAULT = 8;
+constexpr int PIPE_CHUNKS_DEFAULT = 16;     // the first chunk of a pipelined host-pointer batch is 1/16 of it
 struct Ctx {
   bool ready = false;
   int device = -1;
   int cus = 0;
   char name[128] = {0};
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;   // second lane of the pipelined host-pointer path
+  hipStream_t stream2 = nullptr;   // second compute lane of the pipelined host-pointer path (consecutive chunks alternate: the small kernels of one overlap the ladder of the other)
+  hipStream_t stream_in = nullptr, stream_out = nullptr;      // ... its copy lanes: host -> device, device -> host (two DMA engines, full duplex), made on first use
+  std::vector<hipEvent_t> pipe_ev;                            // ... and its events (input arrived / kernels done / output left, per chunk)
+  hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};   // bounce ring of the pageable input path: a slot's last copy to the device
+  uint8_t* pin_out = nullptr; size_t pin_out_bytes = 0;       // page-locked landing area for the outputs of a pageable caller
   uint32_t* table = nullptr;       // KYB_BASE_TABLE_BYTES: radix-16 image (65,536 B), radix-32 image (106,496 B), radix-64 image (163,200 B)
   uint64_t* ck_dev = nullptr;      // 8 bytes: checksum of an imported table image
   std::atomic<bool> table_ready{false};
@@ -86,8 +91,6 @@ struct Ctx {
   std::atomic<int> grid_mul{0};
   uint8_t* stage = nullptr;       // device staging for the host-pointer API
   size_t stage_bytes = 0;
-  uint8_t* stage2 = nullptr;      // staging of the second pipeline lane
-  size_t stage2_bytes = 0;
   uint32_t* done_flag = nullptr;          // coherent page-locked word the last kernel of a small host-pointer call writes (launch.h, DoneFlag)
   uint32_t* done_counter = nullptr;       // device word: finished items of that kernel
   uint32_t done_seq = 0;                  // under mu
@@ -109,7 +112,7 @@ struct Ctx {
   std::atomic<int> opt_finish{1};             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
   std::atomic<int> opt_finish_min{1};         // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size; cross-check)
   std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
-  std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: chunks that alternate between the two lanes
+  std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: the chunk unit is 1/this of the batch (plan_chunks)
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
   std::atomic<int> opt_ladder_skip_canonical{1};  // the batch ladder skips the four leading bits when no scalar of the launch has one set (canonical scalars)
   std::atomic<int> opt_mul_short_scalars{0};     // 1: EVERY host-pointer kyb_mul_batch of <= 64 items is treated like kyb_mul_public_batch (multipliers declared public:
@@ -189,15 +192,6 @@ int ensure_stage(Ctx& g, size_t bytes) {
   g.stage_bytes = want;
   return KYB_OK;
 }
-int ensure_stage2(Ctx& g, size_t bytes) {
-  if (bytes <= g.stage2_bytes) return KYB_OK;
-  if (g.stage2) { wipe_free_dev(g.stage2, g.stage2_bytes); g.stage2 = nullptr; g.stage2_bytes = 0; }
-  size_t want = bytes + (bytes >> 2) + 4096;
-  hipError_t e = hipMalloc(&g.stage2, want);
-  if (e != hipSuccess) return fail(KYB_E_NOMEM, "staging allocation", e);
-  g.stage2_bytes = want;
-  return KYB_OK;
-}
 int ensure_pin(Ctx& g, int lane, size_t bytes) {
   if (bytes <= g.pin_bytes[lane]) return KYB_OK;
   if (g.pin[lane]) { memset(g.pin[lane], 0, g.pin_bytes[lane]); HIPCK(hipHostFree(g.pin[lane])); g.pin[lane] = nullptr; g.pin_bytes[lane] = 0; }
@@ -270,12 +264,11 @@ struct DoneScope {          // posts / withdraws the request around the launch s
   ~DoneScope() { tl_done = nullptr; }
 };
 
-// Host-pointer batches of fixed-size records: the batch is cut into chunks that alternate between two
-// streams (each with its own staging and scratch) so that the H2D copy of chunk c+1 and the D2H copy
-// of chunk c-1 overlap the kernels of chunk c.  Page-locked caller buffers (kyb_host_alloc) are handed to
-// the DMA engines as they are.  Pageable ones would make every hipMemcpyAsync a blocking, single-threaded
-// staging copy inside the runtime (~7 GB/s); they go through the context's own page-locked bounce buffers
-// instead, filled and drained by CopyPool threads while the GPU works on the neighbouring chunk.
+// Host-pointer batches of fixed-size records (run_host_batch): up to 512 KiB the kernels work on page-locked host memory directly;
+// up to 2^16 items the arrays are copied in, processed and copied out on the engine stream; beyond that the batch is pipelined
+// over copy lanes and compute lanes (run_host_batch_pipelined).  Page-locked caller buffers (kyb_host_alloc) are handed to the DMA
+// engines as they are.  Pageable ones would make every hipMemcpyAsync a blocking, single-threaded staging copy inside the runtime
+// (~7 GB/s); they go through the context's own page-locked bounce ring instead, filled by CopyPool threads while the GPU works.
 // One host-pointer call at a time per CONTEXT (g.mu); callers that want several in flight use several contexts.
 struct HostArr { const void* in; void* out; size_t bytes; bool secret = false; };    // per-item size; exactly one of in/out, or neither = absent;
                                                                                      // secret: private keys / nonces / DH secrets — every copy the engine made is cleared before the call returns
@@ -284,14 +277,160 @@ template <class F> ScopeExit<F> on_scope_exit(F f) { return ScopeExit<F>{f}; }
 constexpr size_t PIPE_MIN_ITEMS = (size_t)1 << 16;
 constexpr size_t ZERO_COPY_BYTES = (size_t)1 << 19;      // host-pointer calls up to this size skip the copies: kernels work on page-locked host memory
 
+// ---- large host-pointer batches: copy lanes and compute lanes ------------------------------------------------------
+// The whole batch gets device staging of its own (a 2^20-item variable-base batch: 235 MB of 288 GB), so nothing waits for a
+// staging buffer to come free:
+//   stream_in    every chunk's operands, back to back (page-locked caller memory: DMA straight from it; pageable: CopyPool threads
+//                fill a ring of four 4 MiB page-locked slots that the DMA engine drains behind them)
+//   stream/2     the chunk's kernels as soon as its operands have arrived (event), consecutive chunks on alternating streams
+//   stream_out   the chunk's results as soon as its kernels are done (page-locked: straight into caller memory; pageable: into a
+//                page-locked landing area, moved to the caller by CopyPool threads while later chunks compute)
+// Chunk sizes ramp up and down, 1 1 2 4 4 2 2 sixteenths of the batch: the first kernels start after a sixteenth of the input has
+// crossed PCIe (0.25 ms), the middle launches fill the chip, the last result copy is an eighth of the output.  Round 2 cut the batch
+// into 8 equal chunks on two lanes with ONE staging buffer each: a chunk's input copy could not start before the chunk two places
+// ahead had left the device, and the timeline (tools/host_pipeline_trace.py) showed the GPU idle for a third of the call.
+constexpr int PIPE_MAX_CHUNKS = 16;
+int ensure_pipe(Ctx& g, int chunks) {
+  if (!g.stream_in) HIPCK(hipStreamCreateWithFlags(&g.stream_in, hipStreamNonBlocking));
+  if (!g.stream_out) HIPCK(hipStreamCreateWithFlags(&g.stream_out, hipStreamNonBlocking));
+  while ((int)g.pipe_ev.size() < 3 * chunks) {
+    hipEvent_t e;
+    HIPCK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    g.pipe_ev.push_back(e);
+  }
+  for (int i = 0; i < 4; ++i) if (!g.ev_ring[i]) HIPCK(hipEventCreateWithFlags(&g.ev_ring[i], hipEventDisableTiming));
+  return KYB_OK;
+}
+int ensure_pin_out(Ctx& g, size_t bytes) {
+  if (bytes <= g.pin_out_bytes) return KYB_OK;
+  if (g.pin_out) { HIPCK(hipHostFree(g.pin_out)); g.pin_out = nullptr; g.pin_out_bytes = 0; }
+  const size_t want = bytes + (bytes >> 3) + 4096;
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&g.pin_out), want, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "page-locked output landing area", e);
+  g.pin_out_bytes = want;
+  return KYB_OK;
+}
+// chunk sizes (items, multiples of 1024 except the last): sixteenths of the batch in the pattern above; `first_div` (option
+// host.pipe_chunks, default 16) sets the unit
+int plan_chunks(size_t n, int first_div, size_t* sizes) {
+  static const int pattern[7] = {1, 1, 2, 4, 4, 2, 2};      // other shapes (1 1 2 4 8, 1 2 4 4 3 2, ...) are within 2 % (profiles/r03/host_pipeline.log)
+  size_t unit = ((n + (size_t)first_div - 1) / (size_t)first_div + 1023) & ~(size_t)1023;
+  if (unit < 16384) unit = 16384;
+  int c = 0;
+  size_t left = n;
+  for (int i = 0; left > 0 && c < PIPE_MAX_CHUNKS; ++i) {
+    size_t want = unit * (size_t)(i < 7 ? pattern[i] : 2);
+    if (c == PIPE_MAX_CHUNKS - 1 || want > left) want = left;
+    sizes[c++] = want;
+    left -= want;
+  }
+  return c;
+}
+constexpr size_t RING_SLOT = (size_t)4 << 20;
+template <class Fn>
+int run_host_batch_pipelined(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
+  size_t sizes[PIPE_MAX_CHUNKS];
+  const int nchunks = plan_chunks(n, g.opt_pipe_chunks, sizes);
+  const size_t n_pad = (n + 1023) & ~(size_t)1023;
+  size_t off[8], total = 0, out_off[8], out_total = 0;
+  for (int k = 0; k < na; ++k) {
+    off[k] = total; total += up256(arrs[k].bytes * n_pad);
+    out_off[k] = out_total; if (arrs[k].out) out_total += up256(arrs[k].bytes * n_pad);
+  }
+  int rc = ensure_stage(g, total); if (rc) return rc;
+  rc = ensure_pipe(g, nchunks); if (rc) return rc;
+  bool pinned = true;
+  for (int k = 0; k < na; ++k) {
+    if (arrs[k].in) pinned = pinned && is_pinned(arrs[k].in);
+    if (arrs[k].out) pinned = pinned && is_pinned(arrs[k].out);
+  }
+  const int threads = copy_threads(g);
+  if (!pinned) {
+    rc = ensure_pin(g, 0, 4 * RING_SLOT); if (rc) return rc;
+    rc = ensure_pin_out(g, out_total); if (rc) return rc;
+  }
+  hipStream_t cmp[2] = {g.stream, g.stream2};
+  auto quiesce = [&] { (void)hipStreamSynchronize(g.stream_in); (void)hipStreamSynchronize(g.stream); (void)hipStreamSynchronize(g.stream2); (void)hipStreamSynchronize(g.stream_out); };
+  // every way out: nothing of this call is left in flight, and the secret operands are gone from the staging and the bounce ring
+  auto wipe = on_scope_exit([&] {
+    quiesce();
+    bool any = false;
+    for (int k = 0; k < na; ++k)
+      if (arrs[k].secret && arrs[k].in) { (void)hipMemsetAsync(g.stage + off[k], 0, arrs[k].bytes * n_pad, g.stream); any = true; }
+    if (any && !pinned && g.pin[0]) memset(g.pin[0], 0, 4 * RING_SLOT);
+    if (any) (void)hipStreamSynchronize(g.stream);
+  });
+  int ring_next = 0;
+  bool ring_used[4] = {false, false, false, false};
+  auto bounce_in = [&](uint8_t* dst, const uint8_t* src, size_t bytes) -> int {
+    for (size_t o = 0; o < bytes; o += RING_SLOT) {
+      const int slot = ring_next & 3;
+      const size_t nb = bytes - o < RING_SLOT ? bytes - o : RING_SLOT;
+      if (ring_used[slot]) HIPCK(hipEventSynchronize(g.ev_ring[slot]));        // the DMA engine has drained this slot
+      kyb::CopyPool::Job job{g.pin[0] + (size_t)slot * RING_SLOT, src + o, nb};
+      g.copy.run(&job, 1, threads);
+      HIPCK(hipMemcpyAsync(dst + o, g.pin[0] + (size_t)slot * RING_SLOT, nb, hipMemcpyHostToDevice, g.stream_in));
+      HIPCK(hipEventRecord(g.ev_ring[slot], g.stream_in));
+      ring_used[slot] = true;
+      ++ring_next;
+    }
+    return KYB_OK;
+  };
+  // pageable caller: results of chunk c from the landing area to the caller's arrays, once they have left the device
+  size_t lo_of[PIPE_MAX_CHUNKS];
+  auto deliver = [&](int c) -> int {
+    HIPCK(hipEventSynchronize(g.pipe_ev[3 * c + 2]));
+    kyb::CopyPool::Job jobs[8];
+    int nj = 0;
+    for (int k = 0; k < na; ++k)
+      if (arrs[k].out) jobs[nj++] = kyb::CopyPool::Job{static_cast<uint8_t*>(arrs[k].out) + arrs[k].bytes * lo_of[c], g.pin_out + out_off[k] + arrs[k].bytes * lo_of[c], arrs[k].bytes * sizes[c]};
+    g.copy.run(jobs, nj, threads);
+    return KYB_OK;
+  };
+  size_t lo = 0;
+  int delivered = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const size_t cn = sizes[c];
+    lo_of[c] = lo;
+    hipEvent_t ev_in = g.pipe_ev[3 * c], ev_done = g.pipe_ev[3 * c + 1], ev_out = g.pipe_ev[3 * c + 2];
+    uint8_t* dptr[8];
+    for (int k = 0; k < na; ++k) {
+      dptr[k] = (arrs[k].in || arrs[k].out) ? g.stage + off[k] + arrs[k].bytes * lo : nullptr;
+      if (!arrs[k].in) continue;
+      const uint8_t* src = static_cast<const uint8_t*>(arrs[k].in) + arrs[k].bytes * lo;
+      if (pinned) HIPCK(hipMemcpyAsync(dptr[k], src, arrs[k].bytes * cn, hipMemcpyHostToDevice, g.stream_in));
+      else { rc = bounce_in(dptr[k], src, arrs[k].bytes * cn); if (rc) return rc; }
+    }
+    HIPCK(hipEventRecord(ev_in, g.stream_in));
+    hipStream_t st = cmp[c & 1];
+    HIPCK(hipStreamWaitEvent(st, ev_in, 0));
+    rc = launch(st, cn, dptr);
+    if (rc) return rc;
+    HIPCK(hipEventRecord(ev_done, st));
+    HIPCK(hipStreamWaitEvent(g.stream_out, ev_done, 0));
+    for (int k = 0; k < na; ++k) {
+      if (!arrs[k].out) continue;
+      uint8_t* dst = pinned ? static_cast<uint8_t*>(arrs[k].out) + arrs[k].bytes * lo : g.pin_out + out_off[k] + arrs[k].bytes * lo;
+      HIPCK(hipMemcpyAsync(dst, dptr[k], arrs[k].bytes * cn, hipMemcpyDeviceToHost, g.stream_out));
+    }
+    HIPCK(hipEventRecord(ev_out, g.stream_out));
+    // pageable: hand over whatever has already landed (never waits for a chunk that is still computing)
+    while (!pinned && delivered < c && hipEventQuery(g.pipe_ev[3 * delivered + 2]) == hipSuccess) { rc = deliver(delivered++); if (rc) return rc; }
+    lo += cn;
+  }
+  if (!pinned) for (; delivered < nchunks; ++delivered) { rc = deliver(delivered); if (rc) return rc; }
+  HIPCK(hipStreamSynchronize(g.stream_out));
+  return KYB_OK;
+}
+
 template <class Fn>
 int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
   std::lock_guard<std::mutex> lk(g.mu);
-  const int nchunks = n >= PIPE_MIN_ITEMS ? (int)g.opt_pipe_chunks : 1;
-  const size_t cap = (((n + nchunks - 1) / nchunks) + 1023) & ~(size_t)1023;      // items per chunk
+  if (n >= PIPE_MIN_ITEMS) return run_host_batch_pipelined(g, n, arrs, na, launch);
+  const size_t cap = (n + 1023) & ~(size_t)1023;
   size_t off[8], total = 0;
   for (int k = 0; k < na; ++k) { off[k] = total; total += up256(arrs[k].bytes * cap); }
-  if (nchunks == 1 && total <= ZERO_COPY_BYTES) {
+  if (total <= ZERO_COPY_BYTES) {
     // small batch: kernels on the page-locked buffer itself (see HostCall::run)
     int rc = ensure_pin(g, 0, ZERO_COPY_BYTES);
     if (rc) return rc;
@@ -317,100 +456,26 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
       if (arrs[k].out) memcpy(arrs[k].out, g.pin[0] + off[k], arrs[k].bytes * n);
     return KYB_OK;
   }
+  // in between (up to 2^16 items): copy in, run, copy out, on the engine stream
   int rc = ensure_stage(g, total);
   if (rc) return rc;
-  if (nchunks > 1) { rc = ensure_stage2(g, total); if (rc) return rc; }
-  hipStream_t streams[2] = {g.stream, g.stream2};
-  uint8_t* stages[2] = {g.stage, g.stage2};
-  bool bounce = false;
-  // secret operands: their device staging slots (and bounce-buffer slots) are cleared on every way out of the call
   auto wipe = on_scope_exit([&] {
     bool any = false;
-    for (int k = 0; k < na; ++k) any = any || (arrs[k].secret && arrs[k].in);
-    if (!any) return;
-    const int lanes = nchunks > 1 ? 2 : 1;
-    for (int l = 0; l < lanes; ++l) (void)hipStreamSynchronize(streams[l]);        // an error return may have left work in flight
-    for (int l = 0; l < lanes; ++l)
-      for (int k = 0; k < na; ++k)
-        if (arrs[k].secret && arrs[k].in) {
-          (void)hipMemsetAsync(stages[l] + off[k], 0, arrs[k].bytes * cap, streams[l]);
-          if (bounce && g.pin[l]) memset(g.pin[l] + off[k], 0, arrs[k].bytes * cap);
-        }
-    for (int l = 0; l < lanes; ++l) (void)hipStreamSynchronize(streams[l]);
-  });
-  bool pinned = true;
-  for (int k = 0; k < na; ++k) {
-    if (arrs[k].in) pinned = pinned && is_pinned(arrs[k].in);
-    if (arrs[k].out) pinned = pinned && is_pinned(arrs[k].out);
-  }
-  if (nchunks > 1 && !pinned) {
-    rc = ensure_pin(g, 0, total); if (rc) return rc;
-    rc = ensure_pin(g, 1, total); if (rc) return rc;
-    bounce = true;
-    const int threads = copy_threads(g);
-    kyb::CopyPool::Job jobs[8];
-    auto chunk_items = [&](int c) { const size_t lo = (size_t)c * cap; return lo >= n ? (size_t)0 : ((lo + cap <= n) ? cap : n - lo); };
-    auto copy_out = [&](int c) -> int {             // chunk c has been queued on its lane: wait for it, hand the results over
-      const int lane = c & 1;
-      HIPCK(hipStreamSynchronize(streams[lane]));
-      const size_t lo = (size_t)c * cap, cn = chunk_items(c);
-      int nj = 0;
-      for (int k = 0; k < na; ++k)
-        if (arrs[k].out) jobs[nj++] = kyb::CopyPool::Job{static_cast<uint8_t*>(arrs[k].out) + arrs[k].bytes * lo, g.pin[lane] + off[k], arrs[k].bytes * cn};
-      g.copy.run(jobs, nj, threads);
-      return KYB_OK;
-    };
-    int queued = -1;
-    for (int c = 0; c < nchunks && chunk_items(c) > 0; ++c) {
-      const int lane = c & 1;
-      const size_t lo = (size_t)c * cap, cn = chunk_items(c);
-      if (c >= 2) { rc = copy_out(c - 2); if (rc) return rc; }     // frees this lane's bounce and staging buffers
-      int nj = 0;
-      for (int k = 0; k < na; ++k)
-        if (arrs[k].in) jobs[nj++] = kyb::CopyPool::Job{g.pin[lane] + off[k], static_cast<const uint8_t*>(arrs[k].in) + arrs[k].bytes * lo, arrs[k].bytes * cn};
-      g.copy.run(jobs, nj, threads);
-      uint8_t* dptr[8];
-      for (int k = 0; k < na; ++k) {
-        dptr[k] = (arrs[k].in || arrs[k].out) ? stages[lane] + off[k] : nullptr;
-        if (arrs[k].in) HIPCK(hipMemcpyAsync(dptr[k], g.pin[lane] + off[k], arrs[k].bytes * cn, hipMemcpyHostToDevice, streams[lane]));
-      }
-      rc = launch(streams[lane], cn, dptr);
-      if (rc) return rc;
-      for (int k = 0; k < na; ++k)
-        if (arrs[k].out) HIPCK(hipMemcpyAsync(g.pin[lane] + off[k], stages[lane] + off[k], arrs[k].bytes * cn, hipMemcpyDeviceToHost, streams[lane]));
-      queued = c;
-    }
-    if (queued >= 1) { rc = copy_out(queued - 1); if (rc) return rc; }
-    if (queued >= 0) { rc = copy_out(queued); if (rc) return rc; }
-    return KYB_OK;
-  }
-  auto d2h = [&](int c) -> int {
-    const int lane = c & 1;
-    const size_t lo = (size_t)c * cap, cn = (lo + cap <= n) ? cap : n - lo;
+    (void)hipStreamSynchronize(g.stream);            // an error return may have left work in flight
     for (int k = 0; k < na; ++k)
-      if (arrs[k].out) HIPCK(hipMemcpyAsync(static_cast<uint8_t*>(arrs[k].out) + arrs[k].bytes * lo, stages[lane] + off[k], arrs[k].bytes * cn, hipMemcpyDeviceToHost, streams[lane]));
-    return KYB_OK;
-  };
-  int last = -1;
-  for (int c = 0; c < nchunks; ++c) {
-    const size_t lo = (size_t)c * cap;
-    if (lo >= n) break;
-    const size_t cn = (lo + cap <= n) ? cap : n - lo;
-    const int lane = c & 1;
-    if (c >= 2) HIPCK(hipStreamSynchronize(streams[lane]));      // chunk c-2 has left this lane's staging
-    uint8_t* dptr[8];
-    for (int k = 0; k < na; ++k) {
-      dptr[k] = (arrs[k].in || arrs[k].out) ? stages[lane] + off[k] : nullptr;
-      if (arrs[k].in) HIPCK(hipMemcpyAsync(dptr[k], static_cast<const uint8_t*>(arrs[k].in) + arrs[k].bytes * lo, arrs[k].bytes * cn, hipMemcpyHostToDevice, streams[lane]));
-    }
-    rc = launch(streams[lane], cn, dptr);
-    if (rc) return rc;
-    if (c >= 1) { rc = d2h(c - 1); if (rc) return rc; }
-    last = c;
+      if (arrs[k].secret && arrs[k].in) { (void)hipMemsetAsync(g.stage + off[k], 0, arrs[k].bytes * cap, g.stream); any = true; }
+    if (any) (void)hipStreamSynchronize(g.stream);
+  });
+  uint8_t* dptr[8];
+  for (int k = 0; k < na; ++k) {
+    dptr[k] = (arrs[k].in || arrs[k].out) ? g.stage + off[k] : nullptr;
+    if (arrs[k].in) HIPCK(hipMemcpyAsync(dptr[k], arrs[k].in, arrs[k].bytes * n, hipMemcpyHostToDevice, g.stream));
   }
-  if (last >= 0) { rc = d2h(last); if (rc) return rc; }
+  rc = launch(g.stream, n, dptr);
+  if (rc) return rc;
+  for (int k = 0; k < na; ++k)
+    if (arrs[k].out) HIPCK(hipMemcpyAsync(arrs[k].out, dptr[k], arrs[k].bytes * n, hipMemcpyDeviceToHost, g.stream));
   HIPCK(hipStreamSynchronize(g.stream));
-  if (nchunks > 1) HIPCK(hipStreamSynchronize(g.stream2));
   return KYB_OK;
 }
 
@@ -655,9 +720,13 @@ void ctx_release(Ctx* c) {
   for (StreamRes* r : c->res) free_slot(r);
   c->res.clear();
   wipe_free_dev(c->stage, c->stage_bytes);
-  wipe_free_dev(c->stage2, c->stage2_bytes);
   for (int l = 0; l < 2; ++l) if (c->pin[l]) { memset(c->pin[l], 0, c->pin_bytes[l]); (void)hipHostFree(c->pin[l]); }
   for (int l = 0; l < 2; ++l) if (c->ev_pin[l]) (void)hipEventDestroy(c->ev_pin[l]);
+  for (int l = 0; l < 4; ++l) if (c->ev_ring[l]) (void)hipEventDestroy(c->ev_ring[l]);
+  for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
+  if (c->pin_out) { memset(c->pin_out, 0, c->pin_out_bytes); (void)hipHostFree(c->pin_out); }
+  if (c->stream_in) { (void)hipStreamSynchronize(c->stream_in); (void)hipStreamDestroy(c->stream_in); }
+  if (c->stream_out) { (void)hipStreamSynchronize(c->stream_out); (void)hipStreamDestroy(c->stream_out); }
   if (c->done_flag) (void)hipHostFree(c->done_flag);
   if (c->done_counter) (void)hipFree(c->done_counter);
   { std::lock_guard<std::mutex> lk(c->prof.mu);

@@ -56,6 +56,7 @@ k_decode_to_proj(const uint8_t* __restrict__ enc, size_t n, uint4* __restrict__ 
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
 k_mont_prep(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ proj, size_t stride, const uint8_t* __restrict__ scalars,
             uint32_t* __restrict__ top_or) {
+  KYB_SHORT_KERNEL_PRIORITY();
   const size_t M = (n + FINISH_K - 1) / FINISH_K;
   const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (j >= M) return;

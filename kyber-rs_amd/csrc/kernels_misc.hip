@@ -21,6 +21,7 @@ using namespace kyb;
 // segmented sum, 1 otherwise).
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
 k_finish(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, size_t src_mul) {
+  KYB_SHORT_KERNEL_PRIORITY();
   const size_t M = (n + FINISH_K - 1) / FINISH_K;
   const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (j >= M) return;

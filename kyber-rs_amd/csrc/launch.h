@@ -25,6 +25,17 @@ constexpr int KYB_BLOCK = 256;      // threads per workgroup of every one-item-p
 constexpr int KYB_BLOCK32 = 1024;   // radix-32 fixed-base kernel
 constexpr int FINISH_K = 8;         // items per shared field inversion (k_finish, k_mont_prep, k_encode_batched)
 
+// The short kernels either side of the ladder (k_mont_prep, k_finish: one wavefront per 512 items, a 265-multiplication inversion chain
+// each) raise their wavefronts' issue priority.  Alone on the chip it changes nothing.  In the pipelined host-pointer path they share
+// SIMDs with the ladder of the neighbouring chunk: the arbiter serves the OLDEST wavefront first, so a young short-kernel wavefront
+// starves behind two resident ladder wavefronts for a whole ladder lifetime (1.9 ms instead of 0.1) while its 180-230 registers keep
+// a third ladder wavefront out — the SIMD runs at two thirds (tools/host_pipeline_trace.py; -DKYB_NO_SETPRIO for the A/B).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KYB_NO_SETPRIO)
+#define KYB_SHORT_KERNEL_PRIORITY() __builtin_amdgcn_s_setprio(3)
+#else
+#define KYB_SHORT_KERNEL_PRIORITY() ((void)0)
+#endif
+
 namespace launch {
 
 // ---- kernels_base.hip / kernels_base_alt.hip ----

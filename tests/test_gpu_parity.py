@@ -717,6 +717,20 @@ def test_host_pointer_paths_agree(engine, oracle):
         engine.set_option("host.copy_threads", 0)
     idx = np.concatenate([rng.choice(n, 256, replace=False), [0, n - 1, (1 << 17) - 1, 1 << 17]])
     assert np.array_equal(enc_m[idx], oracle.mul_batch(t[idx], ext[idx], nthreads=8))
+    # other chunk plans of the pipeline (unit = 1/2 and 1/64 of the batch: two chunks / the 16-chunk cap), page-locked and pageable,
+    # with both outputs travelling back
+    unit = engine.get_option("host.pipe_chunks")
+    try:
+        for div in (2, 64):
+            engine.set_option("host.pipe_chunks", div)
+            po[:] = 0
+            engine.mul_into(ps, pe, po)
+            assert np.array_equal(po, enc_m), div
+            e2, x2 = engine.mul(t, pts_ext=ext, want_ext=True)
+            assert np.array_equal(e2, enc_m) and np.array_equal(engine.encode(x2[idx]), enc_m[idx]), div
+            assert np.array_equal(engine.mul_base(s), enc_b), div
+    finally:
+        engine.set_option("host.pipe_chunks", unit)
 
 
 def test_large_pageable_input_of_an_unchunked_call(engine, oracle):
