@@ -28,9 +28,12 @@
 // writes that are issued in a block — which is why the operands of the products live in LDS memory.
 //
 // Same limb format and bounds notation as fe25519.h; results are bit-identical to the one-lane code (tests compare both
-// paths with the oracle).  Constant time: the instruction stream and every lane index are independent of secret data except
-// the row index of the ladder's conditional swap, which goes through the conflict-free ds_bpermute crossbar exactly like the
-// window selection of the fixed-base kernel.
+// paths with the oracle).  Constant time, checked on the compiled code by tools/ct_check.py: no branch and no memory address (global
+// or LDS) depends on a scalar.  Secret-dependent data moves in exactly two ways: the LANE SELECT of ds_bpermute_b32 (the ladder's
+// conditional swap exchanges two rows; coop_table_entry pulls the wanted table word: a lone permute takes 60 cycles whatever the
+// pattern, tools/microbench/bpermute_patterns.hip) and csel() below, a v_bfi_b32 under an opaque mask — never `flag ? a : b` on a
+// secret-derived flag: all lanes of a wavefront serve ONE item, so every such flag is wave-uniform and the compiler turns the
+// ternary into a scalar branch (round 2's y-recovery had them for its exceptional cases).
 // All of this needs the FULL wavefront active: a DPP or ds_bpermute read of a lane that EXEC has switched off returns 0, so
 // no cross-lane operation may sit under a lane-dependent branch (`cond ? move(a) : move(b)` must be written move, move, select).
 #pragma once
@@ -40,6 +43,16 @@ namespace kyb {
 namespace coop {
 
 typedef uint32_t cq;      // one lane's share of a quad
+
+// Select by a flag (0 / 1) that may derive from secret data: flag ? a : b.  Every lane of a wavefront works on the SAME item here, so such
+// flags are wave-uniform, and the compiler, seeing that, turns a plain `flag ? a : b` into a scalar BRANCH around one arm
+// (tools/ct_check.py found them in the exceptional-case selects of the y-recovery).  The mask is made opaque first; what is left is one
+// v_bfi_b32 whatever the flag.
+__device__ __forceinline__ cq csel(uint32_t flag01, cq a, cq b) {
+  uint32_t m = 0u - flag01;
+  asm volatile("" : "+v"(m));
+  return (a & m) | (b & ~m);
+}
 
 // per-lane constants of the cooperative arithmetic (computed once per kernel)
 struct lane_consts {

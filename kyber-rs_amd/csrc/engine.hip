@@ -83,6 +83,7 @@ struct Ctx {
   hipEvent_t ev_ring[4] = {nullptr, nullptr, nullptr, nullptr};   // bounce ring of the pageable input path: a slot's last copy to the device
   uint8_t* pin_out = nullptr; size_t pin_out_bytes = 0;       // page-locked landing area for the outputs of a pageable caller
   uint32_t* table = nullptr;       // KYB_BASE_TABLE_BYTES: radix-16 image (65,536 B), radix-32 image (106,496 B), radix-64 image (163,200 B)
+  uint32_t* table_coop = nullptr;  // KYB_COOP_TABLE_WORDS: entry-major copy of the radix-64 table for the one-item-per-wavefront kernels, derived from `table` on this GPU
   uint64_t* ck_dev = nullptr;      // 8 bytes: checksum of an imported table image
   std::atomic<bool> table_ready{false};
   std::vector<StreamRes*> res;
@@ -696,6 +697,13 @@ int ensure_aux(Ctx& g, StreamRes* r) {
   return KYB_OK;
 }
 inline const uint32_t* image64(Ctx& g) { return g.table + KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS; }
+inline const uint32_t* coop_table(Ctx& g) { return g.table_coop; }
+// the image in g.table is complete (built here, or imported and validated): derive what this context keeps beside it
+int table_finalize(Ctx& g, hipStream_t st) {
+  LAUNCHCK(launch::build_coop_table(image64(g), g.table_coop, st));
+  HIPCK(hipStreamSynchronize(st));
+  return KYB_OK;
+}
 inline bool use_split(Ctx& g, size_t n) { return g.opt_finish == 1 && n >= (size_t)g.opt_finish_min; }
 
 // ---- context life cycle ------------------------------------------------------------------------------------
@@ -709,7 +717,7 @@ int table_validate(Ctx& g, hipStream_t st) {
   HIPCK(hipStreamSynchronize(st));
   const uint64_t want = (uint64_t)emb[0] | ((uint64_t)emb[1] << 32);
   if (got != want) return fail(KYB_E_BAD_ARG, "base table image failed its checksum (truncated or corrupted transfer): table not installed");
-  return KYB_OK;
+  return table_finalize(g, st);
 }
 
 void ctx_release(Ctx* c) {
@@ -734,6 +742,7 @@ void ctx_release(Ctx* c) {
     delete[] c->prof.recs; c->prof.recs = nullptr; c->prof.cap = c->prof.used = 0; c->prof.on = false; }
   if (c->table) (void)hipFree(c->table);
   if (c->ck_dev) (void)hipFree(c->ck_dev);
+  if (c->table_coop) (void)hipFree(c->table_coop);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -765,12 +774,14 @@ int ctx_new(int device, bool build_table, Ctx** out) {
   CTXCK(hipStreamCreateWithFlags(&g.stream2, hipStreamNonBlocking));
   CTXCK(hipMalloc(&g.table, KYB_BASE_TABLE_BYTES));
   CTXCK(hipMalloc(&g.ck_dev, 16));
+  CTXCK(hipMalloc(reinterpret_cast<void**>(&g.table_coop), KYB_COOP_TABLE_WORDS * sizeof(uint32_t)));
   // persistent grids of the windowed kernel: 2 blocks of 256 threads per CU = 2 waves per SIMD (needed to saturate
   // v_mad_u64_u32 issue, profiles/r01_valu_rates_mi355x.jsonl)
   g.grid_mul = g.cus * 2;
   g.ws_bytes = (size_t)g.grid_mul * (KYB_BLOCK / 64) * (8 * 10 * 64) * sizeof(uint4);
   if (build_table) {
     CTXCK(launch::build_tables(g.table, g.stream));
+    CTXCK(launch::build_coop_table(image64(g), g.table_coop, g.stream));
     CTXCK(hipStreamSynchronize(g.stream));
     g.table_ready = true;
   }
@@ -1053,7 +1064,7 @@ int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t*
   SlotUse use(r, st);
   if (n <= (size_t)g.opt_coop_base_max) {
     ProfScope ps(g, st, KID_MUL_BASE_COOP);
-    LAUNCHCK(launch::mul_base_coop(st, sc, n, oenc, oext, image64(g), nullptr, 0, 0, nullptr, 0, take_done_flag(g, st, n),
+    LAUNCHCK(launch::mul_base_coop(st, sc, n, oenc, oext, coop_table(g), nullptr, 0, 0, nullptr, 0, take_done_flag(g, st, n),
                                    n <= 2 * (size_t)g.opt_coop_verify_max ? 4 : 1,      // few items (measured: up to 1,024): four wavefronts share an item's 43 windows
                                    g.opt_ext_projective != 0));
     return KYB_OK;
@@ -1089,7 +1100,7 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
   if (n <= (size_t)g.opt_coop_verify_max && 2 * n <= (size_t)g.opt_coop_base_max) {
     // few signatures: one launch, two wavefronts each (kernels_coop.hip)
     ProfScope ps(g, st, KID_SIGN_COOP);
-    LAUNCHCK(launch::sign_coop(st, x, k, pub_in, msgs, off, n, sig, pub_out, image64(g), take_done_flag(g, st, n)));
+    LAUNCHCK(launch::sign_coop(st, x, k, pub_in, msgs, off, n, sig, pub_out, coop_table(g), take_done_flag(g, st, n)));
     return KYB_OK;
   }
   if (pub_in != nullptr) {
@@ -1097,7 +1108,7 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
     int rc = ensure_enc(g, r, 32 * n); if (rc) return rc;
     if (n <= (size_t)g.opt_coop_base_max) {
       ProfScope ps(g, st, KID_MUL_BASE_COOP);
-      LAUNCHCK(launch::mul_base_coop(st, k, n, r->enc, nullptr, image64(g)));
+      LAUNCHCK(launch::mul_base_coop(st, k, n, r->enc, nullptr, coop_table(g)));
     } else if (use_split(g, n)) {
       rc = ensure_proj(g, r, n); if (rc) return rc;
       rc = launch_base(g, true, k, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
@@ -1118,7 +1129,7 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
     int rc = ensure_enc(g, r, 64 * n); if (rc) return rc;
     {
       ProfScope ps(g, st, KID_MUL_BASE_COOP);
-      LAUNCHCK(launch::mul_base_coop(st, k, n, r->enc, nullptr, image64(g), nullptr, 0, 0, x, n));      // R in [0, n), A in [n, 2n)
+      LAUNCHCK(launch::mul_base_coop(st, k, n, r->enc, nullptr, coop_table(g), nullptr, 0, 0, x, n));      // R in [0, n), A in [n, 2n)
     }
     {
       ProfScope ps(g, st, KID_SIGN_HASH);
@@ -1190,7 +1201,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   if (g.opt_mul_algo == 1 && n <= (size_t)g.opt_coop_verify_max) {
     // few signatures: the whole verification in one launch, three wavefronts per signature (kernels_coop.hip)
     ProfScope ps(g, st, KID_VERIFY_COOP);
-    LAUNCHCK(launch::verify_coop(st, pubs, sigs, msgs, off, n, flavor, image64(g), status, take_done_flag(g, st, n)));
+    LAUNCHCK(launch::verify_coop(st, pubs, sigs, msgs, off, n, flavor, coop_table(g), status, take_done_flag(g, st, n)));
     return KYB_OK;
   }
   StreamRes* r = nullptr;
@@ -1227,7 +1238,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   if (fork) {
     HIPCK(hipEventRecord(r->ev_fork, st));                 // s*B reads sbuf, which the A-half kernel has just been asked to write
     HIPCK(hipStreamWaitEvent(side, r->ev_fork, 0));
-    if (coop) { ProfScope ps(g, side, KID_MUL_BASE_COOP); LAUNCHCK(launch::mul_base_coop(side, sbuf, n, nullptr, nullptr, image64(g), r->proj, r->proj_items, n)); }
+    if (coop) { ProfScope ps(g, side, KID_MUL_BASE_COOP); LAUNCHCK(launch::mul_base_coop(side, sbuf, n, nullptr, nullptr, coop_table(g), r->proj, r->proj_items, n)); }
     else { rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side); if (rc) return rc; }
     HIPCK(hipEventRecord(r->ev_join, side));
   }
@@ -1244,7 +1255,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     LAUNCHCK(launch::mul_window(g.opt_mul_select, false, true, grid, st, hbuf, nullptr, a_ext, n, nullptr, nullptr, nullptr, r->ws, r->proj, r->proj_items));
   }
   if (fork) HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
-  else if (coop) { ProfScope ps(g, st, KID_MUL_BASE_COOP); LAUNCHCK(launch::mul_base_coop(st, sbuf, n, nullptr, nullptr, image64(g), r->proj, r->proj_items, n)); }
+  else if (coop) { ProfScope ps(g, st, KID_MUL_BASE_COOP); LAUNCHCK(launch::mul_base_coop(st, sbuf, n, nullptr, nullptr, coop_table(g), r->proj, r->proj_items, n)); }
   else { rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, st); if (rc) return rc; }
   {
     ProfScope ps(g, st, KID_VERIFY_FINAL);

@@ -312,6 +312,11 @@ struct tbl_base32_words {
 #define KYB_BASE64_WIN_WORDS 960
 #define KYB_BASE64_TOP_BASE (42 * KYB_BASE64_WIN_WORDS)
 #define KYB_BASE64_TABLE_WORDS (KYB_BASE64_TOP_BASE + 480)
+// Entry-major copy of the same table for the one-item-per-wavefront kernels (kernels_coop.hip, coop_table_entry): 32 words = one
+// 128-byte line per entry (its 30 words, two zeros), 32 entries per window, the top window's 16 behind the 42 full ones.  Each context
+// derives it from the image on its own GPU (k_base_table_coop) when the image is built or imported; it is not part of what travels.
+#define KYB_COOP_WIN_WORDS (32 * 32)
+#define KYB_COOP_TABLE_WORDS (42 * KYB_COOP_WIN_WORDS + 16 * 32)
 // word k (0..9 ypx, 10..19 ymx, 20..29 xy2d) of entry j of a window with E entries, relative to the window:
 //   plane A  words [ 0E,  8E)  [2 quads][E][4]  ypx 0..7        plane a  words [16E, 18E)  [E][2]  ypx 8, 9
 //   plane B  words [ 8E, 16E)  [2 quads][E][4]  ymx 0..7        plane b  words [18E, 20E)  [E][2]  ymx 8, 9

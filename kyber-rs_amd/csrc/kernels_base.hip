@@ -26,6 +26,13 @@ __global__ void __launch_bounds__(64) k_base_table64(uint32_t* image) {
   else if (e < 42 * 32 + 16) ge_base64_table_entry(image, 42, e - 42 * 32);
 }
 
+// entry-major copy for the cooperative kernels: one workgroup of 32 threads per entry (KYB_COOP_TABLE_WORDS, ge_scalarmult.h)
+__global__ void __launch_bounds__(32) k_base_table_coop(const uint32_t* __restrict__ image64, uint32_t* __restrict__ tc) {
+  const int e = blockIdx.x, w = threadIdx.x;                     // e: 0 .. 42 * 32 + 16 - 1
+  const int pos = e < 42 * 32 ? (e >> 5) : 42, j = e < 42 * 32 ? (e & 31) : e - 42 * 32;
+  tc[e * 32 + w] = w < 30 ? image64[KYB_BT64_IDX(pos, j, w)] : 0u;
+}
+
 // Fixed base, signed radix 64: one workgroup per CU owns the whole LDS (163,200 B table); 43 mixed additions
 // per item.  BLOCK = 1024 / 768 / 512 (4 / 3 / 2 waves per SIMD; the register budget is 128 / 168 / 256 VGPRs) when the batch fills
 // the chip, 256 (1 wave/SIMD, four times as many CUs busy) for batches that do not.
@@ -108,6 +115,10 @@ hipError_t build_tables(uint32_t* table, hipStream_t st) {
   hipLaunchKernelGGL(k_base_table32, dim3(13), dim3(64), 0, st, table + KYB_BASE_TABLE_WORDS);
   hipLaunchKernelGGL(k_base_table64, dim3(22), dim3(64), 0, st, table + KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS);
   hipLaunchKernelGGL(k_table_checksum, dim3(1), dim3(1024), 0, st, table, (uint64_t*)nullptr, table);
+  return hipGetLastError();
+}
+hipError_t build_coop_table(const uint32_t* image64, uint32_t* table_coop, hipStream_t st) {
+  hipLaunchKernelGGL(k_base_table_coop, dim3(42 * 32 + 16), dim3(32), 0, st, image64, table_coop);
   return hipGetLastError();
 }
 hipError_t table_checksum(const uint32_t* table, uint64_t* out_dev, hipStream_t st) {

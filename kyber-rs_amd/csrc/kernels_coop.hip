@@ -59,14 +59,14 @@ __device__ __forceinline__ void coop_finish(const lane_consts& c, cq q, uint32_t
       q = cmul4(c, xy, c.row == 3 ? yy : zz);
     }
     const cq ng = cnorm(c, c.p2 - q);                                    // rows 0, 3: -X, -T
-    q = ((c.row == 0 || c.row == 3) && negate_x) ? ng : q;
+    q = csel((uint32_t)(c.row == 0 || c.row == 3) & negate_x, ng, q);
     fe X, Y, Z, T;
     fe_from_quad_row(c, X, q, 0); fe_from_quad_row(c, Y, q, 1); fe_from_quad_row(c, Z, q, 2); fe_from_quad_row(c, T, q, 3);
     if (c.lane == 0) store_ext(out_ext, i, X, Y, Z, T);
     return;
   }
   const cq nq = cnorm(c, c.p2 - q);                                    // row 0: -X
-  q = (c.row == 0 && negate_x) ? nq : q;
+  q = csel((uint32_t)(c.row == 0) & negate_x, nq, q);
   if (out_enc == nullptr && out_ext == nullptr) {
     fe X, Y, Z;
     fe_from_quad_row(c, X, q, 0);
@@ -171,7 +171,7 @@ __device__ __forceinline__ cq coop_mont_prep(const lane_consts& c, cq PQ, uint32
   const uint32_t degenerate = coop_row_is_zero(c, M1, 0);                  // X == 0, or Z == Y with X != 0 (not on the curve): neutral element
   flags = (id | (degenerate & (1u - o2))) | (o2 << 1);
   const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
-  M = degenerate ? (r3 ? 0u : ONE0) : M;
+  M = csel(degenerate, r3 ? 0u : ONE0, M);
   return M;
 }
 
@@ -226,14 +226,15 @@ __device__ __forceinline__ cq coop_mont_recover(const lane_consts& c, cq M, cq S
   const uint32_t z2_zero = coop_row_is_zero(c, SZ, 0), z3_zero = coop_row_is_zero(c, SZ, 2), x2_zero = coop_row_is_zero(c, SX, 0);
   const uint32_t res_inf = z2_zero, res_negp = z3_zero & (1u - z2_zero), res_o2 = x2_zero & (1u - z2_zero);
   const uint32_t p_id = p_flags & 1u, p_o2 = (p_flags >> 1) & 1u;
-  RES = res_negp ? NEG : RES;
-  RES = res_o2 ? O2 : RES;
-  RES = res_inf ? ID : RES;
-  RES = p_id ? ID : RES;
-  RES = p_o2 ? (k_is_odd ? O2 : ID) : RES;
+  // (csel, not ?: — these flags depend on the scalar, and a wave-uniform ?: becomes a branch)
+  RES = csel(res_negp, NEG, RES);
+  RES = csel(res_o2, O2, RES);
+  RES = csel(res_inf, ID, RES);
+  RES = csel(p_id, ID, RES);
+  RES = csel(p_o2, csel(k_is_odd, O2, ID), RES);
   RES = cnorm(c, RES);                                                    // (the constant -1 is 2p - 1 limb-wise)
   const cq nres = cnorm(c, c.p2 - RES);
-  return (r0 && negate) ? nres : RES;
+  return csel((uint32_t)r0 & negate, nres, RES);
 }
 
 // ---- general point arithmetic in quads: PubPoly::eval for small batches (share/poly.rs:457-469) ----------------------------------
@@ -502,31 +503,42 @@ k_poly_eval_sum(const uint32_t* __restrict__ part, size_t n, int segs, uint8_t* 
   if (c.lane == 0) signal_done(df);
 }
 
-// One entry of the radix-64 image for the cooperative layout: lane (row g < 3, limb r) gets word 10 g + r of entry idx of
-// the window at `win` (E entries).  All LINES of a limb's entries are read whatever idx is (four loads 8 entries apart, the
-// wanted one kept by a uniform select): the cache sees the same lines for every digit.
+// One entry of the radix-64 table for the cooperative layout: lane (row g < 3, limb r) gets word 10 g + r of entry idx of a window
+// (E entries) — by a scan whose ADDRESSES depend on nothing secret.  `win` points into the context's entry-major copy of the table
+// (k_base_table_coop: 32 words = one 128-byte line per entry, words 30 and 31 zero).  Lane (half h, l) reads word l of the entries
+// 2m + h, m = 0 .. E/2 - 1: E/2 loads of 256 contiguous bytes each; a select tree over the upper bits of idx (opaque masks, v_bfi_b32)
+// leaves it with word l of entry (idx & ~1) | h; ONE ds_bpermute_b32 then pulls word 10 g' + r from half (idx & 1), where g' swaps
+// the y+x and y-x rows of a negated entry — the lane select of the crossbar is the only place the digit goes (tools/ct_check.py).
+// (Round 2 read four words at addresses that carried idx & 7 and the sign: the same cache LINES whatever the digit, but not the same
+// addresses.)
 template <int E>
 __device__ __forceinline__ cq coop_table_entry(const lane_consts& c, const uint32_t* __restrict__ win, uint32_t idx, uint32_t negate) {
-  const uint32_t g = c.row < 3 ? c.row : 0u;
-  const uint32_t g_eff = (g < 2u) ? (g ^ negate) : g;                 // a negated entry is (ymx, ypx, -xy2d)
-  const uint32_t kk = c.active ? c.k : 0u;
-  uint32_t v = 0;
-  const uint32_t want = idx >> 3;
+  const uint32_t l = c.lane & 31u, half = c.lane >> 5;
+  uint32_t cand[E / 2];
 #pragma unroll
-  for (uint32_t t = 0; t < (uint32_t)(E / 8); ++t) {
-    const uint32_t j = (idx & 7u) | (t << 3);
-    const uint32_t word = win[kyb_bt64_in_win(E, (int)j, (int)(10u * g_eff + kk))];
-    v = (t == want) ? word : v;
+  for (int m = 0; m < E / 2; ++m) cand[m] = win[(2 * m + (int)half) * 32 + (int)l];
+  constexpr int LEVELS = (E == 32) ? 4 : 3;
+#pragma unroll
+  for (int t = 0; t < LEVELS; ++t) {
+    uint32_t mk = 0u - ((idx >> (t + 1)) & 1u);
+    asm volatile("" : "+v"(mk));
+#pragma unroll
+    for (int m = 0; m < (E / 4) >> t; ++m) cand[m] = (cand[2 * m + 1] & mk) | (cand[2 * m] & ~mk);
   }
+  const uint32_t g = c.row < 3 ? c.row : 0u;
+  const uint32_t g_eff = g ^ (negate & (uint32_t)(g < 2u));            // a negated entry is (ymx, ypx, -xy2d)
+  const uint32_t kk = c.active ? c.k : 0u;
+  const uint32_t src = ((idx & 1u) << 5) | (10u * g_eff + kk);
+  uint32_t v = bperm((int)(src << 2), cand[0]);
   v = (c.active && c.row < 3) ? v : 0u;
   const uint32_t nv = c.p2 - v;                                        // 2p - xy2d
-  return (c.row == 2 && negate) ? nv : v;
+  return csel((uint32_t)(c.row == 2) & negate, nv, v);
 }
 
 // a' B for the scalar words a (sc_recode64's signed radix-64 digits): the point (X : Y : Z : T) before the sign of the top digit
 // (`neg`: negate X) is applied.  43 cooperative mixed additions — or the share [pos_lo, pos_hi) of the 43 windows (window 42 is the
 // top one) when several wavefronts divide them between themselves.
-__device__ __forceinline__ cq coop_base_mul(const lane_consts& c, const uint32_t a[8], const uint32_t* __restrict__ image64, uint32_t& neg,
+__device__ __forceinline__ cq coop_base_mul(const lane_consts& c, const uint32_t a[8], const uint32_t* __restrict__ table_coop, uint32_t& neg,
                                             int pos_lo = 0, int pos_hi = KYB_BASE64_POS) {
   sc_digits64 dg;
   sc_recode64(dg, a);
@@ -550,12 +562,12 @@ __device__ __forceinline__ cq coop_base_mul(const lane_consts& c, const uint32_t
   for (int pos = pos_lo; pos < last; ++pos) {
     uint32_t idx, ng;
     sc_next_digit64(idx, ng, dg, false);
-    h = coop_madd(c, mi, h, coop_table_entry<32>(c, image64 + pos * KYB_BASE64_WIN_WORDS, idx, ng));
+    h = coop_madd(c, mi, h, coop_table_entry<32>(c, table_coop + pos * KYB_COOP_WIN_WORDS, idx, ng));
   }
   if (pos_hi == KYB_BASE64_POS) {
     uint32_t idx, ng;
     sc_next_digit64(idx, ng, dg, true);
-    h = coop_madd(c, mi, h, coop_table_entry<16>(c, image64 + KYB_BASE64_TOP_BASE, idx, 0u));
+    h = coop_madd(c, mi, h, coop_table_entry<16>(c, table_coop + 42 * KYB_COOP_WIN_WORDS, idx, 0u));
   }
   neg = dg.neg;
   return h;
@@ -566,7 +578,7 @@ __device__ __forceinline__ cq coop_base_mul(const lane_consts& c, const uint32_t
 // instead of 43.
 __global__ void __launch_bounds__(256)
 k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ scalars_b, size_t n_a, size_t n, uint8_t* __restrict__ out_enc,
-                int32_t* __restrict__ out_ext, const uint32_t* __restrict__ image64, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset,
+                int32_t* __restrict__ out_ext, const uint32_t* __restrict__ table_coop, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset,
                 int waves, int ext_proj, kyb::launch::DoneFlag df) {
   __shared__ uint32_t sh_part[3 * 40];
   const size_t i = blockIdx.x;
@@ -578,7 +590,7 @@ k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__
   uint32_t neg;
   const int per = (KYB_BASE64_POS + waves - 1) / waves;
   const int lo = wave * per, hi = (wave + 1) * per < KYB_BASE64_POS ? (wave + 1) * per : KYB_BASE64_POS;
-  cq h = coop_base_mul(c, a, image64, neg, lo, hi);
+  cq h = coop_base_mul(c, a, table_coop, neg, lo, hi);
   if (waves > 1) {
     if (wave > 0 && c.active) sh_part[(wave - 1) * 40 + 10 * c.row + c.k] = h;
     __syncthreads();
@@ -701,7 +713,7 @@ k_verify_prep_r_coop(const uint8_t* __restrict__ sigs, size_t n, uint8_t* __rest
 __global__ void __launch_bounds__(512)
 k_sign_coop(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ msgs,
             const uint32_t* __restrict__ msg_off, size_t n, uint8_t* __restrict__ sig, uint8_t* __restrict__ pub_out,
-            const uint32_t* __restrict__ image64, kyb::launch::DoneFlag df) {
+            const uint32_t* __restrict__ table_coop, kyb::launch::DoneFlag df) {
   __shared__ uint32_t sh_a[8], sh_part[6 * 40];
   const size_t i = blockIdx.x;
   if (i >= n) return;
@@ -715,7 +727,7 @@ k_sign_coop(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const 
     load_words8(a, grp == 0 ? k : x, i);
     const int per = (KYB_BASE64_POS + 3) / 4;
     const int lo = sub * per, hi = (sub + 1) * per < KYB_BASE64_POS ? (sub + 1) * per : KYB_BASE64_POS;
-    h = coop_base_mul(c, a, image64, neg, lo, hi);
+    h = coop_base_mul(c, a, table_coop, neg, lo, hi);
     if (sub > 0 && c.active) sh_part[(grp * 3 + sub - 1) * 40 + 10 * c.row + c.k] = h;
   }
   __syncthreads();
@@ -817,7 +829,7 @@ k_mul_enc_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ 
 // for up to `coop.verify_max_items` signatures had the decode of A in front of the ladder and four launch gaps.
 __global__ void __launch_bounds__(192)
 k_verify_coop(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ msgs, const uint32_t* __restrict__ msg_off,
-              size_t n, int flavor, const uint32_t* __restrict__ image64, uint8_t* __restrict__ status, kyb::launch::DoneFlag df) {
+              size_t n, int flavor, const uint32_t* __restrict__ table_coop, uint8_t* __restrict__ status, kyb::launch::DoneFlag df) {
   __shared__ uint32_t sh_ax[10], sh_rx[10], sh_ry[10], sh_sb[30], sh_fl[4];
   const size_t i = blockIdx.x;
   if (i >= n) return;
@@ -864,7 +876,7 @@ k_verify_coop(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs
     }
   } else {
     uint32_t neg;
-    cq hq = coop_base_mul(c, sig + 8, image64, neg);
+    cq hq = coop_base_mul(c, sig + 8, table_coop, neg);
     const cq nq = cnorm(c, c.p2 - hq);
     hq = (c.row == 0 && neg) ? nq : hq;
     if (c.active && c.row < 3) sh_sb[10 * c.row + c.k] = hq;
@@ -897,7 +909,7 @@ k_verify_coop(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs
 // 4 table entry (window, idx, negate) = (B[0], B[1], B[2]) of the radix-64 image, 5 csub(A, B), 6 one ladder step S = A,
 // U1 / W1 in rows 0 / 2 of B, swap / bit in B lanes 16 / 17 (returns S'), 7 quad -> fe -> quad round trip of every row, 8 csq4(A).
 __global__ void __launch_bounds__(64)
-k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, uint32_t* __restrict__ out, const uint32_t* __restrict__ image64) {
+k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, uint32_t* __restrict__ out, const uint32_t* __restrict__ table_coop) {
   KYB_COOP_CONSTS(c, 1);
   const cq a = A[c.lane], b = B[c.lane];
   cq r = 0;
@@ -908,7 +920,7 @@ k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restri
   else if (op == 8) r = csq4(c, a);
   else if (op == 4) {
     const uint32_t pos = B[0], idx = B[1], neg = B[2];
-    r = pos < 42 ? coop_table_entry<32>(c, image64 + pos * KYB_BASE64_WIN_WORDS, idx, neg) : coop_table_entry<16>(c, image64 + KYB_BASE64_TOP_BASE, idx, 0u);
+    r = pos < 42 ? coop_table_entry<32>(c, table_coop + pos * KYB_COOP_WIN_WORDS, idx, neg) : coop_table_entry<16>(c, table_coop + 42 * KYB_COOP_WIN_WORDS, idx, 0u);
   } else if (op == 3) {
     r = coop_madd(c, madd_idx_init(c), a, b);
   } else if (op == 6) {
@@ -945,8 +957,8 @@ k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restri
 }
 
 namespace kyb { namespace launch {
-hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* image64) {
-  hipLaunchKernelGGL(k_coop_selftest, dim3(1), dim3(64), 0, st, op, A, B, out, image64);
+hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* table_coop) {
+  hipLaunchKernelGGL(k_coop_selftest, dim3(1), dim3(64), 0, st, op, A, B, out, table_coop);
   return hipGetLastError();
 }
 hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul, DoneFlag df,
@@ -977,8 +989,8 @@ hipError_t poly_eval_coop(hipStream_t st, const int32_t* commits, int t, const u
   return hipGetLastError();
 }
 hipError_t sign_coop(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, size_t n,
-                     uint8_t* sig, uint8_t* pub_out, const uint32_t* image64, DoneFlag df) {
-  hipLaunchKernelGGL(k_sign_coop, dim3((unsigned)n), dim3(512), 0, st, x, k, pubs, msgs, off, n, sig, pub_out, image64, df);
+                     uint8_t* sig, uint8_t* pub_out, const uint32_t* table_coop, DoneFlag df) {
+  hipLaunchKernelGGL(k_sign_coop, dim3((unsigned)n), dim3(512), 0, st, x, k, pubs, msgs, off, n, sig, pub_out, table_coop, df);
   return hipGetLastError();
 }
 hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, DoneFlag df) {
@@ -986,8 +998,8 @@ hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, 
   return hipGetLastError();
 }
 hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, int flavor,
-                       const uint32_t* image64, uint8_t* status, DoneFlag df) {
-  hipLaunchKernelGGL(k_verify_coop, dim3((unsigned)n), dim3(192), 0, st, pubs, sigs, msgs, off, n, flavor, image64, status, df);
+                       const uint32_t* table_coop, uint8_t* status, DoneFlag df) {
+  hipLaunchKernelGGL(k_verify_coop, dim3((unsigned)n), dim3(192), 0, st, pubs, sigs, msgs, off, n, flavor, table_coop, status, df);
   return hipGetLastError();
 }
 hipError_t poly_eval_seg(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, size_t per_poly, int len, int segs,
@@ -1004,9 +1016,9 @@ hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size
                      waves, ext_proj ? 1 : 0, part, df);
   return hipGetLastError();
 }
-hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
+hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* table_coop,
                          uint4* proj, size_t proj_stride, size_t proj_offset, const uint8_t* sc_b, size_t n_b, DoneFlag df, int waves, bool ext_proj) {
-  hipLaunchKernelGGL(k_mul_base_coop, dim3((unsigned)(n + n_b)), dim3(64u * (unsigned)waves), 0, st, sc, sc_b, n, n + n_b, oenc, oext, image64, proj, proj_stride, proj_offset,
+  hipLaunchKernelGGL(k_mul_base_coop, dim3((unsigned)(n + n_b)), dim3(64u * (unsigned)waves), 0, st, sc, sc_b, n, n + n_b, oenc, oext, table_coop, proj, proj_stride, proj_offset,
                      waves, ext_proj ? 1 : 0, df);
   return hipGetLastError();
 }

@@ -70,7 +70,10 @@ k_mont_prep(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ p
       const size_t i = j + (size_t)t * M;
       if (i < n) top |= reinterpret_cast<const uint32_t*>(scalars)[8 * i + 7] >> 28;
     }
-    if (top != 0u) atomicOr(top_or, top);
+    // one unconditional atomic per wavefront, by its first lane, with the wave-wide answer as DATA: no branch and no address depends on
+    // a scalar (tools/ct_check.py); what the launch learns — "some scalar of it is not canonical" — is the documented exception
+    const uint32_t any = __ballot(top != 0u) != 0ull ? 1u : 0u;
+    if ((threadIdx.x & 63u) == 0u) atomicOr(top_or, any);
   }
   auto load = [&](int t, fe& d) {
     const size_t i = j + (size_t)t * M;

@@ -41,6 +41,7 @@ namespace launch {
 // ---- kernels_base.hip / kernels_base_alt.hip ----
 hipError_t build_tables(uint32_t* table, hipStream_t st);                       // radix-16, -32 and -64 images, then the embedded checksum
 hipError_t table_checksum(const uint32_t* table, uint64_t* out_dev, hipStream_t st);   // out_dev[0] = checksum of the image (embed slot excluded)
+hipError_t build_coop_table(const uint32_t* image64, uint32_t* table_coop, hipStream_t st);      // entry-major copy of the radix-64 table for kernels_coop.hip
 hipError_t mul_base64(bool split, int block, int grid, hipStream_t st, const uint8_t* sc, const uint8_t* sc_b, size_t n_a, size_t n,
                       uint8_t* oenc, int32_t* oext, const uint4* img64, uint4* proj, size_t stride, size_t offset);
 hipError_t mul_base32(bool split, int grid, hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint4* img32,
@@ -77,10 +78,10 @@ hipError_t verify_prep_r_coop(hipStream_t st, const uint8_t* sigs, size_t n, uin
 hipError_t poly_eval_coop(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly,
                           uint8_t* oenc, int32_t* oext, DoneFlag df = DoneFlag{}, bool ext_proj = false);
 hipError_t sign_coop(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, size_t n,
-                     uint8_t* sig, uint8_t* pub_out, const uint32_t* image64, DoneFlag df = DoneFlag{});
+                     uint8_t* sig, uint8_t* pub_out, const uint32_t* table_coop, DoneFlag df = DoneFlag{});
 hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, DoneFlag df = DoneFlag{});
 hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, int flavor,
-                       const uint32_t* image64, uint8_t* status, DoneFlag df = DoneFlag{});
+                       const uint32_t* table_coop, uint8_t* status, DoneFlag df = DoneFlag{});
 // segs wavefronts (2..32) per evaluation, len coefficients each (segs * len >= t); part: n * segs * 40 words of device scratch
 hipError_t poly_eval_seg(hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, size_t per_poly, int len, int segs,
                          uint32_t* part, uint8_t* oenc, int32_t* oext, DoneFlag df = DoneFlag{}, bool ext_proj = false);
@@ -95,10 +96,10 @@ hipError_t sum_coop(hipStream_t st, const uint32_t* part, const int32_t* pts_ext
 hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul,
                        DoneFlag df = DoneFlag{}, bool ext_proj = false);
 // sc_b != nullptr: n_b more scalars follow the first n in the same launch (their results behind the first n)
-hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* image64,
+hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* table_coop,
                          uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, const uint8_t* sc_b = nullptr, size_t n_b = 0,
                          DoneFlag df = DoneFlag{}, int waves = 1, bool ext_proj = false);      // waves: 1, or 4 wavefronts per item sharing the 43 windows
-hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* image64);
+hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* table_coop);
 
 // ---- kernels_verify.hip ----
 hipError_t verify_prep(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,
