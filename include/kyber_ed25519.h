@@ -295,6 +295,23 @@ int kyb_pubpoly_eval_multi_enc_batch_dev(const uint8_t* commits_enc, size_t t, s
 int kyb_sum_enc_batch(const uint8_t* pts_enc, size_t m, size_t t, int item_major, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok);
 int kyb_sum_enc_batch_dev(const uint8_t* pts_enc, size_t m, size_t t, int item_major, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok, void* stream);
 
+/* ---- the verifier's side of one DKG round in ONE call ---------------------------------------------------------------------- */
+/* Every node of a Pedersen DKG receives m deals, each with its dealer's t commitments as 32-byte encodings (Deal.commitments,
+ * vss/pedersen/vss.rs:113-124), and needs two things from the same m x t points: dealer g's public polynomial evaluated at the node's own
+ * share index (vss.rs:904-909, PubPoly::eval, poly.rs:457-469) and the coefficient-wise sum over the dealers (the distributed public
+ * polynomial, dkg.rs:905-953 folding PubPoly::add, poly.rs:486-507).  kyb_pubpoly_eval_multi_enc_batch + kyb_sum_enc_batch do that
+ * in two calls that each move and decode the m x t encodings; this one moves and decodes them once.
+ *   commits_enc  m x t x 32, dealer after dealer, as received          index     the node's share index (x = index + 1)
+ *   eval_enc / eval_ext   m outputs: polynomial g at `index` (one of the two may be NULL)
+ *   sum_enc / sum_ext     t outputs: sum over the dealers of commitment j (both NULL: evaluations only)
+ *   ok           m x t flags (may be NULL): 0 = that encoding is not a point; it then counts as the neutral element in both results,
+ *                and the caller rejects the dealer as the reference's unmarshal error does
+ * index_dev (device flavour): m copies of `index` in device memory. */
+int kyb_dkg_verify_round_enc(const uint8_t* commits_enc, size_t t, size_t m, uint32_t index, uint8_t* eval_enc, int32_t* eval_ext,
+                             uint8_t* sum_enc, int32_t* sum_ext, uint8_t* ok);
+int kyb_dkg_verify_round_enc_dev(const uint8_t* commits_enc, size_t t, size_t m, const uint32_t* index_dev, uint32_t index, uint8_t* eval_enc,
+                                 int32_t* eval_ext, uint8_t* sum_enc, int32_t* sum_ext, uint8_t* ok, void* stream);
+
 /* ---- Point::eq, point.rs:227-241 -------------------------------------------- */
 /* eq[i] = 1 iff a[i] and b[i] have the same encoding (the reference compares the two encodings = two
  * inversions; here a projective cross-multiplication).  Records with Z = 0 (`Point::default()`) behave as in the

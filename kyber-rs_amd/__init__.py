@@ -44,6 +44,7 @@ ABI_SYMBOLS = [
     "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev",
     "kyb_sum_batch", "kyb_sum_batch_dev",
     "kyb_pubpoly_eval_multi_enc_batch", "kyb_pubpoly_eval_multi_enc_batch_dev", "kyb_sum_enc_batch", "kyb_sum_enc_batch_dev",
+    "kyb_dkg_verify_round_enc", "kyb_dkg_verify_round_enc_dev",
     "kyb_host_alloc", "kyb_host_free",
     "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
     "kyb_diag_mad_peak", "kyb_diag_wave_stamps",
@@ -140,6 +141,8 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_pubpoly_eval_multi_enc_batch_dev.argtypes = [vp, sz, sz, vp, sz, ctypes.c_uint32, vp, vp, vp, vp]
     lib.kyb_sum_enc_batch.argtypes = [vp, sz, sz, i32, vp, vp, vp]
     lib.kyb_sum_enc_batch_dev.argtypes = [vp, sz, sz, i32, vp, vp, vp, vp]
+    lib.kyb_dkg_verify_round_enc.argtypes = [vp, sz, sz, ctypes.c_uint32, vp, vp, vp, vp, vp]
+    lib.kyb_dkg_verify_round_enc_dev.argtypes = [vp, sz, sz, vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
     lib.kyb_equal_batch.argtypes = [vp, vp, sz, vp]
     lib.kyb_equal_batch_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.kyb_lincomb_batch.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp]
@@ -456,6 +459,18 @@ class Engine:
         ok = np.empty((m, t), dtype=np.uint8)
         _check(self.lib.kyb_pubpoly_eval_multi_enc_batch(_ptr(c), t, m, _ptr(idx), k, _ptr(enc), _ptr(ext), _ptr(ok)), "kyb_pubpoly_eval_multi_enc_batch")
         return (enc, ext, ok) if want_ext else (enc, ok)
+
+    def dkg_verify_round_enc(self, commits_enc, index: int, want_sums: bool = True):
+        """kyb_dkg_verify_round_enc: commits_enc (m, t, 32) as received -> (evaluations (m, 32) at `index`, column sums (t, 32) or None, ok (m, t))"""
+        c = np.ascontiguousarray(commits_enc, dtype=np.uint8)
+        if c.ndim != 3 or c.shape[2] != 32:
+            raise ValueError("commits_enc must have shape (m, t, 32)")
+        m, t = c.shape[0], c.shape[1]
+        ev = np.empty((m, 32), dtype=np.uint8)
+        sums = np.empty((t, 32), dtype=np.uint8) if want_sums else None
+        ok = np.empty((m, t), dtype=np.uint8)
+        _check(self.lib.kyb_dkg_verify_round_enc(_ptr(c), t, m, int(index), _ptr(ev), None, _ptr(sums), None, _ptr(ok)), "kyb_dkg_verify_round_enc")
+        return ev, sums, ok
 
     def sum_points_enc(self, pts_enc, item_major: bool = False, want_ext: bool = False):
         """sums of wire encodings: pts_enc (m, t, 32) -> out[g] = sum_j pts[g, j]; item_major: pts_enc (t, m, 32) -> out[g] = sum_j pts[j, g]

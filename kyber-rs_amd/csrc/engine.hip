@@ -921,15 +921,9 @@ int launch_lincomb(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t
   return launch_finish(g, r, m, oenc, oext, st, t, true);
 }
 
-// out[g] = sum_j P[g*t + j]: the halving passes of launch_lincomb on the points themselves.
-// penc != nullptr: the points come as wire encodings (decoded here, ok[i] per encoding, failed decodes = neutral element);
-// item_major (encodings only): point j of group g is encoding j*m + g — t dealers' polynomials of m coefficients each, as received.
-int launch_sum(Ctx& g, const int32_t* pext, const uint8_t* penc, uint8_t* ok, bool item_major, size_t m, size_t t, uint8_t* oenc, int32_t* oext, hipStream_t st) {
-  if (m == 0) return KYB_OK;
-  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
-  StreamRes* r = nullptr;
-  { int rc = res_for(g, st, &r); if (rc) return rc; }
-  SlotUse use(r, st);
+// (launch_mu held, slot in use)  ext_item_major: pext holds t rows of m points (point j of group g = record j*m + g), transposed on the way
+int sum_locked(Ctx& g, StreamRes* r, const int32_t* pext, const uint8_t* penc, uint8_t* ok, bool item_major, size_t m, size_t t, uint8_t* oenc, int32_t* oext,
+               hipStream_t st, bool ext_item_major = false) {
   const size_t n = m * t;
   const bool small = t <= 32 && m <= (size_t)g.opt_coop_base_max;
   if (penc != nullptr && small && !item_major) {
@@ -945,7 +939,7 @@ int launch_sum(Ctx& g, const int32_t* pext, const uint8_t* penc, uint8_t* ok, bo
     pext = dec;
     penc = nullptr;
   }
-  if (penc == nullptr && small) {
+  if (penc == nullptr && small && !ext_item_major) {
     // short sums of few groups: one group per wavefront, one launch
     ProfScope ps(g, st, KID_FINISH_COOP);
     LAUNCHCK(launch::sum_coop(st, nullptr, pext, m, t, oenc, oext, g.opt_ext_projective != 0, take_done_flag(g, st, m)));
@@ -956,10 +950,21 @@ int launch_sum(Ctx& g, const int32_t* pext, const uint8_t* penc, uint8_t* ok, bo
     ProfScope ps(g, st, KID_DECODE);
     LAUNCHCK(launch::decode_to_proj(st, penc, n, r->proj, r->proj_items, ok, item_major ? t : 0, item_major ? m : 0));
   } else {
-    LAUNCHCK(launch::ext_to_proj(st, pext, n, r->proj, r->proj_items));
+    LAUNCHCK(launch::ext_to_proj(st, pext, n, r->proj, r->proj_items, ext_item_major ? t : 0, ext_item_major ? m : 0));
   }
   { int rc = launch_pair_sums(g, r, m, t, st); if (rc) return rc; }
   return launch_finish(g, r, m, oenc, oext, st, t, true);
+}
+// out[g] = sum_j P[g*t + j]: the halving passes of launch_lincomb on the points themselves.
+// penc != nullptr: the points come as wire encodings (decoded here, ok[i] per encoding, failed decodes = neutral element);
+// item_major (encodings only): point j of group g is encoding j*m + g — t dealers' polynomials of m coefficients each, as received.
+int launch_sum(Ctx& g, const int32_t* pext, const uint8_t* penc, uint8_t* ok, bool item_major, size_t m, size_t t, uint8_t* oenc, int32_t* oext, hipStream_t st) {
+  if (m == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  return sum_locked(g, r, pext, penc, ok, item_major, m, t, oenc, oext, st);
 }
 
 // skip_hint: leading zero bits EVERY scalar of the call has (host-pointer calls of a few items look; 0 = unknown).  multipliers_public
@@ -1303,13 +1308,10 @@ int poly_batch_segments(const Ctx& g, size_t n, size_t t, int nbits) {
 
 // commits_enc != nullptr: the commitments as wire encodings (what a Deal carries), decoded here first; ok[i] per commitment,
 // a failed decode counts as the neutral element
-int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* idx, size_t n, uint32_t max_index, uint8_t* oenc, int32_t* oext, hipStream_t st,
-                     size_t per_poly = 0, const uint8_t* commits_enc = nullptr, uint8_t* ok = nullptr) {
-  if (n == 0) return KYB_OK;
-  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
-  StreamRes* r = nullptr;
-  { int rc = res_for(g, st, &r); if (rc) return rc; }
-  SlotUse use(r, st);
+// (launch_mu held, slot in use)  keep_commits: leave the decoded commitments in r->part for the caller (the combined DKG call sums them next);
+// last: nothing is queued behind this call's kernels (they may carry the completion flag)
+int poly_eval_locked(Ctx& g, StreamRes* r, const int32_t* commits, size_t t, const uint32_t* idx, size_t n, uint32_t max_index, uint8_t* oenc, int32_t* oext,
+                     hipStream_t st, size_t per_poly, const uint8_t* commits_enc, uint8_t* ok, const int32_t** decoded = nullptr, bool last = true) {
   if (commits_enc != nullptr) {
     const size_t np = t * (per_poly ? (n + per_poly - 1) / per_poly : 1);
     int rc = ensure_ws_part(g, r, np); if (rc) return rc;
@@ -1322,6 +1324,7 @@ int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* i
       LAUNCHCK(launch::decode_or_identity(st, commits_enc, np, dec, ok));
     }
     commits = dec;
+    if (decoded != nullptr) *decoded = dec;
   }
   int nbits = 1;
   while (nbits < 32 && ((uint64_t)max_index + 1) >> nbits) ++nbits;      // bit length of max x = max_index + 1
@@ -1341,7 +1344,7 @@ int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* i
         }
         rc = launch_ladder_core(g, part_sc, nullptr, part_ext, N, nullptr, r, st, 0, 1); if (rc) return rc;      // |multiplier| < 4L < 2^255
         rc = launch_pair_sums(g, r, n, (size_t)segs, st); if (rc) return rc;
-        return launch_finish(g, r, n, oenc, oext, st, (size_t)segs, true);
+        return launch_finish(g, r, n, oenc, oext, st, (size_t)segs, last);
       }
     }
   }
@@ -1360,12 +1363,12 @@ int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* i
       const int len = (int)((t + (size_t)segs - 1) / (size_t)segs);
       int rc = ensure_enc(g, r, 160 * n * (size_t)segs + 256); if (rc) return rc;
       ProfScope ps(g, st, KID_POLY_EVAL_COOP);
-      LAUNCHCK(launch::poly_eval_seg(st, commits, (int)t, idx, n, per_poly, len, segs, reinterpret_cast<uint32_t*>(r->enc), oenc, oext, take_done_flag(g, st, n),
+      LAUNCHCK(launch::poly_eval_seg(st, commits, (int)t, idx, n, per_poly, len, segs, reinterpret_cast<uint32_t*>(r->enc), oenc, oext, (last ? take_done_flag(g, st, n) : launch::DoneFlag{}),
                                      g.opt_ext_projective != 0));
       return KYB_OK;
     }
     ProfScope ps(g, st, KID_POLY_EVAL_COOP);
-    LAUNCHCK(launch::poly_eval_coop(st, commits, (int)t, idx, n, nbits, per_poly, oenc, oext, take_done_flag(g, st, n), g.opt_ext_projective != 0));
+    LAUNCHCK(launch::poly_eval_coop(st, commits, (int)t, idx, n, nbits, per_poly, oenc, oext, (last ? take_done_flag(g, st, n) : launch::DoneFlag{}), g.opt_ext_projective != 0));
     return KYB_OK;
   }
   const bool split = use_split(g, n);
@@ -1374,8 +1377,39 @@ int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* i
     ProfScope ps(g, st, KID_POLY_EVAL);
     LAUNCHCK(launch::poly_eval(split, st, commits, (int)t, idx, n, nbits, per_poly, oenc, oext, r->proj, r->proj_items));
   }
-  if (split) return launch_finish(g, r, n, oenc, oext, st, 1, true);
+  if (split) return launch_finish(g, r, n, oenc, oext, st, 1, last);
   return KYB_OK;
+}
+
+
+// commits_enc != nullptr: the commitments as wire encodings (what a Deal carries), decoded here first; ok[i] per commitment,
+// a failed decode counts as the neutral element
+int launch_poly_eval(Ctx& g, const int32_t* commits, size_t t, const uint32_t* idx, size_t n, uint32_t max_index, uint8_t* oenc, int32_t* oext, hipStream_t st,
+                     size_t per_poly = 0, const uint8_t* commits_enc = nullptr, uint8_t* ok = nullptr) {
+  if (n == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  return poly_eval_locked(g, r, commits, t, idx, n, max_index, oenc, oext, st, per_poly, commits_enc, ok);
+}
+
+// The verifier's curve work of one DKG round on the deals as they arrive (vss/pedersen/vss.rs:904-909 + dkg.rs:905-953): the m dealers'
+// t commitments each are decoded ONCE; dealer g's polynomial is evaluated at `index` (eval outputs, m of them) and coefficient j is summed
+// over the dealers (the distributed public polynomial, t outputs).  idx_dev: m copies of `index` in device memory.
+int launch_dkg_round(Ctx& g, const uint8_t* commits_enc, size_t t, size_t m, const uint32_t* idx_dev, uint32_t index, uint8_t* eval_enc, int32_t* eval_ext,
+                     uint8_t* sum_enc, int32_t* sum_ext, uint8_t* ok, hipStream_t st) {
+  if (m == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  const int32_t* dec = nullptr;
+  const bool want_sum = sum_enc != nullptr || sum_ext != nullptr;
+  int rc = poly_eval_locked(g, r, nullptr, t, idx_dev, m, index, eval_enc, eval_ext, st, 1, commits_enc, ok, &dec, !want_sum);
+  if (rc || !want_sum) return rc;
+  // the decoded commitments are still in r->part (dealer-major): sum the columns — groups of m records after the transposition
+  return sum_locked(g, r, dec, nullptr, nullptr, false, t, m, sum_enc, sum_ext, st, true);
 }
 
 }  // namespace

@@ -148,13 +148,16 @@ k_pair_sum(uint4* __restrict__ proj, size_t stride, size_t m, size_t gstride, si
 }
 
 // extended limbs -> projective staging records (input of the k_pair_sum passes of kyb_sum_batch)
+// rows > 0: the points form a rows x cols matrix (row-major) and the records its transpose (as k_decode_to_proj)
 __global__ void __launch_bounds__(KYB_BLOCK)
-k_ext_to_proj(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ proj, size_t stride) {
+k_ext_to_proj(const int32_t* __restrict__ pts_ext, size_t n, uint4* __restrict__ proj, size_t stride, size_t rows, size_t cols) {
   const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (i >= n) return;
   ge_p3 P;
   load_ext(P, pts_ext, i);
-  store_proj(proj, stride, i, P.X, P.Y, P.Z);
+  size_t d = i;
+  if (rows != 0) { const size_t rr = i / cols, cc = i - rr * cols; d = cc * rows + rr; }
+  store_proj(proj, stride, d, P.X, P.Y, P.Z);
 }
 
 
@@ -185,8 +188,8 @@ hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t
   hipLaunchKernelGGL(k_pair_sum, dim3(blocks_for(lanes)), dim3(KYB_BLOCK), 0, st, proj, stride, m, gstride, len, half);
   return hipGetLastError();
 }
-hipError_t ext_to_proj(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride) {
-  hipLaunchKernelGGL(k_ext_to_proj, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, pext, n, proj, stride);
+hipError_t ext_to_proj(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride, size_t rows, size_t cols) {
+  hipLaunchKernelGGL(k_ext_to_proj, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, pext, n, proj, stride, rows, cols);
   return hipGetLastError();
 }
 hipError_t diag_stamps_ladder(uint64_t* buf) { return kyb_set_stamp_slot(buf); }

@@ -101,3 +101,30 @@ def test_wire_format_bad_arguments(engine):
     assert lib.kyb_pubpoly_eval_multi_enc_batch(p(z), 2, 2, p(idx), 1, None, None, None) != 0
     idx[0] = 0xffffffff
     assert lib.kyb_pubpoly_eval_multi_enc_batch(p(z), 2, 2, p(idx), 1, p(out), None, None) != 0   # index + 1 must fit 32 bits
+
+
+@pytest.mark.parametrize("m,t", [(1, 1), (5, 3), (16, 11), (64, 43), (300, 201), (40, 700)])
+def test_dkg_round_in_one_call(engine, oracle, m, t):
+    """kyb_dkg_verify_round_enc: the m x t commitments decoded once, every dealer's polynomial evaluated at the node's index AND the columns
+    summed == the two separate wire-format calls == the oracle (decode, then PubPoly::eval / add), with encodings the reference rejects,
+    non-canonical forms it accepts and small-order points in the mix"""
+    ext, enc = _points(oracle, m * t, 900 + m)
+    enc, ext, want_ok = _spoil(oracle, enc, ext)
+    index = (m * 7 + t) % 1500
+    ev, sums, ok = engine.dkg_verify_round_enc(enc.reshape(m, t, 32), index)
+    assert np.array_equal(ok.reshape(-1), want_ok)
+    ev2, ok2 = engine.pubpoly_eval_multi_enc(enc.reshape(m, t, 32), np.full((m, 1), index, dtype=np.uint32))
+    assert np.array_equal(ev, ev2[:, 0]) and np.array_equal(ok2, ok)
+    sums2, _ = engine.sum_points_enc(enc.reshape(m, t, 32), item_major=True)
+    assert np.array_equal(sums, sums2)
+    E = ext.reshape(m, t, 40)
+    for g in sorted({0, m // 2, m - 1}):
+        assert bytes(ev[g]) == oracle.pubpoly_eval(E[g], index), (g, "eval")
+    for j in sorted({0, t // 2, t - 1}):
+        acc = E[0, j]
+        for g in range(1, m):
+            acc = oracle.add(acc, E[g, j])
+        assert bytes(sums[j]) == oracle.encode(acc), (j, "sum")
+    # evaluations only
+    ev3, none, _ = engine.dkg_verify_round_enc(enc.reshape(m, t, 32), index, want_sums=False)
+    assert none is None and np.array_equal(ev3, ev)

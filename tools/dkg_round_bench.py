@@ -100,8 +100,11 @@ for n in args.n:
     assert np.array_equal(ev_w, ev) and ok_w.all()
     (dist_w, ok_w), dist_wire_ms = timed(lambda: eng.sum_points_enc(polys_enc, item_major=True))
     assert np.array_equal(dist_w, dist) and ok_w.all()
+    (ev_1, dist_1, ok_1), round_wire_ms = timed(lambda: eng.dkg_verify_round_enc(polys_enc, me_i))      # both from ONE transfer and ONE decode
+    assert np.array_equal(ev_1, ev[:, 0]) and np.array_equal(dist_1, dist) and ok_1.all()
     assert bytes(commit_enc[1]) == orc.mul(bytes(coeffs[1]), orc.base()) and bytes(dh[3]) == orc.mul(bytes(longterm[0]), orc.decode(bytes(pubs[3]))[0])
     gpu_ms = sum(br.values())
     cpu_ms = t * cpu["mul"] + n * (cpu["sign"] + cpu["mul"]) + n * (cpu["verify"] + cpu["mul"]) + n * (cpu["mul_base"] + t * cpu["eval_per_coeff"]) + n * t * 0.0005
     print(f"{n}, {t}, {gpu_ms:.2f}, {cpu_ms:.0f}, {cpu_ms / gpu_ms:.0f}x, " + " ".join(f"{k}={v:.2f}" for k, v in br.items()) + f" (eval one per lane: {eval_batch_ms:.2f}, one per wavefront: {eval_coop_ms:.2f})"
-          + f"   [wire: {gpu_ms - br['eval'] - br['dist_poly'] + eval_wire_ms + dist_wire_ms:.2f} ms, eval={eval_wire_ms:.2f} dist_poly={dist_wire_ms:.2f}; CPU {cpu_ms + n * t * cpu['unmarshal']:.0f} ms]", flush=True)
+          + f"   [wire: {gpu_ms - br['eval'] - br['dist_poly'] + eval_wire_ms + dist_wire_ms:.2f} ms, eval={eval_wire_ms:.2f} dist_poly={dist_wire_ms:.2f}; "
+          + f"one call (kyb_dkg_verify_round_enc): {gpu_ms - br['eval'] - br['dist_poly'] + round_wire_ms:.2f} ms, eval+dist_poly={round_wire_ms:.2f}; CPU {cpu_ms + n * t * cpu['unmarshal']:.0f} ms]", flush=True)
