@@ -271,6 +271,17 @@ int kyb_lincomb_batch(const uint8_t* scalars, const uint8_t* pts_enc, const int3
 int kyb_lincomb_batch_dev(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, int shared_points,
                           size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok, void* stream);
 
+/* The same linear combinations for scalars the CALLER DECLARES PUBLIC — the Lagrange basis coefficients of recover_pub_poly
+ * (poly.rs:607-668) and the Lagrange coefficients of recover_commit (poly.rs:580-594) are functions of public share indices.  With
+ * shared_points = 1 and enough outputs to pay for it (m >= 16, m * t >= 8192, t <= 8192) every point gets a table of its radix-64 window
+ * multiples on the GPU and a product costs 43 table additions instead of a 255-step ladder (t = m = 683: several times faster); table
+ * addresses and skipped zero digits depend on the scalars, so NEVER pass a secret here.  Every other shape takes kyb_lincomb_batch's
+ * constant-time path.  Same results as kyb_lincomb_batch, also on small-order and mixed-order points. */
+int kyb_lincomb_public_batch(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, int shared_points,
+                             size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok);
+int kyb_lincomb_public_batch_dev(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, int shared_points,
+                                 size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok, void* stream);
+
 /* Sums of points without scalars: out[g] = sum_{j<t} pts[g*t + j] (m groups of t points, extended limbs).  The
  * distributed public polynomial of a DKG round is the coefficient-wise sum of the dealers' commitment polynomials
  * (dkg.rs:905-953 applies PubPoly::add, poly.rs:486-507, dealer after dealer): m = threshold, t = number of dealers,

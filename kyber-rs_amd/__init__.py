@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "kyb_schnorr_sign_keyed_batch", "kyb_schnorr_sign_keyed_batch_dev", "kyb_eddsa_sign_keyed_batch", "kyb_eddsa_sign_keyed_batch_dev",
     "kyb_verify_batch", "kyb_verify_batch_dev", "kyb_pubpoly_eval_batch", "kyb_pubpoly_eval_batch_dev",
     "kyb_pubpoly_eval_multi_batch", "kyb_pubpoly_eval_multi_batch_dev",
-    "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev",
+    "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev", "kyb_lincomb_public_batch", "kyb_lincomb_public_batch_dev",
     "kyb_sum_batch", "kyb_sum_batch_dev",
     "kyb_pubpoly_eval_multi_enc_batch", "kyb_pubpoly_eval_multi_enc_batch_dev", "kyb_sum_enc_batch", "kyb_sum_enc_batch_dev",
     "kyb_dkg_verify_round_enc", "kyb_dkg_verify_round_enc_dev",
@@ -147,6 +147,8 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_equal_batch_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.kyb_lincomb_batch.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp]
     lib.kyb_lincomb_batch_dev.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp, vp]
+    lib.kyb_lincomb_public_batch.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp]
+    lib.kyb_lincomb_public_batch_dev.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp, vp]
     lib.kyb_set_option.argtypes = [ctypes.c_char_p, i32]
     lib.kyb_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(i32)]
     lib.kyb_host_alloc.argtypes = [sz]
@@ -498,7 +500,7 @@ class Engine:
             return ext
         return (enc, ext) if want_ext else enc
 
-    def lincomb(self, scalars, pts_ext=None, pts_enc=None, want_ext: bool = False, want_ok: bool = False):
+    def lincomb(self, scalars, pts_ext=None, pts_enc=None, want_ext: bool = False, want_ok: bool = False, public: bool = False):
         """out[g] = sum_j scalars[g, j] * P[g, j]  (points of shape (m, t, ..)) or * P[j] (points of shape (t, ..), shared
         by all groups) -- recover_commit / recover_pub_poly / PubPoly::add accumulation, poly.rs:486-507, 566-634"""
         sc = np.ascontiguousarray(scalars, dtype=np.uint8)
@@ -522,8 +524,9 @@ class Engine:
         enc = np.empty((m, 32), dtype=np.uint8)
         ext = np.empty((m, 40), dtype=np.int32) if want_ext else None
         ok = np.empty((t if shared else m * t,), dtype=np.uint8) if want_ok else None
-        _check(self.lib.kyb_lincomb_batch(_ptr(sc), _ptr(pts) if pts_enc is not None else None, _ptr(pts) if pts_ext is not None else None,
-                                          shared, m, t, _ptr(enc), _ptr(ext), _ptr(ok)), "kyb_lincomb_batch")
+        fn = self.lib.kyb_lincomb_public_batch if public else self.lib.kyb_lincomb_batch      # public: the scalars are declared public (point tables)
+        _check(fn(_ptr(sc), _ptr(pts) if pts_enc is not None else None, _ptr(pts) if pts_ext is not None else None,
+                  shared, m, t, _ptr(enc), _ptr(ext), _ptr(ok)), "kyb_lincomb_batch")
         out = (enc,)
         if want_ext:
             out += (ext,)

@@ -41,9 +41,9 @@ thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
 enum KernelId { KID_MUL, KID_MUL_BASE, KID_FINISH, KID_SIGN, KID_SIGN_HASH, KID_VERIFY_PREP, KID_VERIFY_FINAL, KID_POLY_EVAL, KID_MONT_PREP,
-                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_VERIFY_COOP, KID_FINISH_COOP, KID_SIGN_COOP, KID_COUNT };
+                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_VERIFY_COOP, KID_FINISH_COOP, KID_SIGN_COOP, KID_MSM_TABLES, KID_MSM_ACCUMULATE, KID_COUNT };
 const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval",
-                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop", "k_verify_coop", "k_finish_coop", "k_sign_coop"};
+                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop", "k_verify_coop", "k_finish_coop", "k_sign_coop", "k_msm_tables", "k_msm_accumulate"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   std::mutex mu;                  // begin / read / every ProfScope: callable from any thread
@@ -63,6 +63,7 @@ struct StreamRes {
   hipStream_t stream = nullptr;
   uint4* ws = nullptr; uint4* proj = nullptr; size_t proj_items = 0; uint8_t* enc = nullptr; size_t enc_bytes = 0;
   uint32_t* part = nullptr; size_t part_items = 0;      // extended quads of a small linear combination's products
+  uint32_t* msm = nullptr; size_t msm_points = 0;        // kyb_lincomb_public_batch over shared points: window bases + tables of the points (221,760 B per point)
   uint32_t* top_or = nullptr; unsigned top_seq = 0;     // two alternating words behind the projective staging records (k_mont_prep / k_mul_ladder)
   hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_last = nullptr;
   bool used = false, own = false;
@@ -606,6 +607,7 @@ void free_slot(StreamRes* r) {
   if (r->proj) wipe_free_dev(r->proj, r->proj_items * 8 * sizeof(uint4));
   if (r->enc) wipe_free_dev(r->enc, r->enc_bytes);
   if (r->part) wipe_free_dev(r->part, r->part_items * 160);
+  if (r->msm) (void)hipFree(r->msm);
   if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->ev_fork); (void)hipEventDestroy(r->ev_join); }
   if (r->ev_last) (void)hipEventDestroy(r->ev_last);
   delete r;
@@ -674,6 +676,19 @@ int ensure_ws_part(Ctx& g, StreamRes* r, size_t items) {
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->part), want * 160);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "product staging allocation", e);
   r->part_items = want;
+  return KYB_OK;
+}
+constexpr size_t MSM_BASE_WORDS = 43 * 40, MSM_TAB_WORDS = 43 * 32 * 40;      // per point
+int ensure_msm(Ctx& g, StreamRes* r, size_t points) {
+  (void)g;
+  if (points <= r->msm_points) return KYB_OK;
+  HIPCK(hipStreamSynchronize(r->stream));
+  if (r->msm) (void)hipFree(r->msm);
+  r->msm = nullptr; r->msm_points = 0;
+  const size_t want = points + (points >> 3) + 16;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->msm), want * (MSM_BASE_WORDS + MSM_TAB_WORDS) * sizeof(uint32_t));
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "point table allocation", e);
+  r->msm_points = want;
   return KYB_OK;
 }
 int ensure_enc(Ctx& g, StreamRes* r, size_t bytes) {
@@ -955,6 +970,45 @@ int sum_locked(Ctx& g, StreamRes* r, const int32_t* pext, const uint8_t* penc, u
   { int rc = launch_pair_sums(g, r, m, t, st); if (rc) return rc; }
   return launch_finish(g, r, m, oenc, oext, st, t, true);
 }
+// kyb_lincomb_public_batch: the same sums for scalars the caller declares PUBLIC.  Over shared points with enough outputs to pay for them,
+// every point gets a table of the multiples 1 .. 32 of its 43 radix-64 window bases (kernels_msm.hip) and a product costs 43 table
+// additions instead of a 255-step ladder; anything else takes the constant-time path.
+int launch_lincomb_public(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pext, bool shared, size_t m, size_t t, uint8_t* ok,
+                          uint8_t* oenc, int32_t* oext, hipStream_t st) {
+  if (m == 0) return KYB_OK;
+  const bool tables = shared && g.opt_mul_algo == 1 && m >= 16 && t >= 2 && t <= 8192 && m * t >= 8192;
+  if (!tables) return launch_lincomb(g, sc, penc, pext, shared, m, t, ok, oenc, oext, st);
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  if (penc != nullptr) {           // unmarshal_binary of the shared points first (ok flags; failed decodes become the neutral element)
+    int rc = ensure_enc(g, r, 160 * t + 256); if (rc) return rc;
+    int32_t* tmp = reinterpret_cast<int32_t*>(r->enc);
+    if (t <= (size_t)g.opt_coop_decode_max) { ProfScope ps(g, st, KID_DECODE_COOP); LAUNCHCK(launch::decode_coop(st, penc, t, tmp, ok, true)); }
+    else { ProfScope ps(g, st, KID_DECODE); LAUNCHCK(launch::decode_or_identity(st, penc, t, tmp, ok)); }
+    pext = tmp;
+  } else if (ok != nullptr) {
+    HIPCK(hipMemsetAsync(ok, 1, t, st));
+  }
+  int rc = ensure_msm(g, r, t); if (rc) return rc;
+  uint32_t* bases = r->msm;
+  uint32_t* tab = r->msm + r->msm_points * MSM_BASE_WORDS;
+  // lanes of the accumulation: about two wavefronts per SIMD; a lane takes `chunk` points of one output
+  size_t chunk = (m * t + 131071) / 131072;
+  if (chunk < 2) chunk = 2;
+  if (chunk > t) chunk = t;
+  const size_t nchunks = (t + chunk - 1) / chunk;
+  rc = ensure_proj(g, r, m * nchunks); if (rc) return rc;
+  { ProfScope ps(g, st, KID_MSM_TABLES);
+    LAUNCHCK(launch::msm_bases_coop(st, pext, t, bases));
+    LAUNCHCK(launch::msm_tables(st, bases, t, tab)); }
+  { ProfScope ps(g, st, KID_MSM_ACCUMULATE);
+    LAUNCHCK(launch::msm_accumulate(st, sc, tab, m, t, (int)chunk, nchunks, r->proj, r->proj_items)); }
+  rc = launch_pair_sums(g, r, m, nchunks, st); if (rc) return rc;
+  return launch_finish(g, r, m, oenc, oext, st, nchunks, true);
+}
+
 // out[g] = sum_j P[g*t + j]: the halving passes of launch_lincomb on the points themselves.
 // penc != nullptr: the points come as wire encodings (decoded here, ok[i] per encoding, failed decodes = neutral element);
 // item_major (encodings only): point j of group g is encoding j*m + g — t dealers' polynomials of m coefficients each, as received.

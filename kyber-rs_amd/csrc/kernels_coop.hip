@@ -381,6 +381,29 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
   if (c.lane == 0) signal_done(df);
 }
 
+// kyb_lincomb_public_batch, shared points (kernels_msm.hip): the window bases 64^w P for w = 0 .. 42 of one point per wavefront — 252
+// cooperative doublings, a dependent chain of 0.1 ms where one lane would need 0.6 — as raw extended quads (40 tight limbs each).
+__global__ void __launch_bounds__(64)
+k_msm_bases_coop(const int32_t* __restrict__ pts_ext, size_t t, uint32_t* __restrict__ bases) {
+  const size_t j = blockIdx.x;
+  if (j >= t) return;
+  KYB_COOP_CONSTS(c, 1);
+  const uint32_t word = c.active ? (uint32_t)pts_ext[40 * j + 10 * c.row + c.k] : 0u;
+  cq PQ = cnorm(c, c.active ? word + (c.p2 << 3) : 0u);                 // fe_from_ref10: signed limb + 16p, one carry pass
+  // (the T an input carries is not trusted to be X Y / Z: rebuilt from X, Y, Z as the product kernels do)
+  {
+    const cq zz = bperm(rowperm_idx(c, 2, 2, 2, 2), PQ), xy = bperm(rowperm_idx(c, 0, 1, 2, 0), PQ), yy = bperm(rowperm_idx(c, 1, 1, 1, 1), PQ);
+    PQ = cmul4(c, xy, c.row == 3 ? yy : zz);                             // (X Z : Y Z : Z^2 : X Y)
+  }
+#pragma unroll 1
+  for (int w = 0; w < 43; ++w) {
+    if (c.active) bases[(j * 43 + (size_t)w) * 40 + 10 * c.row + c.k] = PQ;
+    if (w == 42) break;
+#pragma unroll 1
+    for (int d = 0; d < 6; ++d) PQ = coop_dbl(c, PQ);
+  }
+}
+
 // h + E for h = (X : Y : Z : T) in rows 0..3 and an affine table entry E = (y+x, y-x, 2dxy, 0): ge_madd followed by
 // ge_p1p1_to_p3 (ge25519.h), two cooperative multiplication levels.
 struct madd_idx { int I_1133, I_0000, I_2222, I_1122; };
@@ -957,6 +980,10 @@ k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restri
 }
 
 namespace kyb { namespace launch {
+hipError_t msm_bases_coop(hipStream_t st, const int32_t* pts_ext, size_t t, uint32_t* bases) {
+  hipLaunchKernelGGL(k_msm_bases_coop, dim3((unsigned)t), dim3(64), 0, st, pts_ext, t, bases);
+  return hipGetLastError();
+}
 hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* table_coop) {
   hipLaunchKernelGGL(k_coop_selftest, dim3(1), dim3(64), 0, st, op, A, B, out, table_coop);
   return hipGetLastError();

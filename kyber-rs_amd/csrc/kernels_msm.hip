@@ -1,0 +1,114 @@
+// Linear combinations over SHARED points with PUBLIC scalars (one of the translation units mapped in launch.h):
+//   out[g] = sum_{j < t} s[g][j] * P[j],   g < m                                     recover_pub_poly, share/poly.rs:607-634
+// The reference performs the m * t multiplications one by one with its 64-window routine; kyb_lincomb_batch runs them as m * t
+// constant-time ladders.  When the caller DECLARES the scalars public (kyb_lincomb_public_batch: Lagrange basis coefficients of
+// public share indices) the t points are worth a table each, shared by all m outputs:
+//   k_msm_bases_coop  (kernels_coop.hip)  64^w P_j, w = 0 .. 42: one wavefront per point, 252 cooperative doublings
+//   k_msm_tables      T[j][w][e] = (e + 1) * 64^w * P_j, e = 0 .. 31, as cached elements (Y+X, Y-X, Z, 2dT): one lane per (j, w), 31 additions
+//   k_msm_accumulate  one lane per (output g, chunk of points): signed radix-64 digits d in -32 .. 31 of the integer the reference
+//                     multiplies by (sc_effective: the scalar as stored, top-digit quirk included), one table addition per non-zero
+//                     digit — 43 additions per product where the ladder has 255 steps of the same size; the chunk's partial sum
+//                     goes to the projective staging buffer, k_pair_sum and k_finish (the constant-time path's own tail) do the rest.
+// Exact on every curve point (the complete addition law; small-order and mixed-order points included).  NOT constant time: table
+// addresses and the skipped zero digits depend on the scalars — which is why the entry point exists only in a "public" form.
+#include <hip/hip_runtime.h>
+#include "launch.h"
+#include "ge_scalarmult.h"
+using namespace kyb;
+#include "device_tables.h"
+
+constexpr int MSM_WINDOWS = 43, MSM_ENTRIES = 32;
+
+__device__ __forceinline__ void msm_load40(uint32_t f[40], const uint32_t* __restrict__ p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) { const uint4 v = q[i]; f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w; }
+}
+__device__ __forceinline__ void msm_store_cached(uint32_t* __restrict__ p, const ge_cached& c) {
+  uint32_t f[40];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { f[k] = c.YpX.v[k]; f[10 + k] = c.YmX.v[k]; f[20 + k] = c.Z.v[k]; f[30 + k] = c.T2d.v[k]; }
+  uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) q[i] = make_uint4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+}
+
+// lane (w, j), w-major: the lanes of a wavefront share their window
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_msm_tables(const uint32_t* __restrict__ bases, size_t t, uint32_t* __restrict__ tab) {
+  const size_t id = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (id >= t * MSM_WINDOWS) return;
+  const size_t w = id / t, j = id - w * t;
+  uint32_t f[40];
+  msm_load40(f, bases + (j * MSM_WINDOWS + w) * 40);
+  ge_p3 E;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { E.X.v[k] = f[k]; E.Y.v[k] = f[10 + k]; E.Z.v[k] = f[20 + k]; E.T.v[k] = f[30 + k]; }
+  ge_cached B, c;
+  ge_p3_to_cached(B, E);
+  fe_reduce_weak(B.YpX, B.YpX); fe_reduce_weak(B.YmX, B.YmX); fe_reduce_weak(B.T2d, B.T2d);      // tight: inside every bound ge_add states
+  uint32_t* out = tab + ((j * MSM_WINDOWS + w) * MSM_ENTRIES) * 40;
+  msm_store_cached(out, B);
+#pragma unroll 1
+  for (int e = 1; e < MSM_ENTRIES; ++e) {
+    ge_p1p1 r;
+    ge_add(r, E, B);
+    ge_p1p1_to_p3_after_add(E, r);
+    ge_p3_to_cached(c, E);
+    fe_reduce_weak(c.YpX, c.YpX); fe_reduce_weak(c.YmX, c.YmX); fe_reduce_weak(c.T2d, c.T2d);
+    msm_store_cached(out + 40 * e, c);
+  }
+}
+
+// lane (chunk, g), chunk-major: the lanes of a wavefront walk the same points' tables
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_msm_accumulate(const uint8_t* __restrict__ scalars, const uint32_t* __restrict__ tab, size_t m, size_t t, int chunk, size_t nchunks,
+                 uint4* __restrict__ proj, size_t stride) {
+  const size_t id = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (id >= m * nchunks) return;
+  const size_t c = id / m, g = id - c * m;
+  const size_t j_lo = c * (size_t)chunk, j_hi = (j_lo + (size_t)chunk < t) ? j_lo + (size_t)chunk : t;
+  ge_p3 acc;
+  ge_p3_0(acc);
+#pragma unroll 1
+  for (size_t j = j_lo; j < j_hi; ++j) {
+    uint32_t a[8], neg, mag[8];
+    load_words8(a, scalars, g * t + j);
+    sc_effective(neg, mag, a);                       // the integer the reference multiplies by (|.| < 9 * 2^252), and its sign
+    const uint32_t* tj = tab + (j * MSM_WINDOWS) * MSM_ENTRIES * 40;
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (int w = 0; w < MSM_WINDOWS; ++w) {
+      const uint32_t raw = (mag[0] & 63u) + carry;   // 0 .. 64
+      KYB_UNROLL for (int i = 0; i < 7; ++i) mag[i] = (mag[i] >> 6) | (mag[i + 1] << 26);
+      mag[7] >>= 6;
+      carry = raw >= 32u ? 1u : 0u;
+      const int d = (int)raw - (int)(carry << 6);    // -32 .. 31
+      if (d == 0) continue;                          // public scalars: nothing to hide
+      const uint32_t dneg = (uint32_t)(d < 0) ^ neg;
+      const uint32_t idx = (uint32_t)(d < 0 ? -d : d) - 1u;
+      uint32_t f[40];
+      msm_load40(f, tj + ((size_t)w * MSM_ENTRIES + idx) * 40);
+      ge_cached q;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) { q.YpX.v[k] = f[k]; q.YmX.v[k] = f[10 + k]; q.Z.v[k] = f[20 + k]; q.T2d.v[k] = f[30 + k]; }
+      ge_cached_cneg(q, dneg);
+      ge_p1p1 r;
+      ge_add(r, acc, q);
+      ge_p1p1_to_p3_after_add(acc, r);
+    }
+  }
+  store_proj(proj, stride, g * nchunks + c, acc.X, acc.Y, acc.Z);
+}
+
+namespace kyb { namespace launch {
+static inline unsigned blocks_for(size_t n) { return (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK); }
+hipError_t msm_tables(hipStream_t st, const uint32_t* bases, size_t t, uint32_t* tab) {
+  hipLaunchKernelGGL(k_msm_tables, dim3(blocks_for(t * MSM_WINDOWS)), dim3(KYB_BLOCK), 0, st, bases, t, tab);
+  return hipGetLastError();
+}
+hipError_t msm_accumulate(hipStream_t st, const uint8_t* scalars, const uint32_t* tab, size_t m, size_t t, int chunk, size_t nchunks, uint4* proj, size_t stride) {
+  hipLaunchKernelGGL(k_msm_accumulate, dim3(blocks_for(m * nchunks)), dim3(KYB_BLOCK), 0, st, scalars, tab, m, t, chunk, nchunks, proj, stride);
+  return hipGetLastError();
+}
+}}  // namespace kyb::launch

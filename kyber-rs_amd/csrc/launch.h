@@ -1,4 +1,4 @@
-// Host-callable launchers of every kernel group.  The library is built from eight translation units that hipcc
+// Host-callable launchers of every kernel group.  The library is built from nine translation units that hipcc
 // compiles in parallel (csrc/Makefile):
 //
 //   kernels_base.hip      fixed base: table builders, table checksum, k_mul_base64 (the default fixed-base kernel)
@@ -7,6 +7,7 @@
 //   kernels_window.hip    windowed variable-base k_mul (mul.algo=0, cross-check of the ladder)
 //   kernels_verify.hip    SHA-512 users: k_verify_prep / _r / _final, k_sign_hash, k_eddsa_prep
 //   kernels_misc.hip      k_finish, k_encode_batched, k_add, k_equal, k_encode, k_decode, k_poly_eval, k_poly_eval_part
+//   kernels_msm.hip       linear combinations over shared points with PUBLIC scalars: k_msm_tables, k_msm_accumulate (+ k_msm_bases_coop in kernels_coop.hip)
 //   kernels_coop.hip      small batches: one item per wavefront (or two / three wavefronts per item), lane-cooperative field arithmetic:
 //                         k_mul_coop, k_mul_enc_coop, k_mul_base_coop, k_decode_coop, k_finish_coop, k_verify_coop, k_verify_prep(_r)_coop, k_poly_eval_coop
 //   engine.hip            contexts, per-stream scratch, launch sequences, host-pointer pipeline, multi-device groups, C ABI
@@ -125,6 +126,13 @@ hipError_t encode(hipStream_t st, const int32_t* pext, size_t n, uint8_t* oenc);
 hipError_t decode(hipStream_t st, const uint8_t* enc, size_t n, int32_t* out_ext, uint8_t* ok);
 hipError_t poly_eval(bool split, hipStream_t st, const int32_t* commits, int t, const uint32_t* idx, size_t n, int nbits, size_t per_poly,
                      uint8_t* oenc, int32_t* oext, uint4* proj, size_t stride);
+
+// ---- kernels_msm.hip (+ msm_bases_coop in kernels_coop.hip): kyb_lincomb_public_batch over shared points ----
+// bases: t x 43 x 40 words (64^w P_j as raw extended quads); tab: t x 43 x 32 x 40 words (cached multiples 1 .. 32 of every base);
+// partial sums of output g land in staging records g * nchunks + c
+hipError_t msm_bases_coop(hipStream_t st, const int32_t* pts_ext, size_t t, uint32_t* bases);
+hipError_t msm_tables(hipStream_t st, const uint32_t* bases, size_t t, uint32_t* tab);
+hipError_t msm_accumulate(hipStream_t st, const uint8_t* scalars, const uint32_t* tab, size_t m, size_t t, int chunk, size_t nchunks, uint4* proj, size_t stride);
 
 // benchmark diagnostic (kyb_diag_wave_stamps, diag_stamp.h): the five 64-bit sums into which the wavefronts of k_mul_ladder /
 // k_mul_base64 on the CURRENT device add their start / end (shader cycles, 100 MHz ticks); nullptr = off.  Synchronous.

@@ -1026,3 +1026,46 @@ def test_fixed_base_workgroup_sizes_and_wave_chunks(engine, oracle, block64):
         engine.set_option("mul_base.block64", old[0])
         engine.set_option("mul_base.small_chunks", old[1])
         engine.set_option("coop.base_max_items", old[2])
+
+
+@pytest.mark.parametrize("m,t", [(16, 512), (64, 128), (300, 40), (683, 683)])
+def test_lincomb_public_point_tables(engine, oracle, m, t):
+    """kyb_lincomb_public_batch over shared points (window tables of the points, kernels_msm.hip) == kyb_lincomb_batch (constant-time ladders)
+    == the oracle's mul + add, with the scalars the multiplication routines treat specially (0, 1, L - 1, L, 8L, 2^255 - 1, >= 2^255:
+    top-digit quirk, all ones) and points that are neutral, of small order, of mixed order, repeated and negated; wire encodings in, one of
+    them not a point"""
+    L = synth.L
+    weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
+    sc = synth.scalars(m * t, 5000 + t).reshape(m, t, 32).copy()
+    pts = oracle.mul_base_ext_batch(synth.scalars(t, 5100 + t, b"point")).copy()
+    special = [0, 1, 2, 31, 32, 33, 63, 64, L - 1, L, L + 1, 8 * L, (1 << 255) - 1, 1 << 255, (1 << 255) + (1 << 252) * 5 + 12345, (1 << 256) - 1, 1 << 252, (1 << 252) - 1]
+    for k, v in enumerate(special):
+        sc[k % m, (3 * k + 1) % t] = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8)
+    sc[m - 1] = synth.raw256(t, 5200 + t)                                    # a row of unreduced 256-bit scalars
+    pts[0] = oracle.null()
+    pts[1] = weak[2]
+    pts[2] = oracle.add(pts[3], weak[3])
+    pts[4] = pts[5]
+    pts[6] = oracle.neg(pts[5])
+    got, ext = engine.lincomb(sc, pts_ext=pts, want_ext=True, public=True)
+    ref = engine.lincomb(sc, pts_ext=pts)
+    assert np.array_equal(got, ref)
+    for g in sorted({0, 1, m // 2, m - 1}):
+        assert bytes(got[g]) == oracle.lincomb(sc[g], pts), (m, t, g)
+        assert oracle.encode(ext[g]) == bytes(got[g])
+    pe = oracle.encode_batch(pts)
+    bad = next(bytes([v]) + bytes(31) for v in range(2, 50) if not oracle.decode(bytes([v]) + bytes(31))[1])
+    pe[7] = np.frombuffer(bad, dtype=np.uint8)
+    pts2 = pts.copy(); pts2[7] = oracle.null()
+    got2, ok = engine.lincomb(sc, pts_enc=pe, want_ok=True, public=True)
+    assert ok.sum() == t - 1 and ok[7] == 0
+    assert np.array_equal(got2, engine.lincomb(sc, pts_ext=pts2))
+
+
+def test_lincomb_public_small_shapes_take_the_ladder(engine, oracle):
+    """shapes below the table threshold (and points that are not shared) go through kyb_lincomb_batch's own path: same bytes"""
+    for m, t, shared in ((3, 5, True), (15, 700, True), (40, 9, False)):
+        sc = synth.scalars(m * t, 5300 + t).reshape(m, t, 32)
+        pts = oracle.mul_base_ext_batch(synth.scalars(t if shared else m * t, 5400 + t, b"point"))
+        pts = pts if shared else pts.reshape(m, t, 40)
+        assert np.array_equal(engine.lincomb(sc, pts_ext=pts, public=True), engine.lincomb(sc, pts_ext=pts))

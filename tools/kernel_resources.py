@@ -11,7 +11,7 @@ import argparse, concurrent.futures, json, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "kyber-rs_amd", "csrc")
-UNITS = ["kernels_base", "kernels_base_alt", "kernels_ladder", "kernels_window", "kernels_verify", "kernels_misc", "kernels_coop"]
+UNITS = ["kernels_base", "kernels_base_alt", "kernels_ladder", "kernels_window", "kernels_verify", "kernels_misc", "kernels_msm", "kernels_coop"]
 
 
 def unit_asm(unit, flags):
