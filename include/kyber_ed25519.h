@@ -282,6 +282,15 @@ int kyb_lincomb_public_batch(const uint8_t* scalars, const uint8_t* pts_enc, con
 int kyb_lincomb_public_batch_dev(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, int shared_points,
                                  size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok, void* stream);
 
+/* The scalar side of recover_commit (poly.rs:580-594): for m share sets of t PUBLIC share indices each,
+ *     out[g*t + i] = prod_{j != i} x_j / (x_j - x_i) mod L,   x = index + 1,
+ * the Lagrange coefficients at 0, as canonical 32-byte scalars — the reference's num / den with its Scalar::div (= multiplication by
+ * den^(L-2), scalar.rs:185-215).  The reference walks the t^2 products and t inversions on one core; here one lane per coefficient.
+ * Indices of one set must be distinct (the reference keys its shares by index); a repeated index gives 0 for the coefficients it touches.
+ * Feed the result to kyb_lincomb_public_batch (shared_points = 0: every set has its own share points). */
+int kyb_lagrange_coeffs_batch(const uint32_t* indices, size_t m, size_t t, uint8_t* out_scalars);
+int kyb_lagrange_coeffs_batch_dev(const uint32_t* indices, size_t m, size_t t, uint8_t* out_scalars, void* stream);
+
 /* Sums of points without scalars: out[g] = sum_{j<t} pts[g*t + j] (m groups of t points, extended limbs).  The
  * distributed public polynomial of a DKG round is the coefficient-wise sum of the dealers' commitment polynomials
  * (dkg.rs:905-953 applies PubPoly::add, poly.rs:486-507, dealer after dealer): m = threshold, t = number of dealers,

@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "kyb_schnorr_sign_keyed_batch", "kyb_schnorr_sign_keyed_batch_dev", "kyb_eddsa_sign_keyed_batch", "kyb_eddsa_sign_keyed_batch_dev",
     "kyb_verify_batch", "kyb_verify_batch_dev", "kyb_pubpoly_eval_batch", "kyb_pubpoly_eval_batch_dev",
     "kyb_pubpoly_eval_multi_batch", "kyb_pubpoly_eval_multi_batch_dev",
-    "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev", "kyb_lincomb_public_batch", "kyb_lincomb_public_batch_dev",
+    "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev", "kyb_lincomb_public_batch", "kyb_lincomb_public_batch_dev", "kyb_lagrange_coeffs_batch", "kyb_lagrange_coeffs_batch_dev",
     "kyb_sum_batch", "kyb_sum_batch_dev",
     "kyb_pubpoly_eval_multi_enc_batch", "kyb_pubpoly_eval_multi_enc_batch_dev", "kyb_sum_enc_batch", "kyb_sum_enc_batch_dev",
     "kyb_dkg_verify_round_enc", "kyb_dkg_verify_round_enc_dev",
@@ -147,6 +147,8 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_equal_batch_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.kyb_lincomb_batch.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp]
     lib.kyb_lincomb_batch_dev.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp, vp]
+    lib.kyb_lagrange_coeffs_batch.argtypes = [vp, sz, sz, vp]
+    lib.kyb_lagrange_coeffs_batch_dev.argtypes = [vp, sz, sz, vp, vp]
     lib.kyb_lincomb_public_batch.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp]
     lib.kyb_lincomb_public_batch_dev.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp, vp]
     lib.kyb_set_option.argtypes = [ctypes.c_char_p, i32]
@@ -533,6 +535,15 @@ class Engine:
         if want_ok:
             out += (ok,)
         return out if len(out) > 1 else enc
+
+    def lagrange_coeffs(self, indices) -> np.ndarray:
+        """kyb_lagrange_coeffs_batch: indices (m, t) uint32 share indices -> (m, t, 32) Lagrange coefficients at 0 (x = index + 1), mod L"""
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        if idx.ndim != 2:
+            raise ValueError("indices must have shape (m, t)")
+        out = np.empty(idx.shape + (32,), dtype=np.uint8)
+        _check(self.lib.kyb_lagrange_coeffs_batch(_ptr(idx), idx.shape[0], idx.shape[1], _ptr(out)), "kyb_lagrange_coeffs_batch")
+        return out
 
     def equal(self, a_ext, b_ext) -> np.ndarray:
         a = np.ascontiguousarray(a_ext, dtype=np.int32).reshape(-1, 40)

@@ -9,11 +9,13 @@
 //                     multiplies by (sc_effective: the scalar as stored, top-digit quirk included), one table addition per non-zero
 //                     digit — 43 additions per product where the ladder has 255 steps of the same size; the chunk's partial sum
 //                     goes to the projective staging buffer, k_pair_sum and k_finish (the constant-time path's own tail) do the rest.
+//   k_lagrange_at_zero the Lagrange coefficients at 0 of recover_commit (poly.rs:580-594) for m share sets, one lane per coefficient
 // Exact on every curve point (the complete addition law; small-order and mixed-order points included).  NOT constant time: table
 // addresses and the skipped zero digits depend on the scalars — which is why the entry point exists only in a "public" form.
 #include <hip/hip_runtime.h>
 #include "launch.h"
 #include "ge_scalarmult.h"
+#include "sc25519.h"
 using namespace kyb;
 #include "device_tables.h"
 
@@ -101,7 +103,72 @@ k_msm_accumulate(const uint8_t* __restrict__ scalars, const uint32_t* __restrict
   store_proj(proj, stride, g * nchunks + c, acc.X, acc.Y, acc.Z);
 }
 
+// Lagrange coefficients at 0 of recover_commit (poly.rs:580-594): for share set g with indices idx[g][0 .. t), x_i = idx_i + 1 as Scalars,
+//     lambda[g][i] = prod_{j != i} x_j * ( prod_{j != i} (x_j - x_i) )^(L - 2)   mod L
+// — the reference's num / den with its Scalar::div = multiplication by den^(L-2) (scalar.rs:185-215; the inverse of 0 is 0).  One lane per
+// (g, i): 2 (t - 1) products and one fixed 253-bit exponentiation, where the reference walks the t^2 products on one core.  Share
+// indices are public: nothing here needs to be constant time (it is anyway: fixed loop bounds, no data-dependent branch).
+__device__ __forceinline__ void sc_from_u32(uint32_t r[8], uint32_t v) {
+  r[0] = v;
+  KYB_UNROLL for (int i = 1; i < 8; ++i) r[i] = 0u;
+}
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_lagrange_at_zero(const uint32_t* __restrict__ idx, size_t m, size_t t, uint8_t* __restrict__ out) {
+  const size_t id = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (id >= m * t) return;
+  const size_t g = id / t, i = id - g * t;
+  const uint32_t* xs = idx + g * t;
+  const uint32_t Lw[8] = KYB_W_L;
+  const uint32_t zero[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  const uint64_t xi = (uint64_t)xs[i] + 1u;
+  uint32_t num[8], den[8];
+  sc_from_u32(num, 1u);
+  sc_from_u32(den, 1u);
+#pragma unroll 1
+  for (size_t j = 0; j < t; ++j) {
+    if (j == i) continue;                              // (wave-divergent for one iteration per lane; indices are public)
+    const uint64_t xj = (uint64_t)xs[j] + 1u;
+    uint32_t a[8], d[8], r[8];
+    a[0] = (uint32_t)xj; a[1] = (uint32_t)(xj >> 32);
+    KYB_UNROLL for (int q = 2; q < 8; ++q) a[q] = 0u;
+    sc_muladd(r, num, a, zero);
+    KYB_UNROLL for (int q = 0; q < 8; ++q) num[q] = r[q];
+    // x_j - x_i mod L: the difference itself, or L minus its magnitude
+    const bool below = xj < xi;
+    const uint64_t mag = below ? xi - xj : xj - xi;
+    uint32_t mg[8];
+    mg[0] = (uint32_t)mag; mg[1] = (uint32_t)(mag >> 32);
+    KYB_UNROLL for (int q = 2; q < 8; ++q) mg[q] = 0u;
+    uint32_t lm[8];
+    mw_sub<8>(lm, Lw, mg);
+    KYB_UNROLL for (int q = 0; q < 8; ++q) d[q] = below ? lm[q] : mg[q];
+    sc_muladd(r, den, d, zero);
+    KYB_UNROLL for (int q = 0; q < 8; ++q) den[q] = r[q];
+  }
+  // den^(L - 2): square-and-multiply over the fixed exponent, top bit first
+  uint32_t e[8];
+  { const uint32_t two[8] = {2u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}; mw_sub<8>(e, Lw, two); }
+  uint32_t inv[8];
+  sc_from_u32(inv, 1u);
+#pragma unroll 1
+  for (int b = 252; b >= 0; --b) {
+    uint32_t r[8];
+    sc_muladd(r, inv, inv, zero);
+    const uint32_t bit = (e[b >> 5] >> (b & 31)) & 1u;
+    uint32_t r2[8];
+    sc_muladd(r2, r, den, zero);
+    KYB_UNROLL for (int q = 0; q < 8; ++q) inv[q] = bit ? r2[q] : r[q];
+  }
+  uint32_t lam[8];
+  sc_muladd(lam, num, inv, zero);
+  store_words8(out, id, lam);
+}
+
 namespace kyb { namespace launch {
+hipError_t lagrange_at_zero(hipStream_t st, const uint32_t* idx, size_t m, size_t t, uint8_t* out) {
+  hipLaunchKernelGGL(k_lagrange_at_zero, dim3((unsigned)((m * t + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, idx, m, t, out);
+  return hipGetLastError();
+}
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK); }
 hipError_t msm_tables(hipStream_t st, const uint32_t* bases, size_t t, uint32_t* tab) {
   hipLaunchKernelGGL(k_msm_tables, dim3(blocks_for(t * MSM_WINDOWS)), dim3(KYB_BLOCK), 0, st, bases, t, tab);

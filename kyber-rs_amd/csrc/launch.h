@@ -132,6 +132,7 @@ hipError_t poly_eval(bool split, hipStream_t st, const int32_t* commits, int t, 
 // partial sums of output g land in staging records g * nchunks + c
 hipError_t msm_bases_coop(hipStream_t st, const int32_t* pts_ext, size_t t, uint32_t* bases);
 hipError_t msm_tables(hipStream_t st, const uint32_t* bases, size_t t, uint32_t* tab);
+hipError_t lagrange_at_zero(hipStream_t st, const uint32_t* idx, size_t m, size_t t, uint8_t* out);      // out: m x t scalars, 32 bytes each
 hipError_t msm_accumulate(hipStream_t st, const uint8_t* scalars, const uint32_t* tab, size_t m, size_t t, int chunk, size_t nchunks, uint4* proj, size_t stride);
 
 // benchmark diagnostic (kyb_diag_wave_stamps, diag_stamp.h): the five 64-bit sums into which the wavefronts of k_mul_ladder /

@@ -225,12 +225,24 @@ inline std::vector<Scalar> lagrange_at_zero(const std::vector<Scalar>& x) {
   }
   return lam;
 }
-inline std::vector<Point> lincomb(const std::vector<Scalar>& sc, const std::vector<Point>& pts, bool shared, size_t m, size_t t, const char* what) {
+// The same coefficients from the engine (kyb_lagrange_coeffs_batch: one GPU lane per coefficient) for m share sets of t indices each —
+// what recover_commit uses below; lagrange_at_zero above stays as the host restatement of the reference's loop (tests compare the two).
+inline std::vector<Scalar> lagrange_at_zero_gpu(const std::vector<uint32_t>& indices, size_t m, size_t t) {
+  std::vector<uint8_t> out(32 * m * t);
+  group::edwards25519::detail::engine_must(kyb_lagrange_coeffs_batch(indices.data(), m, t, out.data()), "lagrange_at_zero");
+  std::vector<Scalar> lam(m * t);
+  for (size_t i = 0; i < m * t; ++i) std::memcpy(lam[i].v.data(), &out[32 * i], 32);
+  return lam;
+}
+// scalars_public: Lagrange coefficients of public share indices — the engine may then use tables of the points (kyb_lincomb_public_batch)
+inline std::vector<Point> lincomb(const std::vector<Scalar>& sc, const std::vector<Point>& pts, bool shared, size_t m, size_t t, const char* what,
+                                  bool scalars_public = false) {
   std::vector<uint8_t> s(32 * m * t);
   std::vector<int32_t> p(40 * pts.size()), out(40 * m);
   for (size_t i = 0; i < m * t; ++i) std::memcpy(&s[32 * i], sc[i].v.data(), 32);
   for (size_t i = 0; i < pts.size(); ++i) std::memcpy(&p[40 * i], pts[i].ge, 160);
-  group::edwards25519::detail::engine_must(kyb_lincomb_batch(s.data(), nullptr, p.data(), shared ? 1 : 0, m, t, nullptr, out.data(), nullptr), what);
+  const auto fn = scalars_public ? kyb_lincomb_public_batch : kyb_lincomb_batch;
+  group::edwards25519::detail::engine_must(fn(s.data(), nullptr, p.data(), shared ? 1 : 0, m, t, nullptr, out.data(), nullptr), what);
   std::vector<Point> r(m);
   for (size_t g = 0; g < m; ++g) std::memcpy(r[g].ge, &out[40 * g], 160);
   return r;
@@ -242,21 +254,23 @@ inline Point recover_commit(const std::vector<std::optional<PubShare>>& shares, 
   XYCommit xy = xy_commit(shares, t, n);
   if (xy.x.size() < t) throw PolyError("not enough good public shares to reconstruct secret commitment");
   if (xy.x.empty()) return Point().null();
-  return detail::lincomb(detail::lagrange_at_zero(xy.x), xy.y, false, 1, xy.x.size(), "recover_commit")[0];
+  // share indices are public: the coefficients come from the GPU (the reference's t^2 Scalar products run on one core) and the
+  // combination may use point tables
+  std::vector<uint32_t> idx(xy.idx.begin(), xy.idx.end());
+  return detail::lincomb(detail::lagrange_at_zero_gpu(idx, 1, idx.size()), xy.y, false, 1, xy.x.size(), "recover_commit", true)[0];
 }
 // the same for many share sets in one launch (every peer's commitment of a DKG round)
 inline std::vector<Point> recover_commit_batch(const std::vector<std::vector<std::optional<PubShare>>>& sets, size_t t, size_t n) {
   if (t == 0) return std::vector<Point>(sets.size(), Point().null());
-  std::vector<Scalar> sc;
+  std::vector<uint32_t> idx;
   std::vector<Point> pts;
   for (const auto& shares : sets) {
     XYCommit xy = xy_commit(shares, t, n);
     if (xy.x.size() < t) throw PolyError("not enough good public shares to reconstruct secret commitment");
-    std::vector<Scalar> lam = detail::lagrange_at_zero(xy.x);
-    sc.insert(sc.end(), lam.begin(), lam.end());
+    idx.insert(idx.end(), xy.idx.begin(), xy.idx.end());
     pts.insert(pts.end(), xy.y.begin(), xy.y.end());
   }
-  return detail::lincomb(sc, pts, false, sets.size(), t, "recover_commit_batch");
+  return detail::lincomb(detail::lagrange_at_zero_gpu(idx, sets.size(), t), pts, false, sets.size(), t, "recover_commit_batch", true);
 }
 
 // poly.rs:313-319 (minus_const: x - c) and :640-668 (lagrange_basis)
@@ -290,7 +304,7 @@ inline PubPoly recover_pub_poly(const std::vector<std::optional<PubShare>>& shar
     PriPoly basis = lagrange_basis(j, xy.x);
     for (size_t g = 0; g < k; ++g) sc[g * k + j] = basis.coeffs[g];
   }
-  r.commits = detail::lincomb(sc, xy.y, true, k, k, "recover_pub_poly");
+  r.commits = detail::lincomb(sc, xy.y, true, k, k, "recover_pub_poly", true);      // Lagrange basis coefficients of public indices
   return r;
 }
 

@@ -313,6 +313,14 @@ int main() {
     std::string err;
     try { (void)recover_commit(holes, t, n); } catch (const PolyError& e) { err = e.what(); }
     CHECK(err == "not enough good public shares to reconstruct secret commitment", "test_public_recovery_delete_fail");
+    // the Lagrange coefficients the engine computes (one GPU lane each) are the ones the reference's loop gives (poly.rs:585-594)
+    {
+      std::vector<uint32_t> idx = {0, 3, 4, 6, 9, 17, 250};
+      std::vector<Scalar> xs;
+      for (uint32_t i : idx) xs.push_back(Scalar().set_int64((int64_t)i + 1));
+      std::vector<Scalar> host = kyber::share::detail::lagrange_at_zero(xs), gpu = kyber::share::detail::lagrange_at_zero_gpu(idx, 1, idx.size());
+      for (size_t i = 0; i < idx.size(); ++i) CHECK(host[i] == gpu[i], "lagrange_at_zero: engine == host restatement");
+    }
     // batch of share sets in one launch == one by one
     {
       std::vector<std::vector<std::optional<PubShare>>> sets;

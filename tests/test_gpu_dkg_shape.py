@@ -88,3 +88,42 @@ def test_pedersen_round_shape(engine, oracle):
     rec = engine.lincomb(np.broadcast_to(lam_b, (n, t, 32)), pts_ext=pub_shares)
     assert np.array_equal(rec, enc.reshape(n, t, 32)[:, 0])
     assert bytes(rec[7]) == oracle.lincomb(lam_b, pub_shares[7])
+
+
+def test_lagrange_coefficients_and_recover_commit_on_the_gpu(engine, oracle):
+    """kyb_lagrange_coeffs_batch == Python integers (prod x_j / (x_j - x_i) mod L, x = index + 1) for ragged index sets, and the whole
+    recover_commit (poly.rs:566-603) — coefficients on the GPU, then kyb_lincomb_public_batch over the share points — gives back the secret
+    commitment a_0 * B of the polynomial the shares were made from"""
+    import time
+    L = synth.L
+    rng = np.random.default_rng(321)
+    for m, t in ((1, 1), (1, 2), (3, 7), (5, 64), (2, 683)):
+        idx = np.stack([np.sort(rng.choice(3 * t + 5, t, replace=False)) for _ in range(m)]).astype(np.uint32)
+        if t > 2:
+            idx[0, -1] = 0xfffffffe                                       # x = 2^32 - 1: the largest index the ABI takes
+        lam = engine.lagrange_coeffs(idx)
+        for g in range(m):
+            xs = [int(v) + 1 for v in idx[g]]
+            for i in sorted({0, t // 2, t - 1}):
+                num = den = 1
+                for j in range(t):
+                    if j != i:
+                        num = num * xs[j] % L
+                        den = den * (xs[j] - xs[i]) % L
+                want = num * pow(den, L - 2, L) % L
+                assert int.from_bytes(bytes(lam[g, i]), "little") == want, (m, t, g, i)
+    # a repeated index: the reference cannot produce one (shares are keyed by index); the coefficients it touches are 0 (inverse of 0 is 0)
+    lam = engine.lagrange_coeffs(np.array([[4, 9, 4, 1]], dtype=np.uint32))
+    assert not lam[0, 0].any() and not lam[0, 2].any() and lam[0, 1].any()
+    # recover_commit of 40 share sets, threshold 21: shares f(x_i) * B of one secret polynomial per set
+    m, t = 40, 21
+    coeffs = [[int.from_bytes(bytes(c), "little") for c in synth.scalars(t, 700 + g)] for g in range(m)]
+    idx = np.stack([np.sort(rng.choice(64, t, replace=False)) for _ in range(m)]).astype(np.uint32)
+    shares = np.frombuffer(b"".join((sum(c * pow(int(i) + 1, k, L) for k, c in enumerate(coeffs[g])) % L).to_bytes(32, "little")
+                                    for g in range(m) for i in idx[g]), dtype=np.uint8).reshape(m * t, 32)
+    _, share_pts = engine.mul_base(shares, want_ext=True)
+    lam = engine.lagrange_coeffs(idx)
+    got = engine.lincomb(lam, pts_ext=share_pts.reshape(m, t, 40), public=True)
+    want = engine.mul_base(np.frombuffer(b"".join(c[0].to_bytes(32, "little") for c in coeffs), dtype=np.uint8).reshape(m, 32))
+    assert np.array_equal(got, want)
+    assert bytes(got[3]) == oracle.mul_base(coeffs[3][0].to_bytes(32, "little"))
