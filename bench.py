@@ -269,10 +269,14 @@ def time_workload(w, eng, rt, steps, warmup, barrier):
     return elapsed
 
 
-def kernel_clock(w, eng, rt, steps=3):
-    """the clock the stamped kernels of this step (k_mul_ladder, k_mul_base64) run at: extra UNTIMED steps with the wave stamps on"""
+def kernel_clock(w, eng, rt, steps=3, warm=10):
+    """the clock the stamped kernels of this step (k_mul_ladder, k_mul_base64) run at: extra UNTIMED steps with the wave stamps on, behind
+    `warm` plain steps (the parity check before this leaves the GPU idle for seconds, and the first launches after an idle period run at
+    a lower clock than the timed region saw)"""
     torch = rt.torch
     buf = torch.zeros(8, dtype=torch.int64, device=rt.dev)
+    for _ in range(warm):
+        w["step"]()
     rt.sync()
     eng.wave_stamps(buf)
     try:

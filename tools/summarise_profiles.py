@@ -15,9 +15,9 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = "gpurun_out/prof"
 dst = os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-DOM = {"mul": "k_mul_ladder<", "mul_base": "k_mul_base", "sign": "k_mul_base", "verify": "k_mul_ladder<"}
-ITEMS = {"mul": 1 << 20, "mul_base": 1 << 20, "sign": 1 << 18, "verify": 1 << 20}
-for w in ("mul", "mul_base", "sign", "verify"):
+DOM = {"mul": "k_mul_ladder<", "mul_enc": "k_mul_ladder<", "mul_base": "k_mul_base", "sign": "k_mul_base", "verify": "k_mul_ladder<"}
+ITEMS = {"mul": 1 << 20, "mul_enc": 1 << 20, "mul_base": 1 << 20, "sign": 1 << 18, "verify": 1 << 20}
+for w in ("mul", "mul_enc", "mul_base", "sign", "verify"):
     ks = sorted(glob.glob(f"{src}/{w}_trace/*/*kernel_stats.csv"), key=os.path.getmtime)
     if ks:
         shutil.copyfile(ks[-1], os.path.join(dst, f"{w}_kernel_stats.csv"))      # newest run only
