@@ -574,6 +574,8 @@ def run_ranks(args):
         elapsed = float(t.item())
 
     if rank == 0:
+        if len({d["table_sha256_16"] for d in idents}) != 1:
+            raise SystemExit(f"TABLE MISMATCH: the ranks hold different base-point table images: {[d['table_sha256_16'] for d in idents]}")
         line = common_line(args, wl, n, world, elapsed, eng)
         line.update({"input_gen_s": round(gen_s, 2), "ranks_seen": len(idents), "dist_backend": backend, "devices": idents,
                      "table_identical_on_all_ranks": len({d["table_sha256_16"] for d in idents}) == 1,
@@ -710,6 +712,8 @@ def run_group(args):
         if not np.array_equal(got, want):
             raise SystemExit(f"PARITY FAILURE (group rank {r}, {wl}): GPU output differs from the oracle")
         checked += len(idx)
+    if len({d["table_sha256_16"] for d in idents}) != 1:
+        raise SystemExit(f"TABLE MISMATCH: the group's contexts hold different base-point table images: {[d['table_sha256_16'] for d in idents]}")
     line = common_line(args, wl, n, world, elapsed, engs[0])
     per_kernel = {}
     for name, ms in launches:

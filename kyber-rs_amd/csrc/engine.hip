@@ -63,7 +63,7 @@ struct StreamRes {
   hipStream_t stream = nullptr;
   uint4* ws = nullptr; uint4* proj = nullptr; size_t proj_items = 0; uint8_t* enc = nullptr; size_t enc_bytes = 0;
   uint32_t* part = nullptr; size_t part_items = 0;      // extended quads of a small linear combination's products
-  uint32_t* msm = nullptr; size_t msm_points = 0;        // kyb_lincomb_public_batch over shared points: window bases + tables of the points (221,760 B per point)
+  uint32_t* msm = nullptr; size_t msm_points = 0;        // kyb_lincomb_public_batch over shared points: window bases + tables of the points (227,040 B per point)
   uint32_t* top_or = nullptr; unsigned top_seq = 0;     // two alternating words behind the projective staging records (k_mont_prep / k_mul_ladder)
   hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_last = nullptr;
   bool used = false, own = false;

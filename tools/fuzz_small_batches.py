@@ -85,7 +85,7 @@ while time.time() < t_end:
     n = int(rng.choice(SIZES)) if rng.integers(0, 3) else int(rng.integers(1, 900))
     lo = int(rng.integers(0, NMAX - n + 1))
     sl = slice(lo, lo + n)
-    op = str(rng.choice(["mul_base", "mul_ext", "mul_enc", "sign", "verify", "decode", "encode", "eval", "eval_wire", "lincomb", "sum", "sum_wire"]))
+    op = str(rng.choice(["mul_base", "mul_ext", "mul_enc", "sign", "verify", "decode", "encode", "eval", "eval_wire", "lincomb", "lincomb_pub", "dkg_round", "lagrange", "sum", "sum_wire"]))
     counts[op] = counts.get(op, 0) + 1
     cases += 1
     ctx = (op, n, lo, opts)
@@ -181,6 +181,53 @@ while time.time() < t_end:
             got = eng.lincomb(sc, pts_ext=pp)
             for g_ in range(0, m, max(1, m // 8)):
                 assert bytes(got[g_]) == orc.lincomb(sc[g_], pp[g_])
+        elif op == "lincomb_pub":
+            # public multipliers: shared points in large enough shapes take the per-point window tables, the rest the short/plain ladders
+            t = int(rng.choice([1, 2, 3, 16, 33, 130]))
+            shared = bool(rng.integers(0, 2))
+            m = max(1, int(rng.choice([n, 6 * n, 12000])) // t) if shared else max(1, min(n, 2000) // t)
+            m = min(m, 12000 // t + 1)
+            sc = np.ascontiguousarray(np.resize(K2, (m * t, 32))).reshape(m, t, 32).copy()
+            if rng.integers(0, 3) == 0:                                        # short multipliers as well
+                sc[:, :, int(rng.choice([1, 4, 8])):] = 0
+            pp = POOL_P[lo % 64:lo % 64 + t] if shared else POOL_P[:m * t].reshape(m, t, 40)
+            got = eng.lincomb(sc, pts_ext=pp, public=True)
+            for g_ in sorted({0, m - 1, *range(0, m, max(1, m // 6))}):
+                assert bytes(got[g_]) == orc.lincomb(sc[g_], pp if shared else pp[g_])
+        elif op == "dkg_round":
+            t = int(rng.choice([1, 2, 3, 20, 60]))
+            m = max(1, min(n, 1500) // t)
+            base_i = lo if lo + m * t <= NMAX else 0
+            enc_in = POOL_E_BAD[base_i:base_i + m * t].reshape(m, t, 32)
+            index = int(rng.integers(0, 1 << int(rng.choice([1, 4, 10, 16, 32])))) % 0xffffffff
+            sums_wanted = bool(rng.integers(0, 2))
+            ev, sums, ok = eng.dkg_verify_round_enc(enc_in, index, want_sums=sums_wanted)
+            good = np.array([[((base_i + g_ * t + j) % 53) != 0 for j in range(t)] for g_ in range(m)])
+            assert np.array_equal(ok.astype(bool), good)
+            for g_ in sorted({0, m - 1, *range(0, m, max(1, m // 5))}):
+                pts = [POOL_P[base_i + g_ * t + j] if good[g_, j] else orc.null() for j in range(t)]
+                assert bytes(ev[g_]) == orc.pubpoly_eval(np.stack(pts), index)
+            if sums_wanted:
+                for j in sorted({0, t - 1, t // 2}):
+                    acc = orc.null()
+                    for g_ in range(m):
+                        if good[g_, j]:
+                            acc = orc.add(acc, POOL_P[base_i + g_ * t + j])
+                    assert bytes(sums[j]) == orc.encode(acc)
+        elif op == "lagrange":
+            t = int(rng.choice([1, 2, 3, 17, 64, 200]))
+            m = max(1, min(n, 1200) // t)
+            idx = np.stack([np.sort(rng.choice(1 << int(rng.choice([9, 16, 31])), t, replace=False)) for _ in range(m)]).astype(np.uint32)
+            lam = eng.lagrange_coeffs(idx)
+            for g_ in sorted({0, m - 1}):
+                xs = [int(v) + 1 for v in idx[g_]]
+                for i in sorted({0, t // 2, t - 1}):
+                    num = den = 1
+                    for j in range(t):
+                        if j != i:
+                            num = num * xs[j] % L
+                            den = den * (xs[j] - xs[i]) % L
+                    assert int.from_bytes(bytes(lam[g_, i]), "little") == num * pow(den, L - 2, L) % L
         else:
             t = int(rng.choice([1, 2, 5, 16]))
             m = max(1, min(n, 1200) // t)
