@@ -359,6 +359,13 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *                     (default 4096), coop.decode_max_items for a bare decode (default 1024), coop.verify_max_items for the
  *                     kernels that give ONE item several wavefronts (verification in one launch, signing in one launch, the fixed
  *                     base with four wavefronts per item; default 512).  Same results either way.
+ *   ladder.pair_max_items  ladder launches (variable base, verification, linear combinations) of at most this many items give every item TWO
+ *                     lanes of a wavefront, which split the products of a ladder step between them and keep the operand's Montgomery image
+ *                     projective, so that no inversion runs in front (default 32768 = one wavefront per SIMD, 0 = never): up to there the
+ *                     call time is one lane's chain of 255 steps, and the two-lane form takes 0.49 instead of 0.79 ms.  Same results.  These
+ *                     launches always walk 256 bits (minus publicly known zeros): ladder.skip_canonical does not apply to them.
+ *   coop.ladder_max_items  variable base and linear combinations leave the one-item-per-wavefront kernels above this many items (default 3072;
+ *                     verification at 7/8 of it) even when coop.max_items would still allow them: from there the two-lane ladder is faster.
  *   ladder.skip_canonical  1 (default): the batch ladder starts four bits lower when no scalar of the launch reaches 2^252 — true of a scalar
  *                     reduced mod L (L = 2^252 + 2.8e37) except for 2^-127 of them, so the test (an OR over the batch, taken on the way by the
  *                     kernel that prepares the points) says nothing about a canonical secret; one unreduced scalar anywhere and the launch

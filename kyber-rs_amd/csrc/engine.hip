@@ -41,9 +41,9 @@ thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
 enum KernelId { KID_MUL, KID_MUL_BASE, KID_FINISH, KID_SIGN, KID_SIGN_HASH, KID_VERIFY_PREP, KID_VERIFY_FINAL, KID_POLY_EVAL, KID_MONT_PREP,
-                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_VERIFY_COOP, KID_FINISH_COOP, KID_SIGN_COOP, KID_MSM_TABLES, KID_MSM_ACCUMULATE, KID_COUNT };
+                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_VERIFY_COOP, KID_FINISH_COOP, KID_SIGN_COOP, KID_MSM_TABLES, KID_MSM_ACCUMULATE, KID_MUL_LADDER_PAIR, KID_COUNT };
 const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval",
-                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop", "k_verify_coop", "k_finish_coop", "k_sign_coop", "k_msm_tables", "k_msm_accumulate"};
+                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop", "k_verify_coop", "k_finish_coop", "k_sign_coop", "k_msm_tables", "k_msm_accumulate", "k_mul_ladder_pair"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   std::mutex mu;                  // begin / read / every ProfScope: callable from any thread
@@ -116,6 +116,8 @@ struct Ctx {
   std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: the chunk unit is 1/this of the batch (plan_chunks)
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
+  std::atomic<int> opt_ladder_pair_max{32768};    // ladder launches of at most this many items give each item two lanes (k_mul_ladder_pair: one wavefront per SIMD up to here); 0 = never
+  std::atomic<int> opt_coop_ladder_max{3072};     // variable base, linear combinations (verification: 7/8 of it): above this the two-lane batch ladder is faster than one item per wavefront (profiles/r03/ladder_pair_probe.log)
   std::atomic<int> opt_ladder_skip_canonical{1};  // the batch ladder skips the four leading bits when no scalar of the launch has one set (canonical scalars)
   std::atomic<int> opt_mul_short_scalars{0};     // 1: EVERY host-pointer kyb_mul_batch of <= 64 items is treated like kyb_mul_public_batch (multipliers declared public:
                                                  // when all are below 2^64 the ladder skips the leading zeros).  Off by default: the ABI cannot know that a multiplier is public.
@@ -866,6 +868,13 @@ int launch_ladder_core(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int
   } else if (ok != nullptr) {
     HIPCK(hipMemsetAsync(ok, 1, np, st));          // extended operands are taken as they are (k_mul does the same)
   }
+  if (n <= (size_t)g.opt_ladder_pair_max) {
+    // more SIMDs than wavefronts: two lanes per item shorten the dependent chain and keep the base point projective — no k_mont_prep,
+    // no inversion in front (ge_ladder_pair.h).  Without the prep there is no launch-wide canonical test: 256 - skip_bits steps.
+    ProfScope ps(g, st, KID_MUL_LADDER_PAIR);
+    LAUNCHCK(launch::mul_ladder_pair(st, sc, n, pext, npts, r->proj, r->proj_items, skip_bits));
+    return KYB_OK;
+  }
   // Are all scalars canonical (below 2^252)?  k_mont_prep ORs their top four bits into one of two alternating words on the way (one scalar
   // per point only), the ladder starts four bits lower when the word stayed 0 and clears the other word for the next call on this stream.
   uint32_t* top_or = nullptr;
@@ -906,7 +915,7 @@ int launch_lincomb(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
   const size_t n = m * t;
-  if (n <= (size_t)g.opt_coop_max && g.opt_mul_algo == 1) {
+  if (n <= (size_t)g.opt_coop_max && n <= (size_t)g.opt_coop_ladder_max && g.opt_mul_algo == 1) {
     // few products: one per wavefront, handed over projective (no inversion) to the halving passes
     const size_t np = shared ? t : n;
     int rc = ensure_proj(g, r, n); if (rc) return rc;
@@ -1032,7 +1041,7 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
   StreamRes* r = nullptr;
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
-  if (n <= (size_t)g.opt_coop_max && g.opt_mul_algo == 1) {
+  if (n <= (size_t)g.opt_coop_max && n <= (size_t)g.opt_coop_ladder_max && g.opt_mul_algo == 1) {
     // small batch: one item per wavefront, the whole multiplication in one launch (kernels_coop.hip)
     if (penc != nullptr && 4 * n <= (size_t)g.opt_coop_max) {
       // from the wire encoding, two wavefronts per item: the ladder starts on y while the decode is still looking for x
@@ -1274,7 +1283,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   // the R half (decode of R, s*B) is independent of the A half (decode of A, hash, h*A): while the batch leaves most of
   // the chip idle it runs on the side stream
   const bool fork = g.opt_verify_overlap && n <= (size_t)64 * (size_t)g.cus;
-  const bool coop = g.opt_mul_algo == 1 && n <= (size_t)g.opt_coop_max && n <= (size_t)g.opt_coop_base_max;     // small batch: one item per wavefront
+  const bool coop = g.opt_mul_algo == 1 && n <= (size_t)g.opt_coop_max && n <= (size_t)g.opt_coop_base_max && 8 * n <= 7 * (size_t)g.opt_coop_ladder_max;     // small batch: one item per wavefront
   hipStream_t side = st;
   if (fork) {
     rc = ensure_aux(g, r); if (rc) return rc;

@@ -9,6 +9,7 @@
 #include "launch.h"
 #include "ge_scalarmult.h"
 #include "ge_ladder.h"
+#include "ge_ladder_pair.h"
 #include "device_batch_invert.h"
 #include "diag_stamp.h"
 using namespace kyb;
@@ -130,6 +131,25 @@ k_mul_ladder(const uint8_t* __restrict__ scalars, size_t n, uint4* __restrict__ 
   KYB_STAMP_END();
 }
 
+// The same multiplication with two lanes per item (ge_ladder_pair.h): for batches that leave SIMDs idle.  Lanes 2i and 2i+1 load the
+// same scalar and the same extended point (item i's, or point i mod pts_mod of a shared set), build its projective Montgomery image,
+// walk the ladder together, both recover the point, the even lane stores it.  No k_mont_prep in front (so no launch-wide canonical test:
+// the step count is 256 - skip_bits for public skip_bits only).
+__global__ void __launch_bounds__(KYB_BLOCK, 2)      // launched for at most one wavefront per SIMD (ladder.pair_max_items): registers are free, no spills
+k_mul_ladder_pair(const uint8_t* __restrict__ scalars, size_t n, const int32_t* __restrict__ pts_ext, size_t pts_mod, uint4* __restrict__ proj, size_t stride, int skip_bits) {
+  const size_t lane = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  const size_t i = lane >> 1;
+  const uint32_t odd = threadIdx.x & 1u;
+  if (i >= n) return;
+  uint32_t a[8];
+  load_words8(a, scalars, i);
+  ge_p3 P;
+  load_ext(P, pts_ext, pts_mod ? i % pts_mod : i);
+  ge_p2 r;
+  ge_scalarmult_ladder_pair(r, a, P, skip_bits, odd);
+  if (odd == 0u) store_proj(proj, stride, i, r.X, r.Y, r.Z);
+}
+
 // One halving pass of the segmented sum behind kyb_lincomb_batch: in each of the m groups (group g
 // starts at record g * gstride and currently holds `len` partial sums) record j + half is added onto
 // record j for j < len - half.  ceil(log2 t) passes leave the group total in the group's first record.
@@ -181,6 +201,10 @@ hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, ui
   if (waves >= 4)      hipLaunchKernelGGL((k_mul_ladder<4>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits, top_or, zero_next);
   else if (waves == 3) hipLaunchKernelGGL((k_mul_ladder<3>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits, top_or, zero_next);
   else                 hipLaunchKernelGGL((k_mul_ladder<2>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits, top_or, zero_next);
+  return hipGetLastError();
+}
+hipError_t mul_ladder_pair(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, size_t pts_mod, uint4* proj, size_t stride, int skip_bits) {
+  hipLaunchKernelGGL(k_mul_ladder_pair, dim3(blocks_for(2 * n)), dim3(KYB_BLOCK), 0, st, sc, n, pext, pts_mod, proj, stride, skip_bits);
   return hipGetLastError();
 }
 hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half) {

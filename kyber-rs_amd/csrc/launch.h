@@ -61,6 +61,7 @@ hipError_t mont_prep(hipStream_t st, const int32_t* pext, size_t n, uint4* proj,
 // top_or != nullptr: the word mont_prep collected into — the kernel takes skip_bits = 4 when it is 0, else 0; zero_next: cleared for the next call
 hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, uint4* proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits,
                       const uint32_t* top_or = nullptr, uint32_t* zero_next = nullptr);
+hipError_t mul_ladder_pair(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, size_t pts_mod, uint4* proj, size_t stride, int skip_bits);
 hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half);
 hipError_t ext_to_proj(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride, size_t rows = 0, size_t cols = 0);      // rows != 0: transposed, as decode_to_proj
 

@@ -30,6 +30,7 @@ def _find(rows, prefix):
 DEFAULT_PATH = [
     ("_Z12k_mul_ladderILi3E", 168),                       # variable base, mul.ladder_waves = 3 (default)
     ("_Z12k_mul_ladderILi2E", 256),
+    ("_Z17k_mul_ladder_pair", 256),                       # two lanes per item, batches of at most one wavefront per SIMD
     ("_Z12k_mul_base64ILb1ELi1024E", 128),                # fixed base, full batches: 4 waves/SIMD, the table owns the LDS
     ("_Z12k_mul_base64ILb1ELi256E", 512),                 # fixed base, batches that do not fill the chip: 1 wave/SIMD
     ("_Z11k_mont_prepPKim", 256), ("_Z8k_finishPK", 256), ("_Z16k_encode_batchedPKimPh", 256),

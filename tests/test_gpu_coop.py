@@ -16,12 +16,13 @@ KATS = json.load(open(os.path.join(HERE, "golden", "kats.json")))
 
 @pytest.fixture()
 def coop_engine(engine):
-    old = (engine.get_option("coop.max_items"), engine.get_option("coop.base_max_items"))
-    engine.set_option("coop.max_items", 1 << 20)
-    engine.set_option("coop.base_max_items", 1 << 20)
+    keys = ("coop.max_items", "coop.base_max_items", "coop.ladder_max_items")
+    old = [engine.get_option(k) for k in keys]
+    for k in keys:
+        engine.set_option(k, 1 << 20)
     yield engine
-    engine.set_option("coop.max_items", old[0])
-    engine.set_option("coop.base_max_items", old[1])
+    for k, v in zip(keys, old):
+        engine.set_option(k, v)
 
 
 def test_coop_fixed_base_matches_oracle(coop_engine, oracle):
@@ -336,7 +337,7 @@ def test_coop_and_batch_kernels_agree_at_the_threshold(engine, oracle):
         assert np.array_equal(engine.mul_base(s[:64]), ref_base[:64])
         assert np.array_equal(engine.mul_base(s[:65]), ref_base[:65])
         names = [k for k, _ in engine.profile_read(64)]
-        assert names.count("k_mul_coop") == 1 and names.count("k_mul_base_coop") == 1 and "k_mul_ladder" in names
+        assert names.count("k_mul_coop") == 1 and names.count("k_mul_base_coop") == 1 and "k_mul_ladder_pair" in names
     finally:
         engine.profile_begin(0)
         engine.set_option("coop.max_items", old[0])          # (this used to leave the session's engine with the small-batch kernels switched off)

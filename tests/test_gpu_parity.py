@@ -425,6 +425,70 @@ def test_ladder_path_matches_oracle(engine, oracle, waves):
         engine.set_option("mul.ladder_waves", 3)
 
 
+def test_two_lane_ladder_matches_one_lane_and_oracle(engine, oracle):
+    """k_mul_ladder_pair (two lanes per item, ge_ladder_pair.h; launches of at most ladder.pair_max_items items) == k_mul_ladder == the oracle:
+    quirk vectors, mixed-order points, scalars around multiples of L, canonical-only batches (252 steps) and batches with one unreduced
+    scalar (256), invalid encodings, ragged and odd sizes, shared operands (linear combinations) and the h*A of a verification"""
+    saved = {k: engine.get_option(k) for k in ("coop.max_items", "coop.base_max_items", "coop.verify_max_items", "ladder.pair_max_items")}
+    try:
+        for k in ("coop.max_items", "coop.base_max_items", "coop.verify_max_items"):
+            engine.set_option(k, 0)                                       # small batches reach the ladder kernels
+        q = [v for v in KATS["quirk_mul"] if v["ok"]]
+        sc = np.frombuffer(b"".join(bytes.fromhex(v["scalar"]) for v in q), dtype=np.uint8)
+        pe = np.frombuffer(b"".join(bytes.fromhex(v["point"]) for v in q), dtype=np.uint8)
+        n = 1501
+        rng = np.random.default_rng(611)
+        s = np.concatenate([synth.scalars(600, 611), synth.raw256(n - 600, 611)])
+        for j, k in enumerate([1, 2, 4, 8]):
+            for d in (-1, 0, 1):
+                s[3 * j + d + 1] = np.frombuffer(((k * synth.L + d) % 2**256).to_bytes(32, "little"), dtype=np.uint8)
+        pts = rand_points_ext(oracle, n, 611)
+        weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
+        for i in range(0, n, 3):
+            pts[i] = oracle.add(pts[i], weak[int(rng.integers(0, 5))])
+        pts[5], pts[6] = weak[0], oracle.null()
+        want = oracle.mul_batch(s, pts, nthreads=8)
+        canon = synth.scalars(777, 612)                                   # every scalar below 2^252: the launch skips four steps
+        want_canon = oracle.mul_batch(canon, pts[:777], nthreads=8)
+        bad = [bytes.fromhex(h) for h in KATS["invalid_encodings"]]
+        good = [oracle.encode(p) for p in pts[:30]]
+        encs = good[:11] + bad + good[11:]
+        s2 = synth.scalars(len(encs), 613)
+        # verification and linear combinations run the same launch
+        x = synth.scalars(700, 614); kk = synth.scalars(700, 615, b"k"); msgs = synth.messages(700, 616)
+        sigs = oracle.schnorr_sign_batch(x, kk, msgs, nthreads=8)
+        pubs = oracle.mul_base_batch(x, nthreads=8)
+        sigs[::5, 40] ^= 4
+        want_st = oracle.verify_batch(1, pubs, msgs, sigs, nthreads=8)
+        lsc = synth.scalars(40 * 9, 617).reshape(40, 9, 32)
+        lp = pts[:9]
+        results = {}
+        for pair_max in (0, 1 << 20):
+            engine.set_option("ladder.pair_max_items", pair_max)
+            got, ok = engine.mul(sc, pts_enc=pe, want_ok=True)
+            assert ok.all() and [bytes(r).hex() for r in got] == [v["out"] for v in q], pair_max
+            g1, gext = engine.mul(s, pts_ext=pts, want_ext=True)
+            assert np.array_equal(g1, want), pair_max
+            assert np.array_equal(engine.mul(canon, pts_ext=pts[:777]), want_canon), pair_max
+            got, ok = engine.mul(s2, pts_enc=np.frombuffer(b"".join(encs), dtype=np.uint8), want_ok=True)
+            for i, e in enumerate(encs):
+                pe_, okk = oracle.decode(e)
+                assert ok[i] == okk and bytes(got[i]) == (oracle.mul(bytes(s2[i]), pe_) if okk else IDENT), (pair_max, i)
+            for m in (1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 129, 255, 257):
+                assert np.array_equal(engine.mul(s[:m], pts_ext=pts[:m]), want[:m]), (pair_max, m)
+            assert np.array_equal(engine.verify(pubs, msgs, sigs, 1), want_st), pair_max
+            lc_shared = engine.lincomb(lsc, pts_ext=lp)
+            lc_own = engine.lincomb(lsc, pts_ext=pts[:360].reshape(40, 9, 40))
+            for g_ in (0, 17, 39):
+                assert bytes(lc_shared[g_]) == oracle.lincomb(lsc[g_], lp) and bytes(lc_own[g_]) == oracle.lincomb(lsc[g_], pts[9 * g_:9 * g_ + 9]), (pair_max, g_)
+            results[pair_max] = (g1, gext, lc_shared, lc_own)
+        for a_, b_ in zip(results[0], results[1 << 20]):
+            assert np.array_equal(a_, b_)                                 # limbs included: the same field operations on the same values
+    finally:
+        for k, v in saved.items():
+            engine.set_option(k, v)
+
+
 def test_fixed_base_radix32_kernel(engine, oracle):
     """the 43-window radix-64 kernel (1024-thread workgroups, the whole 160 KiB LDS as table) == the 52-window radix-32
     kernel (104 KiB table) == the radix-16 kernel == oracle, through mul_base, sign and verify; quirk scalars included"""
@@ -983,6 +1047,16 @@ def test_ladder_skips_the_leading_zeros_only_when_every_scalar_is_canonical(engi
     s = synth.scalars(n, 61)
     pts = oracle.mul_base_ext_batch(synth.scalars(n, 62, b"p"))
     want = oracle.mul_batch(s, pts, nthreads=8)
+    assert np.array_equal(engine.mul(s, pts_ext=pts), want)      # (two lanes per item at this size: no canonical test, always 256 steps)
+    pair_max = engine.get_option("ladder.pair_max_items")
+    engine.set_option("ladder.pair_max_items", 0)                # the one-lane kernel behind k_mont_prep, as for batches beyond 32,768 items
+    try:
+        _skip_canonical_cases(engine, oracle, n, s, pts, want)
+    finally:
+        engine.set_option("ladder.pair_max_items", pair_max)
+
+
+def _skip_canonical_cases(engine, oracle, n, s, pts, want):
     assert np.array_equal(engine.mul(s, pts_ext=pts), want)
     for pos, top in ((n - 3, 0x10), (17, 0x20), (5, 0x80), (4097, 0xff)):
         t = s.copy()

@@ -86,4 +86,4 @@ def test_automatic_choice_takes_the_segmented_shape_for_long_polynomials(eng, or
     got = eng.pubpoly_eval_multi(commits, idx)
     names = [n for n, _ in eng.profile_read(16)]
     assert np.array_equal(got, want)
-    assert "k_mul_ladder" in names, names
+    assert any(n.startswith("k_mul_ladder") for n in names), names

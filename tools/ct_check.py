@@ -41,6 +41,7 @@ CSRC = os.path.join(ROOT, "kyber-rs_amd", "csrc")
 SECRET_ARGS = {
     "_Z12k_mul_ladderILi3E": ("kernels_ladder", {0: "scalars"}),
     "_Z12k_mul_ladderILi2E": ("kernels_ladder", {0: "scalars"}),
+    "_Z17k_mul_ladder_pair": ("kernels_ladder", {0: "scalars"}),
     "_Z11k_mont_prepPKim": ("kernels_ladder", {32: "scalars (top bits, canonical test)"}),
     "_Z12k_mul_base64ILb1ELi1024E": ("kernels_base", {0: "scalars", 8: "scalars_b"}),
     "_Z12k_mul_base64ILb1ELi768E": ("kernels_base", {0: "scalars", 8: "scalars_b"}),
