@@ -282,6 +282,14 @@ int kyb_lincomb_public_batch(const uint8_t* scalars, const uint8_t* pts_enc, con
 int kyb_lincomb_public_batch_dev(const uint8_t* scalars, const uint8_t* pts_enc, const int32_t* pts_ext, int shared_points,
                                  size_t m, size_t t, uint8_t* out_enc, int32_t* out_ext, uint8_t* ok, void* stream);
 
+/* PriPoly::eval / PriPoly::shares — src/share/poly.rs:133-152: out_shares[g][i] = sum_j coeffs[g][j] * x_i^j mod L with x_i = indices[i] + 1,
+ * for m SECRET polynomials of t coefficients (32-byte scalars, any 256-bit value, used as the reference's sc_mul / sc_add use them) at k
+ * public share indices; outputs are the canonical residues the reference's Scalar holds.  A dealer's n shares of a threshold-t polynomial
+ * are n * t scalar multiply-adds on one core in the reference; here the Horner chains are cut into segments, a lane each.  Constant time in
+ * the coefficients (the arithmetic of the signing kernel; loop bounds from t and the public indices only); host staging is wiped. */
+int kyb_pripoly_eval_batch(const uint8_t* coeffs, size_t m, size_t t, const uint32_t* indices, size_t k, uint8_t* out_shares);
+int kyb_pripoly_eval_batch_dev(const uint8_t* coeffs, size_t m, size_t t, const uint32_t* indices, size_t k, uint8_t* out_shares, void* stream);
+
 /* The scalar side of recover_commit (poly.rs:580-594): for m share sets of t PUBLIC share indices each,
  *     out[g*t + i] = prod_{j != i} x_j / (x_j - x_i) mod L,   x = index + 1,
  * the Lagrange coefficients at 0, as canonical 32-byte scalars — the reference's num / den with its Scalar::div (= multiplication by

@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "kyb_schnorr_sign_keyed_batch", "kyb_schnorr_sign_keyed_batch_dev", "kyb_eddsa_sign_keyed_batch", "kyb_eddsa_sign_keyed_batch_dev",
     "kyb_verify_batch", "kyb_verify_batch_dev", "kyb_pubpoly_eval_batch", "kyb_pubpoly_eval_batch_dev",
     "kyb_pubpoly_eval_multi_batch", "kyb_pubpoly_eval_multi_batch_dev",
-    "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev", "kyb_lincomb_public_batch", "kyb_lincomb_public_batch_dev", "kyb_lagrange_coeffs_batch", "kyb_lagrange_coeffs_batch_dev",
+    "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev", "kyb_lincomb_public_batch", "kyb_lincomb_public_batch_dev", "kyb_pripoly_eval_batch", "kyb_pripoly_eval_batch_dev", "kyb_lagrange_coeffs_batch", "kyb_lagrange_coeffs_batch_dev",
     "kyb_sum_batch", "kyb_sum_batch_dev",
     "kyb_pubpoly_eval_multi_enc_batch", "kyb_pubpoly_eval_multi_enc_batch_dev", "kyb_sum_enc_batch", "kyb_sum_enc_batch_dev",
     "kyb_dkg_verify_round_enc", "kyb_dkg_verify_round_enc_dev",
@@ -147,6 +147,8 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_equal_batch_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.kyb_lincomb_batch.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp]
     lib.kyb_lincomb_batch_dev.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp, vp]
+    lib.kyb_pripoly_eval_batch.argtypes = [vp, sz, sz, vp, sz, vp]
+    lib.kyb_pripoly_eval_batch_dev.argtypes = [vp, sz, sz, vp, sz, vp, vp]
     lib.kyb_lagrange_coeffs_batch.argtypes = [vp, sz, sz, vp]
     lib.kyb_lagrange_coeffs_batch_dev.argtypes = [vp, sz, sz, vp, vp]
     lib.kyb_lincomb_public_batch.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp]
@@ -535,6 +537,20 @@ class Engine:
         if want_ok:
             out += (ok,)
         return out if len(out) > 1 else enc
+
+    def pripoly_eval(self, coeffs, indices) -> np.ndarray:
+        """kyb_pripoly_eval_batch: coeffs (m, t, 32) secret polynomials (or (t, 32) for one), indices (k,) uint32 -> shares (m, k, 32) (or (k, 32)),
+        PriPoly::eval at x = index + 1 (poly.rs:133-141)"""
+        c = np.ascontiguousarray(coeffs, dtype=np.uint8)
+        one = c.ndim == 2
+        if one:
+            c = c[None]
+        if c.ndim != 3 or c.shape[2] != 32:
+            raise ValueError("coeffs must have shape (m, t, 32) or (t, 32)")
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        out = np.empty((c.shape[0], idx.shape[0], 32), dtype=np.uint8)
+        _check(self.lib.kyb_pripoly_eval_batch(_ptr(c), c.shape[0], c.shape[1], _ptr(idx), idx.shape[0], _ptr(out)), "kyb_pripoly_eval_batch")
+        return out[0] if one else out
 
     def lagrange_coeffs(self, indices) -> np.ndarray:
         """kyb_lagrange_coeffs_batch: indices (m, t) uint32 share indices -> (m, t, 32) Lagrange coefficients at 0 (x = index + 1), mod L"""

@@ -41,9 +41,9 @@ thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
 enum KernelId { KID_MUL, KID_MUL_BASE, KID_FINISH, KID_SIGN, KID_SIGN_HASH, KID_VERIFY_PREP, KID_VERIFY_FINAL, KID_POLY_EVAL, KID_MONT_PREP,
-                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_VERIFY_COOP, KID_FINISH_COOP, KID_SIGN_COOP, KID_MSM_TABLES, KID_MSM_ACCUMULATE, KID_MUL_LADDER_PAIR, KID_COUNT };
+                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_VERIFY_COOP, KID_FINISH_COOP, KID_SIGN_COOP, KID_MSM_TABLES, KID_MSM_ACCUMULATE, KID_MUL_LADDER_PAIR, KID_PRIPOLY_EVAL, KID_COUNT };
 const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval",
-                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop", "k_verify_coop", "k_finish_coop", "k_sign_coop", "k_msm_tables", "k_msm_accumulate", "k_mul_ladder_pair"};
+                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop", "k_verify_coop", "k_finish_coop", "k_sign_coop", "k_msm_tables", "k_msm_accumulate", "k_mul_ladder_pair", "k_pripoly_eval"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   std::mutex mu;                  // begin / read / every ProfScope: callable from any thread
@@ -1237,6 +1237,25 @@ int launch_sign(Ctx& g, const uint8_t* x, const uint8_t* k, const uint8_t* pub_i
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
   return sign_locked(g, r, x, k, pub_in, msgs, off, n, sig, nullptr, st);
+}
+
+// PriPoly::eval / shares (poly.rs:133-152) of m secret polynomials at k public indices: the Horner chains cut into segments so that
+// evaluations x segments fill the chip (a lane per segment; kernels_verify.hip), partial values in the stream's scratch, cleared by the sum.
+int launch_pripoly_eval(Ctx& g, const uint8_t* coeffs, size_t m, size_t t, const uint32_t* indices, size_t k, uint8_t* out, hipStream_t st) {
+  if (m == 0 || k == 0) return KYB_OK;
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  const size_t evals = m * k;
+  size_t segs = evals >= 65536 ? 1 : 65536 / evals;
+  if (segs > t / 8) segs = t / 8;                     // a segment is worth its 25 multiplications of x^(s len) only when it is a few coefficients long
+  if (segs > 64) segs = 64;
+  if (segs < 1) segs = 1;
+  if (segs > 1) { int rc = ensure_enc(g, r, 32 * evals * segs + 256); if (rc) return rc; }
+  ProfScope ps(g, st, KID_PRIPOLY_EVAL);
+  LAUNCHCK(launch::pripoly_eval(st, coeffs, m, t, indices, k, (uint32_t)segs, static_cast<uint8_t*>(r->enc), out));
+  return KYB_OK;
 }
 
 // EdDSA::sign for n (seed, msg) pairs: expansion + nonce, then the Schnorr pipeline.  pub_in: the public keys

@@ -56,6 +56,67 @@ k_sign_hash(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const 
   signal_done(df);
 }
 
+// PriPoly::eval / shares (share/poly.rs:133-152): out[g][i] = sum_j coeffs[g][j] * x_i^j mod L, x_i = indices[i] + 1 — a dealer's n private
+// shares of its secret polynomial (n x t scalar multiply-adds on one core in the reference).  The coefficients are SECRET: everything
+// below is sc_muladd (the signing kernel's arithmetic: fixed instruction stream, no address or branch from the operands) under loop bounds
+// that depend on t, the segment length and the public indices only.
+// Stage 1: lane (g, i, s) evaluates segment s of the chain, Q_s(x) = sum_{j < len} c[s*len + j] x^j, and multiplies it by x^(s*len)
+// (square-and-multiply over the 24 bits of the public exponent); stage 2 adds the S partial values of an evaluation and clears them.
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_pripoly_eval_part(const uint8_t* __restrict__ coeffs, size_t m, size_t t, const uint32_t* __restrict__ indices, size_t k, uint32_t segs, uint32_t len,
+                    uint8_t* __restrict__ part) {
+  const size_t id = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (id >= m * k * segs) return;
+  const size_t s = id % segs, gi = id / segs, i = gi % k, g = gi / k;
+  const size_t lo = s * (size_t)len, hi = (lo + len < t) ? lo + len : t;
+  uint32_t x[8], v[8], r[8];
+  const uint64_t xv = (uint64_t)indices[i] + 1u;
+  x[0] = (uint32_t)xv; x[1] = (uint32_t)(xv >> 32);
+  KYB_UNROLL for (int q = 2; q < 8; ++q) x[q] = 0u;
+  KYB_UNROLL for (int q = 0; q < 8; ++q) v[q] = 0u;
+#pragma unroll 1
+  for (size_t j = hi; j-- > lo;) {
+    uint32_t c[8];
+    load_words8(c, coeffs, g * t + j);
+    sc_muladd(r, v, x, c);
+    KYB_UNROLL for (int q = 0; q < 8; ++q) v[q] = r[q];
+  }
+  if (segs > 1u) {                                   // x^(s * len) mod L, exponent below 2^24 (t <= 2^24)
+    const uint32_t zero[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t pw[8] = {1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    const uint32_t e = (uint32_t)lo;
+#pragma unroll 1
+    for (int b = 23; b >= 0; --b) {
+      uint32_t sq[8], sx[8];
+      sc_muladd(sq, pw, pw, zero);
+      sc_muladd(sx, sq, x, zero);
+      const uint32_t bit = (e >> b) & 1u;
+      KYB_UNROLL for (int q = 0; q < 8; ++q) pw[q] = bit ? sx[q] : sq[q];
+    }
+    sc_muladd(r, v, pw, zero);
+    KYB_UNROLL for (int q = 0; q < 8; ++q) v[q] = r[q];
+  }
+  store_words8(part, id, v);
+}
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_pripoly_eval_sum(uint8_t* __restrict__ part, size_t n, uint32_t segs, uint8_t* __restrict__ out) {
+  const size_t gi = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (gi >= n) return;
+  const uint32_t one[8] = {1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, zero[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  uint32_t acc[8], r[8];
+  load_words8(acc, part, gi * segs);
+  store_words8(part, gi * segs, zero);
+#pragma unroll 1
+  for (uint32_t s = 1; s < segs; ++s) {
+    uint32_t p[8];
+    load_words8(p, part, gi * segs + s);
+    store_words8(part, gi * segs + s, zero);        // partial values of a secret polynomial do not stay in the scratch buffer
+    sc_muladd(r, p, one, acc);
+    KYB_UNROLL for (int q = 0; q < 8; ++q) acc[q] = r[q];
+  }
+  store_words8(out, gi, acc);
+}
+
 // verification, A half: s < L, checks and decode of the public key, h = SHA-512(R || A || msg) mod L.
 // Writes h and s as contiguous 32-byte records and A in reference limbs (inputs of the two multiplications).
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
@@ -210,6 +271,14 @@ hipError_t verify_tail_enc(hipStream_t st, uint4* proj, size_t stride, size_t n,
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_verify_fixup, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sigs, n, flags_a, flavor, status, df);
+  return hipGetLastError();
+}
+hipError_t pripoly_eval(hipStream_t st, const uint8_t* coeffs, size_t m, size_t t, const uint32_t* indices, size_t k, uint32_t segs, uint8_t* part, uint8_t* out) {
+  const uint32_t len = (uint32_t)((t + segs - 1) / segs);
+  hipLaunchKernelGGL(k_pripoly_eval_part, dim3(blocks_for(m * k * segs)), dim3(KYB_BLOCK), 0, st, coeffs, m, t, indices, k, segs, len, segs > 1u ? part : out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || segs == 1u) return e;
+  hipLaunchKernelGGL(k_pripoly_eval_sum, dim3(blocks_for(m * k)), dim3(KYB_BLOCK), 0, st, part, m * k, segs, out);
   return hipGetLastError();
 }
 hipError_t sign_hash(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n,

@@ -133,6 +133,8 @@ hipError_t poly_eval(bool split, hipStream_t st, const int32_t* commits, int t, 
 // partial sums of output g land in staging records g * nchunks + c
 hipError_t msm_bases_coop(hipStream_t st, const int32_t* pts_ext, size_t t, uint32_t* bases);
 hipError_t msm_tables(hipStream_t st, const uint32_t* bases, size_t t, uint32_t* tab);
+// out[g][i] = poly_g(indices[i] + 1) mod L for m secret polynomials of t coefficients at k public indices; part: m * k * segs * 32 bytes of scratch when segs > 1
+hipError_t pripoly_eval(hipStream_t st, const uint8_t* coeffs, size_t m, size_t t, const uint32_t* indices, size_t k, uint32_t segs, uint8_t* part, uint8_t* out);
 hipError_t lagrange_at_zero(hipStream_t st, const uint32_t* idx, size_t m, size_t t, uint8_t* out);      // out: m x t scalars, 32 bytes each
 hipError_t msm_accumulate(hipStream_t st, const uint8_t* scalars, const uint32_t* tab, size_t m, size_t t, int chunk, size_t nchunks, uint4* proj, size_t stride);
 

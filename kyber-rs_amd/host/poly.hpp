@@ -92,6 +92,20 @@ class PriPoly {
     for (size_t j = coeffs.size(); j-- > 0;) v = v * xi + coeffs[j];
     return PriShare{i, v};
   }
+  // poly.rs:144-152: the n shares p(1) .. p(n) — one engine call (kyb_pripoly_eval_batch: constant time in the coefficients) instead of
+  // n * t Scalar multiply-adds; same canonical residues as eval() above (tests compare the two)
+  std::vector<PriShare> shares(size_t n) const {
+    std::vector<uint8_t> c(32 * coeffs.size()), out(32 * n);
+    for (size_t j = 0; j < coeffs.size(); ++j) std::memcpy(&c[32 * j], coeffs[j].v.data(), 32);
+    std::vector<uint32_t> idx(n);
+    for (size_t i = 0; i < n; ++i) idx[i] = (uint32_t)i;
+    group::edwards25519::detail::engine_must(kyb_pripoly_eval_batch(c.data(), 1, coeffs.size(), idx.data(), n, out.data()), "PriPoly::shares");
+    std::vector<PriShare> r(n);
+    for (size_t i = 0; i < n; ++i) { r[i].i = i; std::memcpy(r[i].v.v.data(), &out[32 * i], 32); }
+    for (auto& b : c) { volatile uint8_t* q = &b; *q = 0; }
+    for (auto& b : out) { volatile uint8_t* q = &b; *q = 0; }
+    return r;
+  }
   // poly.rs:213-235
   PriPoly mul(const PriPoly& q) const {
     PriPoly r;

@@ -62,6 +62,13 @@ extern "C" {
                                             out_ext: *mut i32, ok: *mut u8) -> c_int;
     pub fn kyb_sum_enc_batch(pts_enc: *const u8, m: size_t, t: size_t, item_major: c_int, out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8) -> c_int;
     // page-locked batch buffers (optional: pageable slices work, through the engine's bounce buffers)
+    // round 3: a verifier's DKG round in one call, public-multiplier combinations, Lagrange coefficients, a dealer's private shares
+    pub fn kyb_dkg_verify_round_enc(commits_enc: *const u8, t: size_t, m: size_t, index: u32, eval_enc: *mut u8, eval_ext: *mut i32,
+                                    sums_enc: *mut u8, sums_ext: *mut i32, ok: *mut u8) -> c_int;
+    pub fn kyb_lincomb_public_batch(scalars: *const u8, pts_enc: *const u8, pts_ext: *const i32, shared_points: c_int, m: size_t, t: size_t,
+                                    out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8) -> c_int;
+    pub fn kyb_lagrange_coeffs_batch(indices: *const u32, m: size_t, t: size_t, out_scalars: *mut u8) -> c_int;
+    pub fn kyb_pripoly_eval_batch(coeffs: *const u8, m: size_t, t: size_t, indices: *const u32, k: size_t, out_shares: *mut u8) -> c_int;
     pub fn kyb_host_alloc(bytes: size_t) -> *mut c_void;
     pub fn kyb_host_free(p: *mut c_void);
 }

@@ -624,6 +624,17 @@ void orc_pubpoly_eval(uint8_t out_enc[32], const int32_t* commits_ext, size_t t,
   p3_tobytes(out_enc, &v);
 }
 
+/* PriPoly::eval (share/poly.rs:133-141): xi = set_int64(1 + i); v = zero; for j = t-1..0: v = v * xi (sc_mul); v = v + coeffs[j] (sc_add).
+ * Both steps leave the canonical residue, so one sc_mul_add per coefficient gives the same 32 bytes. */
+void orc_pripoly_eval(uint8_t out[32], const uint8_t* coeffs, size_t t, uint32_t index) {
+  uint8_t xi[32], v[32], w[32];
+  memset(xi, 0, 32); memset(v, 0, 32);
+  uint64_t x = (uint64_t)index + 1;
+  for (int b = 0; b < 8; b++) xi[b] = (uint8_t)(x >> (8 * b));
+  for (size_t j = t; j-- > 0;) { orc_sc_muladd(w, v, xi, coeffs + 32 * j); memcpy(v, w, 32); }
+  memcpy(out, v, 32);
+}
+
 /* recover_commit's accumulation (share/poly.rs:579-600): acc = null; for each i: tmp = mul(c_i, Some(y_i)); acc = add(acc, tmp).
  * (The Lagrange coefficients c_i are scalar arithmetic and are the caller's; PubPoly::add / recover_pub_poly, poly.rs:486-507,
  * 607-634, reduce to the same sum per coefficient.) */

@@ -321,6 +321,14 @@ int main() {
       std::vector<Scalar> host = kyber::share::detail::lagrange_at_zero(xs), gpu = kyber::share::detail::lagrange_at_zero_gpu(idx, 1, idx.size());
       for (size_t i = 0; i < idx.size(); ++i) CHECK(host[i] == gpu[i], "lagrange_at_zero: engine == host restatement");
     }
+    // PriPoly::shares through the engine == PriPoly::eval on the host (poly.rs:133-152), short and long polynomials
+    for (size_t tt : {size_t(1), size_t(5), size_t(90)}) {
+      PriPoly q = new_pri_poly(tt);
+      std::vector<PriShare> sh = q.shares(37);
+      bool same = sh.size() == 37;
+      for (size_t i = 0; i < sh.size(); ++i) same = same && sh[i].i == i && sh[i].v == q.eval(i).v;
+      CHECK(same, "PriPoly::shares: engine == host Horner");
+    }
     // batch of share sets in one launch == one by one
     {
       std::vector<std::vector<std::optional<PubShare>>> sets;

@@ -203,6 +203,12 @@ class Oracle:
         self.lib.orc_pubpoly_eval(o, _p(c), ctypes.c_size_t(c.shape[0]), ctypes.c_uint32(index))
         return o.raw
 
+    def pripoly_eval(self, coeffs, index: int) -> bytes:
+        c = np.ascontiguousarray(coeffs, dtype=np.uint8).reshape(-1, 32)
+        o = self._b(32)
+        self.lib.orc_pripoly_eval(o, _p(c), ctypes.c_size_t(c.shape[0]), ctypes.c_uint32(index))
+        return o.raw
+
     def lincomb(self, scalars, pts_ext) -> bytes:
         sc = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
         c = _i32(pts_ext).reshape(-1, 40)

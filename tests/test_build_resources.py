@@ -41,6 +41,7 @@ DEFAULT_PATH = [
     ("_Z10k_mul_coopPKhPKim", 256), ("_Z15k_mul_base_coopPKhS0_mm", 256), ("_Z14k_mul_enc_coopPKhS0_m", 256), ("_Z13k_verify_coopPKhS0_S0_PKjmi", 256),
     ("_Z11k_sign_coopPKhS0_S0_S0_PKjm", 256), ("_Z13k_decode_coopPKhmPiPhi", 256), ("_Z13k_finish_coopPK", 256), ("_Z10k_sum_coopPKjPKimm", 256),
     ("_Z16k_poly_eval_coopPKiiPKjmim", 256), ("_Z15k_poly_eval_segPKiiPKjmmii", 256), ("_Z15k_poly_eval_sumPKjmi", 256),
+    ("_Z19k_pripoly_eval_part", 256), ("_Z18k_pripoly_eval_sum", 256),
     ("_Z15k_diag_mad_peakILb0E", 64), ("_Z15k_diag_mad_peakILb1E", 64),      # the peak microbenchmark runs 8 wavefronts per SIMD
     ("_Z12k_mul_base64ILb1ELi768E", 168), ("_Z12k_mul_base64ILb1ELi512E", 256),   # selectable workgroup sizes of the fixed-base kernel
 ]

@@ -127,3 +127,35 @@ def test_lagrange_coefficients_and_recover_commit_on_the_gpu(engine, oracle):
     want = engine.mul_base(np.frombuffer(b"".join(c[0].to_bytes(32, "little") for c in coeffs), dtype=np.uint8).reshape(m, 32))
     assert np.array_equal(got, want)
     assert bytes(got[3]) == oracle.mul_base(coeffs[3][0].to_bytes(32, "little"))
+
+
+def test_pripoly_shares_on_the_gpu(engine, oracle):
+    """kyb_pripoly_eval_batch (PriPoly::eval / shares, poly.rs:133-152) == the oracle == Python integers: one lane per evaluation and chains cut
+    into segments (few evaluations of a long polynomial), several polynomials in one call, unreduced coefficients, index 2^32 - 2; and the
+    dealer's identity  share_i * B == PubPoly::eval(i)  of the committed polynomial"""
+    L = synth.L
+    rng = np.random.default_rng(77)
+    for m, t, k in ((1, 1, 1), (1, 2, 5), (1, 43, 64), (3, 17, 9), (1, 683, 1024), (2, 683, 40), (1, 3000, 3), (1, 8, 70000)):
+        coeffs = synth.scalars(m * t, 1000 + t).reshape(m, t, 32)
+        coeffs[0, t // 2] = synth.raw256(1, 5)[0]                       # one unreduced value
+        idx = rng.integers(0, 1 << 16, k, dtype=np.uint64).astype(np.uint32)
+        idx[0] = 0
+        if k > 2:
+            idx[1], idx[2] = 0xfffffffe, k - 1
+        got = engine.pripoly_eval(coeffs, idx)
+        assert got.shape == (m, k, 32)
+        for g in range(m):
+            ints = [int.from_bytes(bytes(c), "little") for c in coeffs[g]]
+            for i in sorted({0, 1, 2, k // 2, k - 1} & set(range(k))):
+                x = int(idx[i]) + 1
+                want = sum(c * pow(x, j, L) for j, c in enumerate(ints)) % L
+                assert int.from_bytes(bytes(got[g, i]), "little") == want, (m, t, k, g, i)
+                if t <= 700:
+                    assert bytes(got[g, i]) == oracle.pripoly_eval(coeffs[g], int(idx[i])), (m, t, k, g, i)
+    # one polynomial given as (t, 32): shares p(1) .. p(n), and the commitments' evaluation agrees with them
+    t, n = 21, 64
+    coeffs = synth.scalars(t, 2024)
+    shares = engine.pripoly_eval(coeffs, np.arange(n, dtype=np.uint32))
+    assert shares.shape == (n, 32)
+    _, commits = engine.mul_base(coeffs, want_ext=True)
+    assert np.array_equal(engine.mul_base(shares), engine.pubpoly_eval(commits, np.arange(n, dtype=np.uint32)))

@@ -210,3 +210,17 @@ def test_point_is_canonical_follows_the_reference_expression(oracle):
                     for flavor in (0, 1):
                         assert M.verify(flavor, enc, msg, sig) == oracle.verify(flavor, enc, msg, sig)
                         assert M.verify(flavor, pub, msg, enc + sig[32:]) == oracle.verify(flavor, pub, msg, enc + sig[32:])
+
+
+def test_pripoly_eval_matches_python_integers(oracle):
+    """orc_pripoly_eval (PriPoly::eval, poly.rs:133-141) == sum c_j x^j mod L in Python integers: canonical and unreduced coefficients, t = 1, the
+    largest index the ABI takes"""
+    import numpy as np
+    import synth
+    L = synth.L
+    for t, seed in ((1, 1), (2, 2), (9, 3), (64, 4)):
+        coeffs = np.concatenate([synth.scalars(t - t // 2, 900 + seed), synth.raw256(t // 2, 900 + seed)])
+        ints = [int.from_bytes(bytes(c), "little") for c in coeffs]
+        for index in (0, 1, 2, 511, 65535, 0xfffffffe):
+            want = sum(c * pow(index + 1, j, L) for j, c in enumerate(ints)) % L
+            assert int.from_bytes(oracle.pripoly_eval(coeffs, index), "little") == want, (t, index)

@@ -52,6 +52,8 @@ SECRET_ARGS = {
     "_Z11k_sign_coopPKhS0_S0_S0_PKjm": ("kernels_coop", {0: "x (private keys)", 8: "k (nonces)"}),
     "_Z11k_sign_hashPKhS0_S0_PKjm": ("kernels_verify", {0: "x (private keys)", 8: "k (nonces)"}),
     "_Z12k_eddsa_prepPKhS0_PKjm": ("kernels_verify", {0: "seeds"}),
+    "_Z19k_pripoly_eval_part": ("kernels_verify", {0: "coefficients of secret polynomials"}),
+    "_Z18k_pripoly_eval_sum": ("kernels_verify", {0: "partial values of secret polynomials"}),
     "_Z8k_finishPK": ("kernels_misc", {0: "projective results (a DH shared secret before its encoding)"}),
 }
 # the windowed-table kernels (mul.algo = 0, radix-16 / -32 fixed base) are selectable cross-checks, not default paths; the public-input

@@ -86,7 +86,7 @@ while time.time() < t_end:
     n = int(rng.choice(SIZES)) if rng.integers(0, 3) else int(rng.integers(1, 900))
     lo = int(rng.integers(0, NMAX - n + 1))
     sl = slice(lo, lo + n)
-    op = str(rng.choice(["mul_base", "mul_ext", "mul_enc", "sign", "verify", "decode", "encode", "eval", "eval_wire", "lincomb", "lincomb_pub", "dkg_round", "lagrange", "sum", "sum_wire"]))
+    op = str(rng.choice(["mul_base", "mul_ext", "mul_enc", "sign", "verify", "decode", "encode", "eval", "eval_wire", "lincomb", "lincomb_pub", "dkg_round", "lagrange", "pripoly", "sum", "sum_wire"]))
     counts[op] = counts.get(op, 0) + 1
     cases += 1
     ctx = (op, n, lo, opts)
@@ -215,6 +215,17 @@ while time.time() < t_end:
                         if good[g_, j]:
                             acc = orc.add(acc, POOL_P[base_i + g_ * t + j])
                     assert bytes(sums[j]) == orc.encode(acc)
+        elif op == "pripoly":
+            t = int(rng.choice([1, 2, 7, 8, 64, 200, 900]))
+            k_ = max(1, min(n, 3000))
+            m = int(rng.choice([1, 1, 3]))
+            cf = np.resize(POOL_S[lo:] if lo + 8 < NMAX else POOL_S, (m * t, 32)).reshape(m, t, 32).copy()      # canonical, unreduced and quirk scalars
+            idx = rng.integers(0, 1 << int(rng.choice([1, 10, 16, 32])), k_, dtype=np.uint64).astype(np.uint32)
+            idx[idx == 0xffffffff] = 3
+            got = eng.pripoly_eval(cf, idx)
+            for g_ in sorted({0, m - 1}):
+                for i in sorted({0, k_ // 2, k_ - 1}):
+                    assert bytes(got[g_, i]) == orc.pripoly_eval(cf[g_], int(idx[i]))
         elif op == "lagrange":
             t = int(rng.choice([1, 2, 3, 17, 64, 200]))
             m = max(1, min(n, 1200) // t)
