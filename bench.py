@@ -22,7 +22,7 @@ collective; the only collective is the one-time broadcast of the base-point tabl
 
 Rank 0 prints ONE JSON line.  `value` is whole-job items/s of the PRIMARY workload over the timed K steps (barrier + synchronize on
 both sides, max over ranks).  At N = 1 the other single-GPU configurations are then timed the same way, each in its own timed
-region OUTSIDE the primary one, and reported under `workloads`; `small_calls` gives the wall time of ONE synchronous host-pointer
+region OUTSIDE the primary one, and reported under `workloads`; `small_calls` (and `mid_size_calls`, 8,192 items) give the wall time of ONE synchronous host-pointer
 call with 1 / 64 items, and the `mul` workload carries `host_pinned` / `host_pageable`: the rate of kyb_mul_batch on 2^20 items in
 host memory (PCIe-inclusive; never `value`).
 
@@ -78,7 +78,7 @@ HBM_PEAK_GBS = 8000.0
 DEFAULT_N = {"mul": 1 << 20, "mul_enc": 1 << 20, "mul_base": 1 << 20, "sign": 1 << 18, "verify": 1 << 20}
 PROFILE_ROUNDS = ("r03", "r02", "r01")
 OPTION_KEYS = ("mul.algo", "mul.ladder_waves", "mul.select", "mul_base.radix", "mul_base.select", "mul_base.block", "finish.batched", "finish.min_items",
-               "ladder.skip_canonical")
+               "ladder.skip_canonical", "ladder.pair_max_items")
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -438,6 +438,42 @@ def device_identity(torch, local):
     return ident
 
 
+def mid_size_calls(eng, orc, threads, n=8192):
+    """A DKG-round-sized call (n = 8,192: more SIMDs than wavefronts): ONE synchronous host-pointer call per operation, median wall time in
+    milliseconds, and the same variable-base call with the two-lane ladder switched off (k_mul_ladder_pair).  Every output of
+    mul / mul_base, and the verification statuses, are checked against the oracle.  Not a throughput figure."""
+    import numpy as np
+    import synth as _s
+    s = _s.scalars(n, 81)
+    k = _s.scalars(n, 82, b"k")
+    enc, ext = eng.mul_base(s, want_ext=True)
+    msgs = _s.messages(n, 83)
+    sigs = eng.schnorr_sign(s, k, msgs)
+    sigs[::7, 33] ^= 1
+    if not (np.array_equal(enc, orc.mul_base_batch(s, nthreads=threads)) and np.array_equal(eng.mul(k, pts_ext=ext), orc.mul_batch(k, ext, nthreads=threads))
+            and np.array_equal(eng.verify(enc, msgs, sigs, 1), orc.verify_batch(1, enc, msgs, sigs, nthreads=threads))):
+        raise SystemExit("PARITY FAILURE (mid-size calls): GPU output differs from the oracle")
+
+    def med(fn, reps=15):
+        fn(); fn()
+        ts = []
+        for _ in range(reps):
+            a = time.perf_counter(); fn(); ts.append(time.perf_counter() - a)
+        return round(sorted(ts)[len(ts) // 2] * 1e3, 4)
+
+    out = {"unit": "ms per host-pointer call (median of 15)", "items": n, "checked_against_oracle": True,
+           "mul_base": med(lambda: eng.mul_base(s)), "mul": med(lambda: eng.mul(k, pts_ext=ext)), "mul_enc": med(lambda: eng.mul(k, pts_enc=enc)),
+           "sign": med(lambda: eng.schnorr_sign(s, k, msgs)), "verify": med(lambda: eng.verify(enc, msgs, sigs, 1))}
+    pair = eng.get_option("ladder.pair_max_items")
+    eng.set_option("ladder.pair_max_items", 0)
+    try:
+        out["mul_one_lane_per_item"] = med(lambda: eng.mul(k, pts_ext=ext))
+        out["verify_one_lane_per_item"] = med(lambda: eng.verify(enc, msgs, sigs, 1))
+    finally:
+        eng.set_option("ladder.pair_max_items", pair)
+    return out
+
+
 def table_digest(eng):
     """what this rank's engine holds as the base-point table after the broadcast: every rank must report the same"""
     return hashlib.sha256(eng.base_table().tobytes()).hexdigest()[:16]
@@ -476,7 +512,7 @@ def small_call_latency(eng, orc):
     return out
 
 
-def host_pointer_rates(w, eng, orc, threads, calls=3):
+def host_pointer_rates(w, eng, orc, threads, calls=5):
     """kyb_mul_batch on the same 2^20 items in HOST memory (what a Rust caller holds): page-locked buffers (kyb_host_alloc) and ordinary
     pageable numpy arrays; PCIe-inclusive, synchronous calls, 256 outputs of each against the oracle.  Never `value`."""
     import numpy as np
@@ -490,14 +526,14 @@ def host_pointer_rates(w, eng, orc, threads, calls=3):
     outp = np.empty((n, 32), dtype=np.uint8)
     res = {}
     for name, fn, out in (("host_pinned", lambda: eng.mul_into(ps, pe, po), po), ("host_pageable", lambda: eng.mul_into(sc, pts, outp), outp)):
-        fn()
-        t0 = time.perf_counter()
+        fn(); fn()                                       # the first calls size the staging buffers and wake the copy threads
+        ts = []
         for _ in range(calls):
-            fn()
-        dt = (time.perf_counter() - t0) / calls
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        dt = sorted(ts)[len(ts) // 2]                    # median call
         if not np.array_equal(out[idx], want):
             raise SystemExit(f"PARITY FAILURE ({name}): host-pointer output differs from the oracle")
-        res[name] = {"value": round(n / dt, 1), "unit": UNIT["mul"], "ms_per_call": round(dt * 1e3, 3), "calls": calls, "items": n,
+        res[name] = {"value": round(n / dt, 1), "unit": UNIT["mul"], "ms_per_call": round(dt * 1e3, 3), "calls": calls, "statistic": "median call after two warm-up calls", "items": n,
                      "bytes_over_pcie_per_item": 224, "pcie_gb_s": round(224 * n / dt / 1e9, 2), "parity_checked_items": 256}
     return res
 
@@ -620,6 +656,7 @@ def run_ranks(args):
                     del ow
                 line["workloads"] = others
                 line["small_calls"] = small_call_latency(eng, orc)
+                line["mid_size_calls"] = mid_size_calls(eng, orc, threads)
                 peak2 = eng.mad_peak(50.0)
                 line["roofline"]["peak_repeat_at_end_of_run"] = {"peak": round(peak2["mads_per_s"] / 1e12, 3), "clock_ghz": round(peak2["clock_ghz"], 4)}
         print(json.dumps(line), flush=True)

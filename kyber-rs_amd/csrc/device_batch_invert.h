@@ -1,6 +1,6 @@
 // Montgomery's trick on the device (included by the kernel units that share one field inversion between FINISH_K items).
 #pragma once
-#include "fe25519.h"
+#include "fe_invert_gcd.h"
 
 namespace kyb {
 
@@ -13,7 +13,7 @@ __device__ __forceinline__ void batch_invert(const fe& prefix_prev, fe& inv_prev
   fe d, pre, inv, di;
   load(T, d);
   if (T == 0) fe_copy(pre, d); else fe_mul(pre, prefix_prev, d);
-  if constexpr (T + 1 < K) batch_invert<T + 1, K>(pre, inv, load, emit); else fe_invert(inv, pre);
+  if constexpr (T + 1 < K) batch_invert<T + 1, K>(pre, inv, load, emit); else fe_inv(inv, pre);
   if (T == 0) fe_copy(di, inv); else fe_mul(di, inv, prefix_prev);
   emit(T, di);
   if (T > 0) { load(T, d); fe_mul(inv_prev, inv, d); }

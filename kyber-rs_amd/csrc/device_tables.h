@@ -306,7 +306,7 @@ __device__ __forceinline__ void store_ext(int32_t* base, size_t i, const fe& X, 
 // encode (and optionally emit affine extended limbs, Z = 1) from a projective result
 __device__ __forceinline__ void finish_point(const fe& X, const fe& Y, const fe& Z, uint8_t* out_enc, int32_t* out_ext, size_t i, bool live) {
   fe zi, x, y;
-  fe_invert(zi, Z);
+  fe_inv(zi, Z);
   fe_mul(x, X, zi);
   fe_mul(y, Y, zi);
   if (out_enc != nullptr) {

@@ -13,6 +13,7 @@
 // which is what p1p1_to_p2 / p1p1_to_p3 require.
 #pragma once
 #include "fe25519.h"
+#include "fe_invert_gcd.h"
 
 namespace kyb {
 
@@ -185,7 +186,7 @@ KYB_HD void ge_precomp_cneg(ge_precomp& c, uint32_t neg) {
 // 32-byte encoding as 8 LE words (ge.rs:112-122): y with the sign of x in bit 255
 KYB_HD void ge_encode(uint32_t w[8], const fe& X, const fe& Y, const fe& Z) {
   fe recip, x, y;
-  fe_invert(recip, Z);
+  fe_inv(recip, Z);
   fe_mul(x, X, recip);
   fe_mul(y, Y, recip);
   fe_to_words(w, y);

@@ -24,7 +24,7 @@ KYB_HD void schnorr_sign(uint32_t sig[16], const uint32_t x[8], const uint32_t k
   ge_scalarmult_base(A, x, tbl);
   fe zz, zi, ziR, ziA;
   fe_mul(zz, R.Z, A.Z);
-  fe_invert(zi, zz);
+  fe_inv(zi, zz);
   fe_mul(ziR, zi, A.Z);     // 1/Z_R
   fe_mul(ziA, zi, R.Z);     // 1/Z_A
   uint32_t renc[8], aenc[8];

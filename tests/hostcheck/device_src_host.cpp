@@ -108,6 +108,29 @@ void hd_fe_invert(uint8_t out[32], const uint8_t a[32]) {
   fe_to_words(w, h);
   memcpy(out, w, 32);
 }
+// the divstep inversion (fe_invert_gcd.h) on the same input convention
+void hd_fe_invert_gcd(uint8_t out[32], const uint8_t a[32]) {
+  uint32_t wa[8], w[8];
+  load_words(wa, a);
+  fe fa, h;
+  fe_from_words(fa, wa);
+  fe_invert_gcd(h, fa);
+  fe_to_words(w, h);
+  memcpy(out, w, 32);
+}
+// ... and on limbs at the upper end of what the finish kernels hand it (every limb 3.9 x its mask: a value far above p)
+void hd_fe_invert_gcd_loose(uint8_t out[32], uint8_t out_fermat[32], const uint8_t a[32]) {
+  uint32_t wa[8], w[8];
+  load_words(wa, a);
+  fe fa, t, h, h2;
+  fe_from_words(fa, wa);
+  fe_add(t, fa, fa); fe_add(t, t, fa);                // 3 x tight, no carry
+  fe_invert_gcd(h, t);
+  fe_reduce_weak(t, t);
+  fe_invert(h2, t);
+  fe_to_words(w, h); memcpy(out, w, 32);
+  fe_to_words(w, h2); memcpy(out_fermat, w, 32);
+}
 // worst-case bound probe: all limbs of f at kf*T, of g at kg*T (in 1/100 units)
 void hd_fe_mul_bound_probe(int kf100, int kg100) {
   fe f, g, h;

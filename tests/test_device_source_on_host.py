@@ -63,6 +63,24 @@ def test_field_ops_match_integers(hd):
     assert hd.hd_overflows() == 0
 
 
+def test_divstep_inversion_equals_the_exponentiation(hd):
+    """fe_invert_gcd (600 constant-time divsteps, fe_invert_gcd.h) == z^(p-2) mod p: edge values (0 -> 0, 1, p - 1, values >= p, powers of
+    two), 4000 random values, and loose limbs (3 x tight) against the exponentiation on the same element"""
+    rnd = random.Random(7)
+    P = M.P
+    vals = [0, 1, 2, 3, 19, 38, P - 1, P - 2, P - 19, P, P + 1, P + 18, 2**255 - 1, (P - 1) // 2, (P + 1) // 2, 2**254, 2**254 - 1, 2**30, 2**30 - 1]
+    vals += [1 << k for k in range(0, 255, 5)] + [P - (1 << k) for k in range(1, 254, 9)] + [rnd.getrandbits(255) for _ in range(4000)]
+    for v in vals:
+        o = B(32)
+        hd.hd_fe_invert_gcd(o, v.to_bytes(32, "little"))
+        assert int.from_bytes(o.raw, "little") == pow(v % P, P - 2, P), hex(v)
+    for v in vals[:200]:
+        o, o2 = B(32), B(32)
+        hd.hd_fe_invert_gcd_loose(o, o2, v.to_bytes(32, "little"))
+        assert o.raw == o2.raw and int.from_bytes(o.raw, "little") == pow(3 * v % P, P - 2, P), hex(v)
+    assert hd.hd_overflows() == 0
+
+
 def test_limb_bound_contract(hd):
     """fe_mul(f <= 6T, g <= 3.3T) and fe_sq(f <= 3.3T) never overflow; just beyond, they do."""
     base = hd.hd_overflows()
