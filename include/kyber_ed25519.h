@@ -369,7 +369,7 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *                     base with four wavefronts per item; default 512).  Same results either way.
  *   ladder.pair_max_items  ladder launches (variable base, verification, linear combinations) of at most this many items give every item TWO
  *                     lanes of a wavefront, which split the products of a ladder step between them and keep the operand's Montgomery image
- *                     projective, so that no inversion runs in front (default 32768 = one wavefront per SIMD, 0 = never): up to there the
+ *                     projective, so that no inversion runs in front (default 128 x compute units = one wavefront per SIMD: 32768 on an MI355X, 0 = never): up to there the
  *                     call time is one lane's chain of 255 steps, and the two-lane form takes 0.49 instead of 0.79 ms.  Same results.  These
  *                     launches always walk 256 bits (minus publicly known zeros): ladder.skip_canonical does not apply to them.
  *   coop.ladder_max_items  variable base and linear combinations leave the one-item-per-wavefront kernels above this many items (default 3072;
@@ -393,6 +393,9 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *                     split the Horner chain, 2..32)
  *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder
  *   verify.by_encoding 1 (default): large batches test the equation as enc(s*B - h*A) == R bytes and decode R only on a mismatch
+ *   host.zero_copy_kib  host-pointer calls whose arrays together fit this many KiB skip every hipMemcpy: the inputs are copied into the
+ *                     context's page-locked buffer by the calling thread and the kernels read and write it over PCIe (default 4096).
+ *                     Larger calls of fewer than 2^16 items copy in, run and copy out on the engine stream.
  *   host.pipe_chunks  host-pointer batches of 2^16 items or more are pipelined (one copy-in lane, two compute lanes, one copy-out lane)
  *                     over chunks of 1 1 2 4 4 2 2 .. units; the unit is 1/value of the batch (default 16, 2..64)
  *   host.copy_threads host threads that move pageable batches through the bounce buffers (0 = auto)

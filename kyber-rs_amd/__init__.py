@@ -195,8 +195,36 @@ def _rows(a: Optional[np.ndarray], n: int, name: str) -> None:
         raise ValueError(f"{name} holds {a.shape[0]} records, expected {n}")
 
 
-def _msg_blob(msgs: Sequence[bytes], n: int):
+class PackedMessages:
+    """n messages in the C ABI's own form — one byte blob and n + 1 offsets — packed once (pack_messages) and handed to any number of
+    sign / verify calls, so that a timed call does not contain the Python loop that concatenates them"""
+
+    def __init__(self, blob: np.ndarray, off: np.ndarray):
+        self.blob, self.off = blob, off
+
+    def __len__(self):
+        return self.off.shape[0] - 1
+
+    def __getitem__(self, sl):
+        """messages [a, b) of the pack (a slice with step 1): the same blob, offsets rebased"""
+        a, b, step = sl.indices(len(self))
+        if step != 1:
+            raise ValueError("PackedMessages takes contiguous slices only")
+        off = self.off[a:b + 1]
+        lo, hi = int(off[0]), int(off[-1])
+        return PackedMessages(np.ascontiguousarray(np.append(self.blob[lo:hi], np.uint8(0))), (off - off[0]).astype(np.uint32))
+
+
+def pack_messages(msgs: Sequence[bytes]) -> PackedMessages:
+    return PackedMessages(*_msg_blob(msgs, len(msgs)))
+
+
+def _msg_blob(msgs, n: int):
     """concatenated messages + the n+1 offsets of the C ABI (uint32: the blob must stay below 4 GiB)"""
+    if isinstance(msgs, PackedMessages):
+        if len(msgs) != n:
+            raise ValueError(f"{len(msgs)} messages for {n} items")
+        return msgs.blob, msgs.off
     if len(msgs) != n:
         raise ValueError(f"{len(msgs)} messages for {n} items")
     total = sum(len(m) for m in msgs)

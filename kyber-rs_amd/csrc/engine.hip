@@ -116,6 +116,7 @@ struct Ctx {
   std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: the chunk unit is 1/this of the batch (plan_chunks)
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
+  std::atomic<int> opt_zero_copy_kib{4096};         // host-pointer calls whose arrays fit this many KiB run their kernels on the context's page-locked buffer (no hipMemcpy); 512 in round 2, 4 MiB wins up to 16,384 items (profiles/r03/mid_size_host_calls.log)
   std::atomic<int> opt_ladder_pair_max{32768};    // ladder launches of at most this many items give each item two lanes (k_mul_ladder_pair: one wavefront per SIMD up to here); 0 = never
   std::atomic<int> opt_coop_ladder_max{3072};     // variable base, linear combinations (verification: 7/8 of it): above this the two-lane batch ladder is faster than one item per wavefront (profiles/r03/ladder_pair_probe.log)
   std::atomic<int> opt_ladder_skip_canonical{1};  // the batch ladder skips the four leading bits when no scalar of the launch has one set (canonical scalars)
@@ -268,7 +269,7 @@ struct DoneScope {          // posts / withdraws the request around the launch s
   ~DoneScope() { tl_done = nullptr; }
 };
 
-// Host-pointer batches of fixed-size records (run_host_batch): up to 512 KiB the kernels work on page-locked host memory directly;
+// Host-pointer batches of fixed-size records (run_host_batch): up to host.zero_copy_kib (4 MiB) the kernels work on page-locked host memory directly;
 // up to 2^16 items the arrays are copied in, processed and copied out on the engine stream; beyond that the batch is pipelined
 // over copy lanes and compute lanes (run_host_batch_pipelined).  Page-locked caller buffers (kyb_host_alloc) are handed to the DMA
 // engines as they are.  Pageable ones would make every hipMemcpyAsync a blocking, single-threaded staging copy inside the runtime
@@ -279,7 +280,7 @@ struct HostArr { const void* in; void* out; size_t bytes; bool secret = false; }
 template <class F> struct ScopeExit { F f; ~ScopeExit() { f(); } };
 template <class F> ScopeExit<F> on_scope_exit(F f) { return ScopeExit<F>{f}; }
 constexpr size_t PIPE_MIN_ITEMS = (size_t)1 << 16;
-constexpr size_t ZERO_COPY_BYTES = (size_t)1 << 19;      // host-pointer calls up to this size skip the copies: kernels work on page-locked host memory
+inline size_t zero_copy_bytes(const Ctx& g) { return (size_t)g.opt_zero_copy_kib << 10; }      // host-pointer calls up to this size skip the copies: kernels work on page-locked host memory (host.zero_copy_kib)
 
 // ---- large host-pointer batches: copy lanes and compute lanes ------------------------------------------------------
 // The whole batch gets device staging of its own (a 2^20-item variable-base batch: 235 MB of 288 GB), so nothing waits for a
@@ -434,9 +435,9 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
   const size_t cap = (n + 1023) & ~(size_t)1023;
   size_t off[8], total = 0;
   for (int k = 0; k < na; ++k) { off[k] = total; total += up256(arrs[k].bytes * cap); }
-  if (total <= ZERO_COPY_BYTES) {
+  if (total <= zero_copy_bytes(g)) {
     // small batch: kernels on the page-locked buffer itself (see HostCall::run)
-    int rc = ensure_pin(g, 0, ZERO_COPY_BYTES);
+    int rc = ensure_pin(g, 0, zero_copy_bytes(g));
     if (rc) return rc;
     uint8_t* dptr[8];
     for (int k = 0; k < na; ++k) {
@@ -534,10 +535,10 @@ class HostCall {
   int run(Body body) {
     Ctx& g = g_;
     std::lock_guard<std::mutex> lk(g.mu);
-    if (total_ <= ZERO_COPY_BYTES) {
+    if (total_ <= zero_copy_bytes(g)) {
       // small call: the kernels read and write the context's page-locked buffer directly over PCIe — no hipMemcpy at all
       // (each costs ~10 us of runtime work, more than the transfer), one launch sequence and one stream synchronisation
-      int rc = ensure_pin(g, 0, ZERO_COPY_BYTES);
+      int rc = ensure_pin(g, 0, zero_copy_bytes(g));
       if (rc) return rc;
       base_ = g.pin[0];
       // secret(): cleared on EVERY way out (each return below is behind a completed wait or a stream synchronisation)
@@ -785,6 +786,7 @@ int ctx_new(int device, bool build_table, Ctx** out) {
   Ctx& g = *c;
   g.device = device;
   g.cus = prop.multiProcessorCount;
+  g.opt_ladder_pair_max = g.cus * 128;               // two lanes per item while that is at most one wavefront per SIMD: 4 SIMDs x 64 lanes / 2 per CU (32,768 on 256 CUs)
   snprintf(g.name, sizeof(g.name), "%s", prop.name);
 #define CTXCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ctx_release(c); return fail(KYB_E_HIP, #x, e_); } } while (0)
   CTXCK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));

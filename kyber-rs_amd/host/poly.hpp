@@ -7,6 +7,7 @@
 //   recover_commit    src/share/poly.rs:566-603                   Lagrange at 0: one linear combination
 //   recover_pub_poly  src/share/poly.rs:607-634                   t linear combinations over shared points
 //   PriPoly::mul, minus_const, lagrange_basis   src/share/poly.rs:213-235, 313-319, 640-668   scalar side, host
+//   PriPoly::shares, recover_secret             src/share/poly.rs:144-152, 244-280              kyb_pripoly_eval_batch / kyb_lagrange_coeffs_batch + host dot product
 #pragma once
 #include <algorithm>
 #include <optional>
@@ -285,6 +286,29 @@ inline std::vector<Point> recover_commit_batch(const std::vector<std::vector<std
     pts.insert(pts.end(), xy.y.begin(), xy.y.end());
   }
   return detail::lincomb(detail::lagrange_at_zero_gpu(idx, sets.size(), t), pts, false, sets.size(), t, "recover_commit_batch", true);
+}
+
+// poly.rs:244-280 (recover_secret; xy_scalar :282-311 sorts by index, keeps the first t, a repeated index overwrites): the secret p(0) from
+// t private shares.  The reference spends 2 t^2 Scalar products and t divisions on the Lagrange coefficients of the PUBLIC indices; those come
+// from the engine (kyb_lagrange_coeffs_batch), the t products with the secret shares stay on the host.  Same canonical scalar.
+inline Scalar recover_secret(const std::vector<std::optional<PriShare>>& shares, size_t t, size_t /*n*/) {
+  std::vector<const PriShare*> sorted;
+  for (const auto& s : shares) if (s) sorted.push_back(&*s);
+  std::stable_sort(sorted.begin(), sorted.end(), [](const PriShare* a, const PriShare* b) { return a->i < b->i; });
+  std::vector<uint32_t> idx;
+  std::vector<Scalar> y;
+  for (const PriShare* s : sorted) {
+    if (!idx.empty() && idx.back() == (uint32_t)s->i) { y.back() = s->v; continue; }
+    idx.push_back((uint32_t)s->i);
+    y.push_back(s->v);
+    if (idx.size() == t) break;
+  }
+  if (idx.size() < t) throw PolyError("not enough shares to recover secret");
+  Scalar acc = Scalar().zero();
+  if (idx.empty()) return acc;
+  const std::vector<Scalar> lam = detail::lagrange_at_zero_gpu(idx, 1, idx.size());
+  for (size_t i = 0; i < idx.size(); ++i) acc = acc + y[i] * lam[i];
+  return acc;
 }
 
 // poly.rs:313-319 (minus_const: x - c) and :640-668 (lagrange_basis)

@@ -329,6 +329,19 @@ int main() {
       for (size_t i = 0; i < sh.size(); ++i) same = same && sh[i].i == i && sh[i].v == q.eval(i).v;
       CHECK(same, "PriPoly::shares: engine == host Horner");
     }
+    // recover_secret (poly.rs:244-280): the secret back from t of the n private shares, whichever t (the first t by index are used)
+    {
+      PriPoly q = new_pri_poly(t);
+      std::vector<PriShare> sh = q.shares(n);
+      std::vector<std::optional<PriShare>> some(sh.begin(), sh.end());
+      CHECK(recover_secret(some, t, n) == q.coeffs[0], "recover_secret: all shares");
+      some[0].reset(); some[3].reset();
+      CHECK(recover_secret(some, t, n) == q.coeffs[0], "recover_secret: with holes");
+      std::string e2;
+      for (size_t i = 0; i + t - 1 < some.size(); ++i) some[i].reset();
+      try { (void)recover_secret(some, t, n); } catch (const PolyError& e) { e2 = e.what(); }
+      CHECK(e2 == "not enough shares to recover secret", "recover_secret: too few shares");
+    }
     // batch of share sets in one launch == one by one
     {
       std::vector<std::vector<std::optional<PubShare>>> sets;

@@ -749,6 +749,40 @@ def test_cfg5_shard_2_21_linearity(engine, oracle):
     assert np.array_equal(got, want)
 
 
+def test_mid_size_host_calls_agree_whichever_way_the_arrays_travel(engine, oracle):
+    """A DKG-sized host-pointer call takes the page-locked zero-copy window (host.zero_copy_kib, 4 MiB by default) or, above it, copies on
+    the engine stream: same bytes both ways, for the record batches (mul, mul_base) and the calls with mixed arrays (sign, verify, dealer
+    shares, linear combinations) — and the option is restored"""
+    import kyber_rs_amd as K
+    n = 6000
+    s = synth.scalars(n, 910); kk = synth.scalars(n, 911, b"k")
+    pts = oracle.mul_base_ext_batch(synth.scalars(n, 912, b"p"))
+    msg_list = synth.messages(n, 913)
+    msgs = K.pack_messages(msg_list)
+    assert len(msgs) == n and np.array_equal(engine.schnorr_sign(s[100:164], kk[100:164], msgs[100:164]), engine.schnorr_sign(s[100:164], kk[100:164], msg_list[100:164]))
+    was = engine.get_option("host.zero_copy_kib")
+    got = {}
+    try:
+        for kib in (0, 64, 4096, 65536):
+            engine.set_option("host.zero_copy_kib", kib)
+            pubs = engine.mul_base(s)
+            sig = engine.schnorr_sign(s, kk, msgs)
+            bad = sig.copy(); bad[::11, 40] ^= 2
+            got[kib] = (pubs, engine.mul(kk, pts_ext=pts), engine.mul(kk, pts_enc=pubs), sig, engine.verify(pubs, msgs, bad, 1),
+                        engine.pripoly_eval(s[:300], np.arange(n, dtype=np.uint32)), engine.lincomb(s[:5400].reshape(600, 9, 32), pts_ext=pts[:5400].reshape(600, 9, 40)))
+    finally:
+        engine.set_option("host.zero_copy_kib", was)
+    for kib in (64, 4096, 65536):
+        for a_, b_ in zip(got[0], got[kib]):
+            assert np.array_equal(a_, b_), kib
+    pubs, mul_ext, mul_enc, sig, st, shares, lc = got[4096]
+    assert np.array_equal(pubs, oracle.mul_base_batch(s, nthreads=8)) and np.array_equal(mul_ext, oracle.mul_batch(kk, pts, nthreads=8))
+    assert np.array_equal(sig, oracle.schnorr_sign_batch(s, kk, msg_list, nthreads=8))
+    bad = sig.copy(); bad[::11, 40] ^= 2
+    assert np.array_equal(st, oracle.verify_batch(1, pubs, msg_list, bad, nthreads=8))
+    assert bytes(shares[n - 1]) == oracle.pripoly_eval(s[:300], n - 1) and bytes(lc[599]) == oracle.lincomb(s[5391:5400], pts[5391:5400])
+
+
 def test_host_pointer_paths_agree(engine, oracle):
     """The chunked host-pointer pipeline gives the same bytes whichever way the batch travels: pageable
     caller memory (engine's bounce buffers + copy threads), page-locked caller memory (direct DMA), one

@@ -3,6 +3,7 @@ single-thread CPU port: what a kyber-rs node would gain by routing its loops to 
 
 Per node with n participants and threshold t (call sites: dkg.rs / vss/pedersen/vss.rs / poly.rs):
   dealer    commit                 t  x mul(coeff, Some(B))                     vss.rs:303
+            shares                 n  x PriPoly::eval (t scalar multiply-adds)  poly.rs:133-152
             deals                  n  x (schnorr::sign + dh_exchange)           vss.rs:361-386
   verifier  process n deals        n  x (schnorr::verify + dh_exchange)         vss.rs:640-660
             verify_deal            n  x (mul(f_i, None) + PubPoly::eval(i))     vss.rs:904-909
@@ -55,6 +56,10 @@ t0 = time.perf_counter()
 for e in pub256:
     orc.decode(bytes(e))
 cpu["unmarshal"] = (time.perf_counter() - t0) / 256 * 1e3                     # incl. the ctypes call (~2 us)
+t0 = time.perf_counter()
+for i in range(8):
+    orc.pripoly_eval(s256, i)
+cpu["share_per_coeff"] = (time.perf_counter() - t0) / 8 / 256 * 1e3
 print("CPU port, 1 thread, ms per op:", {k: round(v, 4) for k, v in cpu.items()})
 print("n, t, gpu_ms_total, cpu_ms_estimate, speedup, breakdown_ms   [wire: the n*t commitments arrive as 32-byte encodings; GPU total with "
       "kyb_pubpoly_eval_multi_enc_batch / kyb_sum_enc_batch, CPU estimate with the n*t unmarshal_binary calls the reference makes]")
@@ -67,7 +72,9 @@ for n in args.n:
     br = {}
     (commit_enc, commit_ext), br["commit"] = timed(lambda: eng.mul(coeffs, pts_ext=base, want_ext=True))
     ci = [int.from_bytes(bytes(c), "little") for c in coeffs]
-    shares = np.frombuffer(b"".join((sum(c * pow(i + 1, j, L) for j, c in enumerate(ci)) % L).to_bytes(32, "little") for i in range(n)), dtype=np.uint8).reshape(n, 32)
+    shares, br["shares"] = timed(lambda: eng.pripoly_eval(coeffs, np.arange(n, dtype=np.uint32)))      # PriPoly::shares: n Horner chains of t scalar multiply-adds
+    for i in (0, n // 2, n - 1):
+        assert int.from_bytes(bytes(shares[i]), "little") == sum(c * pow(i + 1, j, L) for j, c in enumerate(ci)) % L
     msgs = synth.messages(n, n)
     nonces = synth.scalars(n, 300 + n)
     me = np.tile(longterm[0], (n, 1))
@@ -104,7 +111,7 @@ for n in args.n:
     assert np.array_equal(ev_1, ev[:, 0]) and np.array_equal(dist_1, dist) and ok_1.all()
     assert bytes(commit_enc[1]) == orc.mul(bytes(coeffs[1]), orc.base()) and bytes(dh[3]) == orc.mul(bytes(longterm[0]), orc.decode(bytes(pubs[3]))[0])
     gpu_ms = sum(br.values())
-    cpu_ms = t * cpu["mul"] + n * (cpu["sign"] + cpu["mul"]) + n * (cpu["verify"] + cpu["mul"]) + n * (cpu["mul_base"] + t * cpu["eval_per_coeff"]) + n * t * 0.0005
+    cpu_ms = t * cpu["mul"] + n * (cpu["sign"] + cpu["mul"]) + n * (cpu["verify"] + cpu["mul"]) + n * (cpu["mul_base"] + t * cpu["eval_per_coeff"]) + n * t * 0.0005 + n * t * cpu["share_per_coeff"]
     print(f"{n}, {t}, {gpu_ms:.2f}, {cpu_ms:.0f}, {cpu_ms / gpu_ms:.0f}x, " + " ".join(f"{k}={v:.2f}" for k, v in br.items()) + f" (eval one per lane: {eval_batch_ms:.2f}, one per wavefront: {eval_coop_ms:.2f})"
           + f"   [wire: {gpu_ms - br['eval'] - br['dist_poly'] + eval_wire_ms + dist_wire_ms:.2f} ms, eval={eval_wire_ms:.2f} dist_poly={dist_wire_ms:.2f}; "
           + f"one call (kyb_dkg_verify_round_enc): {gpu_ms - br['eval'] - br['dist_poly'] + round_wire_ms:.2f} ms, eval+dist_poly={round_wire_ms:.2f}; CPU {cpu_ms + n * t * cpu['unmarshal']:.0f} ms]", flush=True)
