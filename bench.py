@@ -271,13 +271,17 @@ def time_workload(w, eng, rt, steps, warmup, barrier):
 
 def kernel_clock(w, eng, rt, steps=3, warm=10):
     """the clock the stamped kernels of this step (k_mul_ladder, k_mul_base64) run at: extra UNTIMED steps with the wave stamps on, behind
-    `warm` plain steps (the parity check before this leaves the GPU idle for seconds, and the first launches after an idle period run at
-    a lower clock than the timed region saw)"""
+    at least `warm` plain steps and 0.25 s of load (the parity check before this leaves the GPU idle for seconds, and the first launches
+    after an idle period run at a lower clock than the timed region saw: tools/base_clock_probe.py, 1.9 GHz cold, 2.36 after 50 ms)"""
     torch = rt.torch
     buf = torch.zeros(8, dtype=torch.int64, device=rt.dev)
-    for _ in range(warm):
-        w["step"]()
-    rt.sync()
+    t0 = time.perf_counter()
+    done = 0
+    while done < warm or time.perf_counter() - t0 < 0.25:      # at least a quarter of a second of load: the clock needs ~50 ms to come up from idle
+        for _ in range(warm):
+            w["step"]()
+        rt.sync()
+        done += warm
     eng.wave_stamps(buf)
     try:
         for _ in range(steps):
