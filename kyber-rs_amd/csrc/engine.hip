@@ -116,6 +116,7 @@ struct Ctx {
   std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: the chunk unit is 1/this of the batch (plan_chunks)
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
+  std::atomic<int> opt_coop_share{1};             // divide the small-batch thresholds by the number of host-pointer calls in flight in this process (coop_lim)
   std::atomic<int> opt_zero_copy_kib{4096};         // host-pointer calls whose arrays fit this many KiB run their kernels on the context's page-locked buffer (no hipMemcpy); 512 in round 2, 4 MiB wins up to 16,384 items (profiles/r03/mid_size_host_calls.log)
   std::atomic<int> opt_ladder_pair_max{32768};    // ladder launches of at most this many items give each item two lanes (k_mul_ladder_pair: one wavefront per SIMD up to here); 0 = never
   std::atomic<int> opt_coop_ladder_max{3072};     // variable base, linear combinations (verification: 7/8 of it): above this the two-lane batch ladder is faster than one item per wavefront (profiles/r03/ladder_pair_probe.log)
@@ -197,6 +198,26 @@ int ensure_stage(Ctx& g, size_t bytes) {
   g.stage_bytes = want;
   return KYB_OK;
 }
+// The one-item-per-wavefront kernels (64 lanes per item) and the two-lane ladder buy latency with lanes: right while the rest of the chip
+// would idle.  When several host threads have synchronous host-pointer calls in flight — each on its own context — they share the chip,
+// and a 4,096-item fixed-base call that fills it with 4,096 wavefronts makes the others wait (16 threads: 1.8e7 items/s with fixed
+// thresholds, 1.5e8 with thresholds divided by the number of calls in flight; tools/concurrent_mid_calls.py).  coop.share_by_load = 0
+// keeps the thresholds as set.  Results do not depend on the routing.
+std::atomic<int> g_host_calls_in_flight{0};
+struct InflightScope {
+  InflightScope() { g_host_calls_in_flight.fetch_add(1, std::memory_order_relaxed); }
+  ~InflightScope() { g_host_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+};
+inline int host_load(const Ctx& g) {
+  if (g.opt_coop_share == 0) return 1;
+  const int load = g_host_calls_in_flight.load(std::memory_order_relaxed);
+  return load < 1 ? 1 : (load > 64 ? 64 : load);
+}
+inline size_t coop_lim(const Ctx& g, int opt) { return opt <= 0 ? 0 : (size_t)opt / (size_t)host_load(g); }
+// the two-lane ladder spends 2 lanes on an item, not 64: it stays worth its 12 % of extra work until the calls in flight fill the chip
+// several times over (16 threads x 4,096 items: 5.7e7 items/s with it, 4.2e7 without)
+inline size_t pair_lim(const Ctx& g, int opt) { const int l = host_load(g) / 4; return opt <= 0 ? 0 : (size_t)opt / (size_t)(l < 1 ? 1 : l); }
+
 int ensure_pin(Ctx& g, int lane, size_t bytes) {
   if (bytes <= g.pin_bytes[lane]) return KYB_OK;
   if (g.pin[lane]) { memset(g.pin[lane], 0, g.pin_bytes[lane]); HIPCK(hipHostFree(g.pin[lane])); g.pin[lane] = nullptr; g.pin_bytes[lane] = 0; }
@@ -241,7 +262,12 @@ int ensure_done_flag(Ctx& g) {
   *g.done_flag = 0;
   e = hipMalloc(reinterpret_cast<void**>(&g.done_counter), 64);
   if (e != hipSuccess) { (void)hipHostFree(g.done_flag); g.done_flag = nullptr; return fail(KYB_E_NOMEM, "completion counter allocation", e); }
-  HIPCK(hipMemset(g.done_counter, 0, 64));
+  // on the stream the counting kernels run on, and finished before the first of them is queued: a plain hipMemset of device memory may
+  // return before it has run and is not ordered with a non-blocking stream — a kernel that overtook it counted from whatever the recycled
+  // allocation held, fired the flag early by that amount in every later call, and the caller read results the last workgroups had not
+  // written yet (seen with six fresh contexts starting at once, tests/test_gpu_contexts.py)
+  HIPCK(hipMemsetAsync(g.done_counter, 0, 64, g.stream));
+  HIPCK(hipStreamSynchronize(g.stream));
   return KYB_OK;
 }
 // after the launch sequence of a zero-copy call: wait for its results
@@ -430,6 +456,7 @@ int run_host_batch_pipelined(Ctx& g, size_t n, const HostArr* arrs, int na, Fn l
 
 template <class Fn>
 int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
+  InflightScope in_flight;
   std::lock_guard<std::mutex> lk(g.mu);
   if (n >= PIPE_MIN_ITEMS) return run_host_batch_pipelined(g, n, arrs, na, launch);
   const size_t cap = (n + 1023) & ~(size_t)1023;
@@ -534,6 +561,7 @@ class HostCall {
   template <class Body>
   int run(Body body) {
     Ctx& g = g_;
+    InflightScope in_flight;
     std::lock_guard<std::mutex> lk(g.mu);
     if (total_ <= zero_copy_bytes(g)) {
       // small call: the kernels read and write the context's page-locked buffer directly over PCIe — no hipMemcpy at all
@@ -842,7 +870,7 @@ int do_init(int device, bool build_table) {
 // ---- launch sequences ------------------------------------------------------------------------------------
 // last: nothing is queued behind this launch in its call (it may carry the completion flag)
 int launch_finish(Ctx& g, StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st, size_t src_mul = 1, bool last = false) {
-  if (n <= (size_t)g.opt_coop_decode_max) {          // few points: one per wavefront
+  if (n <= coop_lim(g, g.opt_coop_decode_max)) {          // few points: one per wavefront
     ProfScope ps(g, st, KID_FINISH_COOP);
     LAUNCHCK(launch::finish_coop(st, r->proj, r->proj_items, nullptr, n, oenc, oext, src_mul, last ? take_done_flag(g, st, n) : launch::DoneFlag{},
                                  g.opt_ext_projective != 0));
@@ -870,7 +898,7 @@ int launch_ladder_core(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int
   } else if (ok != nullptr) {
     HIPCK(hipMemsetAsync(ok, 1, np, st));          // extended operands are taken as they are (k_mul does the same)
   }
-  if (n <= (size_t)g.opt_ladder_pair_max) {
+  if (n <= pair_lim(g, g.opt_ladder_pair_max)) {
     // more SIMDs than wavefronts: two lanes per item shorten the dependent chain and keep the base point projective — no k_mont_prep,
     // no inversion in front (ge_ladder_pair.h).  Without the prep there is no launch-wide canonical test: 256 - skip_bits steps.
     ProfScope ps(g, st, KID_MUL_LADDER_PAIR);
@@ -917,7 +945,7 @@ int launch_lincomb(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
   const size_t n = m * t;
-  if (n <= (size_t)g.opt_coop_max && n <= (size_t)g.opt_coop_ladder_max && g.opt_mul_algo == 1) {
+  if (n <= coop_lim(g, g.opt_coop_max) && n <= coop_lim(g, g.opt_coop_ladder_max) && g.opt_mul_algo == 1) {
     // few products: one per wavefront, handed over projective (no inversion) to the halving passes
     const size_t np = shared ? t : n;
     int rc = ensure_proj(g, r, n); if (rc) return rc;
@@ -951,11 +979,11 @@ int launch_lincomb(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t
 int sum_locked(Ctx& g, StreamRes* r, const int32_t* pext, const uint8_t* penc, uint8_t* ok, bool item_major, size_t m, size_t t, uint8_t* oenc, int32_t* oext,
                hipStream_t st, bool ext_item_major = false) {
   const size_t n = m * t;
-  const bool small = t <= 32 && m <= (size_t)g.opt_coop_base_max;
+  const bool small = t <= 32 && m <= coop_lim(g, g.opt_coop_base_max);
   if (penc != nullptr && small && !item_major) {
     int rc = ensure_ws_part(g, r, n); if (rc) return rc;
     int32_t* dec = reinterpret_cast<int32_t*>(r->part);
-    if (n <= (size_t)g.opt_coop_decode_max) {
+    if (n <= coop_lim(g, g.opt_coop_decode_max)) {
       ProfScope ps(g, st, KID_DECODE_COOP);
       LAUNCHCK(launch::decode_coop(st, penc, n, dec, ok, true));
     } else {
@@ -996,7 +1024,7 @@ int launch_lincomb_public(Ctx& g, const uint8_t* sc, const uint8_t* penc, const 
   if (penc != nullptr) {           // unmarshal_binary of the shared points first (ok flags; failed decodes become the neutral element)
     int rc = ensure_enc(g, r, 160 * t + 256); if (rc) return rc;
     int32_t* tmp = reinterpret_cast<int32_t*>(r->enc);
-    if (t <= (size_t)g.opt_coop_decode_max) { ProfScope ps(g, st, KID_DECODE_COOP); LAUNCHCK(launch::decode_coop(st, penc, t, tmp, ok, true)); }
+    if (t <= coop_lim(g, g.opt_coop_decode_max)) { ProfScope ps(g, st, KID_DECODE_COOP); LAUNCHCK(launch::decode_coop(st, penc, t, tmp, ok, true)); }
     else { ProfScope ps(g, st, KID_DECODE); LAUNCHCK(launch::decode_or_identity(st, penc, t, tmp, ok)); }
     pext = tmp;
   } else if (ok != nullptr) {
@@ -1043,9 +1071,9 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
   StreamRes* r = nullptr;
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
-  if (n <= (size_t)g.opt_coop_max && n <= (size_t)g.opt_coop_ladder_max && g.opt_mul_algo == 1) {
+  if (n <= coop_lim(g, g.opt_coop_max) && n <= coop_lim(g, g.opt_coop_ladder_max) && g.opt_mul_algo == 1) {
     // small batch: one item per wavefront, the whole multiplication in one launch (kernels_coop.hip)
-    if (penc != nullptr && 4 * n <= (size_t)g.opt_coop_max) {
+    if (penc != nullptr && 4 * n <= coop_lim(g, g.opt_coop_max)) {
       // from the wire encoding, two wavefronts per item: the ladder starts on y while the decode is still looking for x
       ProfScope ps(g, st, KID_MUL_COOP);
       LAUNCHCK(launch::mul_enc_coop(st, sc, penc, n, oenc, oext, ok, take_done_flag(g, st, n)));
@@ -1064,7 +1092,7 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
     // (canonical scalars, all below 2^252: the top wavefront's piece starts four bits lower, as the batch ladder does)
     const int canon_skip = (skip_hint >= 4 && g.opt_ladder_skip_canonical != 0) ? 4 : 0;
     LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, short_scalars ? (skip_hint > 255 ? 255 : skip_hint) : canon_skip, nullptr, 0, 0, take_done_flag(g, st, n), 0,
-                              (!short_scalars && 2 * n <= (size_t)g.opt_coop_verify_max) ? 4 : 1,   // very few items (measured: up to 256): four wavefronts share an item's scalar
+                              (!short_scalars && 2 * n <= coop_lim(g, g.opt_coop_verify_max)) ? 4 : 1,   // very few items (measured: up to 256): four wavefronts share an item's scalar
                               g.opt_ext_projective != 0));
     return KYB_OK;
   }
@@ -1132,10 +1160,10 @@ int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t*
   StreamRes* r = nullptr;
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
-  if (n <= (size_t)g.opt_coop_base_max) {
+  if (n <= coop_lim(g, g.opt_coop_base_max)) {
     ProfScope ps(g, st, KID_MUL_BASE_COOP);
     LAUNCHCK(launch::mul_base_coop(st, sc, n, oenc, oext, coop_table(g), nullptr, 0, 0, nullptr, 0, take_done_flag(g, st, n),
-                                   n <= 2 * (size_t)g.opt_coop_verify_max ? 4 : 1,      // few items (measured: up to 1,024): four wavefronts share an item's 43 windows
+                                   n <= 2 * coop_lim(g, g.opt_coop_verify_max) ? 4 : 1,      // few items (measured: up to 1,024): four wavefronts share an item's 43 windows
                                    g.opt_ext_projective != 0));
     return KYB_OK;
   }
@@ -1149,7 +1177,7 @@ int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t*
 // marshal_binary of n extended points: one shared inversion per FINISH_K points
 int launch_encode(Ctx& g, const int32_t* pext, size_t n, uint8_t* oenc, hipStream_t st) {
   if (n == 0) return KYB_OK;
-  if (n <= (size_t)g.opt_coop_decode_max) {
+  if (n <= coop_lim(g, g.opt_coop_decode_max)) {
     ProfScope ps(g, st, KID_FINISH_COOP);
     LAUNCHCK(launch::finish_coop(st, nullptr, 0, pext, n, oenc, nullptr, 1, take_done_flag(g, st, n)));
     return KYB_OK;
@@ -1167,7 +1195,7 @@ int launch_encode(Ctx& g, const int32_t* pext, size_t n, uint8_t* oenc, hipStrea
 // pub_out != nullptr: receives enc(x*B).
 int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const uint8_t* pub_in, const uint8_t* msgs, const uint32_t* off, size_t n,
                 uint8_t* sig, uint8_t* pub_out, hipStream_t st) {
-  if (n <= (size_t)g.opt_coop_verify_max && 2 * n <= (size_t)g.opt_coop_base_max) {
+  if (n <= coop_lim(g, g.opt_coop_verify_max) && 2 * n <= coop_lim(g, g.opt_coop_base_max)) {
     // few signatures: one launch, two wavefronts each (kernels_coop.hip)
     ProfScope ps(g, st, KID_SIGN_COOP);
     LAUNCHCK(launch::sign_coop(st, x, k, pub_in, msgs, off, n, sig, pub_out, coop_table(g), take_done_flag(g, st, n)));
@@ -1176,7 +1204,7 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
   if (pub_in != nullptr) {
     // R = k*B only
     int rc = ensure_enc(g, r, 32 * n); if (rc) return rc;
-    if (n <= (size_t)g.opt_coop_base_max) {
+    if (n <= coop_lim(g, g.opt_coop_base_max)) {
       ProfScope ps(g, st, KID_MUL_BASE_COOP);
       LAUNCHCK(launch::mul_base_coop(st, k, n, r->enc, nullptr, coop_table(g)));
     } else if (use_split(g, n)) {
@@ -1194,7 +1222,7 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
     if (pub_out != nullptr && pub_out != pub_in) HIPCK(hipMemcpyAsync(pub_out, pub_in, 32 * n, hipMemcpyDeviceToDevice, st));
     return KYB_OK;
   }
-  if (2 * n <= (size_t)g.opt_coop_base_max) {
+  if (2 * n <= coop_lim(g, g.opt_coop_base_max)) {
     // small batch: the 2n fixed-base multiplications as 2n wavefronts of the cooperative kernel, encodings straight out
     int rc = ensure_enc(g, r, 64 * n); if (rc) return rc;
     {
@@ -1287,7 +1315,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
                   uint8_t* status, hipStream_t st) {
   if (n == 0) return KYB_OK;
   std::lock_guard<std::mutex> launch_lock(g.launch_mu);
-  if (g.opt_mul_algo == 1 && n <= (size_t)g.opt_coop_verify_max) {
+  if (g.opt_mul_algo == 1 && n <= coop_lim(g, g.opt_coop_verify_max)) {
     // few signatures: the whole verification in one launch, three wavefronts per signature (kernels_coop.hip)
     ProfScope ps(g, st, KID_VERIFY_COOP);
     LAUNCHCK(launch::verify_coop(st, pubs, sigs, msgs, off, n, flavor, coop_table(g), status, take_done_flag(g, st, n)));
@@ -1303,8 +1331,8 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   uint8_t* flags_a = r->enc + o_fa; uint8_t* flags_r = r->enc + o_fr;
   // the R half (decode of R, s*B) is independent of the A half (decode of A, hash, h*A): while the batch leaves most of
   // the chip idle it runs on the side stream
-  const bool fork = g.opt_verify_overlap && n <= (size_t)64 * (size_t)g.cus;
-  const bool coop = g.opt_mul_algo == 1 && n <= (size_t)g.opt_coop_max && n <= (size_t)g.opt_coop_base_max && 8 * n <= 7 * (size_t)g.opt_coop_ladder_max;     // small batch: one item per wavefront
+  const bool fork = g.opt_verify_overlap && n <= (size_t)64 * (size_t)g.cus && host_load(g) < 4;      // with several calls in flight the other calls fill the idle SIMDs; a side stream only adds queue traffic
+  const bool coop = g.opt_mul_algo == 1 && n <= coop_lim(g, g.opt_coop_max) && n <= coop_lim(g, g.opt_coop_base_max) && 8 * n <= 7 * coop_lim(g, g.opt_coop_ladder_max);     // small batch: one item per wavefront
   hipStream_t side = st;
   if (fork) {
     rc = ensure_aux(g, r); if (rc) return rc;
@@ -1370,7 +1398,7 @@ int poly_batch_segments(const Ctx& g, size_t n, size_t t, int nbits) {
   if (nbits <= 1) return 1;                                            // x = 1: the chain is t additions
   const double f = (1.5 * (double)nbits + 1.0) / 16.0;
   double best;
-  if (n <= (size_t)g.opt_coop_max) {
+  if (n <= coop_lim(g, g.opt_coop_max)) {
     int cs = g.opt_poly_segments;
     if (cs == 0) { const size_t by_len = t / 24, by_room = 2048 / n; cs = (int)(by_len < by_room ? by_len : by_room); if (cs > 32) cs = 32; if (cs < 1) cs = 1; }
     const double waves = (double)n * cs, crowd = waves > 1536.0 ? waves / 1536.0 : 1.0;
@@ -1400,7 +1428,7 @@ int poly_eval_locked(Ctx& g, StreamRes* r, const int32_t* commits, size_t t, con
     const size_t np = t * (per_poly ? (n + per_poly - 1) / per_poly : 1);
     int rc = ensure_ws_part(g, r, np); if (rc) return rc;
     int32_t* dec = reinterpret_cast<int32_t*>(r->part);
-    if (np <= (size_t)g.opt_coop_decode_max) {
+    if (np <= coop_lim(g, g.opt_coop_decode_max)) {
       ProfScope ps(g, st, KID_DECODE_COOP);
       LAUNCHCK(launch::decode_coop(st, commits_enc, np, dec, ok, true));
     } else {
@@ -1432,7 +1460,7 @@ int poly_eval_locked(Ctx& g, StreamRes* r, const int32_t* commits, size_t t, con
       }
     }
   }
-  if (n <= (size_t)g.opt_coop_max) {
+  if (n <= coop_lim(g, g.opt_coop_max)) {
     // few evaluations: one per wavefront (kernels_coop.hip); a long polynomial at very few indices: several wavefronts per evaluation.
     // A segment costs its wavefront one 255-step multiplication (~26 Horner steps of a 10-bit index) on top of its share of the chain,
     // and the segments of all evaluations should find idle SIMDs (2,048 wavefronts).

@@ -93,6 +93,51 @@ def test_private_contexts_from_fresh_threads_dev_api(oracle):
         e.close()
 
 
+def test_host_calls_in_flight_share_the_chip(engine, oracle):
+    """Six threads with a context each issue mid-size host-pointer calls at the same time: the small-batch thresholds shrink with the number of
+    calls in flight (coop.share_by_load; the routing of a call then depends on what else is running), and every call still returns the bytes
+    of a call made alone — with the option on and off.  One lone call keeps its one-item-per-wavefront kernels."""
+    import kyber_rs_amd
+    n = 3000
+    s = synth.scalars(n, 71); k = synth.scalars(n, 72, b"k")
+    pts = oracle.mul_base_ext_batch(synth.scalars(n, 73, b"p"))
+    msgs = kyber_rs_amd.pack_messages(synth.messages(n, 74))
+    want_base = oracle.mul_base_batch(s, nthreads=8)
+    want_mul = oracle.mul_batch(k, pts, nthreads=8)
+    sig = engine.schnorr_sign(s, k, msgs)
+    bad = sig.copy(); bad[::5, 3] ^= 1
+    want_st = engine.verify(want_base, msgs, bad, 1)
+    engine.profile_begin(8)
+    assert np.array_equal(engine.mul_base(s), want_base)
+    assert [nm for nm, _ in engine.profile_read(8)][0] == "k_mul_base_coop"      # alone: 3,000 items take the latency kernels
+    engine.profile_begin(0)
+    for share in (1, 0):
+        engines = [kyber_rs_amd.Engine(0, private=True) for _ in range(6)]
+        errors = []
+
+        def work(i):
+            try:
+                e = engines[i]
+                e.set_option("coop.share_by_load", share)
+                for r in range(12):
+                    m = n - 37 * ((i + r) % 5)
+                    assert np.array_equal(e.mul_base(s[:m]), want_base[:m]), ("mul_base", i, r)
+                    assert np.array_equal(e.mul(k[:m], pts_ext=pts[:m]), want_mul[:m]), ("mul", i, r)
+                    assert np.array_equal(e.schnorr_sign(s[:m], k[:m], msgs[:m]), sig[:m]), ("sign", i, r)
+                    assert np.array_equal(e.verify(want_base[:m], msgs[:m], bad[:m], 1), want_st[:m]), ("verify", i, r)
+            except Exception as ex:  # noqa: BLE001
+                errors.append(repr(ex))
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for e in engines:
+            e.close()
+        assert not errors, errors[:3]
+
+
 def test_corrupted_table_image_is_refused(engine):
     import kyber_rs_amd
     img = engine.base_table()
