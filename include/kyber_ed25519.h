@@ -368,7 +368,7 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *                     kernels that give ONE item several wavefronts (verification in one launch, signing in one launch, the fixed
  *                     base with four wavefronts per item; default 512).  Same results either way.
  *   coop.share_by_load  1 (default): the coop.* and ladder.pair_max_items thresholds are divided by the number of synchronous host-pointer
- *                     calls this process has in flight (each on its own context): kernels that spend 64 or 2 lanes on an item are for a chip
+ *                     calls this process has in flight on the same GPU (each on its own context): kernels that spend 64 or 2 lanes on an item are for a chip
  *                     that would otherwise idle, not for one that 16 threads share.  0: thresholds as set.  Same results either way.
  *   ladder.pair_max_items  ladder launches (variable base, verification, linear combinations) of at most this many items give every item TWO
  *                     lanes of a wavefront, which split the products of a ladder step between them and keep the operand's Montgomery image

@@ -200,17 +200,21 @@ int ensure_stage(Ctx& g, size_t bytes) {
 }
 // The one-item-per-wavefront kernels (64 lanes per item) and the two-lane ladder buy latency with lanes: right while the rest of the chip
 // would idle.  When several host threads have synchronous host-pointer calls in flight — each on its own context — they share the chip,
-// and a 4,096-item fixed-base call that fills it with 4,096 wavefronts makes the others wait (16 threads: 1.8e7 items/s with fixed
+// and on ONE GPU a 4,096-item fixed-base call that fills it with 4,096 wavefronts makes the others wait (16 threads: 1.8e7 items/s with fixed
 // thresholds, 1.5e8 with thresholds divided by the number of calls in flight; tools/concurrent_mid_calls.py).  coop.share_by_load = 0
 // keeps the thresholds as set.  Results do not depend on the routing.
-std::atomic<int> g_host_calls_in_flight{0};
+constexpr int MAX_COUNTED_DEVICES = 64;
+std::atomic<int> g_host_calls_in_flight[MAX_COUNTED_DEVICES];      // per device: the shards of a kyb_group call run on different GPUs and do not share one
 struct InflightScope {
-  InflightScope() { g_host_calls_in_flight.fetch_add(1, std::memory_order_relaxed); }
-  ~InflightScope() { g_host_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+  std::atomic<int>* slot;
+  explicit InflightScope(const Ctx& g) : slot(g.device >= 0 && g.device < MAX_COUNTED_DEVICES ? &g_host_calls_in_flight[g.device] : nullptr) {
+    if (slot) slot->fetch_add(1, std::memory_order_relaxed);
+  }
+  ~InflightScope() { if (slot) slot->fetch_sub(1, std::memory_order_relaxed); }
 };
 inline int host_load(const Ctx& g) {
-  if (g.opt_coop_share == 0) return 1;
-  const int load = g_host_calls_in_flight.load(std::memory_order_relaxed);
+  if (g.opt_coop_share == 0 || g.device < 0 || g.device >= MAX_COUNTED_DEVICES) return 1;
+  const int load = g_host_calls_in_flight[g.device].load(std::memory_order_relaxed);
   return load < 1 ? 1 : (load > 64 ? 64 : load);
 }
 inline size_t coop_lim(const Ctx& g, int opt) { return opt <= 0 ? 0 : (size_t)opt / (size_t)host_load(g); }
@@ -456,7 +460,7 @@ int run_host_batch_pipelined(Ctx& g, size_t n, const HostArr* arrs, int na, Fn l
 
 template <class Fn>
 int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
-  InflightScope in_flight;
+  InflightScope in_flight(g);
   std::lock_guard<std::mutex> lk(g.mu);
   if (n >= PIPE_MIN_ITEMS) return run_host_batch_pipelined(g, n, arrs, na, launch);
   const size_t cap = (n + 1023) & ~(size_t)1023;
@@ -561,7 +565,7 @@ class HostCall {
   template <class Body>
   int run(Body body) {
     Ctx& g = g_;
-    InflightScope in_flight;
+    InflightScope in_flight(g);
     std::lock_guard<std::mutex> lk(g.mu);
     if (total_ <= zero_copy_bytes(g)) {
       // small call: the kernels read and write the context's page-locked buffer directly over PCIe — no hipMemcpy at all
