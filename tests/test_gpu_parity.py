@@ -876,6 +876,22 @@ def test_bad_arguments_are_rejected(engine, oracle):
     assert lib.kyb_pubpoly_eval_batch(p(ext), 4, p(np.array([0xFFFFFFFF], dtype=np.uint32)), 1, p(out), None) == -2   # index + 1 overflows
     assert lib.kyb_set_option(b"no.such.option", 1) == -2
     assert lib.kyb_set_option(b"mul_base.radix", 48) == -2
+    # this round's entry points: the same discipline
+    bigidx = np.array([3, 0xFFFFFFFF], dtype=np.uint32)
+    sh = np.zeros((2, 32), dtype=np.uint8)
+    assert lib.kyb_pripoly_eval_batch(p(s), 1, 4, p(bigidx), 2, p(sh)) == -2 and b"index" in lib.kyb_last_error()
+    assert lib.kyb_pripoly_eval_batch(p(s), 1, 0, p(bigidx), 1, p(sh)) == -2                                   # no coefficients
+    assert lib.kyb_pripoly_eval_batch(None, 0, 4, None, 0, None) == 0 and lib.kyb_pripoly_eval_batch(p(s), 1, 4, None, 0, None) == 0
+    lam = np.zeros((2, 32), dtype=np.uint8)
+    assert lib.kyb_lagrange_coeffs_batch(p(bigidx), 1, 2, p(lam)) == -2 and lib.kyb_lagrange_coeffs_batch(None, 0, 2, None) == 0
+    assert lib.kyb_dkg_verify_round_enc(p(enc), 0, 1, 0, p(out), None, None, None, None) == -2                 # t = 0
+    assert lib.kyb_dkg_verify_round_enc(p(enc), 4, 1, 0xFFFFFFFF, p(out), None, None, None, None) == -2
+    assert lib.kyb_dkg_verify_round_enc(p(enc), 4, 1, 0, None, None, None, None, None) == -2                   # nowhere to put the evaluations
+    assert lib.kyb_lincomb_public_batch(p(s), None, p(ext), 0, 2, 0, p(out), None, None) == -2
+    assert lib.kyb_lincomb_public_batch(p(s), p(enc), p(ext), 0, 2, 2, p(out), None, None) == -2               # both point forms
+    assert lib.kyb_mul_public_batch(p(s), None, None, 4, p(out), None, None) == -2                             # no points
+    assert lib.kyb_set_option(b"host.zero_copy_kib", -1) == -2 and lib.kyb_set_option(b"coop.share_by_load", 2) == -2
+    assert lib.kyb_set_option(b"ladder.pair_max_items", -5) == -2
     # device-pointer API: misaligned buffers are refused before any launch
     d = torch.zeros(4 * 32 + 16, dtype=torch.uint8, device="cuda:0")
     o = torch.zeros((4, 32), dtype=torch.uint8, device="cuda:0")
