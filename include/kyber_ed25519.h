@@ -235,6 +235,14 @@ int kyb_verify_batch(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* m
                      size_t n, int flavor, uint8_t* status);
 int kyb_verify_batch_dev(const uint8_t* pubs, const uint8_t* msgs, const uint32_t* msg_off, const uint8_t* sigs,
                          size_t n, int flavor, uint8_t* status, void* stream);
+/* The same verification with the public keys given as POINTS (160-byte extended limbs, any Z): schnorr::verify (schnorr_sig.rs:114-127) and
+ * eddsa::verify (eddsa_sig.rs:216-...) — what dkg.rs, vss.rs and dss_sig.rs call — take &Point, marshal it and hand the bytes to
+ * verify_with_checks, which unmarshals them again.  Here the engine marshals the points (one shared inversion per 8) for the hash and the
+ * byte-level checks and multiplies the caller's limbs directly: no square root per key unless a set of limbs is not a point of the curve, in
+ * which case its bytes decide, as in the reference.  status[i] == kyb_verify_batch on marshal_binary(point i), for every input. */
+int kyb_verify_points_batch(const int32_t* pubs_ext, const uint8_t* msgs, const uint32_t* msg_off, const uint8_t* sigs, size_t n, int flavor, uint8_t* status);
+int kyb_verify_points_batch_dev(const int32_t* pubs_ext, const uint8_t* msgs, const uint32_t* msg_off, const uint8_t* sigs, size_t n, int flavor,
+                                uint8_t* status, void* stream);
 
 /* ---- PubPoly::eval / shares, poly.rs:457-478 ------------------------------- */
 /* One public polynomial (t commitments, extended limbs) evaluated at n share indices:

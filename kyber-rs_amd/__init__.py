@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "kyb_decode_batch", "kyb_decode_batch_dev", "kyb_schnorr_sign_batch", "kyb_schnorr_sign_batch_dev",
     "kyb_eddsa_sign_batch", "kyb_eddsa_sign_batch_dev",
     "kyb_schnorr_sign_keyed_batch", "kyb_schnorr_sign_keyed_batch_dev", "kyb_eddsa_sign_keyed_batch", "kyb_eddsa_sign_keyed_batch_dev",
-    "kyb_verify_batch", "kyb_verify_batch_dev", "kyb_pubpoly_eval_batch", "kyb_pubpoly_eval_batch_dev",
+    "kyb_verify_batch", "kyb_verify_batch_dev", "kyb_verify_points_batch", "kyb_verify_points_batch_dev", "kyb_pubpoly_eval_batch", "kyb_pubpoly_eval_batch_dev",
     "kyb_pubpoly_eval_multi_batch", "kyb_pubpoly_eval_multi_batch_dev",
     "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev", "kyb_lincomb_public_batch", "kyb_lincomb_public_batch_dev", "kyb_pripoly_eval_batch", "kyb_pripoly_eval_batch_dev", "kyb_lagrange_coeffs_batch", "kyb_lagrange_coeffs_batch_dev",
     "kyb_sum_batch", "kyb_sum_batch_dev",
@@ -131,6 +131,8 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_eddsa_sign_batch_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     lib.kyb_verify_batch.argtypes = [vp, vp, vp, vp, sz, i32, vp]
     lib.kyb_verify_batch_dev.argtypes = [vp, vp, vp, vp, sz, i32, vp, vp]
+    lib.kyb_verify_points_batch.argtypes = [vp, vp, vp, vp, sz, i32, vp]
+    lib.kyb_verify_points_batch_dev.argtypes = [vp, vp, vp, vp, sz, i32, vp, vp]
     lib.kyb_pubpoly_eval_batch.argtypes = [vp, sz, vp, sz, vp, vp]
     lib.kyb_pubpoly_eval_batch_dev.argtypes = [vp, sz, vp, sz, ctypes.c_uint32, vp, vp, vp]
     lib.kyb_pubpoly_eval_multi_batch.argtypes = [vp, sz, sz, vp, sz, vp, vp]
@@ -450,6 +452,22 @@ class Engine:
         st = np.empty((n,), dtype=np.uint8)
         _check(self.lib.kyb_verify_batch(_ptr(ps), _ptr(blob), _ptr(off), _ptr(ss), n, flavor, _ptr(st)), "kyb_verify_batch")
         return st
+
+    def verify_points(self, pubs_ext, msgs: Sequence[bytes], sigs, flavor: int = 0) -> np.ndarray:
+        """kyb_verify_points_batch: as verify(), the public keys given as points (n x 40 limbs, any Z) — schnorr::verify / eddsa::verify"""
+        px = np.ascontiguousarray(pubs_ext, dtype=np.int32).reshape(-1, 40)
+        ss = _u8(sigs, 64, "sigs")
+        n = px.shape[0]
+        _rows(ss, n, "sigs")
+        blob, off = _msg_blob(msgs, n)
+        st = np.empty((n,), dtype=np.uint8)
+        _check(self.lib.kyb_verify_points_batch(_ptr(px), _ptr(blob), _ptr(off), _ptr(ss), n, flavor, _ptr(st)), "kyb_verify_points_batch")
+        return st
+
+    def verify_points_dev(self, pubs_ext, msgs, msg_off, sigs, status, flavor: int = 0, stream: int = 0) -> None:
+        n = pubs_ext.numel() // 40
+        _check(self.lib.kyb_verify_points_batch_dev(self._dp(pubs_ext), self._dp(msgs), self._dp(msg_off), self._dp(sigs), n, flavor, self._dp(status), ctypes.c_void_p(stream)),
+               "kyb_verify_points_batch_dev")
 
     def verify_dev(self, pubs, msgs, msg_off, sigs, status, flavor: int = 0, stream: int = 0) -> None:
         n = pubs.numel() // 32

@@ -63,6 +63,7 @@ struct StreamRes {
   hipStream_t stream = nullptr;
   uint4* ws = nullptr; uint4* proj = nullptr; size_t proj_items = 0; uint8_t* enc = nullptr; size_t enc_bytes = 0;
   uint32_t* part = nullptr; size_t part_items = 0;      // extended quads of a small linear combination's products
+  uint8_t* pub_enc = nullptr; size_t pub_enc_items = 0;    // kyb_verify_points_batch: marshal_binary of the callers' public-key points
   uint32_t* msm = nullptr; size_t msm_points = 0;        // kyb_lincomb_public_batch over shared points: window bases + tables of the points (227,040 B per point)
   uint32_t* top_or = nullptr; unsigned top_seq = 0;     // two alternating words behind the projective staging records (k_mont_prep / k_mul_ladder)
   hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_last = nullptr;
@@ -643,6 +644,7 @@ void free_slot(StreamRes* r) {
   if (r->enc) wipe_free_dev(r->enc, r->enc_bytes);
   if (r->part) wipe_free_dev(r->part, r->part_items * 160);
   if (r->msm) (void)hipFree(r->msm);
+  if (r->pub_enc) (void)hipFree(r->pub_enc);
   if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->ev_fork); (void)hipEventDestroy(r->ev_join); }
   if (r->ev_last) (void)hipEventDestroy(r->ev_last);
   delete r;
@@ -736,6 +738,18 @@ int ensure_enc(Ctx& g, StreamRes* r, size_t bytes) {
   hipError_t e = hipMalloc(&r->enc, want);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "encoding staging allocation", e);
   r->enc_bytes = want;
+  return KYB_OK;
+}
+int ensure_pub_enc(Ctx& g, StreamRes* r, size_t items) {
+  (void)g;
+  if (items <= r->pub_enc_items) return KYB_OK;
+  HIPCK(hipStreamSynchronize(r->stream));
+  if (r->pub_enc) (void)hipFree(r->pub_enc);
+  r->pub_enc = nullptr; r->pub_enc_items = 0;
+  const size_t want = items + (items >> 3) + 1024;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->pub_enc), 32 * want);
+  if (e != hipSuccess) return fail(KYB_E_NOMEM, "public-key encoding buffer allocation", e);
+  r->pub_enc_items = want;
   return KYB_OK;
 }
 int ensure_aux(Ctx& g, StreamRes* r) {
@@ -1315,19 +1329,33 @@ int launch_eddsa_sign(Ctx& g, const uint8_t* seeds, const uint8_t* pub_in, const
 }
 
 // verification pipeline on one stream: prep -> ladder (h, A) -> fixed base (s) -> final
+// pubs_ext != nullptr (pubs == nullptr): the public keys are the callers' POINTS (schnorr::verify / eddsa::verify, verify.h): they are
+// marshalled here (one shared inversion per 8), and the batch path then skips the square root of unmarshalling them again; the small-batch
+// kernels simply run on the encodings.
 int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, const uint8_t* sigs, size_t n, int flavor,
-                  uint8_t* status, hipStream_t st) {
+                  uint8_t* status, hipStream_t st, const int32_t* pubs_ext = nullptr) {
   if (n == 0) return KYB_OK;
   std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  if (pubs_ext != nullptr) {
+    int rc = ensure_pub_enc(g, r, n); if (rc) return rc;
+    if (n <= coop_lim(g, g.opt_coop_decode_max)) {
+      ProfScope ps(g, st, KID_FINISH_COOP);
+      LAUNCHCK(launch::finish_coop(st, nullptr, 0, pubs_ext, n, r->pub_enc, nullptr, 1));          // (not the call's last kernel: no completion flag)
+    } else {
+      ProfScope ps(g, st, KID_ENCODE);
+      LAUNCHCK(launch::encode_batched(st, pubs_ext, n, r->pub_enc));
+    }
+    pubs = r->pub_enc;
+  }
   if (g.opt_mul_algo == 1 && n <= coop_lim(g, g.opt_coop_verify_max)) {
     // few signatures: the whole verification in one launch, three wavefronts per signature (kernels_coop.hip)
     ProfScope ps(g, st, KID_VERIFY_COOP);
     LAUNCHCK(launch::verify_coop(st, pubs, sigs, msgs, off, n, flavor, coop_table(g), status, take_done_flag(g, st, n)));
     return KYB_OK;
   }
-  StreamRes* r = nullptr;
-  { int rc = res_for(g, st, &r); if (rc) return rc; }
-  SlotUse use(r, st);
   int rc = ensure_proj(g, r, 3 * n); if (rc) return rc;
   const size_t o_h = 0, o_s = up256(32 * n), o_a = o_s + up256(32 * n), o_fa = o_a + up256(160 * n), o_fr = o_fa + up256(n);
   rc = ensure_enc(g, r, o_fr + up256(n)); if (rc) return rc;
@@ -1354,6 +1382,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   {
     ProfScope ps(g, st, KID_VERIFY_PREP);
     if (coop) LAUNCHCK(launch::verify_prep_coop(st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext));
+    else if (pubs_ext != nullptr) LAUNCHCK(launch::verify_prep_pts(st, pubs, pubs_ext, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext));
     else LAUNCHCK(launch::verify_prep(st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext));
   }
   if (fork) {

@@ -136,6 +136,26 @@ k_verify_prep(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs
   store_words8(sbuf, i, sig + 8);
   store_ext(a_ext, i, A.X, A.Y, A.Z, A.T);
 }
+// the same with the public keys given as points (schnorr::verify / eddsa::verify, verify.h): pub_enc = their marshal_binary, made by
+// k_encode_batched in front of this kernel; no square root unless the limbs are not a point of the curve
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_verify_prep_pts(const uint8_t* __restrict__ pub_enc, const int32_t* __restrict__ pubs_ext, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ msgs,
+                  const uint32_t* __restrict__ msg_off, size_t n, uint8_t* __restrict__ flags_a,
+                  uint8_t* __restrict__ hbuf, uint8_t* __restrict__ sbuf, int32_t* __restrict__ a_ext) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t pub[8], sig[16], h[8];
+  load_words8(pub, pub_enc, i);
+  load_words8(sig, sigs, 2 * i);
+  load_words8(sig + 8, sigs, 2 * i + 1);
+  const uint32_t off = msg_off[i], len = msg_off[i + 1] - off;
+  ge_p3 P, A;
+  load_ext(P, pubs_ext, i);
+  flags_a[i] = (uint8_t)verify_prep_a_point_with(h, A, P, pub, sig, msgs + off, len, ge_decode_fn());
+  store_words8(hbuf, i, h);
+  store_words8(sbuf, i, sig + 8);
+  store_ext(a_ext, i, A.X, A.Y, A.Z, A.T);
+}
 // verification, R half: checks and decode of R into the projective staging buffer at [proj_offset, proj_offset + n)
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
 k_verify_prep_r(const uint8_t* __restrict__ sigs, size_t n, uint8_t* __restrict__ flags_r, uint4* __restrict__ proj, size_t stride, size_t proj_offset) {
@@ -252,6 +272,11 @@ static inline unsigned blocks_for(size_t n) { return (unsigned)((n + KYB_BLOCK -
 hipError_t verify_prep(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,
                        uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf, int32_t* a_ext) {
   hipLaunchKernelGGL(k_verify_prep, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext);
+  return hipGetLastError();
+}
+hipError_t verify_prep_pts(hipStream_t st, const uint8_t* pub_enc, const int32_t* pubs_ext, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,
+                           uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf, int32_t* a_ext) {
+  hipLaunchKernelGGL(k_verify_prep_pts, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, pub_enc, pubs_ext, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext);
   return hipGetLastError();
 }
 hipError_t verify_prep_r(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* flags_r, uint4* proj, size_t stride, size_t offset) {

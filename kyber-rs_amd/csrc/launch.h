@@ -107,6 +107,8 @@ hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* o
 hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* table_coop);
 
 // ---- kernels_verify.hip ----
+hipError_t verify_prep_pts(hipStream_t st, const uint8_t* pub_enc, const int32_t* pubs_ext, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,
+                           uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf, int32_t* a_ext);      // public keys as points (+ their encodings)
 hipError_t verify_prep(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,
                        uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf, int32_t* a_ext);
 hipError_t verify_prep_r(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* flags_r, uint4* proj, size_t stride, size_t offset);

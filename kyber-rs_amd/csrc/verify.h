@@ -94,6 +94,54 @@ KYB_HD uint32_t verify_prep_r_with(ge_p3& R, const uint32_t sig[16], Dec&& decod
   fe_cmov(R.X, id.X, 1u - r_dec); fe_cmov(R.Y, id.Y, 1u - r_dec); fe_cmov(R.Z, id.Z, 1u - r_dec); fe_cmov(R.T, id.T, 1u - r_dec);
   return r_can | (r_dec << 1) | (r_small << 2);
 }
+// ---- the public key given as a POINT -----------------------------------------------------------------------------------
+// schnorr::verify and eddsa::verify (schnorr_sig.rs:114-127, eddsa_sig.rs:216-...: what every caller in dkg / vss / dss uses) take the
+// public key as a Point, marshal it, and hand the bytes to verify_with_checks, which unmarshals them again — a second square root for a point
+// the caller already holds.  Given the point and its encoding, the decode is only needed when the limbs are NOT a point of the curve:
+// a set of limbs with Z != 0, X Y = Z T and -X^2 + Y^2 = Z^2 + d T^2 is the group element its own encoding decodes to, so the rest of the
+// verification (which depends on the group element only) may use it as it is.  Anything else goes through the bytes, as the reference would.
+KYB_HD uint32_t ge_on_curve(const ge_p3& P) {
+  const fe d = {KYB_FE_D};
+  fe xx, yy, zz, tt, lhs, rhs, xy, zt, e1, e2;
+  fe_sq(xx, P.X); fe_sq(yy, P.Y); fe_sq(zz, P.Z); fe_sq(tt, P.T);
+  fe_sub(lhs, yy, xx);                   // 3T
+  fe_mul(rhs, tt, d);
+  fe_add(rhs, rhs, zz);                  // 2T
+  fe_sub4(e1, lhs, rhs);                 // rhs 2T: 4p bias
+  fe_mul(xy, P.X, P.Y);
+  fe_mul(zt, P.Z, P.T);
+  fe_sub(e2, xy, zt);
+  return (1u - fe_is_nonzero(e1)) & (1u - fe_is_nonzero(e2)) & fe_is_nonzero(P.Z);
+}
+// as verify_prep_a_with; P = the caller's point (tight limbs), pub = its marshal_binary (computed by the engine, ge.rs:112-122)
+template <class Dec>
+KYB_HD uint32_t verify_prep_a_point_with(uint32_t h[8], ge_p3& A, const ge_p3& P, const uint32_t pub[8], const uint32_t sig[16], const uint8_t* msg, uint32_t msg_len,
+                                         Dec&& decode) {
+  const uint32_t s_ok = sc_is_canonical_w(sig + 8);
+  const uint32_t a_can = pt_is_canonical_w(pub);
+  uint32_t a_dec = 1u;
+  if (ge_on_curve(P)) {                  // public data: the branch reveals nothing
+    A = P;
+  } else {
+    a_dec = decode(A, pub);
+  }
+  fe y;
+  fe_from_words(y, pub);                 // the y the decode works on (bit 255 ignored)
+  const uint32_t a_small = pt_has_small_order(y);
+  ge_p3 id;
+  ge_p3_0(id);
+  fe_cmov(A.X, id.X, 1u - a_dec); fe_cmov(A.Y, id.Y, 1u - a_dec); fe_cmov(A.Z, id.Z, 1u - a_dec); fe_cmov(A.T, id.T, 1u - a_dec);
+  uint32_t ra[16];
+  for (int i = 0; i < 8; ++i) { ra[i] = sig[i]; ra[8 + i] = pub[i]; }
+  sha512_ctx c;
+  sha512_init(c);
+  sha512_words64(c, ra);
+  sha512_bytes(c, msg, msg_len);
+  uint32_t dig[16];
+  sha512_final(dig, c);
+  sc_reduce512(h, dig);
+  return s_ok | (a_can << 1) | (a_dec << 2) | (a_small << 3);
+}
 struct ge_decode_fn { KYB_HD uint32_t operator()(ge_p3& P, const uint32_t w[8]) const { return KYB_GE_DECODE(P, w); } };
 KYB_HD uint32_t verify_prep_a(uint32_t h[8], ge_p3& A, const uint32_t pub[8], const uint32_t sig[16], const uint8_t* msg, uint32_t msg_len) {
   return verify_prep_a_with(h, A, pub, sig, msg, msg_len, ge_decode_fn());

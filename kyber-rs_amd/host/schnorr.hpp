@@ -37,6 +37,15 @@ inline void throw_status(int st, size_t sig_len, bool eddsa) {
     default: throw SignatureError(9, "reconstructed S is not equal to signature");
   }
 }
+// the public key as the Point the caller holds (schnorr::verify / eddsa::verify): kyb_verify_points_batch marshals it on the GPU and skips
+// the square root of unmarshalling it again; same status as verify_one on marshal_binary(pub)
+inline int verify_point_one(const group::edwards25519::Point& pub, const uint8_t* msg, size_t n, const uint8_t* sig, size_t sig_len, int flavor) {
+  if (sig_len != 64) return 1;
+  uint32_t off[2] = {0, (uint32_t)n};
+  uint8_t st = 0, dummy = 0;
+  group::edwards25519::detail::engine_must(kyb_verify_points_batch(pub.ge, n ? msg : &dummy, off, sig, 1, flavor, &st), "verify");
+  return st;
+}
 inline int verify_one(const uint8_t pub[32], const uint8_t* msg, size_t n, const uint8_t* sig, size_t sig_len, int flavor) {
   if (sig_len != 64) return 1;
   uint32_t off[2] = {0, (uint32_t)n};
@@ -64,10 +73,25 @@ inline void verify_with_checks(const uint8_t* pub, size_t pub_len, const uint8_t
   if (pub_len != 32) throw SignatureError(7, "invalid Ed25519 curve point");
   detail::throw_status(detail::verify_one(pub, msg, n, sig, sig_len, 1), sig_len, false);
 }
-// schnorr_sig.rs:114-126
+// schnorr_sig.rs:114-126 (marshal_binary of the key, then verify_with_checks: both on the GPU here)
 inline void verify(const Point& pub, const uint8_t* msg, size_t n, const uint8_t* sig, size_t sig_len) {
-  std::vector<uint8_t> pb = pub.marshal_binary();
-  verify_with_checks(pb.data(), pb.size(), msg, n, sig, sig_len);
+  detail::throw_status(detail::verify_point_one(pub, msg, n, sig, sig_len, 1), sig_len, false);
+}
+// many (key, message, signature) triples in one call: status per item, 0 = valid (the codes of throw_status)
+inline std::vector<uint8_t> verify_batch(const std::vector<Point>& pubs, const std::vector<std::vector<uint8_t>>& msgs, const std::vector<std::vector<uint8_t>>& sigs) {
+  const size_t n = pubs.size();
+  std::vector<int32_t> px(40 * n);
+  std::vector<uint8_t> blob(1), sg(64 * n), st(n, 1);
+  std::vector<uint32_t> off(n + 1, 0);
+  for (size_t i = 0; i < n; ++i) {
+    std::memcpy(&px[40 * i], pubs[i].ge, 160);
+    blob.insert(blob.end() - 1, msgs[i].begin(), msgs[i].end());
+    off[i + 1] = (uint32_t)(blob.size() - 1);
+    if (sigs[i].size() == 64) std::memcpy(&sg[64 * i], sigs[i].data(), 64);
+  }
+  if (n) group::edwards25519::detail::engine_must(kyb_verify_points_batch(px.data(), blob.data(), off.data(), sg.data(), n, 1, st.data()), "schnorr::verify_batch");
+  for (size_t i = 0; i < n; ++i) if (sigs[i].size() != 64) st[i] = 1;
+  return st;
 }
 }  // namespace schnorr
 

@@ -68,6 +68,7 @@ extern "C" {
     pub fn kyb_lincomb_public_batch(scalars: *const u8, pts_enc: *const u8, pts_ext: *const i32, shared_points: c_int, m: size_t, t: size_t,
                                     out_enc: *mut u8, out_ext: *mut i32, ok: *mut u8) -> c_int;
     pub fn kyb_lagrange_coeffs_batch(indices: *const u32, m: size_t, t: size_t, out_scalars: *mut u8) -> c_int;
+    pub fn kyb_verify_points_batch(pubs_ext: *const i32, msgs: *const u8, msg_off: *const u32, sigs: *const u8, n: size_t, flavor: c_int, status: *mut u8) -> c_int;
     pub fn kyb_pripoly_eval_batch(coeffs: *const u8, m: size_t, t: size_t, indices: *const u32, k: size_t, out_shares: *mut u8) -> c_int;
     pub fn kyb_host_alloc(bytes: size_t) -> *mut c_void;
     pub fn kyb_host_free(p: *mut c_void);

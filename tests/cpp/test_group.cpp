@@ -221,6 +221,26 @@ int main() {
     err.clear();
     try { schnorr::verify(X, msg, sizeof(msg) - 1, mal.data(), 64); } catch (const SignatureError& e) { err = e.what(); }
     CHECK(err == "signature is not canonical", "s + L is rejected");
+    // many triples in one call, keys as points: the same answers as one by one
+    {
+      std::vector<Point> keys;
+      std::vector<std::vector<uint8_t>> ms, sgs;
+      for (int i = 0; i < 9; ++i) {
+        Scalar xi = Scalar().pick(rand);
+        keys.push_back(Point().mul(xi, nullptr));
+        ms.push_back(std::vector<uint8_t>(msg, msg + (sizeof(msg) - 1 - (size_t)i % 4)));
+        sgs.push_back(schnorr::sign(rand, xi, ms.back().data(), ms.back().size()));
+      }
+      sgs[2][40] ^= 1; sgs[5] = mal; sgs[7].pop_back();
+      std::vector<uint8_t> stv = schnorr::verify_batch(keys, ms, sgs);
+      bool same = stv.size() == 9;
+      for (int i = 0; i < 9 && same; ++i) {
+        int one = 0;
+        try { schnorr::verify(keys[i], ms[i].data(), ms[i].size(), sgs[i].data(), sgs[i].size()); } catch (const SignatureError& e) { one = e.code; }
+        same = (stv[i] == 0) == (one == 0) && (i == 2 ? stv[i] == 9 : true) && (i == 7 ? stv[i] == 1 : true);
+      }
+      CHECK(same, "schnorr::verify_batch == verify one by one");
+    }
     std::vector<uint8_t> pb = X.marshal_binary();
     ok = true;
     try { eddsa::verify_with_checks(pb.data(), 32, msg, sizeof(msg) - 1, sig.data(), 64); } catch (const SignatureError&) { ok = false; }

@@ -749,6 +749,48 @@ def test_cfg5_shard_2_21_linearity(engine, oracle):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n", [5, 700, 3000, 9000])
+def test_verification_with_the_public_keys_given_as_points(engine, oracle, n):
+    """kyb_verify_points_batch (schnorr::verify / eddsa::verify take &Point and marshal it, schnorr_sig.rs:114-127): status == kyb_verify_batch on
+    marshal_binary(point) == the oracle on those bytes, both check orders — valid and corrupted signatures, small-order keys, projective
+    representations (Z != 1), and limbs that are NOT a point of the curve (random limbs, Z = 0), where the bytes decide as in the reference"""
+    x = synth.scalars(n, 1200 + n); x[:, 31] &= 0x7f
+    k = synth.scalars(n, 1300 + n, b"k")
+    msg_list = synth.messages(n, 1400 + n)
+    sigs = oracle.schnorr_sign_batch(x, k, msg_list, nthreads=8)
+    pts = oracle.mul_base_ext_batch(x)
+    rng = np.random.default_rng(n)
+    weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
+    for j, w in enumerate(weak):
+        if 3 + 7 * j < n:
+            pts[3 + 7 * j] = w                                              # small-order public keys
+    if n >= 64:
+        engine.set_option("ext.projective", 1)                             # the same keys as (X : Y : Z : T) with Z != 1
+        try:
+            proj = engine.mul_base(x[40:60], ext_only=True)
+        finally:
+            engine.set_option("ext.projective", 0)
+        assert (proj[:, 20:30] != pts[40:60, 20:30]).any()
+        pts[40:60] = proj
+    if n >= 700:
+        pts[100:110] = rng.integers(-(1 << 24), 1 << 24, (10, 40), dtype=np.int64).astype(np.int32)      # not points at all
+        pts[111, 20:30] = 0                                                 # Z = 0
+        pts[113, 30:40] = pts[114, 30:40]                                   # T inconsistent with X Y / Z
+    bad = sigs.copy()
+    bad[::4, 35] ^= 0x10
+    bad[2::9, 0] ^= 1
+    bad[5::13, 63] |= 0xf0                                                  # s not canonical
+    enc = engine.encode(pts)
+    for i in sorted({0, 3, min(10, n - 1), n - 1} | ({100, 105, 111, 113} if n >= 700 else set())):
+        assert bytes(enc[i]) == oracle.encode(pts[i])
+    for flavor in (0, 1):
+        want = engine.verify(enc, msg_list, bad, flavor)
+        assert np.array_equal(want, oracle.verify_batch(flavor, enc, msg_list, bad, nthreads=8))
+        got = engine.verify_points(pts, msg_list, bad, flavor)
+        assert np.array_equal(got, want), (flavor, np.nonzero(got != want)[0][:10])
+    assert (engine.verify_points(pts, msg_list, sigs, 1) == 0).sum() >= n - 40      # the untouched keys verify their signatures
+
+
 def test_mid_size_host_calls_agree_whichever_way_the_arrays_travel(engine, oracle):
     """A DKG-sized host-pointer call takes the page-locked zero-copy window (host.zero_copy_kib, 4 MiB by default) or, above it, copies on
     the engine stream: same bytes both ways, for the record batches (mul, mul_base) and the calls with mixed arrays (sign, verify, dealer

@@ -52,6 +52,7 @@ KN = synth.scalars(NMAX, 4000 + seed, b"k")
 MSGS = synth.messages(NMAX, 5000 + seed)
 WANT_SIG = orc.schnorr_sign_batch(X, KN, MSGS, nthreads=8)
 PUBS = orc.mul_base_batch(X, nthreads=8)
+PUBS_EXT = orc.mul_base_ext_batch(X)
 BAD_SIG = WANT_SIG.copy(); BAD_SIG[::4, 35] ^= 0x10
 BAD_SIG[2::9, 0] ^= 1                                       # R corrupted: usually no longer a point
 WANT_ST = {fl: orc.verify_batch(fl, PUBS, MSGS, BAD_SIG, nthreads=8) for fl in (0, 1)} if hasattr(orc, "verify_batch") else None
@@ -128,7 +129,10 @@ while time.time() < t_end:
             assert np.array_equal(eng.schnorr_sign(X[sl], KN[sl], MSGS[lo:lo + n], pubs=PUBS[sl] if keyed else None), WANT_SIG[sl])
         elif op == "verify":
             fl = int(rng.integers(0, 2))
-            assert np.array_equal(eng.verify(PUBS[sl], MSGS[lo:lo + n], BAD_SIG[sl], fl), WANT_ST[fl][sl])
+            if rng.integers(0, 3) == 0:                        # the public keys as points (schnorr::verify): same statuses
+                assert np.array_equal(eng.verify_points(PUBS_EXT[sl], MSGS[lo:lo + n], BAD_SIG[sl], fl), WANT_ST[fl][sl])
+            else:
+                assert np.array_equal(eng.verify(PUBS[sl], MSGS[lo:lo + n], BAD_SIG[sl], fl), WANT_ST[fl][sl])
         elif op == "decode":
             ext, ok = eng.decode(POOL_E_BAD[sl])
             for i in range(0, n, max(1, n // 40)):
