@@ -241,8 +241,12 @@ def setup_workload(wl, n, eng, inp, rt, keyed):
             w["sigs"] = sigs = torch.empty((n, 64), dtype=torch.uint8, device=dev)
             w["pubs"] = pubs = torch.empty((n, 32), dtype=torch.uint8, device=dev)
             eng.sign_dev(sc, k, msgs, off, sigs, stream=stream)
-            eng.mul_base_dev(sc, out_enc=pubs, stream=stream)
+            w["pubs_ext"] = pubs_ext = torch.empty((n, 40), dtype=torch.int32, device=dev)
+            eng.mul_base_dev(sc, out_enc=pubs, out_ext=pubs_ext, stream=stream)
             w["step"] = lambda: eng.verify_dev(pubs, msgs, off, sigs, out, flavor=1, stream=stream)
+            # the same verifications with the public keys as points (schnorr::verify's own signature, kyb_verify_points_batch): timed after the
+            # primary region and reported next to it
+            w["step_points"] = lambda: eng.verify_points_dev(pubs_ext, msgs, off, sigs, out, flavor=1, stream=stream)
         w["_keep"] = (msgs, off, pubs)
     rt.sync()
     return w
@@ -440,6 +444,26 @@ def device_identity(torch, local):
         if hasattr(p, key):
             ident[key] = str(getattr(p, key))
     return ident
+
+
+def verify_points_rate(w, eng, rt, steps, warmup):
+    """the verify workload's signatures checked through kyb_verify_points_batch (keys handed over as points): K steps after W warm-up steps,
+    statuses compared with the byte form's"""
+    torch = rt.torch
+    w["step"](); rt.sync()
+    ref = w["out"].clone()
+    for _ in range(warmup):
+        w["step_points"]()
+    rt.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        w["step_points"]()
+    rt.sync()
+    dt = time.perf_counter() - t0
+    if not torch.equal(w["out"], ref):
+        raise SystemExit("PARITY FAILURE (verify, keys as points): statuses differ from the byte form")
+    return {"value": round(w["n"] * steps / dt, 1), "unit": UNIT["verify"], "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+            "entry_point": "kyb_verify_points_batch_dev (schnorr::verify takes &Point, schnorr_sig.rs:114-127)", "statuses_equal_to_byte_form": True}
 
 
 def mid_size_calls(eng, orc, threads, n=8192):
@@ -659,6 +683,8 @@ def run_ranks(args):
                                    "parity_checked_items": ochk}
                     if owl == "mul":
                         others[owl].update(host_pointer_rates(ow, eng, orc, threads))
+                    if owl == "verify":
+                        others[owl]["public_keys_as_points"] = verify_points_rate(ow, eng, rt, args.steps, args.warmup)
                     del ow
                 line["workloads"] = others
                 line["small_calls"] = small_call_latency(eng, orc)
