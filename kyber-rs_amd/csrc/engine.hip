@@ -517,7 +517,8 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
 }
 
 static_assert(KYB_BASE_TABLE_BYTES == 4u * (KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS + KYB_BASE64_TABLE_WORDS), "table image layout");
-constexpr int KYB_CK_LO = KYB_BT_IDX(0, 0, 30), KYB_CK_HI = KYB_BT_IDX(0, 0, 31);   // where the image carries its own checksum
+constexpr int KYB_CK_LO = KYB_BT_IDX(0, 0, 30);   // where the image carries its own checksum (two words: KYB_CK_LO, KYB_CK_LO + 1)
+static_assert(KYB_BT_IDX(0, 0, 31) == KYB_CK_LO + 1, "the checksum words are adjacent");
 
 // One synchronous host-pointer call of the small (non-pipelined) kind: the caller's arrays are laid out in the
 // context's device staging buffer, inputs copied in, `body` queues the kernels on the engine stream, outputs copied
