@@ -217,6 +217,18 @@ int hd_verify(int flavor, const uint8_t pub[32], const uint8_t* msg, uint32_t n,
   uint32_t eq = verify_final(R.X, R.Y, hA, sB);
   return (int)((st == 0 && !eq) ? 9u : st);
 }
+// the A half with the public key given as a point (verify_prep_a_point_with): flags, and whether A is the same group element as the byte form's
+int hd_verify_prep_point(const int32_t ext[40], const uint8_t pub[32], const uint8_t* msg, uint32_t n, const uint8_t sig[64], int* same_point, int* on_curve) {
+  uint32_t wp[8], ws[16], h1[8], h2[8];
+  load_words(wp, pub); memcpy(ws, sig, 64);
+  ge_p3 P, A1, A2;
+  fe_from_ref10(P.X, ext); fe_from_ref10(P.Y, ext + 10); fe_from_ref10(P.Z, ext + 20); fe_from_ref10(P.T, ext + 30);
+  const uint32_t f1 = verify_prep_a_point_with(h1, A1, P, wp, ws, msg, n, ge_decode_fn());
+  const uint32_t f2 = verify_prep_a(h2, A2, wp, ws, msg, n);
+  *on_curve = (int)ge_on_curve(P);
+  *same_point = (int)(ge_equal(A1, A2) && memcmp(h1, h2, 32) == 0);
+  return (int)(f1 == f2 ? f1 : 0x100u | f1 | (f2 << 4));
+}
 void hd_pubpoly_eval(uint8_t out[32], const int32_t* commits, int t, uint32_t index, int nbits) {
   ge_p2 r;
   ge_poly_eval(r, [&](int j, ge_p3& c) {

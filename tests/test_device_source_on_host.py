@@ -275,6 +275,47 @@ def test_verify_matches_oracle_and_model(hd, oracle):
     assert hd.hd_overflows() == base
 
 
+def test_verify_prep_with_the_key_as_a_point(hd, oracle):
+    """verify_prep_a_point_with (kyb_verify_points_batch) == verify_prep_a on marshal_binary(point): same flags, same challenge, same group
+    element — affine and projective representations, small-order keys, and limbs that are no point of the curve (their bytes decide)"""
+    import numpy as np
+    base = hd.hd_overflows()
+    P = M.P
+    rnd = random.Random(3)
+
+    def limbs(v):                                        # integer -> ten reference limbs (radix 2^25.5, non-negative)
+        out, bits = [], [26, 25] * 5
+        for b in bits:
+            out.append(v & ((1 << b) - 1)); v >>= b
+        return out
+
+    keys = [oracle.mul_base_ext((rnd.getrandbits(250)).to_bytes(32, "little")) for _ in range(12)]
+    keys += [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
+    cases = []
+    for e in keys:
+        cases.append(np.array(e, dtype=np.int32))
+        X0, Y0, Z0 = [sum(int(e[10 * c + i]) << (0, 26, 51, 77, 102, 128, 153, 179, 204, 230)[i] for i in range(10)) % P for c in (0, 1, 2)]
+        x, y = X0 * pow(Z0, P - 2, P) % P, Y0 * pow(Z0, P - 2, P) % P      # (the oracle's own limbs are a projective representation already)
+        lam = rnd.randrange(2, P)
+        X, Y, Z = x * lam % P, y * lam % P, lam
+        T = X * Y * pow(Z, P - 2, P) % P
+        cases.append(np.array(limbs(X) + limbs(Y) + limbs(Z) + limbs(T), dtype=np.int32))           # the same point, Z != 1
+        cases.append(np.array(limbs(X) + limbs(Y) + limbs(Z) + limbs((T + 1) % P), dtype=np.int32))  # T inconsistent: not a point
+    cases.append(np.array(limbs(5) + limbs(7) + limbs(0) + limbs(0), dtype=np.int32))                # Z = 0
+    cases.append(np.array([rnd.randrange(-(1 << 24), 1 << 24) for _ in range(40)], dtype=np.int32))  # random limbs
+    on = 0
+    for ext in cases:
+        pub = oracle.encode(ext)
+        msg = bytes(rnd.getrandbits(8) for _ in range(rnd.randrange(0, 70)))
+        sig = bytes(rnd.getrandbits(8) for _ in range(64))
+        same, onc = ctypes.c_int(0), ctypes.c_int(0)
+        fl = hd.hd_verify_prep_point(ext.ctypes.data_as(ctypes.c_void_p), pub, msg, len(msg), sig, ctypes.byref(same), ctypes.byref(onc))
+        assert fl < 0x100 and same.value == 1, (hex(fl), same.value, onc.value)
+        on += onc.value
+    assert on == 2 * len(keys)                           # exactly the oracle's own and the re-scaled representations pass the curve test
+    assert hd.hd_overflows() == base
+
+
 def test_pubpoly_eval_and_equal(hd, oracle):
     """short-ladder Horner == the reference's eval (64-window mult by x = i + 1, then add), poly.rs:457-469"""
     base = hd.hd_overflows()
