@@ -1435,18 +1435,21 @@ int poly_batch_segments(const Ctx& g, size_t n, size_t t, int nbits) {
   if (n <= coop_lim(g, g.opt_coop_max)) {
     int cs = g.opt_poly_segments;
     if (cs == 0) { const size_t by_len = t / 24, by_room = 2048 / n; cs = (int)(by_len < by_room ? by_len : by_room); if (cs > 32) cs = 32; if (cs < 1) cs = 1; }
-    const double waves = (double)n * cs, crowd = waves > 1536.0 ? waves / 1536.0 : 1.0;
+    const double waves = (double)n * cs, crowd = waves > 1280.0 ? waves / 1280.0 : 1.0;      // (1,536 until the two-lane ladder moved the boundary: profiles/r03/poly_eval_pair_probe.log)
     best = ((double)((t + cs - 1) / cs) * 6.2 * f + (cs > 1 ? 160.0 : 0.0)) * crowd + 40.0;
   } else {
     best = (double)((n + 65535) / 65536) * (double)t * 31.0 * f + 100.0;
   }
   int segs = 1;
-  const size_t cand[] = {65536 / n, (65536 + n - 1) / n, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
+  const size_t cand[] = {65536 / n, (65536 + n - 1) / n, 32768 / n, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};
   for (size_t sgs : cand) {
     if (sgs < 2 || sgs > 256 || sgs > t / 4) continue;                // at least four coefficients per segment
     const size_t len = (t + sgs - 1) / sgs;
     const double rounds = (double)((n * sgs + 65535) / 65536);
-    const double cost = (rounds * ((double)len * 35.0 * f + 700.0) + 300.0) * 1.05;      // Horner chain + 255-step ladder per round; images, sums, finish
+    // Horner chain + 255-step ladder per round; images, sums, finish.  Up to ladder.pair_max_items products the two-lane ladder runs them
+    // (0.40 ms, no image kernel in front) instead of k_mont_prep + k_mul_ladder (0.10 + 0.61 ms)
+    const bool pair = n * sgs <= pair_lim(g, g.opt_ladder_pair_max);
+    const double cost = (rounds * ((double)len * 35.0 * f + (pair ? 400.0 : 700.0)) + (pair ? 200.0 : 300.0)) * 1.05;
     if (cost < best) { best = cost; segs = (int)sgs; }
   }
   return segs;
