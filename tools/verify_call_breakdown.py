@@ -35,3 +35,20 @@ for n in (1024, 2048, 2560):
     ids = (ctypes.c_int * 16)(); ms = (ctypes.c_float * 16)(); cnt = ctypes.c_int(0)
     lib.kyb_profile_read(ids, ms, 16, ctypes.byref(cnt)); lib.kyb_profile_begin(0)
     print(os.path.basename(sys.argv[1]), n, f"{sorted(ts)[15]*1e3:.3f} ms", " ".join(f"{lib.kyb_kernel_name(ids[i]).decode()}={ms[i]:.3f}" for i in range(cnt.value)), flush=True)
+
+# the same with eight calls queued back to back (no synchronisation between them): per-kernel means
+for n in (2048,):
+    fn = lambda: lib.kyb_verify_batch_dev(p(pubs), p(msgs), p(off), p(sigs), n, 1, p(out), None)
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    lib.kyb_profile_begin(64)
+    t0 = time.perf_counter()
+    for _ in range(8): fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 8
+    ids = (ctypes.c_int * 64)(); ms = (ctypes.c_float * 64)(); cnt = ctypes.c_int(0)
+    lib.kyb_profile_read(ids, ms, 64, ctypes.byref(cnt)); lib.kyb_profile_begin(0)
+    agg = {}
+    for i in range(cnt.value):
+        agg.setdefault(lib.kyb_kernel_name(ids[i]).decode(), []).append(ms[i])
+    print(os.path.basename(sys.argv[1]), n, f"queued back to back: {dt*1e3:.3f} ms per call;", " ".join(f"{k_}={sum(v)/len(v):.3f}" for k_, v in agg.items()), flush=True)
