@@ -167,6 +167,29 @@ def eddsa_public(seed):
     return encode(point_mul(secret))
 
 
+def embed(data, stream):
+    """Point::embed / Point::pick (point.rs:90-92, 106-167) over a replayed key stream (bytes, 32 per candidate); data None = pick.
+    Returns (affine point, blocks consumed) or (None, -1) when the stream runs out.  Group-theoretic restatement: a candidate that
+    decodes is accepted by pick when 8 P != O (and 8 P is returned), by embed when L P == O (and P itself is returned)."""
+    dl = 0 if data is None else min(29, len(data))
+    for i in range(len(stream) // 32):
+        b = bytearray(stream[32 * i:32 * i + 32])
+        if data is not None:
+            b[0] = dl
+            b[1:1 + dl] = data[:dl]
+        pt = decode(bytes(b))
+        if pt is None:
+            continue
+        if data is None:
+            q = mul_int(8, pt)
+            if q == IDENT:
+                continue
+            return q, i + 1
+        if mul_int(L, pt) == IDENT:
+            return pt, i + 1
+    return None, -1
+
+
 # ---- verification (eddsa_sig.rs:159-212 / schnorr_sig.rs:53-110); status codes as in ed25519_oracle.c ----
 def _order8_ys():
     # y-coordinates of the two order-8 point classes, derived from the group law

@@ -572,6 +572,47 @@ void orc_add(int32_t out[40], const int32_t a[40], const int32_t b[40], int sub)
 void orc_neg(int32_t out[40], const int32_t a[40]) { ge_p3 A; ext_in(&A, a); fe_neg(A.X, A.X); fe_neg(A.T, A.T); ext_out(out, &A); }
 void orc_base(int32_t out[40]) { ensure(); ext_out(out, &BASEPT); }
 void orc_null(int32_t out[40]) { ge_p3 z; p3_0(&z); ext_out(out, &z); }
+/* Point::embed(data, rand) / Point::pick(rand) = embed(None, rand)  (point.rs:90-92, 106-167) over a REPLAYED key stream: block i of
+ * `stream` is what the i-th `rand.xor_key_stream(&mut b, &[0; 32])` of the loop yields.  data_len < 0 means `None`.
+ *   dl = min(embed_len() = 29, data.len())            (longer data is silently truncated, :108-116)
+ *   candidate b = block; with data: b[0] = dl, b[1..1+dl] = data[..dl]   (:121-127)
+ *   !set_bytes(b)                         -> next block                  (:129-132)
+ *   None:  Q = mul(COFACTOR_SCALAR = 8, P); Q == NULL_POINT (by encoding, point.rs:227) -> next block, else return Q   (:144-153)
+ *   Some:  mul(PRIME_ORDER_SCALAR = L, P) == NULL_POINT -> return P (the decoded candidate itself), else next block   (:158-164)
+ * Both constants are the unreduced 32-byte integers (constants.rs:45-49).  Returns the number of blocks consumed, or -1 when the
+ * stream ran out before a candidate was accepted (the reference would keep drawing). */
+long orc_embed(int32_t out_ext[40], uint8_t out_enc[32], const uint8_t* data, long data_len, const uint8_t* stream, size_t blocks) {
+  ensure();
+  static const uint8_t Lb[32] = {0xed,0xd3,0xf5,0x5c,0x1a,0x63,0x12,0x58,0xd6,0x9c,0xf7,0xa2,0xde,0xf9,0xde,0x14,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0x10};
+  static const uint8_t eight[32] = {8}, null_enc[32] = {1};
+  size_t dl = (255 - 8 - 8) / 8;
+  const size_t have = data_len < 0 ? 0 : (size_t)data_len;
+  if (dl > have) dl = have;
+  for (size_t i = 0; i < blocks; i++) {
+    uint8_t b[32], enc[32];
+    memcpy(b, stream + 32 * i, 32);
+    if (data_len >= 0) { b[0] = (uint8_t)dl; memcpy(b + 1, data, dl); }
+    ge_p3 P, Q;
+    if (!p3_frombytes(&P, b)) continue;
+    ge_scalarmult(&Q, data_len < 0 ? eight : Lb, &P);
+    p3_tobytes(enc, &Q);
+    const int is_null = memcmp(enc, null_enc, 32) == 0;
+    if (data_len < 0 ? is_null : !is_null) continue;
+    const ge_p3* R = data_len < 0 ? &Q : &P;
+    if (out_ext) ext_out(out_ext, R);
+    if (out_enc) p3_tobytes(out_enc, R);
+    return (long)i + 1;
+  }
+  return -1;
+}
+/* Point::data (point.rs:169-177): the bytes embed() placed; -1 = PointError::EmbedDataLength */
+long orc_point_data(uint8_t out[29], const int32_t ext[40]) {
+  ensure(); ge_p3 h; ext_in(&h, ext); uint8_t b[32]; p3_tobytes(b, &h);
+  const size_t dl = b[0];
+  if (dl > (255 - 8 - 8) / 8) return -1;
+  memcpy(out, b + 1, dl);
+  return (long)dl;
+}
 /* read-only views for the constants-vs-reference test: D, D2, SQRT_M1, BASE[i][j] as 32-byte values */
 void orc_const_bytes(uint8_t out[32], int which) { ensure(); fe_tobytes(out, which == 0 ? D : which == 1 ? D2 : SQRTM1); }
 void orc_base_table_bytes(uint8_t out[96], int i, int j) { ensure(); fe_tobytes(out, BASE[i][j].ypx); fe_tobytes(out + 32, BASE[i][j].ymx); fe_tobytes(out + 64, BASE[i][j].xy2d); }

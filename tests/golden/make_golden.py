@@ -12,7 +12,10 @@ What is copied is DATA the reference's own tests hold for this path (SURVEY.md ย
         weak_keys      src/group/edwards25519/constants.rs:3744-3775
     plus quirk vectors whose expected outputs come from the C oracle and are cross-checked against
     oracle/bigint_model.py before being written (no reference test covers them; SURVEY.md ยง8c).
+        embed          Point::embed / Point::pick (point.rs:90-92, 106-167) over replayed key streams: accepted candidate, blocks
+                       consumed and the reason every earlier candidate was rejected (C oracle == big-int model, as above)
 """
+import hashlib
 import json
 import os
 import re
@@ -113,9 +116,90 @@ def main():
     out["verify_negative"] = dict(golang_msg="54657374", golang_sig=sig2.hex(), golang_pk=pk2.hex(),
                                   non_canonical_point=noncanon.hex(), small_order_point=small.hex())
     assert orc.verify(0, pk2, bytes.fromhex("54657374"), sig2) == 2 == M.verify(0, pk2, bytes.fromhex("54657374"), sig2)
+    out["embed"] = embed_vectors(orc, M, out)
     with open(os.path.join(HERE, "kats.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", len(q), "quirk_mul,", len(qb), "quirk_mul_base vectors")
+
+
+def key_stream(tag: bytes, blocks: int) -> bytes:
+    """a deterministic stand-in for `rand.xor_key_stream(&mut b, &[0; 32])`: block i = SHA-512("kyber-hip/v1/embed" || tag || le64(i))[:32]"""
+    return b"".join(hashlib.sha512(b"kyber-hip/v1/embed" + tag + i.to_bytes(8, "little")).digest()[:32] for i in range(blocks))
+
+
+def embed_vectors(orc, M, out):
+    """Known answers for A13.  Every vector: data (hex, or null for pick), the key stream up to one block past the accepted candidate,
+    the accepted point's encoding, the blocks consumed, the bytes Point::data() returns, and `rejected` = why each earlier candidate
+    failed ("decode": no square root; "order": decodes, but 8 P = O for pick / L P != O for embed)."""
+    def why(data, stream, n):
+        r = []
+        dl = 0 if data is None else min(29, len(data))
+        for i in range(n - 1):
+            b = bytearray(stream[32 * i:32 * i + 32])
+            if data is not None:
+                b[0] = dl
+                b[1:1 + dl] = data[:dl]
+            r.append("decode" if M.decode(bytes(b)) is None else "order")
+        return r
+
+    vecs = []
+
+    def add(data, stream, note):
+        e, enc, n = orc.embed(data, stream)
+        pm, nm = M.embed(data, stream)
+        assert n == nm and n > 0 and enc == M.encode(pm), note
+        d_out = None if data is None else orc.point_data(e)
+        if data is not None:
+            assert d_out == data[:29], note
+        # the accepted candidate must not depend on what follows it; keep one block more to show that it is not drawn
+        keep = stream[:32 * min(n + 1, len(stream) // 32)]
+        assert orc.embed(data, keep)[1] == enc
+        vecs.append(dict(note=note, data=None if data is None else data.hex(), stream=keep.hex(), out=enc.hex(), consumed=n,
+                         point_data=None if d_out is None else d_out.hex(), rejected=why(data, stream, n)))
+
+    # natural streams: pick accepts about every second candidate, embed about one in sixteen (decodes AND lies in the prime-order
+    # subgroup); tags are searched so that the committed streams stay short but both kinds of rejection occur
+    datas = [None, b"", b"H", b"Hi!", bytes(range(1, 30)), b"The quick brown fox jumps over the lazy dog", bytes([0xff] * 29), bytes(40)]
+    for data in datas:
+        got = 0
+        k = 0
+        while got < 3:
+            tag = (b"-" if data is None else data[:4]) + b"/" + str(k).encode()
+            k += 1
+            st = key_stream(tag, 80)
+            n = M.embed(data, st)[1]
+            lim = 6 if data is None else 24
+            if 0 < n <= lim and (got != 2 or n >= 2):
+                add(data, st, "natural stream " + tag.decode("latin1"))
+                got += 1
+    # crafted pick streams: encodings that do not decode, then every small-order encoding (8 P = O: "unlucky; try again"), then B
+    bad = [bytes.fromhex(h) for h in out["invalid_encodings"]]
+    weak = [bytes.fromhex(h) for h in out["weak_keys"]]
+    ident = bytes([1] + [0] * 31)
+    add(None, b"".join(bad) + M.encode(M.B) + ident, "pick: four undecodable blocks, then B")
+    add(None, b"".join(weak) + ident + M.encode(M.B) + ident, "pick: the five WEAK_KEYS and the neutral element are skipped, then B")
+    add(None, weak[2] + bad[0] + bytes([weak[3][0]]) + weak[3][1:31] + bytes([weak[3][31] | 0x80]) + M.encode(M.point_mul((7).to_bytes(32, "little"))) + ident,
+        "pick: small order, undecodable, small order with the sign bit, then 7B")
+    # a mixed-order candidate (B + a point of order 8): pick returns 8 (B + T) = 8 B; embed's order test must reject such a point
+    t8 = M.decode(weak[2])
+    mixed = M.encode(M.add(M.B, t8))
+    add(None, mixed + ident, "pick: mixed-order candidate, the result is 8 times it")
+    # crafted embed streams: the data bytes overwrite the front of the block, so take an accepted natural candidate and prepend failures
+    for data in (b"", b"Hi!"):
+        st = key_stream(b"craft/" + data, 400)
+        pm, n = M.embed(data, st)
+        good = st[32 * (n - 1):32 * n]
+        # a block whose candidate decodes to a point outside the subgroup: search the stream for one
+        dl = len(data)
+        order_fail = None
+        for i in range(n - 1):
+            b = bytearray(st[32 * i:32 * i + 32]); b[0] = dl; b[1:1 + dl] = data
+            if M.decode(bytes(b)) is not None:
+                order_fail = st[32 * i:32 * i + 32]
+                break
+        assert order_fail is not None
+        add(data, order_fail + order_fail + good + ident, "embed %r: two candidates outside the prime-order subgroup, then an accepted one" % data)
+    return vecs
 
 
 if __name__ == "__main__":

@@ -139,6 +139,22 @@ class Oracle:
         self.lib.orc_base_table_bytes(o, i, j)
         return o.raw
 
+    def embed(self, data, stream: bytes):
+        """Point::embed(data, rand) (data None = Point::pick) over a replayed key stream -> (ext limbs, encoding, blocks consumed);
+        (None, None, -1) when the stream ends before a candidate is accepted"""
+        e = np.zeros(40, dtype=np.int32)
+        o = self._b(32)
+        self.lib.orc_embed.restype = ctypes.c_long
+        n = self.lib.orc_embed(_p(e), o, data, ctypes.c_long(-1 if data is None else len(data)), stream, ctypes.c_size_t(len(stream) // 32))
+        return (e, o.raw, int(n)) if n > 0 else (None, None, -1)
+
+    def point_data(self, ext):
+        """Point::data -> bytes, or None for PointError::EmbedDataLength"""
+        o = self._b(29)
+        self.lib.orc_point_data.restype = ctypes.c_long
+        n = self.lib.orc_point_data(o, _p(_i32(ext)))
+        return None if n < 0 else o.raw[:n]
+
     # ---- batches (numpy) ----
     def mul_base_batch(self, scalars, nthreads: int = 1) -> np.ndarray:
         s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)

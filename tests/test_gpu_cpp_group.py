@@ -33,3 +33,37 @@ def test_reference_group_test_through_cpp_mirror(oracle):
     assert len(pts) == 4 + 5 + 2 + 5
     for h in pts[4:]:                                                            # picked / embedded points decode
         assert oracle.decode(bytes.fromhex(h))[1] == 1
+
+
+def test_embed_and_pick_known_answers_through_cpp_mirror():
+    """A13: the mirror's embed / pick (rejection loop on the engine: kyb_decode_batch, kyb_mul_batch by 8 or by L) over the replayed key
+    streams of tests/golden/kats.json["embed"]: accepted candidate (bytes), blocks drawn and Point::data must equal the known answers;
+    a stream cut in front of the accepted block must be drawn to its end without a result."""
+    import json
+    kats = json.load(open(os.path.join(ROOT, "tests", "golden", "kats.json")))["embed"]
+    src = os.path.join(ROOT, "tests", "cpp", "test_embed.cpp")
+    out = os.path.join(ROOT, "tests", "cpp", "_build", "test_embed")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    libdir = os.path.join(ROOT, "kyber-rs_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-o", out, src,
+                           "-L", libdir, "-lkyber_ed25519_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    lines, want = [], []
+    for v in kats:
+        d = "-" if v["data"] is None else ("=" if v["data"] == "" else v["data"])
+        lines.append(f"{d} {v['stream']}")
+        pd = "!" if v["data"] is None and v["point_data"] is None else ("=" if v["point_data"] == "" else v["point_data"])
+        want.append((v["out"], str(v["consumed"]), pd))
+        cut = v["stream"][:64 * (v["consumed"] - 1)]
+        if cut:
+            lines.append(f"{d} {cut}")
+            want.append(("exhausted", str(v["consumed"] - 1), "-"))
+    r = subprocess.run([out], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0
+    got = [tuple(ln.split()) for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(got) == len(want)
+    for g, w, ln in zip(got, want, lines):
+        if w[2] == "!":                                    # pick: Point::data of a random point errs or returns garbage; not part of the known answer
+            assert g[:2] == w[:2], (ln[:80], g, w)
+        else:
+            assert g == w, (ln[:80], g, w)

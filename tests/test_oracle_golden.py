@@ -212,6 +212,45 @@ def test_point_is_canonical_follows_the_reference_expression(oracle):
                         assert M.verify(flavor, pub, msg, enc + sig[32:]) == oracle.verify(flavor, pub, msg, enc + sig[32:])
 
 
+def test_embed_and_pick_known_answers(oracle):
+    """A13, point.rs:90-92 / 106-167 over replayed key streams: the accepted candidate (bytes), how many blocks the loop drew and
+    Point::data of the result — C oracle and big-int model against the committed vectors; the rejected candidates fail for the
+    recorded reason (no square root / 8 P = O for pick / L P != O for embed)."""
+    assert len(KATS["embed"]) >= 30
+    seen = set()
+    for v in KATS["embed"]:
+        data = None if v["data"] is None else bytes.fromhex(v["data"])
+        stream = bytes.fromhex(v["stream"])
+        ext, enc, n = oracle.embed(data, stream)
+        assert (enc.hex(), n) == (v["out"], v["consumed"]), v["note"]
+        pm, nm = M.embed(data, stream)
+        assert (M.encode(pm).hex(), nm) == (v["out"], v["consumed"]), v["note"]
+        if data is None:
+            assert v["point_data"] is None
+            assert M.mul_int(M.L, pm) == M.IDENT and pm != M.IDENT              # pick lands in the prime-order subgroup
+        else:
+            assert oracle.point_data(ext).hex() == v["point_data"] == data[:29].hex()
+            assert enc[0] == min(29, len(data)) and enc[1:1 + enc[0]] == data[:29]
+        # a stream that ends before the accepted block is exhausted without a result
+        assert oracle.embed(data, stream[:32 * (n - 1)])[2] == -1
+        dl = 0 if data is None else min(29, len(data))
+        for i, reason in enumerate(v["rejected"]):
+            b = bytearray(stream[32 * i:32 * i + 32])
+            if data is not None:
+                b[0] = dl
+                b[1:1 + dl] = data[:dl]
+            e, ok = oracle.decode(bytes(b))
+            assert bool(ok) == (reason == "order"), (v["note"], i)
+            if ok:
+                q = oracle.mul((8).to_bytes(32, "little") if data is None else M.L.to_bytes(32, "little"), e)
+                assert (q == M.encode(M.IDENT)) == (data is None), (v["note"], i)
+            seen.add((data is None, reason))
+    assert seen == {(True, "decode"), (True, "order"), (False, "decode"), (False, "order")}
+    # Point::data on a point whose length byte exceeds embed_len: PointError::EmbedDataLength (point.rs:172-175)
+    e, ok = oracle.decode(M.encode(M.B))
+    assert ok and oracle.point_data(e) is None                                     # B's encoding starts with 0x58
+
+
 def test_pripoly_eval_matches_python_integers(oracle):
     """orc_pripoly_eval (PriPoly::eval, poly.rs:133-141) == sum c_j x^j mod L in Python integers: canonical and unreduced coefficients, t = 1, the
     largest index the ABI takes"""
