@@ -36,6 +36,13 @@
  *                  leading zero bits when all are below 2^64.  kyb_mul_batch itself never does.
  *              tools/ct_check.py checks the claim on the compiled kernels (no branch on, and no address from, scalar words).
  *   memory     the caller owns every buffer; the library keeps no pointer after return.
+ *   secrets    host-pointer calls that take secret scalars (kyb_mul_base_batch, kyb_mul_batch, the signing calls, kyb_pripoly_eval_batch)
+ *              clear, before they return and on every error path, the copies of the secret INPUTS the engine made — page-locked zero-copy
+ *              buffer, device staging, bounce ring — and kyb_mul_batch (whose result s*P is a Diffie-Hellman shared secret) also the
+ *              copies of its OUTPUTS in the zero-copy buffer and the device staging.  Not cleared per call: the per-stream device scratch
+ *              (projective staging records; overwritten by the next call on the stream, wiped when the context or the stream slot is
+ *              released) and, for pageable callers of calls of 2^16 items and more, the page-locked landing area of the results (buffers
+ *              from kyb_host_alloc bypass it).  Device-pointer calls work on the caller's own buffers and leave only the scratch.
  *
  * Two flavours of every batch call:
  *   kyb_xxx_batch      host pointers; H2D copy, kernel, D2H copy, synchronous.
@@ -355,6 +362,19 @@ int kyb_dkg_verify_round_enc_dev(const uint8_t* commits_enc, size_t t, size_t m,
 int kyb_equal_batch(const int32_t* a_ext, const int32_t* b_ext, size_t n, uint8_t* eq);
 int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, uint8_t* eq, void* stream);
 
+/* ---- PointCanCheckCanonicalAndSmallOrder, group.rs:71-78, point.rs:286-337 ---- */
+/* flags[i]: bit 0 = is_canonical(b) — the reference's own expression (point.rs:315-337), which also answers "not canonical" for the 217
+ * canonical values y = p-217 .. p-1 (DESIGN.md "Parity definition"); bit 1 = has_small_order().  Exactly one of
+ *   enc      n x 32 received bytes.  has_small_order() looks at the canonical re-encoding of the decoded point with the sign bit masked
+ *            (point.rs:287-301), i.e. at y mod p, which the bytes give without a square root: no field multiplication at all.  For bytes
+ *            that decode to no point the bit is 0 (all five weak y values decode).
+ *   pts_ext  n x 40 limbs of points the caller holds: marshalled on the GPU first, as has_small_order(&self) does, then both checks on
+ *            those bytes (is_canonical then speaks about the point's own marshal_binary).
+ * Callers: schnorr / eddsa verify_with_checks (the batch verification calls do these checks inside); DKG / VSS code checking received
+ * points before use. */
+int kyb_point_checks_batch(const uint8_t* enc, const int32_t* pts_ext, size_t n, uint8_t* flags);
+int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_t n, uint8_t* flags, void* stream);
+
 /* ---- introspection for benchmarks / tests ------------------------------------------------------ */
 /* kernel variant selection: key is e.g. "mul.select" / "mul_base.select"; returns
  * KYB_E_BAD_ARG for unknown keys or values.  Defaults are the fastest measured variants.
@@ -431,7 +451,9 @@ const char* kyb_kernel_name(int kernel_id);
  *   kyb_diag_wave_stamps(dev_buf): dev_buf = 5 x uint64 of device memory, zeroed by the caller; while set, every wavefront of
  *     k_mul_ladder / k_mul_base64 launched on the context's DEVICE adds (shader cycles, 100 MHz ticks) at its start into words 0, 1
  *     and at its end into words 2, 3, and counts itself in word 4: (w2 - w0) / (w3 - w1) x 100 MHz is the in-kernel clock.  NULL
- *     switches it off (the default: the kernels then execute one extra scalar load and branch at each end).  Waits for the device. */
+ *     switches it off (the default: the kernels then execute one extra scalar load and branch at each end).  Waits for the device.
+ *     The buffer must stay allocated until the call with NULL — or until the context that set it is released (kyb_ctx_destroy /
+ *     kyb_shutdown), which switches the stamps off by itself. */
 int kyb_diag_mad_peak(double min_ms, double* mads_per_s, double* clock_ghz, double* simd_cycles_per_mad, double* kernel_ms);
 int kyb_diag_wave_stamps(void* dev_buf);
 

@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "kyb_schnorr_sign_keyed_batch", "kyb_schnorr_sign_keyed_batch_dev", "kyb_eddsa_sign_keyed_batch", "kyb_eddsa_sign_keyed_batch_dev",
     "kyb_verify_batch", "kyb_verify_batch_dev", "kyb_verify_points_batch", "kyb_verify_points_batch_dev", "kyb_pubpoly_eval_batch", "kyb_pubpoly_eval_batch_dev",
     "kyb_pubpoly_eval_multi_batch", "kyb_pubpoly_eval_multi_batch_dev",
-    "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev", "kyb_lincomb_public_batch", "kyb_lincomb_public_batch_dev", "kyb_pripoly_eval_batch", "kyb_pripoly_eval_batch_dev", "kyb_lagrange_coeffs_batch", "kyb_lagrange_coeffs_batch_dev",
+    "kyb_equal_batch", "kyb_equal_batch_dev", "kyb_point_checks_batch", "kyb_point_checks_batch_dev", "kyb_lincomb_batch", "kyb_lincomb_batch_dev", "kyb_lincomb_public_batch", "kyb_lincomb_public_batch_dev", "kyb_pripoly_eval_batch", "kyb_pripoly_eval_batch_dev", "kyb_lagrange_coeffs_batch", "kyb_lagrange_coeffs_batch_dev",
     "kyb_sum_batch", "kyb_sum_batch_dev",
     "kyb_pubpoly_eval_multi_enc_batch", "kyb_pubpoly_eval_multi_enc_batch_dev", "kyb_sum_enc_batch", "kyb_sum_enc_batch_dev",
     "kyb_dkg_verify_round_enc", "kyb_dkg_verify_round_enc_dev",
@@ -147,6 +147,8 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_dkg_verify_round_enc_dev.argtypes = [vp, sz, sz, vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
     lib.kyb_equal_batch.argtypes = [vp, vp, sz, vp]
     lib.kyb_equal_batch_dev.argtypes = [vp, vp, sz, vp, vp]
+    lib.kyb_point_checks_batch.argtypes = [vp, vp, sz, vp]
+    lib.kyb_point_checks_batch_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.kyb_lincomb_batch.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp]
     lib.kyb_lincomb_batch_dev.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp, vp]
     lib.kyb_pripoly_eval_batch.argtypes = [vp, sz, sz, vp, sz, vp]
@@ -615,6 +617,21 @@ class Engine:
         _check(self.lib.kyb_equal_batch(_ptr(a), _ptr(b), a.shape[0], _ptr(eq)), "kyb_equal_batch")
         return eq
 
+    def point_checks(self, enc=None, pts_ext=None) -> np.ndarray:
+        """kyb_point_checks_batch: flags per point, bit 0 = is_canonical (the reference's expression), bit 1 = has_small_order (point.rs:286-337)"""
+        if (enc is None) == (pts_ext is None):
+            raise ValueError("give exactly one of enc / pts_ext")
+        if enc is not None:
+            a = np.ascontiguousarray(enc, dtype=np.uint8).reshape(-1, 32)
+            ext = None
+        else:
+            ext = np.ascontiguousarray(pts_ext, dtype=np.int32).reshape(-1, 40)
+            a = None
+        n = (a if a is not None else ext).shape[0]
+        flags = np.empty((n,), dtype=np.uint8)
+        _check(self.lib.kyb_point_checks_batch(_ptr(a) if a is not None else None, _ptr(ext) if ext is not None else None, n, _ptr(flags)), "kyb_point_checks_batch")
+        return flags
+
     def base_table(self) -> np.ndarray:
         t = np.empty(BASE_TABLE_BYTES, dtype=np.uint8)
         _check(self.lib.kyb_base_table_export(_ptr(t)), "kyb_base_table_export")
@@ -650,6 +667,10 @@ class Engine:
     def equal_dev(self, a_ext, b_ext, eq, stream: int = 0) -> None:
         n = a_ext.numel() // 40
         _check(self.lib.kyb_equal_batch_dev(self._dp(a_ext), self._dp(b_ext), n, self._dp(eq), ctypes.c_void_p(stream)), "kyb_equal_batch_dev")
+
+    def point_checks_dev(self, flags, enc=None, pts_ext=None, stream: int = 0) -> None:
+        n = enc.numel() // 32 if enc is not None else pts_ext.numel() // 40
+        _check(self.lib.kyb_point_checks_batch_dev(self._dp(enc), self._dp(pts_ext), n, self._dp(flags), ctypes.c_void_p(stream)), "kyb_point_checks_batch_dev")
 
     def encode_dev(self, pts_ext, out_enc, stream: int = 0) -> None:
         n = pts_ext.numel() // 40

@@ -117,6 +117,7 @@ struct Ctx {
   std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: the chunk unit is 1/this of the batch (plan_chunks)
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
+  bool stamps_on = false;                        // this context set the device's wave-stamp slots (kyb_diag_wave_stamps): cleared again when it is released
   std::atomic<int> opt_coop_share{1};             // divide the small-batch thresholds by the number of host-pointer calls in flight in this process (coop_lim)
   std::atomic<int> opt_zero_copy_kib{4096};         // host-pointer calls whose arrays fit this many KiB run their kernels on the context's page-locked buffer (no hipMemcpy); 512 in round 2, 4 MiB wins up to 16,384 items (profiles/r03/mid_size_host_calls.log)
   std::atomic<int> opt_ladder_pair_max{32768};    // ladder launches of at most this many items give each item two lanes (k_mul_ladder_pair: one wavefront per SIMD up to here); 0 = never
@@ -307,7 +308,11 @@ struct DoneScope {          // posts / withdraws the request around the launch s
 // (~7 GB/s); they go through the context's own page-locked bounce ring instead, filled by CopyPool threads while the GPU works.
 // One host-pointer call at a time per CONTEXT (g.mu); callers that want several in flight use several contexts.
 struct HostArr { const void* in; void* out; size_t bytes; bool secret = false; };    // per-item size; exactly one of in/out, or neither = absent;
-                                                                                     // secret: private keys / nonces / DH secrets — every copy the engine made is cleared before the call returns
+// secret: private keys / nonces / DH secrets (inputs) and shared secrets s*P (outputs of kyb_mul_batch).  Cleared before the call returns: the copies in
+// the context's page-locked zero-copy buffer, in the device staging buffer and in the bounce ring.  NOT cleared per call (overwritten by the next call on the
+// context, wiped when the context is released): the per-stream device scratch (projective staging records, decoded operands) and, for pageable callers
+// of >= 2^16-item calls, the page-locked landing area of the results — clearing 200 MB of host memory would double such a call; pass kyb_host_alloc
+// memory (no landing area) when that matters.  include/kyber_ed25519.h "secrets" says the same.
 template <class F> struct ScopeExit { F f; ~ScopeExit() { f(); } };
 template <class F> ScopeExit<F> on_scope_exit(F f) { return ScopeExit<F>{f}; }
 constexpr size_t PIPE_MIN_ITEMS = (size_t)1 << 16;
@@ -392,7 +397,7 @@ int run_host_batch_pipelined(Ctx& g, size_t n, const HostArr* arrs, int na, Fn l
     quiesce();
     bool any = false;
     for (int k = 0; k < na; ++k)
-      if (arrs[k].secret && arrs[k].in) { (void)hipMemsetAsync(g.stage + off[k], 0, arrs[k].bytes * n_pad, g.stream); any = true; }
+      if (arrs[k].secret && (arrs[k].in || arrs[k].out)) { (void)hipMemsetAsync(g.stage + off[k], 0, arrs[k].bytes * n_pad, g.stream); any = true; }
     if (any && !pinned && g.pin[0]) memset(g.pin[0], 0, 4 * RING_SLOT);
     if (any) (void)hipStreamSynchronize(g.stream);
   });
@@ -461,8 +466,10 @@ int run_host_batch_pipelined(Ctx& g, size_t n, const HostArr* arrs, int na, Fn l
 
 template <class Fn>
 int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
-  InflightScope in_flight(g);
+  // counted AFTER the context's mutex is taken: threads queued on one shared context are not calls in flight — one of them runs at a
+  // time, and counting the waiters routed a lone running call off the latency kernels
   std::lock_guard<std::mutex> lk(g.mu);
+  InflightScope in_flight(g);
   if (n >= PIPE_MIN_ITEMS) return run_host_batch_pipelined(g, n, arrs, na, launch);
   const size_t cap = (n + 1023) & ~(size_t)1023;
   size_t off[8], total = 0;
@@ -478,7 +485,7 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
     }
     // whatever way the call ends, the secret operands do not stay behind in the page-locked buffer (the kernels have finished by then:
     // every return below is behind a completed wait or a stream synchronisation)
-    auto wipe = on_scope_exit([&] { for (int k = 0; k < na; ++k) if (arrs[k].secret && arrs[k].in) memset(g.pin[0] + off[k], 0, arrs[k].bytes * n); });
+    auto wipe = on_scope_exit([&] { for (int k = 0; k < na; ++k) if (arrs[k].secret && (arrs[k].in || arrs[k].out)) memset(g.pin[0] + off[k], 0, arrs[k].bytes * n); });
     rc = ensure_done_flag(g);
     if (rc) return rc;
     {
@@ -500,7 +507,7 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
     bool any = false;
     (void)hipStreamSynchronize(g.stream);            // an error return may have left work in flight
     for (int k = 0; k < na; ++k)
-      if (arrs[k].secret && arrs[k].in) { (void)hipMemsetAsync(g.stage + off[k], 0, arrs[k].bytes * cap, g.stream); any = true; }
+      if (arrs[k].secret && (arrs[k].in || arrs[k].out)) { (void)hipMemsetAsync(g.stage + off[k], 0, arrs[k].bytes * cap, g.stream); any = true; }
     if (any) (void)hipStreamSynchronize(g.stream);
   });
   uint8_t* dptr[8];
@@ -567,8 +574,8 @@ class HostCall {
   template <class Body>
   int run(Body body) {
     Ctx& g = g_;
-    InflightScope in_flight(g);
     std::lock_guard<std::mutex> lk(g.mu);
+    InflightScope in_flight(g);                    // after the mutex: see run_host_batch
     if (total_ <= zero_copy_bytes(g)) {
       // small call: the kernels read and write the context's page-locked buffer directly over PCIe — no hipMemcpy at all
       // (each costs ~10 us of runtime work, more than the transfer), one launch sequence and one stream synchronisation
@@ -790,6 +797,12 @@ void ctx_release(Ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   c->copy.stop();
+  if (c->stamps_on) {      // the stamp buffer belongs to the caller and may be freed after this: no later launch on this device may write through it
+    (void)hipDeviceSynchronize();
+    (void)launch::diag_stamps_ladder(nullptr);
+    (void)launch::diag_stamps_base(nullptr);
+    c->stamps_on = false;
+  }
   for (StreamRes* r : c->res) free_slot(r);
   c->res.clear();
   wipe_free_dev(c->stage, c->stage_bytes);
@@ -1207,6 +1220,26 @@ int launch_encode(Ctx& g, const int32_t* pext, size_t n, uint8_t* oenc, hipStrea
   } else {
     LAUNCHCK(launch::encode(st, pext, n, oenc));
   }
+  return KYB_OK;
+}
+// PointCanCheckCanonicalAndSmallOrder for n points (point.rs:286-337): from received encodings (bytes only), or from the limbs of points the caller
+// holds — has_small_order(&self) marshals the point first (point.rs:287-290), so do we, into the stream's scratch
+int launch_point_checks(Ctx& g, const uint8_t* enc, const int32_t* pext, size_t n, uint8_t* flags, hipStream_t st) {
+  if (n == 0) return KYB_OK;
+  if (pext == nullptr) { LAUNCHCK(launch::point_checks(st, enc, n, flags)); return KYB_OK; }
+  std::lock_guard<std::mutex> launch_lock(g.launch_mu);
+  StreamRes* r = nullptr;
+  { int rc = res_for(g, st, &r); if (rc) return rc; }
+  SlotUse use(r, st);
+  { int rc = ensure_enc(g, r, 32 * n + 256); if (rc) return rc; }
+  if (n <= coop_lim(g, g.opt_coop_decode_max)) {
+    ProfScope ps(g, st, KID_FINISH_COOP);
+    LAUNCHCK(launch::finish_coop(st, nullptr, 0, pext, n, r->enc, nullptr, 1, launch::DoneFlag{}));      // not the call's last kernel: no completion flag
+  } else {
+    ProfScope ps(g, st, KID_ENCODE);
+    LAUNCHCK(launch::encode_batched(st, pext, n, r->enc));
+  }
+  LAUNCHCK(launch::point_checks(st, r->enc, n, flags));
   return KYB_OK;
 }
 // schnorr::sign for n (x, k, msg) triples.  pub_in != nullptr: the callers' stored public keys enc(x*B) are

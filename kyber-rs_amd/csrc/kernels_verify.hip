@@ -267,7 +267,26 @@ k_verify_fixup(const uint8_t* __restrict__ sigs, size_t n, const uint8_t* __rest
   signal_done(df);
 }
 
+// PointCanCheckCanonicalAndSmallOrder for n encodings (group.rs:71-78, point.rs:286-337), no multiplication: bit 0 = is_canonical(bytes) as the
+// reference evaluates it (pt_is_canonical_w), bit 1 = has_small_order() of the point the bytes decode to.  has_small_order compares the point's
+// canonical re-encoding, sign bit masked, with the five WEAK_KEYS, i.e. looks at y mod p only — which the bytes give without a square root; all five
+// y values do decode, so for bytes that decode to no point the bit is 0.
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_point_checks(const uint8_t* __restrict__ enc, size_t n, uint8_t* __restrict__ flags) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words8(w, enc, i);
+  fe y;
+  fe_from_words(y, w);                       // bit 255 ignored, y >= p accepted (fe_from_bytes); pt_has_small_order canonicalises
+  flags[i] = (uint8_t)(pt_is_canonical_w(w) | (pt_has_small_order(y) << 1));
+}
+
 namespace kyb { namespace launch {
+hipError_t point_checks(hipStream_t st, const uint8_t* enc, size_t n, uint8_t* flags) {
+  hipLaunchKernelGGL(k_point_checks, dim3((unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK)), dim3(KYB_BLOCK), 0, st, enc, n, flags);
+  return hipGetLastError();
+}
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK); }
 hipError_t verify_prep(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,
                        uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf, int32_t* a_ext) {

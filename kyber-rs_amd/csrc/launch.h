@@ -143,6 +143,8 @@ hipError_t pripoly_eval(hipStream_t st, const uint8_t* coeffs, size_t m, size_t 
 hipError_t lagrange_at_zero(hipStream_t st, const uint32_t* idx, size_t m, size_t t, uint8_t* out);      // out: m x t scalars, 32 bytes each
 hipError_t msm_accumulate(hipStream_t st, const uint8_t* scalars, const uint32_t* tab, size_t m, size_t t, int chunk, size_t nchunks, uint4* proj, size_t stride);
 
+// flags[i] = is_canonical(enc_i) | has_small_order(point of enc_i) << 1  (point.rs:286-337); bytes only, no field multiplication
+hipError_t point_checks(hipStream_t st, const uint8_t* enc, size_t n, uint8_t* flags);
 // benchmark diagnostic (kyb_diag_wave_stamps, diag_stamp.h): the five 64-bit sums into which the wavefronts of k_mul_ladder /
 // k_mul_base64 on the CURRENT device add their start / end (shader cycles, 100 MHz ticks); nullptr = off.  Synchronous.
 hipError_t diag_stamps_ladder(uint64_t* buf);

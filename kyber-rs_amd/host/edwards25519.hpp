@@ -20,6 +20,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/kyber_ed25519.h"
@@ -302,6 +303,16 @@ class Point {
     const uint16_t inner = (uint16_t)(1u - (uint16_t)b[0]);
     uint8_t d = (uint8_t)((uint16_t)(0xEDu - inner) >> 8);
     return 1 - (c & d & 1) == 1;
+  }
+
+  // both checks for many RECEIVED encodings in one engine call (kyb_point_checks_batch: bytes only, no curve arithmetic):
+  // first = is_canonical(bytes), second = has_small_order() of the point the bytes unmarshal to (false when they do not)
+  static std::vector<std::pair<bool, bool>> checks_batch(const std::vector<std::array<uint8_t, 32>>& encs) {
+    std::vector<uint8_t> flags(encs.size());
+    if (!encs.empty()) detail::engine_must(kyb_point_checks_batch(encs[0].data(), nullptr, encs.size(), flags.data()), "Point::checks_batch");
+    std::vector<std::pair<bool, bool>> r;
+    for (uint8_t f : flags) r.emplace_back((f & 1) != 0, (f & 2) != 0);
+    return r;
   }
 
   // ---- batch entry points for throughput callers (PriPoly::commit, poly.rs:195-206) ----

@@ -45,6 +45,7 @@ extern "C" {
     pub fn kyb_encode_batch(pts_ext: *const i32, n: size_t, out_enc: *mut u8) -> c_int;
     pub fn kyb_decode_batch(enc: *const u8, n: size_t, out_ext: *mut i32, ok: *mut u8) -> c_int;
     pub fn kyb_equal_batch(a_ext: *const i32, b_ext: *const i32, n: size_t, eq: *mut u8) -> c_int;
+    pub fn kyb_point_checks_batch(enc: *const u8, pts_ext: *const i32, n: size_t, flags: *mut u8) -> c_int;
     // signing / verification
     pub fn kyb_schnorr_sign_batch(x: *const u8, k: *const u8, msgs: *const u8, msg_off: *const u32, n: size_t, sig: *mut u8) -> c_int;
     pub fn kyb_schnorr_sign_keyed_batch(x: *const u8, pubs: *const u8, k: *const u8, msgs: *const u8, msg_off: *const u32, n: size_t, sig: *mut u8) -> c_int;

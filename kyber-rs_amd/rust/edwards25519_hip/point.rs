@@ -4,9 +4,11 @@
 //!   * curve arithmetic — `mul`, `eq`, `marshal_binary`, `unmarshal_binary`, the batch helpers — is FORWARDED to the engine
 //!     (include/kyber_ed25519.h) as batch-of-1 or batch-of-n calls on the 160-byte `ext` record, which is the reference's
 //!     own limb layout;
-//!   * everything that is host logic in the reference — the `embed` / `pick` rejection loop, `data`, `has_small_order`,
-//!     `is_canonical`, the three formatters — is DELEGATED to the reference's own CPU `Point` (`CpuPoint` below, reached through
-//!     the 32-byte encoding).  This module carries no second copy of it.
+//!   * the `embed` / `pick` rejection loop and `is_canonical(bytes)` are DELEGATED to the reference's own CPU `Point` (`CpuPoint`
+//!     below); `data`, the three formatters and `has_small_order` look at the 32 bytes the engine marshals (or ask the engine:
+//!     `kyb_point_checks_batch`) and never round-trip through `CpuPoint::unmarshal_binary` — limbs that are no curve point
+//!     (a `Point` that came out of serde, which derives `Deserialize` on raw limbs) then format and answer like any other
+//!     bytes instead of panicking.  This module carries no second copy of the reference's host logic.
 //! `add` / `sub` of a single pair call the reference's group-element formulas (`ge.rs`) on the same limbs: nine field
 //! multiplications are not worth a round trip to the GPU; vectors of pairs go to the engine (`add_batch`).
 //! Which reference method each one stands for: INTEGRATION.md §3.
@@ -102,13 +104,11 @@ impl Point {
         (ok != 0).then_some(out)
     }
 
-    /// This point as the reference's CPU type, through the wire encoding: how the host-only methods are delegated.
-    fn to_cpu(&self) -> CpuPoint {
-        let mut q = CpuPoint::default();
-        q.unmarshal_binary(&self.encoding()).expect("an encoding produced by the engine decodes");
-        q
+    /// lower-case hex of the 32 marshalled bytes (what the reference's formatters print)
+    fn hex(&self, upper: bool) -> String {
+        self.encoding().iter().map(|byte| if upper { format!("{byte:02X}") } else { format!("{byte:02x}") }).collect()
     }
-    /// ... and back
+    /// A point the reference's CPU type produced (`pick` / `embed`), brought over by its encoding
     fn from_cpu(q: &CpuPoint) -> Self {
         let bytes = q.marshal_binary().expect("marshal_binary of the CPU point");
         Self::from_limbs(Self::decode(&bytes).expect("an encoding produced by the reference decodes"))
@@ -190,6 +190,15 @@ impl Point {
             "add_batch",
         );
         staged.into_iter().map(Point::from_limbs).collect()
+    }
+
+    /// `is_canonical(bytes)` and `has_small_order()` of the decoded point for many RECEIVED encodings in one engine call
+    /// (bytes only, no curve arithmetic): what a DKG / VSS node asks of every point it is sent (point.rs:286-337)
+    pub fn checks_batch(encs: &[[u8; 32]]) -> Vec<(bool, bool)> {
+        ensure_init();
+        let mut flags = vec![0u8; encs.len()];
+        must(unsafe { ffi::kyb_point_checks_batch(encs.as_ptr() as *const u8, std::ptr::null(), encs.len(), flags.as_mut_ptr()) }, "point_checks_batch");
+        flags.into_iter().map(|f| (f & 1 != 0, f & 2 != 0)).collect()
     }
 
     /// a[i] == b[i] for many pairs without any inversion (Point::eq pays two per pair, point.rs:227-241)
@@ -338,7 +347,7 @@ impl group::Point for Point {
 
     /// delegated: the reference's rejection loop on its CPU point, the accepted point brought over by its encoding
     fn pick<S: Stream>(self, rand: &mut S) -> Self {
-        Self::from_cpu(&CpuPoint::default().pick(rand))
+        Point { ge: Self::from_cpu(&CpuPoint::default().pick(rand)).ge, ..self }
     }
 
     fn set(&mut self, p: &Self) -> Self {
@@ -352,12 +361,17 @@ impl group::Point for Point {
 
     /// delegated, as `pick`
     fn embed<S: Stream>(self, data: Option<&[u8]>, rand: &mut S) -> Self {
-        Self::from_cpu(&CpuPoint::default().embed(data, rand))
+        Point { ge: Self::from_cpu(&CpuPoint::default().embed(data, rand)).ge, ..self }
     }
 
-    /// delegated
+    /// the bytes `embed` placed behind the length byte of the encoding
     fn data(&self) -> Result<Vec<u8>, PointError> {
-        self.to_cpu().data()
+        let bytes = self.encoding();
+        let len = usize::from(bytes[0]);
+        if len > self.embed_len() {
+            return Err(PointError::EmbedDataLength);
+        }
+        Ok(bytes[1..=len].to_vec())
     }
 
     /// One pair: the reference's own formulas on the CPU (0.3 us; a batch-of-1 round trip to the GPU is 26 us).  Cargo feature
@@ -415,28 +429,35 @@ impl core::hash::Hash for Point {
     }
 }
 
-// formatting: delegated to the reference's own impls
+// formatting: the reference's three formatters print the marshalled bytes; so do these
 impl Display for Point {
     fn fmt(&self, f: &mut Formatter<'_>) -> core::fmt::Result {
-        Display::fmt(&self.to_cpu(), f)
+        write!(f, "Ed25519Point(0x{})", self.hex(false))
     }
 }
 impl LowerHex for Point {
     fn fmt(&self, f: &mut Formatter<'_>) -> core::fmt::Result {
-        LowerHex::fmt(&self.to_cpu(), f)
+        f.write_str(if f.alternate() { "0x" } else { "" })?;
+        f.write_str(&self.hex(false))
     }
 }
 impl UpperHex for Point {
     fn fmt(&self, f: &mut Formatter<'_>) -> core::fmt::Result {
-        UpperHex::fmt(&self.to_cpu(), f)
+        f.write_str(if f.alternate() { "0X" } else { "" })?;
+        f.write_str(&self.hex(true))
     }
 }
 
-// the two checks of verify_with_checks: delegated (the batch entry point `verify_batch` runs them on the GPU for whole batches)
+// the two checks of verify_with_checks (`verify_batch` runs them on the GPU for whole batches, `Point::checks_batch` for received bytes)
 impl PointCanCheckCanonicalAndSmallOrder for Point {
+    /// on the engine: marshals the limbs and compares with the weak keys (no `unmarshal`, hence total on any limbs)
     fn has_small_order(&self) -> bool {
-        self.to_cpu().has_small_order()
+        ensure_init();
+        let mut flags = 0u8;
+        must(unsafe { ffi::kyb_point_checks_batch(std::ptr::null(), self.ext(), 1, &mut flags) }, "point_checks");
+        flags & 2 != 0
     }
+    /// pure byte logic on the caller's buffer: delegated (no decoding involved)
     fn is_canonical(&self, b: &[u8]) -> bool {
         CpuPoint::default().is_canonical(b)
     }

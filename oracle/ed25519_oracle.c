@@ -760,6 +760,21 @@ static int pt_has_small_order(const ge_p3* P) {
   for (int i = 0; i < 5; i++) k |= (uint16_t)((uint16_t)c[i] - 1);
   return ((k >> 8) & 1) > 0;
 }
+/* PointCanCheckCanonicalAndSmallOrder (group.rs:71-78) on received bytes: bit 0 = is_canonical(b) (point.rs:315-337), bit 1 = has_small_order()
+ * of the point the bytes unmarshal to (point.rs:286-313, on its marshal_binary), bit 2 = the bytes unmarshal at all (point.rs:43-50) */
+int orc_point_checks(const uint8_t enc[32]) {
+  ensure(); weak_init();
+  ge_p3 P;
+  const int dec = p3_frombytes(&P, enc);
+  return pt_is_canonical(enc) | ((dec && pt_has_small_order(&P)) ? 2 : 0) | (dec ? 4 : 0);
+}
+/* the same on a point the caller holds: both checks on its own marshal_binary */
+int orc_point_checks_ext(const int32_t ext[40]) {
+  ensure(); weak_init();
+  ge_p3 P; ext_in(&P, ext);
+  uint8_t enc[32]; p3_tobytes(enc, &P);
+  return pt_is_canonical(enc) | (pt_has_small_order(&P) ? 2 : 0);
+}
 /* flavor 0: eddsa::verify_with_checks (eddsa_sig.rs:159-212); 1: schnorr::verify_with_checks (schnorr_sig.rs:53-110) */
 int orc_verify(int flavor, const uint8_t pub[32], const uint8_t* msg, size_t n, const uint8_t* sig, size_t sig_len) {
   ensure(); weak_init();

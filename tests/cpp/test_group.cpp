@@ -422,6 +422,23 @@ int main() {
     CHECK(err == "invalid Ed25519 curve point", "dh_exchange_batch rejects an invalid remote key");
   }
 
+  // the stand-alone checks on received encodings: one engine call == the per-point methods (point.rs:286-337)
+  {
+    std::vector<std::array<uint8_t, 32>> encs;
+    std::vector<Point> decoded;
+    for (const Point& p : points) { std::array<uint8_t, 32> e; auto b = p.marshal_binary(); std::memcpy(e.data(), b.data(), 32); encs.push_back(e); decoded.push_back(p); }
+    { std::array<uint8_t, 32> e{}; e[0] = 1; encs.push_back(e); decoded.push_back(Point().null()); }                      // the neutral element: small order
+    { std::array<uint8_t, 32> e; e.fill(0xff); e[0] = 0xec; e[31] = 0x7f; encs.push_back(e); Point q; q.unmarshal_binary(e.data(), 32); decoded.push_back(q); }   // y = p - 1: order 2, and "not canonical" by the reference's expression
+    auto flags = Point::checks_batch(encs);
+    CHECK(flags.size() == encs.size(), "checks_batch size");
+    bool saw_small = false, saw_noncanonical = false;
+    for (size_t i = 0; i < encs.size(); ++i) {
+      CHECK(flags[i].first == Point().is_canonical(encs[i].data(), 32), "checks_batch: is_canonical");
+      CHECK(flags[i].second == decoded[i].has_small_order(), "checks_batch: has_small_order");
+      saw_small |= flags[i].second; saw_noncanonical |= !flags[i].first;
+    }
+    CHECK(saw_small && saw_noncanonical, "checks_batch: both flags exercised");
+  }
   for (const Point& p : points) std::printf("POINT %s\n", p.hex().c_str());
   std::printf("S1 %s\nS2 %s\n", s1.hex().c_str(), s2.hex().c_str());
   std::printf(failures ? "FAILED %d\n" : "OK\n", failures);

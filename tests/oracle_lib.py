@@ -155,6 +155,15 @@ class Oracle:
         n = self.lib.orc_point_data(o, _p(_i32(ext)))
         return None if n < 0 else o.raw[:n]
 
+    def point_checks(self, enc: bytes) -> int:
+        """bit 0 is_canonical(bytes), bit 1 has_small_order of the decoded point, bit 2 decodes (point.rs:286-337)"""
+        self.lib.orc_point_checks.restype = ctypes.c_int
+        return int(self.lib.orc_point_checks(enc))
+
+    def point_checks_ext(self, ext) -> int:
+        self.lib.orc_point_checks_ext.restype = ctypes.c_int
+        return int(self.lib.orc_point_checks_ext(_p(_i32(ext))))
+
     # ---- batches (numpy) ----
     def mul_base_batch(self, scalars, nthreads: int = 1) -> np.ndarray:
         s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)

@@ -134,6 +134,49 @@ def test_decode_encode_add_sub(engine, oracle):
         assert rows(engine.encode(out)) == [oracle.encode(oracle.add(x, y, sub=sub)) for x, y in zip(a, b)]
 
 
+def test_point_checks_stand_alone(engine, oracle):
+    """kyb_point_checks_batch (PointCanCheckCanonicalAndSmallOrder, point.rs:286-337) == the oracle: from received bytes (WEAK_KEYS with either sign bit
+    and their non-canonical aliases, y = p-220 .. p+18 where the reference's is_canonical turns, undecodable bytes, random points and random bytes),
+    from limbs (projective representations, small-order and mixed-order points), device-pointer flavour, batch sizes on both sides of the
+    one-point-per-wavefront marshal"""
+    import torch
+    from test_oracle_golden import _point_check_inputs
+    encs = _point_check_inputs()
+    rng = np.random.default_rng(15)
+    encs += [rng.integers(0, 256, 32, dtype=np.uint8).tobytes() for _ in range(3000)]
+    want = np.array([oracle.point_checks(e) & 3 for e in encs], dtype=np.uint8)
+    arr = np.frombuffer(b"".join(encs), dtype=np.uint8).reshape(-1, 32)
+    got = engine.point_checks(enc=arr)
+    assert np.array_equal(got, want)
+    assert {0, 1, 2, 3} <= set(want.tolist())                       # every combination occurs: e.g. y = p (small order, not canonical)
+    assert np.array_equal(engine.point_checks(enc=arr[:1]), want[:1])
+    # limbs: decoded points, times a random Z (projective), plus sums with torsion points
+    exts = []
+    for e in encs[:700]:
+        x, ok = oracle.decode(e)
+        if ok:
+            exts.append(x)
+    weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
+    exts += [oracle.add(exts[10 + i], w) for i, w in enumerate(weak)]      # mixed order: not small
+    exts += [oracle.add(w, weak[(i + 2) % 5]) for i, w in enumerate(weak)]   # sums of torsion points: small
+    exts = np.stack(exts)
+    want_x = np.array([oracle.point_checks_ext(x) for x in exts], dtype=np.uint8)
+    assert np.array_equal(engine.point_checks(pts_ext=exts), want_x)
+    assert np.array_equal(engine.point_checks(pts_ext=exts[:3]), want_x[:3])
+    assert (want_x & 2).any() and not (want_x & 2).all()
+    d_enc = torch.from_numpy(arr.copy()).cuda()
+    d_ext = torch.from_numpy(exts.copy()).cuda()
+    f1 = torch.zeros(arr.shape[0], dtype=torch.uint8, device="cuda")
+    f2 = torch.zeros(exts.shape[0], dtype=torch.uint8, device="cuda")
+    engine.point_checks_dev(f1, enc=d_enc)
+    engine.point_checks_dev(f2, pts_ext=d_ext)
+    engine.sync()
+    assert np.array_equal(f1.cpu().numpy(), want) and np.array_equal(f2.cpu().numpy(), want_x)
+    flags = np.zeros(1, dtype=np.uint8)
+    assert engine.lib.kyb_point_checks_batch(None, None, 1, flags.ctypes.data) < 0                               # neither operand
+    assert engine.lib.kyb_point_checks_batch(arr.ctypes.data, exts.ctypes.data, 1, flags.ctypes.data) < 0      # both
+
+
 def test_sign_random_and_golden(engine, oracle):
     n = 300
     x, k = synth.scalars(n, 6, b"x"), synth.scalars(n, 6, b"k")

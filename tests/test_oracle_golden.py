@@ -212,6 +212,52 @@ def test_point_is_canonical_follows_the_reference_expression(oracle):
                         assert M.verify(flavor, pub, msg, enc + sig[32:]) == oracle.verify(flavor, pub, msg, enc + sig[32:])
 
 
+def _point_check_inputs():
+    """received encodings for the stand-alone checks: the WEAK_KEYS with and without the sign bit, their non-canonical aliases, y = p-220 .. p+18
+    (the reference's is_canonical turns at p-217), bytes that decode to no point, ordinary points"""
+    P = M.P
+    encs = []
+    for h in KATS["weak_keys"]:
+        w = bytes.fromhex(h)
+        encs += [w, w[:31] + bytes([w[31] | 0x80])]
+        y = int.from_bytes(w, "little") & ((1 << 255) - 1)
+        if y + P < (1 << 255):
+            encs += [(y + P).to_bytes(32, "little"), (y + P + (1 << 255)).to_bytes(32, "little")]     # y = 0 -> p, y = 1 -> p + 1: small order, not canonical
+    for y in range(P - 220, P + 19):
+        encs += [y.to_bytes(32, "little"), (y | (1 << 255)).to_bytes(32, "little")]
+    encs += [bytes.fromhex(h) for h in KATS["invalid_encodings"]]
+    rng = random.Random(5)
+    for _ in range(64):
+        encs.append(M.encode(M.point_mul(rng.randrange(1, M.L).to_bytes(32, "little"))))
+        encs.append(bytes(rng.randrange(256) for _ in range(32)))
+    return encs
+
+
+def test_point_checks_oracle_matches_the_model():
+    """orc_point_checks (what tests/test_gpu_parity.py holds kyb_point_checks_batch against) == the big-int model's point_is_canonical /
+    has_small_order / decode on every input class; and the property the engine's byte-only kernel relies on: the small-order bit depends on
+    y mod p alone, and every weak y decodes"""
+    import oracle_lib
+    orc = oracle_lib.Oracle()
+    weak_y = set()
+    for enc in _point_check_inputs():
+        f = orc.point_checks(enc)
+        pt = M.decode(enc)
+        assert bool(f & 4) == (pt is not None), enc.hex()
+        assert bool(f & 1) == M.point_is_canonical(enc) == _ref_is_canonical(enc), enc.hex()
+        assert bool(f & 2) == (pt is not None and M.has_small_order(pt)), enc.hex()
+        if f & 2:
+            weak_y.add(pt[1])
+        if pt is not None:
+            e, ok = orc.decode(enc)
+            assert ok and orc.point_checks_ext(e) == (f & 2) | int(M.point_is_canonical(orc.encode(e)))
+    assert len(weak_y) == 5
+    for y in weak_y:                                           # a byte string whose y mod p is weak always decodes
+        for alias in (y, y + M.P):
+            if alias < (1 << 255):
+                assert M.decode(alias.to_bytes(32, "little")) is not None
+
+
 def test_embed_and_pick_known_answers(oracle):
     """A13, point.rs:90-92 / 106-167 over replayed key streams: the accepted candidate (bytes), how many blocks the loop drew and
     Point::data of the result — C oracle and big-int model against the committed vectors; the rejected candidates fail for the

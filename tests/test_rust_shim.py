@@ -1,5 +1,5 @@
 """The Rust module (kyber-rs_amd/rust/edwards25519_hip/, source only: no toolchain in this image) is checked as text:
-* its extern "C" block declares only functions the header declares, with the same number of parameters;
+* its extern "C" block declares only functions the header declares, with the same parameter and return TYPES;
 * every `impl ... for Point` block of the reference exists for the module's Point with the same method names, and NO file of the module is a
   copy of a reference file (line overlap / difflib ratio below 0.30, no function body shared with its namesake) — tools/check_rust_shim.py,
   only where /root/reference is present (the build container);
@@ -13,22 +13,68 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "kyber-rs_amd", "rust", "edwards25519_hip")
 
 
+C_TO_RUST = {"uint8_t": "u8", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "size_t", "int": "c_int", "char": "c_char",
+             "void": "c_void", "double": "f64", "float": "f32", "kyb_ctx": "kyb_ctx", "kyb_group": "kyb_group"}
+
+
+def _c_type_to_rust(t: str) -> str:
+    """`const uint8_t*` -> `*const u8`, `kyb_ctx**` -> `*mut *mut kyb_ctx`, `size_t` -> `size_t` (pointer constness and width included)"""
+    t = t.strip()
+    stars = t.count("*")
+    base = t.replace("*", " ").split()
+    const = "const" in base
+    names = [w for w in base if w not in ("const", "struct", "unsigned")]
+    assert len(names) == 1, t
+    rust = C_TO_RUST[names[0]]
+    for level in range(stars):
+        rust = ("*const " if const and level == 0 else "*mut ") + rust      # `const T*`: the pointee of the innermost pointer is const
+    return rust
+
+
+def _c_param_type(p: str) -> str:
+    """the type of one C parameter declaration (`const uint8_t* scalars`, `void* stream`, `int`): drop a trailing identifier"""
+    p = re.sub(r"/\*.*?\*/", "", p).strip()
+    m = re.match(r"^(.*?[\s\*])(\w+)$", p)
+    if m and m.group(2) not in C_TO_RUST and m.group(2) != "const":
+        return m.group(1)
+    return p
+
+
 def test_ffi_block_matches_the_header():
+    """every function of the extern "C" block is declared in the header with the same parameter TYPES in the same order (pointer constness,
+    integer width and signedness, usize against u32 — an arity check alone lets such a slip in the never-compiled Rust through) and the same
+    return type"""
     hdr = open(os.path.join(ROOT, "include", "kyber_ed25519.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    decl = {m.group(1): len([a for a in m.group(2).split(",") if a.strip() and a.strip() != "void"])
-            for m in re.finditer(r"\b(kyb_\w+)\s*\(([^)]*)\)\s*;", hdr)}
+    decl = {}
+    for m in re.finditer(r"^\s*([\w\s\*]+?)\b(kyb_\w+)\s*\(([^)]*)\)\s*;", hdr, flags=re.M):
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3)
+        plist = [a for a in params.split(",") if a.strip() and a.strip() != "void"]
+        decl[name] = (None if ret == "void" else _c_type_to_rust(ret), [_c_type_to_rust(_c_param_type(a)) for a in plist])
     ffi = open(os.path.join(SHIM, "ffi.rs")).read()
     ffi = re.sub(r"//.*", "", ffi)
     block = ffi[ffi.index('extern "C" {'):]
     block = block[:block.index("\n}")]
-    fns = {m.group(1): len([a for a in m.group(2).split(",") if a.strip()]) for m in re.finditer(r"pub fn (kyb_\w+)\s*\(([^)]*)\)", block, flags=re.S)}
+    fns = {}
+    for m in re.finditer(r"pub fn (kyb_\w+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
+        params = [re.sub(r"\s+", " ", a.split(":", 1)[1]).strip() for a in m.group(2).split(",") if a.strip()]
+        fns[m.group(1)] = (None if m.group(3) is None else re.sub(r"\s+", " ", m.group(3)).strip(), params)
     assert len(fns) >= 30
-    for name, nargs in fns.items():
+    for name, (ret, params) in fns.items():
         assert name in decl, f"{name} is not declared in include/kyber_ed25519.h"
-        assert decl[name] == nargs, f"{name}: {nargs} parameters in ffi.rs, {decl[name]} in the header"
+        want_ret, want = decl[name]
+        assert len(want) == len(params), f"{name}: {len(params)} parameters in ffi.rs, {len(want)} in the header"
+        assert params == want, f"{name}: ffi.rs has {params}, the header says {want}"
+        assert ret == want_ret, f"{name}: ffi.rs returns {ret}, the header {want_ret}"
     version = int(re.search(r"#define KYB_ABI_VERSION (\d+)", hdr).group(1))
     assert f"KYB_ABI_VERSION: c_int = {version}" in ffi
+
+
+def test_the_type_comparison_catches_a_slip():
+    assert _c_type_to_rust("const uint8_t*") == "*const u8" and _c_type_to_rust("uint8_t*") == "*mut u8"
+    assert _c_type_to_rust("kyb_ctx**") == "*mut *mut kyb_ctx" and _c_type_to_rust("const kyb_group*") == "*const kyb_group"
+    assert _c_type_to_rust(_c_param_type("uint32_t index")) == "u32" and _c_type_to_rust(_c_param_type("size_t n")) == "size_t"
+    assert _c_type_to_rust(_c_param_type("void* stream")) == "*mut c_void" and _c_type_to_rust(_c_param_type("const int* devices")) == "*const c_int"
 
 
 def test_every_reference_impl_block_has_its_counterpart():
@@ -48,8 +94,12 @@ def test_the_module_defines_a_point_and_nothing_else():
     assert not re.search(r"\b(struct|enum)\s+(Curve|Suite)\w*", code) and "impl Group for" not in code
     patch = open(os.path.join(os.path.dirname(SHIM), "kyber-rs.hip-feature.patch")).read()
     assert 'pub use super::edwards25519_hip::Point;' in patch and '#[cfg(feature = "hip")]' in patch
-    # the host-only methods are delegated to the reference's CPU point, not restated
+    # the rejection loop and the byte-level canonical test are delegated to the reference's CPU point, not restated; has_small_order asks the engine;
+    # nothing unmarshals the engine's own encoding back into the CPU type (that panicked on limbs that are no curve point)
     point = open(os.path.join(SHIM, "point.rs")).read()
-    for method in ("embed(data, rand)", "pick(rand)", ".data()", ".has_small_order()", ".is_canonical(b)"):
+    for method in ("embed(data, rand)", "pick(rand)", ".is_canonical(b)", "kyb_point_checks_batch"):
         assert method in point, method
     assert "WEAK_KEYS" not in point and "xor_key_stream" not in point and "0xED" not in point
+    assert "fn to_cpu" not in point and ".unmarshal_binary(&self.encoding())" not in point
+    # pick / embed keep the receiver's var_time flag (point.rs:90-92, 106-167 take `self`)
+    assert point.count("..self }") >= 6
