@@ -10,8 +10,11 @@ A "step" = one pass of the hot path over one batch that is already resident in H
   sign      2^18 Schnorr signatures, 32-byte messages                   (configs[3])
   verify    2^20 Schnorr verifications with the reference's checks      
 
-N > 1 (BASELINE configs[4]; weak scaling: every GPU owns its own shard of N x ITEMS_PER_GPU independent items, no data-path
-collective; the only collective is the one-time broadcast of the base-point table image built on rank 0):
+N > 1 = BASELINE configs[4]: 2^24 variable-base scalar-mults sharded across the N GPUs — rank r owns items [floor(r 2^24 / N),
+floor((r + 1) 2^24 / N)), no data-path collective; the only collective is the one-time broadcast of the base-point table image built on
+rank 0 (RCCL over xGMI).  The total is fixed as N grows (`scaling: "strong"`); `--scaling weak` gives every GPU the single-GPU batch
+instead (2^20 items each).  EVERY rank checks a sample of its own shard against the oracle and the verdicts are gathered before rank 0
+prints: one failing rank fails the job.  `python bench.py --gpus 1 --n 16777216` is the same total on one GPU.
   --mode ranks (default, the mode `value` is quoted in): one process per GPU over torch.distributed / RCCL.  Started either by
       the driver's launcher (torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE in the environment) or plainly as
       `python bench.py --gpus N ...`: the parent then spawns the N rank processes itself BEFORE it makes any GPU call (it never
@@ -569,12 +572,37 @@ def host_pointer_rates(w, eng, orc, threads, calls=5):
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
-def common_line(args, wl, n, world, elapsed, eng):
-    return {"metric": METRIC[wl], "value": round(n * world * args.steps / elapsed, 1), "unit": UNIT[wl], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+CFG5_TOTAL = 1 << 24      # BASELINE.json configs[4]
+
+
+def shard_bounds(total, world, rank):
+    """rank r's slice [floor(r total / world), floor((r + 1) total / world)) of a job of `total` independent items"""
+    return rank * total // world, (rank + 1) * total // world
+
+
+def plan_items(args, wl, world, rank):
+    """-> (items of this rank, total items of the job, scaling, workload text).  N = 1: the single-GPU configuration (or --n).  N > 1: the
+    variable-base workloads run configs[4] — 2^24 items cut into `world` shards — unless --scaling weak or --n say otherwise."""
+    if args.n:
+        return args.n, args.n * world, "weak", f"{wl} x {args.n} per GPU"
+    text = WORKLOAD_TEXT[wl] + (", signers hold their public keys (one fixed-base mult per signature)" if wl == "sign" and args.keyed else "")
+    if world > 1 and wl in ("mul", "mul_enc") and args.scaling != "weak":
+        job = args.total or CFG5_TOTAL
+        lo, hi = shard_bounds(job, world, rank)
+        form = "reference-limb points in" if wl == "mul" else "32-byte wire encodings in (decoded on the GPU inside the step)"
+        size = "2^24" if job == CFG5_TOTAL else str(job)
+        return hi - lo, job, "strong", (f"{size} variable-base scalar-mults sharded across {world}xMI355X ({job // world} per GPU), random scalars+points, "
+                                        f"{form}, 32-byte encodings out, table image broadcast from rank 0 at init")
+    return DEFAULT_N[wl], DEFAULT_N[wl] * world, "weak", text
+
+
+def common_line(args, wl, n, world, elapsed, eng, total=None, scaling="weak", text=None):
+    total = n * world if total is None else total
+    return {"metric": METRIC[wl], "value": round(total * args.steps / elapsed, 1), "unit": UNIT[wl], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u32 limbs (radix 2^25.5), u64 accumulators", "data": "synthetic",
-            "config": {"workload": (WORKLOAD_TEXT[wl] + (", signers hold their public keys (one fixed-base mult per signature)" if wl == "sign" and args.keyed else "")) if not args.n else f"{wl} x {n} per GPU",
-                       "items_per_gpu": n, "mode": args.mode,
+            "config": {"workload": text if text is not None else plan_items(args, wl, world, 0)[3],
+                       "items_per_gpu": n, "total_items": total, "mode": args.mode,
                        "sharding": f"independent shards x{world}, no data-path collective; one table broadcast at init",
                        "options": {k_: eng.get_option(k_) for k_ in OPTION_KEYS} if eng is not None else None}}
 
@@ -622,7 +650,7 @@ def run_ranks(args):
         dist.all_gather_object(idents, ident)
 
     wl = args.workload
-    n = args.n or DEFAULT_N[wl]
+    n, total, scaling, text = plan_items(args, wl, world, rank)
     inp = Inputs(1 + rank, dev)          # every rank gets its own shard of the synthetic stream
 
     def barrier():
@@ -639,10 +667,42 @@ def run_ranks(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- parity: EVERY rank checks a sample of its own shard against the oracle; the verdicts are gathered before anything is printed ----
+    parity = {"rank": rank, "ok": True, "checked": 0, "error": None}
+    orc = None
+    # the GPU box gives one GPU a share of 16 host CPUs although os.cpu_count() reports the whole machine
+    threads = max(1, min(len(os.sched_getaffinity(0)), 16 * world) // world)
+    if args.standin:
+        parity["checked"] = min(args.check, n)           # the stand-in computes nothing: the plumbing of the verdict is what is exercised
+        if os.environ.get("KYB_BENCH_PARITY_FAIL_RANK") == str(rank):
+            parity.update(ok=False, error=f"rank {rank}: asked to report a parity failure (KYB_BENCH_PARITY_FAIL_RANK)")
+    else:
+        import oracle_lib
+        orc = oracle_lib.Oracle()
+        try:
+            parity["checked"] = check_parity(w, orc, args.check, threads, dev)
+        except SystemExit as e:
+            parity.update(ok=False, error=f"rank {rank}: {e}")
+    parities = [parity]
+    if world > 1:
+        parities = [None] * world
+        dist.all_gather_object(parities, parity)
+    failed = [p_ for p_ in parities if not p_["ok"]]
+    if failed:                                            # every rank leaves with a failure status; nothing that looks like a result is printed
+        if rank == 0:
+            print("PARITY FAILURE: " + "; ".join(p_["error"] for p_ in failed), file=sys.stderr, flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        raise SystemExit(3)
+
     if rank == 0:
         if len({d["table_sha256_16"] for d in idents}) != 1:
             raise SystemExit(f"TABLE MISMATCH: the ranks hold different base-point table images: {[d['table_sha256_16'] for d in idents]}")
-        line = common_line(args, wl, n, world, elapsed, eng)
+        line = common_line(args, wl, n, world, elapsed, eng, total, scaling, text)
+        line["parity_checked_items"] = sum(p_["checked"] for p_ in parities)
+        line["parity_checked_items_per_rank"] = [p_["checked"] for p_ in sorted(parities, key=lambda p_: p_["rank"])]
+        line["items_per_rank"] = [shard_bounds(total, world, r_)[1] - shard_bounds(total, world, r_)[0] for r_ in range(world)] if scaling == "strong" else [n] * world
         line.update({"input_gen_s": round(gen_s, 2), "ranks_seen": len(idents), "dist_backend": backend, "devices": idents,
                      "table_identical_on_all_ranks": len({d["table_sha256_16"] for d in idents}) == 1,
                      "launched_by": "self-spawned ranks" if os.environ.get("KYB_BENCH_SPAWNED") else ("external launcher" if world > 1 else "single process")})
@@ -650,17 +710,11 @@ def run_ranks(args):
             line.update({"metric": "STANDIN plumbing run (no GPU, no arithmetic): NOT a measurement", "data": "none (stand-in engine)", "roofline": None, "cpu_baseline": None,
                          "standin_calls": eng.calls})
         else:
-            import oracle_lib
-            orc = oracle_lib.Oracle()
-            # the GPU box gives one GPU a share of 16 host CPUs although os.cpu_count() reports the whole machine
-            threads = max(1, min(len(os.sched_getaffinity(0)), 16))
             cus = eng.device_info()["compute_units"]
-            checked = check_parity(w, orc, args.check, threads, dev)
             clock = kernel_clock(w, eng, rt)
             peak = eng.mad_peak(50.0)                     # the roofline's denominator, measured on this chip in this run (warm from the steps above)
             line["roofline"] = roofline(w, eng, args.steps, peak, clock, cus)
             line["cpu_baseline"] = cpu_baseline(w, orc, threads) if (world == 1 and not args.no_cpu_baseline) else None
-            line["parity_checked_items"] = checked
             # ---- the other single-GPU configurations, each in its own timed region outside the primary one ----
             if world == 1 and not args.only and not args.n:
                 if wl == "mul":
@@ -708,7 +762,9 @@ def run_group(args):
     wl = args.workload
     if wl not in ("mul", "mul_enc", "mul_base"):
         raise SystemExit("--mode group drives the scalar-multiplication workloads (mul, mul_enc, mul_base)")
-    n = args.n or DEFAULT_N[wl]
+    n, total, scaling, text = plan_items(args, wl, world, 0)
+    if scaling == "strong":                      # one shard size for every context of the group: floor(total / world) items each
+        total = n * world
     have = torch.cuda.device_count()
     if have < world:
         raise SystemExit(f"--gpus {world}: this host shows {have} GPU(s)")
@@ -783,7 +839,7 @@ def run_group(args):
         checked += len(idx)
     if len({d["table_sha256_16"] for d in idents}) != 1:
         raise SystemExit(f"TABLE MISMATCH: the group's contexts hold different base-point table images: {[d['table_sha256_16'] for d in idents]}")
-    line = common_line(args, wl, n, world, elapsed, engs[0])
+    line = common_line(args, wl, n, world, elapsed, engs[0], total, scaling, text)
     per_kernel = {}
     for name, ms in launches:
         per_kernel.setdefault(name, []).append(ms)
@@ -806,7 +862,10 @@ def main():
     ap.add_argument("--workload", default="mul", choices=["mul", "mul_enc", "mul_base", "sign", "verify"])
     ap.add_argument("--keyed", action="store_true", help="sign: the signers hold their public keys (EdDSA objects, DSS long-term keys): "
                     "one fixed-base mult per signature instead of the two of schnorr::sign")
-    ap.add_argument("--n", type=int, default=0, help="items per GPU (default 2^20, 2^18 for sign)")
+    ap.add_argument("--n", type=int, default=0, help="items per GPU (default: 2^20, 2^18 for sign; with N > 1 GPUs the variable-base workloads default to 2^24 / N)")
+    ap.add_argument("--total", type=int, default=0, help="N > 1: items of the whole sharded job (default 2^24 = BASELINE configs[4])")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak"], help="N > 1: auto = BASELINE configs[4], 2^24 items in all (strong scaling); "
+                    "weak = the single-GPU batch on every GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only", action="store_true", help="time the primary workload only (no `workloads` object)")
     ap.add_argument("--check", type=int, default=16384, help="items verified against the oracle after timing (per workload)")

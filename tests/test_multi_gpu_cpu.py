@@ -101,6 +101,54 @@ def test_bench_spawns_its_own_ranks_and_prints_one_line():
     assert abs(line["value"] - 2 * 4096 * 3 / (line["ms_per_step"] * 3e-3)) <= 1e-3 * line["value"]      # whole-job rate over the max-over-ranks time
 
 
+def _plain_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def test_bench_with_two_gpus_runs_the_sharded_configuration_and_every_rank_reports_parity():
+    """`python bench.py --gpus 2` without --n is BASELINE configs[4]: ONE job cut into shards [floor(r T / N), floor((r + 1) T / N)) — here
+    T = 10,001 instead of 2^24 so that the stand-in run stays short — `scaling: "strong"`, the workload named as sharded, `value` = T x steps
+    over the max-over-ranks time, and a parity count from EVERY rank in the line"""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--total", "10001", "--check", "64", "--standin"],
+                       capture_output=True, text=True, timeout=300, env=_plain_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["total_items"] == 10001 and line["items_per_rank"] == [5000, 5001] and line["config"]["items_per_gpu"] == 5000
+    assert "sharded across 2xMI355X" in line["config"]["workload"] and line["config"]["workload"].startswith("10001 variable-base")
+    assert line["parity_checked_items_per_rank"] == [64, 64] and line["parity_checked_items"] == 128
+    assert abs(line["value"] - 10001 * 2 / (line["ms_per_step"] * 2e-3)) <= 1e-3 * line["value"]
+    # the default total is 2^24 and the text says so (no run: 2^23 synthetic items per rank take a minute to generate)
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench
+    ns = argparse.Namespace(n=0, total=0, scaling="auto", keyed=False)
+    for world in (2, 4, 8, 3):
+        per = [bench.plan_items(ns, "mul", world, rk) for rk in range(world)]
+        assert sum(p[0] for p in per) == 1 << 24 and {p[1] for p in per} == {1 << 24} and {p[2] for p in per} == {"strong"}
+        assert per[0][3].startswith(f"2^24 variable-base scalar-mults sharded across {world}xMI355X")
+        assert max(p[0] for p in per) - min(p[0] for p in per) <= 1
+    assert bench.plan_items(ns, "mul", 1, 0)[:3] == (1 << 20, 1 << 20, "weak")                     # N = 1 stays configs[1]
+    assert bench.plan_items(argparse.Namespace(n=0, total=0, scaling="weak", keyed=False), "mul", 8, 3)[:3] == (1 << 20, 8 << 20, "weak")
+    assert bench.plan_items(ns, "sign", 8, 3)[:3] == (1 << 18, 8 << 18, "weak")                       # only the variable-base job is configs[4]
+
+
+def test_one_rank_reporting_a_parity_failure_fails_the_whole_job():
+    """rank 1's shard differs from the oracle (simulated): no JSON line, non-zero status from the parent, the failing rank named"""
+    import subprocess
+    env = _plain_env()
+    env["KYB_BENCH_PARITY_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--total", "600", "--standin"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert "PARITY FAILURE" in r.stderr and "rank 1" in r.stderr
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     import subprocess
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
