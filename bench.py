@@ -768,7 +768,9 @@ def run_group(args):
     have = torch.cuda.device_count()
     if have < world:
         raise SystemExit(f"--gpus {world}: this host shows {have} GPU(s)")
-    grp = kyber_rs_amd.Group(list(range(world)))
+    # distinct devices: the native RCCL broadcast is REQUIRED — on the first multi-GPU node a broken transport must be an error, not a quiet
+    # "host-copy" in the line (KYB_GROUP_REQUIRE_RCCL; --allow-host-copy lifts it)
+    grp = kyber_rs_amd.Group(list(range(world)), flags=0 if (world == 1 or args.allow_host_copy) else kyber_rs_amd.Group.REQUIRE_RCCL)
     engs = [grp.engine(r) for r in range(world)]
     for e in engs:
         for kv in args.opt:
@@ -843,7 +845,7 @@ def run_group(args):
     per_kernel = {}
     for name, ms in launches:
         per_kernel.setdefault(name, []).append(ms)
-    line.update({"input_gen_s": round(gen_s, 2), "ranks_seen": world, "dist_backend": None, "table_transport": grp.transport, "devices": idents,
+    line.update({"input_gen_s": round(gen_s, 2), "ranks_seen": world, "dist_backend": None, "table_transport": grp.transport, "table_transport_note": grp.transport_note or None, "devices": idents,
                  "table_identical_on_all_ranks": len({d["table_sha256_16"] for d in idents}) == 1,
                  "launched_by": "one process, kyb_group (one context and stream per GPU, launches queued by one thread)",
                  "rank0_kernels_ms_per_step": {k_: round(sum(v_) / args.steps, 4) for k_, v_ in per_kernel.items()},
@@ -863,6 +865,7 @@ def main():
     ap.add_argument("--keyed", action="store_true", help="sign: the signers hold their public keys (EdDSA objects, DSS long-term keys): "
                     "one fixed-base mult per signature instead of the two of schnorr::sign")
     ap.add_argument("--n", type=int, default=0, help="items per GPU (default: 2^20, 2^18 for sign; with N > 1 GPUs the variable-base workloads default to 2^24 / N)")
+    ap.add_argument("--allow-host-copy", action="store_true", help="--mode group: accept the host-copy fallback for the table image when RCCL is unavailable")
     ap.add_argument("--total", type=int, default=0, help="N > 1: items of the whole sharded job (default 2^24 = BASELINE configs[4])")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak"], help="N > 1: auto = BASELINE configs[4], 2^24 items in all (strong scaling); "
                     "weak = the single-GPU batch on every GPU")

@@ -68,6 +68,7 @@ extern "C" {
 #define KYB_E_NO_DEVICE (-3)
 #define KYB_E_HIP (-4)
 #define KYB_E_NOMEM (-5)
+#define KYB_E_TRANSPORT (-6)  /* kyb_group_create_ex(KYB_GROUP_REQUIRE_RCCL): the RCCL broadcast of the table image could not be done */
 
 /* table image exchanged between GPUs at init — the role of constants.rs:89 BASE (which holds the 32 even
  * radix-16 positions only); affine (y+x, y-x, 2dxy), canonical limbs:
@@ -127,6 +128,18 @@ int kyb_ctx_device(const kyb_ctx* ctx);
  * shards use kyb_group_ctx(g, r) + kyb_ctx_set_current and the kyb_*_dev calls from one thread per rank. */
 typedef struct kyb_group kyb_group;
 int kyb_group_create(const int* devices, int n, kyb_group** out);
+/* The same with flags.  A fallback to the host copy is a success, but never a silent one: kyb_group_table_transport_note (and
+ * kyb_last_error, until the next failure) say at which step the RCCL path stopped — library not loadable, a symbol missing,
+ * ncclCommInitAll / ncclBroadcast returning an error, a repeated device.
+ *   KYB_GROUP_REQUIRE_RCCL           no fallback: the call fails with KYB_E_TRANSPORT when the RCCL broadcast cannot be done (what a
+ *                                    multi-GPU node's bring-up wants: `bench.py --mode group` sets it when the devices are distinct)
+ *   KYB_GROUP_RCCL_EVEN_IF_REPEATED  attempt the RCCL transport although the list repeats a device.  Real RCCL refuses such a list; the flag
+ *                                    exists so that a one-GPU box can drive the library's RCCL call sequence against a stand-in librccl
+ *                                    (tests/test_gpu_rccl_stub.py). */
+#define KYB_GROUP_REQUIRE_RCCL 1u
+#define KYB_GROUP_RCCL_EVEN_IF_REPEATED 2u
+int kyb_group_create_ex(const int* devices, int n, unsigned flags, kyb_group** out);
+const char* kyb_group_table_transport_note(const kyb_group* g);
 void kyb_group_destroy(kyb_group* g);
 int kyb_group_size(const kyb_group* g);
 kyb_ctx* kyb_group_ctx(kyb_group* g, int rank);

@@ -24,13 +24,13 @@ BASE_TABLE_BYTES = 335232
 ABI_VERSION = 2
 
 KYB_OK = 0
-ERRORS = {-1: "KYB_E_NOT_INIT", -2: "KYB_E_BAD_ARG", -3: "KYB_E_NO_DEVICE", -4: "KYB_E_HIP", -5: "KYB_E_NOMEM"}
+ERRORS = {-1: "KYB_E_NOT_INIT", -2: "KYB_E_BAD_ARG", -3: "KYB_E_NO_DEVICE", -4: "KYB_E_HIP", -5: "KYB_E_NOMEM", -6: "KYB_E_TRANSPORT"}
 
 # every symbol include/kyber_ed25519.h declares (tests/test_abi_symbols.py checks header <-> library)
 ABI_SYMBOLS = [
     "kyb_abi_version", "kyb_init", "kyb_init_no_table", "kyb_shutdown", "kyb_last_error", "kyb_device_info", "kyb_sync", "kyb_stream_release",
     "kyb_ctx_create", "kyb_ctx_destroy", "kyb_ctx_set_current", "kyb_ctx_get_current", "kyb_ctx_device",
-    "kyb_group_create", "kyb_group_destroy", "kyb_group_size", "kyb_group_ctx", "kyb_group_table_transport",
+    "kyb_group_create", "kyb_group_create_ex", "kyb_group_table_transport_note", "kyb_group_destroy", "kyb_group_size", "kyb_group_ctx", "kyb_group_table_transport",
     "kyb_group_mul_base_batch", "kyb_group_mul_batch", "kyb_group_schnorr_sign_batch", "kyb_group_verify_batch",
     "kyb_base_table_export_dev", "kyb_base_table_import_dev", "kyb_base_table_export", "kyb_base_table_import",
     "kyb_group_mul_base_batch_dev", "kyb_group_mul_batch_dev", "kyb_group_sync",
@@ -89,6 +89,9 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_ctx_get_current.restype = vp
     lib.kyb_ctx_device.argtypes = [vp]
     lib.kyb_group_create.argtypes = [ctypes.POINTER(i32), i32, ctypes.POINTER(vp)]
+    lib.kyb_group_create_ex.argtypes = [ctypes.POINTER(i32), i32, ctypes.c_uint, ctypes.POINTER(vp)]
+    lib.kyb_group_table_transport_note.argtypes = [vp]
+    lib.kyb_group_table_transport_note.restype = ctypes.c_char_p
     lib.kyb_group_destroy.argtypes = [vp]
     lib.kyb_group_destroy.restype = None
     lib.kyb_group_size.argtypes = [vp]
@@ -169,7 +172,7 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_kernel_name.restype = ctypes.c_char_p
     for name in ABI_SYMBOLS:
         if name not in ("kyb_shutdown", "kyb_last_error", "kyb_kernel_name", "kyb_host_alloc", "kyb_host_free", "kyb_ctx_get_current",
-                        "kyb_group_destroy", "kyb_group_ctx", "kyb_group_table_transport"):
+                        "kyb_group_destroy", "kyb_group_ctx", "kyb_group_table_transport", "kyb_group_table_transport_note"):
             getattr(lib, name).restype = i32
     if lib.kyb_abi_version() != ABI_VERSION:
         raise KyberHipError(f"{LIB_PATH} implements ABI version {lib.kyb_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
@@ -699,14 +702,18 @@ class Group:
     table image moved with ncclBroadcast / a host copy and validated by checksum).  `devices` may repeat a device
     (several contexts on one GPU: how the single-GPU test box exercises the sharding)."""
 
-    def __init__(self, devices: Sequence[int]):
+    REQUIRE_RCCL = 1
+    RCCL_EVEN_IF_REPEATED = 2
+
+    def __init__(self, devices: Sequence[int], flags: int = 0):
         self.lib = load_library()
         arr = (ctypes.c_int * len(devices))(*devices)
         h = ctypes.c_void_p()
-        _check(self.lib.kyb_group_create(arr, len(devices), ctypes.byref(h)), "kyb_group_create")
+        _check(self.lib.kyb_group_create_ex(arr, len(devices), ctypes.c_uint(flags), ctypes.byref(h)), "kyb_group_create_ex")
         self.handle = h
         self.size = self.lib.kyb_group_size(h)
         self.transport = self.lib.kyb_group_table_transport(h).decode()
+        self.transport_note = self.lib.kyb_group_table_transport_note(h).decode()      # why RCCL was not used ("" when it was)
 
     def engine(self, rank: int) -> Engine:
         ctx = self.lib.kyb_group_ctx(self.handle, rank)
