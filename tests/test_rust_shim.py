@@ -24,8 +24,10 @@ def _c_type_to_rust(t: str) -> str:
     base = t.replace("*", " ").split()
     const = "const" in base
     names = [w for w in base if w not in ("const", "struct", "unsigned")]
+    if not names and "unsigned" in base:
+        names = ["unsigned"]
     assert len(names) == 1, t
-    rust = C_TO_RUST[names[0]]
+    rust = "c_uint" if names[0] == "unsigned" or (names[0] == "int" and "unsigned" in base) else C_TO_RUST[names[0]]
     for level in range(stars):
         rust = ("*const " if const and level == 0 else "*mut ") + rust      # `const T*`: the pointee of the innermost pointer is const
     return rust
@@ -35,7 +37,7 @@ def _c_param_type(p: str) -> str:
     """the type of one C parameter declaration (`const uint8_t* scalars`, `void* stream`, `int`): drop a trailing identifier"""
     p = re.sub(r"/\*.*?\*/", "", p).strip()
     m = re.match(r"^(.*?[\s\*])(\w+)$", p)
-    if m and m.group(2) not in C_TO_RUST and m.group(2) != "const":
+    if m and m.group(2) not in C_TO_RUST and m.group(2) not in ("const", "unsigned"):
         return m.group(1)
     return p
 
