@@ -375,6 +375,49 @@ int kyb_dkg_verify_round_enc_dev(const uint8_t* commits_enc, size_t t, size_t m,
 int kyb_equal_batch(const int32_t* a_ext, const int32_t* b_ext, size_t n, uint8_t* eq);
 int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, uint8_t* eq, void* stream);
 
+/* ---- deferred points: batches for callers that stay element-at-a-time (group.rs:85-140) -------------------------------------- */
+/* kyber-rs's protocol code calls Point::mul / add / sub / neg one element at a time and looks at the result later, when it marshals,
+ * compares or hashes it; a batch-of-1 engine call costs more than the CPU's own multiplication.  With these calls a binding hands the
+ * operations over WITHOUT asking for results: every call records a node in the calling context's arena and returns a handle (a 64-bit
+ * sequence number, never reused; 0 is no handle); nothing runs until bytes or limbs are asked for.  A flush evaluates the recorded
+ * graph with as few engine calls as it can (csrc/defer.inc):
+ *   - nodes whose operands are known go out grouped by operation, one batch call per group and dependency level
+ *     (PriPoly::commit, poly.rs:195-206: t independent multiplications = ONE kyb_mul_batch / kyb_mul_base_batch call);
+ *   - a Horner chain v = x v + c_j with one multiplier 1 <= x < 2^32 (PubPoly::eval, poly.rs:457-469: 2 t dependent calls) becomes ONE
+ *     kyb_pubpoly_eval_multi_batch call, shared by all chains of that length in the flush.  The chain's multiplier is thereby treated as
+ *     PUBLIC (it is a share index; a uniformly random secret has that shape with probability 2^-220);
+ *   - a chain of additions acc = acc + term_j (recover_commit, poly.rs:566-603; the sums of dkg.rs:905-953): the terms in one batch,
+ *     then ONE kyb_sum_batch call;
+ *   - when a flush is caused by a request for BYTES, everything it evaluates is marshalled by the same kernels (their shared
+ *     inversions) and cached: the marshal_binary calls that follow cost no engine call.
+ * Results: the same group elements, hence the same 32 bytes, as the eager calls; the limbs are one valid representation of the point
+ * (as everywhere in this ABI).  Option defer.fuse = 0 switches the chain recognition off (level-by-level batches only).
+ * Lifetime: the reference's Point is Copy, so copies of a handle may live anywhere and nodes are not reference-counted.  Evaluated nodes
+ * stay in the arena until kyb_defer_floor(mark) drops everything recorded before `mark` (= an earlier kyb_defer_mark(); e.g. at the end
+ * of a protocol round) or until more than defer.max_nodes (default 2^20, about 250 bytes each) exist, when the oldest are dropped; a
+ * dropped handle is refused with KYB_E_BAD_ARG ("stale handle"), never answered wrongly.  Secret scalars are kept until their node is
+ * evaluated and cleared then (and when a node is dropped).  The arena belongs to the context: use it from the threads that use the context.
+ *   kyb_defer_input   a point the caller holds (40 limbs) as a leaf          kyb_defer_null / _base   the neutral element / B
+ *   kyb_defer_mul_base / _mul / _add (subtract != 0: a - b) / _neg            Point::mul(s, None) / mul(s, Some(p)) / add / sub / neg
+ *   kyb_defer_get(p, out_ext, out_enc)   evaluates p — and everything else recorded so far: who asks for one result will ask for the others —
+ *                                        and returns its limbs and / or marshal_binary; either pointer may be NULL
+ *   kyb_defer_equal(a, b, eq)            Point::eq;   kyb_defer_flush()   evaluates everything recorded
+ *   kyb_defer_stats(out, cap)            nodes recorded, flushes, engine calls made by flushes, Horner chains fused, sums fused,
+ *                                        marshal cache hits, nodes held now, nodes dropped by defer.max_nodes (for tests and benchmarks) */
+int kyb_defer_input(const int32_t* ext, uint64_t* out);
+int kyb_defer_null(uint64_t* out);
+int kyb_defer_base(uint64_t* out);
+int kyb_defer_mul_base(const uint8_t* scalar, uint64_t* out);
+int kyb_defer_mul(const uint8_t* scalar, uint64_t p, uint64_t* out);
+int kyb_defer_add(uint64_t a, uint64_t b, int subtract, uint64_t* out);
+int kyb_defer_neg(uint64_t a, uint64_t* out);
+int kyb_defer_get(uint64_t p, int32_t* out_ext, uint8_t* out_enc);
+int kyb_defer_equal(uint64_t a, uint64_t b, uint8_t* eq);
+int kyb_defer_flush(void);
+uint64_t kyb_defer_mark(void);
+int kyb_defer_floor(uint64_t mark);
+int kyb_defer_stats(uint64_t* out, int cap);
+
 /* ---- PointCanCheckCanonicalAndSmallOrder, group.rs:71-78, point.rs:286-337 ---- */
 /* flags[i]: bit 0 = is_canonical(b) — the reference's own expression (point.rs:315-337), which also answers "not canonical" for the 217
  * canonical values y = p-217 .. p-1 (DESIGN.md "Parity definition"); bit 1 = has_small_order().  Exactly one of

@@ -45,6 +45,8 @@ ABI_SYMBOLS = [
     "kyb_sum_batch", "kyb_sum_batch_dev",
     "kyb_pubpoly_eval_multi_enc_batch", "kyb_pubpoly_eval_multi_enc_batch_dev", "kyb_sum_enc_batch", "kyb_sum_enc_batch_dev",
     "kyb_dkg_verify_round_enc", "kyb_dkg_verify_round_enc_dev",
+    "kyb_defer_input", "kyb_defer_null", "kyb_defer_base", "kyb_defer_mul_base", "kyb_defer_mul", "kyb_defer_add", "kyb_defer_neg", "kyb_defer_get", "kyb_defer_equal",
+    "kyb_defer_flush", "kyb_defer_mark", "kyb_defer_floor", "kyb_defer_stats",
     "kyb_host_alloc", "kyb_host_free",
     "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
     "kyb_diag_mad_peak", "kyb_diag_wave_stamps",
@@ -64,10 +66,13 @@ def load_library() -> ctypes.CDLL:
     if _lib is not None:
         return _lib
     try:
-        # torch bundles its own libamdhip64.so.7 / libhsa-runtime64; whichever HIP runtime is loaded
+        # torch bundles its own libamdhip64.so.7 / libhsa-runtime64 (and librccl); whichever HIP runtime is loaded
         # first owns the GPU for the process, so when torch is going to share device memory with the
         # engine (tests, bench.py) it has to be imported before our library resolves its DT_NEEDED.
-        import torch  # noqa: F401
+        # KYB_NO_TORCH=1: a process that uses host pointers only and wants the system's ROCm libraries
+        # (tests/test_gpu_rccl_stub.py puts a stand-in librccl in front of them).
+        if not os.environ.get("KYB_NO_TORCH"):
+            import torch  # noqa: F401
     except ImportError:
         pass
     if not os.path.exists(LIB_PATH):
@@ -150,6 +155,21 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_dkg_verify_round_enc_dev.argtypes = [vp, sz, sz, vp, ctypes.c_uint32, vp, vp, vp, vp, vp, vp]
     lib.kyb_equal_batch.argtypes = [vp, vp, sz, vp]
     lib.kyb_equal_batch_dev.argtypes = [vp, vp, sz, vp, vp]
+    u64, pu64 = ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)
+    lib.kyb_defer_input.argtypes = [vp, pu64]
+    lib.kyb_defer_null.argtypes = [pu64]
+    lib.kyb_defer_base.argtypes = [pu64]
+    lib.kyb_defer_mul_base.argtypes = [vp, pu64]
+    lib.kyb_defer_mul.argtypes = [vp, u64, pu64]
+    lib.kyb_defer_add.argtypes = [u64, u64, i32, pu64]
+    lib.kyb_defer_neg.argtypes = [u64, pu64]
+    lib.kyb_defer_get.argtypes = [u64, vp, vp]
+    lib.kyb_defer_equal.argtypes = [u64, u64, vp]
+    lib.kyb_defer_flush.argtypes = []
+    lib.kyb_defer_mark.argtypes = []
+    lib.kyb_defer_mark.restype = u64
+    lib.kyb_defer_floor.argtypes = [u64]
+    lib.kyb_defer_stats.argtypes = [pu64, i32]
     lib.kyb_point_checks_batch.argtypes = [vp, vp, sz, vp]
     lib.kyb_point_checks_batch_dev.argtypes = [vp, vp, sz, vp, vp]
     lib.kyb_lincomb_batch.argtypes = [vp, vp, vp, i32, sz, sz, vp, vp, vp]
@@ -172,7 +192,7 @@ def load_library() -> ctypes.CDLL:
     lib.kyb_kernel_name.restype = ctypes.c_char_p
     for name in ABI_SYMBOLS:
         if name not in ("kyb_shutdown", "kyb_last_error", "kyb_kernel_name", "kyb_host_alloc", "kyb_host_free", "kyb_ctx_get_current",
-                        "kyb_group_destroy", "kyb_group_ctx", "kyb_group_table_transport", "kyb_group_table_transport_note"):
+                        "kyb_group_destroy", "kyb_group_ctx", "kyb_group_table_transport", "kyb_group_table_transport_note", "kyb_defer_mark"):
             getattr(lib, name).restype = i32
     if lib.kyb_abi_version() != ABI_VERSION:
         raise KyberHipError(f"{LIB_PATH} implements ABI version {lib.kyb_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
@@ -619,6 +639,65 @@ class Engine:
         eq = np.empty((a.shape[0],), dtype=np.uint8)
         _check(self.lib.kyb_equal_batch(_ptr(a), _ptr(b), a.shape[0], _ptr(eq)), "kyb_equal_batch")
         return eq
+
+    # ---- deferred points (kyb_defer_*): handles are plain ints ----
+    def _defer(self, fn, *args) -> int:
+        h = ctypes.c_uint64(0)
+        _check(fn(*args, ctypes.byref(h)), "kyb_defer_*")
+        return int(h.value)
+
+    def defer_input(self, ext) -> int:
+        e = np.ascontiguousarray(ext, dtype=np.int32).reshape(40)
+        return self._defer(self.lib.kyb_defer_input, _ptr(e))
+
+    def defer_null(self) -> int:
+        return self._defer(self.lib.kyb_defer_null)
+
+    def defer_base(self) -> int:
+        return self._defer(self.lib.kyb_defer_base)
+
+    def defer_mul_base(self, scalar: bytes) -> int:
+        return self._defer(self.lib.kyb_defer_mul_base, ctypes.c_char_p(bytes(scalar)))
+
+    def defer_mul(self, scalar: bytes, p: int) -> int:
+        return self._defer(self.lib.kyb_defer_mul, ctypes.c_char_p(bytes(scalar)), p)
+
+    def defer_add(self, a: int, b: int, subtract: bool = False) -> int:
+        return self._defer(self.lib.kyb_defer_add, a, b, int(subtract))
+
+    def defer_neg(self, a: int) -> int:
+        return self._defer(self.lib.kyb_defer_neg, a)
+
+    def defer_get(self, p: int, want_ext: bool = False):
+        """marshal_binary of a deferred point (and its limbs with want_ext): evaluates what it depends on"""
+        enc = np.empty(32, dtype=np.uint8)
+        ext = np.empty(40, dtype=np.int32) if want_ext else None
+        _check(self.lib.kyb_defer_get(p, _ptr(ext) if want_ext else None, _ptr(enc)), "kyb_defer_get")
+        return (enc.tobytes(), ext) if want_ext else enc.tobytes()
+
+    def defer_get_ext(self, p: int) -> np.ndarray:
+        ext = np.empty(40, dtype=np.int32)
+        _check(self.lib.kyb_defer_get(p, _ptr(ext), None), "kyb_defer_get")
+        return ext
+
+    def defer_equal(self, a: int, b: int) -> bool:
+        eq = np.zeros(1, dtype=np.uint8)
+        _check(self.lib.kyb_defer_equal(a, b, _ptr(eq)), "kyb_defer_equal")
+        return bool(eq[0])
+
+    def defer_flush(self) -> None:
+        _check(self.lib.kyb_defer_flush(), "kyb_defer_flush")
+
+    def defer_mark(self) -> int:
+        return int(self.lib.kyb_defer_mark())
+
+    def defer_floor(self, mark: int) -> None:
+        _check(self.lib.kyb_defer_floor(mark), "kyb_defer_floor")
+
+    def defer_stats(self) -> dict:
+        v = (ctypes.c_uint64 * 8)()
+        _check(self.lib.kyb_defer_stats(v, 8), "kyb_defer_stats")
+        return dict(zip(("nodes", "flushes", "engine_calls", "horner_fused", "sums_fused", "marshal_cache_hits", "nodes_held", "nodes_dropped"), (int(x) for x in v)))
 
     def point_checks(self, enc=None, pts_ext=None) -> np.ndarray:
         """kyb_point_checks_batch: flags per point, bit 0 = is_canonical (the reference's expression), bit 1 = has_small_order (point.rs:286-337)"""

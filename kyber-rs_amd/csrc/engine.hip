@@ -21,11 +21,16 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <type_traits>
+#include <unordered_map>
+#include <unordered_set>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/kyber_ed25519.h"
@@ -35,6 +40,9 @@
 #include "host_copy_pool.h"
 
 using namespace kyb;
+
+struct DeferArena;                          // deferred points of a context (defer.inc)
+void defer_release(DeferArena* a);
 
 namespace {
 
@@ -118,6 +126,9 @@ struct Ctx {
   std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: the chunk unit is 1/this of the batch (plan_chunks)
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
+  DeferArena* defer = nullptr;                   // recorded, not yet evaluated point operations of this context's callers (kyb_defer_*; made on first use)
+  std::atomic<int> opt_defer_fuse{1};            // flushes recognise Horner chains and chains of additions (defer.inc)
+  std::atomic<int> opt_defer_max_nodes{1 << 20}; // evaluated nodes kept for late readers of a handle before the oldest are dropped
   bool stamps_on = false;                        // this context set the device's wave-stamp slots (kyb_diag_wave_stamps): cleared again when it is released
   std::atomic<int> opt_coop_share{1};             // divide the small-batch thresholds by the number of host-pointer calls in flight in this process (coop_lim)
   std::atomic<int> opt_zero_copy_kib{4096};         // host-pointer calls whose arrays fit this many KiB run their kernels on the context's page-locked buffer (no hipMemcpy); 512 in round 2, 4 MiB wins up to 16,384 items (profiles/r03/mid_size_host_calls.log)
@@ -804,6 +815,7 @@ void ctx_release(Ctx* c) {
     (void)launch::diag_stamps_base(nullptr);
     c->stamps_on = false;
   }
+  if (c->defer) { defer_release(c->defer); c->defer = nullptr; }
   for (StreamRes* r : c->res) free_slot(r);
   c->res.clear();
   wipe_free_dev(c->stage, c->stage_bytes);
@@ -1599,3 +1611,4 @@ int launch_dkg_round(Ctx& g, const uint8_t* commits_enc, size_t t, size_t m, con
 
 #include "c_abi.inc"
 #include "engine_group.inc"
+#include "defer.inc"

@@ -9,6 +9,12 @@
 //   Curve::new_key_and_seed_with_input  curve.rs:74-87
 // Every Point operation that does curve arithmetic is a batch-of-1 call into the GPU engine (the
 // trait is per-element and synchronous); throughput callers use the *_batch statics.
+// With set_deferred(true) (per thread) the same methods RECORD their operation in the engine's arena
+// instead (kyb_defer_*, include/kyber_ed25519.h "deferred points") and a Point holds a handle until
+// somebody needs its bytes or limbs — marshal_binary, ==, data, hex, the batch helpers — which is
+// when the engine evaluates the recorded graph in batches (one call for the t multiplications of
+// PriPoly::commit, one for the whole Horner chain of PubPoly::eval, ...).  Protocol code written
+// against the trait, call by call, runs unchanged in either mode and yields the same bytes.
 // Scalar arithmetic stays on the host (microseconds) and shares sc25519.h with
 // the device sign kernel.  `mul`/`add`/... are infallible in the reference: an engine failure aborts.
 #pragma once
@@ -48,6 +54,7 @@ namespace group {
 namespace edwards25519 {
 
 namespace detail {
+inline bool& deferred_flag() { static thread_local bool on = false; return on; }
 inline void engine_must(int rc, const char* what) {
   if (rc != KYB_OK) {  // the trait has no error channel (group.rs:139): abort like a Rust panic
     std::fprintf(stderr, "kyber-ed25519-hip: %s failed (%d): %s\n", what, rc, kyb_last_error());
@@ -59,6 +66,10 @@ inline void bytes(uint8_t b[32], const uint32_t w[8]) { std::memcpy(b, w, 32); }
 static const uint8_t L_BYTES[32] = {0xed, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14,
                                     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x10};
 }  // namespace detail
+
+// deferred evaluation of this thread's Point operations (off by default): see the header of this file
+inline void set_deferred(bool on) { detail::deferred_flag() = on; }
+inline bool deferred() { return detail::deferred_flag(); }
 
 // ------------------------------------------------------------------------------------------ Scalar
 class Scalar {
@@ -178,18 +189,35 @@ class Scalar {
 // ------------------------------------------------------------------------------------------- Point
 class Point {
  public:
-  int32_t ge[40];        // X Y Z T, reference limb layout (ExtendedGroupElement, ge.rs:78-83)
+  // X Y Z T, reference limb layout (ExtendedGroupElement, ge.rs:78-83).  Valid when have_ge; a point recorded in the engine's arena
+  // and not asked for yet has have_ge == false and only its handle.  Read the limbs through limbs(), which fetches them when needed.
+  mutable int32_t ge[40];
   bool var_time = false; // point.rs:26 (never set; kept for layout parity)
+  mutable uint64_t pend = 0;     // handle in the engine's arena (kyb_defer_*), 0 = none
+  mutable bool have_ge = true;
 
   Point() { std::memset(ge, 0, sizeof(ge)); }
 
-  Point null() { std::memset(ge, 0, sizeof(ge)); ge[10] = 1; ge[20] = 1; return *this; }        // point.rs:79-82
+  // the limbs, evaluated now if the point is still only recorded
+  const int32_t* limbs() const {
+    if (!have_ge) { detail::engine_must(kyb_defer_get(pend, ge, nullptr), "Point: evaluation of a deferred point"); have_ge = true; }
+    return ge;
+  }
+  // this point as an operand of a recorded operation: its handle, or a leaf made of its limbs
+  uint64_t handle() const {
+    if (pend == 0) detail::engine_must(kyb_defer_input(ge, &pend), "Point: kyb_defer_input");
+    return pend;
+  }
+
+  Point null() { std::memset(ge, 0, sizeof(ge)); ge[10] = 1; ge[20] = 1; have_ge = true; pend = 0; return *this; }        // point.rs:79-82
   Point base() {                                                                               // point.rs:85-88
+    if (deferred()) { have_ge = false; detail::engine_must(kyb_defer_base(&pend), "Point::base"); return *this; }
     uint8_t one[32] = {1};
     detail::engine_must(kyb_mul_base_batch(one, 1, nullptr, ge), "Point::base");
+    have_ge = true; pend = 0;
     return *this;
   }
-  Point set(const Point& p) { std::memcpy(ge, p.ge, sizeof(ge)); return *this; }                // point.rs:94-97
+  Point set(const Point& p) { std::memcpy(ge, p.ge, sizeof(ge)); pend = p.pend; have_ge = p.have_ge; return *this; }                // point.rs:94-97
   size_t embed_len() const { return (255 - 8 - 8) / 8; }                                        // point.rs:99-104
   Point pick(Stream& rand) { return embed(nullptr, 0, rand); }                                  // point.rs:90-92
 
@@ -202,6 +230,7 @@ class Point {
       rand.xor_key_stream(b, z, 32);
       if (data != nullptr) { b[0] = (uint8_t)dl; std::memcpy(b + 1, data, dl); }
       uint8_t ok = 0;
+      have_ge = true; pend = 0;                                // the rejection loop needs every answer at once: eager calls in either mode
       detail::engine_must(kyb_decode_batch(b, 1, ge, &ok), "Point::embed decode");
       if (!ok) continue;
       if (data == nullptr) {
@@ -225,33 +254,39 @@ class Point {
     if (dl > embed_len()) throw PointError("invalid embedded data length");
     return std::vector<uint8_t>(b.begin() + 1, b.begin() + 1 + dl);
   }
-  Point add(const Point& a, const Point& b) {                                                  // point.rs:179-188
-    int32_t out[40];
-    detail::engine_must(kyb_add_batch(a.ge, b.ge, 1, out, 0), "Point::add");
-    std::memcpy(ge, out, sizeof(ge));
-    return *this;
-  }
-  Point sub(const Point& a, const Point& b) {                                                  // point.rs:190-199
-    int32_t out[40];
-    detail::engine_must(kyb_add_batch(a.ge, b.ge, 1, out, 1), "Point::sub");
-    std::memcpy(ge, out, sizeof(ge));
-    return *this;
-  }
+  Point add(const Point& a, const Point& b) { return add_sub(a, b, 0); }                       // point.rs:179-188
+  Point sub(const Point& a, const Point& b) { return add_sub(a, b, 1); }                       // point.rs:190-199
   Point neg(const Point& a) {                                                                  // point.rs:201-204, ge.rs:86-91... neg X and T
-    for (int i = 0; i < 10; ++i) { ge[i] = -a.ge[i]; ge[10 + i] = a.ge[10 + i]; ge[20 + i] = a.ge[20 + i]; ge[30 + i] = -a.ge[30 + i]; }
+    if (deferred()) { uint64_t h = 0; detail::engine_must(kyb_defer_neg(a.handle(), &h), "Point::neg"); pend = h; have_ge = false; return *this; }
+    const int32_t* l = a.limbs();
+    int32_t out[40];
+    for (int i = 0; i < 10; ++i) { out[i] = -l[i]; out[10 + i] = l[10 + i]; out[20 + i] = l[20 + i]; out[30 + i] = -l[30 + i]; }
+    std::memcpy(ge, out, sizeof(ge)); have_ge = true; pend = 0;
     return *this;
   }
   // point.rs:207-224: p == nullptr -> fixed base (ge_scalar_mult_base), else variable base
   Point mul(const Scalar& s, const Point* p) {
+    if (deferred()) {
+      uint64_t h = 0;
+      if (p == nullptr) detail::engine_must(kyb_defer_mul_base(s.v.data(), &h), "Point::mul (base)");
+      else detail::engine_must(kyb_defer_mul(s.v.data(), p->handle(), &h), "Point::mul");
+      pend = h; have_ge = false;
+      return *this;
+    }
     int32_t out[40];
     if (p == nullptr) detail::engine_must(kyb_mul_base_batch(s.v.data(), 1, nullptr, out), "Point::mul (base)");
-    else detail::engine_must(kyb_mul_batch(s.v.data(), nullptr, p->ge, 1, nullptr, out, nullptr), "Point::mul");
-    std::memcpy(ge, out, sizeof(ge));
+    else detail::engine_must(kyb_mul_batch(s.v.data(), nullptr, p->limbs(), 1, nullptr, out, nullptr), "Point::mul");
+    std::memcpy(ge, out, sizeof(ge)); have_ge = true; pend = 0;
     return *this;
   }
   // Marshaling, point.rs:35-60
   std::vector<uint8_t> marshal_binary() const {
     std::vector<uint8_t> b(32);
+    if (pend != 0) {                       // recorded (or registered as an operand): the arena evaluates what it depends on and caches the bytes
+      detail::engine_must(kyb_defer_get(pend, have_ge ? nullptr : ge, b.data()), "Point::marshal_binary");
+      have_ge = true;
+      return b;
+    }
     detail::engine_must(kyb_encode_batch(ge, 1, b.data()), "Point::marshal_binary");
     return b;
   }
@@ -260,12 +295,13 @@ class Point {
     int32_t out[40];
     if (n == 32) detail::engine_must(kyb_decode_batch(data, 1, out, &ok), "Point::unmarshal_binary");
     if (n != 32 || !ok) throw MarshallingError("invalid Ed25519 curve point");
-    std::memcpy(ge, out, sizeof(ge));
+    std::memcpy(ge, out, sizeof(ge)); have_ge = true; pend = 0;
   }
   size_t marshal_size() const { return 32; }
   // point.rs:227-241 compares the two encodings (two field inversions); the engine compares projectively, same answer
   bool operator==(const Point& o) const {
     uint8_t eq = 0;
+    if (!have_ge || !o.have_ge) { detail::engine_must(kyb_defer_equal(handle(), o.handle(), &eq), "Point::eq"); return eq != 0; }
     detail::engine_must(kyb_equal_batch(ge, o.ge, 1, &eq), "Point::eq");
     return eq != 0;
   }
@@ -323,7 +359,7 @@ class Point {
     for (size_t i = 0; i < n; ++i) std::memcpy(&sc[32 * i], s[i].v.data(), 32);
     if (pts) {
       if (pts->size() != n) throw std::invalid_argument("mul_batch: size mismatch");
-      for (size_t i = 0; i < n; ++i) std::memcpy(&in[40 * i], (*pts)[i].ge, 160);
+      for (size_t i = 0; i < n; ++i) std::memcpy(&in[40 * i], (*pts)[i].limbs(), 160);
       detail::engine_must(kyb_mul_batch(sc.data(), nullptr, in.data(), n, nullptr, out.data(), nullptr), "Point::mul_batch");
     } else {
       detail::engine_must(kyb_mul_base_batch(sc.data(), n, nullptr, out.data()), "Point::mul_batch (base)");
@@ -334,6 +370,13 @@ class Point {
   }
 
  private:
+  Point add_sub(const Point& a, const Point& b, int subtract) {
+    if (deferred()) { uint64_t h = 0; detail::engine_must(kyb_defer_add(a.handle(), b.handle(), subtract, &h), "Point::add"); pend = h; have_ge = false; return *this; }
+    int32_t out[40];
+    detail::engine_must(kyb_add_batch(a.limbs(), b.limbs(), 1, out, subtract), subtract ? "Point::sub" : "Point::add");
+    std::memcpy(ge, out, sizeof(ge)); have_ge = true; pend = 0;
+    return *this;
+  }
   static bool is_identity_encoding(const uint8_t e[32]) {
     if (e[0] != 1) return false;
     for (int i = 1; i < 32; ++i) if (e[i]) return false;

@@ -38,7 +38,7 @@ class PubPoly {
 
   std::vector<PubShare> eval_many(const std::vector<uint32_t>& idx) const {
     std::vector<int32_t> c(40 * commits.size()), out(40 * idx.size());
-    for (size_t j = 0; j < commits.size(); ++j) std::memcpy(&c[40 * j], commits[j].ge, 160);
+    for (size_t j = 0; j < commits.size(); ++j) std::memcpy(&c[40 * j], commits[j].limbs(), 160);
     group::edwards25519::detail::engine_must(
         kyb_pubpoly_eval_batch(c.data(), commits.size(), idx.data(), idx.size(), nullptr, out.data()), "PubPoly::eval");
     std::vector<PubShare> r(idx.size());
@@ -61,7 +61,7 @@ class PubPoly {
     if (threshold() != q.threshold()) throw PolyError("different number of coefficients");
     const size_t t = commits.size();
     std::vector<int32_t> a(40 * t), c(40 * t), out(40 * t);
-    for (size_t j = 0; j < t; ++j) { std::memcpy(&a[40 * j], commits[j].ge, 160); std::memcpy(&c[40 * j], q.commits[j].ge, 160); }
+    for (size_t j = 0; j < t; ++j) { std::memcpy(&a[40 * j], commits[j].limbs(), 160); std::memcpy(&c[40 * j], q.commits[j].limbs(), 160); }
     group::edwards25519::detail::engine_must(kyb_add_batch(a.data(), c.data(), t, out.data(), 0), "PubPoly::add");
     PubPoly r;
     r.b = b;
@@ -75,7 +75,7 @@ class PubPoly {
     if (q.commits.size() < t) throw std::out_of_range("PubPoly::equal: q has fewer commitments");   // the reference indexes q.commits[i] and panics
     std::vector<int32_t> a(40 * t), c(40 * t);
     std::vector<uint8_t> eq(t);
-    for (size_t j = 0; j < t; ++j) { std::memcpy(&a[40 * j], commits[j].ge, 160); std::memcpy(&c[40 * j], q.commits[j].ge, 160); }
+    for (size_t j = 0; j < t; ++j) { std::memcpy(&a[40 * j], commits[j].limbs(), 160); std::memcpy(&c[40 * j], q.commits[j].limbs(), 160); }
     group::edwards25519::detail::engine_must(kyb_equal_batch(a.data(), c.data(), t, eq.data()), "PubPoly::equal");
     bool all = true;
     for (uint8_t e : eq) all &= e != 0;
@@ -124,7 +124,7 @@ class PriPoly {
     if (base) {
       p.b = *base;
       static const Point generator = Point().base();
-      if (std::memcmp(base->ge, generator.ge, sizeof(generator.ge)) == 0) {
+      if (std::memcmp(base->limbs(), generator.limbs(), sizeof(generator.ge)) == 0) {
         p.commits = Point::mul_batch(coeffs, nullptr);
         return p;
       }
@@ -147,7 +147,7 @@ inline std::vector<PubShare> eval_each(const std::vector<PubPoly>& polys, const 
   std::vector<int32_t> c(40 * t * m), out(40 * m);
   for (size_t g = 0; g < m; ++g) {
     if (polys[g].threshold() != t) throw PolyError("different number of coefficients");
-    for (size_t j = 0; j < t; ++j) std::memcpy(&c[40 * (g * t + j)], polys[g].commits[j].ge, 160);
+    for (size_t j = 0; j < t; ++j) std::memcpy(&c[40 * (g * t + j)], polys[g].commits[j].limbs(), 160);
   }
   group::edwards25519::detail::engine_must(kyb_pubpoly_eval_multi_batch(c.data(), t, m, idx.data(), 1, nullptr, out.data()), "eval_each");
   std::vector<PubShare> r(m);
@@ -163,7 +163,7 @@ inline PubPoly sum_polys(const std::vector<PubPoly>& polys) {
   std::vector<int32_t> c(40 * t * n), out(40 * t);
   for (size_t d = 0; d < n; ++d) {
     if (polys[d].threshold() != t) throw PolyError("different number of coefficients");
-    for (size_t j = 0; j < t; ++j) std::memcpy(&c[40 * (j * n + d)], polys[d].commits[j].ge, 160);     // coefficient-major
+    for (size_t j = 0; j < t; ++j) std::memcpy(&c[40 * (j * n + d)], polys[d].commits[j].limbs(), 160);     // coefficient-major
   }
   group::edwards25519::detail::engine_must(kyb_sum_batch(c.data(), t, n, nullptr, out.data()), "sum_polys");
   PubPoly r;
@@ -255,7 +255,7 @@ inline std::vector<Point> lincomb(const std::vector<Scalar>& sc, const std::vect
   std::vector<uint8_t> s(32 * m * t);
   std::vector<int32_t> p(40 * pts.size()), out(40 * m);
   for (size_t i = 0; i < m * t; ++i) std::memcpy(&s[32 * i], sc[i].v.data(), 32);
-  for (size_t i = 0; i < pts.size(); ++i) std::memcpy(&p[40 * i], pts[i].ge, 160);
+  for (size_t i = 0; i < pts.size(); ++i) std::memcpy(&p[40 * i], pts[i].limbs(), 160);
   const auto fn = scalars_public ? kyb_lincomb_public_batch : kyb_lincomb_batch;
   group::edwards25519::detail::engine_must(fn(s.data(), nullptr, p.data(), shared ? 1 : 0, m, t, nullptr, out.data(), nullptr), what);
   std::vector<Point> r(m);

@@ -43,7 +43,7 @@ inline int verify_point_one(const group::edwards25519::Point& pub, const uint8_t
   if (sig_len != 64) return 1;
   uint32_t off[2] = {0, (uint32_t)n};
   uint8_t st = 0, dummy = 0;
-  group::edwards25519::detail::engine_must(kyb_verify_points_batch(pub.ge, n ? msg : &dummy, off, sig, 1, flavor, &st), "verify");
+  group::edwards25519::detail::engine_must(kyb_verify_points_batch(pub.limbs(), n ? msg : &dummy, off, sig, 1, flavor, &st), "verify");
   return st;
 }
 inline int verify_one(const uint8_t pub[32], const uint8_t* msg, size_t n, const uint8_t* sig, size_t sig_len, int flavor) {
@@ -84,7 +84,7 @@ inline std::vector<uint8_t> verify_batch(const std::vector<Point>& pubs, const s
   std::vector<uint8_t> blob(1), sg(64 * n), st(n, 1);
   std::vector<uint32_t> off(n + 1, 0);
   for (size_t i = 0; i < n; ++i) {
-    std::memcpy(&px[40 * i], pubs[i].ge, 160);
+    std::memcpy(&px[40 * i], pubs[i].limbs(), 160);
     blob.insert(blob.end() - 1, msgs[i].begin(), msgs[i].end());
     off[i + 1] = (uint32_t)(blob.size() - 1);
     if (sigs[i].size() == 64) std::memcpy(&sg[64 * i], sigs[i].data(), 64);

@@ -16,7 +16,7 @@ struct ncclComm { int rank, ndev, device; };     // RCCL's ncclComm_t is a point
 typedef ncclComm StubComm;
 
 extern "C" {
-static FILE* logf() {
+static FILE* stub_log() {
   static FILE* f = nullptr;
   if (!f) { const char* p = getenv("KYB_RCCL_STUB_LOG"); f = p ? fopen(p, "a") : stderr; if (!f) f = stderr; }
   return f;
@@ -26,27 +26,27 @@ static std::vector<Pending> g_pending;
 static int g_depth = 0;
 
 ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
-  fprintf(logf(), "ncclCommInitAll ndev=%d devlist=", ndev);
-  for (int i = 0; i < ndev; ++i) fprintf(logf(), "%s%d", i ? "," : "", devlist ? devlist[i] : i);
-  fprintf(logf(), "\n"); fflush(logf());
+  fprintf(stub_log(), "ncclCommInitAll ndev=%d devlist=", ndev);
+  for (int i = 0; i < ndev; ++i) fprintf(stub_log(), "%s%d", i ? "," : "", devlist ? devlist[i] : i);
+  fprintf(stub_log(), "\n"); fflush(stub_log());
   const char* fail = getenv("KYB_RCCL_STUB_FAIL_INIT");
   if (fail) return (ncclResult_t)atoi(fail);
   for (int i = 0; i < ndev; ++i) comms[i] = new StubComm{i, ndev, devlist ? devlist[i] : i};
   return ncclSuccess;
 }
-ncclResult_t ncclGroupStart() { ++g_depth; fprintf(logf(), "ncclGroupStart\n"); fflush(logf()); return ncclSuccess; }
+ncclResult_t ncclGroupStart() { ++g_depth; fprintf(stub_log(), "ncclGroupStart\n"); fflush(stub_log()); return ncclSuccess; }
 ncclResult_t ncclBroadcast(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, int root, ncclComm_t comm, hipStream_t stream) {
   int dev = -1;
   (void)hipGetDevice(&dev);
-  fprintf(logf(), "ncclBroadcast rank=%d count=%zu dtype=%d root=%d in_place=%d in_group=%d current_device=%d comm_device=%d stream_null=%d\n", comm ? comm->rank : -1, count,
+  fprintf(stub_log(), "ncclBroadcast rank=%d count=%zu dtype=%d root=%d in_place=%d in_group=%d current_device=%d comm_device=%d stream_null=%d\n", comm ? comm->rank : -1, count,
           (int)datatype, root, sendbuff == recvbuff, g_depth > 0, dev, comm ? comm->device : -1, stream == nullptr);
-  fflush(logf());
+  fflush(stub_log());
   g_pending.push_back(Pending{sendbuff, recvbuff, count, (int)datatype, root, comm, stream});
   return ncclSuccess;
 }
 ncclResult_t ncclGroupEnd() {
   --g_depth;
-  fprintf(logf(), "ncclGroupEnd pending=%zu\n", g_pending.size()); fflush(logf());
+  fprintf(stub_log(), "ncclGroupEnd pending=%zu\n", g_pending.size()); fflush(stub_log());
   const void* src = nullptr;
   for (const Pending& p : g_pending) if (p.comm->rank == p.root) src = p.send;
   int rc = src ? 0 : 5;
@@ -59,7 +59,7 @@ ncclResult_t ncclGroupEnd() {
   return (ncclResult_t)rc;
 }
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
-  fprintf(logf(), "ncclCommDestroy rank=%d\n", comm ? comm->rank : -1); fflush(logf());
+  fprintf(stub_log(), "ncclCommDestroy rank=%d\n", comm ? comm->rank : -1); fflush(stub_log());
   delete comm;
   return ncclSuccess;
 }

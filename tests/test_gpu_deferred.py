@@ -1,0 +1,187 @@
+"""Deferred points (kyb_defer_*, csrc/defer.inc): element-at-a-time callers hand their operations over without asking for results, a flush
+evaluates the recorded graph in batches.  Every test records the calls the reference's own loops make, asks for bytes the way the
+reference does (marshal_binary / eq), and compares with the oracle; the statistics of the arena show that the batching really happened."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _le(x: int) -> bytes:
+    return int(x).to_bytes(32, "little")
+
+
+@pytest.fixture()
+def eng():
+    """an engine context of its own: the arena's statistics then belong to this test"""
+    import kyber_rs_amd
+    e = kyber_rs_amd.Engine(0, private=True)
+    yield e
+    e.close()
+
+
+def _delta(eng, before):
+    after = eng.defer_stats()
+    return {k: after[k] - before[k] for k in after}
+
+
+def test_commit_is_one_batch_and_its_marshals_are_cache_hits(eng, oracle):
+    """PriPoly::commit (poly.rs:195-206): t times mul(coeff_j, Some(base)) — recorded one by one, evaluated by ONE call when the first commitment
+    is marshalled (session_id hashes all of them, vss.rs:303-307), the other marshals cost nothing"""
+    t = 43
+    coeffs = synth.scalars(t, 41)
+    base = eng.defer_base()
+    before = eng.defer_stats()
+    commits = [eng.defer_mul(coeffs[j].tobytes(), base) for j in range(t)]
+    assert _delta(eng, before)["engine_calls"] == 0                      # nothing has run
+    encs = [eng.defer_get(c) for c in commits]
+    d = _delta(eng, before)
+    assert d["flushes"] == 1 and d["engine_calls"] <= 2 and d["marshal_cache_hits"] == t      # (base point once per arena) + one batched multiplication
+    want = oracle.mul_base_batch(coeffs)
+    assert encs == [bytes(w) for w in want]
+    # the same through the fixed-base node, and limbs on request
+    again = [eng.defer_mul_base(coeffs[j].tobytes()) for j in range(t)]
+    eng.defer_flush()
+    assert [oracle.encode(eng.defer_get_ext(h)) for h in again] == encs
+
+
+def test_pubpoly_eval_chain_is_one_fused_call(eng, oracle):
+    """PubPoly::eval (poly.rs:457-469): v = null; for j = t-1 .. 0: v = mul(xi, Some(v)); v = add(v, commits[j]) — 2 t dependent calls in the
+    reference, one kyb_pubpoly_eval_multi_batch call here; commitments with small-order components included; several verifiers' chains of the
+    same length share the call; defer.fuse = 0 gives the same bytes level by level"""
+    t = 43
+    commits_ext = oracle.mul_base_ext_batch(synth.scalars(t, 42))
+    weak = oracle.decode(bytes.fromhex("c7176a703d4dd84fba3c0b760d10670f2a2053fa2c39ccc64ec7fd7792ac037a"))[0]      # a point of order 8
+    commits_ext[3] = oracle.add(commits_ext[3], weak)
+    cs = [eng.defer_input(c) for c in commits_ext]
+
+    def record_eval(i):
+        v = eng.defer_null()
+        xi = _le(1 + i)
+        for j in reversed(range(t)):
+            v = eng.defer_mul(xi, v)
+            v = eng.defer_add(v, cs[j])
+        return v
+
+    before = eng.defer_stats()
+    v = record_eval(6)
+    got = eng.defer_get(v)
+    d = _delta(eng, before)
+    assert got == oracle.pubpoly_eval(commits_ext, 6)
+    assert d["horner_fused"] == 1 and d["engine_calls"] == 1 and d["flushes"] == 1
+    # n verifiers' evaluations recorded before anybody looks: still one call
+    before = eng.defer_stats()
+    vs = [record_eval(i) for i in (0, 1, 63, 511, 65535, 2**32 - 2)]
+    eng.defer_flush()
+    d = _delta(eng, before)
+    assert d["horner_fused"] == 6 and d["engine_calls"] == 1
+    assert [eng.defer_get(h) for h in vs] == [oracle.pubpoly_eval(commits_ext, i) for i in (0, 1, 63, 511, 65535, 2**32 - 2)]
+    # an inner node of a fused chain is still a point of its own: asking for it evaluates it (its own, shorter chain)
+    v = eng.defer_null()
+    inner = None
+    for j in reversed(range(t)):
+        v = eng.defer_mul(_le(5), v)
+        v = eng.defer_add(v, cs[j])
+        if j == 10:
+            inner = v
+    assert eng.defer_get(v) == oracle.pubpoly_eval(commits_ext, 4)
+    assert eng.defer_get(inner) == oracle.pubpoly_eval(commits_ext[10:], 4)
+    # a multiplier that is no share index (here: a full-size scalar) is not fused and still right
+    big = synth.scalars(1, 43)[0].tobytes()
+    v = eng.defer_null()
+    for j in reversed(range(4)):
+        v = eng.defer_mul(big, v)
+        v = eng.defer_add(v, cs[j])
+    before = eng.defer_stats()
+    got = eng.defer_get(v)
+    assert _delta(eng, before)["horner_fused"] == 0
+    acc = oracle.null()
+    for j in reversed(range(4)):
+        acc = oracle.add(oracle.mul_ext(big, acc), commits_ext[j])
+    assert got == oracle.encode(acc)
+    # fusion off: level by level, same bytes
+    eng.set_option("defer.fuse", 0)
+    try:
+        before = eng.defer_stats()
+        v = record_eval(6)
+        assert eng.defer_get(v) == oracle.pubpoly_eval(commits_ext, 6)
+        d = _delta(eng, before)
+        assert d["horner_fused"] == 0 and d["engine_calls"] >= 2 * t - 1
+    finally:
+        eng.set_option("defer.fuse", 1)
+
+
+def test_recover_commit_chain_is_one_batch_and_one_sum(eng, oracle):
+    """recover_commit (poly.rs:566-603): acc = null; for every share: tmp = mul(num / den, Some(share)); acc = add(acc, tmp) — the t
+    multiplications in one call, the additions in one kyb_sum_batch call"""
+    t = 20
+    lam = synth.scalars(t, 44)
+    shares = oracle.mul_base_ext_batch(synth.scalars(t, 45))
+    hs = [eng.defer_input(s) for s in shares]
+    before = eng.defer_stats()
+    acc = eng.defer_null()
+    for i in range(t):
+        tmp = eng.defer_mul(lam[i].tobytes(), hs[i])
+        acc = eng.defer_add(acc, tmp)
+    got = eng.defer_get(acc)
+    d = _delta(eng, before)
+    assert got == oracle.lincomb(lam, shares)
+    assert d["sums_fused"] == 1 and d["engine_calls"] == 2
+
+
+def test_random_graphs_match_the_eager_calls(eng, oracle):
+    """random expression graphs over every operation, evaluated through random get / equal / flush requests, against the oracle's eager evaluation;
+    a small arena makes old handles stale, and a stale handle is an error, never a wrong answer"""
+    import kyber_rs_amd
+    rng = np.random.default_rng(46)
+    pts = oracle.mul_base_ext_batch(synth.scalars(6, 47))
+    pts = np.concatenate([pts, oracle.decode(bytes.fromhex("26e8958fc2b227b045c3f489f2ef98f0d5dfac05d3c63339b13802886d53fc05"))[0][None]])      # order 8
+    for trial in range(6):
+        nodes = []          # (handle, oracle limbs)
+        for p in pts:
+            nodes.append((eng.defer_input(p), p))
+        nodes.append((eng.defer_null(), oracle.null()))
+        nodes.append((eng.defer_base(), oracle.base()))
+        for step in range(120):
+            op = rng.integers(0, 6)
+            a = nodes[rng.integers(0, len(nodes))]
+            b = nodes[rng.integers(0, len(nodes))]
+            sc = [synth.scalars(1, 1000 * trial + step)[0].tobytes(), _le(int(rng.integers(0, 9))), synth.raw256(1, 1000 * trial + step)[0].tobytes()][rng.integers(0, 3)]
+            if op == 0:
+                nodes.append((eng.defer_mul_base(sc), oracle.mul_base_ext(sc)))
+            elif op == 1:
+                nodes.append((eng.defer_mul(sc, a[0]), oracle.mul_ext(sc, a[1])))
+            elif op == 2:
+                nodes.append((eng.defer_add(a[0], b[0]), oracle.add(a[1], b[1])))
+            elif op == 3:
+                nodes.append((eng.defer_add(a[0], b[0], subtract=True), oracle.add(a[1], b[1], sub=True)))
+            elif op == 4:
+                nodes.append((eng.defer_neg(a[0]), oracle.neg(a[1])))
+            else:
+                k = rng.integers(0, 3)
+                if k == 0:
+                    assert eng.defer_get(a[0]) == oracle.encode(a[1])
+                elif k == 1:
+                    assert eng.defer_equal(a[0], b[0]) == (oracle.encode(a[1]) == oracle.encode(b[1]))
+                else:
+                    eng.defer_flush()
+        for h, want in nodes:
+            enc, ext = eng.defer_get(h, want_ext=True)
+            assert enc == oracle.encode(want) and oracle.encode(ext) == enc
+    # stale handles
+    eng.set_option("defer.max_nodes", 64)
+    try:
+        first = eng.defer_mul_base(_le(5))
+        for i in range(200):
+            eng.defer_mul_base(_le(i))
+        with pytest.raises(kyber_rs_amd.KyberHipError, match="stale"):
+            eng.defer_get(first)
+        assert eng.defer_stats()["nodes_dropped"] > 0
+        m = eng.defer_mark()
+        keep = eng.defer_mul_base(_le(7))
+        eng.defer_floor(m)
+        assert eng.defer_stats()["nodes_held"] == 1 and eng.defer_get(keep) == oracle.mul_base(_le(7))
+    finally:
+        eng.set_option("defer.max_nodes", 1 << 20)

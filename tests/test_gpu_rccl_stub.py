@@ -48,7 +48,7 @@ def _build_stub(tmp_path):
 
 
 def _child(flags, env_extra):
-    env = dict(os.environ, **env_extra)
+    env = dict(os.environ, KYB_NO_TORCH="1", **env_extra)      # torch would bring its own librccl (same SONAME) into the process first
     r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT), str(flags)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

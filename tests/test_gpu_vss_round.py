@@ -1,0 +1,73 @@
+"""Unmodified, element-at-a-time protocol code on the engine: tests/cpp/test_vss_round.cpp restates one Pedersen-VSS dealer round (n = 64 verifiers,
+t = 43) call by call as vss.rs:287-337, 361-386, 904-909 and poly.rs:195-206, 457-469 make the curve calls, and runs it twice — every trait call a
+batch-of-1 engine call, then with the calls recorded and evaluated in batches (kyb_defer_*, csrc/defer.inc).  Here: the two transcripts are equal,
+every byte string in them is what the oracle computes, and the deferred run is at least five times faster."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(n, t):
+    src = os.path.join(ROOT, "tests", "cpp", "test_vss_round.cpp")
+    out = os.path.join(ROOT, "tests", "cpp", "_build", "test_vss_round")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    libdir = os.path.join(ROOT, "kyber-rs_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-o", out, src,
+                           "-L", libdir, "-lkyber_ed25519_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([out, str(n), str(t)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    eager = [ln[2:] for ln in r.stdout.splitlines() if ln.startswith("E ")]
+    lazy = [ln[2:] for ln in r.stdout.splitlines() if ln.startswith("D ")]
+    timing = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("TIMING ")][0][7:])
+    return eager, lazy, timing
+
+
+def _check_against_oracle(lines, n, t, oracle):
+    by = {}
+    for ln in lines:
+        tag, val = ln.split()
+        by.setdefault(tag, []).append(val)
+    b = lambda h: bytes.fromhex(h)
+    assert len(by["COEFF"]) == t and len(by["COMMIT"]) == t and len(by["VPUB"]) == n and len(by["PUBSHARE"]) == n
+    assert by["DPUB"][0] == oracle.mul_base(b(by["LONGTERM"][0])).hex()
+    assert by["COMMIT"] == [oracle.mul_base(b(c)).hex() for c in by["COEFF"]]          # mul(coeff, Some(base)) == mul(coeff, None) as encodings
+    assert by["VPUB"] == [oracle.mul_base(b(v)).hex() for v in by["VPRIV"]]
+    commits_ext = np.stack([oracle.mul_base_ext(b(c)) for c in by["COEFF"]])
+    for i in range(n):
+        assert by["DHKEY"][i] == oracle.mul_base(b(by["DHSECRET"][i])).hex()
+        vpub_ext = oracle.decode(b(by["VPUB"][i]))[0]
+        assert by["PRE"][i] == oracle.mul(b(by["DHSECRET"][i]), vpub_ext).hex()         # dh_exchange
+        assert oracle.verify(1, b(by["DPUB"][0]), b(by["DHKEY"][i]), b(by["SIG"][i])) == 0
+        assert by["PUBSHARE"][i] == oracle.pubpoly_eval(commits_ext, i).hex()
+        # the private share times B is the public share (what verify_deal checks)
+        assert by["PUBSHARE"][i] == oracle.mul_base(oracle.pripoly_eval(np.frombuffer(b("".join(by["COEFF"])), dtype=np.uint8).reshape(-1, 32), i)).hex()
+    assert by["DEALOK"] == ["1"] * n and by["DEALBAD"] == ["0" if t > 1 else "1"]      # t = 1: a constant polynomial, every share is the secret
+
+
+def test_pedersen_dealer_round_call_by_call_eager_and_deferred(oracle):
+    n, t = 64, 43
+    eager, lazy, timing = _run(n, t)
+    assert eager == lazy and len(eager) > 5 * n                    # the same bytes everywhere the reference looks
+    _check_against_oracle(eager, n, t, oracle)
+    print(json.dumps(timing))
+    st = timing["deferred_stats"]
+    assert timing["eager_stats_nodes"] == 0                          # the eager run records nothing
+    assert st["horner_fused"] == n + 1                               # every verifier's PubPoly::eval was ONE engine call
+    assert st["engine_calls"] <= 8 * n + 16                          # against ~ (2 t + 6) n batch-of-1 calls of the eager run
+    assert st["marshal_cache_hits"] >= t                             # session_id's marshals of the commitments
+    assert timing["speedup"] >= 5.0, timing
+    assert timing["deferred_ms"]["verify_deals"] * 10 <= timing["eager_ms"]["verify_deals"], timing
+
+
+def test_small_round_with_odd_shapes(oracle):
+    """n = 3, t = 2 (the shortest chain that is fused) and t = 1 (no chain at all: level by level)"""
+    for n, t in ((3, 2), (2, 1), (5, 7)):
+        eager, lazy, _ = _run(n, t)
+        assert eager == lazy
+        _check_against_oracle(eager, n, t, oracle)
