@@ -542,7 +542,73 @@ def small_call_latency(eng, orc):
                          "mul_public_10bit_index": med(lambda: eng.mul(idx[:n], pts_ext=ext[:n], public=True)),
                          "sign": med(lambda: eng.schnorr_sign(s[:n], k[:n], msgs[:n])), "verify": med(lambda: eng.verify(enc[:n], msgs[:n], sigs[:n], 1)),
                          "decode": med(lambda: eng.decode(enc[:n])), "encode": med(lambda: eng.encode(ext[:n]))}
+    out["call_by_call_t43"] = call_by_call_sequences(eng, orc, med)
     return out
+
+
+def call_by_call_sequences(eng, orc, med, t=43):
+    """The sequences unmodified protocol code runs, element at a time (share/poly.rs:195-206 commit, :457-469 PubPoly::eval, vss.rs:904-909 verify_deal),
+    EAGER = every trait call one batch-of-1 engine call, against DEFERRED = the same calls recorded in the engine's arena (kyb_defer_*, csrc/defer.inc)
+    and evaluated when the bytes are asked for.  Microseconds per whole sequence, median of 20; outputs of both forms checked against the oracle.
+    (The full Pedersen dealer round, n = 64, t = 43, in C++: tests/cpp/test_vss_round.cpp, profiles/r04/vss_round.log.)"""
+    import numpy as np
+    import synth as _s
+    coeffs = _s.scalars(t, 81)
+    one = (1).to_bytes(32, "little")
+    base_ext = eng.mul_base(np.frombuffer(one, dtype=np.uint8).reshape(1, 32), ext_only=True)[0]
+    commits_ext = orc.mul_base_ext_batch(coeffs)
+    index = 6
+    xi = np.frombuffer((index + 1).to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32)
+    share = np.frombuffer(orc.pripoly_eval(coeffs, index), dtype=np.uint8).reshape(1, 32)
+    null_ext = np.zeros(40, dtype=np.int32); null_ext[10] = 1; null_ext[20] = 1
+    want_commits = orc.mul_base_batch(coeffs)
+    want_eval = orc.pubpoly_eval(commits_ext, index)
+
+    def commit_eager():       # t x mul(coeff, Some(base)), then marshal_binary of each (session_id hashes them)
+        pts = [eng.mul(coeffs[j:j + 1], pts_ext=base_ext[None], ext_only=True)[0] for j in range(t)]
+        return [eng.encode(p[None])[0].tobytes() for p in pts]
+
+    def commit_deferred():
+        b = eng.defer_base()
+        hs = [eng.defer_mul(coeffs[j].tobytes(), b) for j in range(t)]
+        return [eng.defer_get(h) for h in hs]
+
+    def eval_eager():         # v = null; t x { v = mul(xi, Some(v)); v = add(v, commits[j]) }
+        v = null_ext
+        for j in reversed(range(t)):
+            v = eng.mul(xi, pts_ext=v[None], ext_only=True)[0]
+            v = eng.add(v[None], commits_ext[j][None])[0]
+        return v
+
+    def verify_deal_eager():  # fig = base().mul(fi.v, None); pub_share = eval(fi.i); fig == pub_share.v
+        fig = eng.mul_base(share, ext_only=True)[0]
+        return bool(eng.equal(fig[None], eval_eager()[None])[0])
+
+    hc = [eng.defer_input(c) for c in commits_ext]
+
+    def eval_deferred_handle():
+        v = eng.defer_input(null_ext)
+        x = xi.tobytes()
+        for j in reversed(range(t)):
+            v = eng.defer_mul(x, v)
+            v = eng.defer_add(v, hc[j])
+        return v
+
+    def verify_deal_deferred():
+        fig = eng.defer_mul_base(share.tobytes())
+        return eng.defer_equal(fig, eval_deferred_handle())
+
+    assert commit_eager() == [bytes(w) for w in want_commits] == commit_deferred()
+    assert orc.encode(eval_eager()) == want_eval == eng.defer_get(eval_deferred_handle())
+    assert verify_deal_eager() and verify_deal_deferred()
+    mark = eng.defer_mark()
+    res = {"unit": "us per whole sequence (median of 20), t = 43", "checked_against_oracle": True,
+           "commit_then_marshal": {"eager": med(commit_eager, 20), "deferred": med(commit_deferred, 20)},
+           "pubpoly_eval": {"eager": med(eval_eager, 20), "deferred": med(lambda: eng.defer_get_ext(eval_deferred_handle()), 20)},
+           "verify_deal": {"eager": med(verify_deal_eager, 20), "deferred": med(verify_deal_deferred, 20)}}
+    res["arena"] = eng.defer_stats()
+    eng.defer_floor(mark)
+    return res
 
 
 def host_pointer_rates(w, eng, orc, threads, calls=5):

@@ -71,6 +71,17 @@ extern "C" {
     pub fn kyb_lagrange_coeffs_batch(indices: *const u32, m: size_t, t: size_t, out_scalars: *mut u8) -> c_int;
     pub fn kyb_verify_points_batch(pubs_ext: *const i32, msgs: *const u8, msg_off: *const u32, sigs: *const u8, n: size_t, flavor: c_int, status: *mut u8) -> c_int;
     pub fn kyb_pripoly_eval_batch(coeffs: *const u8, m: size_t, t: size_t, indices: *const u32, k: size_t, out_shares: *mut u8) -> c_int;
+    // deferred points: operations recorded in the context's arena, evaluated in batches when a result is asked for
+    pub fn kyb_defer_input(ext: *const i32, out: *mut u64) -> c_int;
+    pub fn kyb_defer_mul_base(scalar: *const u8, out: *mut u64) -> c_int;
+    pub fn kyb_defer_mul(scalar: *const u8, p: u64, out: *mut u64) -> c_int;
+    pub fn kyb_defer_add(a: u64, b: u64, subtract: c_int, out: *mut u64) -> c_int;
+    pub fn kyb_defer_neg(a: u64, out: *mut u64) -> c_int;
+    pub fn kyb_defer_get(p: u64, out_ext: *mut i32, out_enc: *mut u8) -> c_int;
+    pub fn kyb_defer_equal(a: u64, b: u64, eq: *mut u8) -> c_int;
+    pub fn kyb_defer_flush() -> c_int;
+    pub fn kyb_defer_mark() -> u64;
+    pub fn kyb_defer_floor(mark: u64) -> c_int;
     pub fn kyb_host_alloc(bytes: size_t) -> *mut c_void;
     pub fn kyb_host_free(p: *mut c_void);
 }

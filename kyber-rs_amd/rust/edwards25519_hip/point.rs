@@ -9,6 +9,12 @@
 //!     `kyb_point_checks_batch`) and never round-trip through `CpuPoint::unmarshal_binary` — limbs that are no curve point
 //!     (a `Point` that came out of serde, which derives `Deserialize` on raw limbs) then format and answer like any other
 //!     bytes instead of panicking.  This module carries no second copy of the reference's host logic.
+//! DEFERRED MODE (`set_deferred(true)` per thread, or KYBER_HIP_DEFERRED in the environment): `mul` / `add` / `sub` / `neg` RECORD their
+//! operation in the engine's arena (`kyb_defer_*`) and return a `Point` that holds only a handle; the engine evaluates what was recorded,
+//! in batches, when somebody needs bytes or limbs (`marshal_binary`, `eq`, `hash`, `data`, serde, the batch helpers).  Unmodified protocol
+//! code then gets one engine call for the t multiplications of `PriPoly::commit` and one for the whole Horner chain of `PubPoly::eval`
+//! (a Pedersen dealer round, n = 64, t = 43, call by call: 616 ms eager, 46 ms deferred; tests/cpp/test_vss_round.cpp is the same logic in
+//! C++).  `Point` stays `Copy`: handles are plain numbers, the arena keeps evaluated nodes until `defer_floor(mark)`.
 //! `add` / `sub` of a single pair call the reference's group-element formulas (`ge.rs`) on the same limbs: nine field
 //! multiplications are not worth a round trip to the GPU; vectors of pairs go to the engine (`add_batch`).
 //! Which reference method each one stands for: INTEGRATION.md §3.
@@ -35,6 +41,26 @@ use super::ffi::{self, ensure_init, must};
 
 type Limbs = [[i32; 10]; 4];
 
+thread_local! {
+    static DEFERRED: std::cell::Cell<bool> = std::cell::Cell::new(std::env::var_os("KYBER_HIP_DEFERRED").is_some());
+}
+/// Record this thread's `mul` / `add` / `sub` / `neg` in the engine's arena instead of running them one by one (module docs).
+pub fn set_deferred(on: bool) {
+    DEFERRED.with(|d| d.set(on));
+}
+fn deferred() -> bool {
+    DEFERRED.with(|d| d.get())
+}
+/// Everything recorded before `mark` (an earlier `defer_mark()`) may be dropped from the arena: call at the end of a protocol round.
+pub fn defer_mark() -> u64 {
+    ensure_init();
+    unsafe { ffi::kyb_defer_mark() }
+}
+pub fn defer_floor(mark: u64) {
+    ensure_init();
+    must(unsafe { ffi::kyb_defer_floor(mark) }, "defer_floor");
+}
+
 /// 1 * B as the engine hands it out, asked for once per process
 fn base_ext() -> &'static Limbs {
     static BASE_EXT: std::sync::OnceLock<Limbs> = std::sync::OnceLock::new();
@@ -54,16 +80,50 @@ fn invalid_point() -> MarshallingError {
 
 /// X, Y, Z, T as 4 x [i32; 10] radix-2^25.5 limbs — the ABI's `ext` record, which is also what the reference's `Point`
 /// keeps in its `ge` field (point.rs:23-27) — plus the reference's `var_time` flag (carried, never acted on: SURVEY.md §2).
-#[derive(Copy, Clone, Eq, Ord, PartialOrd, Debug, Serialize, Deserialize)]
+/// `pend != 0`: the point has been recorded in the engine's arena and not asked for yet; `ge` is then unset and `limbs()` fetches it.
+/// serde sees the two fields of the reference's type (`Plain`): a recorded point is evaluated before it is serialised.
+#[derive(Copy, Clone, Debug, Serialize, Deserialize)]
+#[serde(from = "Plain", into = "Plain")]
 pub struct Point {
     ge: Limbs,
     var_time: bool,
+    pend: u64,
+}
+
+#[derive(Serialize, Deserialize)]
+#[serde(rename = "Point")]
+struct Plain {
+    ge: Limbs,
+    var_time: bool,
+}
+impl From<Plain> for Point {
+    fn from(p: Plain) -> Self {
+        Point { ge: p.ge, var_time: p.var_time, pend: 0 }
+    }
+}
+impl From<Point> for Plain {
+    fn from(p: Point) -> Self {
+        Plain { ge: p.limbs(), var_time: p.var_time }
+    }
 }
 
 impl Default for Point {
     /// all-zero limbs, like the derived default of the reference's element
     fn default() -> Self {
-        Point { ge: [[0; 10]; 4], var_time: false }
+        Point { ge: [[0; 10]; 4], var_time: false, pend: 0 }
+    }
+}
+
+// the reference derives these on the limbs; so do we, on the evaluated limbs
+impl Eq for Point {}
+impl PartialOrd for Point {
+    fn partial_cmp(&self, other: &Self) -> Option<core::cmp::Ordering> {
+        Some(self.cmp(other))
+    }
+}
+impl Ord for Point {
+    fn cmp(&self, other: &Self) -> core::cmp::Ordering {
+        (self.limbs(), self.var_time).cmp(&(other.limbs(), other.var_time))
     }
 }
 
@@ -72,25 +132,52 @@ impl Point {
         Self::default()
     }
     fn from_limbs(ge: Limbs) -> Self {
-        Point { ge, var_time: false }
+        Point { ge, var_time: false, pend: 0 }
     }
-    fn ext(&self) -> *const i32 {
-        self.ge.as_ptr() as *const i32
+    /// a point that exists only as a recorded operation so far
+    fn recorded(self, handle: u64) -> Self {
+        Point { ge: [[0; 10]; 4], pend: handle, ..self }
+    }
+    /// the limbs: held, or evaluated now (with everything else recorded so far) and fetched from the arena
+    fn limbs(&self) -> Limbs {
+        if self.pend == 0 {
+            return self.ge;
+        }
+        ensure_init();
+        let mut out: Limbs = [[0; 10]; 4];
+        must(unsafe { ffi::kyb_defer_get(self.pend, out.as_mut_ptr() as *mut i32, std::ptr::null_mut()) }, "defer_get");
+        out
+    }
+    /// this point as the operand of a recorded operation: its handle, or a leaf made of its limbs (the arena recognises limbs it has seen)
+    fn handle(&self) -> u64 {
+        if self.pend != 0 {
+            return self.pend;
+        }
+        ensure_init();
+        let mut h = 0u64;
+        must(unsafe { ffi::kyb_defer_input(self.ge.as_ptr() as *const i32, &mut h) }, "defer_input");
+        h
     }
     fn ext_mut(&mut self) -> *mut i32 {
+        self.pend = 0;
         self.ge.as_mut_ptr() as *mut i32
     }
     /// the reference's element on the same limbs (no conversion: the layouts are one)
     fn element(&self) -> ExtendedGroupElement {
-        let [x, y, z, t] = self.ge;
+        let [x, y, z, t] = self.limbs();
         ExtendedGroupElement { x, y, z, t }
     }
 
-    /// the 32 bytes of `marshal_binary`, from the engine (one field inversion on the GPU)
+    /// the 32 bytes of `marshal_binary`, from the engine (one field inversion on the GPU; for a recorded point: evaluation in batches,
+    /// bytes cached in the arena)
     fn encoding(&self) -> [u8; 32] {
         ensure_init();
         let mut b = [0u8; 32];
-        must(unsafe { ffi::kyb_encode_batch(self.ext(), 1, b.as_mut_ptr()) }, "encode");
+        if self.pend != 0 {
+            must(unsafe { ffi::kyb_defer_get(self.pend, std::ptr::null_mut(), b.as_mut_ptr()) }, "defer_get");
+        } else {
+            must(unsafe { ffi::kyb_encode_batch(self.ge.as_ptr() as *const i32, 1, b.as_mut_ptr()) }, "encode");
+        }
         b
     }
     /// `unmarshal_binary` on the engine: None iff the bytes are not 32 or do not decode
@@ -128,17 +215,33 @@ impl Point {
     }
     fn pair_on_gpu(p1: &Self, p2: &Self, subtract: bool) -> Limbs {
         ensure_init();
+        let (a, b) = (p1.limbs(), p2.limbs());
         let mut out: Limbs = [[0; 10]; 4];
-        must(unsafe { ffi::kyb_add_batch(p1.ext(), p2.ext(), 1, out.as_mut_ptr() as *mut i32, subtract as c_int) }, "add");
+        must(unsafe { ffi::kyb_add_batch(a.as_ptr() as *const i32, b.as_ptr() as *const i32, 1, out.as_mut_ptr() as *mut i32, subtract as c_int) }, "add");
         out
+    }
+    /// add / sub of the trait: recorded in deferred mode, else one pair on the CPU (or on the GPU with `hip-single-add`)
+    fn add_sub(self, p1: &Self, p2: &Self, subtract: bool) -> Self {
+        if deferred() {
+            ensure_init();
+            let mut h = 0u64;
+            must(unsafe { ffi::kyb_defer_add(p1.handle(), p2.handle(), subtract as c_int, &mut h) }, "defer_add");
+            return self.recorded(h);
+        }
+        let ge = if cfg!(feature = "hip-single-add") { Self::pair_on_gpu(p1, p2, subtract) } else { Self::pair_on_cpu(p1, p2, subtract) };
+        Point { ge, pend: 0, ..self }
     }
 
     /// `mul` for a multiplier the caller KNOWS to be public (a share index, the cofactor): the engine may then skip its leading
     /// zero bits (`kyb_mul_public_batch`; 29 us instead of 158 for a 10-bit index).  Never for a secret.
     pub fn mul_public(mut self, s: &Scalar, p: &Self) -> Self {
         ensure_init();
+        let operand = p.limbs();
         must(
-            unsafe { ffi::kyb_mul_public_batch(s.v.as_ptr(), std::ptr::null(), p.ext(), 1, std::ptr::null_mut(), self.ext_mut(), std::ptr::null_mut()) },
+            unsafe {
+                ffi::kyb_mul_public_batch(s.v.as_ptr(), std::ptr::null(), operand.as_ptr() as *const i32, 1, std::ptr::null_mut(), self.ext_mut(),
+                                          std::ptr::null_mut())
+            },
             "mul_public",
         );
         self
@@ -156,7 +259,7 @@ impl Point {
             None => must(unsafe { ffi::kyb_mul_base_batch(sc.as_ptr(), n, std::ptr::null_mut(), staged.as_mut_ptr() as *mut i32) }, "mul_base_batch"),
             Some(ps) => {
                 assert_eq!(ps.len(), n);
-                let inp: Vec<[[i32; 10]; 4]> = ps.iter().map(|q| q.ge).collect();
+                let inp: Vec<[[i32; 10]; 4]> = ps.iter().map(|q| q.limbs()).collect();
                 must(
                     unsafe {
                         ffi::kyb_mul_batch(sc.as_ptr(), std::ptr::null(), inp.as_ptr() as *const i32, n, std::ptr::null_mut(),
@@ -172,7 +275,7 @@ impl Point {
     /// 32-byte encodings of many points with one shared inversion per 8 (marshal_binary of each, point.rs:35-41)
     pub fn marshal_batch(ps: &[Point]) -> Vec<[u8; 32]> {
         ensure_init();
-        let inp: Vec<[[i32; 10]; 4]> = ps.iter().map(|q| q.ge).collect();
+        let inp: Vec<[[i32; 10]; 4]> = ps.iter().map(|q| q.limbs()).collect();
         let mut out = vec![[0u8; 32]; ps.len()];
         must(unsafe { ffi::kyb_encode_batch(inp.as_ptr() as *const i32, ps.len(), out.as_mut_ptr() as *mut u8) }, "encode_batch");
         out
@@ -182,8 +285,8 @@ impl Point {
     pub fn add_batch(a: &[Point], b: &[Point], subtract: bool) -> Vec<Point> {
         ensure_init();
         assert_eq!(a.len(), b.len());
-        let ia: Vec<[[i32; 10]; 4]> = a.iter().map(|q| q.ge).collect();
-        let ib: Vec<[[i32; 10]; 4]> = b.iter().map(|q| q.ge).collect();
+        let ia: Vec<[[i32; 10]; 4]> = a.iter().map(|q| q.limbs()).collect();
+        let ib: Vec<[[i32; 10]; 4]> = b.iter().map(|q| q.limbs()).collect();
         let mut staged = vec![[[0i32; 10]; 4]; a.len()];
         must(
             unsafe { ffi::kyb_add_batch(ia.as_ptr() as *const i32, ib.as_ptr() as *const i32, a.len(), staged.as_mut_ptr() as *mut i32, subtract as c_int) },
@@ -205,8 +308,8 @@ impl Point {
     pub fn eq_batch(a: &[Point], b: &[Point]) -> Vec<bool> {
         ensure_init();
         assert_eq!(a.len(), b.len());
-        let ia: Vec<[[i32; 10]; 4]> = a.iter().map(|q| q.ge).collect();
-        let ib: Vec<[[i32; 10]; 4]> = b.iter().map(|q| q.ge).collect();
+        let ia: Vec<[[i32; 10]; 4]> = a.iter().map(|q| q.limbs()).collect();
+        let ib: Vec<[[i32; 10]; 4]> = b.iter().map(|q| q.limbs()).collect();
         let mut eq = vec![0u8; a.len()];
         must(unsafe { ffi::kyb_equal_batch(ia.as_ptr() as *const i32, ib.as_ptr() as *const i32, a.len(), eq.as_mut_ptr()) }, "equal_batch");
         eq.into_iter().map(|e| e != 0).collect()
@@ -219,7 +322,7 @@ pub fn recover_commit_accumulate(lagrange: &[Scalar], shares: &[Point]) -> Point
     ensure_init();
     assert_eq!(lagrange.len(), shares.len());
     let sc: Vec<u8> = lagrange.iter().flat_map(|x| x.v).collect();
-    let inp: Vec<[[i32; 10]; 4]> = shares.iter().map(|q| q.ge).collect();
+    let inp: Vec<[[i32; 10]; 4]> = shares.iter().map(|q| q.limbs()).collect();
     let mut out = Point::default();
     must(
         unsafe {
@@ -306,6 +409,7 @@ impl BinaryMarshaler for Point {
 impl BinaryUnmarshaler for Point {
     fn unmarshal_binary(&mut self, data: &[u8]) -> Result<(), MarshallingError> {
         self.ge = Self::decode(data).ok_or_else(invalid_point)?;
+        self.pend = 0;
         Ok(())
     }
 }
@@ -337,21 +441,22 @@ impl group::Point for Point {
         let mut ge: Limbs = [[0; 10]; 4];
         ge[1][0] = 1;
         ge[2][0] = 1;
-        Point { ge, ..self }
+        Point { ge, pend: 0, ..self }
     }
 
     /// 1 * B from the engine (the reference copies a literal; the same point)
     fn base(self) -> Self {
-        Point { ge: *base_ext(), ..self }
+        Point { ge: *base_ext(), pend: 0, ..self }
     }
 
     /// delegated: the reference's rejection loop on its CPU point, the accepted point brought over by its encoding
     fn pick<S: Stream>(self, rand: &mut S) -> Self {
-        Point { ge: Self::from_cpu(&CpuPoint::default().pick(rand)).ge, ..self }
+        Point { ge: Self::from_cpu(&CpuPoint::default().pick(rand)).ge, pend: 0, ..self }
     }
 
     fn set(&mut self, p: &Self) -> Self {
         self.ge = p.ge;
+        self.pend = p.pend;
         *self
     }
 
@@ -361,7 +466,7 @@ impl group::Point for Point {
 
     /// delegated, as `pick`
     fn embed<S: Stream>(self, data: Option<&[u8]>, rand: &mut S) -> Self {
-        Point { ge: Self::from_cpu(&CpuPoint::default().embed(data, rand)).ge, ..self }
+        Point { ge: Self::from_cpu(&CpuPoint::default().embed(data, rand)).ge, pend: 0, ..self }
     }
 
     /// the bytes `embed` placed behind the length byte of the encoding
@@ -376,20 +481,28 @@ impl group::Point for Point {
 
     /// One pair: the reference's own formulas on the CPU (0.3 us; a batch-of-1 round trip to the GPU is 26 us).  Cargo feature
     /// `hip-single-add` sends it to the engine instead (the same point); vectors go there in any case (`Point::add_batch`).
+    /// Deferred mode: recorded (a chain of additions is evaluated as one sum).
     fn add(self, p1: &Self, p2: &Self) -> Self {
-        let ge = if cfg!(feature = "hip-single-add") { Self::pair_on_gpu(p1, p2, false) } else { Self::pair_on_cpu(p1, p2, false) };
-        Point { ge, ..self }
+        self.add_sub(p1, p2, false)
     }
 
     fn sub(self, p1: &Self, p2: &Self) -> Self {
-        let ge = if cfg!(feature = "hip-single-add") { Self::pair_on_gpu(p1, p2, true) } else { Self::pair_on_cpu(p1, p2, true) };
-        Point { ge, ..self }
+        self.add_sub(p1, p2, true)
     }
 
-    /// -(X : Y : Z : T) = (-X : Y : Z : -T), limb by limb; no engine call
+    /// -(X : Y : Z : T) = (-X : Y : Z : -T), limb by limb; no engine call (deferred mode: recorded)
     fn neg(&mut self, a: &Self) -> Self {
+        if deferred() {
+            ensure_init();
+            let mut h = 0u64;
+            must(unsafe { ffi::kyb_defer_neg(a.handle(), &mut h) }, "defer_neg");
+            *self = self.recorded(h);
+            return *self;
+        }
         let flip = |f: &[i32; 10]| f.map(|limb| -limb);
-        self.ge = [flip(&a.ge[0]), a.ge[1], a.ge[2], flip(&a.ge[3])];
+        let l = a.limbs();
+        self.ge = [flip(&l[0]), l[1], l[2], flip(&l[3])];
+        self.pend = 0;
         *self
     }
 
@@ -401,12 +514,23 @@ impl group::Point for Point {
         ensure_init();
         let fixed = match p {
             None => true,
-            Some(q) => q.ge == *base_ext() && s.v[31] & 0x80 == 0,
+            Some(q) => q.pend == 0 && q.ge == *base_ext() && s.v[31] & 0x80 == 0,
         };
+        if deferred() {
+            let mut h = 0u64;
+            let rc = if fixed {
+                unsafe { ffi::kyb_defer_mul_base(s.v.as_ptr(), &mut h) }
+            } else {
+                unsafe { ffi::kyb_defer_mul(s.v.as_ptr(), p.unwrap().handle(), &mut h) }
+            };
+            must(rc, "defer_mul");
+            return self.recorded(h);
+        }
         let rc = if fixed {
             unsafe { ffi::kyb_mul_base_batch(s.v.as_ptr(), 1, std::ptr::null_mut(), self.ext_mut()) }
         } else {
-            unsafe { ffi::kyb_mul_batch(s.v.as_ptr(), std::ptr::null(), p.unwrap().ext(), 1, std::ptr::null_mut(), self.ext_mut(), std::ptr::null_mut()) }
+            let operand = p.unwrap().limbs();
+            unsafe { ffi::kyb_mul_batch(s.v.as_ptr(), std::ptr::null(), operand.as_ptr() as *const i32, 1, std::ptr::null_mut(), self.ext_mut(), std::ptr::null_mut()) }
         };
         must(rc, "mul");
         self
@@ -418,7 +542,11 @@ impl PartialEq for Point {
     fn eq(&self, p2: &Self) -> bool {
         ensure_init();
         let mut e = 0u8;
-        must(unsafe { ffi::kyb_equal_batch(self.ext(), p2.ext(), 1, &mut e) }, "eq");
+        if self.pend != 0 || p2.pend != 0 {
+            must(unsafe { ffi::kyb_defer_equal(self.handle(), p2.handle(), &mut e) }, "defer_equal");
+        } else {
+            must(unsafe { ffi::kyb_equal_batch(self.ge.as_ptr() as *const i32, p2.ge.as_ptr() as *const i32, 1, &mut e) }, "eq");
+        }
         e != 0
     }
 }
@@ -454,7 +582,8 @@ impl PointCanCheckCanonicalAndSmallOrder for Point {
     fn has_small_order(&self) -> bool {
         ensure_init();
         let mut flags = 0u8;
-        must(unsafe { ffi::kyb_point_checks_batch(std::ptr::null(), self.ext(), 1, &mut flags) }, "point_checks");
+        let l = self.limbs();
+        must(unsafe { ffi::kyb_point_checks_batch(std::ptr::null(), l.as_ptr() as *const i32, 1, &mut flags) }, "point_checks");
         flags & 2 != 0
     }
     /// pure byte logic on the caller's buffer: delegated (no decoding involved)
