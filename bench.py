@@ -79,7 +79,7 @@ WORKLOAD_TEXT = {"mul": "2^20 variable-base scalar-mults, random scalars+points,
 PEAK_MAD_NOMINAL = 1024 * 64 / 4 * 2.4e9
 HBM_PEAK_GBS = 8000.0
 DEFAULT_N = {"mul": 1 << 20, "mul_enc": 1 << 20, "mul_base": 1 << 20, "sign": 1 << 18, "verify": 1 << 20}
-PROFILE_ROUNDS = ("r03", "r02", "r01")
+PROFILE_ROUNDS = ("r04", "r03", "r02", "r01")
 OPTION_KEYS = ("mul.algo", "mul.ladder_waves", "mul.select", "mul_base.radix", "mul_base.select", "mul_base.block", "finish.batched", "finish.min_items",
                "ladder.skip_canonical", "ladder.pair_max_items")
 
@@ -407,8 +407,13 @@ def roofline(w, eng, steps, peak, clock, cus):
             pmc = os.path.join(ROOT, "profiles", rnd, f"{wl}_pmc_summary.json")
             if os.path.exists(pmc):
                 d_ = json.load(open(pmc))["_derived"]
-                traffic = round(d_["fetch_bytes_per_dispatch_corrected_x2"] + d_["write_bytes_per_dispatch"])
-                traffic_source = f"profiles/{rnd}/{wl}_pmc_summary.json (rocprofv3 --pmc passes of this command, not this run)"
+                import kyber_rs_amd
+                here, there = kyber_rs_amd.kernel_sources_id(), d_.get("kernel_sources_id")
+                if there == here:
+                    traffic = round(d_["fetch_bytes_per_dispatch_corrected_x2"] + d_["write_bytes_per_dispatch"])
+                    traffic_source = f"profiles/{rnd}/{wl}_pmc_summary.json (rocprofv3 --pmc passes of this command on this kernel code, id {here}; not this run)"
+                else:      # counters of other code say nothing about this build: no number rather than a stale one
+                    traffic_source = f"none: the newest PMC summary (profiles/{rnd}/{wl}_pmc_summary.json) was collected on kernel code {there}, this is {here}"
                 break
     pk = peak["mads_per_s"]
     # the kernel executes about the reference's work (ladder: 0.98 of it) -> price the algorithmic figure; far less (43 of 64 additions)

@@ -53,6 +53,18 @@ ABI_SYMBOLS = [
 ]
 
 
+def kernel_sources_id() -> str:
+    """Identifies the code of the two dominant kernels (k_mul_ladder, k_mul_base64): SHA-256 over their translation units and every header of csrc/.
+    bench.py only replays HBM-traffic counters from profiles/ when they were collected on THIS code (tools/summarise_profiles.py stores the id)."""
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    names = sorted(f for f in os.listdir(csrc) if f.endswith(".h") or f in ("kernels_ladder.hip", "kernels_base.hip", "consts.inc"))
+    h = hashlib.sha256()
+    for f in names:
+        h.update(f.encode() + b"\0" + open(os.path.join(csrc, f), "rb").read() + b"\0")
+    return h.hexdigest()[:16]
+
+
 class KyberHipError(RuntimeError):
     pass
 

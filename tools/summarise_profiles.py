@@ -11,6 +11,9 @@ import os
 import shutil
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import kyber_rs_amd  # noqa: E402
+
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = "gpurun_out/prof"
 dst = os.path.join("profiles", rnd)
@@ -39,7 +42,7 @@ for w in ("mul", "mul_enc", "mul_base", "sign", "verify"):
     if not out:
         continue
     g = lambda k: out[k]["mean_per_dispatch"]
-    d = {"kernel": "/".join(sorted(names)) or DOM[w].rstrip("<"), "note": "separate --pmc passes (SQ / FETCH_SIZE+GRBM / WRITE_SIZE+TCC), MI355X, means over the dispatches of the dominant kernel"}
+    d = {"kernel": "/".join(sorted(names)) or DOM[w].rstrip("<"), "kernel_sources_id": kyber_rs_amd.kernel_sources_id(), "note": "separate --pmc passes (SQ / FETCH_SIZE+GRBM / WRITE_SIZE+TCC), MI355X, means over the dispatches of the dominant kernel"}
     if "SQ_ACTIVE_INST_VALU" in out and "GRBM_GUI_ACTIVE" in out:
         d["VALUBusy_pct"] = 100 * g("SQ_ACTIVE_INST_VALU") * 4 / 1024 / (g("GRBM_GUI_ACTIVE") / 8)
     if "FETCH_SIZE" in out:
