@@ -50,9 +50,9 @@ thread_local std::string g_err;
 
 // optional per-launch timing (bench.py): HIP events recorded on the launch stream around each kernel
 enum KernelId { KID_MUL, KID_MUL_BASE, KID_FINISH, KID_SIGN, KID_SIGN_HASH, KID_VERIFY_PREP, KID_VERIFY_FINAL, KID_POLY_EVAL, KID_MONT_PREP,
-                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_VERIFY_COOP, KID_FINISH_COOP, KID_SIGN_COOP, KID_MSM_TABLES, KID_MSM_ACCUMULATE, KID_MUL_LADDER_PAIR, KID_PRIPOLY_EVAL, KID_COUNT };
+                KID_MUL_LADDER, KID_DECODE, KID_EDDSA_PREP, KID_PAIR_SUM, KID_VERIFY_PREP_R, KID_ENCODE, KID_MUL_COOP, KID_MUL_BASE_COOP, KID_DECODE_COOP, KID_POLY_EVAL_COOP, KID_VERIFY_COOP, KID_FINISH_COOP, KID_SIGN_COOP, KID_MSM_TABLES, KID_MSM_ACCUMULATE, KID_MUL_LADDER_PAIR, KID_PRIPOLY_EVAL, KID_LADDER_RECOVER, KID_COUNT };
 const char* const KERNEL_NAMES[KID_COUNT] = {"k_mul", "k_mul_base", "k_finish", "k_sign", "k_sign_hash", "k_verify_prep", "k_verify_final", "k_poly_eval",
-                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop", "k_verify_coop", "k_finish_coop", "k_sign_coop", "k_msm_tables", "k_msm_accumulate", "k_mul_ladder_pair", "k_pripoly_eval"};
+                                             "k_mont_prep", "k_mul_ladder", "k_decode", "k_eddsa_prep", "k_pair_sum", "k_verify_prep_r", "k_encode_batched", "k_mul_coop", "k_mul_base_coop", "k_decode_coop", "k_poly_eval_coop", "k_verify_coop", "k_finish_coop", "k_sign_coop", "k_msm_tables", "k_msm_accumulate", "k_mul_ladder_pair", "k_pripoly_eval", "k_ladder_recover"};
 struct ProfRec { int id; hipEvent_t a, b; };
 struct Prof {
   std::mutex mu;                  // begin / read / every ProfScope: callable from any thread
@@ -75,7 +75,7 @@ struct StreamRes {
   uint8_t* pub_enc = nullptr; size_t pub_enc_items = 0;    // kyb_verify_points_batch: marshal_binary of the callers' public-key points
   uint32_t* msm = nullptr; size_t msm_points = 0;        // kyb_lincomb_public_batch over shared points: window bases + tables of the points (227,040 B per point)
   uint32_t* top_or = nullptr; unsigned top_seq = 0;     // two alternating words behind the projective staging records (k_mont_prep / k_mul_ladder)
-  hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_last = nullptr;
+  hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr, ev_last = nullptr;
   bool used = false, own = false;
   uint64_t last_use = 0;
 };
@@ -126,6 +126,8 @@ struct Ctx {
   std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: the chunk unit is 1/this of the batch (plan_chunks)
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
+  std::atomic<int> opt_finish_four{1};           // k_finish with 4 instead of 8 items per shared inversion for launches of at most one wavefront per SIMD
+  std::atomic<int> opt_ladder_y_only{1};         // two-lane ladder from wire encodings: ladder on y while a side stream decodes x (0: decode first)
   DeferArena* defer = nullptr;                   // recorded, not yet evaluated point operations of this context's callers (kyb_defer_*; made on first use)
   std::atomic<int> opt_defer_fuse{1};            // flushes recognise Horner chains and chains of additions (defer.inc)
   std::atomic<int> opt_defer_max_nodes{1 << 20}; // evaluated nodes kept for late readers of a handle before the oldest are dropped
@@ -665,7 +667,7 @@ void free_slot(StreamRes* r) {
   if (r->part) wipe_free_dev(r->part, r->part_items * 160);
   if (r->msm) (void)hipFree(r->msm);
   if (r->pub_enc) (void)hipFree(r->pub_enc);
-  if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->ev_fork); (void)hipEventDestroy(r->ev_join); }
+  if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->ev_fork); (void)hipEventDestroy(r->ev_join); if (r->ev_mid) (void)hipEventDestroy(r->ev_mid); }
   if (r->ev_last) (void)hipEventDestroy(r->ev_last);
   delete r;
 }
@@ -778,6 +780,7 @@ int ensure_aux(Ctx& g, StreamRes* r) {
   HIPCK(hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking));
   HIPCK(hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming));
   HIPCK(hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming));
+  HIPCK(hipEventCreateWithFlags(&r->ev_mid, hipEventDisableTiming));
   return KYB_OK;
 }
 inline const uint32_t* image64(Ctx& g) { return g.table + KYB_BASE_TABLE_WORDS + KYB_BASE32_TABLE_WORDS; }
@@ -922,7 +925,8 @@ int launch_finish(Ctx& g, StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, 
     return KYB_OK;
   }
   ProfScope ps(g, st, KID_FINISH);
-  LAUNCHCK(launch::finish(st, r->proj, r->proj_items, n, oenc, oext, src_mul));
+  // up to a wavefront per SIMD of finish lanes the kernel is one lane's chain: four items per inversion shorten it (k_finish4)
+  LAUNCHCK(launch::finish(st, r->proj, r->proj_items, n, oenc, oext, src_mul, g.opt_finish_four != 0 && n <= (size_t)64 * 4 * (size_t)g.cus));
   return KYB_OK;
 }
 
@@ -934,6 +938,23 @@ int launch_ladder_core(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int
                        size_t npts = 0, int skip_bits = 0) {
   const size_t np = npts ? npts : n;
   int rc = ensure_proj(g, r, n + npts); if (rc) return rc;
+  if (penc != nullptr && npts == 0 && g.opt_ladder_y_only != 0 && n <= pair_lim(g, g.opt_ladder_pair_max) && g.opt_verify_overlap && host_load(g) < 4) {
+    // Wire encodings, more SIMDs than wavefronts: the two-lane ladder starts on the y of the encodings while the decode looks for x on a side
+    // stream (252 dependent squarings that used to sit in front of the ladder); a short kernel joins the two (ge_ladder_pair.h, round 4).
+    rc = ensure_enc(g, r, 160 * n + 256); if (rc) return rc;
+    rc = ensure_ws_part(g, r, n); if (rc) return rc;
+    rc = ensure_aux(g, r); if (rc) return rc;
+    int32_t* tmp = reinterpret_cast<int32_t*>(r->enc);
+    uint4* state = reinterpret_cast<uint4*>(r->part);
+    HIPCK(hipEventRecord(r->ev_fork, st));                 // behind whatever the caller queued before this call (the encodings may be its output)
+    HIPCK(hipStreamWaitEvent(r->aux, r->ev_fork, 0));
+    { ProfScope ps(g, r->aux, KID_DECODE); LAUNCHCK(launch::decode_or_identity(r->aux, penc, n, tmp, ok)); }
+    HIPCK(hipEventRecord(r->ev_join, r->aux));
+    { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::mul_ladder_pair_y(st, sc, n, penc, state, skip_bits)); }
+    HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
+    { ProfScope ps(g, st, KID_LADDER_RECOVER); LAUNCHCK(launch::ladder_recover(st, sc, n, tmp, state, r->proj, r->proj_items)); }
+    return KYB_OK;
+  }
   if (penc != nullptr) {           // unmarshal_binary of the operands first (ok flags; failed decodes become the neutral element)
     rc = ensure_enc(g, r, 160 * np + 256); if (rc) return rc;
     int32_t* tmp = reinterpret_cast<int32_t*>(r->enc);
@@ -1410,7 +1431,8 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   uint8_t* flags_a = r->enc + o_fa; uint8_t* flags_r = r->enc + o_fr;
   // the R half (decode of R, s*B) is independent of the A half (decode of A, hash, h*A): while the batch leaves most of
   // the chip idle it runs on the side stream
-  const bool fork = g.opt_verify_overlap && n <= (size_t)64 * (size_t)g.cus && host_load(g) < 4;      // with several calls in flight the other calls fill the idle SIMDs; a side stream only adds queue traffic
+  const size_t fork_max = g.opt_ladder_y_only != 0 && pair_lim(g, g.opt_ladder_pair_max) > (size_t)64 * (size_t)g.cus ? pair_lim(g, g.opt_ladder_pair_max) : (size_t)64 * (size_t)g.cus;
+  const bool fork = g.opt_verify_overlap && n <= fork_max && host_load(g) < 4;      // with several calls in flight the other calls fill the idle SIMDs; a side stream only adds queue traffic
   const bool coop = g.opt_mul_algo == 1 && n <= coop_lim(g, g.opt_coop_max) && n <= coop_lim(g, g.opt_coop_base_max) && 8 * n <= 7 * coop_lim(g, g.opt_coop_ladder_max);     // small batch: one item per wavefront
   hipStream_t side = st;
   if (fork) {
@@ -1421,6 +1443,26 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   }
   // large batches compare encodings (kernels_verify.hip, k_verify_final_enc): R is only decoded for signatures that fail
   const bool by_enc = !coop && g.opt_verify_by_enc != 0;
+  if (by_enc && fork && pubs_ext == nullptr && g.opt_mul_algo == 1 && g.opt_ladder_y_only != 0 && n <= pair_lim(g, g.opt_ladder_pair_max)) {
+    // DKG-sized batch from key BYTES: the decode of A (252 dependent squarings) leaves the critical path.  k_verify_hash gives h and every flag the
+    // bytes decide; the two-lane ladder starts on A's y at once; the side stream decodes A, then multiplies s*B; k_ladder_recover joins (round 4).
+    rc = ensure_ws_part(g, r, n); if (rc) return rc;
+    uint4* state = reinterpret_cast<uint4*>(r->part);
+    { ProfScope ps(g, side, KID_DECODE); LAUNCHCK(launch::decode_or_identity(side, pubs, n, a_ext, flags_r)); }      // flags_r: free in this path, holds "A decodes"
+    HIPCK(hipEventRecord(r->ev_mid, side));
+    { ProfScope ps(g, st, KID_VERIFY_PREP); LAUNCHCK(launch::verify_hash(st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf)); }
+    HIPCK(hipEventRecord(r->ev_fork, st));                 // s*B reads sbuf
+    HIPCK(hipStreamWaitEvent(side, r->ev_fork, 0));
+    rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side); if (rc) return rc;
+    HIPCK(hipEventRecord(r->ev_join, side));
+    { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::mul_ladder_pair_y(st, hbuf, n, pubs, state, 3)); }      // h < L < 2^253
+    HIPCK(hipStreamWaitEvent(st, r->ev_mid, 0));
+    { ProfScope ps(g, st, KID_LADDER_RECOVER); LAUNCHCK(launch::ladder_recover(st, hbuf, n, a_ext, state, r->proj, r->proj_items, flags_a, flags_r)); }
+    HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
+    ProfScope ps(g, st, KID_VERIFY_FINAL);
+    LAUNCHCK(launch::verify_tail_enc(st, r->proj, r->proj_items, n, sigs, flags_a, flavor, status, take_done_flag(g, st, n)));
+    return KYB_OK;
+  }
   if (!by_enc) {
     ProfScope ps(g, side, KID_VERIFY_PREP_R);
     if (coop) LAUNCHCK(launch::verify_prep_r_coop(side, sigs, n, flags_r, r->proj, r->proj_items, 2 * n));

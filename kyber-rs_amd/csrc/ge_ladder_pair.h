@@ -116,4 +116,38 @@ __device__ __forceinline__ void ge_scalarmult_ladder_pair(ge_p2& out, const uint
   mont_recover_to_edwards_proj(out, m, x2, z2, x3, z3, mag[0] & 1u, neg);
 }
 
+// ---- the same from the WIRE encoding, the square root taken out of the way (round 4) ---------------------------------------------------------
+// A multiplication from 32 bytes (Diffie-Hellman: dh_impl.rs:74-80 on a key as it arrived) starts with unmarshal_binary, whose square root
+// z^((p-5)/8) is a chain of 252 squarings — a fifth of a DKG-sized call.  The ladder does not need it: u(P) = (1 + y) / (1 - y) comes from the
+// y of the encoding alone, and the x-only state the ladder leaves does not depend on a common factor of (U1, W1) — (x2 : z2) is built by the
+// doubling alone, (x3 : z3) is scaled by a power of that factor as a whole, and the recovery formulas are homogeneous in (x3, z3).  So the
+// ladder runs on (1 + y : 1 - y) while ANOTHER kernel on a side stream decodes the point; a third, short kernel builds the full projective
+// image (mont_prep_proj on the decoded point) and recovers y(kP) from the stored state.  The point is the same, hence its bytes.
+// Encodings that decode to no point, and the points with x = 0 (u = 0 or infinity), ride the ladder with whatever their y gives; the recovery
+// replaces the result by what the flags of the decoded point say, exactly as the one-kernel form does.
+__device__ __forceinline__ void mont_ladder_pair_from_y(fe& x2, fe& z2, fe& x3, fe& z3, const uint32_t a[8], const uint32_t enc_words[8], int skip, uint32_t odd) {
+  uint32_t neg, mag[8];
+  sc_effective(neg, mag, a);
+  pair_lane s;
+  pair_lane_init(s, odd);
+  fe y, one, U1, W1, q1, q2;
+  fe_from_words(y, enc_words);            // bit 255 ignored, y >= p accepted (fe_from_bytes)
+  fe_one(one);
+  fe_add(U1, one, y);                     // 1 + y
+  fe_sub(W1, one, y);                     // 1 - y  (3T)
+  fe_reduce_weak(U1, U1);
+  fe_reduce_weak(W1, W1);                 // tight: operands of the ladder's last product and its first additions
+  mont_ladder_pair(q1, q2, U1, W1, mag, skip, s);
+  fe_quad<KYB_QP_EVEN>(x2, q1); fe_quad<KYB_QP_ODD>(z2, q1);
+  fe_quad<KYB_QP_EVEN>(x3, q2); fe_quad<KYB_QP_ODD>(z3, q2);
+}
+// ... and the end of it, one lane per item: the decoded point (any representation), the state the ladder left
+__device__ __forceinline__ void ge_recover_from_state(ge_p2& out, const uint32_t a[8], const ge_p3& P, const fe& x2, const fe& z2, const fe& x3, const fe& z3) {
+  uint32_t neg, mag[8];
+  sc_effective(neg, mag, a);
+  mont_point_proj m;
+  mont_prep_proj(m, P);
+  mont_recover_to_edwards_proj(out, m, x2, z2, x3, z3, mag[0] & 1u, neg);
+}
+
 }  // namespace kyb

@@ -150,6 +150,58 @@ k_mul_ladder_pair(const uint8_t* __restrict__ scalars, size_t n, const int32_t* 
   if (odd == 0u) store_proj(proj, stride, i, r.X, r.Y, r.Z);
 }
 
+// The two-lane ladder from the wire encoding (ge_ladder_pair.h, "from the WIRE encoding"): the ladder on (1 + y : 1 - y), its x-only state to a
+// 160-byte record per item (x2, z2, x3, z3 as raw tight limbs); k_decode_or_identity runs beside it on a side stream; k_ladder_recover joins them.
+__device__ __forceinline__ void store_state(uint4* base, size_t i, const fe& a, const fe& b, const fe& c, const fe& d) {
+  uint32_t f[40];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { f[k] = a.v[k]; f[10 + k] = b.v[k]; f[20 + k] = c.v[k]; f[30 + k] = d.v[k]; }
+  uint4* p = base + 10 * i;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) p[q] = make_uint4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+}
+__device__ __forceinline__ void load_state(fe& a, fe& b, fe& c, fe& d, const uint4* base, size_t i) {
+  uint32_t f[40];
+  const uint4* p = base + 10 * i;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) { const uint4 v = p[q]; f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w; }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { a.v[k] = f[k]; b.v[k] = f[10 + k]; c.v[k] = f[20 + k]; d.v[k] = f[30 + k]; }
+}
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_mul_ladder_pair_y(const uint8_t* __restrict__ scalars, size_t n, const uint8_t* __restrict__ pts_enc, uint4* __restrict__ state, int skip_bits) {
+  // the decode kernel runs beside this one and its workgroups land on the same CUs (both grids start at CU 0): the ladder is the critical path, so its
+  // wavefronts win the issue arbitration and the decode takes the slots a lone ladder wavefront leaves empty anyway (profiles/r04/mid_size_kernels.log)
+  __builtin_amdgcn_s_setprio(3);
+  const size_t lane = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  const size_t i = lane >> 1;
+  const uint32_t odd = threadIdx.x & 1u;
+  if (i >= n) return;
+  uint32_t a[8], w[8];
+  load_words8(a, scalars, i);
+  load_words8(w, pts_enc, i);
+  fe x2, z2, x3, z3;
+  mont_ladder_pair_from_y(x2, z2, x3, z3, a, w, skip_bits, odd);
+  if (odd == 0u) store_state(state, i, x2, z2, x3, z3);
+}
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_ladder_recover(const uint8_t* __restrict__ scalars, size_t n, const int32_t* __restrict__ pts_ext, const uint4* __restrict__ state, uint4* __restrict__ proj, size_t stride,
+                 uint8_t* __restrict__ flags, const uint8_t* __restrict__ dec_ok) {
+  KYB_SHORT_KERNEL_PRIORITY();
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  if (flags != nullptr) flags[i] = (uint8_t)(flags[i] | ((dec_ok[i] & 1u) << 2));      // verification: "the key decodes" joins the flags k_verify_hash wrote
+  uint32_t a[8];
+  load_words8(a, scalars, i);
+  ge_p3 P;
+  load_ext(P, pts_ext, i);
+  fe x2, z2, x3, z3;
+  load_state(x2, z2, x3, z3, state, i);
+  ge_p2 r;
+  ge_recover_from_state(r, a, P, x2, z2, x3, z3);
+  store_proj(proj, stride, i, r.X, r.Y, r.Z);
+}
+
 // One halving pass of the segmented sum behind kyb_lincomb_batch: in each of the m groups (group g
 // starts at record g * gstride and currently holds `len` partial sums) record j + half is added onto
 // record j for j < len - half.  ceil(log2 t) passes leave the group total in the group's first record.
@@ -205,6 +257,14 @@ hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, ui
 }
 hipError_t mul_ladder_pair(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, size_t pts_mod, uint4* proj, size_t stride, int skip_bits) {
   hipLaunchKernelGGL(k_mul_ladder_pair, dim3(blocks_for(2 * n)), dim3(KYB_BLOCK), 0, st, sc, n, pext, pts_mod, proj, stride, skip_bits);
+  return hipGetLastError();
+}
+hipError_t mul_ladder_pair_y(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits) {
+  hipLaunchKernelGGL(k_mul_ladder_pair_y, dim3(blocks_for(2 * n)), dim3(KYB_BLOCK), 0, st, sc, n, penc, state, skip_bits);
+  return hipGetLastError();
+}
+hipError_t ladder_recover(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, const uint4* state, uint4* proj, size_t stride, uint8_t* flags, const uint8_t* dec_ok) {
+  hipLaunchKernelGGL(k_ladder_recover, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, pext, state, proj, stride, flags, dec_ok);
   return hipGetLastError();
 }
 hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half) {

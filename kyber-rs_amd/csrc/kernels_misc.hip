@@ -19,10 +19,10 @@ using namespace kyb;
 // and gets the reference's own answer for it (0^(p-2) = 0 -> x = y = 0), so one bad item cannot
 // disturb its K-1 neighbours.  Item i is read from record i * src_mul (src_mul = group length after a
 // segmented sum, 1 otherwise).
-__global__ void __launch_bounds__(KYB_BLOCK, 2)
-k_finish(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, size_t src_mul) {
+template <int K>
+__device__ __forceinline__ void finish_body(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, size_t src_mul) {
   KYB_SHORT_KERNEL_PRIORITY();
-  const size_t M = (n + FINISH_K - 1) / FINISH_K;
+  const size_t M = (n + K - 1) / K;
   const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (j >= M) return;
   auto load = [&](int t, fe& z) {
@@ -57,7 +57,18 @@ k_finish(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __res
   };
   fe unused_prefix, unused_inv;
   fe_one(unused_prefix);
-  batch_invert<0, FINISH_K>(unused_prefix, unused_inv, load, emit);
+  batch_invert<0, K>(unused_prefix, unused_inv, load, emit);
+}
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_finish(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, size_t src_mul) {
+  finish_body<FINISH_K>(proj, stride, n, out_enc, out_ext, src_mul);
+}
+// The same with 4 items per inversion, for launches of at most a wavefront per SIMD (the DKG-sized calls, where this kernel is one lane's
+// chain of 600 divsteps plus 3 (K - 1) + 2 K products and nothing else runs beside it): half the products of the chain (profiles/r03/ab_finish_k.log
+// measured -2..7 % per call for these sizes; full batches keep 8).
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_finish4(const uint4* __restrict__ proj, size_t stride, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext, size_t src_mul) {
+  finish_body<4>(proj, stride, n, out_enc, out_ext, src_mul);
 }
 
 
@@ -247,7 +258,12 @@ hipError_t diag_mad_peak(hipStream_t st, int grid, int iters, uint64_t* stamps, 
   return hipGetLastError();
 }
 static inline unsigned blocks_for(size_t n) { return (unsigned)((n + KYB_BLOCK - 1) / KYB_BLOCK); }
-hipError_t finish(hipStream_t st, const uint4* proj, size_t stride, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul) {
+hipError_t finish(hipStream_t st, const uint4* proj, size_t stride, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul, bool four) {
+  if (four) {
+    const size_t M4 = (n + 3) / 4;
+    hipLaunchKernelGGL(k_finish4, dim3(blocks_for(M4)), dim3(KYB_BLOCK), 0, st, proj, stride, n, oenc, oext, src_mul);
+    return hipGetLastError();
+  }
   const size_t M = (n + FINISH_K - 1) / FINISH_K;
   hipLaunchKernelGGL(k_finish, dim3(blocks_for(M)), dim3(KYB_BLOCK), 0, st, proj, stride, n, oenc, oext, src_mul);
   return hipGetLastError();

@@ -136,6 +136,36 @@ k_verify_prep(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs
   store_words8(sbuf, i, sig + 8);
   store_ext(a_ext, i, A.X, A.Y, A.Z, A.T);
 }
+// The A half WITHOUT the decode (DKG-sized batches, round 4): everything the bytes give — s < L, is_canonical, has_small_order (it looks at y mod p
+// only, verify_prep_a_point_with), the challenge h — so that the two-lane ladder can start on the y of the key at once (ge_ladder_pair.h, "from the
+// WIRE encoding") while k_decode_or_identity looks for x on the side stream; k_ladder_recover adds bit 2 (A decodes) to the flags when it joins them.
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_verify_hash(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ msgs, const uint32_t* __restrict__ msg_off, size_t n,
+              uint8_t* __restrict__ flags_a, uint8_t* __restrict__ hbuf, uint8_t* __restrict__ sbuf) {
+  KYB_SHORT_KERNEL_PRIORITY();
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t pub[8], sig[16], h[8];
+  load_words8(pub, pubs, i);
+  load_words8(sig, sigs, 2 * i);
+  load_words8(sig + 8, sigs, 2 * i + 1);
+  const uint32_t off = msg_off[i], len = msg_off[i + 1] - off;
+  fe y;
+  fe_from_words(y, pub);
+  const uint32_t fl = sc_is_canonical_w(sig + 8) | (pt_is_canonical_w(pub) << 1) | (pt_has_small_order(y) << 3);
+  uint32_t ra[16];
+  for (int k = 0; k < 8; ++k) { ra[k] = sig[k]; ra[8 + k] = pub[k]; }
+  sha512_ctx c;
+  sha512_init(c);
+  sha512_words64(c, ra);
+  sha512_bytes(c, msgs + off, len);
+  uint32_t dig[16];
+  sha512_final(dig, c);
+  sc_reduce512(h, dig);
+  flags_a[i] = (uint8_t)fl;
+  store_words8(hbuf, i, h);
+  store_words8(sbuf, i, sig + 8);
+}
 // the same with the public keys given as points (schnorr::verify / eddsa::verify, verify.h): pub_enc = their marshal_binary, made by
 // k_encode_batched in front of this kernel; no square root unless the limbs are not a point of the curve
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
@@ -291,6 +321,10 @@ static inline unsigned blocks_for(size_t n) { return (unsigned)((n + KYB_BLOCK -
 hipError_t verify_prep(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,
                        uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf, int32_t* a_ext) {
   hipLaunchKernelGGL(k_verify_prep, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext);
+  return hipGetLastError();
+}
+hipError_t verify_hash(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf) {
+  hipLaunchKernelGGL(k_verify_hash, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf);
   return hipGetLastError();
 }
 hipError_t verify_prep_pts(hipStream_t st, const uint8_t* pub_enc, const int32_t* pubs_ext, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,

@@ -65,6 +65,13 @@ hipError_t mont_prep(hipStream_t st, const int32_t* pext, size_t n, uint4* proj,
 hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, uint4* proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits,
                       const uint32_t* top_or = nullptr, uint32_t* zero_next = nullptr);
 hipError_t mul_ladder_pair(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, size_t pts_mod, uint4* proj, size_t stride, int skip_bits);
+// the same from wire encodings: the ladder on (1 + y : 1 - y) leaves its x-only state (160 bytes per item) while the decode runs elsewhere;
+// ladder_recover turns state + decoded point into the projective result (ge_ladder_pair.h)
+hipError_t mul_ladder_pair_y(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits);
+hipError_t ladder_recover(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, const uint4* state, uint4* proj, size_t stride,
+                          uint8_t* flags = nullptr, const uint8_t* dec_ok = nullptr);       // flags != nullptr: flags[i] |= dec_ok[i] << 2 (verification)
+// verification, the A half without the decode: flags (bits 0, 1, 3), h, s from the bytes alone (kernels_verify.hip)
+hipError_t verify_hash(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf);
 hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half);
 hipError_t ext_to_proj(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride, size_t rows = 0, size_t cols = 0);      // rows != 0: transposed, as decode_to_proj
 
@@ -122,7 +129,7 @@ hipError_t sign_hash(hipStream_t st, const uint8_t* x, const uint8_t* k, const u
 hipError_t eddsa_prep(hipStream_t st, const uint8_t* seeds, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* xbuf, uint8_t* kbuf);
 
 // ---- kernels_misc.hip / kernels_window.hip ----
-hipError_t finish(hipStream_t st, const uint4* proj, size_t stride, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul);
+hipError_t finish(hipStream_t st, const uint4* proj, size_t stride, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul, bool four = false);      // four: 4 items per shared inversion (k_finish4)
 hipError_t encode_batched(hipStream_t st, const int32_t* pext, size_t n, uint8_t* oenc);
 hipError_t mul_window(int masked, bool from_enc, bool split, int grid, hipStream_t st, const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n,
                       uint8_t* oenc, int32_t* oext, uint8_t* ok, uint4* ws, uint4* proj, size_t stride);

@@ -358,6 +358,21 @@ def test_verify_matches_oracle(engine, oracle):
             finally:
                 engine.set_option("verify.overlap", 1)
                 engine.set_option("verify.by_encoding", 1)
+    # the same cases through the batch kernels of DKG-sized calls (small-batch kernels off): with ladder.y_only the key's decode runs beside the
+    # two-lane ladder, which starts on the y of the key bytes (k_verify_hash / k_mul_ladder_pair_y / k_ladder_recover, round 4); 0 = decode first
+    saved = {k: engine.get_option(k) for k in ("coop.max_items", "coop.base_max_items", "coop.verify_max_items", "ladder.y_only")}
+    try:
+        for k in ("coop.max_items", "coop.base_max_items", "coop.verify_max_items"):
+            engine.set_option(k, 0)
+        for y_only in (1, 0):
+            engine.set_option("ladder.y_only", y_only)
+            for flavor in (0, 1):
+                want = np.array([oracle.verify(flavor, *c) for c in cases], dtype=np.uint8)
+                for _ in range(2):
+                    assert np.array_equal(engine.verify(pubs, msgs, sigs, flavor), want), (y_only, flavor)
+    finally:
+        for k, v in saved.items():
+            engine.set_option(k, v)
     # all 1024 golden signatures verify; their messages are 0..1023 bytes long
     ps, ms, ss = [], [], []
     for ln in gzip.open(os.path.join(HERE, "golden", "sign.input.gz"), "rt").read().split("\n"):
@@ -527,6 +542,21 @@ def test_two_lane_ladder_matches_one_lane_and_oracle(engine, oracle):
             results[pair_max] = (g1, gext, lc_shared, lc_own)
         for a_, b_ in zip(results[0], results[1 << 20]):
             assert np.array_equal(a_, b_)                                 # limbs included: the same field operations on the same values
+        # from wire encodings the two-lane ladder runs on the y of the encoding while a side stream decodes x (ladder.y_only, round 4): the same
+        # bytes with the option off (decode first), on the quirk points, on encodings that do not decode, on y = +-1 (x = 0) and on non-canonical y
+        engine.set_option("ladder.pair_max_items", 1 << 20)
+        P_ = 2**255 - 19
+        special = [(1).to_bytes(32, "little"), (P_ - 1).to_bytes(32, "little"), (P_ + 1).to_bytes(32, "little"), bytes([1] + [0] * 30 + [0x80]), P_.to_bytes(32, "little")]
+        encs3 = np.frombuffer(b"".join(encs + special + [oracle.encode(p) for p in pts[30:900]]), dtype=np.uint8).reshape(-1, 32)
+        s3 = np.concatenate([synth.scalars(450, 618), synth.raw256(encs3.shape[0] - 450, 618)])
+        want3 = oracle.mul_enc_batch(s3, encs3, nthreads=8)
+        for y_only in (1, 0):
+            engine.set_option("ladder.y_only", y_only)
+            got, ok = engine.mul(sc, pts_enc=pe, want_ok=True)
+            assert ok.all() and [bytes(r).hex() for r in got] == [v["out"] for v in q], y_only
+            got3, ok3 = engine.mul(s3, pts_enc=encs3, want_ok=True)
+            assert np.array_equal(ok3, want3[1]) and np.array_equal(got3, want3[0]), y_only
+        engine.set_option("ladder.y_only", 1)
     finally:
         for k, v in saved.items():
             engine.set_option(k, v)

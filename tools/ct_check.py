@@ -42,6 +42,8 @@ SECRET_ARGS = {
     "_Z12k_mul_ladderILi3E": ("kernels_ladder", {0: "scalars"}),
     "_Z12k_mul_ladderILi2E": ("kernels_ladder", {0: "scalars"}),
     "_Z17k_mul_ladder_pair": ("kernels_ladder", {0: "scalars"}),
+    "_Z19k_mul_ladder_pair_y": ("kernels_ladder", {0: "scalars"}),
+    "_Z16k_ladder_recover": ("kernels_ladder", {0: "scalars", 24: "x-only state the ladder left (a function of the scalar)"}),
     "_Z11k_mont_prepPKim": ("kernels_ladder", {32: "scalars (top bits, canonical test)"}),
     "_Z12k_mul_base64ILb1ELi1024E": ("kernels_base", {0: "scalars", 8: "scalars_b"}),
     "_Z12k_mul_base64ILb1ELi768E": ("kernels_base", {0: "scalars", 8: "scalars_b"}),
@@ -55,6 +57,7 @@ SECRET_ARGS = {
     "_Z19k_pripoly_eval_part": ("kernels_verify", {0: "coefficients of secret polynomials"}),
     "_Z18k_pripoly_eval_sum": ("kernels_verify", {0: "partial values of secret polynomials"}),
     "_Z8k_finishPK": ("kernels_misc", {0: "projective results (a DH shared secret before its encoding)"}),
+    "_Z9k_finish4PK": ("kernels_misc", {0: "projective results (a DH shared secret before its encoding)"}),
 }
 # the windowed-table kernels (mul.algo = 0, radix-16 / -32 fixed base) are selectable cross-checks, not default paths; the public-input
 # kernels (verification, decoding, polynomial evaluation at public indices) have nothing to hide
