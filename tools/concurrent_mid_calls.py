@@ -29,9 +29,16 @@ print(f"threads, op, calls_per_s, items_per_s, mean_call_ms   ({N} items per cal
 VARIANTS = [(nt, {}) for nt in (1, 2, 4, 8, 16)] + [
     (16, {"coop.share_by_load": 0}),                       # thresholds as set, whatever else is in flight (the behaviour before this option)
     (16, {"verify.overlap": 0}),
+    (16, {"_shared_context": 1}),                          # ONE context for all 16 threads (a process-wide default context, as kyb_init gives): the calls are
+                                                           # serialised on its mutex, so each one has the chip to itself and must keep the latency kernels —
+                                                           # the in-flight count is taken AFTER the mutex (round 3 counted the queued threads too)
 ]
 for nt, opts in VARIANTS:
-    engines = [kyber_rs_amd.Engine(0, private=True) for _ in range(nt)]
+    shared = opts.pop("_shared_context", 0) if "_shared_context" in opts else 0
+    engines = [kyber_rs_amd.Engine(0, private=True) for _ in range(1 if shared else nt)]
+    if shared:
+        engines = engines * nt
+        print(f"# {nt} threads sharing ONE context (mean_call_ms = time a call is served, queueing included)", flush=True)
     for e in engines:
         for k_, v_ in opts.items():
             e.set_option(k_, v_)
@@ -64,5 +71,5 @@ for nt, opts in VARIANTS:
         assert all(ok)
         calls = sum(counts)
         print(f"{nt}, {op}, {calls / dt:.0f}, {calls * N / dt:.3e}, {dt * nt / max(calls, 1) * 1e3:.3f}", flush=True)
-    for e in engines:
+    for e in set(engines):
         e.close()
