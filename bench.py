@@ -687,12 +687,14 @@ def run_ranks(args):
         raise SystemExit(f"rank {rank}: asked to fail (KYB_BENCH_FAIL_RANK)")
     import torch
     import torch.distributed as dist
+    if args.same_device:                 # tests: every rank on GPU 0 (the one-GPU box; with --dist-backend gloo, RCCL wants a device per rank)
+        local = 0
     rt = StandinRuntime(local) if args.standin else GpuRuntime(local)
     dev = rt.dev
     backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.standin:
+        if args.standin or args.dist_backend == "gloo":
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -734,7 +736,7 @@ def run_ranks(args):
     gen_s = time.time() - t0
     elapsed = time_workload(w, eng, rt, args.steps, args.warmup, barrier)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -944,6 +946,8 @@ def main():
     ap.add_argument("--only", action="store_true", help="time the primary workload only (no `workloads` object)")
     ap.add_argument("--check", type=int, default=16384, help="items verified against the oracle after timing (per workload)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (kernel variant), repeatable")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)     # tests: real engines, gloo instead of RCCL
+    ap.add_argument("--same-device", action="store_true", help=argparse.SUPPRESS)                           # tests: every rank on GPU 0
     ap.add_argument("--standin", action="store_true", help=argparse.SUPPRESS)      # tests only: CPU stand-in engine over gloo, prints a line marked as no measurement
     args = ap.parse_args()
     if args.gpus < 1:

@@ -39,3 +39,15 @@ def test_bench_group_mode_one_rank():
     assert line["config"]["mode"] == "group" and line["table_transport"] == "none" and line["ranks_seen"] == 1
     assert line["parity_checked_items"] == 1024 and line["table_identical_on_all_ranks"] and line["value"] > 1e7
     assert "k_mul_ladder" in line["rank0_kernels_ms_per_step"]
+
+
+def test_two_real_ranks_on_the_one_gpu_run_the_sharded_configuration():
+    """`bench.py --gpus 2` as the driver will start it on a multi-GPU node — the parent spawns the ranks, each is a real engine process, rank 0 builds the
+    table and broadcasts it, the job is ONE batch cut into two shards, every rank checks its own shard against the oracle — except that both ranks sit
+    on GPU 0 and the process group is gloo (RCCL wants one device per rank): everything of the N > 1 path above the collective's transport"""
+    line = _run("--gpus", "2", "--total", "40001", "--steps", "2", "--warmup", "1", "--check", "512", "--only", "--no-cpu-baseline", "--dist-backend", "gloo", "--same-device")
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "strong" and line["dist_backend"] == "gloo"
+    assert line["config"]["total_items"] == 40001 and line["items_per_rank"] == [20000, 20001]
+    assert line["parity_checked_items_per_rank"] == [512, 512] and line["table_identical_on_all_ranks"]
+    assert line["launched_by"] == "self-spawned ranks" and line["value"] > 1e6
+    assert abs(line["value"] - 40001 * 2 / (line["ms_per_step"] * 2e-3)) <= 1e-3 * line["value"]

@@ -185,3 +185,38 @@ def test_random_graphs_match_the_eager_calls(eng, oracle):
         assert eng.defer_stats()["nodes_held"] == 1 and eng.defer_get(keep) == oracle.mul_base(_le(7))
     finally:
         eng.set_option("defer.max_nodes", 1 << 20)
+
+
+def test_threads_recording_into_one_arena(eng, oracle):
+    """four host threads record and ask on ONE context at the same time (the arena has its own lock; a flush evaluates everybody's nodes): every
+    thread gets its own results right"""
+    import threading
+    errors = []
+
+    def work(i):
+        try:
+            sc = synth.scalars(24, 300 + i)
+            want = oracle.mul_base_batch(sc)
+            for rnd in range(6):
+                hs = [eng.defer_mul_base(sc[j].tobytes()) for j in range(24)]
+                acc = hs[0]
+                for h in hs[1:]:
+                    acc = eng.defer_add(acc, h)
+                if [eng.defer_get(h) for h in hs] != [bytes(w) for w in want]:
+                    errors.append((i, rnd, "products"))
+                ext = [oracle.mul_base_ext(sc[j].tobytes()) for j in range(24)] if rnd == 0 else None
+                if ext is not None:
+                    s = ext[0]
+                    for e in ext[1:]:
+                        s = oracle.add(s, e)
+                    if eng.defer_get(acc) != oracle.encode(s):
+                        errors.append((i, rnd, "sum"))
+        except Exception as ex:  # noqa: BLE001
+            errors.append((i, repr(ex)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
