@@ -478,7 +478,15 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     point accepts such points, kyb_encode_batch pays the inversion when an encoding is wanted
  *   poly.segments     PubPoly::eval of few evaluations: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never
  *                     split the Horner chain, 2..32)
- *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder
+ *   ladder.y_only     1 (default): launches of at most ladder.pair_max_items items whose points come as 32-byte ENCODINGS (kyb_mul_batch with
+ *                     pts_enc, kyb_verify_batch) run the two-lane ladder on the y of the encoding — u = (1 + y) / (1 - y) needs no x — while a side
+ *                     stream takes the square root of the decode; a short kernel joins the two.  0: decode first, then the ladder.  Same results.
+ *   finish.four       1 (default): the batched encode shares one field inversion between 4 instead of 8 items when a launch leaves at most one
+ *                     wavefront per SIMD (shorter dependent chain; full batches keep 8).  Same results.
+ *   defer.fuse        1 (default): a flush of deferred points (kyb_defer_*) evaluates Horner chains and chains of additions as ONE call each; 0:
+ *                     level by level only.  Same results.
+ *   defer.max_nodes   nodes the deferred-point arena keeps before it drops the oldest (default 2^20, at least 16); a dropped handle is refused
+ *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder (and, with ladder.y_only, the decode of A)
  *   verify.by_encoding 1 (default): large batches test the equation as enc(s*B - h*A) == R bytes and decode R only on a mismatch
  *   host.zero_copy_kib  host-pointer calls whose arrays together fit this many KiB skip every hipMemcpy: the inputs are copied into the
  *                     context's page-locked buffer by the calling thread and the kernels read and write it over PCIe (default 4096).
