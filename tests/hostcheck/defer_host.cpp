@@ -1,0 +1,248 @@
+// The deferred-point evaluator (kyber-rs_amd/csrc/defer.inc) compiled for the CPU with the engine's batch entry points replaced by the oracle, and
+// run under AddressSanitizer + UBSan: random expression graphs, Horner chains, addition chains, stale handles, several threads on one arena — every
+// answer against the oracle's own eager evaluation.  A test of the HOST LOGIC of the product source (graph walking, chain recognition, batching, arena
+// bookkeeping) on a machine without a GPU; the engine calls behind it are exercised on the GPU by tests/test_gpu_deferred.py and test_gpu_vss_round.py.
+// Test infrastructure: built and run by tests/test_defer_host.py, nothing outside tests/ uses it.
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <random>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/kyber_ed25519.h"
+
+extern "C" {      // oracle/ed25519_oracle.c
+void orc_init(void);
+void orc_mul_base(uint8_t out_enc[32], int32_t out_ext[40], const uint8_t scalar[32]);
+void orc_mul(uint8_t out_enc[32], int32_t out_ext[40], const uint8_t scalar[32], const int32_t pt_ext[40]);
+int orc_decode(int32_t out_ext[40], const uint8_t enc[32]);
+void orc_encode(uint8_t enc[32], const int32_t ext[40]);
+void orc_add(int32_t out[40], const int32_t a[40], const int32_t b[40], int sub);
+void orc_neg(int32_t out[40], const int32_t a[40]);
+void orc_null(int32_t out[40]);
+void orc_base(int32_t out[40]);
+void orc_pubpoly_eval(uint8_t out_enc[32], const int32_t* commits_ext, size_t t, uint32_t index);
+}
+
+// ---- the little of the engine that defer.inc refers to ---------------------------------------------------------------------------------
+struct DeferArena;
+void defer_release(DeferArena* a);
+namespace {
+struct Ctx {
+  bool ready = true;
+  int device = 0;
+  std::mutex launch_mu;
+  DeferArena* defer = nullptr;
+  std::atomic<int> opt_defer_fuse{1};
+  std::atomic<int> opt_defer_max_nodes{1 << 20};
+};
+Ctx g_ctx;
+Ctx* cur() { return &g_ctx; }
+thread_local std::string g_err;
+int fail(int code, const char* msg) { g_err = msg; return code; }
+std::atomic<long> g_calls{0}, g_items{0};
+}  // namespace
+#define ENTER() Ctx* ctx_ = cur(); Ctx& g = *ctx_
+
+// ---- the batch entry points the evaluator calls, answered by the oracle ----------------------------------------------------------------
+extern "C" {
+int kyb_mul_base_batch(const uint8_t* s, size_t n, uint8_t* enc, int32_t* ext) {
+  ++g_calls; g_items += (long)n;
+  for (size_t i = 0; i < n; ++i) orc_mul_base(enc ? enc + 32 * i : nullptr, ext ? ext + 40 * i : nullptr, s + 32 * i);
+  return KYB_OK;
+}
+int kyb_mul_batch(const uint8_t* s, const uint8_t* pe, const int32_t* px, size_t n, uint8_t* enc, int32_t* ext, uint8_t* ok) {
+  ++g_calls; g_items += (long)n;
+  if (pe != nullptr || ok != nullptr) return fail(KYB_E_BAD_ARG, "the evaluator passes limbs");
+  for (size_t i = 0; i < n; ++i) orc_mul(enc ? enc + 32 * i : nullptr, ext ? ext + 40 * i : nullptr, s + 32 * i, px + 40 * i);
+  return KYB_OK;
+}
+int kyb_add_batch(const int32_t* a, const int32_t* b, size_t n, int32_t* out, int sub) {
+  ++g_calls; g_items += (long)n;
+  for (size_t i = 0; i < n; ++i) orc_add(out + 40 * i, a + 40 * i, b + 40 * i, sub);
+  return KYB_OK;
+}
+int kyb_encode_batch(const int32_t* ext, size_t n, uint8_t* enc) {
+  ++g_calls; g_items += (long)n;
+  for (size_t i = 0; i < n; ++i) orc_encode(enc + 32 * i, ext + 40 * i);
+  return KYB_OK;
+}
+int kyb_equal_batch(const int32_t* a, const int32_t* b, size_t n, uint8_t* eq) {
+  ++g_calls;
+  for (size_t i = 0; i < n; ++i) { uint8_t ea[32], eb[32]; orc_encode(ea, a + 40 * i); orc_encode(eb, b + 40 * i); eq[i] = memcmp(ea, eb, 32) == 0; }
+  return KYB_OK;
+}
+int kyb_pubpoly_eval_multi_batch(const int32_t* commits, size_t t, size_t m, const uint32_t* idx, size_t k, uint8_t* enc, int32_t* ext) {
+  ++g_calls; g_items += (long)(m * k);
+  for (size_t gi = 0; gi < m; ++gi)
+    for (size_t j = 0; j < k; ++j) {
+      uint8_t e[32];
+      orc_pubpoly_eval(e, commits + 40 * t * gi, t, idx[gi * k + j]);
+      if (enc) memcpy(enc + 32 * (gi * k + j), e, 32);
+      if (ext && !orc_decode(ext + 40 * (gi * k + j), e)) return fail(KYB_E_BAD_ARG, "oracle produced an encoding that does not decode");
+    }
+  return KYB_OK;
+}
+int kyb_sum_batch(const int32_t* pts, size_t m, size_t t, uint8_t* enc, int32_t* ext) {
+  ++g_calls; g_items += (long)(m * t);
+  for (size_t gi = 0; gi < m; ++gi) {
+    int32_t acc[40];
+    orc_null(acc);
+    for (size_t j = 0; j < t; ++j) orc_add(acc, acc, pts + 40 * (gi * t + j), 0);
+    if (enc) orc_encode(enc + 32 * gi, acc);
+    if (ext) memcpy(ext + 40 * gi, acc, 160);
+  }
+  return KYB_OK;
+}
+}
+
+#include "../../kyber-rs_amd/csrc/defer.inc"
+
+// ---- the test --------------------------------------------------------------------------------------------------------------------------
+static int failures = 0;
+#define CHECK(c, what) do { if (!(c)) { std::printf("FAIL line %d: %s (%s)\n", __LINE__, what, g_err.c_str()); ++failures; } } while (0)
+struct Val { uint64_t h; int32_t ext[40]; };
+static std::string enc_of(const int32_t* ext) { uint8_t e[32]; orc_encode(e, ext); return std::string((const char*)e, 32); }
+static std::string got_enc(uint64_t h) { uint8_t e[32]; if (kyb_defer_get(h, nullptr, e) != KYB_OK) return "error: " + g_err; return std::string((const char*)e, 32); }
+static void scalar_small(uint8_t s[32], uint32_t x) { memset(s, 0, 32); memcpy(s, &x, 4); }
+
+static void random_graphs(unsigned seed, int steps) {
+  std::mt19937_64 rng(seed);
+  std::vector<Val> nodes;
+  auto rnd_scalar = [&](uint8_t s[32]) { for (int i = 0; i < 32; ++i) s[i] = (uint8_t)rng(); if (rng() % 3 == 0) { memset(s + 1, 0, 31); } if (rng() % 4) s[31] &= 0x0f; };
+  for (int i = 0; i < 5; ++i) { Val v; uint8_t s[32]; rnd_scalar(s); orc_mul_base(nullptr, v.ext, s); CHECK(kyb_defer_input(v.ext, &v.h) == KYB_OK, "input"); nodes.push_back(v); }
+  { Val v; orc_null(v.ext); CHECK(kyb_defer_null(&v.h) == KYB_OK, "null"); nodes.push_back(v); }
+  { Val v; orc_base(v.ext); CHECK(kyb_defer_base(&v.h) == KYB_OK, "base"); nodes.push_back(v); }
+  for (int st = 0; st < steps; ++st) {
+    const Val a = nodes[rng() % nodes.size()], b = nodes[rng() % nodes.size()];
+    uint8_t s[32]; rnd_scalar(s);
+    Val v;
+    switch (rng() % 7) {
+      case 0: orc_mul_base(nullptr, v.ext, s); CHECK(kyb_defer_mul_base(s, &v.h) == KYB_OK, "mul_base"); nodes.push_back(v); break;
+      case 1: orc_mul(nullptr, v.ext, s, a.ext); CHECK(kyb_defer_mul(s, a.h, &v.h) == KYB_OK, "mul"); nodes.push_back(v); break;
+      case 2: orc_add(v.ext, a.ext, b.ext, 0); CHECK(kyb_defer_add(a.h, b.h, 0, &v.h) == KYB_OK, "add"); nodes.push_back(v); break;
+      case 3: orc_add(v.ext, a.ext, b.ext, 1); CHECK(kyb_defer_add(a.h, b.h, 1, &v.h) == KYB_OK, "sub"); nodes.push_back(v); break;
+      case 4: orc_neg(v.ext, a.ext); CHECK(kyb_defer_neg(a.h, &v.h) == KYB_OK, "neg"); nodes.push_back(v); break;
+      case 5: {      // a short Horner chain with a small multiplier on top of a
+        uint8_t x[32]; scalar_small(x, (uint32_t)(1 + rng() % 9));
+        Val cur = a;
+        const int len = 1 + (int)(rng() % 5);
+        for (int k = 0; k < len; ++k) {
+          const Val c = nodes[rng() % nodes.size()];
+          Val m, s2;
+          orc_mul(nullptr, m.ext, x, cur.ext); CHECK(kyb_defer_mul(x, cur.h, &m.h) == KYB_OK, "chain mul");
+          orc_add(s2.ext, m.ext, c.ext, 0); CHECK((rng() & 1 ? kyb_defer_add(m.h, c.h, 0, &s2.h) : kyb_defer_add(c.h, m.h, 0, &s2.h)) == KYB_OK, "chain add");
+          if (rng() % 4 == 0) nodes.push_back(s2);          // sometimes an inner node is kept and asked for later
+          cur = s2;
+        }
+        nodes.push_back(cur);
+        break;
+      }
+      default: {
+        const int k = (int)(rng() % 3);
+        if (k == 0) CHECK(got_enc(a.h) == enc_of(a.ext), "get");
+        else if (k == 1) { uint8_t eq = 2; CHECK(kyb_defer_equal(a.h, b.h, &eq) == KYB_OK && (eq != 0) == (enc_of(a.ext) == enc_of(b.ext)), "equal"); }
+        else CHECK(kyb_defer_flush() == KYB_OK, "flush");
+      }
+    }
+  }
+  for (const Val& v : nodes) {
+    int32_t ext[40]; uint8_t e[32];
+    CHECK(kyb_defer_get(v.h, ext, e) == KYB_OK, "final get");
+    CHECK(std::string((const char*)e, 32) == enc_of(v.ext) && enc_of(ext) == enc_of(v.ext), "final value");
+  }
+}
+
+int main() {
+  orc_init();
+  for (unsigned seed = 1; seed <= 12; ++seed) {
+    g_ctx.opt_defer_fuse = seed % 4 != 0;
+    random_graphs(seed, 220);
+  }
+  g_ctx.opt_defer_fuse = 1;
+  // PubPoly::eval: one call; six chains: still one call
+  {
+    const size_t t = 17;
+    std::vector<int32_t> commits(40 * t);
+    std::vector<uint64_t> hc(t);
+    for (size_t j = 0; j < t; ++j) { uint8_t s[32]; scalar_small(s, 1000 + (uint32_t)j); orc_mul_base(nullptr, &commits[40 * j], s); CHECK(kyb_defer_input(&commits[40 * j], &hc[j]) == KYB_OK, "commit"); }
+    auto record = [&](uint32_t index) {
+      uint8_t x[32]; scalar_small(x, index + 1);
+      uint64_t v; CHECK(kyb_defer_null(&v) == KYB_OK, "null");
+      for (size_t j = t; j-- > 0;) { uint64_t m, a; CHECK(kyb_defer_mul(x, v, &m) == KYB_OK && kyb_defer_add(m, hc[j], 0, &a) == KYB_OK, "horner"); v = a; }
+      return v;
+    };
+    uint64_t st0[8], st1[8];
+    kyb_defer_stats(st0, 8);
+    long c0 = g_calls;
+    std::vector<uint64_t> hs;
+    for (uint32_t i : {0u, 5u, 63u, 4000000000u}) hs.push_back(record(i));
+    CHECK(kyb_defer_flush() == KYB_OK, "flush");
+    kyb_defer_stats(st1, 8);
+    CHECK(g_calls - c0 == 1 && st1[3] - st0[3] == 4, "four chains of one length: one engine call");
+    size_t n = 0;
+    for (uint32_t i : {0u, 5u, 63u, 4000000000u}) { uint8_t e[32]; orc_pubpoly_eval(e, commits.data(), t, i); CHECK(got_enc(hs[n++]) == std::string((const char*)e, 32), "horner value"); }
+  }
+  // recover_commit: one batch of products, one sum
+  {
+    const size_t t = 9;
+    uint64_t acc; CHECK(kyb_defer_null(&acc) == KYB_OK, "null");
+    int32_t want[40]; orc_null(want);
+    long c0 = g_calls;
+    for (size_t j = 0; j < t; ++j) {
+      uint8_t s[32]; for (int i = 0; i < 32; ++i) s[i] = (uint8_t)(37 * j + i); s[31] &= 0x0f;
+      int32_t p[40], prod[40]; uint8_t sp[32]; scalar_small(sp, 77 + (uint32_t)j); orc_mul_base(nullptr, p, sp);
+      uint64_t hp, hm, ha;
+      CHECK(kyb_defer_input(p, &hp) == KYB_OK && kyb_defer_mul(s, hp, &hm) == KYB_OK && kyb_defer_add(acc, hm, 0, &ha) == KYB_OK, "lincomb");
+      acc = ha;
+      orc_mul(nullptr, prod, s, p); orc_add(want, want, prod, 0);
+    }
+    CHECK(got_enc(acc) == enc_of(want) && g_calls - c0 == 2, "sum chain: two engine calls");
+  }
+  // a small arena: old handles become stale, never wrong; floor / mark
+  {
+    g_ctx.opt_defer_max_nodes = 32;
+    uint8_t s[32]; scalar_small(s, 5);
+    uint64_t first, h;
+    CHECK(kyb_defer_mul_base(s, &first) == KYB_OK, "first");
+    for (uint32_t i = 0; i < 100; ++i) { scalar_small(s, i); CHECK(kyb_defer_mul_base(s, &h) == KYB_OK, "fill"); }
+    uint8_t e[32];
+    CHECK(kyb_defer_get(first, nullptr, e) == KYB_E_BAD_ARG && g_err.find("stale") != std::string::npos, "stale handle refused");
+    CHECK(kyb_defer_get(h, nullptr, e) == KYB_OK, "newest handle");
+    const uint64_t mark = kyb_defer_mark();
+    scalar_small(s, 7);
+    CHECK(kyb_defer_mul_base(s, &h) == KYB_OK && kyb_defer_floor(mark) == KYB_OK, "floor");
+    uint64_t st[8]; kyb_defer_stats(st, 8);
+    uint8_t w[32]; orc_mul_base(w, nullptr, s);
+    CHECK(st[6] == 1 && kyb_defer_get(h, nullptr, e) == KYB_OK && memcmp(e, w, 32) == 0, "what was recorded after the mark survives");
+    CHECK(kyb_defer_get(0, nullptr, e) == KYB_E_BAD_ARG && kyb_defer_get(h + 1000, nullptr, e) == KYB_E_BAD_ARG, "null / unknown handles");
+    g_ctx.opt_defer_max_nodes = 1 << 20;
+  }
+  // four threads on the one arena
+  {
+    std::vector<std::thread> th;
+    std::atomic<int> bad{0};
+    for (int i = 0; i < 4; ++i)
+      th.emplace_back([i, &bad] {
+        for (int r = 0; r < 20; ++r) {
+          uint64_t hs[12];
+          for (uint32_t j = 0; j < 12; ++j) { uint8_t s[32]; scalar_small(s, 100 * (uint32_t)i + j + 1); if (kyb_defer_mul_base(s, &hs[j]) != KYB_OK) ++bad; }
+          for (uint32_t j = 0; j < 12; ++j) { uint8_t s[32], e[32], w[32]; scalar_small(s, 100 * (uint32_t)i + j + 1); orc_mul_base(w, nullptr, s); if (kyb_defer_get(hs[j], nullptr, e) != KYB_OK || memcmp(e, w, 32)) ++bad; }
+        }
+      });
+    for (auto& t : th) t.join();
+    CHECK(bad == 0, "threads");
+  }
+  delete g_ctx.defer;
+  std::printf("%s: %ld engine calls for %ld items\n", failures ? "FAILED" : "OK", g_calls.load(), g_items.load());
+  return failures ? 1 : 0;
+}
