@@ -14,7 +14,8 @@
 //! in batches, when somebody needs bytes or limbs (`marshal_binary`, `eq`, `hash`, `data`, serde, the batch helpers).  Unmodified protocol
 //! code then gets one engine call for the t multiplications of `PriPoly::commit` and one for the whole Horner chain of `PubPoly::eval`
 //! (a Pedersen dealer round, n = 64, t = 43, call by call: 616 ms eager, 46 ms deferred; tests/cpp/test_vss_round.cpp is the same logic in
-//! C++).  `Point` stays `Copy`: handles are plain numbers, the arena keeps evaluated nodes until `defer_floor(mark)`.
+//! C++).  `Point` stays `Copy` and `Send`: handles are plain numbers that name the arena (the recording thread's context) they came from, so a
+//! point recorded on one thread can be marshalled or multiplied on another; the arena keeps evaluated nodes until `defer_floor(mark)`.
 //! `add` / `sub` of a single pair call the reference's group-element formulas (`ge.rs`) on the same limbs: nine field
 //! multiplications are not worth a round trip to the GPU; vectors of pairs go to the engine (`add_batch`).
 //! Which reference method each one stands for: INTEGRATION.md §3.

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <random>
 #include <string>
@@ -45,8 +46,9 @@ struct Ctx {
   std::atomic<int> opt_defer_fuse{1};
   std::atomic<int> opt_defer_max_nodes{1 << 20};
 };
-Ctx g_ctx;
-Ctx* cur() { return &g_ctx; }
+Ctx g_ctx, g_ctx2;
+thread_local Ctx* tl_ctx = &g_ctx;
+Ctx* cur() { return tl_ctx; }
 thread_local std::string g_err;
 int fail(int code, const char* msg) { g_err = msg; return code; }
 std::atomic<long> g_calls{0}, g_items{0};
@@ -242,7 +244,32 @@ int main() {
     for (auto& t : th) t.join();
     CHECK(bad == 0, "threads");
   }
-  delete g_ctx.defer;
+  // a handle names its arena: a point recorded through one context is read, and used as an operand, through another — also after the first context is gone
+  {
+    uint8_t s1[32], s2[32], e[32], w[32];
+    scalar_small(s1, 4242); scalar_small(s2, 77);
+    uint64_t h1, h2, h3, mine;
+    CHECK(kyb_defer_mul_base(s1, &h1) == KYB_OK, "recorded in the first arena");
+    tl_ctx = &g_ctx2;
+    CHECK(kyb_defer_mul_base(s1, &mine) == KYB_OK && (mine >> 40) != (h1 >> 40), "handles of two arenas never collide");
+    CHECK(kyb_defer_mul(s2, h1, &h2) == KYB_OK && kyb_defer_add(h2, h1, 0, &h3) == KYB_OK, "foreign operands");
+    int32_t p1[40], p2[40], p3[40];
+    orc_mul_base(nullptr, p1, s1); orc_mul(nullptr, p2, s2, p1); orc_add(p3, p2, p1, 0);
+    CHECK(got_enc(h3) == enc_of(p3) && got_enc(h1) == enc_of(p1), "values across arenas");
+    uint8_t eq = 0;
+    CHECK(kyb_defer_equal(h1, mine, &eq) == KYB_OK && eq == 1 && kyb_defer_equal(h1, h3, &eq) == KYB_OK && eq == 0, "equal across arenas");
+    // the first context goes away with a point still only recorded: its arena is an orphan, the point is still there
+    uint64_t late;
+    tl_ctx = &g_ctx;
+    scalar_small(s1, 999);
+    CHECK(kyb_defer_mul_base(s1, &late) == KYB_OK, "recorded, never asked for");
+    defer_release(g_ctx.defer); g_ctx.defer = nullptr;
+    tl_ctx = &g_ctx2;
+    orc_mul_base(w, nullptr, s1);
+    CHECK(kyb_defer_get(late, nullptr, e) == KYB_OK && memcmp(e, w, 32) == 0, "an orphaned arena is evaluated by whoever asks");
+    CHECK(kyb_defer_get(((uint64_t)0xabcdef << 40) | 5, nullptr, e) == KYB_E_BAD_ARG, "a handle of no arena");
+    tl_ctx = &g_ctx;
+  }
   std::printf("%s: %ld engine calls for %ld items\n", failures ? "FAILED" : "OK", g_calls.load(), g_items.load());
   return failures ? 1 : 0;
 }

@@ -220,3 +220,27 @@ def test_threads_recording_into_one_arena(eng, oracle):
     for t in th:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_points_travel_between_contexts(oracle):
+    """Point is Copy and Send: a point recorded through one context (thread) may be asked for, or used as an operand, through another.  Handles name
+    their arena, so that works — also after the first context is gone (a worker thread that ended before its results were looked at)"""
+    import kyber_rs_amd
+    e1 = kyber_rs_amd.Engine(0, private=True)
+    e2 = kyber_rs_amd.Engine(0, private=True)
+    try:
+        a = e1.defer_mul_base(_le(4242))
+        mine = e2.defer_mul_base(_le(4242))
+        assert (a >> 40) != (mine >> 40)                                  # never the same number for two points of two arenas
+        b = e2.defer_add(e2.defer_mul(_le(77), a), a)
+        pa = oracle.mul_base_ext(_le(4242))
+        assert e2.defer_get(b) == oracle.encode(oracle.add(oracle.mul_ext(_le(77), pa), pa))
+        assert e2.defer_get(a) == oracle.mul_base(_le(4242)) == e1.defer_get(a)
+        assert e2.defer_equal(a, mine) and not e2.defer_equal(a, b)
+        late = e1.defer_mul_base(_le(999))                                # recorded, never asked for ...
+    finally:
+        e1.close()                                                        # ... and its context ends
+    try:
+        assert e2.defer_get(late) == oracle.mul_base(_le(999))
+    finally:
+        e2.close()
