@@ -1461,7 +1461,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     { ProfScope ps(g, st, KID_LADDER_RECOVER); LAUNCHCK(launch::ladder_recover(st, hbuf, n, a_ext, state, r->proj, r->proj_items, flags_a, flags_r)); }
     HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
     ProfScope ps(g, st, KID_VERIFY_FINAL);
-    LAUNCHCK(launch::verify_tail_enc(st, r->proj, r->proj_items, n, sigs, flags_a, flavor, status, take_done_flag(g, st, n)));
+    LAUNCHCK(launch::verify_tail_enc(st, r->proj, r->proj_items, n, sigs, flags_a, flavor, status, take_done_flag(g, st, n), g.opt_finish_four != 0 && n <= (size_t)64 * 4 * (size_t)g.cus));
     return KYB_OK;
   }
   if (!by_enc) {
@@ -1499,7 +1499,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   else { rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, st); if (rc) return rc; }
   {
     ProfScope ps(g, st, KID_VERIFY_FINAL);
-    if (by_enc) LAUNCHCK(launch::verify_tail_enc(st, r->proj, r->proj_items, n, sigs, flags_a, flavor, status, take_done_flag(g, st, n)));
+    if (by_enc) LAUNCHCK(launch::verify_tail_enc(st, r->proj, r->proj_items, n, sigs, flags_a, flavor, status, take_done_flag(g, st, n), g.opt_finish_four != 0 && n <= (size_t)64 * 4 * (size_t)g.cus));
     else LAUNCHCK(launch::verify_final(st, r->proj, r->proj_items, n, flags_a, flags_r, flavor, status, take_done_flag(g, st, n)));
   }
   return KYB_OK;

@@ -241,10 +241,10 @@ k_verify_diff(uint4* __restrict__ proj, size_t stride, size_t n) {
   ge_p1p1_to_p2(D, t);
   store_proj(proj, stride, i, D.X, D.Y, D.Z);
 }
-__global__ void __launch_bounds__(KYB_BLOCK, 2)
-k_verify_final_enc(const uint4* __restrict__ proj, size_t stride, size_t n, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ flags_a,
-                   int flavor, uint8_t* __restrict__ status) {
-  const size_t M = (n + FINISH_K - 1) / FINISH_K;
+template <int K>
+__device__ __forceinline__ void verify_final_enc_body(const uint4* __restrict__ proj, size_t stride, size_t n, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ flags_a,
+                                                      int flavor, uint8_t* __restrict__ status) {
+  const size_t M = (n + K - 1) / K;
   const size_t j = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
   if (j >= M) return;
   auto load = [&](int t, fe& z) {
@@ -279,7 +279,18 @@ k_verify_final_enc(const uint4* __restrict__ proj, size_t stride, size_t n, cons
   };
   fe unused_prefix, unused_inv;
   fe_one(unused_prefix);
-  batch_invert<0, FINISH_K>(unused_prefix, unused_inv, load, emit);
+  batch_invert<0, K>(unused_prefix, unused_inv, load, emit);
+}
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_verify_final_enc(const uint4* __restrict__ proj, size_t stride, size_t n, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ flags_a,
+                   int flavor, uint8_t* __restrict__ status) {
+  verify_final_enc_body<FINISH_K>(proj, stride, n, sigs, flags_a, flavor, status);
+}
+// four items per inversion for launches of at most a wavefront per SIMD (as k_finish4)
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_verify_final_enc4(const uint4* __restrict__ proj, size_t stride, size_t n, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ flags_a,
+                    int flavor, uint8_t* __restrict__ status) {
+  verify_final_enc_body<4>(proj, stride, n, sigs, flags_a, flavor, status);
 }
 // the signatures whose R bytes are not the encoding of s B - h A: the reference's first failing check, else 9 (equation)
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
@@ -340,12 +351,13 @@ hipError_t verify_final(hipStream_t st, const uint4* proj, size_t stride, size_t
   hipLaunchKernelGGL(k_verify_final, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, proj, stride, n, flags_a, flags_r, flavor, status, df);
   return hipGetLastError();
 }
-hipError_t verify_tail_enc(hipStream_t st, uint4* proj, size_t stride, size_t n, const uint8_t* sigs, const uint8_t* flags_a, int flavor, uint8_t* status, DoneFlag df) {
+hipError_t verify_tail_enc(hipStream_t st, uint4* proj, size_t stride, size_t n, const uint8_t* sigs, const uint8_t* flags_a, int flavor, uint8_t* status, DoneFlag df, bool four) {
   const size_t M = (n + FINISH_K - 1) / FINISH_K;
   hipLaunchKernelGGL(k_verify_diff, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, proj, stride, n);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_verify_final_enc, dim3(blocks_for(M)), dim3(KYB_BLOCK), 0, st, proj, stride, n, sigs, flags_a, flavor, status);
+  if (four) hipLaunchKernelGGL(k_verify_final_enc4, dim3(blocks_for((n + 3) / 4)), dim3(KYB_BLOCK), 0, st, proj, stride, n, sigs, flags_a, flavor, status);
+  else hipLaunchKernelGGL(k_verify_final_enc, dim3(blocks_for(M)), dim3(KYB_BLOCK), 0, st, proj, stride, n, sigs, flags_a, flavor, status);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_verify_fixup, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sigs, n, flags_a, flavor, status, df);

@@ -123,7 +123,7 @@ hipError_t verify_final(hipStream_t st, const uint4* proj, size_t stride, size_t
                         DoneFlag df = DoneFlag{});
 // the equation of n verifications on encodings (h A at proj[i], s B at proj[n + i]; record i is overwritten): three launches
 hipError_t verify_tail_enc(hipStream_t st, uint4* proj, size_t stride, size_t n, const uint8_t* sigs, const uint8_t* flags_a, int flavor, uint8_t* status,
-                           DoneFlag df = DoneFlag{});
+                           DoneFlag df = DoneFlag{}, bool four = false);      // four: 4 items per shared inversion in the encode (k_verify_final_enc4)
 hipError_t sign_hash(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* msgs, const uint32_t* off, size_t n,
                      const uint8_t* r_enc, const uint8_t* a_enc, uint8_t* sig, DoneFlag df = DoneFlag{});
 hipError_t eddsa_prep(hipStream_t st, const uint8_t* seeds, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* xbuf, uint8_t* kbuf);

@@ -37,7 +37,7 @@ DEFAULT_PATH = [
     ("_Z11k_mont_prepPKim", 256), ("_Z8k_finishPK", 256), ("_Z9k_finish4PK", 256), ("_Z16k_encode_batchedPKimPh", 256),
     ("_Z20k_decode_or_identityPKhmPiPh", 256), ("_Z16k_decode_to_projPKhm", 256), ("_Z10k_pair_sumP", 256), ("_Z13k_ext_to_projPKim", 256),
     ("_Z13k_verify_prepPKhS0_S0_PKjmPhS3_S3_Pi", 256), ("_Z15k_verify_prep_rPKhmPh", 256), ("_Z13k_verify_hashPKh", 256), ("_Z14k_verify_finalPK", 256), ("_Z13k_verify_diffP", 256),
-    ("_Z18k_verify_final_encPK", 256), ("_Z14k_verify_fixupPKhmS0_iPh", 256), ("_Z11k_sign_hashPKhS0_S0_PKjm", 256), ("_Z12k_eddsa_prepPKhS0_PKjm", 256),
+    ("_Z18k_verify_final_encPK", 256), ("_Z19k_verify_final_enc4PK", 256), ("_Z14k_verify_fixupPKhmS0_iPh", 256), ("_Z11k_sign_hashPKhS0_S0_PKjm", 256), ("_Z12k_eddsa_prepPKhS0_PKjm", 256),
     ("_Z11k_poly_evalILb1EE", 256), ("_Z16k_poly_eval_partPKii", 256), ("_Z7k_equalPKiS0_mPh", 256), ("_Z5k_addPKiS0_mPii", 256), ("_Z8k_decodePKhmPiPh", 256),
     ("_Z10k_mul_coopPKhPKim", 256), ("_Z15k_mul_base_coopPKhS0_mm", 256), ("_Z14k_mul_enc_coopPKhS0_m", 256), ("_Z13k_verify_coopPKhS0_S0_PKjmi", 256),
     ("_Z11k_sign_coopPKhS0_S0_S0_PKjm", 256), ("_Z13k_decode_coopPKhmPiPhi", 256), ("_Z13k_finish_coopPK", 256), ("_Z10k_sum_coopPKjPKimm", 256),
