@@ -481,9 +481,11 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     point accepts such points, kyb_encode_batch pays the inversion when an encoding is wanted
  *   poly.segments     PubPoly::eval of few evaluations: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never
  *                     split the Horner chain, 2..32)
- *   ladder.y_only     1 (default): launches of at most ladder.pair_max_items items whose points come as 32-byte ENCODINGS (kyb_mul_batch with
- *                     pts_enc, kyb_verify_batch) run the two-lane ladder on the y of the encoding — u = (1 + y) / (1 - y) needs no x — while a side
- *                     stream takes the square root of the decode; a short kernel joins the two.  0: decode first, then the ladder.  Same results.
+ *   ladder.y_only     2 (default): launches of at most ladder.pair_max_items items whose points come as 32-byte ENCODINGS (kyb_mul_batch with
+ *                     pts_enc, kyb_verify_batch) run the two-lane ladder on the y of the encoding — u = (1 + y) / (1 - y) needs no x — while
+ *                     further workgroups of the SAME launch take the square root of the decode (a verification: of the key and of R, and its hash
+ *                     moves into the ladder's workgroups); a short kernel joins them.  1: the decode as a kernel of its own on a side stream.
+ *                     0: decode first, then the ladder.  Same results.
  *   finish.four       1 (default): the batched encode shares one field inversion between 4 instead of 8 items when a launch leaves at most one
  *                     wavefront per SIMD (shorter dependent chain; full batches keep 8).  Same results.
  *   defer.fuse        1 (default): a flush of deferred points (kyb_defer_*) evaluates Horner chains and chains of additions as ONE call each; 0:

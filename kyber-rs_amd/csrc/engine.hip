@@ -128,7 +128,7 @@ struct Ctx {
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: the chunk unit is 1/this of the batch (plan_chunks)
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
   std::atomic<int> opt_finish_four{1};           // k_finish with 4 instead of 8 items per shared inversion for launches of at most one wavefront per SIMD
-  std::atomic<int> opt_ladder_y_only{1};         // two-lane ladder from wire encodings: ladder on y while a side stream decodes x (0: decode first)
+  std::atomic<int> opt_ladder_y_only{2};         // two-lane ladder from wire encodings: ladder on y while the decode looks for x — 2: as workgroups of the same launch, 1: on a side stream (0: decode first)
   DeferArena* defer = nullptr;                   // recorded, not yet evaluated point operations of this context's callers (kyb_defer_*; made on first use)
   std::atomic<int> opt_defer_fuse{1};            // flushes recognise Horner chains and chains of additions (defer.inc)
   std::atomic<int> opt_defer_max_nodes{1 << 20}; // evaluated nodes kept for late readers of a handle before the oldest are dropped
@@ -947,6 +947,11 @@ int launch_ladder_core(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int
     rc = ensure_aux(g, r); if (rc) return rc;
     int32_t* tmp = reinterpret_cast<int32_t*>(r->enc);
     uint4* state = reinterpret_cast<uint4*>(r->part);
+    if (g.opt_ladder_y_only == 2) {      // one launch: ladder workgroups first, decoding workgroups behind them (on CUs of their own)
+      { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::mul_ladder_pair_y_dec(st, sc, n, penc, state, skip_bits, tmp, ok)); }
+      { ProfScope ps(g, st, KID_LADDER_RECOVER); LAUNCHCK(launch::ladder_recover(st, sc, n, tmp, state, r->proj, r->proj_items)); }
+      return KYB_OK;
+    }
     HIPCK(hipEventRecord(r->ev_fork, st));                 // behind whatever the caller queued before this call (the encodings may be its output)
     HIPCK(hipStreamWaitEvent(r->aux, r->ev_fork, 0));
     { ProfScope ps(g, r->aux, KID_DECODE); LAUNCHCK(launch::decode_or_identity(r->aux, penc, n, tmp, ok)); }
@@ -1426,8 +1431,8 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     return KYB_OK;
   }
   int rc = ensure_proj(g, r, 3 * n); if (rc) return rc;
-  const size_t o_h = 0, o_s = up256(32 * n), o_a = o_s + up256(32 * n), o_fa = o_a + up256(160 * n), o_fr = o_fa + up256(n);
-  rc = ensure_enc(g, r, o_fr + up256(n)); if (rc) return rc;
+  const size_t o_h = 0, o_s = up256(32 * n), o_a = o_s + up256(32 * n), o_fa = o_a + up256(160 * n), o_fr = o_fa + up256(n), o_ok = o_fr + up256(n);
+  rc = ensure_enc(g, r, o_ok + up256(n)); if (rc) return rc;
   uint8_t* hbuf = r->enc + o_h; uint8_t* sbuf = r->enc + o_s; int32_t* a_ext = reinterpret_cast<int32_t*>(r->enc + o_a);
   uint8_t* flags_a = r->enc + o_fa; uint8_t* flags_r = r->enc + o_fr;
   // the R half (decode of R, s*B) is independent of the A half (decode of A, hash, h*A): while the batch leaves most of
@@ -1449,6 +1454,19 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     // bytes decide; the two-lane ladder starts on A's y at once; the side stream decodes A, then multiplies s*B; k_ladder_recover joins (round 4).
     rc = ensure_ws_part(g, r, n); if (rc) return rc;
     uint4* state = reinterpret_cast<uint4*>(r->part);
+    if (g.opt_ladder_y_only == 2) {
+      // two launches on the critical path: hash + ladder with both decodes as workgroups of their own, then recovery + equation (kernels_ladder.hip,
+      // k_verify_ladder_y); the side stream gathers s and multiplies s*B beside the first one.  R arrives decoded, so no inversion at the end.
+      uint8_t* a_ok = r->enc + o_ok;
+      { ProfScope ps(g, side, KID_VERIFY_PREP_R); LAUNCHCK(launch::sig_scalars(side, sigs, n, sbuf)); }
+      rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side); if (rc) return rc;
+      HIPCK(hipEventRecord(r->ev_join, side));
+      { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::verify_ladder_y(st, pubs, sigs, msgs, off, n, flags_a, flags_r, a_ok, hbuf, state, a_ext, r->proj, r->proj_items)); }
+      HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
+      ProfScope ps(g, st, KID_VERIFY_FINAL);
+      LAUNCHCK(launch::verify_recover_final(st, hbuf, n, a_ext, state, r->proj, r->proj_items, flags_a, a_ok, flags_r, flavor, status, take_done_flag(g, st, n)));
+      return KYB_OK;
+    }
     { ProfScope ps(g, side, KID_DECODE); LAUNCHCK(launch::decode_or_identity(side, pubs, n, a_ext, flags_r)); }      // flags_r: free in this path, holds "A decodes"
     HIPCK(hipEventRecord(r->ev_mid, side));
     { ProfScope ps(g, st, KID_VERIFY_PREP); LAUNCHCK(launch::verify_hash(st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf)); }

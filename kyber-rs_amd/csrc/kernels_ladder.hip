@@ -5,11 +5,15 @@
 //   k_decode_to_proj       unmarshal_binary into projective staging records, optionally transposed (kyb_sum_enc_batch)
 //   k_pair_sum             one halving pass of the segmented sums behind kyb_lincomb_batch / kyb_sum_batch
 //   k_ext_to_proj          extended limbs -> projective staging records
+//   k_mul_ladder_pair_y[_dec] / k_ladder_recover   the two-lane ladder on the y of a wire encoding, the decode beside it (ge_ladder_pair.h)
+//   k_verify_ladder_y / k_verify_recover_final      a DKG-sized verification as two launches (eddsa_sig.rs:159-212, schnorr_sig.rs:53-110; verify.h)
 #include <hip/hip_runtime.h>
 #include "launch.h"
 #include "ge_scalarmult.h"
 #include "ge_ladder.h"
 #include "ge_ladder_pair.h"
+#include "schnorr.h"
+#include "verify.h"
 #include "device_batch_invert.h"
 #include "diag_stamp.h"
 using namespace kyb;
@@ -184,6 +188,37 @@ k_mul_ladder_pair_y(const uint8_t* __restrict__ scalars, size_t n, const uint8_t
   mont_ladder_pair_from_y(x2, z2, x3, z3, a, w, skip_bits, odd);
   if (odd == 0u) store_state(state, i, x2, z2, x3, z3);
 }
+// The two kernels above and k_decode_or_identity as ONE launch (ladder.y_only = 2): workgroups [0, ladder_blocks) walk the ladder, two lanes per item;
+// the workgroups behind them decode the same encodings, one lane per item.  Workgroups of one launch are dealt out to the CUs in order, so the decoding
+// ones land on CUs of their own instead of on the SIMDs the ladder occupies — which is where a second kernel on a side stream puts them (both grids start
+// at the same CU; profiles/r04/side_cu_mask_probe.log) — and no stream has to be forked and joined.  The role depends on blockIdx only.
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_mul_ladder_pair_y_dec(const uint8_t* __restrict__ scalars, size_t n, const uint8_t* __restrict__ pts_enc, uint4* __restrict__ state, int skip_bits,
+                        unsigned ladder_blocks, int32_t* __restrict__ out_ext, uint8_t* __restrict__ ok_out) {
+  if (blockIdx.x < ladder_blocks) {
+    const size_t lane = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+    const size_t i = lane >> 1;
+    const uint32_t odd = threadIdx.x & 1u;
+    if (i >= n) return;
+    uint32_t a[8], w[8];
+    load_words8(a, scalars, i);
+    load_words8(w, pts_enc, i);
+    fe x2, z2, x3, z3;
+    mont_ladder_pair_from_y(x2, z2, x3, z3, a, w, skip_bits, odd);
+    if (odd == 0u) store_state(state, i, x2, z2, x3, z3);
+    return;
+  }
+  const size_t i = (size_t)(blockIdx.x - ladder_blocks) * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words8(w, pts_enc, i);
+  ge_p3 P, id;
+  const uint32_t ok = ge_decode(P, w);
+  ge_p3_0(id);
+  fe_cmov(P.X, id.X, 1u - ok); fe_cmov(P.Y, id.Y, 1u - ok); fe_cmov(P.Z, id.Z, 1u - ok); fe_cmov(P.T, id.T, 1u - ok);
+  store_ext(out_ext, i, P.X, P.Y, P.Z, P.T);
+  if (ok_out != nullptr) ok_out[i] = (uint8_t)ok;
+}
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
 k_ladder_recover(const uint8_t* __restrict__ scalars, size_t n, const int32_t* __restrict__ pts_ext, const uint4* __restrict__ state, uint4* __restrict__ proj, size_t stride,
                  uint8_t* __restrict__ flags, const uint8_t* __restrict__ dec_ok) {
@@ -200,6 +235,101 @@ k_ladder_recover(const uint8_t* __restrict__ scalars, size_t n, const int32_t* _
   ge_p2 r;
   ge_recover_from_state(r, a, P, x2, z2, x3, z3);
   store_proj(proj, stride, i, r.X, r.Y, r.Z);
+}
+
+// ---- verification of a DKG-sized batch from key BYTES in two launches (ladder.y_only = 2) ---------------------------------------------------------
+// Everything that does not need the other multiplication, as ONE launch whose workgroups take one of three roles by blockIdx:
+//   [0, ladder_blocks)                 two lanes per signature: s < L, the byte checks of A, h = SHA-512(R || A || msg) mod L (both lanes hash: both need
+//                                      every bit of h), then the two-lane ladder on A's y with h -> the 160-byte state record
+//   the next item_blocks workgroups    one lane per signature: decode A (the 252-squaring square root) -> extended limbs, "A decodes"
+//   the last item_blocks workgroups    one lane per signature: checks and decode of R (verify_prep_r) -> flags_r, record 2n + i
+// The decoding workgroups are dealt to CUs the ladder does not occupy (up to 128 items per CU in total), so neither square root is on the critical
+// path and R arrives decoded: the equation is checked projectively by k_verify_recover_final, without the field inversion k_verify_final_enc
+// pays to compare encodings.  s*B runs beside this launch on the side stream (k_sig_scalars gathers its scalars first).
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_verify_ladder_y(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ msgs, const uint32_t* __restrict__ msg_off, size_t n,
+                  uint8_t* __restrict__ flags_a, uint8_t* __restrict__ flags_r, uint8_t* __restrict__ a_ok, uint8_t* __restrict__ hbuf, uint4* __restrict__ state,
+                  int32_t* __restrict__ a_ext, uint4* __restrict__ proj, size_t stride, unsigned ladder_blocks, unsigned item_blocks) {
+  if (blockIdx.x < ladder_blocks) {
+    __builtin_amdgcn_s_setprio(3);         // s*B shares these CUs from the side stream; the ladder is the critical path
+    const size_t lane = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+    const size_t i = lane >> 1;
+    const uint32_t odd = threadIdx.x & 1u;
+    if (i >= n) return;
+    uint32_t pub[8], ra[16], h[8];
+    load_words8(pub, pubs, i);
+    load_words8(ra, sigs, 2 * i);
+    load_words8(ra + 8, sigs, 2 * i + 1);
+    const uint32_t off = msg_off[i], len = msg_off[i + 1] - off;
+    fe y;
+    fe_from_words(y, pub);
+    const uint32_t fl = sc_is_canonical_w(ra + 8) | (pt_is_canonical_w(pub) << 1) | (pt_has_small_order(y) << 3);
+    for (int k = 0; k < 8; ++k) ra[8 + k] = pub[k];
+    sha512_ctx c;
+    sha512_init(c);
+    sha512_words64(c, ra);
+    sha512_bytes(c, msgs + off, len);
+    uint32_t dig[16];
+    sha512_final(dig, c);
+    sc_reduce512(h, dig);
+    if (odd == 0u) { flags_a[i] = (uint8_t)fl; store_words8(hbuf, i, h); }
+    fe x2, z2, x3, z3;
+    mont_ladder_pair_from_y(x2, z2, x3, z3, h, pub, 3, odd);      // h < L < 2^253
+    if (odd == 0u) store_state(state, i, x2, z2, x3, z3);
+    return;
+  }
+  const unsigned b = blockIdx.x - ladder_blocks;
+  const bool is_r = b >= item_blocks;                             // uniform in the workgroup
+  const size_t i = (size_t)(is_r ? b - item_blocks : b) * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load_words8(w, is_r ? sigs : pubs, is_r ? 2 * i : i);
+  ge_p3 P, id;
+  const uint32_t ok = ge_decode(P, w);
+  const uint32_t small = pt_has_small_order(P.Y);                 // as verify_prep_r_with: on what the decode left
+  ge_p3_0(id);
+  fe_cmov(P.X, id.X, 1u - ok); fe_cmov(P.Y, id.Y, 1u - ok); fe_cmov(P.Z, id.Z, 1u - ok); fe_cmov(P.T, id.T, 1u - ok);
+  if (is_r) {
+    flags_r[i] = (uint8_t)(pt_is_canonical_w(w) | (ok << 1) | (small << 2));
+    store_proj(proj, stride, 2 * n + i, P.X, P.Y, P.Z);
+  } else {
+    a_ok[i] = (uint8_t)ok;
+    store_ext(a_ext, i, P.X, P.Y, P.Z, P.T);
+  }
+}
+// s of every signature as contiguous 32-byte records (the scalars of the fixed-base multiplication on the side stream)
+__global__ void __launch_bounds__(KYB_BLOCK)
+k_sig_scalars(const uint8_t* __restrict__ sigs, size_t n, uint8_t* __restrict__ sbuf) {
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+  load_words8(s, sigs, 2 * i + 1);
+  store_words8(sbuf, i, s);
+}
+// ... and the join: h*A from the ladder's state and the decoded key (ge_recover_from_state), then the equation R + h*A == s*B on projective
+// coordinates and the status (verify_final, verify_status) — k_ladder_recover and k_verify_final in one pass over the item
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_verify_recover_final(const uint8_t* __restrict__ hbuf, size_t n, const int32_t* __restrict__ a_ext, const uint4* __restrict__ state, const uint4* __restrict__ proj, size_t stride,
+                       const uint8_t* __restrict__ flags_a, const uint8_t* __restrict__ a_ok, const uint8_t* __restrict__ flags_r, int flavor, uint8_t* __restrict__ status,
+                       kyb::launch::DoneFlag df) {
+  KYB_SHORT_KERNEL_PRIORITY();
+  const size_t i = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t h[8];
+  load_words8(h, hbuf, i);
+  ge_p3 A;
+  load_ext(A, a_ext, i);
+  fe x2, z2, x3, z3;
+  load_state(x2, z2, x3, z3, state, i);
+  ge_p2 hA, sB;
+  ge_recover_from_state(hA, h, A, x2, z2, x3, z3);
+  fe RX, RY;
+  load_proj_xy(sB.X, sB.Y, proj, stride, n + i);       load_proj_z(sB.Z, proj, stride, n + i);
+  load_proj_xy(RX, RY, proj, stride, 2 * n + i);
+  const uint32_t eq = verify_final(RX, RY, hA, sB);
+  const uint32_t st = verify_status((uint32_t)flags_a[i] | (((uint32_t)a_ok[i] & 1u) << 2), flags_r[i], flavor);
+  status[i] = (st == 0 && !eq) ? (uint8_t)9 : (uint8_t)st;
+  signal_done(df);
 }
 
 // One halving pass of the segmented sum behind kyb_lincomb_batch: in each of the m groups (group g
@@ -263,8 +393,28 @@ hipError_t mul_ladder_pair_y(hipStream_t st, const uint8_t* sc, size_t n, const 
   hipLaunchKernelGGL(k_mul_ladder_pair_y, dim3(blocks_for(2 * n)), dim3(KYB_BLOCK), 0, st, sc, n, penc, state, skip_bits);
   return hipGetLastError();
 }
+hipError_t mul_ladder_pair_y_dec(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits, int32_t* out_ext, uint8_t* ok) {
+  const unsigned lb = blocks_for(2 * n);
+  hipLaunchKernelGGL(k_mul_ladder_pair_y_dec, dim3(lb + blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, penc, state, skip_bits, lb, out_ext, ok);
+  return hipGetLastError();
+}
 hipError_t ladder_recover(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, const uint4* state, uint4* proj, size_t stride, uint8_t* flags, const uint8_t* dec_ok) {
   hipLaunchKernelGGL(k_ladder_recover, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, pext, state, proj, stride, flags, dec_ok);
+  return hipGetLastError();
+}
+hipError_t verify_ladder_y(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* flags_a, uint8_t* flags_r,
+                           uint8_t* a_ok, uint8_t* hbuf, uint4* state, int32_t* a_ext, uint4* proj, size_t stride) {
+  const unsigned lb = blocks_for(2 * n), ib = blocks_for(n);
+  hipLaunchKernelGGL(k_verify_ladder_y, dim3(lb + 2 * ib), dim3(KYB_BLOCK), 0, st, pubs, sigs, msgs, off, n, flags_a, flags_r, a_ok, hbuf, state, a_ext, proj, stride, lb, ib);
+  return hipGetLastError();
+}
+hipError_t sig_scalars(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* sbuf) {
+  hipLaunchKernelGGL(k_sig_scalars, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sigs, n, sbuf);
+  return hipGetLastError();
+}
+hipError_t verify_recover_final(hipStream_t st, const uint8_t* hbuf, size_t n, const int32_t* a_ext, const uint4* state, const uint4* proj, size_t stride, const uint8_t* flags_a,
+                                const uint8_t* a_ok, const uint8_t* flags_r, int flavor, uint8_t* status, DoneFlag df) {
+  hipLaunchKernelGGL(k_verify_recover_final, dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, hbuf, n, a_ext, state, proj, stride, flags_a, a_ok, flags_r, flavor, status, df);
   return hipGetLastError();
 }
 hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half) {

@@ -68,10 +68,16 @@ hipError_t mul_ladder_pair(hipStream_t st, const uint8_t* sc, size_t n, const in
 // the same from wire encodings: the ladder on (1 + y : 1 - y) leaves its x-only state (160 bytes per item) while the decode runs elsewhere;
 // ladder_recover turns state + decoded point into the projective result (ge_ladder_pair.h)
 hipError_t mul_ladder_pair_y(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits);
+// ladder and decode as one launch: the first workgroups walk the ladder, the ones behind them decode (out_ext / ok as decode_or_identity)
+hipError_t mul_ladder_pair_y_dec(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits, int32_t* out_ext, uint8_t* ok);
 hipError_t ladder_recover(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, const uint4* state, uint4* proj, size_t stride,
                           uint8_t* flags = nullptr, const uint8_t* dec_ok = nullptr);       // flags != nullptr: flags[i] |= dec_ok[i] << 2 (verification)
 // verification, the A half without the decode: flags (bits 0, 1, 3), h, s from the bytes alone (kernels_verify.hip)
 hipError_t verify_hash(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf);
+// ladder.y_only = 2, verification (kernels_ladder.hip): hash + ladder on A's y, decode of A, decode of R as workgroup roles of one launch; the join checks the equation
+hipError_t verify_ladder_y(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* flags_a, uint8_t* flags_r,
+                           uint8_t* a_ok, uint8_t* hbuf, uint4* state, int32_t* a_ext, uint4* proj, size_t stride);
+hipError_t sig_scalars(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* sbuf);
 hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half);
 hipError_t ext_to_proj(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride, size_t rows = 0, size_t cols = 0);      // rows != 0: transposed, as decode_to_proj
 
@@ -119,6 +125,8 @@ hipError_t verify_prep_pts(hipStream_t st, const uint8_t* pub_enc, const int32_t
 hipError_t verify_prep(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,
                        uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf, int32_t* a_ext);
 hipError_t verify_prep_r(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* flags_r, uint4* proj, size_t stride, size_t offset);
+hipError_t verify_recover_final(hipStream_t st, const uint8_t* hbuf, size_t n, const int32_t* a_ext, const uint4* state, const uint4* proj, size_t stride, const uint8_t* flags_a,
+                                const uint8_t* a_ok, const uint8_t* flags_r, int flavor, uint8_t* status, DoneFlag df);      // kernels_ladder.hip
 hipError_t verify_final(hipStream_t st, const uint4* proj, size_t stride, size_t n, const uint8_t* flags_a, const uint8_t* flags_r, int flavor, uint8_t* status,
                         DoneFlag df = DoneFlag{});
 // the equation of n verifications on encodings (h A at proj[i], s B at proj[n + i]; record i is overwritten): three launches

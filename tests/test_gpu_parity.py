@@ -364,7 +364,7 @@ def test_verify_matches_oracle(engine, oracle):
     try:
         for k in ("coop.max_items", "coop.base_max_items", "coop.verify_max_items"):
             engine.set_option(k, 0)
-        for y_only in (1, 0):
+        for y_only in (2, 1, 0):
             engine.set_option("ladder.y_only", y_only)
             for flavor in (0, 1):
                 want = np.array([oracle.verify(flavor, *c) for c in cases], dtype=np.uint8)
@@ -550,13 +550,13 @@ def test_two_lane_ladder_matches_one_lane_and_oracle(engine, oracle):
         encs3 = np.frombuffer(b"".join(encs + special + [oracle.encode(p) for p in pts[30:900]]), dtype=np.uint8).reshape(-1, 32)
         s3 = np.concatenate([synth.scalars(450, 618), synth.raw256(encs3.shape[0] - 450, 618)])
         want3 = oracle.mul_enc_batch(s3, encs3, nthreads=8)
-        for y_only in (1, 0):
+        for y_only in (2, 1, 0):
             engine.set_option("ladder.y_only", y_only)
             got, ok = engine.mul(sc, pts_enc=pe, want_ok=True)
             assert ok.all() and [bytes(r).hex() for r in got] == [v["out"] for v in q], y_only
             got3, ok3 = engine.mul(s3, pts_enc=encs3, want_ok=True)
             assert np.array_equal(ok3, want3[1]) and np.array_equal(got3, want3[0]), y_only
-        engine.set_option("ladder.y_only", 1)
+        engine.set_option("ladder.y_only", 2)
     finally:
         for k, v in saved.items():
             engine.set_option(k, v)

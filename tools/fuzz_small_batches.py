@@ -66,7 +66,7 @@ def set_random_options():
          "coop.verify_max_items": int(rng.choice([512, 512, 0, 4096])), "verify.by_encoding": int(rng.integers(0, 2)),
          "verify.overlap": int(rng.integers(0, 2)), "ladder.pair_max_items": int(rng.choice([32768, 32768, 0, 1 << 20])),
          "coop.ladder_max_items": int(rng.choice([3072, 3072, 1 << 20, 700])),
-         "ladder.y_only": int(rng.integers(0, 2)), "finish.four": int(rng.integers(0, 2))}
+         "ladder.y_only": int(rng.integers(0, 3)), "finish.four": int(rng.integers(0, 2))}
     if rng.integers(0, 8) == 0:
         o["coop.max_items"], o["coop.base_max_items"] = 0, 0
     else:

@@ -1,6 +1,6 @@
 """Same-box A/B of this round's mid-size changes through the HOST-pointer calls (what bench.py's mid_size_calls reports): the two-lane ladder on
 the y of wire encodings / the verification's hash-only A half (ladder.y_only) and four items per inversion in the finish (finish.four), each on and
-off, interleaved, medians of 25 calls.  Kernel times of the same calls: tools/mid_size_kernels.py."""
+off (ladder.y_only = 2: the decodes as workgroups of the ladder's own launch), interleaved, medians of 25 calls.  Kernel times of the same calls: tools/mid_size_kernels.py."""
 import os
 import sys
 import time
@@ -33,10 +33,10 @@ def med(fn, reps=25):
 print("n, ladder.y_only, finish.four: mul, mul_enc, verify   (ms per host-pointer call, median of 25)")
 for n in (4096, 8192, 16384, 32768):
     for rnd in range(2):
-        for y_only, four in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        for y_only, four in ((0, 0), (1, 0), (0, 1), (1, 1), (2, 1)):
             eng.set_option("ladder.y_only", y_only)
             eng.set_option("finish.four", four)
             row = [med(lambda: eng.mul(k[:n], pts_ext=ext[:n])), med(lambda: eng.mul(k[:n], pts_enc=enc[:n])), med(lambda: eng.verify(enc[:n], msgs[:n], sigs[:n], 1))]
             print(f"{n}, {y_only}, {four}: " + ", ".join(f"{v:.3f}" for v in row), flush=True)
-eng.set_option("ladder.y_only", 1)
+eng.set_option("ladder.y_only", 2)
 eng.set_option("finish.four", 1)
