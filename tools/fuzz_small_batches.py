@@ -67,8 +67,9 @@ def set_random_options():
          "verify.overlap": int(rng.integers(0, 2)), "ladder.pair_max_items": int(rng.choice([32768, 32768, 0, 1 << 20])),
          "coop.ladder_max_items": int(rng.choice([3072, 3072, 1 << 20, 700])),
          "ladder.y_only": int(rng.integers(0, 3)), "finish.four": int(rng.integers(0, 2))}
-    if rng.integers(0, 8) == 0:
+    if rng.integers(0, 4) == 0:              # the batch kernels of DKG-sized calls at these sizes (two-lane ladder, ladder.y_only, finish.four)
         o["coop.max_items"], o["coop.base_max_items"] = 0, 0
+        o["coop.verify_max_items"] = int(rng.choice([0, 0, 512]))
     else:
         o["coop.max_items"], o["coop.base_max_items"] = 6144, 4096
     for k_, v in o.items():
