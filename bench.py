@@ -502,6 +502,23 @@ def mid_size_calls(eng, orc, threads, n=8192):
     out = {"unit": "ms per host-pointer call (median of 15)", "items": n, "checked_against_oracle": True,
            "mul_base": med(lambda: eng.mul_base(s)), "mul": med(lambda: eng.mul(k, pts_ext=ext)), "mul_enc": med(lambda: eng.mul(k, pts_enc=enc)),
            "sign": med(lambda: eng.schnorr_sign(s, k, msgs)), "verify": med(lambda: eng.verify(enc, msgs, sigs, 1))}
+    # the same calls on arrays in page-locked memory (kyb_host_alloc): the kernels read and write them where they lie (host.in_place)
+    P, ck, lib = _k._ptr, _k._check, eng.lib
+
+    def pin(a):
+        b = eng.pinned_array(a.shape, a.dtype)
+        b[...] = a
+        return b
+
+    pk, penc, pext, psig, pblob, poff = pin(k), pin(enc), pin(ext), pin(sigs), pin(msgs.blob), pin(msgs.off)
+    pout, pst = eng.pinned_array((n, 32), np.uint8), eng.pinned_array((n,), np.uint8)
+    want_mul, want_st = eng.mul(k, pts_enc=enc), eng.verify(enc, msgs, sigs, 1)
+    out["page_locked_arrays"] = {
+        "mul": med(lambda: ck(lib.kyb_mul_batch(P(pk), None, P(pext), n, P(pout), None, None), "kyb_mul_batch")),
+        "mul_enc": med(lambda: ck(lib.kyb_mul_batch(P(pk), P(penc), None, n, P(pout), None, None), "kyb_mul_batch")),
+        "verify": med(lambda: ck(lib.kyb_verify_batch(P(penc), P(pblob), P(poff), P(psig), n, 1, P(pst)), "kyb_verify_batch"))}
+    if not (np.array_equal(pout, want_mul) and np.array_equal(pst, want_st)):
+        raise SystemExit("PARITY FAILURE (mid-size calls on page-locked arrays): outputs differ from the pageable calls'")
     pair = eng.get_option("ladder.pair_max_items")
     eng.set_option("ladder.pair_max_items", 0)
     try:

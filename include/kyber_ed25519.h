@@ -493,6 +493,9 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *   defer.max_nodes   nodes the deferred-point arena keeps before it drops the oldest (default 2^20, at least 16); a dropped handle is refused
  *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder (and, with ladder.y_only, the decode of A)
  *   verify.by_encoding 1 (default): large batches test the equation as enc(s*B - h*A) == R bytes and decode R only on a mismatch
+ *   host.in_place     1 (default): a host-pointer call small enough for host.zero_copy_kib (and of at least 64 KiB) whose array lies in PAGE-LOCKED
+ *                     memory of this context's device (kyb_host_alloc, 16-byte aligned) has its kernels read / write that array where it lies
+ *                     instead of a copy in the context's buffer (an 8,192-item multiplication: 0.03-0.05 ms less); 0: always copy.  Same results.
  *   host.zero_copy_kib  host-pointer calls whose arrays together fit this many KiB skip every hipMemcpy: the inputs are copied into the
  *                     context's page-locked buffer by the calling thread and the kernels read and write it over PCIe (default 4096).
  *                     Larger calls of fewer than 2^16 items copy in, run and copy out on the engine stream.

@@ -134,6 +134,7 @@ struct Ctx {
   std::atomic<int> opt_defer_max_nodes{1 << 20}; // evaluated nodes kept for late readers of a handle before the oldest are dropped
   bool stamps_on = false;                        // this context set the device's wave-stamp slots (kyb_diag_wave_stamps): cleared again when it is released
   std::atomic<int> opt_coop_share{1};             // divide the small-batch thresholds by the number of host-pointer calls in flight in this process (coop_lim)
+  std::atomic<int> opt_host_inplace{1};           // zero-copy host-pointer calls use page-locked CALLER arrays (kyb_host_alloc) where they lie instead of copying them into the context's buffer
   std::atomic<int> opt_zero_copy_kib{4096};         // host-pointer calls whose arrays fit this many KiB run their kernels on the context's page-locked buffer (no hipMemcpy); 512 in round 2, 4 MiB wins up to 16,384 items (profiles/r03/mid_size_host_calls.log)
   std::atomic<int> opt_ladder_pair_max{32768};    // ladder launches of at most this many items give each item two lanes (k_mul_ladder_pair: one wavefront per SIMD up to here); 0 = never
   std::atomic<int> opt_coop_ladder_max{3072};     // variable base, linear combinations (verification: 7/8 of it): above this the two-lane batch ladder is faster than one item per wavefront (profiles/r03/ladder_pair_probe.log)
@@ -261,6 +262,18 @@ bool is_pinned(const void* p) {
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
   return a.type == hipMemoryTypeHost;
+}
+
+// Device-visible address of a caller's PAGE-LOCKED array (kyb_host_alloc, hipHostRegister), or nullptr.  The kernels of a zero-copy call work on the
+// context's page-locked buffer over PCIe anyway: an array that already is such memory is read and written where it lies, and the calling thread's
+// memcpy into / out of the buffer (0.03 ms of a DKG-sized call) drops out.  Asked only for calls of at least INPLACE_MIN_BYTES (the query costs ~1 us).
+constexpr size_t INPLACE_MIN_BYTES = (size_t)64 << 10;
+uint8_t* pinned_dev_ptr(const Ctx& g, const void* p) {
+  if (p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) != 0) return nullptr;        // the kernels load and store 16-byte words
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (a.type != hipMemoryTypeHost || a.devicePointer == nullptr || a.device != g.device) return nullptr;
+  return static_cast<uint8_t*>(a.devicePointer);
 }
 
 // ---- completion flag of small host-pointer calls --------------------------------------------------------
@@ -494,13 +507,20 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
     int rc = ensure_pin(g, 0, zero_copy_bytes(g));
     if (rc) return rc;
     uint8_t* dptr[8];
+    bool staged[8];
+    const bool try_inplace = g.opt_host_inplace != 0 && total >= INPLACE_MIN_BYTES;
     for (int k = 0; k < na; ++k) {
       dptr[k] = (arrs[k].in || arrs[k].out) ? g.pin[0] + off[k] : nullptr;
-      if (arrs[k].in) memcpy(dptr[k], arrs[k].in, arrs[k].bytes * n);
+      staged[k] = dptr[k] != nullptr;
+      if (try_inplace && staged[k] && (arrs[k].in == nullptr || arrs[k].out == nullptr || arrs[k].in == arrs[k].out)) {
+        uint8_t* own = pinned_dev_ptr(g, arrs[k].in ? arrs[k].in : arrs[k].out);          // page-locked caller array: used where it lies
+        if (own != nullptr) { dptr[k] = own; staged[k] = false; }
+      }
+      if (arrs[k].in && staged[k]) memcpy(dptr[k], arrs[k].in, arrs[k].bytes * n);
     }
     // whatever way the call ends, the secret operands do not stay behind in the page-locked buffer (the kernels have finished by then:
     // every return below is behind a completed wait or a stream synchronisation)
-    auto wipe = on_scope_exit([&] { for (int k = 0; k < na; ++k) if (arrs[k].secret && (arrs[k].in || arrs[k].out)) memset(g.pin[0] + off[k], 0, arrs[k].bytes * n); });
+    auto wipe = on_scope_exit([&] { for (int k = 0; k < na; ++k) if (arrs[k].secret && staged[k]) memset(g.pin[0] + off[k], 0, arrs[k].bytes * n); });
     rc = ensure_done_flag(g);
     if (rc) return rc;
     {
@@ -512,7 +532,7 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
       if (rc) { (void)hipStreamSynchronize(g.stream); return rc; }
     }
     for (int k = 0; k < na; ++k)
-      if (arrs[k].out) memcpy(arrs[k].out, g.pin[0] + off[k], arrs[k].bytes * n);
+      if (arrs[k].out && staged[k]) memcpy(arrs[k].out, g.pin[0] + off[k], arrs[k].bytes * n);
     return KYB_OK;
   }
   // in between (up to 2^16 items): copy in, run, copy out, on the engine stream
@@ -585,7 +605,7 @@ class HostCall {
   int inout(const void* p_in, void* p_out, size_t bytes) { return add(p_in, p_out, bytes, 0); }      // one device array, filled from p_in and/or returned to p_out
   void secret() { secret_ = true; }
   template <class T = uint8_t>
-  T* dev(int slot) const { return a_[slot].present ? reinterpret_cast<T*>(base_ + a_[slot].off) : nullptr; }
+  T* dev(int slot) const { return a_[slot].present ? reinterpret_cast<T*>(a_[slot].own ? a_[slot].own : base_ + a_[slot].off) : nullptr; }
   template <class Body>
   int run(Body body) {
     Ctx& g = g_;
@@ -599,8 +619,13 @@ class HostCall {
       base_ = g.pin[0];
       // secret(): cleared on EVERY way out (each return below is behind a completed wait or a stream synchronisation)
       auto wipe = on_scope_exit([&] { if (secret_ && total_) memset(base_, 0, total_); });
+      if (g.opt_host_inplace != 0 && total_ >= INPLACE_MIN_BYTES)
+        for (int i = 0; i < n_; ++i) {         // page-locked caller arrays are used where they lie (pinned_dev_ptr); not those the kernels may read past the end of
+          Arr& a = a_[i];
+          if (a.present && a.bytes && a.pad == 0 && (a.src == nullptr || a.dst == nullptr || a.src == a.dst)) a.own = pinned_dev_ptr(g, a.src ? a.src : a.dst);
+        }
       for (int i = 0; i < n_; ++i)
-        if (a_[i].src && a_[i].bytes) memcpy(base_ + a_[i].off, a_[i].src, a_[i].bytes);
+        if (a_[i].src && a_[i].bytes && !a_[i].own) memcpy(base_ + a_[i].off, a_[i].src, a_[i].bytes);
       rc = ensure_done_flag(g);
       if (rc) return rc;
       {
@@ -612,7 +637,7 @@ class HostCall {
         if (rc) { (void)hipStreamSynchronize(g.stream); return rc; }
       }
       for (int i = 0; i < n_; ++i)
-        if (a_[i].dst && a_[i].bytes) memcpy(a_[i].dst, base_ + a_[i].off, a_[i].bytes);
+        if (a_[i].dst && a_[i].bytes && !a_[i].own) memcpy(a_[i].dst, base_ + a_[i].off, a_[i].bytes);
       return KYB_OK;
     }
     int rc = ensure_stage(g, total_);
@@ -637,10 +662,10 @@ class HostCall {
   }
 
  private:
-  struct Arr { const void* src; void* dst; size_t bytes, off; bool present; };
+  struct Arr { const void* src; void* dst; size_t bytes, off, pad; bool present; uint8_t* own; };      // own: the caller's page-locked array itself (zero-copy calls)
   int add(const void* src, void* dst, size_t bytes, size_t pad) {
     const bool present = src != nullptr || dst != nullptr;
-    a_[n_] = Arr{src, dst, bytes, total_, present};
+    a_[n_] = Arr{src, dst, bytes, total_, pad, present, nullptr};
     if (present) total_ += up256(bytes + pad);
     return n_++;
   }
