@@ -462,8 +462,11 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     projective, so that no inversion runs in front (default 128 x compute units = one wavefront per SIMD: 32768 on an MI355X, 0 = never): up to there the
  *                     call time is one lane's chain of 255 steps, and the two-lane form takes 0.49 instead of 0.79 ms.  Same results.  These
  *                     launches always walk 256 bits (minus publicly known zeros): ladder.skip_canonical does not apply to them.
- *   coop.ladder_max_items  variable base and linear combinations leave the one-item-per-wavefront kernels above this many items (default 3072;
- *                     verification at 7/8 of it) even when coop.max_items would still allow them: from there the two-lane ladder is faster.
+ *   coop.ladder_max_items  variable base and linear combinations leave the one-item-per-wavefront kernels above this many items (default 2816;
+ *                     verification with the keys given as points at 7/8 of it) even when coop.max_items would still allow them: from there the
+ *                     two-lane ladder is faster.
+ *   coop.ladder_enc_max_items  the same for calls from BYTES — kyb_mul_batch with pts_enc (full-length multipliers), kyb_verify_batch: default 2048
+ *                     (two wavefronts per SIMD); above it the role-split launches of ladder.y_only = 2 are faster.
  *   ladder.skip_canonical  1 (default): the batch ladder starts four bits lower when no scalar of the launch reaches 2^252 — true of a scalar
  *                     reduced mod L (L = 2^252 + 2.8e37) except for 2^-127 of them, so the test (an OR over the batch, taken on the way by the
  *                     kernel that prepares the points) says nothing about a canonical secret; one unreduced scalar anywhere and the launch

@@ -137,7 +137,8 @@ struct Ctx {
   std::atomic<int> opt_host_inplace{1};           // zero-copy host-pointer calls use page-locked CALLER arrays (kyb_host_alloc) where they lie instead of copying them into the context's buffer
   std::atomic<int> opt_zero_copy_kib{4096};         // host-pointer calls whose arrays fit this many KiB run their kernels on the context's page-locked buffer (no hipMemcpy); 512 in round 2, 4 MiB wins up to 16,384 items (profiles/r03/mid_size_host_calls.log)
   std::atomic<int> opt_ladder_pair_max{32768};    // ladder launches of at most this many items give each item two lanes (k_mul_ladder_pair: one wavefront per SIMD up to here); 0 = never
-  std::atomic<int> opt_coop_ladder_max{3072};     // variable base, linear combinations (verification: 7/8 of it): above this the two-lane batch ladder is faster than one item per wavefront (profiles/r03/ladder_pair_probe.log)
+  std::atomic<int> opt_coop_ladder_max{2816};     // variable base from points, linear combinations: above this the two-lane batch ladder is faster than one item per wavefront (3072 until the batch path lost its in-kernel decode wait: profiles/r04/coop_vs_fused.log)
+  std::atomic<int> opt_coop_ladder_enc_max{2048};  // the same for calls from BYTES (multiplication from encodings, verification from key bytes): the role-split launches of ladder.y_only = 2 take over at two wavefronts per SIMD
   std::atomic<int> opt_ladder_skip_canonical{1};  // the batch ladder skips the four leading bits when no scalar of the launch has one set (canonical scalars)
   std::atomic<int> opt_mul_short_scalars{0};     // 1: EVERY host-pointer kyb_mul_batch of <= 64 items is treated like kyb_mul_public_batch (multipliers declared public:
                                                  // when all are below 2^64 the ladder skips the leading zeros).  Off by default: the ABI cannot know that a multiplier is public.
@@ -1168,7 +1169,7 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
   StreamRes* r = nullptr;
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
-  if (n <= coop_lim(g, g.opt_coop_max) && n <= coop_lim(g, g.opt_coop_ladder_max) && g.opt_mul_algo == 1) {
+  if (n <= coop_lim(g, g.opt_coop_max) && n <= coop_lim(g, penc != nullptr && skip_hint < 192 ? g.opt_coop_ladder_enc_max : g.opt_coop_ladder_max) && g.opt_mul_algo == 1) {
     // small batch: one item per wavefront, the whole multiplication in one launch (kernels_coop.hip)
     if (penc != nullptr && 4 * n <= coop_lim(g, g.opt_coop_max)) {
       // from the wire encoding, two wavefronts per item: the ladder starts on y while the decode is still looking for x
@@ -1464,7 +1465,8 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   // the chip idle it runs on the side stream
   const size_t fork_max = g.opt_ladder_y_only != 0 && pair_lim(g, g.opt_ladder_pair_max) > (size_t)64 * (size_t)g.cus ? pair_lim(g, g.opt_ladder_pair_max) : (size_t)64 * (size_t)g.cus;
   const bool fork = g.opt_verify_overlap && n <= fork_max && host_load(g) < 4;      // with several calls in flight the other calls fill the idle SIMDs; a side stream only adds queue traffic
-  const bool coop = g.opt_mul_algo == 1 && n <= coop_lim(g, g.opt_coop_max) && n <= coop_lim(g, g.opt_coop_base_max) && 8 * n <= 7 * coop_lim(g, g.opt_coop_ladder_max);     // small batch: one item per wavefront
+  const bool coop = g.opt_mul_algo == 1 && n <= coop_lim(g, g.opt_coop_max) && n <= coop_lim(g, g.opt_coop_base_max) &&
+                    (pubs_ext == nullptr ? n <= coop_lim(g, g.opt_coop_ladder_enc_max) : 8 * n <= 7 * coop_lim(g, g.opt_coop_ladder_max));     // small batch: one item per wavefront
   hipStream_t side = st;
   if (fork) {
     rc = ensure_aux(g, r); if (rc) return rc;

@@ -16,7 +16,7 @@ KATS = json.load(open(os.path.join(HERE, "golden", "kats.json")))
 
 @pytest.fixture()
 def coop_engine(engine):
-    keys = ("coop.max_items", "coop.base_max_items", "coop.ladder_max_items")
+    keys = ("coop.max_items", "coop.base_max_items", "coop.ladder_max_items", "coop.ladder_enc_max_items")
     old = [engine.get_option(k) for k in keys]
     for k in keys:
         engine.set_option(k, 1 << 20)

@@ -46,6 +46,7 @@ for n in (512, 1024, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 32768):
     for coop in (2, 1, 0):                     # 2: as 1, and verification by the single-launch kernel (three wavefronts per signature)
         eng.set_option("coop.max_items", 1 << 20 if coop else 0)
         eng.set_option("coop.ladder_max_items", 1 << 20)
+        eng.set_option("coop.ladder_enc_max_items", 1 << 20)
         eng.set_option("coop.base_max_items", 1 << 20 if coop else 0)
         eng.set_option("coop.verify_max_items", 1 << 20 if coop == 2 else 0)
         a = t(lambda: eng.mul_base_dev(s[:n], out_enc=out[:n]))

@@ -16,6 +16,7 @@ print("n, path, op, call_us, kernels")
 for coop in (1, 0):
     eng.set_option("coop.max_items", 1 << 20 if coop else 0)
     eng.set_option("coop.ladder_max_items", 1 << 20)
+    eng.set_option("coop.ladder_enc_max_items", 1 << 20)
     eng.set_option("coop.base_max_items", 1 << 20 if coop else 0)
     for n in (1, 64, 1024, 2048, 4096):
         for op, fn in (("mul_base", lambda: eng.mul_base(s[:n])), ("mul", lambda: eng.mul(s[:n], pts_ext=ext[:n])),

@@ -28,7 +28,7 @@ orc = oracle_lib.Oracle()
 KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "kats.json")))
 weak = [orc.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
 L = synth.L
-SIZES = [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 512, 513, 700, 1023, 1024, 1025, 1536, 1537, 2048, 2049, 4096, 4097, 6144, 6145]
+SIZES = [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 512, 513, 700, 1023, 1024, 1025, 1536, 1537, 2048, 2049, 2816, 2817, 4096, 4097, 6144, 6145]
 NMAX = max(SIZES)
 POOL_S = synth.raw256(NMAX, 1000 + seed)
 POOL_S[::3] = synth.scalars(len(POOL_S[::3]), 2000 + seed)
@@ -65,7 +65,7 @@ def set_random_options():
     o = {"ext.projective": int(rng.integers(0, 2)), "poly.segments": int(rng.choice([0, 0, 1, 2, 5, 32])), "poly.batch_segments": int(rng.choice([0, 0, 1, 1, 2, 3, 16, 200])),
          "coop.verify_max_items": int(rng.choice([512, 512, 0, 4096])), "verify.by_encoding": int(rng.integers(0, 2)),
          "verify.overlap": int(rng.integers(0, 2)), "ladder.pair_max_items": int(rng.choice([32768, 32768, 0, 1 << 20])),
-         "coop.ladder_max_items": int(rng.choice([3072, 3072, 1 << 20, 700])),
+         "coop.ladder_max_items": int(rng.choice([2816, 2816, 1 << 20, 700])), "coop.ladder_enc_max_items": int(rng.choice([2048, 2048, 1 << 20, 700])),
          "ladder.y_only": int(rng.integers(0, 3)), "finish.four": int(rng.integers(0, 2))}
     if rng.integers(0, 4) == 0:              # the batch kernels of DKG-sized calls at these sizes (two-lane ladder, ladder.y_only, finish.four)
         o["coop.max_items"], o["coop.base_max_items"] = 0, 0
