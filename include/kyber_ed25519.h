@@ -164,6 +164,8 @@ int kyb_group_sync(kyb_group* g);
 /* The host-pointer calls accept any host memory.  From pageable memory the copies run at ~7 GB/s and
  * dominate (2^20 variable-base items: 33 ms against 9.4 ms of kernels); batch buffers obtained here are
  * page-locked, DMA at PCIe rate and let the chunked two-stream pipeline overlap copies with kernels.
+ * The memory is host-coherent and mapped for the context's device: a call small enough to run without copies
+ * (option host.zero_copy_kib) reads and writes arrays that lie in it where they lie (option host.in_place).
  * Returns NULL on failure (kyb_last_error).  Free with kyb_host_free. */
 void* kyb_host_alloc(size_t bytes);
 void kyb_host_free(void* p);
@@ -496,9 +498,10 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *   defer.max_nodes   nodes the deferred-point arena keeps before it drops the oldest (default 2^20, at least 16); a dropped handle is refused
  *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder (and, with ladder.y_only, the decode of A)
  *   verify.by_encoding 1 (default): large batches test the equation as enc(s*B - h*A) == R bytes and decode R only on a mismatch
- *   host.in_place     1 (default): a host-pointer call small enough for host.zero_copy_kib (and of at least 64 KiB) whose array lies in PAGE-LOCKED
- *                     memory of this context's device (kyb_host_alloc, 16-byte aligned) has its kernels read / write that array where it lies
- *                     instead of a copy in the context's buffer (an 8,192-item multiplication: 0.03-0.05 ms less); 0: always copy.  Same results.
+ *   host.in_place     1 (default): a host-pointer call small enough for host.zero_copy_kib (and of at least 64 KiB) whose array lies in memory
+ *                     kyb_host_alloc handed out on this context's device (16-byte aligned start) has its kernels read / write that array where it
+ *                     lies instead of a copy in the context's buffer (an 8,192-item multiplication: 0.03-0.05 ms less); other page-locked
+ *                     memory may be non-coherent and is copied like pageable memory.  0: always copy.  Same results.
  *   host.zero_copy_kib  host-pointer calls whose arrays together fit this many KiB skip every hipMemcpy: the inputs are copied into the
  *                     context's page-locked buffer by the calling thread and the kernels read and write it over PCIe (default 4096).
  *                     Larger calls of fewer than 2^16 items copy in, run and copy out on the engine stream.

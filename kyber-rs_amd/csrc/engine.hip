@@ -265,16 +265,28 @@ bool is_pinned(const void* p) {
   return a.type == hipMemoryTypeHost;
 }
 
-// Device-visible address of a caller's PAGE-LOCKED array (kyb_host_alloc, hipHostRegister), or nullptr.  The kernels of a zero-copy call work on the
-// context's page-locked buffer over PCIe anyway: an array that already is such memory is read and written where it lies, and the calling thread's
-// memcpy into / out of the buffer (0.03 ms of a DKG-sized call) drops out.  Asked only for calls of at least INPLACE_MIN_BYTES (the query costs ~1 us).
-constexpr size_t INPLACE_MIN_BYTES = (size_t)64 << 10;
-uint8_t* pinned_dev_ptr(const Ctx& g, const void* p) {
-  if (p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) != 0) return nullptr;        // the kernels load and store 16-byte words
-  hipPointerAttribute_t a;
-  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  if (a.type != hipMemoryTypeHost || a.devicePointer == nullptr || a.device != g.device) return nullptr;
-  return static_cast<uint8_t*>(a.devicePointer);
+// Device-visible address of a caller array that lies in memory kyb_host_alloc handed out (page-locked, host-COHERENT, mapped for this device), or
+// nullptr.  The kernels of a zero-copy call work on the context's page-locked buffer over PCIe anyway: an array that already is such memory is read and
+// written where it lies, and the calling thread's memcpy into / out of the buffer (0.03 ms of a DKG-sized call) drops out.  Only kyb_host_alloc memory
+// qualifies — other page-locked memory (hipHostRegister, a hipHostMalloc of the caller's) may be non-coherent, and a zero-copy call reads its results
+// when the completion flag arrives, before the end of the kernel is observed; such arrays are copied like pageable ones.
+constexpr size_t INPLACE_MIN_BYTES = (size_t)64 << 10;      // below this the copies cost less than looking
+struct HostAllocs {
+  struct Rec { size_t bytes; int device; ptrdiff_t dev_delta; };
+  std::mutex mu;
+  std::map<uintptr_t, Rec> recs;
+};
+HostAllocs& host_allocs() { static HostAllocs* h = new HostAllocs; return *h; }      // never destroyed: kyb_host_free may run during process teardown
+uint8_t* pinned_dev_ptr(const Ctx& g, const void* p, size_t bytes) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  if (p == nullptr || (a & 15u) != 0) return nullptr;        // the kernels load and store 16-byte words
+  HostAllocs& h = host_allocs();
+  std::lock_guard<std::mutex> lk(h.mu);
+  auto it = h.recs.upper_bound(a);
+  if (it == h.recs.begin()) return nullptr;
+  --it;
+  if (a - it->first > it->second.bytes || bytes > it->second.bytes - (a - it->first) || it->second.device != g.device) return nullptr;
+  return reinterpret_cast<uint8_t*>(a + it->second.dev_delta);
 }
 
 // ---- completion flag of small host-pointer calls --------------------------------------------------------
@@ -514,7 +526,7 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
       dptr[k] = (arrs[k].in || arrs[k].out) ? g.pin[0] + off[k] : nullptr;
       staged[k] = dptr[k] != nullptr;
       if (try_inplace && staged[k] && (arrs[k].in == nullptr || arrs[k].out == nullptr || arrs[k].in == arrs[k].out)) {
-        uint8_t* own = pinned_dev_ptr(g, arrs[k].in ? arrs[k].in : arrs[k].out);          // page-locked caller array: used where it lies
+        uint8_t* own = pinned_dev_ptr(g, arrs[k].in ? arrs[k].in : arrs[k].out, arrs[k].bytes * n);      // kyb_host_alloc memory: used where it lies
         if (own != nullptr) { dptr[k] = own; staged[k] = false; }
       }
       if (arrs[k].in && staged[k]) memcpy(dptr[k], arrs[k].in, arrs[k].bytes * n);
@@ -621,9 +633,9 @@ class HostCall {
       // secret(): cleared on EVERY way out (each return below is behind a completed wait or a stream synchronisation)
       auto wipe = on_scope_exit([&] { if (secret_ && total_) memset(base_, 0, total_); });
       if (g.opt_host_inplace != 0 && total_ >= INPLACE_MIN_BYTES)
-        for (int i = 0; i < n_; ++i) {         // page-locked caller arrays are used where they lie (pinned_dev_ptr); not those the kernels may read past the end of
+        for (int i = 0; i < n_; ++i) {         // arrays in kyb_host_alloc memory are used where they lie (pinned_dev_ptr); not those the kernels may read past the end of
           Arr& a = a_[i];
-          if (a.present && a.bytes && a.pad == 0 && (a.src == nullptr || a.dst == nullptr || a.src == a.dst)) a.own = pinned_dev_ptr(g, a.src ? a.src : a.dst);
+          if (a.present && a.bytes && a.pad == 0 && (a.src == nullptr || a.dst == nullptr || a.src == a.dst)) a.own = pinned_dev_ptr(g, a.src ? a.src : a.dst, a.bytes);
         }
       for (int i = 0; i < n_; ++i)
         if (a_[i].src && a_[i].bytes && !a_[i].own) memcpy(base_ + a_[i].off, a_[i].src, a_[i].bytes);
