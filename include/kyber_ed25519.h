@@ -453,7 +453,7 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *   encode.batched    1 (default): kyb_encode_batch shares one inversion between 8 points; 0: one per point
  *   coop.max_items    batches of at most this many items take the one-item-per-wavefront kernels (variable base, verification,
  *                     polynomial evaluation; default 6144, 0 = never); coop.base_max_items the same for the fixed base and signing
- *                     (default 4096), coop.decode_max_items for a bare decode (default 1024), coop.verify_max_items for the
+ *                     (default 3328), coop.decode_max_items for a bare decode (default 1024), coop.verify_max_items for the
  *                     kernels that give ONE item several wavefronts (verification in one launch, signing in one launch, the fixed
  *                     base with four wavefronts per item; default 512).  Same results either way.
  *   coop.share_by_load  1 (default): the coop.* and ladder.pair_max_items thresholds are divided by the number of synchronous host-pointer

@@ -147,7 +147,7 @@ struct Ctx {
   std::atomic<int> opt_verify_by_enc{1};         // large verification batches: compare the encoding of s*B - h*A with R's bytes, decode R only on a mismatch
   std::atomic<int> opt_coop_verify_max{512};     // verification: up to this many signatures take the single-launch kernel (three wavefronts each)
   std::atomic<int> opt_coop_decode_max{1024};    // unmarshal_binary alone: the same (crossover between 1024 and 2048)
-  std::atomic<int> opt_coop_base_max{4096};      // fixed base: the same (crossover just above 4096; signing counts its two multiplications per item)
+  std::atomic<int> opt_coop_base_max{3328};      // fixed base: the same (crossover at 13 wavefronts per CU since the batch path's finish shares an inversion between four items: profiles/r04/coop_vs_fused.log; 4096 before; signing counts its two multiplications per item)
   std::atomic<int> opt_encode_batched{1};     // kyb_encode_batch: 1 shared inversion per 8 points (k_encode_batched), 0 one inversion per point (k_encode)
   std::mutex mu;          // host-pointer API: staging buffers + engine streams of this context
   std::mutex launch_mu;   // every launch_* entry: per-stream scratch bookkeeping (calls from any thread, any stream)

@@ -25,6 +25,7 @@ msgs = torch.from_numpy(np.random.default_rng(3).integers(0, 256, 32 * N, dtype=
 off = torch.arange(0, 32 * (N + 1), 32, dtype=torch.int32, device=dev)
 sig = torch.empty((N, 64), dtype=torch.uint8, device=dev)
 status = torch.empty((N,), dtype=torch.uint8, device=dev)
+sig2 = torch.empty((N, 64), dtype=torch.uint8, device=dev)
 eng.mul_base_dev(s, out_enc=pubs, out_ext=ext)
 eng.sign_dev(s, k, msgs, off, sig)
 eng.sync()
@@ -40,8 +41,8 @@ def t(fn, reps=21):
     return sorted(ts)[len(ts) // 2] * 1e3
 
 
-print("n, routing: mul_ms, mul_enc_ms, verify_ms", flush=True)
-for n in (64, 512, 1024, 1536, 1792, 2048, 2304, 2560, 2816, 3072, 3584, 4096, 6144):
+print("n, routing: mul_ms, mul_enc_ms, verify_ms, mul_base_ms, sign_ms", flush=True)
+for n in (64, 512, 1024, 1536, 2048, 2304, 2560, 2816, 3072, 3584, 4096, 5120, 6144):
     for rnd in range(2):
         for name, opts in (("shipped", saved), ("batch kernels", {kk: 0 for kk in KEYS})):
             for kk, v in opts.items():
@@ -49,6 +50,8 @@ for n in (64, 512, 1024, 1536, 1792, 2048, 2304, 2560, 2816, 3072, 3584, 4096, 6
             m = t(lambda: eng.mul_dev(s[:n], pts_ext=ext[:n], out_enc=out[:n]))
             a = t(lambda: eng.mul_dev(s[:n], pts_enc=pubs[:n], out_enc=out[:n]))
             b = t(lambda: eng.verify_dev(pubs[:n], msgs, off[: n + 1], sig[:n], status[:n], 1))
-            print(f"{n}, {name}: {m:.3f}, {a:.3f}, {b:.3f}", flush=True)
+            c = t(lambda: eng.mul_base_dev(s[:n], out_enc=out[:n]))
+            d = t(lambda: eng.sign_dev(s[:n], k[:n], msgs, off[: n + 1], sig2[:n]))
+            print(f"{n}, {name}: {m:.3f}, {a:.3f}, {b:.3f}, {c:.3f}, {d:.3f}", flush=True)
 for kk, v in saved.items():
     eng.set_option(kk, v)

@@ -28,7 +28,7 @@ orc = oracle_lib.Oracle()
 KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "kats.json")))
 weak = [orc.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
 L = synth.L
-SIZES = [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 512, 513, 700, 1023, 1024, 1025, 1536, 1537, 2048, 2049, 2816, 2817, 4096, 4097, 6144, 6145]
+SIZES = [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 512, 513, 700, 1023, 1024, 1025, 1536, 1537, 1664, 1665, 2048, 2049, 2816, 2817, 3328, 3329, 4096, 4097, 6144, 6145]
 NMAX = max(SIZES)
 POOL_S = synth.raw256(NMAX, 1000 + seed)
 POOL_S[::3] = synth.scalars(len(POOL_S[::3]), 2000 + seed)
@@ -71,7 +71,7 @@ def set_random_options():
         o["coop.max_items"], o["coop.base_max_items"] = 0, 0
         o["coop.verify_max_items"] = int(rng.choice([0, 0, 512]))
     else:
-        o["coop.max_items"], o["coop.base_max_items"] = 6144, 4096
+        o["coop.max_items"], o["coop.base_max_items"] = 6144, 3328
     for k_, v in o.items():
         eng.set_option(k_, v)
     return o
