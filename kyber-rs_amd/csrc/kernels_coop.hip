@@ -797,7 +797,7 @@ k_sign_coop(const uint8_t* __restrict__ x, const uint8_t* __restrict__ k, const 
 // a failed decode gives ok = 0 and the neutral element, as k_decode_or_identity + k_mul_coop do in two launches.
 __global__ void __launch_bounds__(128)
 k_mul_enc_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ pts_enc, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
-               uint8_t* __restrict__ ok_out, kyb::launch::DoneFlag df) {
+               uint8_t* __restrict__ ok_out, kyb::launch::DoneFlag df, uint4* __restrict__ proj, size_t proj_stride, uint8_t* __restrict__ flags_or, int skip_bits) {
   __shared__ uint32_t sh_x[10], sh_ok[1];
   const size_t i = blockIdx.x;
   if (i >= n) return;
@@ -816,7 +816,7 @@ k_mul_enc_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ 
     sc_effective(neg, mag, a);
     const cq yq = quad_row_from_fe(c, quad_row_from_fe(c, 0u, 0, Y), 2, Y);
     const cq UWQ = cnorm(c, c.row == 0 ? cadd(ONE0, yq) : (c.row == 2 ? csub(c, ONE0, yq) : 0u));
-    coop_ladder_run(c, mag, 0, UWQ, SX, SZ);
+    coop_ladder_run(c, mag, skip_bits, UWQ, SX, SZ);
   } else {
     ge_p3 P;
     const uint32_t ok = coop_decode_fn{c}(P, w);
@@ -834,9 +834,11 @@ k_mul_enc_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ 
   uint32_t p_flags;
   const cq M = coop_mont_prep(c, PQ, p_flags);
   const cq RES = coop_mont_recover(c, M, SX, SZ, p_flags, mag[0] & 1u, neg);
-  coop_finish(c, RES, 0u, out_enc, out_ext, i);
+  // (proj: the h A of a verification, handed on projective to k_verify_final; flags_or: "the key decodes" joins the flags k_verify_hash wrote)
+  coop_finish(c, RES, 0u, out_enc, out_ext, i, proj, proj_stride, 0);
   if (c.lane == 0) {
     if (ok_out != nullptr) ok_out[i] = (uint8_t)ok;
+    if (flags_or != nullptr) flags_or[i] = (uint8_t)(flags_or[i] | (ok << 2));
     signal_done(df);
   }
 }
@@ -1020,8 +1022,9 @@ hipError_t sign_coop(hipStream_t st, const uint8_t* x, const uint8_t* k, const u
   hipLaunchKernelGGL(k_sign_coop, dim3((unsigned)n), dim3(512), 0, st, x, k, pubs, msgs, off, n, sig, pub_out, table_coop, df);
   return hipGetLastError();
 }
-hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, DoneFlag df) {
-  hipLaunchKernelGGL(k_mul_enc_coop, dim3((unsigned)n), dim3(128), 0, st, sc, penc, n, oenc, oext, ok, df);
+hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, DoneFlag df,
+                        uint4* proj, size_t proj_stride, uint8_t* flags_or, int skip_bits) {
+  hipLaunchKernelGGL(k_mul_enc_coop, dim3((unsigned)n), dim3(128), 0, st, sc, penc, n, oenc, oext, ok, df, proj, proj_stride, flags_or, skip_bits);
   return hipGetLastError();
 }
 hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, int flavor,

@@ -97,7 +97,8 @@ hipError_t poly_eval_coop(hipStream_t st, const int32_t* commits, int t, const u
                           uint8_t* oenc, int32_t* oext, DoneFlag df = DoneFlag{}, bool ext_proj = false);
 hipError_t sign_coop(hipStream_t st, const uint8_t* x, const uint8_t* k, const uint8_t* pubs, const uint8_t* msgs, const uint32_t* off, size_t n,
                      uint8_t* sig, uint8_t* pub_out, const uint32_t* table_coop, DoneFlag df = DoneFlag{});
-hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, DoneFlag df = DoneFlag{});
+hipError_t mul_enc_coop(hipStream_t st, const uint8_t* sc, const uint8_t* penc, size_t n, uint8_t* oenc, int32_t* oext, uint8_t* ok, DoneFlag df = DoneFlag{},
+                        uint4* proj = nullptr, size_t proj_stride = 0, uint8_t* flags_or = nullptr, int skip_bits = 0);      // proj / flags_or: the h A of a verification (record i, projective; flags_or[i] |= decodes << 2)
 hipError_t verify_coop(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, int flavor,
                        const uint32_t* table_coop, uint8_t* status, DoneFlag df = DoneFlag{});
 // segs wavefronts (2..32) per evaluation, len coefficients each (segs * len >= t); part: n * segs * 40 words of device scratch
