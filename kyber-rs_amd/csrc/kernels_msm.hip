@@ -106,11 +106,17 @@ k_msm_accumulate(const uint8_t* __restrict__ scalars, const uint32_t* __restrict
 // Lagrange coefficients at 0 of recover_commit (poly.rs:580-594): for share set g with indices idx[g][0 .. t), x_i = idx_i + 1 as Scalars,
 //     lambda[g][i] = prod_{j != i} x_j * ( prod_{j != i} (x_j - x_i) )^(L - 2)   mod L
 // — the reference's num / den with its Scalar::div = multiplication by den^(L-2) (scalar.rs:185-215; the inverse of 0 is 0).  One lane per
-// (g, i): 2 (t - 1) products and one fixed 253-bit exponentiation, where the reference walks the t^2 products on one core.  Share
-// indices are public: nothing here needs to be constant time (it is anyway: fixed loop bounds, no data-dependent branch).
-__device__ __forceinline__ void sc_from_u32(uint32_t r[8], uint32_t v) {
-  r[0] = v;
-  KYB_UNROLL for (int i = 1; i < 8; ++i) r[i] = 0u;
+// (g, i), where the reference walks the t^2 products on one core.  Share indices are public, so nothing here needs to be constant time, and
+// a multiplication mod L (sc_muladd: a 512-bit product and its reduction, ~1 us of a lone lane) is what the time goes to:
+//   * the factors are small — x_j <= 2^32, |x_j - x_i| < 2^32, ten bits for the share indices of a real DKG — so F = floor(63 / bits of the
+//     group's largest x) of them are multiplied in a 64-bit word first and only every F-th step is a multiplication mod L (the sign of the
+//     denominator is counted and applied once); F is the same for every lane of a group, the schedule is uniform;
+//   * den^(L - 2) walks the FIXED exponent with a sliding window over the odd powers den^1 .. den^15: 253 squarings, 8 + 28 products instead of
+//     253 + 253.
+// 1,870 -> 560 multiplications mod L for one set of 683 ten-bit indices.
+__device__ __forceinline__ void sc_from_u64(uint32_t r[8], uint64_t v) {
+  r[0] = (uint32_t)v; r[1] = (uint32_t)(v >> 32);
+  KYB_UNROLL for (int i = 2; i < 8; ++i) r[i] = 0u;
 }
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
 k_lagrange_at_zero(const uint32_t* __restrict__ idx, size_t m, size_t t, uint8_t* __restrict__ out) {
@@ -121,43 +127,83 @@ k_lagrange_at_zero(const uint32_t* __restrict__ idx, size_t m, size_t t, uint8_t
   const uint32_t Lw[8] = KYB_W_L;
   const uint32_t zero[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   const uint64_t xi = (uint64_t)xs[i] + 1u;
+  uint32_t top = 0;
+#pragma unroll 1
+  for (size_t j = 0; j < t; ++j) top = xs[j] > top ? xs[j] : top;
+  const int bits = 64 - __clzll((unsigned long long)top + 1ull);      // of the largest x (and of every difference): 1 .. 33
+  const int F = 63 / bits;                                             // factors per 64-bit word
   uint32_t num[8], den[8];
-  sc_from_u32(num, 1u);
-  sc_from_u32(den, 1u);
+  sc_from_u64(num, 1u);
+  sc_from_u64(den, 1u);
+  uint64_t pn = 1, pd = 1;
+  uint32_t neg = 0;
+  int cnt = 0;
 #pragma unroll 1
   for (size_t j = 0; j < t; ++j) {
-    if (j == i) continue;                              // (wave-divergent for one iteration per lane; indices are public)
     const uint64_t xj = (uint64_t)xs[j] + 1u;
-    uint32_t a[8], d[8], r[8];
-    a[0] = (uint32_t)xj; a[1] = (uint32_t)(xj >> 32);
-    KYB_UNROLL for (int q = 2; q < 8; ++q) a[q] = 0u;
-    sc_muladd(r, num, a, zero);
-    KYB_UNROLL for (int q = 0; q < 8; ++q) num[q] = r[q];
-    // x_j - x_i mod L: the difference itself, or L minus its magnitude
-    const bool below = xj < xi;
-    const uint64_t mag = below ? xi - xj : xj - xi;
-    uint32_t mg[8];
-    mg[0] = (uint32_t)mag; mg[1] = (uint32_t)(mag >> 32);
-    KYB_UNROLL for (int q = 2; q < 8; ++q) mg[q] = 0u;
-    uint32_t lm[8];
-    mw_sub<8>(lm, Lw, mg);
-    KYB_UNROLL for (int q = 0; q < 8; ++q) d[q] = below ? lm[q] : mg[q];
-    sc_muladd(r, den, d, zero);
-    KYB_UNROLL for (int q = 0; q < 8; ++q) den[q] = r[q];
+    const bool skip = j == i, below = xj < xi;
+    pn *= skip ? 1ull : xj;
+    pd *= skip ? 1ull : (below ? xi - xj : xj - xi);                   // |x_j - x_i|; 0 for a repeated index: the coefficient becomes 0
+    neg ^= (uint32_t)(below && !skip);
+    if (++cnt == F || j + 1 == t) {                                    // uniform in the group: F and t are
+      uint32_t a[8], r[8];
+      sc_from_u64(a, pn);
+      sc_muladd(r, num, a, zero);
+      KYB_UNROLL for (int q = 0; q < 8; ++q) num[q] = r[q];
+      sc_from_u64(a, pd);
+      sc_muladd(r, den, a, zero);
+      KYB_UNROLL for (int q = 0; q < 8; ++q) den[q] = r[q];
+      pn = pd = 1; cnt = 0;
+    }
   }
-  // den^(L - 2): square-and-multiply over the fixed exponent, top bit first
+  {                                                                    // an odd number of negative factors: den = L - den (0 stays 0)
+    uint32_t nd[8], nz = 0;
+    mw_sub<8>(nd, Lw, den);
+    KYB_UNROLL for (int q = 0; q < 8; ++q) nz |= den[q];
+    const bool flip = neg != 0u && nz != 0u;
+    KYB_UNROLL for (int q = 0; q < 8; ++q) den[q] = flip ? nd[q] : den[q];
+  }
+  // den^(L - 2), top bit first, sliding window of 4 bits over the odd powers (the exponent is a constant: every branch below is uniform)
   uint32_t e[8];
   { const uint32_t two[8] = {2u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}; mw_sub<8>(e, Lw, two); }
+  uint32_t p1[8], p3[8], p5[8], p7[8], p9[8], p11[8], p13[8], p15[8], d2[8];      // (named, not an array: nothing may index them at run time)
+  KYB_UNROLL for (int q = 0; q < 8; ++q) p1[q] = den[q];
+  sc_muladd(d2, den, den, zero);
+  sc_muladd(p3, p1, d2, zero); sc_muladd(p5, p3, d2, zero); sc_muladd(p7, p5, d2, zero); sc_muladd(p9, p7, d2, zero);
+  sc_muladd(p11, p9, d2, zero); sc_muladd(p13, p11, d2, zero); sc_muladd(p15, p13, d2, zero);
   uint32_t inv[8];
-  sc_from_u32(inv, 1u);
+  sc_from_u64(inv, 1u);
+  auto ebit = [&](int b) -> uint32_t {
+    uint32_t w = 0;
+    KYB_UNROLL for (int q = 0; q < 8; ++q) w = (b >> 5) == q ? e[q] : w;
+    return (w >> (b & 31)) & 1u;
+  };
+  int b = 252;
 #pragma unroll 1
-  for (int b = 252; b >= 0; --b) {
+  while (b >= 0) {
     uint32_t r[8];
-    sc_muladd(r, inv, inv, zero);
-    const uint32_t bit = (e[b >> 5] >> (b & 31)) & 1u;
-    uint32_t r2[8];
-    sc_muladd(r2, r, den, zero);
-    KYB_UNROLL for (int q = 0; q < 8; ++q) inv[q] = bit ? r2[q] : r[q];
+    if (ebit(b) == 0u) {
+      sc_muladd(r, inv, inv, zero);
+      KYB_UNROLL for (int q = 0; q < 8; ++q) inv[q] = r[q];
+      --b;
+      continue;
+    }
+    int lo = b - 3 < 0 ? 0 : b - 3;                                   // the window [b .. lo] ends on a set bit
+    while (ebit(lo) == 0u) ++lo;
+    uint32_t v = 0;
+    for (int c = b; c >= lo; --c) v = (v << 1) | ebit(c);
+#pragma unroll 1
+    for (int c = b; c >= lo; --c) {
+      sc_muladd(r, inv, inv, zero);
+      KYB_UNROLL for (int q = 0; q < 8; ++q) inv[q] = r[q];
+    }
+    uint32_t f[8];
+    const uint32_t h = v >> 1;
+    KYB_UNROLL for (int q = 0; q < 8; ++q)
+      f[q] = h == 0u ? p1[q] : h == 1u ? p3[q] : h == 2u ? p5[q] : h == 3u ? p7[q] : h == 4u ? p9[q] : h == 5u ? p11[q] : h == 6u ? p13[q] : p15[q];
+    sc_muladd(r, inv, f, zero);
+    KYB_UNROLL for (int q = 0; q < 8; ++q) inv[q] = r[q];
+    b = lo - 1;
   }
   uint32_t lam[8];
   sc_muladd(lam, num, inv, zero);
