@@ -1,0 +1,133 @@
+// The end of a DKG, restated CALL BY CALL against the C++ mirror of the trait surface — the two places where the reference adds points one at a time:
+//   DistKeyGenerator::dist_key_share   /root/reference src/share/dkg/rabin/dkg.rs:905-953: the distributed public polynomial is the sum of the
+//                                      qualified dealers' commitment polynomials, folded dealer after dealer with
+//   PubPoly::add                       src/share/poly.rs:486-507: t times  commits.push(point().add(&self.commits[i], &q.commits[i]))
+//   recover_commit                     src/share/poly.rs:566-603: for every share  tmp_p = mul(num / den, Some(&y_i));  acc = acc + tmp_p
+//                                      (num, den: the Lagrange products over the share indices, host Scalar arithmetic as in the reference)
+// A batch-of-1 Point::add is 27 us of launch and PCIe for 2 us of arithmetic — (n - 1) t of them for the distributed key.  With set_deferred(true)
+// the additions are recorded; when the first commitment is marshalled the arena finds t chains of n - 1 additions and evaluates them as ONE
+// kyb_sum_batch call (csrc/defer.inc, "a chain of additions"), and recover_commit becomes one batched multiplication and one sum.
+// Prints both transcripts (tests/test_gpu_vss_round.py compares them with each other and with the oracle) and the wall times.
+//
+//   test_dkg_finish [n dealers = 64] [t = 43]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../kyber-rs_amd/host/edwards25519.hpp"
+
+using namespace kyber;
+using namespace kyber::group::edwards25519;
+
+struct XorShiftStream : Stream {
+  uint64_t s[2] = {0x243F6A8885A308D3ULL, 0x13198A2E03707344ULL};
+  uint64_t next() {
+    uint64_t a = s[0], b = s[1];
+    s[0] = b;
+    a ^= a << 23; a ^= a >> 17; a ^= b ^ (b >> 26);
+    s[1] = a;
+    return a + b;
+  }
+  void xor_key_stream(uint8_t* dst, const uint8_t* src, size_t n) override {
+    for (size_t i = 0; i < n; ++i) dst[i] = src[i] ^ (uint8_t)(next() >> 32);
+  }
+};
+static std::string hex(const std::vector<uint8_t>& v) {
+  static const char* d = "0123456789abcdef";
+  std::string s;
+  for (uint8_t b : v) { s.push_back(d[b >> 4]); s.push_back(d[b & 15]); }
+  return s;
+}
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct Transcript { std::vector<std::string> lines; void put(const char* tag, const std::vector<uint8_t>& b) { lines.push_back(std::string(tag) + " " + hex(b)); } };
+struct Timing { double dist_key = 0, recover = 0; };
+
+// poly.rs:486-507
+static std::vector<Point> pubpoly_add(const std::vector<Point>& p, const std::vector<Point>& q) {
+  std::vector<Point> commits;
+  for (size_t i = 0; i < p.size(); ++i) commits.push_back(Point().add(p[i], q[i]));
+  return commits;
+}
+// poly.rs:133-141
+static Scalar pripoly_eval(const std::vector<Scalar>& coeffs, size_t i) {
+  Scalar xi = Scalar().set_int64(1 + (int64_t)i);
+  Scalar v = Scalar().zero();
+  for (size_t j = coeffs.size(); j-- > 0;) { v = v * xi; v = v + coeffs[j]; }
+  return v;
+}
+
+static void finish_once(size_t n, size_t t, bool deferred_mode, Transcript& tr, Timing& tm, uint64_t stats[8]) {
+  XorShiftStream rand;
+  set_deferred(false);
+  // ---- what the node holds when the protocol is certified (outside the timed part: eager in both runs) ----
+  // every dealer's commitment polynomial (t points), as verified deals left them in self.commitments
+  std::vector<std::vector<Scalar>> coeffs(n, std::vector<Scalar>(t));
+  std::vector<std::vector<Point>> commitments(n, std::vector<Point>(t));
+  for (size_t d = 0; d < n; ++d)
+    for (size_t j = 0; j < t; ++j) {
+      coeffs[d][j] = Scalar().pick(rand);
+      commitments[d][j] = Point().mul(coeffs[d][j], nullptr);
+      tr.put("COEFF", std::vector<uint8_t>(coeffs[d][j].v.begin(), coeffs[d][j].v.end()));      // dealer-major
+    }
+  // public shares of dealer 0's polynomial at t indices (every third index from 1: not consecutive), as recover_commit receives them
+  std::vector<size_t> xs(t);
+  std::vector<Point> ys(t);
+  for (size_t k = 0; k < t; ++k) { xs[k] = 1 + 3 * k; ys[k] = Point().mul(pripoly_eval(coeffs[0], xs[k]), nullptr); }
+  uint64_t s0[8], s1[8];
+  kyb_defer_stats(s0, 8);
+  set_deferred(deferred_mode);
+
+  // ---- dist_key_share, dkg.rs:905-953: pubb = first polynomial, then pubb = pubb.add(poly) for every other qualified dealer ----
+  double t0 = now_ms();
+  std::vector<Point> pubb = commitments[0];
+  for (size_t d = 1; d < n; ++d) pubb = pubpoly_add(pubb, commitments[d]);
+  for (size_t j = 0; j < t; ++j) tr.put("DISTCOMMIT", pubb[j].marshal_binary());       // DistKeyShare.commits, as they go on the wire / into Public()
+  tm.dist_key = now_ms() - t0;
+
+  // ---- recover_commit, poly.rs:566-603 ----
+  t0 = now_ms();
+  Point acc = Point().null();
+  for (size_t i = 0; i < t; ++i) {
+    Scalar num = Scalar().one(), den = Scalar().one();
+    Scalar xi = Scalar().set_int64(1 + (int64_t)xs[i]);
+    for (size_t j = 0; j < t; ++j) {
+      if (i == j) continue;
+      Scalar xj = Scalar().set_int64(1 + (int64_t)xs[j]);
+      num = num * xj;
+      Scalar tmp = Scalar().sub(xj, xi);
+      den = den * tmp;
+    }
+    Scalar lam = Scalar().div(num, den);
+    Point tmp_p = Point().mul(lam, &ys[i]);
+    Point acc_clone = acc;
+    acc = Point().add(acc_clone, tmp_p);
+  }
+  tr.put("RECOVERED", acc.marshal_binary());
+  tm.recover = now_ms() - t0;
+  set_deferred(false);
+  kyb_defer_stats(s1, 8);
+  for (int k = 0; k < 8; ++k) stats[k] = s1[k] - s0[k];
+}
+
+int main(int argc, char** argv) {
+  const size_t n = argc > 1 ? (size_t)atol(argv[1]) : 64, t = argc > 2 ? (size_t)atol(argv[2]) : 43;
+  if (kyb_init(0) != KYB_OK) { std::printf("kyb_init failed: %s\n", kyb_last_error()); return 2; }
+  { Transcript warm; Timing w; uint64_t st[8]; finish_once(n < 3 ? n : 3, t < 4 ? t : 4, false, warm, w, st); finish_once(n < 3 ? n : 3, t < 4 ? t : 4, true, warm, w, st); }
+  Transcript eager, lazy;
+  Timing te, tl;
+  uint64_t se[8], sl[8];
+  finish_once(n, t, false, eager, te, se);
+  finish_once(n, t, true, lazy, tl, sl);
+  for (const std::string& ln : eager.lines) std::printf("E %s\n", ln.c_str());
+  for (const std::string& ln : lazy.lines) std::printf("D %s\n", ln.c_str());
+  std::printf("TIMING {\"n\": %zu, \"t\": %zu, \"eager_ms\": {\"dist_key_share\": %.3f, \"recover_commit\": %.3f}, \"deferred_ms\": {\"dist_key_share\": %.3f, \"recover_commit\": %.3f}, "
+              "\"point_additions\": %zu, \"deferred_stats\": {\"nodes\": %llu, \"flushes\": %llu, \"engine_calls\": %llu, \"horner_fused\": %llu, \"sums_fused\": %llu, \"marshal_cache_hits\": %llu}, "
+              "\"eager_stats_nodes\": %llu}\n",
+              n, t, te.dist_key, te.recover, tl.dist_key, tl.recover, (n - 1) * t + t,
+              (unsigned long long)sl[0], (unsigned long long)sl[1], (unsigned long long)sl[2], (unsigned long long)sl[3], (unsigned long long)sl[4], (unsigned long long)sl[5],
+              (unsigned long long)se[0]);
+  kyb_shutdown();
+  return 0;
+}

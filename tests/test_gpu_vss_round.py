@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(n, t):
-    src = os.path.join(ROOT, "tests", "cpp", "test_vss_round.cpp")
-    out = os.path.join(ROOT, "tests", "cpp", "_build", "test_vss_round")
+def _run(n, t, prog="test_vss_round"):
+    src = os.path.join(ROOT, "tests", "cpp", prog + ".cpp")
+    out = os.path.join(ROOT, "tests", "cpp", "_build", prog)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     libdir = os.path.join(ROOT, "kyber-rs_amd")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-o", out, src,
@@ -71,3 +71,33 @@ def test_small_round_with_odd_shapes(oracle):
         eager, lazy, _ = _run(n, t)
         assert eager == lazy
         _check_against_oracle(eager, n, t, oracle)
+
+
+def test_end_of_a_dkg_call_by_call_eager_and_deferred(oracle):
+    """tests/cpp/test_dkg_finish.cpp: dist_key_share (dkg.rs:905-953: PubPoly::add dealer after dealer, poly.rs:486-507) and recover_commit
+    (poly.rs:566-603) as the reference makes the calls — (n - 1) t + t one-at-a-time Point::add.  The two transcripts are equal, the distributed
+    commitments are the commitments of the summed coefficients, the recovered commitment is the secret's, and the recorded run evaluates every
+    chain of additions as one sum."""
+    import synth
+    L = synth.L
+    for n, t in ((64, 43), (2, 1), (3, 5)):
+        eager, lazy, timing = _run(n, t, "test_dkg_finish")
+        assert eager == lazy
+        by = {}
+        for ln in eager:
+            tag, val = ln.split()
+            by.setdefault(tag, []).append(val)
+        coeffs = [int.from_bytes(bytes.fromhex(c), "little") for c in by["COEFF"]]
+        assert len(coeffs) == n * t and len(by["DISTCOMMIT"]) == t
+        for j in range(t):
+            total = sum(coeffs[d * t + j] for d in range(n)) % L
+            assert by["DISTCOMMIT"][j] == oracle.mul_base(total.to_bytes(32, "little")).hex(), (n, t, j)
+        assert by["RECOVERED"] == [oracle.mul_base(coeffs[0].to_bytes(32, "little")).hex()]
+        st = timing["deferred_stats"]
+        assert timing["eager_stats_nodes"] == 0
+        if n >= 4:
+            print(json.dumps(timing))
+            assert st["sums_fused"] == t + 1                         # t chains of the distributed polynomial, one for recover_commit
+            assert st["engine_calls"] <= 8                           # against (n - 1) t + 2 t batch-of-1 calls
+            assert timing["deferred_ms"]["dist_key_share"] * 20 <= timing["eager_ms"]["dist_key_share"], timing
+            assert timing["deferred_ms"]["recover_commit"] * 3 <= timing["eager_ms"]["recover_commit"], timing
