@@ -620,6 +620,29 @@ def call_by_call_sequences(eng, orc, med, t=43):
         fig = eng.defer_mul_base(share.tobytes())
         return eng.defer_equal(fig, eval_deferred_handle())
 
+    # dist_key_share (dkg.rs:905-953): pubb = pubb.add(poly) for 8 dealers' commitment polynomials, t one-at-a-time Point::add per fold (poly.rs:486-507)
+    dealers = 8
+    polys = [orc.mul_base_ext_batch(_s.scalars(t, 90 + d)) for d in range(dealers)]
+    want_fold = []
+    for j in range(t):
+        acc = polys[0][j]
+        for d in range(1, dealers):
+            acc = orc.add(acc, polys[d][j])
+        want_fold.append(orc.encode(acc))
+
+    def fold_eager():
+        pubb = [polys[0][j] for j in range(t)]
+        for d in range(1, dealers):
+            pubb = [eng.add(pubb[j][None], polys[d][j][None])[0] for j in range(t)]
+        return [eng.encode(p[None])[0].tobytes() for p in pubb]
+
+    def fold_deferred():
+        pubb = [eng.defer_input(polys[0][j]) for j in range(t)]
+        for d in range(1, dealers):
+            pubb = [eng.defer_add(pubb[j], eng.defer_input(polys[d][j])) for j in range(t)]
+        return [eng.defer_get(h) for h in pubb]
+
+    assert fold_eager() == want_fold == fold_deferred()
     assert commit_eager() == [bytes(w) for w in want_commits] == commit_deferred()
     assert orc.encode(eval_eager()) == want_eval == eng.defer_get(eval_deferred_handle())
     assert verify_deal_eager() and verify_deal_deferred()
@@ -627,7 +650,8 @@ def call_by_call_sequences(eng, orc, med, t=43):
     res = {"unit": "us per whole sequence (median of 20), t = 43", "checked_against_oracle": True,
            "commit_then_marshal": {"eager": med(commit_eager, 20), "deferred": med(commit_deferred, 20)},
            "pubpoly_eval": {"eager": med(eval_eager, 20), "deferred": med(lambda: eng.defer_get_ext(eval_deferred_handle()), 20)},
-           "verify_deal": {"eager": med(verify_deal_eager, 20), "deferred": med(verify_deal_deferred, 20)}}
+           "verify_deal": {"eager": med(verify_deal_eager, 20), "deferred": med(verify_deal_deferred, 20)},
+           "pubpoly_add_fold_8_dealers": {"eager": med(fold_eager, 10), "deferred": med(fold_deferred, 10)}}
     res["arena"] = eng.defer_stats()
     eng.defer_floor(mark)
     return res
