@@ -1590,6 +1590,27 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
 // when the lanes of a wavefront disagree, none for the bits no lane has set) and the coefficient's addition: ~1.5 nbits + 1 point
 // operations; the constants were measured with 10-bit indices (16 operations).  The lane-per-item kernels keep a lane's latency
 // up to one wavefront per SIMD (65,536 lanes) and take one more "round" for every further 65,536.
+// Wavefronts per evaluation in the one-evaluation-per-wavefront regime (k_poly_eval_seg).  A segment's wavefront pays one full-length multiplication
+// (x^(s len) of its partial value: ~0.195 ms) on top of its share of the chain, whose steps cost ~0.45 us per unit of (1.5 nbits + 1) — so cutting
+// pays from the chain length at which t steps cost more than that, and then as many segments as there are idle SIMDs for are best (two coefficients per
+// segment at least; profiles/r04/poly_segments_probe.log: t = 43 at a 10-bit index 0.348 -> 0.245 ms, at a 6-bit index one wavefront stays the best).
+int coop_poly_segments(const Ctx& g, size_t n, size_t t, int nbits) {
+  int cs = g.opt_poly_segments;
+  if (cs == 0) {
+    if (nbits <= 1) return 1;                                          // x = 1: the chain is t additions, nothing to gain
+    size_t m = t / 2;
+    const size_t by_room = 2048 / (n ? n : 1);                         // at most two wavefronts per SIMD: both still run near single-wavefront speed
+    if (m > by_room) m = by_room;
+    if (m > 32) m = 32;
+    if (m < 2) return 1;
+    const double step = 0.42 * (1.5 * (double)nbits + 1.0);
+    const double one = (double)t * step, cut = (double)((t + m - 1) / m) * step + 195.0;
+    cs = cut + 10.0 < one ? (int)m : 1;
+  }
+  if (cs > 32) cs = 32;
+  if (cs < 1) cs = 1;
+  return cs;
+}
 int poly_batch_segments(const Ctx& g, size_t n, size_t t, int nbits) {
   const int forced = g.opt_poly_batch_segments;
   if (forced != 0) return forced;
@@ -1597,8 +1618,7 @@ int poly_batch_segments(const Ctx& g, size_t n, size_t t, int nbits) {
   const double f = (1.5 * (double)nbits + 1.0) / 16.0;
   double best;
   if (n <= coop_lim(g, g.opt_coop_max)) {
-    int cs = g.opt_poly_segments;
-    if (cs == 0) { const size_t by_len = t / 24, by_room = 2048 / n; cs = (int)(by_len < by_room ? by_len : by_room); if (cs > 32) cs = 32; if (cs < 1) cs = 1; }
+    const int cs = coop_poly_segments(g, n, t, nbits);
     const double waves = (double)n * cs, crowd = waves > 1280.0 ? waves / 1280.0 : 1.0;      // (1,536 until the two-lane ladder moved the boundary: profiles/r03/poly_eval_pair_probe.log)
     best = ((double)((t + cs - 1) / cs) * 6.2 * f + (cs > 1 ? 160.0 : 0.0)) * crowd + 40.0;
   } else {
@@ -1665,13 +1685,7 @@ int poly_eval_locked(Ctx& g, StreamRes* r, const int32_t* commits, size_t t, con
     // few evaluations: one per wavefront (kernels_coop.hip); a long polynomial at very few indices: several wavefronts per evaluation.
     // A segment costs its wavefront one 255-step multiplication (~26 Horner steps of a 10-bit index) on top of its share of the chain,
     // and the segments of all evaluations should find idle SIMDs (2,048 wavefronts).
-    int segs = g.opt_poly_segments;
-    if (segs == 0) {
-      const size_t by_len = t / 24, by_room = 2048 / n;         // at most two wavefronts per SIMD: both still run near single-wavefront speed
-      segs = (int)(by_len < by_room ? by_len : by_room);
-      if (nbits <= 1) segs = 1;                              // x = 1: the chain is t additions, nothing to gain
-    }
-    if (segs > 32) segs = 32;
+    const int segs = coop_poly_segments(g, n, t, nbits);
     if (segs >= 2 && (size_t)segs <= t) {
       const int len = (int)((t + (size_t)segs - 1) / (size_t)segs);
       int rc = ensure_enc(g, r, 160 * n * (size_t)segs + 256); if (rc) return rc;
