@@ -239,6 +239,7 @@ inline int host_load(const Ctx& g) {
 inline size_t coop_lim(const Ctx& g, int opt) { return opt <= 0 ? 0 : (size_t)opt / (size_t)host_load(g); }
 // the two-lane ladder spends 2 lanes on an item, not 64: it stays worth its 12 % of extra work until the calls in flight fill the chip
 // several times over (16 threads x 4,096 items: 5.7e7 items/s with it, 4.2e7 without)
+inline bool finish_four(const Ctx& g, size_t n) { return g.opt_finish_four != 0 && n <= (size_t)64 * 4 * (size_t)g.cus; }      // launches of at most a wavefront per SIMD share an inversion between 4 items (finish.four)
 inline size_t pair_lim(const Ctx& g, int opt) { const int l = host_load(g) / 4; return opt <= 0 ? 0 : (size_t)opt / (size_t)(l < 1 ? 1 : l); }
 
 int ensure_pin(Ctx& g, int lane, size_t bytes) {
@@ -965,7 +966,7 @@ int launch_finish(Ctx& g, StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, 
   }
   ProfScope ps(g, st, KID_FINISH);
   // up to a wavefront per SIMD of finish lanes the kernel is one lane's chain: four items per inversion shorten it (k_finish4)
-  LAUNCHCK(launch::finish(st, r->proj, r->proj_items, n, oenc, oext, src_mul, g.opt_finish_four != 0 && n <= (size_t)64 * 4 * (size_t)g.cus));
+  LAUNCHCK(launch::finish(st, r->proj, r->proj_items, n, oenc, oext, src_mul, finish_four(g, n)));
   return KYB_OK;
 }
 
@@ -1294,7 +1295,7 @@ int launch_encode(Ctx& g, const int32_t* pext, size_t n, uint8_t* oenc, hipStrea
   }
   if (g.opt_encode_batched == 1) {
     ProfScope ps(g, st, KID_ENCODE);
-    LAUNCHCK(launch::encode_batched(st, pext, n, oenc));
+    LAUNCHCK(launch::encode_batched(st, pext, n, oenc, finish_four(g, n)));
   } else {
     LAUNCHCK(launch::encode(st, pext, n, oenc));
   }
@@ -1315,7 +1316,7 @@ int launch_point_checks(Ctx& g, const uint8_t* enc, const int32_t* pext, size_t 
     LAUNCHCK(launch::finish_coop(st, nullptr, 0, pext, n, r->enc, nullptr, 1, launch::DoneFlag{}));      // not the call's last kernel: no completion flag
   } else {
     ProfScope ps(g, st, KID_ENCODE);
-    LAUNCHCK(launch::encode_batched(st, pext, n, r->enc));
+    LAUNCHCK(launch::encode_batched(st, pext, n, r->enc, finish_four(g, n)));
   }
   LAUNCHCK(launch::point_checks(st, r->enc, n, flags));
   return KYB_OK;
@@ -1458,7 +1459,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
       LAUNCHCK(launch::finish_coop(st, nullptr, 0, pubs_ext, n, r->pub_enc, nullptr, 1));          // (not the call's last kernel: no completion flag)
     } else {
       ProfScope ps(g, st, KID_ENCODE);
-      LAUNCHCK(launch::encode_batched(st, pubs_ext, n, r->pub_enc));
+      LAUNCHCK(launch::encode_batched(st, pubs_ext, n, r->pub_enc, finish_four(g, n)));
     }
     pubs = r->pub_enc;
   }
@@ -1536,7 +1537,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     { ProfScope ps(g, st, KID_LADDER_RECOVER); LAUNCHCK(launch::ladder_recover(st, hbuf, n, a_ext, state, r->proj, r->proj_items, flags_a, flags_r)); }
     HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
     ProfScope ps(g, st, KID_VERIFY_FINAL);
-    LAUNCHCK(launch::verify_tail_enc(st, r->proj, r->proj_items, n, sigs, flags_a, flavor, status, take_done_flag(g, st, n), g.opt_finish_four != 0 && n <= (size_t)64 * 4 * (size_t)g.cus));
+    LAUNCHCK(launch::verify_tail_enc(st, r->proj, r->proj_items, n, sigs, flags_a, flavor, status, take_done_flag(g, st, n), finish_four(g, n)));
     return KYB_OK;
   }
   if (!by_enc) {
@@ -1574,7 +1575,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   else { rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, st); if (rc) return rc; }
   {
     ProfScope ps(g, st, KID_VERIFY_FINAL);
-    if (by_enc) LAUNCHCK(launch::verify_tail_enc(st, r->proj, r->proj_items, n, sigs, flags_a, flavor, status, take_done_flag(g, st, n), g.opt_finish_four != 0 && n <= (size_t)64 * 4 * (size_t)g.cus));
+    if (by_enc) LAUNCHCK(launch::verify_tail_enc(st, r->proj, r->proj_items, n, sigs, flags_a, flavor, status, take_done_flag(g, st, n), finish_four(g, n)));
     else LAUNCHCK(launch::verify_final(st, r->proj, r->proj_items, n, flags_a, flags_r, flavor, status, take_done_flag(g, st, n)));
   }
   return KYB_OK;

@@ -139,7 +139,7 @@ hipError_t eddsa_prep(hipStream_t st, const uint8_t* seeds, const uint8_t* msgs,
 
 // ---- kernels_misc.hip / kernels_window.hip ----
 hipError_t finish(hipStream_t st, const uint4* proj, size_t stride, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul, bool four = false);      // four: 4 items per shared inversion (k_finish4)
-hipError_t encode_batched(hipStream_t st, const int32_t* pext, size_t n, uint8_t* oenc);
+hipError_t encode_batched(hipStream_t st, const int32_t* pext, size_t n, uint8_t* oenc, bool four = false);      // four: 4 instead of FINISH_K points per inversion
 hipError_t mul_window(int masked, bool from_enc, bool split, int grid, hipStream_t st, const uint8_t* sc, const uint8_t* penc, const int32_t* pext, size_t n,
                       uint8_t* oenc, int32_t* oext, uint8_t* ok, uint4* ws, uint4* proj, size_t stride);
 hipError_t add(hipStream_t st, const int32_t* a, const int32_t* b, size_t n, int32_t* out, int subtract);

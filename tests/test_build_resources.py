@@ -36,7 +36,7 @@ DEFAULT_PATH = [
     ("_Z17k_verify_ladder_y", 256), ("_Z22k_verify_recover_final", 256), ("_Z13k_sig_scalars", 512),      # a DKG-sized verification in two launches
     ("_Z12k_mul_base64ILb1ELi1024E", 128),                # fixed base, full batches: 4 waves/SIMD, the table owns the LDS
     ("_Z12k_mul_base64ILb1ELi256E", 512),                 # fixed base, batches that do not fill the chip: 1 wave/SIMD
-    ("_Z11k_mont_prepPKim", 256), ("_Z8k_finishPK", 256), ("_Z9k_finish4PK", 256), ("_Z16k_encode_batchedPKimPh", 256),
+    ("_Z11k_mont_prepPKim", 256), ("_Z8k_finishPK", 256), ("_Z9k_finish4PK", 256), ("_Z16k_encode_batchedPKimPh", 256), ("_Z17k_encode_batched4PKimPh", 256),
     ("_Z20k_decode_or_identityPKhmPiPh", 256), ("_Z16k_decode_to_projPKhm", 256), ("_Z10k_pair_sumP", 256), ("_Z13k_ext_to_projPKim", 256),
     ("_Z13k_verify_prepPKhS0_S0_PKjmPhS3_S3_Pi", 256), ("_Z15k_verify_prep_rPKhmPh", 256), ("_Z13k_verify_hashPKh", 256), ("_Z14k_verify_finalPK", 256), ("_Z13k_verify_diffP", 256),
     ("_Z18k_verify_final_encPK", 256), ("_Z19k_verify_final_enc4PK", 256), ("_Z14k_verify_fixupPKhmS0_iPh", 256), ("_Z11k_sign_hashPKhS0_S0_PKjm", 256), ("_Z12k_eddsa_prepPKhS0_PKjm", 256),
