@@ -1505,8 +1505,11 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     LAUNCHCK(launch::verify_final(st, r->proj, r->proj_items, n, flags_a, flags_r, flavor, status, take_done_flag(g, st, n)));
     return KYB_OK;
   }
+  // keys given as POINTS, DKG-sized batch: nothing to decode on the A side; R is decoded by further workgroups of the ladder's launch (k_mul_ladder_pair_r) and
+  // the equation is tested on projective coordinates — no inversion at the end, a failing signature costs what a valid one does (as the path from key bytes above)
+  const bool r_role = !coop && pubs_ext != nullptr && fork && g.opt_mul_algo == 1 && g.opt_ladder_y_only == 2 && n <= pair_lim(g, g.opt_ladder_pair_max);
   // large batches compare encodings (kernels_verify.hip, k_verify_final_enc): R is only decoded for signatures that fail
-  const bool by_enc = !coop && g.opt_verify_by_enc != 0;
+  const bool by_enc = !coop && !r_role && g.opt_verify_by_enc != 0;
   if (by_enc && fork && pubs_ext == nullptr && g.opt_mul_algo == 1 && g.opt_ladder_y_only != 0 && n <= pair_lim(g, g.opt_ladder_pair_max)) {
     // DKG-sized batch from key BYTES: the decode of A (252 dependent squarings) leaves the critical path.  k_verify_hash gives h and every flag the
     // bytes decide; the two-lane ladder starts on A's y at once; the side stream decodes A, then multiplies s*B; k_ladder_recover joins (round 4).
@@ -1540,15 +1543,17 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     LAUNCHCK(launch::verify_tail_enc(st, r->proj, r->proj_items, n, sigs, flags_a, flavor, status, take_done_flag(g, st, n), finish_four(g, n)));
     return KYB_OK;
   }
-  if (!by_enc) {
+  if (!by_enc && !r_role) {
     ProfScope ps(g, side, KID_VERIFY_PREP_R);
     if (coop) LAUNCHCK(launch::verify_prep_r_coop(side, sigs, n, flags_r, r->proj, r->proj_items, 2 * n));
     else LAUNCHCK(launch::verify_prep_r(side, sigs, n, flags_r, r->proj, r->proj_items, 2 * n));
   }
   {
     ProfScope ps(g, st, KID_VERIFY_PREP);
-    if (coop) LAUNCHCK(launch::verify_prep_coop(st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext));
-    else if (pubs_ext != nullptr) LAUNCHCK(launch::verify_prep_pts(st, pubs, pubs_ext, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext));
+    // (keys as points need no square root: the one-lane-per-item kernel — hash and an on-curve test, 0.036 ms — also in the one-item-per-wavefront regime)
+    // (up to four wavefronts per SIMD in flight: beyond that the slower cooperative kernel, which lets the side stream's work finish first, wins — 2,048 signatures 0.467 against 0.496 ms)
+    if (pubs_ext != nullptr && (!coop || n <= coop_lim(g, 4 * g.cus))) LAUNCHCK(launch::verify_prep_pts(st, pubs, pubs_ext, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext));
+    else if (coop) LAUNCHCK(launch::verify_prep_coop(st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext));
     else LAUNCHCK(launch::verify_prep(st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf, a_ext));
   }
   if (fork) {
@@ -1561,6 +1566,9 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   if (coop) {
     ProfScope ps(g, st, KID_MUL_COOP);
     LAUNCHCK(launch::mul_coop(st, hbuf, a_ext, n, nullptr, nullptr, 3, r->proj, r->proj_items, 0));      // h < L < 2^253
+  } else if (r_role) {
+    ProfScope ps(g, st, KID_MUL_LADDER_PAIR);
+    LAUNCHCK(launch::mul_ladder_pair_r(st, hbuf, n, a_ext, r->proj, r->proj_items, 3, sigs, flags_r, 2 * n));      // h < L < 2^253
   } else if (g.opt_mul_algo == 1) {
     rc = launch_ladder_core(g, hbuf, nullptr, a_ext, n, nullptr, r, st, 0, 3); if (rc) return rc;      // h < L < 2^253
   } else {

@@ -154,6 +154,37 @@ k_mul_ladder_pair(const uint8_t* __restrict__ scalars, size_t n, const int32_t* 
   if (odd == 0u) store_proj(proj, stride, i, r.X, r.Y, r.Z);
 }
 
+// The same launch with the R half of a verification as further workgroups (keys given as POINTS: nothing to decode on the A side, but R's square
+// root would otherwise be paid at the end, inside the encode-and-compare tail): workgroups [0, ladder_blocks) are k_mul_ladder_pair, the ones behind
+// them k_verify_prep_r — checks and decode of R into record r_offset + i — on CUs of their own (ladder.y_only = 2).
+__global__ void __launch_bounds__(KYB_BLOCK, 2)
+k_mul_ladder_pair_r(const uint8_t* __restrict__ scalars, size_t n, const int32_t* __restrict__ pts_ext, uint4* __restrict__ proj, size_t stride, int skip_bits,
+                    unsigned ladder_blocks, const uint8_t* __restrict__ sigs, uint8_t* __restrict__ flags_r, size_t r_offset) {
+  if (blockIdx.x < ladder_blocks) {
+    __builtin_amdgcn_s_setprio(3);         // s*B shares these CUs from the side stream; the ladder is the critical path
+    const size_t lane = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+    const size_t i = lane >> 1;
+    const uint32_t odd = threadIdx.x & 1u;
+    if (i >= n) return;
+    uint32_t a[8];
+    load_words8(a, scalars, i);
+    ge_p3 P;
+    load_ext(P, pts_ext, i);
+    ge_p2 r;
+    ge_scalarmult_ladder_pair(r, a, P, skip_bits, odd);
+    if (odd == 0u) store_proj(proj, stride, i, r.X, r.Y, r.Z);
+    return;
+  }
+  const size_t i = (size_t)(blockIdx.x - ladder_blocks) * KYB_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint32_t sig[16];
+  load_words8(sig, sigs, 2 * i);
+  load_words8(sig + 8, sigs, 2 * i + 1);
+  ge_p3 R;
+  flags_r[i] = (uint8_t)verify_prep_r(R, sig);
+  store_proj(proj, stride, r_offset + i, R.X, R.Y, R.Z);
+}
+
 // The two-lane ladder from the wire encoding (ge_ladder_pair.h, "from the WIRE encoding"): the ladder on (1 + y : 1 - y), its x-only state to a
 // 160-byte record per item (x2, z2, x3, z3 as raw tight limbs); k_decode_or_identity runs beside it on a side stream; k_ladder_recover joins them.
 __device__ __forceinline__ void store_state(uint4* base, size_t i, const fe& a, const fe& b, const fe& c, const fe& d) {
@@ -387,6 +418,11 @@ hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, ui
 }
 hipError_t mul_ladder_pair(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, size_t pts_mod, uint4* proj, size_t stride, int skip_bits) {
   hipLaunchKernelGGL(k_mul_ladder_pair, dim3(blocks_for(2 * n)), dim3(KYB_BLOCK), 0, st, sc, n, pext, pts_mod, proj, stride, skip_bits);
+  return hipGetLastError();
+}
+hipError_t mul_ladder_pair_r(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, uint4* proj, size_t stride, int skip_bits, const uint8_t* sigs, uint8_t* flags_r, size_t r_offset) {
+  const unsigned lb = blocks_for(2 * n);
+  hipLaunchKernelGGL(k_mul_ladder_pair_r, dim3(lb + blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, pext, proj, stride, skip_bits, lb, sigs, flags_r, r_offset);
   return hipGetLastError();
 }
 hipError_t mul_ladder_pair_y(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits) {

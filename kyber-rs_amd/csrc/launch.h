@@ -67,6 +67,8 @@ hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, ui
 hipError_t mul_ladder_pair(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, size_t pts_mod, uint4* proj, size_t stride, int skip_bits);
 // the same from wire encodings: the ladder on (1 + y : 1 - y) leaves its x-only state (160 bytes per item) while the decode runs elsewhere;
 // ladder_recover turns state + decoded point into the projective result (ge_ladder_pair.h)
+// k_mul_ladder_pair with the R half of a verification (k_verify_prep_r: flags_r, record r_offset + i) as further workgroups of the launch
+hipError_t mul_ladder_pair_r(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, uint4* proj, size_t stride, int skip_bits, const uint8_t* sigs, uint8_t* flags_r, size_t r_offset);
 hipError_t mul_ladder_pair_y(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits);
 // ladder and decode as one launch: the first workgroups walk the ladder, the ones behind them decode (out_ext / ok as decode_or_identity)
 hipError_t mul_ladder_pair_y_dec(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits, int32_t* out_ext, uint8_t* ok);
