@@ -398,7 +398,8 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  * stay in the arena until kyb_defer_floor(mark) drops everything recorded before `mark` (= an earlier kyb_defer_mark(); e.g. at the end
  * of a protocol round) or until more than defer.max_nodes (default 2^20, about 250 bytes each) exist, when the oldest are dropped; a
  * dropped handle is refused with KYB_E_BAD_ARG ("stale handle"), never answered wrongly.  Secret scalars are kept until their node is
- * evaluated and cleared then (and when a node is dropped).  A handle carries the number of the arena it came from (upper 24 bits), so handles of
+ * evaluated and cleared then; a node's limbs and bytes — a recorded Diffie-Hellman exchange leaves the shared point there — are cleared when the
+ * node is dropped (floor, defer.max_nodes, the end of the arena): call kyb_defer_floor when a round's secrets are done with.  A handle carries the number of the arena it came from (upper 24 bits), so handles of
  * two contexts never collide and a point recorded through one context may be read, compared or used as an operand through another (the reference's
  * Point is Send: a worker thread may hand its points to the thread that marshals them) — the evaluation then runs on the reader's context.  The arena
  * of a released context stays readable as an orphan until sixteen younger orphans exist.
