@@ -36,6 +36,10 @@
  *                  leading zero bits when all are below 2^64.  kyb_mul_batch itself never does.
  *              tools/ct_check.py checks the claim on the compiled kernels (no branch on, and no address from, scalar words).
  *   memory     the caller owns every buffer; the library keeps no pointer after return.
+ *   aliasing   host-pointer calls: an output array may be (or overlap) an input array of the same call — an in-place update such as
+ *              out_ext == pts_ext — with the results of separate arrays: inputs are copied before anything is written, and page-locked
+ *              caller arrays used where they lie (host.in_place) are staged instead when they share bytes with an array that is written.
+ *              Two OUTPUT arrays of one call must not overlap.  Device-pointer (_dev) calls: no array may overlap another.
  *   secrets    host-pointer calls that take secret scalars (kyb_mul_base_batch, kyb_mul_batch, the signing calls, kyb_pripoly_eval_batch)
  *              clear, before they return and on every error path, the copies of the secret INPUTS the engine made — page-locked zero-copy
  *              buffer, device staging, bounce ring — and kyb_mul_batch (whose result s*P is a Diffie-Hellman shared secret) also the
@@ -69,6 +73,7 @@ extern "C" {
 #define KYB_E_HIP (-4)
 #define KYB_E_NOMEM (-5)
 #define KYB_E_TRANSPORT (-6)  /* kyb_group_create_ex(KYB_GROUP_REQUIRE_RCCL): the RCCL broadcast of the table image could not be done */
+#define KYB_E_STALE (-7)      /* deferred points: the handle names a node the arena has dropped (kyb_defer_floor, defer.max_nodes) */
 
 /* table image exchanged between GPUs at init — the role of constants.rs:89 BASE (which holds the 32 even
  * radix-16 positions only); affine (y+x, y-x, 2dxy), canonical limbs:
@@ -397,7 +402,7 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  * Lifetime: the reference's Point is Copy, so copies of a handle may live anywhere and nodes are not reference-counted.  Evaluated nodes
  * stay in the arena until kyb_defer_floor(mark) drops everything recorded before `mark` (= an earlier kyb_defer_mark(); e.g. at the end
  * of a protocol round) or until more than defer.max_nodes (default 2^20, about 250 bytes each) exist, when the oldest are dropped; a
- * dropped handle is refused with KYB_E_BAD_ARG ("stale handle"), never answered wrongly.  Secret scalars are kept until their node is
+ * dropped handle is refused with KYB_E_STALE ("stale handle"), never answered wrongly (a binding whose point still holds its limbs registers them again: host/edwards25519.hpp).  Secret scalars are kept until their node is
  * evaluated and cleared then; a node's limbs and bytes — a recorded Diffie-Hellman exchange leaves the shared point there — are cleared when the
  * node is dropped (floor, defer.max_nodes, the end of the arena): call kyb_defer_floor when a round's secrets are done with.  A handle carries the number of the arena it came from (upper 24 bits), so handles of
  * two contexts never collide and a point recorded through one context may be read, compared or used as an operand through another (the reference's

@@ -24,7 +24,7 @@ BASE_TABLE_BYTES = 335232
 ABI_VERSION = 2
 
 KYB_OK = 0
-ERRORS = {-1: "KYB_E_NOT_INIT", -2: "KYB_E_BAD_ARG", -3: "KYB_E_NO_DEVICE", -4: "KYB_E_HIP", -5: "KYB_E_NOMEM", -6: "KYB_E_TRANSPORT"}
+ERRORS = {-1: "KYB_E_NOT_INIT", -2: "KYB_E_BAD_ARG", -3: "KYB_E_NO_DEVICE", -4: "KYB_E_HIP", -5: "KYB_E_NOMEM", -6: "KYB_E_TRANSPORT", -7: "KYB_E_STALE"}
 
 # every symbol include/kyber_ed25519.h declares (tests/test_abi_symbols.py checks header <-> library)
 ABI_SYMBOLS = [

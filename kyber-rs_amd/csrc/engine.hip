@@ -290,6 +290,14 @@ uint8_t* pinned_dev_ptr(const Ctx& g, const void* p, size_t bytes) {
   return reinterpret_cast<uint8_t*>(a + it->second.dev_delta);
 }
 
+// Two caller arrays of one call that are both used where they lie must not share bytes when one of them is written: staged arrays were
+// copied apart (in-place updates like out_ext == pts_ext worked), the kernels' __restrict__ pointers and shared-inversion lanes do not
+// allow it in place.  An overlapping INPUT is then staged as before the in-place path existed.
+inline bool host_ranges_overlap(const void* a, size_t na, const void* b, size_t nb) {
+  const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
+  return a != nullptr && b != nullptr && na != 0 && nb != 0 && x < y + nb && y < x + na;
+}
+
 // ---- completion flag of small host-pointer calls --------------------------------------------------------
 // A zero-copy host-pointer call (run_host_batch / HostCall::run) posts a request in this thread-local; the launch sequence it runs
 // on the engine stream hands the flag to its LAST kernel (take_done_flag, only where nothing is queued behind that kernel), and
@@ -530,8 +538,15 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
         uint8_t* own = pinned_dev_ptr(g, arrs[k].in ? arrs[k].in : arrs[k].out, arrs[k].bytes * n);      // kyb_host_alloc memory: used where it lies
         if (own != nullptr) { dptr[k] = own; staged[k] = false; }
       }
-      if (arrs[k].in && staged[k]) memcpy(dptr[k], arrs[k].in, arrs[k].bytes * n);
     }
+    for (int k = 0; k < na; ++k)               // an in-place array that shares bytes with an in-place array the kernels write: staged after all
+      for (int j = 0; j < na && dptr[k] && !staged[k]; ++j) {
+        if (j == k || !dptr[j] || staged[j] || (arrs[k].out == nullptr && arrs[j].out == nullptr)) continue;
+        const void *pk = arrs[k].in ? arrs[k].in : arrs[k].out, *pj = arrs[j].in ? arrs[j].in : arrs[j].out;
+        if (host_ranges_overlap(pk, arrs[k].bytes * n, pj, arrs[j].bytes * n) && (arrs[k].out == nullptr || j < k)) { dptr[k] = g.pin[0] + off[k]; staged[k] = true; }
+      }
+    for (int k = 0; k < na; ++k)
+      if (arrs[k].in && staged[k]) memcpy(dptr[k], arrs[k].in, arrs[k].bytes * n);
     // whatever way the call ends, the secret operands do not stay behind in the page-locked buffer (the kernels have finished by then:
     // every return below is behind a completed wait or a stream synchronisation)
     auto wipe = on_scope_exit([&] { for (int k = 0; k < na; ++k) if (arrs[k].secret && staged[k]) memset(g.pin[0] + off[k], 0, arrs[k].bytes * n); });
@@ -637,6 +652,11 @@ class HostCall {
         for (int i = 0; i < n_; ++i) {         // arrays in kyb_host_alloc memory are used where they lie (pinned_dev_ptr); not those the kernels may read past the end of
           Arr& a = a_[i];
           if (a.present && a.bytes && a.pad == 0 && (a.src == nullptr || a.dst == nullptr || a.src == a.dst)) a.own = pinned_dev_ptr(g, a.src ? a.src : a.dst, a.bytes);
+        }
+      for (int k = 0; k < n_; ++k)             // shared bytes between two in-place arrays, one of them written: that input is staged (host_ranges_overlap)
+        for (int j = 0; j < n_ && a_[k].own; ++j) {
+          if (j == k || !a_[j].own || (a_[k].dst == nullptr && a_[j].dst == nullptr)) continue;
+          if (host_ranges_overlap(a_[k].src ? a_[k].src : a_[k].dst, a_[k].bytes, a_[j].src ? a_[j].src : a_[j].dst, a_[j].bytes) && (a_[k].dst == nullptr || j < k)) a_[k].own = nullptr;
         }
       for (int i = 0; i < n_; ++i)
         if (a_[i].src && a_[i].bytes && !a_[i].own) memcpy(base_ + a_[i].off, a_[i].src, a_[i].bytes);

@@ -203,10 +203,26 @@ class Point {
     if (!have_ge) { detail::engine_must(kyb_defer_get(pend, ge, nullptr), "Point: evaluation of a deferred point"); have_ge = true; }
     return ge;
   }
-  // this point as an operand of a recorded operation: its handle, or a leaf made of its limbs
+  // this point as an operand of a recorded operation: its handle, or a leaf made of its limbs.  A point that HOLDS its limbs keeps the
+  // handle only as a cache (the marshal_binary that follows is then a hit in the arena): when the arena has dropped the node meanwhile
+  // (kyb_defer_floor, defer.max_nodes -> KYB_E_STALE) the limbs are registered again instead of aborting — record() / marshal / == below.
   uint64_t handle() const {
     if (pend == 0) detail::engine_must(kyb_defer_input(ge, &pend), "Point: kyb_defer_input");
     return pend;
+  }
+  bool forget_stale_handle() const { if (have_ge && pend != 0) { pend = 0; return true; } return false; }
+  // one recorded operation on up to two operands; a stale CACHED handle of an operand that still holds its limbs is renewed once
+  template <class F>
+  static uint64_t record(const char* what, const Point* a, const Point* b, F call) {
+    uint64_t h = 0;
+    int rc = call(&h);
+    if (rc == KYB_E_STALE) {
+      bool renewed = a != nullptr && a->forget_stale_handle();
+      if (b != nullptr && b != a) renewed = b->forget_stale_handle() || renewed;
+      if (renewed) rc = call(&h);
+    }
+    detail::engine_must(rc, what);
+    return h;
   }
 
   Point null() { std::memset(ge, 0, sizeof(ge)); ge[10] = 1; ge[20] = 1; have_ge = true; pend = 0; return *this; }        // point.rs:79-82
@@ -257,7 +273,7 @@ class Point {
   Point add(const Point& a, const Point& b) { return add_sub(a, b, 0); }                       // point.rs:179-188
   Point sub(const Point& a, const Point& b) { return add_sub(a, b, 1); }                       // point.rs:190-199
   Point neg(const Point& a) {                                                                  // point.rs:201-204, ge.rs:86-91... neg X and T
-    if (deferred()) { uint64_t h = 0; detail::engine_must(kyb_defer_neg(a.handle(), &h), "Point::neg"); pend = h; have_ge = false; return *this; }
+    if (deferred()) { const uint64_t h = record("Point::neg", &a, nullptr, [&](uint64_t* o) { return kyb_defer_neg(a.handle(), o); }); pend = h; have_ge = false; return *this; }
     const int32_t* l = a.limbs();
     int32_t out[40];
     for (int i = 0; i < 10; ++i) { out[i] = -l[i]; out[10 + i] = l[10 + i]; out[20 + i] = l[20 + i]; out[30 + i] = -l[30 + i]; }
@@ -267,9 +283,8 @@ class Point {
   // point.rs:207-224: p == nullptr -> fixed base (ge_scalar_mult_base), else variable base
   Point mul(const Scalar& s, const Point* p) {
     if (deferred()) {
-      uint64_t h = 0;
-      if (p == nullptr) detail::engine_must(kyb_defer_mul_base(s.v.data(), &h), "Point::mul (base)");
-      else detail::engine_must(kyb_defer_mul(s.v.data(), p->handle(), &h), "Point::mul");
+      const uint64_t h = p == nullptr ? record("Point::mul (base)", nullptr, nullptr, [&](uint64_t* o) { return kyb_defer_mul_base(s.v.data(), o); })
+                                      : record("Point::mul", p, nullptr, [&](uint64_t* o) { return kyb_defer_mul(s.v.data(), p->handle(), o); });
       pend = h; have_ge = false;
       return *this;
     }
@@ -283,9 +298,12 @@ class Point {
   std::vector<uint8_t> marshal_binary() const {
     std::vector<uint8_t> b(32);
     if (pend != 0) {                       // recorded (or registered as an operand): the arena evaluates what it depends on and caches the bytes
-      detail::engine_must(kyb_defer_get(pend, have_ge ? nullptr : ge, b.data()), "Point::marshal_binary");
-      have_ge = true;
-      return b;
+      const int rc = kyb_defer_get(pend, have_ge ? nullptr : ge, b.data());
+      if (!(rc == KYB_E_STALE && forget_stale_handle())) {      // (a dropped node of a point that holds its limbs: marshal the limbs, below)
+        detail::engine_must(rc, "Point::marshal_binary");
+        have_ge = true;
+        return b;
+      }
     }
     detail::engine_must(kyb_encode_batch(ge, 1, b.data()), "Point::marshal_binary");
     return b;
@@ -301,7 +319,12 @@ class Point {
   // point.rs:227-241 compares the two encodings (two field inversions); the engine compares projectively, same answer
   bool operator==(const Point& o) const {
     uint8_t eq = 0;
-    if (!have_ge || !o.have_ge) { detail::engine_must(kyb_defer_equal(handle(), o.handle(), &eq), "Point::eq"); return eq != 0; }
+    if (!have_ge || !o.have_ge) {
+      int rc = kyb_defer_equal(handle(), o.handle(), &eq);
+      if (rc == KYB_E_STALE && (forget_stale_handle() | o.forget_stale_handle())) rc = kyb_defer_equal(handle(), o.handle(), &eq);
+      detail::engine_must(rc, "Point::eq");
+      return eq != 0;
+    }
     detail::engine_must(kyb_equal_batch(ge, o.ge, 1, &eq), "Point::eq");
     return eq != 0;
   }
@@ -371,7 +394,7 @@ class Point {
 
  private:
   Point add_sub(const Point& a, const Point& b, int subtract) {
-    if (deferred()) { uint64_t h = 0; detail::engine_must(kyb_defer_add(a.handle(), b.handle(), subtract, &h), "Point::add"); pend = h; have_ge = false; return *this; }
+    if (deferred()) { const uint64_t h = record("Point::add", &a, &b, [&](uint64_t* o) { return kyb_defer_add(a.handle(), b.handle(), subtract, o); }); pend = h; have_ge = false; return *this; }
     int32_t out[40];
     detail::engine_must(kyb_add_batch(a.limbs(), b.limbs(), 1, out, subtract), subtract ? "Point::sub" : "Point::add");
     std::memcpy(ge, out, sizeof(ge)); have_ge = true; pend = 0;

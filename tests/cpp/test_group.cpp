@@ -439,6 +439,32 @@ int main() {
     }
     CHECK(saw_small && saw_noncanonical, "checks_batch: both flags exercised");
   }
+  // a long-lived key used as a deferred operand keeps a CACHED handle; when the arena drops the node (kyb_defer_floor at the end of a round,
+  // defer.max_nodes) the limbs the point still holds are registered again — no abort, same bytes (KYB_E_STALE)
+  {
+    Scalar k = Scalar().pick(rand), x = Scalar().pick(rand);
+    Point key = Point().mul(k, nullptr);                               // eager: holds its limbs
+    const std::vector<uint8_t> key_bytes = key.marshal_binary();
+    const Point eager = Point().add(Point().mul(x, &key), key);
+    set_deferred(true);
+    Point r1 = Point().add(Point().mul(x, &key), key);                 // key is registered as a leaf, its handle cached
+    CHECK(key.pend != 0 && key.have_ge, "the operand caches its handle");
+    CHECK(r1.marshal_binary() == eager.marshal_binary(), "deferred result before the floor");
+    CHECK(kyb_defer_floor(kyb_defer_mark()) == KYB_OK, "end of the round: everything recorded so far is dropped");
+    uint8_t e32[32];
+    CHECK(kyb_defer_get(key.pend, nullptr, e32) == KYB_E_STALE, "the cached handle is stale now");
+    CHECK(key.marshal_binary() == key_bytes, "marshal of a point with a stale cached handle: its limbs");
+    CHECK(key.pend == 0, "the stale handle is forgotten");
+    Point again = Point().mul(x, &key); (void)again;
+    CHECK(kyb_defer_floor(kyb_defer_mark()) == KYB_OK, "floor");        // `again` is lost (it held no limbs), `key` is not
+    Point r2 = Point().add(Point().mul(x, &key), key);                 // stale cached operand handle -> renewed
+    CHECK(r2.marshal_binary() == eager.marshal_binary(), "deferred result after the floor");
+    CHECK(kyb_defer_floor(kyb_defer_mark()) == KYB_OK, "floor");
+    CHECK(key == Point().mul(k, nullptr), "== with a stale cached handle on one side");
+    CHECK(Point().neg(key).marshal_binary() == Point().sub(Point().null(), key).marshal_binary(), "neg of a point with a stale handle");
+    CHECK(kyb_defer_floor(0) == KYB_OK, "the mark of a thread that recorded nothing");
+    set_deferred(false);
+  }
   for (const Point& p : points) std::printf("POINT %s\n", p.hex().c_str());
   std::printf("S1 %s\nS2 %s\n", s1.hex().c_str(), s2.hex().c_str());
   std::printf(failures ? "FAILED %d\n" : "OK\n", failures);

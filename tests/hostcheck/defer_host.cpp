@@ -144,6 +144,8 @@ static void random_graphs(unsigned seed, int steps) {
           orc_mul(nullptr, m.ext, x, cur.ext); CHECK(kyb_defer_mul(x, cur.h, &m.h) == KYB_OK, "chain mul");
           orc_add(s2.ext, m.ext, c.ext, 0); CHECK((rng() & 1 ? kyb_defer_add(m.h, c.h, 0, &s2.h) : kyb_defer_add(c.h, m.h, 0, &s2.h)) == KYB_OK, "chain add");
           if (rng() % 4 == 0) nodes.push_back(s2);          // sometimes an inner node is kept and asked for later
+          if (rng() % 5 == 0) nodes.push_back(m);           // ... and so is an inner PRODUCT (`m = x v; s = m + c; ...; m.marshal_binary()`)
+          if (rng() % 16 == 0) CHECK(got_enc(m.h) == enc_of(m.ext), "inner product asked for while its chain is pending");
           cur = s2;
         }
         nodes.push_back(cur);
@@ -194,6 +196,27 @@ int main() {
     size_t n = 0;
     for (uint32_t i : {0u, 5u, 63u, 4000000000u}) { uint8_t e[32]; orc_pubpoly_eval(e, commits.data(), t, i); CHECK(got_enc(hs[n++]) == std::string((const char*)e, 32), "horner value"); }
   }
+  // an inner product of a pending Horner chain asked for by name, first as limbs+bytes, then through equal(): it ends the chain below it, it is
+  // evaluated, and the chain above it is still right (defer.inc is_step)
+  for (int how = 0; how < 3; ++how) {
+    const size_t t = 5;
+    uint8_t x[32]; scalar_small(x, 7);
+    std::vector<Val> c(t), prod, sums;
+    for (size_t j = 0; j < t; ++j) { uint8_t s[32]; scalar_small(s, 31 + (uint32_t)j + 100 * how); orc_mul_base(nullptr, c[j].ext, s); CHECK(kyb_defer_input(c[j].ext, &c[j].h) == KYB_OK, "coeff"); }
+    Val v = c[t - 1];
+    for (size_t j = t - 1; j-- > 0;) {
+      Val m, a;
+      orc_mul(nullptr, m.ext, x, v.ext); CHECK(kyb_defer_mul(x, v.h, &m.h) == KYB_OK, "chain mul");
+      orc_add(a.ext, m.ext, c[j].ext, 0); CHECK(kyb_defer_add(m.h, c[j].h, 0, &a.h) == KYB_OK, "chain add");
+      prod.push_back(m); sums.push_back(a); v = a;
+    }
+    const Val& inner = prod[1];
+    if (how == 0) { int32_t ext[40]; uint8_t e[32]; CHECK(kyb_defer_get(inner.h, ext, e) == KYB_OK && enc_of(ext) == enc_of(inner.ext) && std::string((const char*)e, 32) == enc_of(inner.ext), "inner product: get"); }
+    if (how == 1) { uint8_t eq = 2; CHECK(kyb_defer_equal(inner.h, prod[2].h, &eq) == KYB_OK && eq == 0 && kyb_defer_equal(inner.h, inner.h, &eq) == KYB_OK && eq == 1, "inner product: equal"); }
+    if (how == 2) { CHECK(got_enc(v.h) == enc_of(v.ext), "sink first"); }          // the chain is evaluated as a whole: the inner nodes are dead, and asked for afterwards
+    for (const Val& p : prod) CHECK(got_enc(p.h) == enc_of(p.ext), "every product of the chain");
+    for (const Val& p : sums) CHECK(got_enc(p.h) == enc_of(p.ext), "every sum of the chain");
+  }
   // recover_commit: one batch of products, one sum
   {
     const size_t t = 9;
@@ -218,7 +241,7 @@ int main() {
     CHECK(kyb_defer_mul_base(s, &first) == KYB_OK, "first");
     for (uint32_t i = 0; i < 100; ++i) { scalar_small(s, i); CHECK(kyb_defer_mul_base(s, &h) == KYB_OK, "fill"); }
     uint8_t e[32];
-    CHECK(kyb_defer_get(first, nullptr, e) == KYB_E_BAD_ARG && g_err.find("stale") != std::string::npos, "stale handle refused");
+    CHECK(kyb_defer_get(first, nullptr, e) == KYB_E_STALE && g_err.find("stale") != std::string::npos, "stale handle refused");
     CHECK(kyb_defer_get(h, nullptr, e) == KYB_OK, "newest handle");
     const uint64_t mark = kyb_defer_mark();
     scalar_small(s, 7);

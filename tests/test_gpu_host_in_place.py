@@ -70,3 +70,54 @@ def test_pinned_arrays_are_used_in_place_with_the_same_results(engine, n):
     engine.set_option("host.in_place", 1)
     # the caller's secret scalars were read where they lay and are still there (nothing of the caller's is wiped)
     assert np.array_equal(pk, k)
+
+
+def _guarded(engine, a, guard=64):
+    """a page-locked copy of `a` with `guard` bytes of 0xA5 on either side of it inside the same allocation (start kept 16-byte aligned)"""
+    flat = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    raw = engine.pinned_array((flat.size + 2 * guard,), np.uint8)
+    raw[:] = 0xA5
+    raw[guard:guard + flat.size] = flat
+    return raw, raw[guard:guard + flat.size].view(a.dtype).reshape(a.shape)
+
+
+@pytest.mark.parametrize("n", [2049, 8191, 20001])      # odd sizes: the last 16-byte word / the last lanes of a shared inversion are partial
+def test_in_place_arrays_are_never_read_or_written_past_their_end_and_may_alias(engine, n):
+    """(1) guard bytes behind (and in front of) every page-locked caller array stay untouched at odd n; (2) an output array that IS an
+    input array of the same call (in-place update: out_ext == pts_ext, out == a) gives the results of separate arrays — the engine stages the
+    input when two in-place arrays share bytes and one is written."""
+    orc = oracle_lib.Oracle()
+    lib = engine.lib
+    P = kyber_rs_amd._ptr
+    k = synth.scalars(n, 911)
+    enc, ext = engine.mul_base(synth.scalars(n, 912), want_ext=True)
+    want_ext_enc = engine.mul(k, pts_ext=ext)
+    want_sum = engine.encode(engine.add(ext, ext))
+    idx = [0, n // 2, n - 1]
+    for i in idx:
+        assert bytes(want_ext_enc[i]) == orc.mul(bytes(k[i]), ext[i])
+    engine.set_option("host.in_place", 1)
+    rk, pk = _guarded(engine, k)
+    rx, px = _guarded(engine, ext)
+    ro, po = _guarded(engine, np.zeros((n, 32), np.uint8))
+    rx2, px2 = _guarded(engine, np.zeros((n, 40), np.int32))
+    kyber_rs_amd._check(lib.kyb_mul_batch(P(pk), None, P(px), n, P(po), P(px2), None), "kyb_mul_batch")
+    assert np.array_equal(po, want_ext_enc)
+    assert np.array_equal(engine.encode(np.array(px2)), want_ext_enc)
+    for raw in (rk, rx, ro, rx2):
+        assert (raw[:64] == 0xA5).all() and (raw[-64:] == 0xA5).all(), "guard bytes around a page-locked caller array were written"
+    assert np.array_equal(pk, k) and np.array_equal(px, ext)
+    # in-place update: the products land on top of the operands
+    kyber_rs_amd._check(lib.kyb_mul_batch(P(pk), None, P(px), n, P(po), P(px), None), "kyb_mul_batch (out_ext == pts_ext)")
+    assert np.array_equal(po, want_ext_enc) and np.array_equal(engine.encode(np.array(px)), want_ext_enc)
+    assert (rx[:64] == 0xA5).all() and (rx[-64:] == 0xA5).all()
+    # a + a -> a
+    px[:] = ext
+    kyber_rs_amd._check(lib.kyb_add_batch(P(px), P(px), n, P(px), 0), "kyb_add_batch (out == a == b)")
+    assert np.array_equal(engine.encode(np.array(px)), want_sum)
+    # shifted overlap: the output starts one record into the input
+    big = engine.pinned_array(((n + 1) * 40,), np.int32)
+    big[:n * 40] = ext.reshape(-1)
+    src, dst = big[:n * 40].reshape(n, 40), big[40:].reshape(n, 40)
+    kyber_rs_amd._check(lib.kyb_add_batch(P(src), P(src), n, P(dst), 0), "kyb_add_batch (out overlaps a, shifted)")
+    assert np.array_equal(engine.encode(np.array(dst)), want_sum)

@@ -89,3 +89,13 @@ def test_a_broken_rccl_transport_is_an_error_when_required_and_a_reported_fallba
     assert "KYB_E_TRANSPORT" in out.get("error", "") and "repeats a device" in out["error"], out
     out = _child(0, {})
     assert out["transport"] == "host-copy" and "repeats a device" in out["note"]
+
+
+def test_a_missing_rccl_library_is_a_reported_fallback_or_an_error_never_a_crash(tmp_path):
+    """ADVICE r4: the message was built with two dlerror() calls, the second answers NULL -> std::string(nullptr)."""
+    REQUIRE, EVEN = 1, 2
+    env = {"KYB_RCCL_LIBRARY": str(tmp_path / "no_such_librccl.so.1")}
+    out = _child(EVEN, env)
+    assert out["transport"] == "host-copy" and "librccl could not be loaded" in out["note"] and "no_such_librccl" in out["note"] and out["tables_equal"], out
+    out = _child(REQUIRE | EVEN, env)
+    assert "KYB_E_TRANSPORT" in out.get("error", "") and "librccl could not be loaded" in out["error"], out
