@@ -226,13 +226,17 @@ class Point {
   }
 
   Point null() { std::memset(ge, 0, sizeof(ge)); ge[10] = 1; ge[20] = 1; have_ge = true; pend = 0; return *this; }        // point.rs:79-82
-  Point base() {                                                                               // point.rs:85-88
-    if (deferred()) { have_ge = false; detail::engine_must(kyb_defer_base(&pend), "Point::base"); return *this; }
-    uint8_t one[32] = {1};
-    detail::engine_must(kyb_mul_base_batch(one, 1, nullptr, ge), "Point::base");
-    have_ge = true; pend = 0;
-    return *this;
+  // 1 * B as the engine hands it out, asked for once per process (the reference copies the literal BASEEXT, constants.rs:70-87: the same point)
+  static const int32_t* base_ext() {
+    static const std::array<int32_t, 40> b = [] {
+      std::array<int32_t, 40> l{};
+      uint8_t one[32] = {1};
+      detail::engine_must(kyb_mul_base_batch(one, 1, nullptr, l.data()), "Point::base");
+      return l;
+    }();
+    return b.data();
   }
+  Point base() { std::memcpy(ge, base_ext(), sizeof(ge)); have_ge = true; pend = 0; return *this; }   // point.rs:85-88
   Point set(const Point& p) { std::memcpy(ge, p.ge, sizeof(ge)); pend = p.pend; have_ge = p.have_ge; return *this; }                // point.rs:94-97
   size_t embed_len() const { return (255 - 8 - 8) / 8; }                                        // point.rs:99-104
   Point pick(Stream& rand) { return embed(nullptr, 0, rand); }                                  // point.rs:90-92
@@ -280,8 +284,11 @@ class Point {
     std::memcpy(ge, out, sizeof(ge)); have_ge = true; pend = 0;
     return *this;
   }
-  // point.rs:207-224: p == nullptr -> fixed base (ge_scalar_mult_base), else variable base
+  // point.rs:207-224: p == nullptr -> fixed base (ge_scalar_mult_base), else variable base.  Every in-tree caller passes the generator as
+  // Some(base) (PriPoly::commit, poly.rs:195-206; vss): when the operand is, limb for limb, what base() hands out and the scalar is below
+  // 2^255 (no top-digit quirk in either routine, ge.rs:440-441) the fixed-base kernel gives the same point in a sixth of the time.
   Point mul(const Scalar& s, const Point* p) {
+    if (p != nullptr && p->have_ge && (s.v[31] & 0x80) == 0 && std::memcmp(p->ge, base_ext(), sizeof(ge)) == 0) p = nullptr;
     if (deferred()) {
       const uint64_t h = p == nullptr ? record("Point::mul (base)", nullptr, nullptr, [&](uint64_t* o) { return kyb_defer_mul_base(s.v.data(), o); })
                                       : record("Point::mul", p, nullptr, [&](uint64_t* o) { return kyb_defer_mul(s.v.data(), p->handle(), o); });
@@ -335,22 +342,12 @@ class Point {
     for (uint8_t b : marshal_binary()) { s.push_back(d[b >> 4]); s.push_back(d[b & 15]); }
     return s;
   }
-  // point.rs:286-313 (WEAK_KEYS, constants.rs:3744-3775: the five small-order encodings below p)
+  // point.rs:286-313: the encoding against the five WEAK_KEYS below p (constants.rs:3744-3775) — on the engine, which marshals the limbs
+  // and compares (kyb_point_checks_batch, bit 1): total on any limbs, as the reference's is
   bool has_small_order() const {
-    static const uint8_t weak[5][32] = {
-        {0},
-        {1},
-        {0x26, 0xe8, 0x95, 0x8f, 0xc2, 0xb2, 0x27, 0xb0, 0x45, 0xc3, 0xf4, 0x89, 0xf2, 0xef, 0x98, 0xf0, 0xd5, 0xdf, 0xac, 0x05, 0xd3, 0xc6, 0x33, 0x39, 0xb1, 0x38, 0x02, 0x88, 0x6d, 0x53, 0xfc, 0x05},
-        {0xc7, 0x17, 0x6a, 0x70, 0x3d, 0x4d, 0xd8, 0x4f, 0xba, 0x3c, 0x0b, 0x76, 0x0d, 0x10, 0x67, 0x0f, 0x2a, 0x20, 0x53, 0xfa, 0x2c, 0x39, 0xcc, 0xc6, 0x4e, 0xc7, 0xfd, 0x77, 0x92, 0xac, 0x03, 0x7a},
-        {0xec, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0x7f}};
-    std::vector<uint8_t> s = marshal_binary();
-    uint8_t c[5] = {0};
-    for (int j = 0; j < 31; ++j)
-      for (int i = 0; i < 5; ++i) c[i] |= s[j] ^ weak[i][j];
-    for (int i = 0; i < 5; ++i) c[i] |= (s[31] & 0x7f) ^ weak[i][31];
-    uint16_t k = 0;
-    for (int i = 0; i < 5; ++i) k |= (uint16_t)((uint16_t)c[i] - 1);
-    return ((k >> 8) & 1) > 0;
+    uint8_t flags = 0;
+    detail::engine_must(kyb_point_checks_batch(nullptr, limbs(), 1, &flags), "Point::has_small_order");
+    return (flags & 2) != 0;
   }
   // point.rs:315-337
   bool is_canonical(const uint8_t* b, size_t n) const {

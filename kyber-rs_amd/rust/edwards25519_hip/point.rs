@@ -1,23 +1,23 @@
 //! `Point` of the HIP group: the type behind `group::edwards25519::Point` when kyber-rs is built with the `hip` feature.
 //!
-//! Two kinds of methods, and only two:
-//!   * curve arithmetic — `mul`, `eq`, `marshal_binary`, `unmarshal_binary`, the batch helpers — is FORWARDED to the engine
-//!     (include/kyber_ed25519.h) as batch-of-1 or batch-of-n calls on the 160-byte `ext` record, which is the reference's
-//!     own limb layout;
-//!   * the `embed` / `pick` rejection loop and `is_canonical(bytes)` are DELEGATED to the reference's own CPU `Point` (`CpuPoint`
-//!     below); `data`, the three formatters and `has_small_order` look at the 32 bytes the engine marshals (or ask the engine:
-//!     `kyb_point_checks_batch`) and never round-trip through `CpuPoint::unmarshal_binary` — limbs that are no curve point
-//!     (a `Point` that came out of serde, which derives `Deserialize` on raw limbs) then format and answer like any other
-//!     bytes instead of panicking.  This module carries no second copy of the reference's host logic.
+//! ONE code path: every method that does curve arithmetic — `mul`, `add`, `sub`, `neg`, `eq`, `marshal_binary`, `unmarshal_binary`,
+//! `has_small_order`, the `pick` / `embed` rejection loop (decode, then `mul` by the cofactor or by the group order) and the batch
+//! helpers — reaches the engine (include/kyber_ed25519.h) on the 160-byte `ext` record, which is the reference's own limb layout.
+//! The reference's CPU `Point` (`point.rs`) and its `ge.rs` formulas are NOT used: under the feature the reference's `mod point` is
+//! compiled out (kyber-rs.hip-feature.patch).  What stays on the host is what involves no field arithmetic: the key-stream handling of
+//! `embed`, the length byte of `data`, the byte comparison of `is_canonical`, the formatters (they print the bytes the engine marshals).
+//! tools/check_rust_shim.py checks, method by method, that this file reaches the same `kyb_*` entry points as the C++ mirror
+//! `host/edwards25519.hpp`, which the GPU tests drive.
 //! DEFERRED MODE (`set_deferred(true)` per thread, or KYBER_HIP_DEFERRED in the environment): `mul` / `add` / `sub` / `neg` RECORD their
 //! operation in the engine's arena (`kyb_defer_*`) and return a `Point` that holds only a handle; the engine evaluates what was recorded,
 //! in batches, when somebody needs bytes or limbs (`marshal_binary`, `eq`, `hash`, `data`, serde, the batch helpers).  Unmodified protocol
 //! code then gets one engine call for the t multiplications of `PriPoly::commit` and one for the whole Horner chain of `PubPoly::eval`
-//! (a Pedersen dealer round, n = 64, t = 43, call by call: 616 ms eager, 46 ms deferred; tests/cpp/test_vss_round.cpp is the same logic in
-//! C++).  `Point` stays `Copy` and `Send`: handles are plain numbers that name the arena (the recording thread's context) they came from, so a
-//! point recorded on one thread can be marshalled or multiplied on another; the arena keeps evaluated nodes until `defer_floor(mark)`.
-//! `add` / `sub` of a single pair call the reference's group-element formulas (`ge.rs`) on the same limbs: nine field
-//! multiplications are not worth a round trip to the GPU; vectors of pairs go to the engine (`add_batch`).
+//! (tests/cpp/test_vss_round.cpp is the same logic in C++, timed).  This is the mode to run protocol code in: an eager `add` of one pair
+//! is a round trip to the GPU (27 us; the CPU needs 0.3 us), a recorded one costs a fraction of a microsecond and is evaluated as part
+//! of a sum.  `Point` stays `Copy` and `Send`: handles are plain numbers that name the arena (the recording thread's context) they came
+//! from, so a point recorded on one thread can be marshalled or multiplied on another.  The arena keeps evaluated nodes until
+//! `defer_floor(mark)` or until `defer.max_nodes` of them exist; a point that must outlive that (a long-term key, a distributed public
+//! key) is detached with `materialize()`, which fetches its limbs — after that it depends on nothing.
 //! Which reference method each one stands for: INTEGRATION.md §3.
 use core::fmt::{Debug, Display, Formatter, LowerHex, UpperHex};
 
@@ -26,14 +26,7 @@ use serde::{Deserialize, Serialize};
 use crate::{
     cipher::Stream,
     encoding::{BinaryMarshaler, BinaryUnmarshaler, Marshaling, MarshallingError},
-    group::{
-        self,
-        edwards25519::ge::{CachedGroupElement, CompletedGroupElement, ExtendedGroupElement},
-        edwards25519::point::Point as CpuPoint,
-        edwards25519::Scalar,
-        internal::marshalling,
-        PointCanCheckCanonicalAndSmallOrder, PointError,
-    },
+    group::{self, edwards25519::Scalar, internal::marshalling, PointCanCheckCanonicalAndSmallOrder, PointError},
 };
 
 use std::os::raw::c_int;
@@ -74,6 +67,14 @@ fn base_ext() -> &'static Limbs {
         b
     })
 }
+
+/// `marshal_id` of the reference's type ("ed.point", point.rs:21)
+const MARSHAL_POINT_ID: [u8; 8] = *b"ed.point";
+/// the group order L and the cofactor 8 as the 32 little-endian bytes of `PRIME_ORDER_SCALAR` / `COFACTOR_SCALAR` (constants.rs:45-49)
+const ORDER_LE: [u8; 32] = [0xed, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x10];
+const COFACTOR_LE: [u8; 32] = [8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0];
+/// marshal_binary of the neutral element
+const NEUTRAL_ENC: [u8; 32] = [1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0];
 
 fn invalid_point() -> MarshallingError {
     MarshallingError::InvalidInput("invalid Ed25519 curve point".to_owned())
@@ -163,10 +164,12 @@ impl Point {
         self.pend = 0;
         self.ge.as_mut_ptr() as *mut i32
     }
-    /// the reference's element on the same limbs (no conversion: the layouts are one)
-    fn element(&self) -> ExtendedGroupElement {
-        let [x, y, z, t] = self.limbs();
-        ExtendedGroupElement { x, y, z, t }
+    /// Detach this point from the arena: its limbs are fetched (evaluating what it depends on) and it no longer names a handle.
+    /// For points that outlive a protocol round — the arena drops old nodes (`defer_floor`, `defer.max_nodes`), limbs are forever.
+    pub fn materialize(&mut self) -> Self {
+        self.ge = self.limbs();
+        self.pend = 0;
+        *self
     }
 
     /// the 32 bytes of `marshal_binary`, from the engine (one field inversion on the GPU; for a recorded point: evaluation in batches,
@@ -196,41 +199,18 @@ impl Point {
     fn hex(&self, upper: bool) -> String {
         self.encoding().iter().map(|byte| if upper { format!("{byte:02X}") } else { format!("{byte:02x}") }).collect()
     }
-    /// A point the reference's CPU type produced (`pick` / `embed`), brought over by its encoding
-    fn from_cpu(q: &CpuPoint) -> Self {
-        let bytes = q.marshal_binary().expect("marshal_binary of the CPU point");
-        Self::from_limbs(Self::decode(&bytes).expect("an encoding produced by the reference decodes"))
-    }
-
-    /// p1 + p2 or p1 - p2 for ONE pair, by the reference's own element formulas on the CPU
-    fn pair_on_cpu(p1: &Self, p2: &Self, subtract: bool) -> Limbs {
-        let (mut cached, mut sum, mut out) = (CachedGroupElement::default(), CompletedGroupElement::default(), ExtendedGroupElement::default());
-        p2.element().write_cached(&mut cached);
-        if subtract {
-            sum.sub(&p1.element(), &cached);
-        } else {
-            sum.add(&p1.element(), &cached);
-        }
-        sum.to_extended(&mut out);
-        [out.x, out.y, out.z, out.t]
-    }
-    fn pair_on_gpu(p1: &Self, p2: &Self, subtract: bool) -> Limbs {
-        ensure_init();
-        let (a, b) = (p1.limbs(), p2.limbs());
-        let mut out: Limbs = [[0; 10]; 4];
-        must(unsafe { ffi::kyb_add_batch(a.as_ptr() as *const i32, b.as_ptr() as *const i32, 1, out.as_mut_ptr() as *mut i32, subtract as c_int) }, "add");
-        out
-    }
-    /// add / sub of the trait: recorded in deferred mode, else one pair on the CPU (or on the GPU with `hip-single-add`)
+    /// add / sub of the trait: recorded in deferred mode, else one pair through the engine (`kyb_add_batch`, a batch of one)
     fn add_sub(self, p1: &Self, p2: &Self, subtract: bool) -> Self {
+        ensure_init();
         if deferred() {
-            ensure_init();
             let mut h = 0u64;
             must(unsafe { ffi::kyb_defer_add(p1.handle(), p2.handle(), subtract as c_int, &mut h) }, "defer_add");
             return self.recorded(h);
         }
-        let ge = if cfg!(feature = "hip-single-add") { Self::pair_on_gpu(p1, p2, subtract) } else { Self::pair_on_cpu(p1, p2, subtract) };
-        Point { ge, pend: 0, ..self }
+        let (a, b) = (p1.limbs(), p2.limbs());
+        let mut out: Limbs = [[0; 10]; 4];
+        must(unsafe { ffi::kyb_add_batch(a.as_ptr() as *const i32, b.as_ptr() as *const i32, 1, out.as_mut_ptr() as *mut i32, subtract as c_int) }, "add");
+        Point { ge: out, pend: 0, ..self }
     }
 
     /// `mul` for a multiplier the caller KNOWS to be public (a share index, the cofactor): the engine may then skip its leading
@@ -421,7 +401,7 @@ impl Marshaling for Point {
         marshalling::point_marshal_to(self, w)
     }
     fn marshal_size(&self) -> usize {
-        CpuPoint::default().marshal_size()
+        32
     }
     fn unmarshal_from(&mut self, r: &mut impl std::io::Read) -> Result<(), MarshallingError> {
         marshalling::point_unmarshal_from(self, r)
@@ -430,7 +410,7 @@ impl Marshaling for Point {
         marshalling::point_unmarshal_from_random(self, r);
     }
     fn marshal_id(&self) -> [u8; 8] {
-        CpuPoint::default().marshal_id()
+        MARSHAL_POINT_ID
     }
 }
 
@@ -450,9 +430,9 @@ impl group::Point for Point {
         Point { ge: *base_ext(), pend: 0, ..self }
     }
 
-    /// delegated: the reference's rejection loop on its CPU point, the accepted point brought over by its encoding
+    /// `embed` without data (point.rs:90-92)
     fn pick<S: Stream>(self, rand: &mut S) -> Self {
-        Point { ge: Self::from_cpu(&CpuPoint::default().pick(rand)).ge, pend: 0, ..self }
+        self.embed(None, rand)
     }
 
     fn set(&mut self, p: &Self) -> Self {
@@ -461,13 +441,42 @@ impl group::Point for Point {
         *self
     }
 
+    /// 29: a length byte below and a byte of randomness above the data (point.rs:99-104)
     fn embed_len(&self) -> usize {
-        CpuPoint::default().embed_len()
+        (255 - 8 - 8) / 8
     }
 
-    /// delegated, as `pick`
+    /// The rejection loop of point.rs:106-167 with its curve arithmetic on the engine: a candidate is 32 bytes of key stream (the
+    /// length and the data laid over bytes 0..=dl); `kyb_decode_batch` says whether it is a point; without data the candidate times
+    /// the cofactor is the result unless that is the neutral element; with data the candidate itself is, provided it lies in the
+    /// prime-order subgroup (candidate times L is the neutral element).  Eager calls in either mode: every answer decides the next step.
     fn embed<S: Stream>(self, data: Option<&[u8]>, rand: &mut S) -> Self {
-        Point { ge: Self::from_cpu(&CpuPoint::default().embed(data, rand)).ge, pend: 0, ..self }
+        ensure_init();
+        let dl = data.map_or(0, |d| d.len().min(self.embed_len()));
+        loop {
+            let mut cand = [0u8; 32];
+            rand.xor_key_stream(&mut cand, &[0u8; 32]).unwrap();
+            if let Some(d) = data {
+                cand[0] = dl as u8;
+                cand[1..=dl].copy_from_slice(&d[..dl]);
+            }
+            let Some(limbs) = Self::decode(&cand) else { continue };
+            let (scalar, keep_product) = if data.is_none() { (&COFACTOR_LE, true) } else { (&ORDER_LE, false) };
+            let (mut enc, mut product) = ([0u8; 32], [[0i32; 10]; 4]);
+            must(
+                unsafe {
+                    ffi::kyb_mul_batch(scalar.as_ptr(), std::ptr::null(), limbs.as_ptr() as *const i32, 1, enc.as_mut_ptr(), product.as_mut_ptr() as *mut i32,
+                                       std::ptr::null_mut())
+                },
+                "embed",
+            );
+            if keep_product && enc != NEUTRAL_ENC {
+                return Point { ge: product, pend: 0, ..self };
+            }
+            if !keep_product && enc == NEUTRAL_ENC {
+                return Point { ge: limbs, pend: 0, ..self };
+            }
+        }
     }
 
     /// the bytes `embed` placed behind the length byte of the encoding
@@ -480,9 +489,7 @@ impl group::Point for Point {
         Ok(bytes[1..=len].to_vec())
     }
 
-    /// One pair: the reference's own formulas on the CPU (0.3 us; a batch-of-1 round trip to the GPU is 26 us).  Cargo feature
-    /// `hip-single-add` sends it to the engine instead (the same point); vectors go there in any case (`Point::add_batch`).
-    /// Deferred mode: recorded (a chain of additions is evaluated as one sum).
+    /// One pair through the engine; deferred mode: recorded (a chain of additions is evaluated as one sum).  Vectors: `Point::add_batch`.
     fn add(self, p1: &Self, p2: &Self) -> Self {
         self.add_sub(p1, p2, false)
     }
@@ -587,8 +594,20 @@ impl PointCanCheckCanonicalAndSmallOrder for Point {
         must(unsafe { ffi::kyb_point_checks_batch(std::ptr::null(), l.as_ptr() as *const i32, 1, &mut flags) }, "point_checks");
         flags & 2 != 0
     }
-    /// pure byte logic on the caller's buffer: delegated (no decoding involved)
+    /// Byte logic on the caller's buffer, no decoding: false for the encodings point.rs:315-337 refuses — bytes 1..=30 all 0xff, the
+    /// low seven bits of byte 31 all set, and byte 0 at least 0x14.  (The reference computes 0xED - (1 - b0) in wrapping 16-bit
+    /// arithmetic and looks at bit 8, which is set from b0 = 0x14 on — libsodium's form would say 0xED; csrc/verify.h has the derivation
+    /// and the GPU's verify kernels use the same threshold.)  Every byte is looked at whatever the others hold.
     fn is_canonical(&self, b: &[u8]) -> bool {
-        CpuPoint::default().is_canonical(b)
+        if b.len() != 32 {
+            return false;
+        }
+        let mut high_differs = (b[31] & 0x7f) ^ 0x7f;
+        for byte in &b[1..31] {
+            high_differs |= byte ^ 0xff;
+        }
+        let high_all_ones = high_differs == 0;
+        let low_too_big = b[0] >= 0x14;
+        !(high_all_ones & low_too_big)
     }
 }

@@ -95,13 +95,32 @@ def test_the_module_defines_a_point_and_nothing_else():
     code = re.sub(r"//.*", "", src)
     assert not re.search(r"\b(struct|enum)\s+(Curve|Suite)\w*", code) and "impl Group for" not in code
     patch = open(os.path.join(os.path.dirname(SHIM), "kyber-rs.hip-feature.patch")).read()
-    assert 'pub use super::edwards25519_hip::Point;' in patch and '#[cfg(feature = "hip")]' in patch
-    # the rejection loop and the byte-level canonical test are delegated to the reference's CPU point, not restated; has_small_order asks the engine;
-    # nothing unmarshals the engine's own encoding back into the CPU type (that panicked on limbs that are no curve point)
+    assert '+pub use super::edwards25519_hip::Point;' in patch and '+#[cfg(feature = "hip")]' in patch and "--- a/src/group.rs" in patch
+    # ONE code path (round-4 review): nothing names the reference's CPU point or its formulas; pick is embed without data; the rejection loop
+    # decodes and multiplies on the engine; a single add is an engine call, not the reference's ge.rs; has_small_order asks the engine
     point = open(os.path.join(SHIM, "point.rs")).read()
-    for method in ("embed(data, rand)", "pick(rand)", ".is_canonical(b)", "kyb_point_checks_batch"):
-        assert method in point, method
-    assert "WEAK_KEYS" not in point and "xor_key_stream" not in point and "0xED" not in point
-    assert "fn to_cpu" not in point and ".unmarshal_binary(&self.encoding())" not in point
+    code = re.sub(r"//.*", "", point)
+    for word in ("CpuPoint", "GroupElement", "pair_on_cpu", "hip-single-add", "WEAK_KEYS", "fn to_cpu", "fn from_cpu"):
+        assert word not in code, word
+    for needle in ("self.embed(None, rand)", "ffi::kyb_decode_batch", "ffi::kyb_add_batch", "ffi::kyb_point_checks_batch", "COFACTOR_LE", "ORDER_LE", "pub fn materialize"):
+        assert needle in code, needle
     # pick / embed keep the receiver's var_time flag (point.rs:90-92, 106-167 take `self`)
     assert point.count("..self }") >= 6
+
+
+def test_the_symbol_comparison_with_the_cpp_mirror_catches_a_second_code_path():
+    """tools/check_rust_shim.py part 3 on doctored copies: a method that loses its engine call, a method that gains one, a CPU delegation"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_rust_shim as chk
+    point = open(os.path.join(SHIM, "point.rs")).read()
+    bad = []
+    rows = chk.one_code_path(bad)
+    assert not bad and len(rows) == 16 and {r[0] for r in rows} >= {"null", "base", "pick", "set", "embed", "data", "add", "sub", "neg", "mul", "marshal_binary", "unmarshal_binary", "eq"}
+    assert dict((r[0], r[1]) for r in rows)["embed"] == "`kyb_decode_batch`, `kyb_mul_batch`"
+    for old, new, what in (("ffi::kyb_defer_neg(a.handle(), &mut h)", "0", "`neg`"),                                   # an operation that no longer reaches the engine
+                           ("ffi::kyb_add_batch(a.as_ptr()", "ffi::kyb_sum_batch(a.as_ptr()", "`add`"),                 # ... or reaches another entry point
+                           ("self.embed(None, rand)", "Self::from_limbs(CpuPoint::default().pick(rand).limbs())", "CpuPoint")):
+        assert old in point
+        bad = []
+        chk.one_code_path(bad, rust_text=point.replace(old, new))
+        assert bad and any(what in b for b in bad), (what, bad)

@@ -12,6 +12,11 @@ container only — the GPU box has no /root/reference and the test that calls th
        anything; what remains in common for point.rs are the trait signatures an `impl group::Point for Point` must spell out)
      * no function of the module has a body (> 2 code lines) equal to the body of a same-named function of the reference.
 
+3. ONE code path, the same on both sides of the language border (round-4 review): for every method of the trait surface the set of `kyb_*`
+   entry points the Rust method can reach — through the helper functions of its file — equals the set the C++ mirror's method of that
+   name reaches (host/edwards25519.hpp, which the GPU tests drive), and nothing in the module names the reference's CPU point or its
+   `ge.rs` formulas.  (This part needs no reference and also runs where /root/reference is absent.)
+
   python tools/check_rust_shim.py [--reference /root/reference] [--markdown]
 """
 import argparse
@@ -88,6 +93,123 @@ def fn_bodies(text):
     return out
 
 
+def _body_at(code, k):
+    """the text between the brace at code[k] and its partner"""
+    depth, j = 0, k
+    while j < len(code):
+        depth += code[j] == "{"
+        depth -= code[j] == "}"
+        if depth == 0:
+            break
+        j += 1
+    return code[k + 1:j], j
+
+
+def rust_fn_texts(text):
+    """{fn name: body text} of every fn with a body in a Rust file (bodies of one name in several impl blocks — three `fmt` — are joined)"""
+    code = re.sub(r"//.*", "", text)
+    out = {}
+    for m in re.finditer(r"\bfn\s+(\w+)", code):
+        k, depth = m.end(), 0                       # the first `{` or `;` outside (), [] — `-> [u8; 32] {` has a body
+        while k < len(code) and not (depth == 0 and code[k] in "{;"):
+            depth += code[k] in "(["
+            depth -= code[k] in ")]"
+            k += 1
+        if k >= len(code) or code[k] == ";":
+            continue
+        body, _ = _body_at(code, k)
+        out[m.group(1)] = out.get(m.group(1), "") + "\n" + body
+    return out
+
+
+def cpp_method_texts(text, cls="Point"):
+    """{method name: body text} of the methods defined inside `class <cls> { ... };` (member functions at class depth, `operator==` included)"""
+    code = re.sub(r"//.*", "", text)
+    m = re.search(r"\bclass\s+%s\s*\{" % cls, code)
+    body, _ = _body_at(code, m.end() - 1)
+    out, depth, i = {}, 0, 0
+    while i < len(body):
+        c = body[i]
+        if c == "{":
+            depth += 1
+        elif c == "}":
+            depth -= 1
+        elif depth == 0:
+            f = re.match(r"(operator==|\w+)\s*\(", body[i:])
+            if f and (i == 0 or not (body[i - 1].isalnum() or body[i - 1] == "_")):
+                # the parameter list, then `const`, then either a body or (a declaration, an initialiser) something else
+                j, d = i + f.end() - 1, 0
+                while j < len(body):
+                    d += body[j] == "("
+                    d -= body[j] == ")"
+                    if d == 0:
+                        break
+                    j += 1
+                rest = re.match(r"\s*(?:const\s*)?\{", body[j + 1:])
+                if rest:
+                    k = j + 1 + rest.end() - 1
+                    mb, end = _body_at(body, k)
+                    out[f.group(1)] = out.get(f.group(1), "") + "\n" + mb
+                    i = end + 1
+                    continue
+        i += 1
+    return out
+
+
+def reachable_symbols(fns, name, skip=()):
+    """kyb_* names in the body of `name` and in the bodies of the file's own functions it calls, transitively"""
+    seen, todo, syms = set(), [name], set()
+    while todo:
+        f = todo.pop()
+        if f in seen or f not in fns:
+            continue
+        seen.add(f)
+        syms |= set(re.findall(r"\bkyb_\w+", fns[f]))
+        # a call of one of the file's own functions: bare, `self.f(`, `Self::f(`, `this->f(` — or `operand.f(` / `operand->f(` when the name
+        # cannot be a method of another type (`l.data()` of a std::array, `cell.set(..)`, `bytes.hash(..)` are not ours)
+        for pre, callee in re.findall(r"((?:\bself\s*\.|\bSelf\s*::|\bthis\s*->|\.|->)?)\s*\b(\w+)\s*(?:::<[^>]*>)?\(", fns[f]):
+            if callee not in fns or callee in skip:
+                continue
+            if pre in (".", "->") and callee in AMBIGUOUS:
+                continue
+            todo.append(callee)
+    return syms
+
+
+AMBIGUOUS = {"data", "set", "get", "hash", "cmp", "eq", "fmt", "new", "from", "size", "fill", "add", "sub", "neg", "mul", "null", "base"}
+# trait surface: Rust method -> the mirror's method.  (`must` / `ensure_init` / `engine_must` are error and context plumbing, not operations.)
+SURFACE = [("null", "null"), ("base", "base"), ("pick", "pick"), ("set", "set"), ("embed_len", "embed_len"), ("embed", "embed"), ("data", "data"),
+           ("add", "add"), ("sub", "sub"), ("neg", "neg"), ("mul", "mul"), ("marshal_binary", "marshal_binary"), ("unmarshal_binary", "unmarshal_binary"),
+           ("eq", "operator=="), ("has_small_order", "has_small_order"), ("is_canonical", "is_canonical")]
+
+
+def one_code_path(bad, markdown=False, rust_text=None, cpp_text=None):
+    rust_text = rust_text if rust_text is not None else open(os.path.join(SHIM, "point.rs")).read()
+    rust = rust_fn_texts(rust_text)
+    cpp = cpp_method_texts(cpp_text if cpp_text is not None else open(os.path.join(ROOT, "kyber-rs_amd", "host", "edwards25519.hpp")).read())
+    rows = []
+    for rname, cname in SURFACE:
+        if rname not in rust:
+            bad.append(f"one code path: the Rust module has no fn {rname}")
+            continue
+        if cname not in cpp:
+            bad.append(f"one code path: the C++ mirror has no method {cname}")
+            continue
+        rs, cs = reachable_symbols(rust, rname), reachable_symbols(cpp, cname)
+        if rs != cs:
+            bad.append(f"one code path: `{rname}` reaches {sorted(rs)} in Rust but {sorted(cs)} in the C++ mirror (`{cname}`)")
+        rows.append((rname, ", ".join(f"`{x}`" for x in sorted(rs)) or "— (host only)", "same" if rs == cs else "DIFFERENT"))
+    code = re.sub(r"//.*", "", rust_text + "".join(open(os.path.join(SHIM, f)).read() for f in sorted(os.listdir(SHIM)) if f.endswith(".rs") and f != "point.rs"))
+    for word in ("CpuPoint", "edwards25519::point", "edwards25519::ge", "GroupElement", "hip-single-add", "pair_on_cpu"):
+        if word in code:
+            bad.append(f"one code path: the module names `{word}` — the reference's CPU point / formulas are a second path")
+    if markdown:
+        print("\n| trait method | engine entry points reached (Rust module = C++ mirror) | |\n|---|---|---|")
+        for r in rows:
+            print("| `" + r[0] + "` | " + r[1] + " | " + r[2] + " |")
+    return rows
+
+
 def similarity(shim_text, ref_text):
     a, b = strip(shim_text), strip(ref_text)
     if len(a) < 8:                        # a three-line mod.rs shares `mod point;` with anybody's
@@ -103,10 +225,14 @@ def main():
     ap.add_argument("--markdown", action="store_true")
     a = ap.parse_args()
     ref_dir = os.path.join(a.reference, "src", "group", "edwards25519")
-    if not os.path.isdir(ref_dir):
-        print("reference not present: nothing to compare")
-        return 0
     bad, rows = [], []
+    surface = one_code_path(bad, a.markdown)
+    print(f"one code path: {len(surface)} trait methods compared with the C++ mirror, symbol set by symbol set")
+    if not os.path.isdir(ref_dir):
+        for b in bad:
+            print("MISMATCH:", b)
+        print(f"reference not present: impl blocks and similarity not compared; {len(bad)} mismatches")
+        return 1 if bad else 0
     # 1. the stand-in is complete
     ref = impl_blocks(open(os.path.join(ref_dir, "point.rs")).read())
     shim = impl_blocks(open(os.path.join(SHIM, "point.rs")).read())
