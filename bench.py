@@ -564,6 +564,10 @@ def small_call_latency(eng, orc):
                          "mul_public_10bit_index": med(lambda: eng.mul(idx[:n], pts_ext=ext[:n], public=True)),
                          "sign": med(lambda: eng.schnorr_sign(s[:n], k[:n], msgs[:n])), "verify": med(lambda: eng.verify(enc[:n], msgs[:n], sigs[:n], 1)),
                          "decode": med(lambda: eng.decode(enc[:n])), "encode": med(lambda: eng.encode(ext[:n]))}
+    # the same single operations on the CPU port (one oracle call each through ctypes): what a batch-of-1 engine call competes with
+    s0, k0, e0, x0, m0 = s[0].tobytes(), k[0].tobytes(), enc[0].tobytes(), ext[0], msgs[:1]
+    out["cpu_port_n=1"] = {"mul_base": med(lambda: orc.mul_base(s0)), "mul": med(lambda: orc.mul(k0, x0)), "decode": med(lambda: orc.decode(e0)), "encode": med(lambda: orc.encode(x0)),
+                           "sign": med(lambda: orc.schnorr_sign_batch(s[:1], k[:1], m0)), "verify": med(lambda: orc.verify_batch(1, enc[:1], m0, sigs[:1]))}
     out["call_by_call_t43"] = call_by_call_sequences(eng, orc, med)
     return out
 
@@ -642,19 +646,71 @@ def call_by_call_sequences(eng, orc, med, t=43):
             pubb = [eng.defer_add(pubb[j], eng.defer_input(polys[d][j])) for j in range(t)]
         return [eng.defer_get(h) for h in pubb]
 
+    # the same four sequences call by call on the CPU port (the oracle through ctypes, one thread): the column the engine's two are read against
+    base_cpu = orc.base()
+
+    def commit_cpu():
+        return [orc.encode(orc.mul_ext(coeffs[j].tobytes(), base_cpu)) for j in range(t)]
+
+    def eval_cpu():
+        v = orc.null()
+        for j in reversed(range(t)):
+            v = orc.add(orc.mul_ext(xi.tobytes(), v), commits_ext[j])
+        return v
+
+    def verify_deal_cpu():
+        return orc.encode(orc.mul_base_ext(share.tobytes())) == orc.encode(eval_cpu())
+
+    def fold_cpu():
+        pubb = [polys[0][j] for j in range(t)]
+        for d in range(1, dealers):
+            pubb = [orc.add(pubb[j], polys[d][j]) for j in range(t)]
+        return [orc.encode(p) for p in pubb]
+
+    assert fold_cpu() == want_fold and commit_cpu() == [bytes(w) for w in want_commits] and orc.encode(eval_cpu()) == want_eval and verify_deal_cpu()
     assert fold_eager() == want_fold == fold_deferred()
     assert commit_eager() == [bytes(w) for w in want_commits] == commit_deferred()
     assert orc.encode(eval_eager()) == want_eval == eng.defer_get(eval_deferred_handle())
     assert verify_deal_eager() and verify_deal_deferred()
     mark = eng.defer_mark()
     res = {"unit": "us per whole sequence (median of 20), t = 43", "checked_against_oracle": True,
-           "commit_then_marshal": {"eager": med(commit_eager, 20), "deferred": med(commit_deferred, 20)},
-           "pubpoly_eval": {"eager": med(eval_eager, 20), "deferred": med(lambda: eng.defer_get_ext(eval_deferred_handle()), 20)},
-           "verify_deal": {"eager": med(verify_deal_eager, 20), "deferred": med(verify_deal_deferred, 20)},
-           "pubpoly_add_fold_8_dealers": {"eager": med(fold_eager, 10), "deferred": med(fold_deferred, 10)}}
+           "cpu_port": "the oracle (C restatement of the reference algorithm) call by call through ctypes, one thread, same box",
+           "commit_then_marshal": {"cpu_port": med(commit_cpu, 10), "eager": med(commit_eager, 20), "deferred": med(commit_deferred, 20)},
+           "pubpoly_eval": {"cpu_port": med(eval_cpu, 10), "eager": med(eval_eager, 20), "deferred": med(lambda: eng.defer_get_ext(eval_deferred_handle()), 20)},
+           "verify_deal": {"cpu_port": med(verify_deal_cpu, 10), "eager": med(verify_deal_eager, 20), "deferred": med(verify_deal_deferred, 20)},
+           "pubpoly_add_fold_8_dealers": {"cpu_port": med(fold_cpu, 10), "eager": med(fold_eager, 10), "deferred": med(fold_deferred, 10)}}
     res["arena"] = eng.defer_stats()
     eng.defer_floor(mark)
     return res
+
+
+def protocol_phases(n=64, t=43):
+    """Unmodified call-by-call protocol code, phase by phase, with the CPU beside it (round-4 review item 3): tests/cpp/test_vss_round.cpp (a Pedersen dealer
+    round: vss.rs:287-337, 361-386, 904-909) and tests/cpp/test_dkg_finish.cpp (dkg.rs:905-953, poly.rs:566-603) are compiled twice — against the engine
+    (eager = every trait call a batch-of-1 engine call; deferred = calls recorded and evaluated in batches; batched = the same round written with the batch
+    entry points) and against tests/cpp/cpu_port_abi.cpp, the oracle behind the same ABI: the IDENTICAL sequence on one host core (cpu_port_ms).  All four
+    transcripts of a program are byte-identical (checked here; against the oracle item by item in tests/test_gpu_vss_round.py).  Milliseconds, one run each
+    after one untimed pass.  Phases where deferred loses to the CPU are sequences of one-item requests, each waited for before the next is made
+    (encrypted_deals: key, signature, shared point per verifier; new_dealer: n marshals) — the price is the GPU's one-item latency, see DESIGN.md."""
+    import importlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        rounds = importlib.import_module("test_gpu_vss_round")
+        out = {"n": n, "t": t, "unit": "ms per phase", "cpu_port": "the C restatement of the reference algorithm (oracle/) behind the same ABI, one thread"}
+        for prog in ("test_vss_round", "test_dkg_finish"):
+            lines, timing = rounds.run_program(rounds.build(prog), n, t)
+            cpu_lines, cpu = rounds.run_program(rounds.build(prog, cpu_port=True), n, t, "eager")
+            same = lines["E"] == lines["D"] == cpu_lines["E"] and (not lines["B"] or lines["B"] == lines["E"])
+            phases = {}
+            for ph, ms in cpu["eager_ms"].items():
+                phases[ph] = {"cpu_port_ms": ms, "eager_ms": timing["eager_ms"][ph], "deferred_ms": timing["deferred_ms"][ph]}
+                if "batched_ms" in timing:
+                    phases[ph]["batched_ms"] = timing["batched_ms"][ph]
+                phases[ph]["deferred_vs_cpu"] = round(ms / timing["deferred_ms"][ph], 2)
+            out[prog] = {"phases": phases, "transcripts_identical": same, "deferred_stats": timing["deferred_stats"]}
+        return out
+    except Exception as e:      # a missing g++ on the bench box must not cost the bench line
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def host_pointer_rates(w, eng, orc, threads, calls=5):
@@ -857,6 +913,7 @@ def run_ranks(args):
                 line["workloads"] = others
                 line["small_calls"] = small_call_latency(eng, orc)
                 line["mid_size_calls"] = mid_size_calls(eng, orc, threads)
+                line["protocol_phases"] = protocol_phases()
                 peak2 = eng.mad_peak(50.0)
                 line["roofline"]["peak_repeat_at_end_of_run"] = {"peak": round(peak2["mads_per_s"] / 1e12, 3), "clock_ghz": round(peak2["clock_ghz"], 4)}
         print(json.dumps(line), flush=True)

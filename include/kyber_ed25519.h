@@ -401,7 +401,7 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  * (as everywhere in this ABI).  Option defer.fuse = 0 switches the chain recognition off (level-by-level batches only).
  * Lifetime: the reference's Point is Copy, so copies of a handle may live anywhere and nodes are not reference-counted.  Evaluated nodes
  * stay in the arena until kyb_defer_floor(mark) drops everything recorded before `mark` (= an earlier kyb_defer_mark(); e.g. at the end
- * of a protocol round) or until more than defer.max_nodes (default 2^20, about 250 bytes each) exist, when the oldest are dropped; a
+ * of a protocol round) or until more than defer.max_nodes (default 2^18; a node is 40 bytes, plus 224 where it holds a scalar or a value: at most 69 MB per arena) exist, when the oldest are dropped; a
  * dropped handle is refused with KYB_E_STALE ("stale handle"), never answered wrongly (a binding whose point still holds its limbs registers them again: host/edwards25519.hpp).  Secret scalars are kept until their node is
  * evaluated and cleared then; a node's limbs and bytes — a recorded Diffie-Hellman exchange leaves the shared point there — are cleared when the
  * node is dropped (floor, defer.max_nodes, the end of the arena): call kyb_defer_floor when a round's secrets are done with.  A handle carries the number of the arena it came from (upper 24 bits), so handles of
@@ -501,7 +501,7 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     wavefront per SIMD (shorter dependent chain; full batches keep 8).  Same results.
  *   defer.fuse        1 (default): a flush of deferred points (kyb_defer_*) evaluates Horner chains and chains of additions as ONE call each; 0:
  *                     level by level only.  Same results.
- *   defer.max_nodes   nodes the deferred-point arena keeps before it drops the oldest (default 2^20, at least 16); a dropped handle is refused
+ *   defer.max_nodes   nodes the deferred-point arena keeps before it drops the oldest (default 2^18 = at most 69 MB, at least 16); a dropped handle is refused
  *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder (and, with ladder.y_only, the decode of A)
  *   verify.by_encoding 1 (default): large batches test the equation as enc(s*B - h*A) == R bytes and decode R only on a mismatch
  *   host.in_place     1 (default): a host-pointer call small enough for host.zero_copy_kib (and of at least 64 KiB) whose array lies in memory
@@ -540,6 +540,16 @@ const char* kyb_kernel_name(int kernel_id);
  *     kyb_shutdown), which switches the stamps off by itself. */
 int kyb_diag_mad_peak(double min_ms, double* mads_per_s, double* clock_ghz, double* simd_cycles_per_mad, double* kernel_ms);
 int kyb_diag_wave_stamps(void* dev_buf);
+/* Test hooks for the error paths and the "secrets" convention above (tests/test_gpu_fault_injection.py):
+ *   options diag.fail_alloc_after = k / diag.fail_launch_after = k (kyb_set_option; 0 = off): the k-th buffer allocation / kernel launch this
+ *     context attempts from now on fails without being made — KYB_E_NOMEM naming the buffer / KYB_E_HIP naming the launch — and the counter
+ *     is spent.  A failed call leaves the context usable: the next call gives the ordinary results.
+ *   kyb_get_option diag.dev_kib / diag.host_kib: KiB of device / page-locked memory the context's lazily grown buffers hold now.
+ *   kyb_diag_scratch_read(which, dst, cap, bytes): copies up to cap bytes of one of the context's buffers to dst and stores the buffer's
+ *     size in *bytes (0 = not allocated).  which: 0, 1 page-locked zero-copy / bounce buffers; 2 device staging of host-pointer calls;
+ *     3 page-locked landing area of large pageable results; 4, 5, 6 the engine stream's scratch (projective records, encodings, products of
+ *     small linear combinations).  Waits for the device first.  Never needed by a caller of the engine. */
+int kyb_diag_scratch_read(int which, uint8_t* dst, size_t cap, size_t* bytes);
 
 #ifdef __cplusplus
 }

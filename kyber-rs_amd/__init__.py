@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "kyb_defer_flush", "kyb_defer_mark", "kyb_defer_floor", "kyb_defer_stats",
     "kyb_host_alloc", "kyb_host_free",
     "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
-    "kyb_diag_mad_peak", "kyb_diag_wave_stamps",
+    "kyb_diag_mad_peak", "kyb_diag_wave_stamps", "kyb_diag_scratch_read",
 ]
 
 
@@ -135,6 +135,7 @@ def load_library() -> ctypes.CDLL:
     dp = ctypes.POINTER(ctypes.c_double)
     lib.kyb_diag_mad_peak.argtypes = [ctypes.c_double, dp, dp, dp, dp]
     lib.kyb_diag_wave_stamps.argtypes = [vp]
+    lib.kyb_diag_scratch_read.argtypes = [ctypes.c_int, vp, sz, ctypes.POINTER(ctypes.c_size_t)]
     lib.kyb_add_batch.argtypes = [vp, vp, sz, vp, i32]
     lib.kyb_add_batch_dev.argtypes = [vp, vp, sz, vp, i32, vp]
     lib.kyb_encode_batch.argtypes = [vp, sz, vp]
@@ -368,6 +369,16 @@ class Engine:
         r, c, y, k = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
         _check(self.lib.kyb_diag_mad_peak(float(min_ms), ctypes.byref(r), ctypes.byref(c), ctypes.byref(y), ctypes.byref(k)), "kyb_diag_mad_peak")
         return {"mads_per_s": r.value, "clock_ghz": c.value, "simd_cycles_per_mad": y.value, "kernel_ms": k.value}
+
+    def scratch_read(self, which: int) -> bytes:
+        """kyb_diag_scratch_read: the present contents of one of the context's buffers (test hook for the secret-hygiene checks)"""
+        size = ctypes.c_size_t(0)
+        _check(self.lib.kyb_diag_scratch_read(which, None, 0, ctypes.byref(size)), "kyb_diag_scratch_read")
+        if size.value == 0:
+            return b""
+        buf = np.empty(size.value, dtype=np.uint8)
+        _check(self.lib.kyb_diag_scratch_read(which, _ptr(buf), size.value, ctypes.byref(size)), "kyb_diag_scratch_read")
+        return buf.tobytes()
 
     def wave_stamps(self, buf) -> None:
         """kyb_diag_wave_stamps: buf = zeroed torch int64 tensor of 5 words on this engine's device, or None = off"""

@@ -102,6 +102,10 @@ struct Ctx {
   uint64_t use_clock = 0;
   size_t ws_bytes = 0;
   std::atomic<int> grid_mul{0};
+  // fault injection and accounting for tests (kyb_set_option diag.fail_alloc_after / diag.fail_launch_after, kyb_get_option diag.dev_kib / diag.host_kib):
+  // counters > 0 count DOWN on every allocation attempt / kernel launch of this context; the attempt that brings one to 0 fails without being made
+  std::atomic<int> diag_fail_alloc{0}, diag_fail_launch{0};
+  std::atomic<long long> diag_dev_bytes{0}, diag_host_bytes{0};      // live bytes of the context's lazily grown buffers (device / page-locked)
   uint8_t* stage = nullptr;       // device staging for the host-pointer API
   size_t stage_bytes = 0;
   uint32_t* done_flag = nullptr;          // coherent page-locked word the last kernel of a small host-pointer call writes (launch.h, DoneFlag)
@@ -129,9 +133,9 @@ struct Ctx {
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
   std::atomic<int> opt_finish_four{1};           // k_finish with 4 instead of 8 items per shared inversion for launches of at most one wavefront per SIMD
   std::atomic<int> opt_ladder_y_only{2};         // two-lane ladder from wire encodings: ladder on y while the decode looks for x — 2: as workgroups of the same launch, 1: on a side stream (0: decode first)
-  DeferArena* defer = nullptr;                   // recorded, not yet evaluated point operations of this context's callers (kyb_defer_*; made on first use)
+  std::atomic<DeferArena*> defer{nullptr};       // recorded, not yet evaluated point operations of this context's callers (kyb_defer_*; made on first use)
   std::atomic<int> opt_defer_fuse{1};            // flushes recognise Horner chains and chains of additions (defer.inc)
-  std::atomic<int> opt_defer_max_nodes{1 << 20}; // evaluated nodes kept for late readers of a handle before the oldest are dropped
+  std::atomic<int> opt_defer_max_nodes{1 << 18}; // nodes kept for late readers of a handle before the oldest are dropped (40 B each + 224 B where a value is held: at most 69 MB)
   bool stamps_on = false;                        // this context set the device's wave-stamp slots (kyb_diag_wave_stamps): cleared again when it is released
   std::atomic<int> opt_coop_share{1};             // divide the small-batch thresholds by the number of host-pointer calls in flight in this process (coop_lim)
   std::atomic<int> opt_host_inplace{1};           // zero-copy host-pointer calls use page-locked CALLER arrays (kyb_host_alloc) where they lie instead of copying them into the context's buffer
@@ -168,7 +172,28 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
   return code;
 }
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(KYB_E_HIP, #x, e_); } while (0)
-#define LAUNCHCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(KYB_E_HIP, #x, e_); } while (0)
+// a kernel launch of an entry point (`g` = its context in scope): the injected failure is reported without the launch being made
+#define LAUNCHCK(x) do { if (diag_trip(g.diag_fail_launch)) return fail(KYB_E_HIP, "injected launch failure (diag.fail_launch_after) at " #x); \
+                         hipError_t e_ = (x); if (e_ != hipSuccess) return fail(KYB_E_HIP, #x, e_); } while (0)
+inline bool diag_trip(std::atomic<int>& c) {
+  if (c.load(std::memory_order_relaxed) <= 0) return false;
+  return c.fetch_sub(1, std::memory_order_relaxed) == 1;
+}
+// every buffer a context grows on demand comes from these four: one place for the injected failure and for the byte accounting the leak tests read
+inline hipError_t ctx_malloc(Ctx& g, void** p, size_t bytes) {
+  if (diag_trip(g.diag_fail_alloc)) { *p = nullptr; return hipErrorOutOfMemory; }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) g.diag_dev_bytes.fetch_add((long long)bytes, std::memory_order_relaxed);
+  return e;
+}
+inline hipError_t ctx_host_malloc(Ctx& g, void** p, size_t bytes, unsigned flags) {
+  if (diag_trip(g.diag_fail_alloc)) { *p = nullptr; return hipErrorOutOfMemory; }
+  hipError_t e = hipHostMalloc(p, bytes, flags);
+  if (e == hipSuccess) g.diag_host_bytes.fetch_add((long long)bytes, std::memory_order_relaxed);
+  return e;
+}
+inline void ctx_free(Ctx& g, void* p, size_t bytes) { if (p) { (void)hipFree(p); g.diag_dev_bytes.fetch_sub((long long)bytes, std::memory_order_relaxed); } }
+inline hipError_t ctx_host_free(Ctx& g, void* p, size_t bytes) { if (!p) return hipSuccess; g.diag_host_bytes.fetch_sub((long long)bytes, std::memory_order_relaxed); return hipHostFree(p); }
 
 Ctx* cur() {
   Ctx* c = tl_cur;
@@ -182,6 +207,12 @@ Ctx* cur() {
   if (ctx_ == nullptr || !ctx_->ready) return fail(KYB_E_NOT_INIT, "no initialised context: kyb_init / kyb_ctx_create has not succeeded"); \
   Ctx& g = *ctx_;                                                                                            \
   HIPCK(hipSetDevice(g.device))
+// entry points that only touch host memory (recording a deferred operation, a cache hit): no device call on the way in — whatever they
+// go on to run on the GPU passes through an ordinary entry point, which makes the device current
+#define ENTER_HOST()                                                                                         \
+  Ctx* ctx_ = cur();                                                                                         \
+  if (ctx_ == nullptr || !ctx_->ready) return fail(KYB_E_NOT_INIT, "no initialised context: kyb_init / kyb_ctx_create has not succeeded"); \
+  Ctx& g = *ctx_
 #define REQUIRE_TABLE() do { if (!g.table_ready.load()) return fail(KYB_E_NOT_INIT, "base table not built or imported"); } while (0)
 
 struct ProfScope {
@@ -202,17 +233,17 @@ inline hipStream_t pick(Ctx& g, void* s) { return s ? reinterpret_cast<hipStream
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // device buffers that held caller data (possibly private keys and nonces) are cleared before they go back to the runtime
-void wipe_free_dev(void* p, size_t bytes) {
+void wipe_free_dev(Ctx& g, void* p, size_t bytes) {
   if (!p) return;
   (void)hipMemset(p, 0, bytes);
-  (void)hipFree(p);
+  ctx_free(g, p, bytes);
 }
 
 int ensure_stage(Ctx& g, size_t bytes) {
   if (bytes <= g.stage_bytes) return KYB_OK;
-  if (g.stage) { wipe_free_dev(g.stage, g.stage_bytes); g.stage = nullptr; g.stage_bytes = 0; }
+  if (g.stage) { wipe_free_dev(g, g.stage, g.stage_bytes); g.stage = nullptr; g.stage_bytes = 0; }
   size_t want = bytes + (bytes >> 2) + 4096;
-  hipError_t e = hipMalloc(&g.stage, want);
+  hipError_t e = ctx_malloc(g, reinterpret_cast<void**>(&g.stage), want);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "staging allocation", e);
   g.stage_bytes = want;
   return KYB_OK;
@@ -244,10 +275,10 @@ inline size_t pair_lim(const Ctx& g, int opt) { const int l = host_load(g) / 4; 
 
 int ensure_pin(Ctx& g, int lane, size_t bytes) {
   if (bytes <= g.pin_bytes[lane]) return KYB_OK;
-  if (g.pin[lane]) { memset(g.pin[lane], 0, g.pin_bytes[lane]); HIPCK(hipHostFree(g.pin[lane])); g.pin[lane] = nullptr; g.pin_bytes[lane] = 0; }
+  if (g.pin[lane]) { memset(g.pin[lane], 0, g.pin_bytes[lane]); HIPCK(ctx_host_free(g, g.pin[lane], g.pin_bytes[lane])); g.pin[lane] = nullptr; g.pin_bytes[lane] = 0; }
   size_t want = bytes + (bytes >> 2) + 4096;
   // coherent: the zero-copy path reads results out of it as soon as the last kernel signals, before the runtime has seen the kernel end
-  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&g.pin[lane]), want, hipHostMallocCoherent);
+  hipError_t e = ctx_host_malloc(g, reinterpret_cast<void**>(&g.pin[lane]), want, hipHostMallocCoherent);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "pinned bounce buffer allocation", e);
   g.pin_bytes[lane] = want;
   return KYB_OK;
@@ -313,11 +344,11 @@ launch::DoneFlag take_done_flag(Ctx& g, hipStream_t st, size_t total) {
 }
 int ensure_done_flag(Ctx& g) {
   if (g.done_flag != nullptr) return KYB_OK;
-  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&g.done_flag), 64, hipHostMallocCoherent);
+  hipError_t e = ctx_host_malloc(g, reinterpret_cast<void**>(&g.done_flag), 64, hipHostMallocCoherent);
   if (e != hipSuccess) { g.done_flag = nullptr; return fail(KYB_E_NOMEM, "completion flag allocation", e); }
   *g.done_flag = 0;
-  e = hipMalloc(reinterpret_cast<void**>(&g.done_counter), 64);
-  if (e != hipSuccess) { (void)hipHostFree(g.done_flag); g.done_flag = nullptr; return fail(KYB_E_NOMEM, "completion counter allocation", e); }
+  e = ctx_malloc(g, reinterpret_cast<void**>(&g.done_counter), 64);
+  if (e != hipSuccess) { (void)ctx_host_free(g, g.done_flag, 64); g.done_flag = nullptr; return fail(KYB_E_NOMEM, "completion counter allocation", e); }
   // on the stream the counting kernels run on, and finished before the first of them is queued: a plain hipMemset of device memory may
   // return before it has run and is not ordered with a non-blocking stream — a kernel that overtook it counted from whatever the recycled
   // allocation held, fired the flag early by that amount in every later call, and the caller read results the last workgroups had not
@@ -394,9 +425,9 @@ int ensure_pipe(Ctx& g, int chunks) {
 }
 int ensure_pin_out(Ctx& g, size_t bytes) {
   if (bytes <= g.pin_out_bytes) return KYB_OK;
-  if (g.pin_out) { HIPCK(hipHostFree(g.pin_out)); g.pin_out = nullptr; g.pin_out_bytes = 0; }
+  if (g.pin_out) { HIPCK(ctx_host_free(g, g.pin_out, g.pin_out_bytes)); g.pin_out = nullptr; g.pin_out_bytes = 0; }
   const size_t want = bytes + (bytes >> 3) + 4096;
-  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&g.pin_out), want, hipHostMallocDefault);
+  hipError_t e = ctx_host_malloc(g, reinterpret_cast<void**>(&g.pin_out), want, hipHostMallocDefault);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "page-locked output landing area", e);
   g.pin_out_bytes = want;
   return KYB_OK;
@@ -719,14 +750,17 @@ int check_messages(const uint8_t* msgs, const uint32_t* msg_off, size_t n, size_
 }
 
 // ---- per-stream scratch slots ---------------------------------------------------------------------------
-void free_slot(StreamRes* r) {
+constexpr size_t MSM_BASE_WORDS = 43 * 40, MSM_TAB_WORDS = 43 * 32 * 40;      // per point
+inline size_t proj_alloc_bytes(size_t items) { return items * 8 * sizeof(uint4) + 256; }
+inline size_t msm_alloc_bytes(size_t points) { return points * (MSM_BASE_WORDS + MSM_TAB_WORDS) * sizeof(uint32_t); }
+void free_slot(Ctx& g, StreamRes* r) {
   if (r->ev_last && r->used) (void)hipEventSynchronize(r->ev_last);      // everything that used the scratch has finished
-  if (r->ws) (void)hipFree(r->ws);
-  if (r->proj) wipe_free_dev(r->proj, r->proj_items * 8 * sizeof(uint4));
-  if (r->enc) wipe_free_dev(r->enc, r->enc_bytes);
-  if (r->part) wipe_free_dev(r->part, r->part_items * 160);
-  if (r->msm) (void)hipFree(r->msm);
-  if (r->pub_enc) (void)hipFree(r->pub_enc);
+  if (r->ws) ctx_free(g, r->ws, g.ws_bytes);
+  if (r->proj) wipe_free_dev(g, r->proj, proj_alloc_bytes(r->proj_items));
+  if (r->enc) wipe_free_dev(g, r->enc, r->enc_bytes);
+  if (r->part) wipe_free_dev(g, r->part, r->part_items * 160);
+  if (r->msm) ctx_free(g, r->msm, msm_alloc_bytes(r->msm_points));
+  if (r->pub_enc) ctx_free(g, r->pub_enc, 32 * r->pub_enc_items);
   if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->ev_fork); (void)hipEventDestroy(r->ev_join); if (r->ev_mid) (void)hipEventDestroy(r->ev_mid); }
   if (r->ev_last) (void)hipEventDestroy(r->ev_last);
   delete r;
@@ -740,7 +774,7 @@ int res_for(Ctx& g, hipStream_t st, StreamRes** out) {
     for (size_t i = 0; i < g.res.size(); ++i)
       if (!g.res[i]->own && (victim == g.res.size() || g.res[i]->last_use < g.res[victim]->last_use)) victim = i;
     if (victim == g.res.size()) return fail(KYB_E_NOMEM, "no stream scratch slot can be recycled");
-    free_slot(g.res[victim]);
+    free_slot(g, g.res[victim]);
     g.res.erase(g.res.begin() + (long)victim);
   }
   StreamRes* r = new StreamRes();
@@ -765,19 +799,18 @@ struct SlotUse {
 // the windowed-table kernel's per-wave table slots (160 MiB): only allocated if that kernel is used
 int ensure_ws(Ctx& g, StreamRes* r) {
   if (r->ws) return KYB_OK;
-  hipError_t e = hipMalloc(&r->ws, g.ws_bytes);
+  hipError_t e = ctx_malloc(g, reinterpret_cast<void**>(&r->ws), g.ws_bytes);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "table workspace allocation", e);
   return KYB_OK;
 }
 // grow-only; growth synchronises the stream first because earlier launches may still use the old buffer
 int ensure_proj(Ctx& g, StreamRes* r, size_t items) {
-  (void)g;
   if (items <= r->proj_items) return KYB_OK;
   HIPCK(hipStreamSynchronize(r->stream));
-  if (r->proj) wipe_free_dev(r->proj, r->proj_items * 8 * sizeof(uint4));
+  if (r->proj) wipe_free_dev(g, r->proj, proj_alloc_bytes(r->proj_items));
   r->proj = nullptr; r->proj_items = 0; r->top_or = nullptr;
   const size_t want = ((items + (items >> 3)) + 1023) & ~(size_t)1023;
-  hipError_t e = hipMalloc(&r->proj, want * 8 * sizeof(uint4) + 256);
+  hipError_t e = ctx_malloc(g, reinterpret_cast<void**>(&r->proj), proj_alloc_bytes(want));
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "projective staging allocation", e);
   r->proj_items = want;
   r->top_or = reinterpret_cast<uint32_t*>(r->proj + want * 8);
@@ -786,50 +819,45 @@ int ensure_proj(Ctx& g, StreamRes* r, size_t items) {
 }
 // extended quads of k_mul_coop's products for k_sum_coop (40 words per item)
 int ensure_ws_part(Ctx& g, StreamRes* r, size_t items) {
-  (void)g;
   if (items <= r->part_items) return KYB_OK;
   HIPCK(hipStreamSynchronize(r->stream));
-  if (r->part) wipe_free_dev(r->part, r->part_items * 160);
+  if (r->part) wipe_free_dev(g, r->part, r->part_items * 160);
   r->part = nullptr; r->part_items = 0;
   const size_t want = ((items + (items >> 3)) + 1023) & ~(size_t)1023;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->part), want * 160);
+  hipError_t e = ctx_malloc(g, reinterpret_cast<void**>(&r->part), want * 160);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "product staging allocation", e);
   r->part_items = want;
   return KYB_OK;
 }
-constexpr size_t MSM_BASE_WORDS = 43 * 40, MSM_TAB_WORDS = 43 * 32 * 40;      // per point
 int ensure_msm(Ctx& g, StreamRes* r, size_t points) {
-  (void)g;
   if (points <= r->msm_points) return KYB_OK;
   HIPCK(hipStreamSynchronize(r->stream));
-  if (r->msm) (void)hipFree(r->msm);
+  if (r->msm) ctx_free(g, r->msm, msm_alloc_bytes(r->msm_points));
   r->msm = nullptr; r->msm_points = 0;
   const size_t want = points + (points >> 3) + 16;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->msm), want * (MSM_BASE_WORDS + MSM_TAB_WORDS) * sizeof(uint32_t));
+  hipError_t e = ctx_malloc(g, reinterpret_cast<void**>(&r->msm), msm_alloc_bytes(want));
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "point table allocation", e);
   r->msm_points = want;
   return KYB_OK;
 }
 int ensure_enc(Ctx& g, StreamRes* r, size_t bytes) {
-  (void)g;
   if (bytes <= r->enc_bytes) return KYB_OK;
   HIPCK(hipStreamSynchronize(r->stream));
-  if (r->enc) wipe_free_dev(r->enc, r->enc_bytes);
+  if (r->enc) wipe_free_dev(g, r->enc, r->enc_bytes);
   r->enc = nullptr; r->enc_bytes = 0;
   const size_t want = bytes + (bytes >> 3) + 4096;
-  hipError_t e = hipMalloc(&r->enc, want);
+  hipError_t e = ctx_malloc(g, reinterpret_cast<void**>(&r->enc), want);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "encoding staging allocation", e);
   r->enc_bytes = want;
   return KYB_OK;
 }
 int ensure_pub_enc(Ctx& g, StreamRes* r, size_t items) {
-  (void)g;
   if (items <= r->pub_enc_items) return KYB_OK;
   HIPCK(hipStreamSynchronize(r->stream));
-  if (r->pub_enc) (void)hipFree(r->pub_enc);
+  if (r->pub_enc) ctx_free(g, r->pub_enc, 32 * r->pub_enc_items);
   r->pub_enc = nullptr; r->pub_enc_items = 0;
   const size_t want = items + (items >> 3) + 1024;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->pub_enc), 32 * want);
+  hipError_t e = ctx_malloc(g, reinterpret_cast<void**>(&r->pub_enc), 32 * want);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "public-key encoding buffer allocation", e);
   r->pub_enc_items = want;
   return KYB_OK;
@@ -878,19 +906,19 @@ void ctx_release(Ctx* c) {
     (void)launch::diag_stamps_base(nullptr);
     c->stamps_on = false;
   }
-  if (c->defer) { defer_release(c->defer); c->defer = nullptr; }
-  for (StreamRes* r : c->res) free_slot(r);
+  if (DeferArena* da = c->defer.exchange(nullptr)) defer_release(da);
+  for (StreamRes* r : c->res) free_slot(*c, r);
   c->res.clear();
-  wipe_free_dev(c->stage, c->stage_bytes);
-  for (int l = 0; l < 2; ++l) if (c->pin[l]) { memset(c->pin[l], 0, c->pin_bytes[l]); (void)hipHostFree(c->pin[l]); }
+  wipe_free_dev(*c, c->stage, c->stage_bytes);
+  for (int l = 0; l < 2; ++l) if (c->pin[l]) { memset(c->pin[l], 0, c->pin_bytes[l]); (void)ctx_host_free(*c, c->pin[l], c->pin_bytes[l]); }
   for (int l = 0; l < 2; ++l) if (c->ev_pin[l]) (void)hipEventDestroy(c->ev_pin[l]);
   for (int l = 0; l < 4; ++l) if (c->ev_ring[l]) (void)hipEventDestroy(c->ev_ring[l]);
   for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
-  if (c->pin_out) { memset(c->pin_out, 0, c->pin_out_bytes); (void)hipHostFree(c->pin_out); }
+  if (c->pin_out) { memset(c->pin_out, 0, c->pin_out_bytes); (void)ctx_host_free(*c, c->pin_out, c->pin_out_bytes); }
   if (c->stream_in) { (void)hipStreamSynchronize(c->stream_in); (void)hipStreamDestroy(c->stream_in); }
   if (c->stream_out) { (void)hipStreamSynchronize(c->stream_out); (void)hipStreamDestroy(c->stream_out); }
-  if (c->done_flag) (void)hipHostFree(c->done_flag);
-  if (c->done_counter) (void)hipFree(c->done_counter);
+  if (c->done_flag) (void)ctx_host_free(*c, c->done_flag, 64);
+  if (c->done_counter) ctx_free(*c, c->done_counter, 64);
   { std::lock_guard<std::mutex> lk(c->prof.mu);
     for (int i = 0; i < c->prof.cap; ++i) { (void)hipEventDestroy(c->prof.recs[i].a); (void)hipEventDestroy(c->prof.recs[i].b); }
     delete[] c->prof.recs; c->prof.recs = nullptr; c->prof.cap = c->prof.used = 0; c->prof.on = false; }

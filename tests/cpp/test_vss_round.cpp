@@ -13,7 +13,14 @@
 // bytes are asked for: csrc/defer.inc) — prints both transcripts and the wall time of each phase.  tests/test_gpu_vss_round.py
 // compares the transcripts with each other and with the oracle.
 //
-//   test_vss_round [n verifiers = 64] [t = 43]
+// A third run writes the same round the way a BATCH-AWARE caller would: the dealer's t + 1 multiplications in one
+// kyb_mul_base_batch call, the n verifier keys marshalled by one kyb_encode_batch, the n ephemeral keys / signatures / Diffie-Hellman points by
+// one call each, the n deal checks as one kyb_pubpoly_eval_batch + kyb_mul_base_batch + kyb_equal_batch — the same bytes, and the figure that
+// says what the phases made of strictly serial one-item requests (encrypted_deals: ask, wait, ask) cost only because of the call shape.
+// Built with -DKYB_CPU_PORT against tests/cpp/cpu_port_abi.cpp (the oracle behind the same ABI) and run with mode "eager", the program times
+// the identical call-by-call sequence on one host core: the cpu_port_ms column.
+//
+//   test_vss_round [n verifiers = 64] [t = 43] [mode: all | eager]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -148,23 +155,112 @@ static void round_once(size_t n, size_t t, bool deferred_mode, Transcript& tr, T
   for (int k = 0; k < 8; ++k) stats[k] = s1[k] - s0[k];
 }
 
+#ifndef KYB_CPU_PORT
+// the same round by a caller that owns its batches: raw C-ABI batch calls, the random stream drawn in the order of the call-by-call run
+static void round_batched(size_t n, size_t t, Transcript& tr, Timing& tm) {
+  XorShiftStream rand;
+  auto must = [](int rc, const char* what) { if (rc != KYB_OK) { std::fprintf(stderr, "%s failed (%d): %s\n", what, rc, kyb_last_error()); std::abort(); } };
+  Scalar longterm = Scalar().pick(rand), secret = Scalar().pick(rand);
+  std::vector<uint8_t> v_priv(32 * n), v_enc(32 * n);
+  std::vector<int32_t> v_ext(40 * n);
+  for (size_t i = 0; i < n; ++i) { Scalar s = Scalar().pick(rand); std::memcpy(&v_priv[32 * i], s.v.data(), 32); }
+  must(kyb_mul_base_batch(v_priv.data(), n, nullptr, v_ext.data()), "verifier keys");            // outside the round, as in round_once
+  std::vector<Scalar> coeffs(t);
+  coeffs[0] = secret;
+  for (size_t j = 1; j < t; ++j) coeffs[j] = Scalar().pick(rand);
+  auto bytes32 = [](const uint8_t* p) { return std::vector<uint8_t>(p, p + 32); };
+  tr.put("LONGTERM", bytes32(longterm.v.data()));
+  for (size_t j = 0; j < t; ++j) tr.put("COEFF", bytes32(coeffs[j].v.data()));
+  for (size_t i = 0; i < n; ++i) tr.put("VPRIV", bytes32(&v_priv[32 * i]));
+  // ---- new_dealer: d_pubb and the t commitments are ONE fixed-base call; the verifier keys ONE encode ----
+  double t0 = now_ms();
+  std::vector<uint8_t> sc(32 * (t + 1)), enc(32 * (t + 1));
+  std::vector<int32_t> commits_ext(40 * (t + 1));
+  std::memcpy(&sc[0], longterm.v.data(), 32);
+  for (size_t j = 0; j < t; ++j) std::memcpy(&sc[32 * (j + 1)], coeffs[j].v.data(), 32);
+  must(kyb_mul_base_batch(sc.data(), t + 1, enc.data(), commits_ext.data()), "commit");
+  must(kyb_encode_batch(v_ext.data(), n, v_enc.data()), "marshal of the verifier keys");
+  tr.put("DPUB", bytes32(&enc[0]));
+  for (size_t i = 0; i < n; ++i) tr.put("VPUB", bytes32(&v_enc[32 * i]));
+  for (size_t j = 0; j < t; ++j) tr.put("COMMIT", bytes32(&enc[32 * (j + 1)]));
+  std::vector<Scalar> shares(n);
+  for (size_t i = 0; i < n; ++i) shares[i] = pripoly_eval(coeffs, i);
+  tm.dealer_setup = now_ms() - t0;
+  // ---- encrypted_deals: n ephemeral keys, n signatures over them, n Diffie-Hellman points: three calls ----
+  t0 = now_ms();
+  std::vector<uint8_t> dh_secret(32 * n), nonce(32 * n), xs(32 * n), dh_key(32 * n), sigs(64 * n), pre(32 * n);
+  std::vector<uint32_t> off(n + 1);
+  for (size_t i = 0; i < n; ++i) {
+    Scalar d = Scalar().pick(rand), k = Scalar().pick(rand);                                     // the order round_once draws them in
+    std::memcpy(&dh_secret[32 * i], d.v.data(), 32); std::memcpy(&nonce[32 * i], k.v.data(), 32); std::memcpy(&xs[32 * i], longterm.v.data(), 32);
+    off[i] = (uint32_t)(32 * i);
+  }
+  off[n] = (uint32_t)(32 * n);
+  must(kyb_mul_base_batch(dh_secret.data(), n, dh_key.data(), nullptr), "ephemeral keys");
+  must(kyb_schnorr_sign_batch(xs.data(), nonce.data(), dh_key.data(), off.data(), n, sigs.data()), "signatures");
+  must(kyb_mul_batch(dh_secret.data(), nullptr, v_ext.data(), n, pre.data(), nullptr, nullptr), "dh_exchange");
+  for (size_t i = 0; i < n; ++i) {
+    tr.put("DHSECRET", bytes32(&dh_secret[32 * i]));
+    tr.put("DHKEY", bytes32(&dh_key[32 * i]));
+    tr.put("SIG", std::vector<uint8_t>(&sigs[64 * i], &sigs[64 * i] + 64));
+    tr.put("PRE", bytes32(&pre[32 * i]));
+  }
+  tm.encrypted_deals = now_ms() - t0;
+  // ---- verify_deal for every verifier: share * B, the polynomial at every index, the comparison: three calls ----
+  t0 = now_ms();
+  std::vector<uint8_t> sh(32 * (n + 1)), eq(n + 1), ps_enc(32 * (n + 1));
+  std::vector<int32_t> fig(40 * (n + 1)), ps_ext(40 * (n + 1));
+  std::vector<uint32_t> idx(n + 1);
+  for (size_t i = 0; i < n; ++i) { std::memcpy(&sh[32 * i], shares[i].v.data(), 32); idx[i] = (uint32_t)i; }
+  std::memcpy(&sh[32 * n], shares[n > 1 ? 1 : 0].v.data(), 32); idx[n] = 0;                      // the deal that does NOT verify
+  must(kyb_mul_base_batch(sh.data(), n + 1, nullptr, fig.data()), "share * B");
+  must(kyb_pubpoly_eval_batch(commits_ext.data() + 40, t, idx.data(), n + 1, ps_enc.data(), ps_ext.data()), "PubPoly::eval");
+  must(kyb_equal_batch(fig.data(), ps_ext.data(), n + 1, eq.data()), "deal check");
+  for (size_t i = 0; i < n; ++i) { tr.lines.push_back(std::string("DEALOK ") + (eq[i] ? "1" : "0")); tr.put("PUBSHARE", bytes32(&ps_enc[32 * i])); }
+  tr.lines.push_back(std::string("DEALBAD ") + (eq[n] ? "1" : "0"));
+  tm.verify_deals = now_ms() - t0;
+}
+#endif
+
 int main(int argc, char** argv) {
   const size_t n = argc > 1 ? (size_t)atol(argv[1]) : 64, t = argc > 2 ? (size_t)atol(argv[2]) : 43;
+  const bool eager_only = argc > 3 && std::string(argv[3]) == "eager";
   if (kyb_init(0) != KYB_OK) { std::printf("kyb_init failed: %s\n", kyb_last_error()); return 2; }
-  { Transcript warm; Timing w; uint64_t st[8]; round_once(n < 4 ? n : 4, t < 5 ? t : 5, false, warm, w, st); round_once(n < 4 ? n : 4, t < 5 ? t : 5, true, warm, w, st); }   // first-use allocations out of the way
-  Transcript eager, lazy;
-  Timing te, tl;
-  uint64_t se[8], sl[8];
+  // one untimed pass at the timed shape (deferred: the eager pass of a large round is seconds, a small one is enough for it): the context's staging
+  // buffers are allocated on the first call of a size, once per context; the CPU port gets a pass as well (caches, page faults)
+  {
+    Transcript warm; Timing w; uint64_t st[8];
+    if (eager_only) round_once(n, t, false, warm, w, st);
+    else { round_once(n < 4 ? n : 4, t < 5 ? t : 5, false, warm, w, st); round_once(n, t, true, warm, w, st); }
+  }
+  if (!eager_only && kyb_defer_floor(kyb_defer_mark()) != KYB_OK) return 3;      // the timed run records into an EMPTY arena: no leaf of the warm pass is found again
+  Transcript eager, lazy, batched;
+  Timing te, tl, tb;
+  uint64_t se[8], sl[8] = {0};
   round_once(n, t, false, eager, te, se);
-  round_once(n, t, true, lazy, tl, sl);
   for (const std::string& ln : eager.lines) std::printf("E %s\n", ln.c_str());
+  const double e_all = te.dealer_setup + te.encrypted_deals + te.verify_deals;
+  if (eager_only) {
+    std::printf("TIMING {\"n\": %zu, \"t\": %zu, \"eager_ms\": {\"new_dealer\": %.3f, \"encrypted_deals\": %.3f, \"verify_deals\": %.3f, \"round\": %.3f}}\n",
+                n, t, te.dealer_setup, te.encrypted_deals, te.verify_deals, e_all);
+    kyb_shutdown();
+    return 0;
+  }
+  round_once(n, t, true, lazy, tl, sl);
   for (const std::string& ln : lazy.lines) std::printf("D %s\n", ln.c_str());
-  const double e_all = te.dealer_setup + te.encrypted_deals + te.verify_deals, l_all = tl.dealer_setup + tl.encrypted_deals + tl.verify_deals;
+#ifndef KYB_CPU_PORT
+  { Transcript warm; Timing w; round_batched(n, t, warm, w); }
+  round_batched(n, t, batched, tb);
+  for (const std::string& ln : batched.lines) std::printf("B %s\n", ln.c_str());
+#endif
+  const double l_all = tl.dealer_setup + tl.encrypted_deals + tl.verify_deals, b_all = tb.dealer_setup + tb.encrypted_deals + tb.verify_deals;
   std::printf("TIMING {\"n\": %zu, \"t\": %zu, \"eager_ms\": {\"new_dealer\": %.3f, \"encrypted_deals\": %.3f, \"verify_deals\": %.3f, \"round\": %.3f}, "
-              "\"deferred_ms\": {\"new_dealer\": %.3f, \"encrypted_deals\": %.3f, \"verify_deals\": %.3f, \"round\": %.3f}, \"speedup\": %.2f, "
+              "\"deferred_ms\": {\"new_dealer\": %.3f, \"encrypted_deals\": %.3f, \"verify_deals\": %.3f, \"round\": %.3f}, "
+              "\"batched_ms\": {\"new_dealer\": %.3f, \"encrypted_deals\": %.3f, \"verify_deals\": %.3f, \"round\": %.3f}, \"speedup\": %.2f, "
               "\"deferred_stats\": {\"nodes\": %llu, \"flushes\": %llu, \"engine_calls\": %llu, \"horner_fused\": %llu, \"sums_fused\": %llu, \"marshal_cache_hits\": %llu}, "
               "\"eager_stats_nodes\": %llu}\n",
-              n, t, te.dealer_setup, te.encrypted_deals, te.verify_deals, e_all, tl.dealer_setup, tl.encrypted_deals, tl.verify_deals, l_all, e_all / l_all,
+              n, t, te.dealer_setup, te.encrypted_deals, te.verify_deals, e_all, tl.dealer_setup, tl.encrypted_deals, tl.verify_deals, l_all,
+              tb.dealer_setup, tb.encrypted_deals, tb.verify_deals, b_all, e_all / l_all,
               (unsigned long long)sl[0], (unsigned long long)sl[1], (unsigned long long)sl[2], (unsigned long long)sl[3], (unsigned long long)sl[4], (unsigned long long)sl[5],
               (unsigned long long)se[0]);
   kyb_shutdown();

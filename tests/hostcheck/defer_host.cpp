@@ -42,9 +42,9 @@ struct Ctx {
   bool ready = true;
   int device = 0;
   std::mutex launch_mu;
-  DeferArena* defer = nullptr;
+  std::atomic<DeferArena*> defer{nullptr};
   std::atomic<int> opt_defer_fuse{1};
-  std::atomic<int> opt_defer_max_nodes{1 << 20};
+  std::atomic<int> opt_defer_max_nodes{1 << 18};
 };
 Ctx g_ctx, g_ctx2;
 thread_local Ctx* tl_ctx = &g_ctx;
@@ -54,6 +54,7 @@ int fail(int code, const char* msg) { g_err = msg; return code; }
 std::atomic<long> g_calls{0}, g_items{0};
 }  // namespace
 #define ENTER() Ctx* ctx_ = cur(); Ctx& g = *ctx_
+#define ENTER_HOST() ENTER()
 
 // ---- the batch entry points the evaluator calls, answered by the oracle ----------------------------------------------------------------
 extern "C" {
@@ -250,7 +251,49 @@ int main() {
     uint8_t w[32]; orc_mul_base(w, nullptr, s);
     CHECK(st[6] == 1 && kyb_defer_get(h, nullptr, e) == KYB_OK && memcmp(e, w, 32) == 0, "what was recorded after the mark survives");
     CHECK(kyb_defer_get(0, nullptr, e) == KYB_E_BAD_ARG && kyb_defer_get(h + 1000, nullptr, e) == KYB_E_BAD_ARG, "null / unknown handles");
-    g_ctx.opt_defer_max_nodes = 1 << 20;
+    g_ctx.opt_defer_max_nodes = 1 << 18;
+  }
+  // the arena's storage: headers in chunks of 4,096, payloads in slabs of 256, the leaf table doubling — crossed in every direction
+  {
+    const uint64_t mark0 = kyb_defer_mark();
+    uint64_t st0[8]; kyb_defer_stats(st0, 8);
+    // 1,500 distinct leaves (the table grows 1,024 -> 2,048 -> 4,096), each registered twice: the second time is a hit
+    std::vector<Val> leaves(1500);
+    for (size_t i = 0; i < leaves.size(); ++i) { uint8_t sc[32]; scalar_small(sc, 50000 + (uint32_t)i); orc_mul_base(nullptr, leaves[i].ext, sc); CHECK(kyb_defer_input(leaves[i].ext, &leaves[i].h) == KYB_OK, "leaf"); }
+    for (size_t i = 0; i < leaves.size(); ++i) { uint64_t again = 0; CHECK(kyb_defer_input(leaves[i].ext, &again) == KYB_OK && again == leaves[i].h, "a leaf seen before keeps its handle (table grown meanwhile)"); }
+    // one chain of 9,000 additions over them (three chunks of headers, no payload for the inner sums), asked at the end and in the middle
+    Val acc = leaves[0];
+    std::vector<Val> kept;
+    for (size_t i = 1; i <= 9000; ++i) {
+      const Val& l = leaves[i % leaves.size()];
+      Val nx; orc_add(nx.ext, acc.ext, l.ext, 0);
+      CHECK(kyb_defer_add(acc.h, l.h, 0, &nx.h) == KYB_OK, "long chain");
+      acc = nx;
+      if (i % 2500 == 0) kept.push_back(acc);
+    }
+    uint64_t st1[8]; kyb_defer_stats(st1, 8);
+    CHECK(st1[6] - st0[6] == 1500 + 9000, "nodes held");
+    CHECK(got_enc(kept[1].h) == enc_of(kept[1].ext), "a sum in the middle of the chain, asked first");
+    CHECK(got_enc(acc.h) == enc_of(acc.ext), "the end of the chain");
+    for (const Val& k : kept) CHECK(got_enc(k.h) == enc_of(k.ext), "kept sums");
+    // a floor in the middle of a chunk, then across chunks; handles on either side
+    CHECK(kyb_defer_floor(kept[0].h) == KYB_OK, "floor at a node handle (a mark is a handle)");
+    uint8_t e32[32];
+    CHECK(kyb_defer_get(leaves[7].h, nullptr, e32) == KYB_E_STALE && kyb_defer_get(kept[0].h, nullptr, e32) == KYB_OK, "floor: below dropped, at and above kept");
+    CHECK(got_enc(acc.h) == enc_of(acc.ext), "values above the floor survive it");
+    CHECK(kyb_defer_floor(kyb_defer_mark()) == KYB_OK, "floor at the end");
+    uint64_t st2[8]; kyb_defer_stats(st2, 8);
+    CHECK(st2[6] == 0 && kyb_defer_get(acc.h, nullptr, e32) == KYB_E_STALE, "empty arena");
+    // a small cap across the chunk boundary: 10,000 nodes through a window of 100
+    g_ctx.opt_defer_max_nodes = 100;
+    uint64_t h = 0;
+    uint8_t sc[32];
+    for (uint32_t i = 0; i < 10000; ++i) { scalar_small(sc, 7 + i % 3); CHECK(kyb_defer_mul_base(sc, &h) == KYB_OK, "window"); if (i % 50 == 49) CHECK(kyb_defer_flush() == KYB_OK, "window flush"); }
+    uint8_t w[32]; scalar_small(sc, 7 + 9999 % 3); orc_mul_base(w, nullptr, sc);
+    uint64_t st3[8]; kyb_defer_stats(st3, 8);
+    CHECK(kyb_defer_get(h, nullptr, e32) == KYB_OK && memcmp(e32, w, 32) == 0 && st3[6] == 100 && st3[7] - st2[7] == 9900, "the newest of 10,000 through a window of 100");
+    g_ctx.opt_defer_max_nodes = 1 << 18;
+    (void)mark0;
   }
   // four threads on the one arena
   {
@@ -286,7 +329,7 @@ int main() {
     tl_ctx = &g_ctx;
     scalar_small(s1, 999);
     CHECK(kyb_defer_mul_base(s1, &late) == KYB_OK, "recorded, never asked for");
-    defer_release(g_ctx.defer); g_ctx.defer = nullptr;
+    defer_release(g_ctx.defer.exchange(nullptr));
     tl_ctx = &g_ctx2;
     orc_mul_base(w, nullptr, s1);
     CHECK(kyb_defer_get(late, nullptr, e) == KYB_OK && memcmp(e, w, 32) == 0, "an orphaned arena is evaluated by whoever asks");

@@ -184,7 +184,7 @@ def test_random_graphs_match_the_eager_calls(eng, oracle):
         eng.defer_floor(m)
         assert eng.defer_stats()["nodes_held"] == 1 and eng.defer_get(keep) == oracle.mul_base(_le(7))
     finally:
-        eng.set_option("defer.max_nodes", 1 << 20)
+        eng.set_option("defer.max_nodes", 1 << 18)
 
 
 def test_threads_recording_into_one_arena(eng, oracle):

@@ -13,19 +13,42 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(n, t, prog="test_vss_round"):
+def build(prog, cpu_port=False):
+    """tests/cpp/<prog>.cpp against the engine — or, cpu_port, against tests/cpp/cpu_port_abi.cpp: the oracle behind the same entry points, so that the
+    very same call-by-call sequence runs on one host core (the CPU column of the per-phase tables; test infrastructure, nothing of it ships)"""
     src = os.path.join(ROOT, "tests", "cpp", prog + ".cpp")
-    out = os.path.join(ROOT, "tests", "cpp", "_build", prog)
+    out = os.path.join(ROOT, "tests", "cpp", "_build", prog + ("_cpu_port" if cpu_port else ""))
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    libdir = os.path.join(ROOT, "kyber-rs_amd")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-o", out, src,
-                           "-L", libdir, "-lkyber_ed25519_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
-    r = subprocess.run([out, str(n), str(t)], capture_output=True, text=True, timeout=600)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-o", out, src]
+    if cpu_port:
+        orc = os.path.join(ROOT, "oracle", "_build")
+        cmd += ["-DKYB_CPU_PORT", os.path.join(ROOT, "tests", "cpp", "cpu_port_abi.cpp"), "-L", orc, "-loracle", f"-Wl,-rpath,{orc}"]
+    else:
+        libdir = os.path.join(ROOT, "kyber-rs_amd")
+        cmd += ["-L", libdir, "-lkyber_ed25519_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return out
+
+
+def run_program(out, n, t, mode="all"):
+    r = subprocess.run([out, str(n), str(t), mode], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    eager = [ln[2:] for ln in r.stdout.splitlines() if ln.startswith("E ")]
-    lazy = [ln[2:] for ln in r.stdout.splitlines() if ln.startswith("D ")]
+    lines = {k: [ln[2:] for ln in r.stdout.splitlines() if ln.startswith(k + " ")] for k in "EDB"}
     timing = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("TIMING ")][0][7:])
-    return eager, lazy, timing
+    return lines, timing
+
+
+def _run(n, t, prog="test_vss_round"):
+    lines, timing = run_program(build(prog), n, t)
+    if lines["B"]:
+        assert lines["B"] == lines["E"], "the batch-aware form of the round must produce the bytes of the call-by-call form"
+    return lines["E"], lines["D"], timing
+
+
+def _cpu_port(n, t, prog):
+    """the same program on the CPU port: transcript and wall time per phase of the identical sequence, one host thread"""
+    lines, timing = run_program(build(prog, cpu_port=True), n, t, "eager")
+    return lines["E"], timing["eager_ms"]
 
 
 def _check_against_oracle(lines, n, t, oracle):
@@ -55,7 +78,10 @@ def test_pedersen_dealer_round_call_by_call_eager_and_deferred(oracle):
     eager, lazy, timing = _run(n, t)
     assert eager == lazy and len(eager) > 5 * n                    # the same bytes everywhere the reference looks
     _check_against_oracle(eager, n, t, oracle)
-    print(json.dumps(timing))
+    cpu_lines, timing["cpu_port_ms"] = _cpu_port(n, t, "test_vss_round")
+    assert cpu_lines == eager                                        # the CPU port walks the identical sequence to the identical bytes
+    print("PHASES " + json.dumps(timing))
+    assert timing["batched_ms"]["round"] * 20 <= timing["cpu_port_ms"]["round"], timing      # a batch-aware caller: the whole round in a dozen calls
     st = timing["deferred_stats"]
     assert timing["eager_stats_nodes"] == 0                          # the eager run records nothing
     assert st["horner_fused"] == n + 1                               # every verifier's PubPoly::eval was ONE engine call
@@ -96,7 +122,9 @@ def test_end_of_a_dkg_call_by_call_eager_and_deferred(oracle):
         st = timing["deferred_stats"]
         assert timing["eager_stats_nodes"] == 0
         if n >= 4:
-            print(json.dumps(timing))
+            cpu_lines, timing["cpu_port_ms"] = _cpu_port(n, t, "test_dkg_finish")
+            assert cpu_lines == eager
+            print("PHASES " + json.dumps(timing))
             assert st["sums_fused"] == t + 1                         # t chains of the distributed polynomial, one for recover_commit
             assert st["engine_calls"] <= 8                           # against (n - 1) t + 2 t batch-of-1 calls
             assert timing["deferred_ms"]["dist_key_share"] * 10 <= timing["eager_ms"]["dist_key_share"], timing
