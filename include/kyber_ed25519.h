@@ -457,11 +457,15 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *   finish.batched    1 (default): results stay projective and one inversion serves 8 items (k_finish)
  *   finish.min_items  smallest batch that takes the batched finish / the radix-64, -32 kernels (default 1)
  *   encode.batched    1 (default): kyb_encode_batch shares one inversion between 8 points; 0: one per point
+ *   device.cus        compute units the context's launches are sized for (default 0 = what the device reports).  A host that confines the engine
+ *                     to a CU-masked stream, or runs on a partition whose streams see fewer compute units than the device property says, declares
+ *                     the number here: the hand-over sizes below — kept as wavefronts per compute unit — and the persistent grids follow it.
  *   coop.max_items    batches of at most this many items take the one-item-per-wavefront kernels (variable base, verification,
- *                     polynomial evaluation; default 6144, 0 = never); coop.base_max_items the same for the fixed base and signing
- *                     (default 3328), coop.decode_max_items for a bare decode (default 1024), coop.verify_max_items for the
- *                     kernels that give ONE item several wavefronts (verification in one launch, signing in one launch, the fixed
- *                     base with four wavefronts per item; default 512).  Same results either way.
+ *                     polynomial evaluation; default 24 per compute unit = 6144 on an MI355X, 0 = never); coop.base_max_items the same for the
+ *                     fixed base and signing (13 per compute unit = 3328), coop.decode_max_items for a bare decode (4 per compute unit = 1024),
+ *                     coop.verify_max_items for the kernels that give ONE item several wavefronts (verification in one launch, signing in one
+ *                     launch, the fixed base with four wavefronts per item; 2 per compute unit = 512).  Setting one of them sets an absolute
+ *                     item count (until device.cus is set again).  Same results either way.
  *   coop.share_by_load  1 (default): the coop.* and ladder.pair_max_items thresholds are divided by the number of synchronous host-pointer
  *                     calls this process has in flight on the same GPU (each on its own context): kernels that spend 64 or 2 lanes on an item are for a chip
  *                     that would otherwise idle, not for one that 16 threads share.  0: thresholds as set.  Same results either way.
@@ -470,10 +474,10 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     projective, so that no inversion runs in front (default 128 x compute units = one wavefront per SIMD: 32768 on an MI355X, 0 = never): up to there the
  *                     call time is one lane's chain of 255 steps, and the two-lane form takes 0.49 instead of 0.79 ms.  Same results.  These
  *                     launches always walk 256 bits (minus publicly known zeros): ladder.skip_canonical does not apply to them.
- *   coop.ladder_max_items  variable base and linear combinations leave the one-item-per-wavefront kernels above this many items (default 2816;
+ *   coop.ladder_max_items  variable base and linear combinations leave the one-item-per-wavefront kernels above this many items (default 11 per compute unit = 2816;
  *                     verification with the keys given as points at 7/8 of it) even when coop.max_items would still allow them: from there the
  *                     two-lane ladder is faster.
- *   coop.ladder_enc_max_items  the same for calls from BYTES — kyb_mul_batch with pts_enc (full-length multipliers), kyb_verify_batch: default 2048
+ *   coop.ladder_enc_max_items  the same for calls from BYTES — kyb_mul_batch with pts_enc (full-length multipliers), kyb_verify_batch: default 8 per compute unit = 2048
  *                     (two wavefronts per SIMD); above it the role-split launches of ladder.y_only = 2 are faster.
  *   ladder.skip_canonical  1 (default): the batch ladder starts four bits lower when no scalar of the launch reaches 2^252 — true of a scalar
  *                     reduced mod L (L = 2^252 + 2.8e37) except for 2^-127 of them, so the test (an OR over the batch, taken on the way by the

@@ -86,7 +86,8 @@ constexpr int PIPE_CHUNKS_DEFAULT = 16;     // the first chunk of a pipelined ho
 struct Ctx {
   bool ready = false;
   int device = -1;
-  int cus = 0;
+  int cus = 0;                    // compute units the launches are sized for: hw_cus, or option device.cus
+  int hw_cus = 0;                 // what the device reports
   char name[128] = {0};
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // second compute lane of the pipelined host-pointer path (consecutive chunks alternate: the small kernels of one overlap the ladder of the other)
@@ -128,7 +129,7 @@ struct Ctx {
   std::atomic<int> opt_ladder_waves{3};       // launch bound of k_mul_ladder: waves per SIMD the register allocator must allow
   std::atomic<int> opt_finish{1};             // 0 fused inversion per item, 1 split + batched inversion (n >= finish_min)
   std::atomic<int> opt_finish_min{1};         // batches below it: fused per-item inversion in the radix-16 kernels (slower at every size; cross-check)
-  std::atomic<int> opt_coop_max{6144};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
+  std::atomic<int> opt_coop_max{0};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: the chunk unit is 1/this of the batch (plan_chunks)
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
   std::atomic<int> opt_finish_four{1};           // k_finish with 4 instead of 8 items per shared inversion for launches of at most one wavefront per SIMD
@@ -140,18 +141,18 @@ struct Ctx {
   std::atomic<int> opt_coop_share{1};             // divide the small-batch thresholds by the number of host-pointer calls in flight in this process (coop_lim)
   std::atomic<int> opt_host_inplace{1};           // zero-copy host-pointer calls use page-locked CALLER arrays (kyb_host_alloc) where they lie instead of copying them into the context's buffer
   std::atomic<int> opt_zero_copy_kib{4096};         // host-pointer calls whose arrays fit this many KiB run their kernels on the context's page-locked buffer (no hipMemcpy); 512 in round 2, 4 MiB wins up to 16,384 items (profiles/r03/mid_size_host_calls.log)
-  std::atomic<int> opt_ladder_pair_max{32768};    // ladder launches of at most this many items give each item two lanes (k_mul_ladder_pair: one wavefront per SIMD up to here); 0 = never
-  std::atomic<int> opt_coop_ladder_max{2816};     // variable base from points, linear combinations: above this the two-lane batch ladder is faster than one item per wavefront (3072 until the batch path lost its in-kernel decode wait: profiles/r04/coop_vs_fused.log)
-  std::atomic<int> opt_coop_ladder_enc_max{2048};  // the same for calls from BYTES (multiplication from encodings, verification from key bytes): the role-split launches of ladder.y_only = 2 take over at two wavefronts per SIMD
+  std::atomic<int> opt_ladder_pair_max{0};    // ladder launches of at most this many items give each item two lanes (k_mul_ladder_pair: one wavefront per SIMD up to here); 0 = never
+  std::atomic<int> opt_coop_ladder_max{0};     // variable base from points, linear combinations: above this the two-lane batch ladder is faster than one item per wavefront (3072 until the batch path lost its in-kernel decode wait: profiles/r04/coop_vs_fused.log)
+  std::atomic<int> opt_coop_ladder_enc_max{0};  // the same for calls from BYTES (multiplication from encodings, verification from key bytes): the role-split launches of ladder.y_only = 2 take over at two wavefronts per SIMD
   std::atomic<int> opt_ladder_skip_canonical{1};  // the batch ladder skips the four leading bits when no scalar of the launch has one set (canonical scalars)
   std::atomic<int> opt_mul_short_scalars{0};     // 1: EVERY host-pointer kyb_mul_batch of <= 64 items is treated like kyb_mul_public_batch (multipliers declared public:
                                                  // when all are below 2^64 the ladder skips the leading zeros).  Off by default: the ABI cannot know that a multiplier is public.
   std::atomic<int> opt_poly_batch_segments{0};   // PubPoly::eval, long polynomials at 10^3..10^4 evaluations: lanes per evaluation of the batch kernels (0 = cost model, 1 = never, 2..256)
   std::atomic<int> opt_poly_segments{0};         // PubPoly::eval, small batches: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never split, 2..32)
   std::atomic<int> opt_verify_by_enc{1};         // large verification batches: compare the encoding of s*B - h*A with R's bytes, decode R only on a mismatch
-  std::atomic<int> opt_coop_verify_max{512};     // verification: up to this many signatures take the single-launch kernel (three wavefronts each)
-  std::atomic<int> opt_coop_decode_max{1024};    // unmarshal_binary alone: the same (crossover between 1024 and 2048)
-  std::atomic<int> opt_coop_base_max{3328};      // fixed base: the same (crossover at 13 wavefronts per CU since the batch path's finish shares an inversion between four items: profiles/r04/coop_vs_fused.log; 4096 before; signing counts its two multiplications per item)
+  std::atomic<int> opt_coop_verify_max{0};     // verification: up to this many signatures take the single-launch kernel (three wavefronts each)
+  std::atomic<int> opt_coop_decode_max{0};    // unmarshal_binary alone: the same (crossover between 1024 and 2048)
+  std::atomic<int> opt_coop_base_max{0};      // fixed base: the same (crossover at 13 wavefronts per CU since the batch path's finish shares an inversion between four items: profiles/r04/coop_vs_fused.log; 4096 before; signing counts its two multiplications per item)
   std::atomic<int> opt_encode_batched{1};     // kyb_encode_batch: 1 shared inversion per 8 points (k_encode_batched), 0 one inversion per point (k_encode)
   std::mutex mu;          // host-pointer API: staging buffers + engine streams of this context
   std::mutex launch_mu;   // every launch_* entry: per-stream scratch bookkeeping (calls from any thread, any stream)
@@ -237,6 +238,25 @@ void wipe_free_dev(Ctx& g, void* p, size_t bytes) {
   if (!p) return;
   (void)hipMemset(p, 0, bytes);
   ctx_free(g, p, bytes);
+}
+
+// The hand-over sizes between the kernel families are WAVEFRONTS PER COMPUTE UNIT — where a one-item-per-wavefront kernel has filled the SIMDs as
+// often as it pays — not item counts: measured on 256 CUs (profiles/r02/coop_crossover.log, r04/coop_vs_fused.log, r04/coop_max_probe.log) and kept
+// as per-CU figures, multiplied by the CUs the context works with: the device's, or what the host declares with option device.cus (a CU-masked
+// stream, a partitioned device whose streams see fewer CUs than the property says; profiles/r05/coop_crossover_cu_mask.log).  An explicit
+// kyb_set_option of one of the thresholds still sets an absolute item count.
+constexpr int COOP_MAX_PER_CU = 24, COOP_BASE_MAX_PER_CU = 13, COOP_LADDER_MAX_PER_CU = 11, COOP_LADDER_ENC_MAX_PER_CU = 8, COOP_DECODE_MAX_PER_CU = 4,
+              COOP_VERIFY_MAX_PER_CU = 2, LADDER_PAIR_MAX_PER_CU = 128;      // (128: two lanes per item up to one wavefront per SIMD = 4 SIMDs x 64 lanes / 2)
+void apply_cu_count(Ctx& g, int cus) {
+  g.cus = cus;
+  g.opt_coop_max = COOP_MAX_PER_CU * cus;                       // 6,144 on 256 CUs
+  g.opt_coop_base_max = COOP_BASE_MAX_PER_CU * cus;             // 3,328
+  g.opt_coop_ladder_max = COOP_LADDER_MAX_PER_CU * cus;         // 2,816
+  g.opt_coop_ladder_enc_max = COOP_LADDER_ENC_MAX_PER_CU * cus; // 2,048
+  g.opt_coop_decode_max = COOP_DECODE_MAX_PER_CU * cus;         // 1,024
+  g.opt_coop_verify_max = COOP_VERIFY_MAX_PER_CU * cus;         // 512
+  g.opt_ladder_pair_max = LADDER_PAIR_MAX_PER_CU * cus;         // 32,768
+  g.grid_mul = cus * 2;
 }
 
 int ensure_stage(Ctx& g, size_t bytes) {
@@ -949,8 +969,8 @@ int ctx_new(int device, bool build_table, Ctx** out) {
   Ctx* c = new Ctx();
   Ctx& g = *c;
   g.device = device;
-  g.cus = prop.multiProcessorCount;
-  g.opt_ladder_pair_max = g.cus * 128;               // two lanes per item while that is at most one wavefront per SIMD: 4 SIMDs x 64 lanes / 2 per CU (32,768 on 256 CUs)
+  g.hw_cus = prop.multiProcessorCount;
+  apply_cu_count(g, g.hw_cus);
   snprintf(g.name, sizeof(g.name), "%s", prop.name);
 #define CTXCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ctx_release(c); return fail(KYB_E_HIP, #x, e_); } } while (0)
   CTXCK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
@@ -960,8 +980,7 @@ int ctx_new(int device, bool build_table, Ctx** out) {
   CTXCK(hipMalloc(reinterpret_cast<void**>(&g.table_coop), KYB_COOP_TABLE_WORDS * sizeof(uint32_t)));
   // persistent grids of the windowed kernel: 2 blocks of 256 threads per CU = 2 waves per SIMD (needed to saturate
   // v_mad_u64_u32 issue, profiles/r01_valu_rates_mi355x.jsonl)
-  g.grid_mul = g.cus * 2;
-  g.ws_bytes = (size_t)g.grid_mul * (KYB_BLOCK / 64) * (8 * 10 * 64) * sizeof(uint4);
+  g.ws_bytes = (size_t)(g.hw_cus * 2) * (KYB_BLOCK / 64) * (8 * 10 * 64) * sizeof(uint4);
   if (build_table) {
     CTXCK(launch::build_tables(g.table, g.stream));
     CTXCK(launch::build_coop_table(image64(g), g.table_coop, g.stream));

@@ -288,19 +288,35 @@ def test_projective_extended_results_on_request(oracle):
         eng.close()
 
 
-def test_every_routing_boundary_with_default_options(oracle):
-    """a fresh context with the DEFAULT thresholds: batch sizes on both sides of every routing boundary (multi-wavefront kernels up to
-    256 / 512 / 1,024 items, mul from encodings up to 1,536, cooperative kernels up to 4,096 / 6,144, batch kernels above), all four
-    operations against the oracle"""
+@pytest.mark.parametrize("cus", [0, 64])
+def test_every_routing_boundary_with_default_options(oracle, cus):
+    """a fresh context with the DEFAULT thresholds — wavefronts per compute unit times the compute units the context works with: the device's, and
+    64 declared with option device.cus (a CU-masked stream, a partition) — batch sizes on both sides of every routing boundary the options imply
+    (multi-wavefront kernels, mul from encodings, cooperative kernels, two-lane ladder, batch kernels above), all four operations against the oracle"""
     import kyber_rs_amd
     eng = kyber_rs_amd.Engine(0, private=True)
     try:
-        sizes = (255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1535, 1536, 1537, 2047, 2048, 2049, 4095, 4096, 4097, 6143, 6144, 6145)
+        hw = eng.get_option("device.cus")
+        assert hw == eng.device_info()["compute_units"]
+        if cus:
+            eng.set_option("device.cus", cus)
+        n_cu = cus or hw
+        opt = {k: eng.get_option(k) for k in ("coop.max_items", "coop.base_max_items", "coop.ladder_max_items", "coop.ladder_enc_max_items", "coop.decode_max_items",
+                                              "coop.verify_max_items", "ladder.pair_max_items")}
+        assert opt == {"coop.max_items": 24 * n_cu, "coop.base_max_items": 13 * n_cu, "coop.ladder_max_items": 11 * n_cu, "coop.ladder_enc_max_items": 8 * n_cu,
+                       "coop.decode_max_items": 4 * n_cu, "coop.verify_max_items": 2 * n_cu, "ladder.pair_max_items": 128 * n_cu}, opt      # no absolute item count among the defaults
+        # every size the routing of engine.hip compares a batch with, from these options (x/2, x/4, 2x, 7x/8: the derived comparisons there)
+        marks = set()
+        for v in opt.values():
+            marks |= {v, v // 2, v // 4, 2 * v, 7 * v // 8}
+        marks |= {4 * n_cu}
+        sizes = sorted({n for m in marks for n in (m - 1, m, m + 1) if 1 <= n <= 24 * n_cu + 1 and n <= 6200})
         nmax = max(sizes)
         s = synth.raw256(nmax, 31); s[::7] = synth.scalars(len(s[::7]), 32)
         k = synth.scalars(nmax, 33, b"k")
         pts = oracle.mul_base_ext_batch(synth.scalars(nmax, 34, b"point"))
-        enc = np.stack([np.frombuffer(oracle.encode(p), dtype=np.uint8) for p in pts[:1600]])
+        enc_max = min(nmax, 8 * n_cu + 64)
+        enc = np.stack([np.frombuffer(oracle.encode(p), dtype=np.uint8) for p in pts[:enc_max]])
         msgs = synth.messages(nmax, 35)
         want_base = oracle.mul_base_batch(s, nthreads=8)
         want_mul = oracle.mul_batch(s, pts, nthreads=8)
@@ -312,10 +328,19 @@ def test_every_routing_boundary_with_default_options(oracle):
         for n in sizes:
             assert np.array_equal(eng.mul_base(s[:n]), want_base[:n]), n
             assert np.array_equal(eng.mul(s[:n], pts_ext=pts[:n]), want_mul[:n]), n
-            if n <= 1600:
+            if n <= enc_max:
                 assert np.array_equal(eng.mul(s[:n], pts_enc=enc[:n]), want_mul[:n]), n
             assert np.array_equal(eng.schnorr_sign(x[:n], k[:n], msgs[:n]), want_sig[:n]), n
             assert np.array_equal(eng.verify(pubs[:n], msgs[:n], bad[:n], 1), want_st[:n]), n
+        # the kernel families really change with the declared CU count: 1,000 variable-base items are a one-item-per-wavefront launch on 256 CUs
+        # (11 per CU = 2,816) and a two-lane ladder launch on 64 (704)
+        eng.profile_begin(16)
+        eng.mul(s[:1000], pts_ext=pts[:1000])
+        names = [nm for nm, _ in eng.profile_read(16)]
+        assert ("k_mul_coop" in names) == (1000 <= 11 * n_cu) and ("k_mul_ladder_pair" in names) == (1000 > 11 * n_cu), (n_cu, names)
+        if cus:
+            eng.set_option("device.cus", 0)
+            assert eng.get_option("coop.max_items") == 24 * hw
     finally:
         eng.close()
 
