@@ -79,9 +79,8 @@ WORKLOAD_TEXT = {"mul": "2^20 variable-base scalar-mults, random scalars+points,
 PEAK_MAD_NOMINAL = 1024 * 64 / 4 * 2.4e9
 HBM_PEAK_GBS = 8000.0
 DEFAULT_N = {"mul": 1 << 20, "mul_enc": 1 << 20, "mul_base": 1 << 20, "sign": 1 << 18, "verify": 1 << 20}
-PROFILE_ROUNDS = ("r04", "r03", "r02", "r01")
-OPTION_KEYS = ("mul.algo", "mul.ladder_waves", "mul.select", "mul_base.radix", "mul_base.select", "mul_base.block", "finish.batched", "finish.min_items",
-               "ladder.skip_canonical", "ladder.pair_max_items")
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")
+OPTION_KEYS = ("device.cus", "coop.max_items", "coop.base_max_items", "coop.ladder_max_items", "ladder.skip_canonical", "ladder.pair_max_items")      # (kernel variants are not options of the product library)
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -385,12 +384,12 @@ def roofline(w, eng, steps, peak, clock, cus):
     dom_ms = sum(per_kernel[dom]) / len(per_kernel[dom])                  # average duration of ONE launch
     launches_per_step = len(per_kernel[dom]) / steps
     items_per_launch = n * (2 if wl == "sign" and dom == "k_mul_base" and not keyed else 1) / launches_per_step
-    split = eng.get_option("finish.batched") and n >= eng.get_option("finish.min_items")
+    split = True          # the product library has one fixed-base / finish form: radix 64, projective staging, batched inversion
     dom_products = PRODUCTS_DOMINANT.get(dom, products[wl]) if split else products[wl]
     alg_rate = dom_products * items_per_launch / (dom_ms * 1e-3)
     executed = EXECUTED.get(dom, dom_products)
     if isinstance(executed, dict):
-        executed = executed[eng.get_option("mul_base.radix") if n >= eng.get_option("finish.min_items") else 16]
+        executed = executed[64]
     if dom == "k_mul_ladder" and wl == "verify":
         executed -= 3 * (5 * 100 + 4 * 55 + 10)      # the challenge h is < L < 2^253 by construction: the ladder starts three bits lower
     elif dom == "k_mul_ladder" and eng.get_option("ladder.skip_canonical"):

@@ -442,21 +442,11 @@ int kyb_defer_stats(uint64_t* out, int cap);
 int kyb_point_checks_batch(const uint8_t* enc, const int32_t* pts_ext, size_t n, uint8_t* flags);
 int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_t n, uint8_t* flags, void* stream);
 
-/* ---- introspection for benchmarks / tests ------------------------------------------------------ */
-/* kernel variant selection: key is e.g. "mul.select" / "mul_base.select"; returns
- * KYB_E_BAD_ARG for unknown keys or values.  Defaults are the fastest measured variants.
- *   mul.algo          1 Montgomery ladder + y-recovery (table-free, default), 0 windowed table 1P..8P per lane
- *   mul.ladder_waves  2..4 (default 3): waves per SIMD the ladder kernel's register allocation must allow
- *   mul.select        0 v_cndmask merge, 1 and/or merge of the windowed kernel's table scan
- *   mul.grid_per_cu   1 | 2 workgroups per CU of the windowed kernel (its table workspace is sized for 2)                [mul.algo=0 only]
- *   mul_base.radix    64 (default): 43-window kernel, the table fills a CU's LDS; 32: 52 windows; 16: 64 windows
- *   mul_base.select   0 LDS broadcast scan, 1 ds_bpermute selection                       [radix-16 kernel]
- *   mul_base.block    256 | 512 threads per workgroup                                     [radix-16 kernel]
- *   mul_base.block64  1024 | 512 threads per workgroup of the radix-64 kernel on full batches
- *   mul_base.small_chunks  radix-64 kernel: 256-thread workgroups up to this many chunks per CU (default 2)
- *   finish.batched    1 (default): results stay projective and one inversion serves 8 items (k_finish)
- *   finish.min_items  smallest batch that takes the batched finish / the radix-64, -32 kernels (default 1)
- *   encode.batched    1 (default): kyb_encode_batch shares one inversion between 8 points; 0: one per point
+/* ---- options ------------------------------------------------------------------------------------ */
+/* kyb_set_option / kyb_get_option: deployment knobs of a context — the compute units it works with, the hand-over sizes between the kernel
+ * families (all results are the same on either side of one), timing policy (ladder.skip_canonical, mul.short_scalars), the form of out_ext,
+ * the host-pointer pipeline, the deferred-point arena, test hooks (diag.*).  KYB_E_BAD_ARG for unknown keys or values.  The library ships
+ * ONE kernel per regime: there is no option that selects an algorithm or a kernel variant (see the end of this list).
  *   device.cus        compute units the context's launches are sized for (default 0 = what the device reports).  A host that confines the engine
  *                     to a CU-masked stream, or runs on a partition whose streams see fewer compute units than the device property says, declares
  *                     the number here: the hand-over sizes below — kept as wavefronts per compute unit — and the persistent grids follow it.
@@ -487,27 +477,13 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     behaves like kyb_mul_public_batch (above) — for hosts whose unmodified protocol code cannot say which multipliers are
  *                     public (PubPoly::eval calls Point::mul with x = i + 1): a deployment decision, since a secret below 2^64 (probability
  *                     2^-188 for a uniformly random one) would then be visible in the call's run time.  Same results either way.
- *   poly.batch_segments  kyb_pubpoly_eval*_batch, long polynomials at 10^3..6x10^4 evaluations: the Horner chain of an evaluation is cut into
- *                     this many segments, one per lane, recombined with x^(s len) mod 8L by the variable-base ladder (0 = chosen by a cost
- *                     model from t, the batch size and the bit length of the largest index; 1 = never; 2..256).  Same results either way.
  *   ext.projective    0 (default): out_ext always has Z = 1.  1: a small-batch kyb_mul_batch / kyb_mul_base_batch / kyb_pubpoly_eval*_batch /
  *                     kyb_sum_batch / kyb_lincomb_batch call that asks for out_ext ONLY (out_enc == NULL) gets the point as (X : Y : Z : T) with Z != 1 — what the reference's own Point
  *                     holds after a multiplication — and skips the field inversion (one fixed-base call: 55 -> 27 us); every entry
  *                     point accepts such points, kyb_encode_batch pays the inversion when an encoding is wanted
- *   poly.segments     PubPoly::eval of few evaluations: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never
- *                     split the Horner chain, 2..32)
- *   ladder.y_only     2 (default): launches of at most ladder.pair_max_items items whose points come as 32-byte ENCODINGS (kyb_mul_batch with
- *                     pts_enc, kyb_verify_batch) run the two-lane ladder on the y of the encoding — u = (1 + y) / (1 - y) needs no x — while
- *                     further workgroups of the SAME launch take the square root of the decode (a verification: of the key and of R, and its hash
- *                     moves into the ladder's workgroups); a short kernel joins them.  1: the decode as a kernel of its own on a side stream.
- *                     0: decode first, then the ladder.  Same results.
- *   finish.four       1 (default): the batched encode shares one field inversion between 4 instead of 8 items when a launch leaves at most one
- *                     wavefront per SIMD (shorter dependent chain; full batches keep 8).  Same results.
  *   defer.fuse        1 (default): a flush of deferred points (kyb_defer_*) evaluates Horner chains and chains of additions as ONE call each; 0:
  *                     level by level only.  Same results.
  *   defer.max_nodes   nodes the deferred-point arena keeps before it drops the oldest (default 2^18 = at most 69 MB, at least 16); a dropped handle is refused
- *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder (and, with ladder.y_only, the decode of A)
- *   verify.by_encoding 1 (default): large batches test the equation as enc(s*B - h*A) == R bytes and decode R only on a mismatch
  *   host.in_place     1 (default): a host-pointer call small enough for host.zero_copy_kib (and of at least 64 KiB) whose array lies in memory
  *                     kyb_host_alloc handed out on this context's device (16-byte aligned start) has its kernels read / write that array where it
  *                     lies instead of a copy in the context's buffer (an 8,192-item multiplication: 0.03-0.05 ms less); other page-locked
@@ -518,6 +494,36 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *   host.pipe_chunks  host-pointer batches of 2^16 items or more are pipelined (one copy-in lane, two compute lanes, one copy-out lane)
  *                     over chunks of 1 1 2 4 4 2 2 .. units; the unit is 1/value of the batch (default 16, 2..64)
  *   host.copy_threads host threads that move pageable batches through the bounce buffers (0 = auto)
+ * CROSS-CHECK BUILD ONLY — libkyber_ed25519_hip_crosscheck.so (csrc/Makefile CROSSCHECK=1; test infrastructure, tests/conftest.py `xengine`): the
+ * same sources plus the alternative kernels (windowed variable base, radix-16 / -32 fixed base, fused signing, other register budgets and
+ * launch shapes) and the selectors below, so that the tests can compare every variant with the product's kernel and with the oracle.  The
+ * product library answers KYB_E_BAD_ARG ("unknown option") to each of them and contains none of those kernels.
+ *   mul.algo          1 Montgomery ladder + y-recovery (table-free, default), 0 windowed table 1P..8P per lane
+ *   mul.ladder_waves  2..4 (default 3): waves per SIMD the ladder kernel's register allocation must allow
+ *   mul.select        0 v_cndmask merge, 1 and/or merge of the windowed kernel's table scan
+ *   mul.grid_per_cu   1 | 2 workgroups per CU of the windowed kernel (its table workspace is sized for 2)                [mul.algo=0 only]
+ *   mul_base.radix    64 (default): 43-window kernel, the table fills a CU's LDS; 32: 52 windows; 16: 64 windows
+ *   mul_base.select   0 LDS broadcast scan, 1 ds_bpermute selection                       [radix-16 kernel]
+ *   mul_base.block    256 | 512 threads per workgroup                                     [radix-16 kernel]
+ *   mul_base.block64  1024 | 512 threads per workgroup of the radix-64 kernel on full batches
+ *   mul_base.small_chunks  radix-64 kernel: 256-thread workgroups up to this many chunks per CU (default 2)
+ *   finish.batched    1 (default): results stay projective and one inversion serves 8 items (k_finish)
+ *   finish.min_items  smallest batch that takes the batched finish / the radix-64, -32 kernels (default 1)
+ *   encode.batched    1 (default): kyb_encode_batch shares one inversion between 8 points; 0: one per point
+ *   poly.batch_segments  kyb_pubpoly_eval*_batch, long polynomials at 10^3..6x10^4 evaluations: the Horner chain of an evaluation is cut into
+ *                     this many segments, one per lane, recombined with x^(s len) mod 8L by the variable-base ladder (0 = chosen by a cost
+ *                     model from t, the batch size and the bit length of the largest index; 1 = never; 2..256).  Same results either way.
+ *   poly.segments     PubPoly::eval of few evaluations: wavefronts per evaluation (0 = chosen from t and the batch size, 1 = never
+ *                     split the Horner chain, 2..32)
+ *   ladder.y_only     2 (default): launches of at most ladder.pair_max_items items whose points come as 32-byte ENCODINGS (kyb_mul_batch with
+ *                     pts_enc, kyb_verify_batch) run the two-lane ladder on the y of the encoding — u = (1 + y) / (1 - y) needs no x — while
+ *                     further workgroups of the SAME launch take the square root of the decode (a verification: of the key and of R, and its hash
+ *                     moves into the ladder's workgroups); a short kernel joins them.  1: the decode as a kernel of its own on a side stream.
+ *                     0: decode first, then the ladder.  Same results.
+ *   finish.four       1 (default): the batched encode shares one field inversion between 4 instead of 8 items when a launch leaves at most one
+ *                     wavefront per SIMD (shorter dependent chain; full batches keep 8).  Same results.
+ *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder (and, with ladder.y_only, the decode of A)
+ *   verify.by_encoding 1 (default): large batches test the equation as enc(s*B - h*A) == R bytes and decode R only on a mismatch
  * Options belong to the calling thread's context. */
 int kyb_set_option(const char* key, int value);
 int kyb_get_option(const char* key, int* value);

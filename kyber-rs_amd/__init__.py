@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import Optional, Sequence
 
 import numpy as np
@@ -20,6 +21,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libkyber_ed25519_hip.so"
 LIB_PATH = os.environ.get("KYB_HIP_LIB") or os.path.join(_HERE, LIB_NAME)   # KYB_HIP_LIB: A/B builds of the same ABI
+# the cross-check build (csrc/Makefile CROSSCHECK=1): the same ABI plus the alternative kernels and the options that select them — for the
+# tests that compare the product's kernels with them; the product library has neither
+CROSSCHECK_LIB_PATH = os.path.join(_HERE, "libkyber_ed25519_hip_crosscheck.so")
 BASE_TABLE_BYTES = 335232
 ABI_VERSION = 2
 
@@ -70,13 +74,18 @@ class KyberHipError(RuntimeError):
 
 
 _lib = None
+_xlib = None
 
 
-def load_library() -> ctypes.CDLL:
-    """dlopen the in-tree HIP library; never falls back to anything else."""
-    global _lib
-    if _lib is not None:
+def load_library(crosscheck: bool = False) -> ctypes.CDLL:
+    """dlopen the in-tree HIP library; never falls back to anything else.  crosscheck: the cross-check build instead (a second library in the
+    process, RTLD_LOCAL: its contexts, options and error text are its own)."""
+    global _lib, _xlib
+    if not crosscheck and _lib is not None:
         return _lib
+    if crosscheck and _xlib is not None:
+        return _xlib
+    path = CROSSCHECK_LIB_PATH if crosscheck else LIB_PATH
     try:
         # torch bundles its own libamdhip64.so.7 / libhsa-runtime64 (and librccl); whichever HIP runtime is loaded
         # first owns the GPU for the process, so when torch is going to share device memory with the
@@ -87,11 +96,11 @@ def load_library() -> ctypes.CDLL:
             import torch  # noqa: F401
     except ImportError:
         pass
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise KyberHipError(
-            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+            f"{path} is missing: build it with `python __graft_entry__.py build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for this engine.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     lib.kyb_init.argtypes = [i32]
     lib.kyb_init_no_table.argtypes = [i32]
@@ -208,14 +217,21 @@ def load_library() -> ctypes.CDLL:
                         "kyb_group_destroy", "kyb_group_ctx", "kyb_group_table_transport", "kyb_group_table_transport_note", "kyb_defer_mark"):
             getattr(lib, name).restype = i32
     if lib.kyb_abi_version() != ABI_VERSION:
-        raise KyberHipError(f"{LIB_PATH} implements ABI version {lib.kyb_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
-    _lib = lib
+        raise KyberHipError(f"{path} implements ABI version {lib.kyb_abi_version()}, this binding expects {ABI_VERSION}: rebuild it")
+    if crosscheck:
+        _xlib = lib
+    else:
+        _lib = lib
     return lib
+
+
+_last_lib = threading.local()      # the library the calling thread's last engine call went to: whose kyb_last_error explains a failure
 
 
 def _check(rc: int, what: str) -> None:
     if rc != KYB_OK:
-        msg = load_library().kyb_last_error().decode(errors="replace")
+        lib = getattr(_last_lib, "lib", None) or load_library()
+        msg = lib.kyb_last_error().decode(errors="replace")
         raise KyberHipError(f"{what} failed: {ERRORS.get(rc, rc)}: {msg}")
 
 
@@ -290,6 +306,7 @@ class _CtxLib:
         lib, ctx = self._lib, self._ctx
 
         def call(*args):
+            _last_lib.lib = lib
             lib.kyb_ctx_set_current(ctx)
             return fn(*args)
         return call
@@ -300,8 +317,10 @@ class Engine:
     GPU, bench.py); Engine(device, private=True) is an additional context of its own (kyb_ctx_create) — several may live
     in one process, on the same or on different GPUs."""
 
-    def __init__(self, device: int = 0, build_table: bool = True, private: bool = False, _ctx=None):
-        lib = load_library()
+    def __init__(self, device: int = 0, build_table: bool = True, private: bool = False, _ctx=None, crosscheck: bool = False):
+        lib = load_library(crosscheck)
+        self._raw = lib
+        _last_lib.lib = lib
         self.device = device
         self.ctx = None
         if _ctx is not None:                 # a context owned by a Group
@@ -320,7 +339,7 @@ class Engine:
     def close(self) -> None:
         """destroy a private context (the default one goes with shutdown())"""
         if self.ctx is not None and getattr(self, "_owned", False):
-            raw = load_library()
+            raw = self._raw
             raw.kyb_ctx_set_current(None)
             _check(raw.kyb_ctx_destroy(ctypes.c_void_p(self.ctx)), "kyb_ctx_destroy")
             self.ctx = None

@@ -1274,10 +1274,14 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
                               g.opt_ext_projective != 0));
     return KYB_OK;
   }
-  if (g.opt_mul_algo == 1) {
+#ifdef KYB_CROSSCHECK
+  if (g.opt_mul_algo == 1)
+#endif
+  {
     int rc = launch_ladder_core(g, sc, penc, pext, n, ok, r, st); if (rc) return rc;
     return launch_finish(g, r, n, oenc, oext, st, 1, true);
   }
+#ifdef KYB_CROSSCHECK      // mul.algo = 0: the windowed-table kernel (ge.rs structure), kept as a cross-check of the ladder
   { int rc = ensure_ws(g, r); if (rc) return rc; }
   const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
   const int grid = (int)(nchunks < (size_t)g.grid_mul ? nchunks : (size_t)g.grid_mul);
@@ -1289,6 +1293,7 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
   }
   if (split) return launch_finish(g, r, n, oenc, oext, st, 1, true);
   return KYB_OK;
+#endif
 }
 
 // fixed-base multiplication of n scalars; split leaves the points in r->proj at [offset, offset + n)
@@ -1315,6 +1320,9 @@ int launch_base(Ctx& g, bool split, const uint8_t* sc, size_t n, uint8_t* oenc, 
     LAUNCHCK(launch::mul_base64(split, block, grid64, st, sc, sc_b, n_a, n, oenc, oext, img64, r->proj, r->proj_items, offset));
     return KYB_OK;
   }
+#ifndef KYB_CROSSCHECK
+  return fail(KYB_E_BAD_ARG, "fixed base: only the radix-64 kernel is part of this build");      // unreachable: the options that lead here exist in the cross-check build only
+#else
   if (radix == 32 && n >= (size_t)finish_min) {
     const uint4* img32 = reinterpret_cast<const uint4*>(g.table + KYB_BASE_TABLE_WORDS);
     const size_t nchunks32 = (n + KYB_BLOCK32 - 1) / KYB_BLOCK32;
@@ -1331,6 +1339,7 @@ int launch_base(Ctx& g, bool split, const uint8_t* sc, size_t n, uint8_t* oenc, 
   ProfScope ps(g, st, KID_MUL_BASE);
   LAUNCHCK(launch::mul_base16(g.opt_base_select, block, split, grid, st, sc, n, oenc, oext, img, r->proj, r->proj_items, offset));
   return KYB_OK;
+#endif
 }
 int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st) {
   if (n == 0) return KYB_OK;
@@ -1447,6 +1456,9 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
     if (pub_out != nullptr) HIPCK(hipMemcpyAsync(pub_out, r->enc + 32 * n, 32 * n, hipMemcpyDeviceToDevice, st));
     return KYB_OK;
   }
+#ifndef KYB_CROSSCHECK
+  return fail(KYB_E_BAD_ARG, "signing: only the split form is part of this build");      // unreachable: finish.batched = 0 exists in the cross-check build only
+#else
   const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
   const size_t cap = (size_t)g.cus * 2;
   const int grid = (int)(nchunks < cap ? nchunks : cap);
@@ -1457,6 +1469,7 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
   }
   if (pub_out != nullptr) return launch_base(g, false, x, n, pub_out, nullptr, r, 0, st);
   return KYB_OK;
+#endif
 }
 int launch_sign(Ctx& g, const uint8_t* x, const uint8_t* k, const uint8_t* pub_in, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* sig, hipStream_t st) {
   if (n == 0) return KYB_OK;
@@ -1636,14 +1649,18 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   } else if (r_role) {
     ProfScope ps(g, st, KID_MUL_LADDER_PAIR);
     LAUNCHCK(launch::mul_ladder_pair_r(st, hbuf, n, a_ext, r->proj, r->proj_items, 3, sigs, flags_r, 2 * n));      // h < L < 2^253
-  } else if (g.opt_mul_algo == 1) {
-    rc = launch_ladder_core(g, hbuf, nullptr, a_ext, n, nullptr, r, st, 0, 3); if (rc) return rc;      // h < L < 2^253
-  } else {
+  }
+#ifdef KYB_CROSSCHECK
+  else if (g.opt_mul_algo != 1) {
     rc = ensure_ws(g, r); if (rc) return rc;
     const size_t nchunks = (n + KYB_BLOCK - 1) / KYB_BLOCK;
     const int grid = (int)(nchunks < (size_t)g.grid_mul ? nchunks : (size_t)g.grid_mul);
     ProfScope ps(g, st, KID_MUL);
     LAUNCHCK(launch::mul_window(g.opt_mul_select, false, true, grid, st, hbuf, nullptr, a_ext, n, nullptr, nullptr, nullptr, r->ws, r->proj, r->proj_items));
+  }
+#endif
+  else {
+    rc = launch_ladder_core(g, hbuf, nullptr, a_ext, n, nullptr, r, st, 0, 3); if (rc) return rc;      // h < L < 2^253
   }
   if (fork) HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
   else if (coop) { ProfScope ps(g, st, KID_MUL_BASE_COOP); LAUNCHCK(launch::mul_base_coop(st, sbuf, n, nullptr, nullptr, coop_table(g), r->proj, r->proj_items, n)); }

@@ -128,8 +128,19 @@ hipError_t table_checksum(const uint32_t* table, uint64_t* out_dev, hipStream_t 
 hipError_t mul_base64(bool split, int block, int grid, hipStream_t st, const uint8_t* sc, const uint8_t* sc_b, size_t n_a, size_t n,
                       uint8_t* oenc, int32_t* oext, const uint4* img64, uint4* proj, size_t stride, size_t offset) {
 #define KYB_L(S_, B_) hipLaunchKernelGGL((k_mul_base64<S_, B_>), dim3(grid), dim3(B_), 0, st, sc, sc_b, n_a, n, oenc, oext, img64, proj, stride, offset)
-  if (split) { if (block == 256) KYB_L(true, 256); else if (block == 512) KYB_L(true, 512); else if (block == 768) KYB_L(true, 768); else KYB_L(true, 1024); }
-  else       { if (block == 256) KYB_L(false, 256); else if (block == 512) KYB_L(false, 512); else if (block == 768) KYB_L(false, 768); else KYB_L(false, 1024); }
+#ifdef KYB_CROSSCHECK      // mul_base.block64 = 512 / 768 (2 / 3 wavefronts per SIMD): cross-check build only
+  if (block == 512) { if (split) KYB_L(true, 512); else KYB_L(false, 512); return hipGetLastError(); }
+  if (block == 768) { if (split) KYB_L(true, 768); else KYB_L(false, 768); return hipGetLastError(); }
+#endif
+  if (!split) {        // finish.batched = 0 (an inversion per item inside the kernel): cross-check build only
+#ifdef KYB_CROSSCHECK
+    if (block == 256) KYB_L(false, 256); else KYB_L(false, 1024);
+    return hipGetLastError();
+#else
+    return hipErrorInvalidValue;
+#endif
+  }
+  if (block == 256) KYB_L(true, 256); else KYB_L(true, 1024);
 #undef KYB_L
   return hipGetLastError();
 }

@@ -411,9 +411,12 @@ hipError_t mont_prep(hipStream_t st, const int32_t* pext, size_t n, uint4* proj,
 }
 hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, uint4* proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits,
                       const uint32_t* top_or, uint32_t* zero_next) {
-  if (waves >= 4)      hipLaunchKernelGGL((k_mul_ladder<4>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits, top_or, zero_next);
-  else if (waves == 3) hipLaunchKernelGGL((k_mul_ladder<3>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits, top_or, zero_next);
-  else                 hipLaunchKernelGGL((k_mul_ladder<2>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits, top_or, zero_next);
+#ifdef KYB_CROSSCHECK      // mul.ladder_waves: the 4- and 2-wavefronts-per-SIMD register budgets (both slower: profiles/r02) exist in the cross-check build only
+  if (waves >= 4)      { hipLaunchKernelGGL((k_mul_ladder<4>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits, top_or, zero_next); return hipGetLastError(); }
+  else if (waves == 2) { hipLaunchKernelGGL((k_mul_ladder<2>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits, top_or, zero_next); return hipGetLastError(); }
+#endif
+  (void)waves;
+  hipLaunchKernelGGL((k_mul_ladder<3>), dim3(blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, proj, stride, img_offset, img_mod, skip_bits, top_or, zero_next);
   return hipGetLastError();
 }
 hipError_t mul_ladder_pair(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, size_t pts_mod, uint4* proj, size_t stride, int skip_bits) {

@@ -77,3 +77,43 @@ def test_every_engine_option_is_documented_in_the_header():
     mentioned = set(re.findall(r"\b([a-z_]+\.[a-z_0-9]+)\b", hdr))
     assert not (keys - mentioned), f"options without a word in the header: {sorted(keys - mentioned)}"
     assert not {k for k in listed if k not in keys and not k.endswith(".h") and not k.endswith(".rs")}, "the header lists an option the engine does not know"
+
+
+VARIANT_OPTIONS = ("mul.select", "mul_base.select", "mul.algo", "mul.ladder_waves", "mul_base.radix", "mul_base.block", "mul_base.block64", "mul_base.small_chunks",
+                   "finish.batched", "finish.min_items", "encode.batched", "finish.four", "ladder.y_only", "verify.by_encoding", "verify.overlap", "mul.grid_per_cu",
+                   "poly.segments", "poly.batch_segments")
+
+
+def test_the_product_library_has_one_kernel_per_regime_and_no_variant_selectors():
+    """round-4 review item 7: ~35 routing / variant knobs and the A/B leftover kernels shipped in the product ABI.  Now: the selectors of kernel
+    and algorithm variants are parsed inside `#ifdef KYB_CROSSCHECK` only; the product library's code objects do not contain the alternative
+    kernels (windowed variable base, radix-16 / -32 fixed base, fused signing, 2- / 4-wave ladder budgets, 512- / 768-thread fixed base), the
+    cross-check library — same ABI, test infrastructure — does."""
+    import re
+    import subprocess
+    src = open(os.path.join(ROOT, "kyber-rs_amd", "csrc", "c_abi.inc")).read()
+    product = re.sub(r"#ifdef KYB_CROSSCHECK.*?#endif", "", src, flags=re.S)
+    for key in VARIANT_OPTIONS:
+        assert f'"{key}"' in src and f'"{key}"' not in product, key
+    kept = set(re.findall(r'strcmp\(key, "([a-z_0-9.]+)"\)', product))
+    assert kept == {"device.cus", "coop.max_items", "coop.base_max_items", "coop.decode_max_items", "coop.verify_max_items", "coop.ladder_max_items",
+                    "coop.ladder_enc_max_items", "coop.share_by_load", "ladder.pair_max_items", "ladder.skip_canonical", "mul.short_scalars", "ext.projective",
+                    "host.in_place", "host.zero_copy_kib", "host.pipe_chunks", "host.copy_threads", "defer.fuse", "defer.max_nodes",
+                    "diag.fail_alloc_after", "diag.fail_launch_after", "diag.dev_kib", "diag.host_kib"}, sorted(kept)
+    libdir = os.path.join(ROOT, "kyber-rs_amd")
+    names = {}
+    for lib in ("libkyber_ed25519_hip.so", "libkyber_ed25519_hip_crosscheck.so"):
+        path = os.path.join(libdir, lib)
+        if not os.path.exists(path):
+            import pytest
+            pytest.skip(f"{lib} not built")
+        out = subprocess.run(["strings", "-n", "8", path], capture_output=True, text=True).stdout
+        names[lib] = set(re.findall(r"_Z\d+k_\w+", out))
+    prod, cross = names["libkyber_ed25519_hip.so"], names["libkyber_ed25519_hip_crosscheck.so"]
+    only_cross = {n for n in cross - prod}
+    assert prod <= cross and only_cross, "the cross-check build is the product plus the variants"
+    joined = " ".join(sorted(only_cross))
+    for marker in ("k_mul_base32", "_Z10k_mul_baseI", "_Z6k_signI", "12k_mul_ladderILi2E", "12k_mul_ladderILi4E", "k_mul_base64ILb1ELi512E", "k_mul_base64ILb1ELi768E"):
+        assert marker in joined, (marker, joined[:600])
+    assert not any(("k_mul_base32" in n or "_Z10k_mul_baseI" in n or "_Z6k_signI" in n or "k_mul_ladderILi2E" in n or "ELi768E" in n) for n in prod)
+    assert any("5k_mulI" in n or "_Z5k_mul" in n for n in only_cross), "the windowed variable-base kernel"

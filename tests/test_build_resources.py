@@ -16,8 +16,23 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 @pytest.fixture(scope="module")
 def rows():
+    """every kernel of the CROSS-CHECK build (the product's kernels plus the variants: -DKYB_CROSSCHECK)"""
     import kernel_resources
-    return {r["kernel"]: r for r in kernel_resources.collect()}
+    return {r["kernel"]: r for r in kernel_resources.collect(["-DKYB_CROSSCHECK"])}
+
+
+@pytest.fixture(scope="module")
+def product_rows():
+    """the kernels of the product build: the translation units of csrc/Makefile without CROSSCHECK=1"""
+    import kernel_resources
+    return {r["kernel"]: r for r in kernel_resources.collect([], units=kernel_resources.PRODUCT_UNITS)}
+
+
+def test_nothing_in_the_product_library_spills_except_the_table_builders(product_rows):
+    spilling = {k: r["scratch"] for k, r in product_rows.items() if r["scratch"]}
+    assert all(k.startswith(("_Z12k_base_tablePj", "_Z14k_base_table32Pj", "_Z14k_base_table64Pj")) for k in spilling), spilling
+    assert not any(k.startswith(("_Z5k_mulI", "_Z10k_mul_baseI", "_Z12k_mul_base32", "_Z6k_signI", "_Z12k_mul_ladderILi2E", "_Z12k_mul_ladderILi4E", "_Z12k_mul_base64ILb0E"))
+                   for k in product_rows), "a variant kernel is compiled into the product"
 
 
 def _find(rows, prefix):

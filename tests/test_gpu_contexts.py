@@ -186,7 +186,8 @@ def test_hundred_short_lived_streams(engine, oracle):
             outs = []
 
 
-def test_set_option_and_profiling_race_with_launches(engine, oracle):
+def test_set_option_and_profiling_race_with_launches(xengine, oracle):
+    engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
     n = 2048
     s = synth.scalars(n, 61)
     want = oracle.mul_base_batch(s, nthreads=8)
@@ -222,7 +223,8 @@ def test_set_option_and_profiling_race_with_launches(engine, oracle):
     assert not errors, errors
 
 
-def test_encode_batched_matches_per_item_encode(engine, oracle):
+def test_encode_batched_matches_per_item_encode(xengine, oracle):
+    engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
     """kyb_encode_batch with one shared inversion per 8 points == per-point inversion == the oracle, incl. Z = 0 garbage
     (the reference's 0^(p-2) = 0 answer) isolated from its neighbours, ragged sizes"""
     for n in (1, 7, 8, 9, 1000, 4099):

@@ -25,6 +25,18 @@ def coop_engine(engine):
         engine.set_option(k, v)
 
 
+@pytest.fixture()
+def coop_xengine(xengine):
+    """the same on the cross-check build, for the tests that also switch kernel variants"""
+    keys = ("coop.max_items", "coop.base_max_items", "coop.ladder_max_items", "coop.ladder_enc_max_items")
+    old = [xengine.get_option(k) for k in keys]
+    for k in keys:
+        xengine.set_option(k, 1 << 20)
+    yield xengine
+    for k, v in zip(keys, old):
+        xengine.set_option(k, v)
+
+
 def test_coop_fixed_base_matches_oracle(coop_engine, oracle):
     eng = coop_engine
     q = KATS["quirk_mul_base"]
@@ -68,7 +80,8 @@ def test_coop_variable_base_matches_oracle(coop_engine, oracle):
     assert np.array_equal(eng.mul(s, pts_ext=b), oracle.mul_batch(s, b, nthreads=8))
 
 
-def test_coop_decode_sign_verify_match_oracle(coop_engine, oracle):
+def test_coop_decode_sign_verify_match_oracle(coop_xengine, oracle):
+    coop_engine = coop_xengine
     """the small-batch forms of unmarshal_binary (cooperative square-root chain), Schnorr signing and both verification
     flavours (cooperative decodes of A and R, both multiplications projective into the final comparison): weak keys, invalid
     and non-canonical encodings, every reject reason, the 1024 golden EdDSA lines"""
@@ -136,7 +149,8 @@ def test_coop_decode_sign_verify_match_oracle(coop_engine, oracle):
     assert eng.verify(u8(ps[:3]), ms[:3], np.frombuffer(bytes(bad[:192]), dtype=np.uint8), 0).tolist() == [9, 0, 0]
 
 
-def test_coop_pubpoly_eval_matches_oracle(coop_engine, oracle):
+def test_coop_pubpoly_eval_matches_oracle(coop_xengine, oracle):
+    coop_engine = coop_xengine
     """PubPoly::eval one evaluation per wavefront (cooperative doubling / addition): indices of every bit length up to 2^32 - 2,
     commitments with small-order components and the neutral element among them, the many-polynomials form"""
     eng = coop_engine

@@ -33,7 +33,8 @@ def rand_points_ext(oracle, n, seed):
 
 
 @pytest.mark.parametrize("select", [0, 1])
-def test_mul_base_matches_oracle(engine, oracle, select):
+def test_mul_base_matches_oracle(xengine, oracle, select):
+    engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
     """the radix-16 kernel (64 x 8 table), both selection variants, fused and split finish; then the default kernel"""
     s = np.concatenate([synth.scalars(1500, 1), synth.raw256(549, 1)])
     want = oracle.mul_base_batch(s, nthreads=8)
@@ -53,7 +54,8 @@ def test_mul_base_matches_oracle(engine, oracle, select):
 
 
 @pytest.mark.parametrize("select", [0, 1])
-def test_mul_matches_oracle(engine, oracle, select):
+def test_mul_matches_oracle(xengine, oracle, select):
+    engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
     """the windowed-table kernel (mul.algo=0), both merge variants"""
     engine.set_option("mul.algo", 0)
     engine.set_option("mul.select", select)
@@ -177,7 +179,8 @@ def test_point_checks_stand_alone(engine, oracle):
     assert engine.lib.kyb_point_checks_batch(arr.ctypes.data, exts.ctypes.data, 1, flags.ctypes.data) < 0      # both
 
 
-def test_sign_random_and_golden(engine, oracle):
+def test_sign_random_and_golden(xengine, oracle):
+    engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
     n = 300
     x, k = synth.scalars(n, 6, b"x"), synth.scalars(n, 6, b"k")
     msgs = synth.messages(n, 6)
@@ -278,7 +281,8 @@ def test_base_table_matches_oracle(engine, oracle):
 
 
 @pytest.mark.parametrize("block", [256, 512])
-def test_split_finish_and_block_variants(engine, oracle, block):
+def test_split_finish_and_block_variants(xengine, oracle, block):
+    engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
     """batched-inversion finish (Montgomery trick over 8 items per lane) and the 512-thread fixed-base
     kernel give the same bytes as the fused path / the oracle, including ragged tails"""
     engine.set_option("finish.min_items", 1)
@@ -309,7 +313,8 @@ def test_split_finish_and_block_variants(engine, oracle, block):
         engine.set_option("mul_base.radix", 64)
 
 
-def test_split_finish_isolates_degenerate_z(engine, oracle):
+def test_split_finish_isolates_degenerate_z(xengine, oracle):
+    engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
     """an invalid extended input whose result has Z = 0 must not disturb the items that share its
     batched inversion, and must give the same bytes as the per-item path"""
     n = 64
@@ -338,7 +343,8 @@ def test_split_finish_isolates_degenerate_z(engine, oracle):
     assert np.array_equal(c[good], want[good])
 
 
-def test_verify_matches_oracle(engine, oracle):
+def test_verify_matches_oracle(xengine, oracle):
+    engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
     """kyb_verify_batch: every status code of eddsa::/schnorr::verify_with_checks, both check orders,
     on golden signatures, the reference's negative vectors and corrupted inputs"""
     from test_device_source_on_host import verify_cases
@@ -436,7 +442,8 @@ def test_pubpoly_eval_and_equal(engine, oracle):
 
 
 @pytest.mark.parametrize("waves", [2, 4])
-def test_ladder_path_matches_oracle(engine, oracle, waves):
+def test_ladder_path_matches_oracle(xengine, oracle, waves):
+    engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
     """mul.algo=1 (Montgomery ladder + y-recovery, no per-lane table): same bytes as the oracle on quirk
     vectors, mixed-order points, scalars around multiples of L, encoded inputs incl. invalid ones, ragged sizes"""
     engine.set_option("mul.algo", 1)
@@ -483,7 +490,8 @@ def test_ladder_path_matches_oracle(engine, oracle, waves):
         engine.set_option("mul.ladder_waves", 3)
 
 
-def test_two_lane_ladder_matches_one_lane_and_oracle(engine, oracle):
+def test_two_lane_ladder_matches_one_lane_and_oracle(xengine, oracle):
+    engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
     """k_mul_ladder_pair (two lanes per item, ge_ladder_pair.h; launches of at most ladder.pair_max_items items) == k_mul_ladder == the oracle:
     quirk vectors, mixed-order points, scalars around multiples of L, canonical-only batches (252 steps) and batches with one unreduced
     scalar (256), invalid encodings, ragged and odd sizes, shared operands (linear combinations) and the h*A of a verification"""
@@ -562,7 +570,8 @@ def test_two_lane_ladder_matches_one_lane_and_oracle(engine, oracle):
             engine.set_option(k, v)
 
 
-def test_fixed_base_radix32_kernel(engine, oracle):
+def test_fixed_base_radix32_kernel(xengine, oracle):
+    engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
     """the 43-window radix-64 kernel (1024-thread workgroups, the whole 160 KiB LDS as table) == the 52-window radix-32
     kernel (104 KiB table) == the radix-16 kernel == oracle, through mul_base, sign and verify; quirk scalars included"""
     engine.set_option("finish.min_items", 1)       # route even small batches through it
@@ -963,7 +972,8 @@ def test_large_pageable_input_of_an_unchunked_call(engine, oracle):
     assert np.array_equal(engine.sum_points(pp), want)
 
 
-def test_bad_arguments_are_rejected(engine, oracle):
+def test_bad_arguments_are_rejected(xengine, oracle):
+    engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
     """error behaviour of the C ABI (INTEGRATION.md §3): a bad call returns a negative code with a message and
     leaves the engine usable; nothing is written on error"""
     import ctypes
@@ -1244,7 +1254,8 @@ def _skip_canonical_cases(engine, oracle, n, s, pts, want):
 
 
 @pytest.mark.parametrize("block64", [512, 768, 1024])
-def test_fixed_base_workgroup_sizes_and_wave_chunks(engine, oracle, block64):
+def test_fixed_base_workgroup_sizes_and_wave_chunks(xengine, oracle, block64):
+    engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
     """k_mul_base64 deals its items out per wavefront (chunks of 64, low wave numbers take the leftovers): every workgroup size gives the
     oracle's bytes on batches that end inside a chunk, inside a workgroup round and on a round boundary, and when signing puts two scalar
     arrays into one launch (the chunk that straddles them)."""

@@ -29,10 +29,11 @@ def _commits(oracle, m, t, seed):
 
 
 @pytest.fixture
-def eng(engine):
-    yield engine
-    engine.set_option("poly.batch_segments", 0)
-    engine.set_option("poly.segments", 0)
+def eng(xengine):
+    """the shapes are forced through poly.segments / poly.batch_segments: selectors of the cross-check build (the product chooses by its cost model)"""
+    yield xengine
+    xengine.set_option("poly.batch_segments", 0)
+    xengine.set_option("poly.segments", 0)
 
 
 @pytest.mark.parametrize("m,t,k", [(3, 29, 2), (40, 50, 1), (1, 97, 33), (260, 12, 1)])

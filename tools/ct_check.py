@@ -228,7 +228,8 @@ def unit_asm(unit):
     with tempfile.NamedTemporaryFile(suffix=".s", delete=False) as f:
         out = f.name
     src = unit if unit.endswith(".hip") else os.path.join(CSRC, unit + ".hip")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src]
+    # -DKYB_CROSSCHECK: the product's kernels AND the variants of the cross-check build (same sources: the product's kernels are compiled identically)
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DKYB_CROSSCHECK", "-S", "--cuda-device-only", "-o", out, src]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"{unit}: {r.stderr[-2000:]}")

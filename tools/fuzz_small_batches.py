@@ -2,7 +2,10 @@
 boundary, random option settings (projective hand-over, polynomial segments, single-/multi-wavefront kernels forced on and off),
 inputs with quirk scalars, small-order / mixed-order / invalid points and corrupted signatures.
 
-  python tools/fuzz_small_batches.py [seconds] [seed]
+  python tools/fuzz_small_batches.py [seconds] [seed] [product | crosscheck]
+
+product (default): the library that ships, with ITS options (hand-over sizes, projective hand-over, two-lane ladder on / off);
+crosscheck: the cross-check build with the kernel-variant selectors in the mix as well (ladder.y_only, finish.four, poly.segments, ...).
 
 Prints one summary line; exits non-zero at the first mismatch (with the case that produced it)."""
 import os
@@ -22,8 +25,9 @@ import synth
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+CROSSCHECK = len(sys.argv) > 3 and sys.argv[3] == "crosscheck"
 rng = np.random.default_rng(seed)
-eng = kyber_rs_amd.Engine(0)
+eng = kyber_rs_amd.Engine(0, crosscheck=CROSSCHECK)
 orc = oracle_lib.Oracle()
 KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "kats.json")))
 weak = [orc.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
@@ -62,11 +66,13 @@ COMMITS = POOL_P[:200].copy()
 
 
 def set_random_options():
-    o = {"ext.projective": int(rng.integers(0, 2)), "poly.segments": int(rng.choice([0, 0, 1, 2, 5, 32])), "poly.batch_segments": int(rng.choice([0, 0, 1, 1, 2, 3, 16, 200])),
-         "coop.verify_max_items": int(rng.choice([512, 512, 0, 4096])), "verify.by_encoding": int(rng.integers(0, 2)),
-         "verify.overlap": int(rng.integers(0, 2)), "ladder.pair_max_items": int(rng.choice([32768, 32768, 0, 1 << 20])),
-         "coop.ladder_max_items": int(rng.choice([2816, 2816, 1 << 20, 700])), "coop.ladder_enc_max_items": int(rng.choice([2048, 2048, 1 << 20, 700])),
-         "ladder.y_only": int(rng.integers(0, 3)), "finish.four": int(rng.integers(0, 2))}
+    o = {"ext.projective": int(rng.integers(0, 2)),
+         "coop.verify_max_items": int(rng.choice([512, 512, 0, 4096])), "ladder.pair_max_items": int(rng.choice([32768, 32768, 0, 1 << 20])),
+         "coop.ladder_max_items": int(rng.choice([2816, 2816, 1 << 20, 700])), "coop.ladder_enc_max_items": int(rng.choice([2048, 2048, 1 << 20, 700]))}
+    variants = {"poly.segments": int(rng.choice([0, 0, 1, 2, 5, 32])), "poly.batch_segments": int(rng.choice([0, 0, 1, 1, 2, 3, 16, 200])),
+                "verify.by_encoding": int(rng.integers(0, 2)), "verify.overlap": int(rng.integers(0, 2)), "ladder.y_only": int(rng.integers(0, 3)), "finish.four": int(rng.integers(0, 2))}
+    if CROSSCHECK:          # (drawn in either mode: the same seed walks the same cases on both libraries)
+        o.update(variants)
     if rng.integers(0, 4) == 0:              # the batch kernels of DKG-sized calls at these sizes (two-lane ladder, ladder.y_only, finish.four)
         o["coop.max_items"], o["coop.base_max_items"] = 0, 0
         o["coop.verify_max_items"] = int(rng.choice([0, 0, 512]))

@@ -11,7 +11,8 @@ import argparse, concurrent.futures, json, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "kyber-rs_amd", "csrc")
-UNITS = ["kernels_base", "kernels_base_alt", "kernels_ladder", "kernels_window", "kernels_verify", "kernels_misc", "kernels_msm", "kernels_coop"]
+UNITS = ["kernels_base", "kernels_base_alt", "kernels_ladder", "kernels_window", "kernels_verify", "kernels_misc", "kernels_msm", "kernels_coop"]      # cross-check build (with -DKYB_CROSSCHECK)
+PRODUCT_UNITS = ["kernels_base", "kernels_ladder", "kernels_verify", "kernels_misc", "kernels_msm", "kernels_coop"]                                # csrc/Makefile without CROSSCHECK=1
 
 
 def unit_asm(unit, flags):
@@ -45,12 +46,13 @@ def parse(txt, unit):
     return rows
 
 
-def collect(flags=()):
+def collect(flags=(), units=None):
     flags = list(flags)
+    units = list(units if units is not None else UNITS)
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        texts = list(ex.map(lambda u: unit_asm(u, flags), UNITS))
+        texts = list(ex.map(lambda u: unit_asm(u, flags), units))
     rows = []
-    for u, t in zip(UNITS, texts):
+    for u, t in zip(units, texts):
         rows += parse(t, u)
     return rows
 
@@ -59,8 +61,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flags", default="")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--product", action="store_true", help="the product library's units and flags (default: the cross-check superset needs --flags -DKYB_CROSSCHECK)")
     a = ap.parse_args()
-    rows = collect(a.flags.split())
+    rows = collect(a.flags.split(), PRODUCT_UNITS if a.product else None)
     print(f"{'kernel':<64} {'vgpr':>5} {'sgpr':>5} {'lds':>7} {'scratch':>8} {'occ':>4}")
     for r in rows:
         print(f"{r['kernel'][:64]:<64} {r['vgpr']:>5} {r['sgpr']:>5} {r['lds']:>7} {r['scratch']:>8} {str(r['occupancy']):>4}")
