@@ -696,9 +696,18 @@ def protocol_phases(n=64, t=43):
     try:
         rounds = importlib.import_module("test_gpu_vss_round")
         out = {"n": n, "t": t, "unit": "ms per phase", "cpu_port": "the C restatement of the reference algorithm (oracle/) behind the same ABI, one thread"}
+        out["repeats"] = "best of 3 runs per program and phase (host-side latencies: a busy host core shows at once)"
         for prog in ("test_vss_round", "test_dkg_finish"):
-            lines, timing = rounds.run_program(rounds.build(prog), n, t)
-            cpu_lines, cpu = rounds.run_program(rounds.build(prog, cpu_port=True), n, t, "eager")
+            gpu_bin, cpu_bin = rounds.build(prog), rounds.build(prog, cpu_port=True)
+            lines, timing = rounds.run_program(gpu_bin, n, t)
+            cpu_lines, cpu = rounds.run_program(cpu_bin, n, t, "eager")
+            for _ in range(2):
+                _l, t2 = rounds.run_program(gpu_bin, n, t)
+                _c, c2 = rounds.run_program(cpu_bin, n, t, "eager")
+                for form in ("eager_ms", "deferred_ms", "batched_ms"):
+                    if form in timing:
+                        timing[form] = {ph: min(ms, t2[form][ph]) for ph, ms in timing[form].items()}
+                cpu["eager_ms"] = {ph: min(ms, c2["eager_ms"][ph]) for ph, ms in cpu["eager_ms"].items()}
             same = lines["E"] == lines["D"] == cpu_lines["E"] and (not lines["B"] or lines["B"] == lines["E"])
             phases = {}
             for ph, ms in cpu["eager_ms"].items():

@@ -49,3 +49,7 @@ with open(os.path.join(dst, name + ".md"), "w") as f:
     for k in keys:
         f.write(f"| {k} | " + " | ".join((f"{res[w]['derived'][k]:.4g}" if isinstance(res[w]['derived'][k], float) else str(res[w]['derived'][k])) for w in res) + " |\n")
 print(open(os.path.join(dst, name + ".md")).read())
+os.makedirs("gpurun_out/profiles_" + rnd, exist_ok=True)
+import shutil
+for ext in (".md", ".json"):
+    shutil.copyfile(os.path.join(dst, name + ext), os.path.join("gpurun_out/profiles_" + rnd, name + ext))
