@@ -124,3 +124,24 @@ def test_the_symbol_comparison_with_the_cpp_mirror_catches_a_second_code_path():
         bad = []
         chk.one_code_path(bad, rust_text=point.replace(old, new))
         assert bad and any(what in b for b in bad), (what, bad)
+
+
+def test_the_call_site_check_catches_a_wrong_arity_and_a_missing_declaration(tmp_path, monkeypatch):
+    """tools/check_rust_shim.py part 4 on a doctored copy of the module: one argument dropped from a call, one call of an undeclared entry point"""
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_rust_shim as chk
+    bad = []
+    calls, declared = chk.ffi_call_sites(bad)
+    assert not bad and calls >= 25 and declared >= 50
+    copy = tmp_path / "edwards25519_hip"
+    shutil.copytree(SHIM, copy)
+    point = (copy / "point.rs").read_text()
+    assert "ffi::kyb_defer_get(self.pend, out.as_mut_ptr() as *mut i32, std::ptr::null_mut())" in point
+    point = point.replace("ffi::kyb_defer_get(self.pend, out.as_mut_ptr() as *mut i32, std::ptr::null_mut())", "ffi::kyb_defer_get(self.pend, out.as_mut_ptr() as *mut i32)")
+    point = point.replace("ffi::kyb_defer_mark()", "ffi::kyb_defer_marker()")
+    (copy / "point.rs").write_text(point)
+    monkeypatch.setattr(chk, "SHIM", str(copy))
+    bad = []
+    chk.ffi_call_sites(bad)
+    assert any("kyb_defer_get is called with 2 arguments" in b for b in bad) and any("kyb_defer_marker" in b for b in bad), bad

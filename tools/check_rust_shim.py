@@ -17,6 +17,10 @@ container only — the GPU box has no /root/reference and the test that calls th
    name reaches (host/edwards25519.hpp, which the GPU tests drive), and nothing in the module names the reference's CPU point or its
    `ge.rs` formulas.  (This part needs no reference and also runs where /root/reference is absent.)
 
+4. Call sites: every `ffi::kyb_*(..)` call passes as many arguments as ffi.rs declares (whose types tests/test_rust_shim.py compares with the
+   header), pointer parameters get pointer-shaped arguments, and the brackets of every file balance — the little a text check can do for
+   source no compiler has seen.
+
   python tools/check_rust_shim.py [--reference /root/reference] [--markdown]
 """
 import argparse
@@ -210,6 +214,62 @@ def one_code_path(bad, markdown=False, rust_text=None, cpp_text=None):
     return rows
 
 
+def _split_top(argtext):
+    """top-level comma-separated pieces of an argument list (nested (), [], {}, <> of turbofish kept together)"""
+    parts, depth, cur = [], 0, ""
+    for ch in argtext:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        parts.append(cur)
+    return [x.strip() for x in parts]
+
+
+def ffi_call_sites(bad):
+    """4. the module has never met a compiler: every `ffi::kyb_*(..)` call in point.rs / mod.rs must at least pass as many arguments as ffi.rs
+    declares for that function, every function called must be declared, pointer arguments must be pointer-shaped (`.as_ptr()`, `.as_mut_ptr()`,
+    `ptr::null*()`, `&mut x`, a `*const`/`*mut` cast) and braces / parentheses of every file must balance."""
+    ffi = re.sub(r"//.*", "", open(os.path.join(SHIM, "ffi.rs")).read())
+    block = ffi[ffi.index('extern "C" {'):]
+    block = block[:block.index("\n}")]
+    decl = {}
+    for m in re.finditer(r"pub fn (kyb_\w+)\s*\(([^)]*)\)", block, flags=re.S):
+        decl[m.group(1)] = [a.split(":", 1)[1].strip() for a in _split_top(m.group(2)) if ":" in a]
+    calls = 0
+    for fname in sorted(f for f in os.listdir(SHIM) if f.endswith(".rs")):
+        text = re.sub(r"//.*", "", open(os.path.join(SHIM, fname)).read())
+        for opener, closer in ("()", "[]", "{}"):
+            if text.count(opener) != text.count(closer):
+                bad.append(f"{fname}: {text.count(opener)} `{opener}` against {text.count(closer)} `{closer}`")
+        if fname == "ffi.rs":
+            continue
+        for m in re.finditer(r"\bffi::(kyb_\w+)\s*\(", text):
+            name, k, depth = m.group(1), m.end(), 1
+            while k < len(text) and depth:
+                depth += text[k] == "("
+                depth -= text[k] == ")"
+                k += 1
+            args = _split_top(text[m.end():k - 1])
+            calls += 1
+            if name not in decl:
+                bad.append(f"{fname}: calls ffi::{name}, which ffi.rs does not declare")
+                continue
+            if len(args) != len(decl[name]):
+                bad.append(f"{fname}: ffi::{name} is called with {len(args)} arguments, ffi.rs declares {len(decl[name])}")
+                continue
+            for a, ty in zip(args, decl[name]):
+                ptr_arg = bool(re.search(r"as_ptr\(\)|as_mut_ptr\(\)|null\(\)|null_mut\(\)|^&mut |as \*(const|mut) |ext_mut\(\)", a))
+                if ty.startswith("*") != ptr_arg and not (ty.startswith("*") and re.fullmatch(r"\w+", a)):
+                    bad.append(f"{fname}: ffi::{name}: argument `{a[:40]}` against parameter type `{ty}`")
+    return calls, len(decl)
+
+
 def similarity(shim_text, ref_text):
     a, b = strip(shim_text), strip(ref_text)
     if len(a) < 8:                        # a three-line mod.rs shares `mod point;` with anybody's
@@ -228,6 +288,8 @@ def main():
     bad, rows = [], []
     surface = one_code_path(bad, a.markdown)
     print(f"one code path: {len(surface)} trait methods compared with the C++ mirror, symbol set by symbol set")
+    calls, declared = ffi_call_sites(bad)
+    print(f"ffi call sites: {calls} calls of {declared} declared entry points checked for arity and pointer shape")
     if not os.path.isdir(ref_dir):
         for b in bad:
             print("MISMATCH:", b)
