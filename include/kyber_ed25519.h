@@ -16,7 +16,9 @@
  *              (fe.rs:67-122) yields for the canonical coordinate value: signed, centred,
  *              |even limb| <= 2^25, |odd limb| <= 2^24 — inside the reference's fe_mul/fe_add input
  *              bounds, so a returned point can be fed straight back into the CPU arithmetic.
- *   return     0 = ok; negative = KYB_E_* (nothing is written on error except where noted).
+ *   return     0 = ok; negative = KYB_E_* (nothing is written on error except where noted; a call that fails after it has queued part of
+ *              its kernels — a device allocation or a launch refused half way — waits for the device before it returns, leaves the
+ *              contents of its OUTPUT arrays undefined and the context usable: the next call gives the ordinary results).
  *   threading  every call may be made from any thread.  Calls act on the calling thread's CONTEXT (kyb_ctx_set_current;
  *              default = the context kyb_init made) and make that context's device current first.  Host-pointer calls
  *              on one context are serialised on its own streams (use one context per concurrent caller, or per GPU);

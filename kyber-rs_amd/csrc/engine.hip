@@ -344,6 +344,13 @@ uint8_t* pinned_dev_ptr(const Ctx& g, const void* p, size_t bytes) {
 // Two caller arrays of one call that are both used where they lie must not share bytes when one of them is written: staged arrays were
 // copied apart (in-place updates like out_ext == pts_ext worked), the kernels' __restrict__ pointers and shared-inversion lanes do not
 // allow it in place.  An overlapping INPUT is then staged as before the in-place path existed.
+// a device-pointer entry point whose launch sequence failed part of the way: what it queued (on the caller's stream, on side streams of the
+// slot) is waited for before the error is returned — the per-stream scratch is then free for the next call, and no kernel of the failed call
+// writes into the caller's arrays after the caller has seen the error (their contents are undefined, include/kyber_ed25519.h)
+inline int drained(int rc) {
+  if (rc != KYB_OK) (void)hipDeviceSynchronize();
+  return rc;
+}
 inline bool host_ranges_overlap(const void* a, size_t na, const void* b, size_t nb) {
   const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
   return a != nullptr && b != nullptr && na != 0 && nb != 0 && x < y + nb && y < x + na;
@@ -607,9 +614,9 @@ int run_host_batch(Ctx& g, size_t n, const HostArr* arrs, int na, Fn launch) {
       DoneScope ds;
       rc = launch(g.stream, n, dptr);
       tl_done = nullptr;
-      if (rc) { (void)hipStreamSynchronize(g.stream); return rc; }
+      if (rc) { (void)hipDeviceSynchronize(); return rc; }      // a failed launch sequence may have forked work onto a side stream: nothing of it is left in flight
       rc = wait_done(g, ds.req);
-      if (rc) { (void)hipStreamSynchronize(g.stream); return rc; }
+      if (rc) { (void)hipDeviceSynchronize(); return rc; }      // a failed launch sequence may have forked work onto a side stream: nothing of it is left in flight
     }
     for (int k = 0; k < na; ++k)
       if (arrs[k].out && staged[k]) memcpy(arrs[k].out, g.pin[0] + off[k], arrs[k].bytes * n);
@@ -717,9 +724,9 @@ class HostCall {
         DoneScope ds;
         rc = body(g.stream);
         tl_done = nullptr;
-        if (rc) { (void)hipStreamSynchronize(g.stream); return rc; }
+        if (rc) { (void)hipDeviceSynchronize(); return rc; }      // a failed launch sequence may have forked work onto a side stream: nothing of it is left in flight
         rc = wait_done(g, ds.req);
-        if (rc) { (void)hipStreamSynchronize(g.stream); return rc; }
+        if (rc) { (void)hipDeviceSynchronize(); return rc; }      // a failed launch sequence may have forked work onto a side stream: nothing of it is left in flight
       }
       for (int i = 0; i < n_; ++i)
         if (a_[i].dst && a_[i].bytes && !a_[i].own) memcpy(a_[i].dst, base_ + a_[i].off, a_[i].bytes);
