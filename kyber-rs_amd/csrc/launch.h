@@ -1,10 +1,10 @@
-// Host-callable launchers of every kernel group.  The library is built from nine translation units that hipcc
-// compiles in parallel (csrc/Makefile):
+// Host-callable launchers of every kernel group.  The library is built from seven translation units that hipcc
+// compiles in parallel (csrc/Makefile); the CROSS-CHECK build (CROSSCHECK=1, -DKYB_CROSSCHECK: test infrastructure) adds two:
 //
-//   kernels_base.hip      fixed base: table builders, table checksum, k_mul_base64 (the default fixed-base kernel)
-//   kernels_base_alt.hip  radix-32 / radix-16 fixed-base kernels and the fused k_sign (selectable cross-checks)
+//   kernels_base.hip      fixed base: table builders, table checksum, k_mul_base64 (the fixed-base kernel)
 //   kernels_ladder.hip    variable base: k_decode_or_identity, k_decode_to_proj, k_mont_prep, k_mul_ladder, k_pair_sum, k_ext_to_proj
-//   kernels_window.hip    windowed variable-base k_mul (mul.algo=0, cross-check of the ladder)
+//   [kernels_base_alt.hip  cross-check build only: radix-32 / radix-16 fixed-base kernels and the fused k_sign]
+//   [kernels_window.hip    cross-check build only: windowed variable-base k_mul (mul.algo=0)]
 //   kernels_verify.hip    SHA-512 users: k_verify_prep / _r / _final, k_sign_hash, k_eddsa_prep
 //   kernels_misc.hip      k_finish, k_encode_batched, k_add, k_equal, k_encode, k_decode, k_poly_eval, k_poly_eval_part
 //   kernels_msm.hip       linear combinations over shared points with PUBLIC scalars: k_msm_tables, k_msm_accumulate (+ k_msm_bases_coop in kernels_coop.hip)
