@@ -1,7 +1,8 @@
 // One Pedersen-VSS dealer round, restated CALL BY CALL against the C++ mirror of the trait surface — the curve-side calls of
 //   new_dealer                 /root/reference src/share/vss/pedersen/vss.rs:287-337   (d_pubb, PriPoly::commit, session_id's marshals)
 //   PriPoly::commit            src/share/poly.rs:195-206                                 (t times mul(coeff, Some(base)))
-//   Dealer::encrypted_deal     vss.rs:361-386 for every verifier (:390-398)              (mul(dh_secret, None), marshal, schnorr::sign, dh_exchange, marshal)
+//   Dealer::encrypted_deal     vss.rs:361-386 for every verifier (:390-398)              (mul(dh_secret, None), marshal, schnorr::sign — itself trait
+//                                                                                         calls: schnorr_sig.rs:25-47 —, dh_exchange, marshal)
 //   Verifier::verify_deal      vss.rs:904-909 for every verifier                         (base().mul(fi.v, None), PubPoly::eval(fi.i), eq)
 //   PubPoly::eval              poly.rs:457-469                                           (v = null; t times { v = mul(xi, Some(v)); v = add(v, commits[j]) })
 // exactly as unmodified protocol code makes them: one trait call at a time, results looked at where the reference looks at them
@@ -83,6 +84,31 @@ static Point pubpoly_eval(const std::vector<Point>& commits, size_t i) {
   return v;
 }
 
+// schnorr::sign as unmodified code runs it, schnorr_sig.rs:25-47 + hash :128-141, trait call by trait call: k = pick, R = mul(k, None),
+// public = mul(private, None), h = SHA-512(R.marshal || public.marshal || msg) as a scalar, s = k + private * h, out = R || s.  (The mirror's
+// schnorr::sign is ONE engine call, kyb_schnorr_sign_batch — what a batch-aware caller uses, and what round_batched below uses: the two must
+// give the same 64 bytes.)  In deferred mode the two multiplications are recorded and evaluated together when the hash marshals R.
+static std::vector<uint8_t> schnorr_sign_by_trait(Stream& rand, const Scalar& priv, const uint8_t* msg, size_t n) {
+  Scalar k = Scalar().pick(rand);
+  Point r = Point().mul(k, nullptr);
+  Point pub = Point().mul(priv, nullptr);
+  std::vector<uint8_t> rb = r.marshal_binary(), pb = pub.marshal_binary();
+  kyb::sha512_ctx c;
+  kyb::sha512_init(c);
+  kyb::sha512_bytes(c, rb.data(), 32);
+  kyb::sha512_bytes(c, pb.data(), 32);
+  if (n) kyb::sha512_bytes(c, msg, (uint32_t)n);
+  uint32_t dw[16];
+  kyb::sha512_final(dw, c);                      // the digest as 16 little-endian words = its 64 bytes on this host
+  uint8_t dig[64];
+  std::memcpy(dig, dw, 64);
+  Scalar h = Scalar().set_bytes(dig, 64);
+  Scalar sc = k + priv * h;
+  std::vector<uint8_t> sig = rb, sb = sc.marshal_binary();
+  sig.insert(sig.end(), sb.begin(), sb.end());
+  return sig;
+}
+
 struct Transcript { std::vector<std::string> lines; void put(const char* tag, const std::vector<uint8_t>& b) { lines.push_back(std::string(tag) + " " + hex(b)); } };
 
 struct Timing { double dealer_setup = 0, encrypted_deals = 0, verify_deals = 0; };
@@ -124,7 +150,7 @@ static void round_once(size_t n, size_t t, bool deferred_mode, Transcript& tr, T
     Scalar dh_secret = Scalar().pick(rand);
     Point dh_public = Point().mul(dh_secret, nullptr);
     std::vector<uint8_t> dh_public_buff = dh_public.marshal_binary();
-    std::vector<uint8_t> signature = sign::schnorr::sign(rand, longterm, dh_public_buff.data(), dh_public_buff.size());
+    std::vector<uint8_t> signature = schnorr_sign_by_trait(rand, longterm, dh_public_buff.data(), dh_public_buff.size());
     Point pre = dh::dh_exchange(dh_secret, verifiers[i]);
     std::vector<uint8_t> pre_buff = pre.marshal_binary();              // AEAD::new -> hkdf over the marshalled shared point
     tr.put("DHSECRET", std::vector<uint8_t>(dh_secret.v.begin(), dh_secret.v.end()));
