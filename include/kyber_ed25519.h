@@ -31,11 +31,15 @@
  *              program: this library never touches the environment; a host that issues one-item calls from many threads sets
  *              GPU_MAX_HW_QUEUES=16 before its first HIP call (16 threads: 16k -> 72k variable-base calls/s).
  *   timing     The instruction stream, the LDS / memory addresses and the launch geometry of every kernel are independent of scalar
- *              VALUES, with two documented exceptions, both launch SHAPES chosen from a public property of a whole batch:
+ *              VALUES, with documented exceptions, each a shape chosen from a PUBLIC property:
  *                ladder.skip_canonical (default 1): a launch whose scalars are ALL below 2^252 walks 252 bits instead of 256 — "is
  *                  reduced mod L", which holds for every scalar kyber-rs's Scalar type produces; set the option to 0 for 256 always;
  *                kyb_mul_public_batch / mul.short_scalars (default 0): multipliers DECLARED public by the caller skip their common
  *                  leading zero bits when all are below 2^64.  kyb_mul_batch itself never does.
+ *              A third shape depends on how a POINT is written, never on what it is: kyb_encode_batch (and what marshals through it:
+ *                  kyb_point_checks_batch on limbs) of at most four points per compute unit skips the field inversion for a point whose Z
+ *                  limbs are literally (1, 0, ..., 0) — what unmarshal_binary yields and what this library returns unless ext.projective is
+ *                  set; a projective result has that Z with probability 2^-255.
  *              tools/ct_check.py checks the claim on the compiled kernels (no branch on, and no address from, scalar words).
  *   memory     the caller owns every buffer; the library keeps no pointer after return.
  *   aliasing   host-pointer calls: an output array may be (or overlap) an input array of the same call — an in-place update such as

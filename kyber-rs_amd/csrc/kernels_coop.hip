@@ -52,7 +52,7 @@ __device__ __forceinline__ void coop_affine(const lane_consts& c, cq q, fe& x, f
 // has_t: row 3 of q already holds T = X Y / Z.
 __device__ __forceinline__ void coop_finish(const lane_consts& c, cq q, uint32_t negate_x,
                                             uint8_t* out_enc, int32_t* out_ext, size_t i, uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0,
-                                            bool ext_proj = false, bool has_t = false) {
+                                            bool ext_proj = false, bool has_t = false, bool z_is_one = false) {
   if (ext_proj && out_enc == nullptr && out_ext != nullptr && proj == nullptr) {
     if (!has_t) {                                                        // (X : Y : Z) -> (X Z : Y Z : Z^2 : X Y)
       const cq zz = bperm(rowperm_idx(c, 2, 2, 2, 2), q), xy = bperm(rowperm_idx(c, 0, 1, 2, 0), q), yy = bperm(rowperm_idx(c, 1, 1, 1, 1), q);
@@ -76,7 +76,8 @@ __device__ __forceinline__ void coop_finish(const lane_consts& c, cq q, uint32_t
     return;
   }
   fe x, y;
-  coop_affine(c, q, x, y);
+  if (z_is_one) { fe_from_quad_row(c, x, q, 0); fe_from_quad_row(c, y, q, 1); }      // (wave-uniform: see k_finish_coop)
+  else coop_affine(c, q, x, y);
   if (out_enc != nullptr) {
     uint32_t w[8];
     fe_to_words(w, y);
@@ -638,15 +639,23 @@ k_finish_coop(const uint4* __restrict__ proj, size_t stride, const int32_t* __re
   if (i >= n) return;
   KYB_COOP_CONSTS(c, 1);
   cq q;
+  // A point handed over as limbs whose Z is LITERALLY one — (1, 0, ..., 0): what unmarshal_binary produces and what every entry point of this
+  // library returns unless ext.projective is set — is affine already: marshal_binary is then a reduction of X and Y, no inversion (38 -> 11 us
+  // for a lone point: the n marshals of the verifier keys in new_dealer, vss.rs:1075-1100).  The test looks at how the point is REPRESENTED,
+  // which the caller's own call history decides; a projective result (a product the engine left with Z != 1) has Z = 1 with probability
+  // 2^-255, so the branch tells an observer nothing about the point (include/kyber_ed25519.h, "timing").
+  bool z_is_one = false;
   if (pts_ext != nullptr) {
     const uint32_t word = c.active ? (uint32_t)pts_ext[40 * i + 10 * c.row + c.k] : 0u;
     q = cnorm(c, c.active ? word + (c.p2 << 3) : 0u);
+    const bool lane_ok = c.row != 2u || !c.active || word == (c.k == 0u ? 1u : 0u);
+    z_is_one = __builtin_amdgcn_ballot_w64(lane_ok) == ~0ull;
   } else {
     const uint32_t w = 10u * (c.row < 3 ? c.row : 0u) + (c.active ? c.k : 0u);
     const uint32_t v = reinterpret_cast<const uint32_t*>(proj)[((size_t)(w >> 2) * stride + i * src_mul) * 4 + (w & 3u)];
     q = (c.active && c.row < 3) ? v : 0u;                                // staging records hold tight limbs
   }
-  coop_finish(c, q, 0u, out_enc, out_ext, i, nullptr, 0, 0, ext_proj != 0, false);
+  coop_finish(c, q, 0u, out_enc, out_ext, i, nullptr, 0, 0, ext_proj != 0, false, z_is_one);
   if (c.lane == 0) signal_done(df);
 }
 

@@ -499,3 +499,24 @@ def test_short_public_scalars_take_a_short_ladder(engine, oracle):
         assert np.array_equal(engine.encode(ext), want)
     finally:
         engine.set_option("ext.projective", 0)
+
+
+def test_encode_of_few_points_with_and_without_a_literal_z_of_one(engine, oracle):
+    """kyb_encode_batch on a handful of points (one point per wavefront, k_finish_coop): points whose Z is literally (1, 0, ..., 0) skip the
+    inversion, everything else — projective Z, Z = 0, and a Z that IS one but not written as the literal (1 + p in limbs) — takes it; every
+    encoding against the oracle, limbs out as well"""
+    n = 24
+    aff = oracle.mul_base_ext_batch(synth.scalars(n, 611))                     # the oracle's multiplication leaves Z != 1
+    enc = np.stack([np.frombuffer(oracle.encode(p), dtype=np.uint8) for p in aff])
+    dec = np.stack([oracle.decode(bytes(e))[0] for e in enc])                   # decoded: Z literally one
+    assert (dec[:, 20] == 1).all() and not dec[:, 21:30].any() and (aff[:, 20:30] != dec[:, 20:30]).any()
+    odd = dec.copy()
+    p_limbs = np.array([0x3ffffed, 0x1ffffff, 0x3ffffff, 0x1ffffff, 0x3ffffff, 0x1ffffff, 0x3ffffff, 0x1ffffff, 0x3ffffff, 0x1ffffff], dtype=np.int64)
+    odd[:, 20:30] = (odd[:, 20:30].astype(np.int64) + p_limbs).astype(np.int32)      # Z = 1 + p: one, but not the literal
+    zero_z = dec[:3].copy(); zero_z[:, 20:30] = 0                                # Z = 0: the reference's 0^(p-2) = 0 -> encoding of (0, 0)
+    mixed = np.concatenate([dec[:8], aff[8:16], odd[16:]])
+    for pts in (dec, aff, odd, mixed, zero_z, dec[:1], aff[:1]):
+        want = np.stack([np.frombuffer(oracle.encode(p), dtype=np.uint8) for p in pts])
+        assert np.array_equal(engine.encode(pts), want)
+    # has_small_order / point checks marshal through the same kernel
+    assert np.array_equal(engine.point_checks(pts_ext=dec), engine.point_checks(enc=enc))
