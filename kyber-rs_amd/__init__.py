@@ -228,9 +228,9 @@ def load_library(crosscheck: bool = False) -> ctypes.CDLL:
 _last_lib = threading.local()      # the library the calling thread's last engine call went to: whose kyb_last_error explains a failure
 
 
-def _check(rc: int, what: str) -> None:
+def _check(rc: int, what: str, lib=None) -> None:
     if rc != KYB_OK:
-        lib = getattr(_last_lib, "lib", None) or load_library()
+        lib = lib or getattr(_last_lib, "lib", None) or load_library()
         msg = lib.kyb_last_error().decode(errors="replace")
         raise KyberHipError(f"{what} failed: {ERRORS.get(rc, rc)}: {msg}")
 
@@ -830,7 +830,7 @@ class Group:
         self.lib = load_library()
         arr = (ctypes.c_int * len(devices))(*devices)
         h = ctypes.c_void_p()
-        _check(self.lib.kyb_group_create_ex(arr, len(devices), ctypes.c_uint(flags), ctypes.byref(h)), "kyb_group_create_ex")
+        _check(self.lib.kyb_group_create_ex(arr, len(devices), ctypes.c_uint(flags), ctypes.byref(h)), "kyb_group_create_ex", self.lib)
         self.handle = h
         self.size = self.lib.kyb_group_size(h)
         self.transport = self.lib.kyb_group_table_transport(h).decode()
@@ -856,20 +856,20 @@ class Group:
         """kyb_group_mul_batch_dev: device-resident shards, asynchronous on every rank's own stream (sync() waits)"""
         n = (ctypes.c_size_t * self.size)(*[t.numel() // 32 for t in scalars])
         _check(self.lib.kyb_group_mul_batch_dev(self.handle, self._ptr_array(scalars), self._ptr_array(pts_enc), self._ptr_array(pts_ext), n,
-                                                self._ptr_array(out_enc), self._ptr_array(out_ext), self._ptr_array(ok)), "kyb_group_mul_batch_dev")
+                                                self._ptr_array(out_enc), self._ptr_array(out_ext), self._ptr_array(ok)), "kyb_group_mul_batch_dev", self.lib)
 
     def mul_base_dev(self, scalars, out_enc=None, out_ext=None) -> None:
         n = (ctypes.c_size_t * self.size)(*[t.numel() // 32 for t in scalars])
         _check(self.lib.kyb_group_mul_base_batch_dev(self.handle, self._ptr_array(scalars), n, self._ptr_array(out_enc), self._ptr_array(out_ext)),
-               "kyb_group_mul_base_batch_dev")
+               "kyb_group_mul_base_batch_dev", self.lib)
 
     def sync(self) -> None:
-        _check(self.lib.kyb_group_sync(self.handle), "kyb_group_sync")
+        _check(self.lib.kyb_group_sync(self.handle), "kyb_group_sync", self.lib)
 
     def mul_base(self, scalars):
         s = _u8(scalars, 32, "scalars")
         enc = np.empty((s.shape[0], 32), dtype=np.uint8)
-        _check(self.lib.kyb_group_mul_base_batch(self.handle, _ptr(s), s.shape[0], _ptr(enc), None), "kyb_group_mul_base_batch")
+        _check(self.lib.kyb_group_mul_base_batch(self.handle, _ptr(s), s.shape[0], _ptr(enc), None), "kyb_group_mul_base_batch", self.lib)
         return enc
 
     def mul(self, scalars, pts_ext=None, pts_enc=None):
@@ -880,7 +880,7 @@ class Group:
         _rows(pe, n, "pts_enc"); _rows(px, n, "pts_ext")
         enc = np.empty((n, 32), dtype=np.uint8)
         ok = np.empty((n,), dtype=np.uint8)
-        _check(self.lib.kyb_group_mul_batch(self.handle, _ptr(s), _ptr(pe), _ptr(px), n, _ptr(enc), None, _ptr(ok)), "kyb_group_mul_batch")
+        _check(self.lib.kyb_group_mul_batch(self.handle, _ptr(s), _ptr(pe), _ptr(px), n, _ptr(enc), None, _ptr(ok)), "kyb_group_mul_batch", self.lib)
         return enc, ok
 
     def schnorr_sign(self, x, k, msgs: Sequence[bytes]):
@@ -889,7 +889,7 @@ class Group:
         _rows(ks, n, "k")
         blob, off = _msg_blob(msgs, n)
         sig = np.empty((n, 64), dtype=np.uint8)
-        _check(self.lib.kyb_group_schnorr_sign_batch(self.handle, _ptr(xs), _ptr(ks), _ptr(blob), _ptr(off), n, _ptr(sig)), "kyb_group_schnorr_sign_batch")
+        _check(self.lib.kyb_group_schnorr_sign_batch(self.handle, _ptr(xs), _ptr(ks), _ptr(blob), _ptr(off), n, _ptr(sig)), "kyb_group_schnorr_sign_batch", self.lib)
         return sig
 
     def verify(self, pubs, msgs: Sequence[bytes], sigs, flavor: int = 0):
@@ -898,5 +898,5 @@ class Group:
         _rows(ss, n, "sigs")
         blob, off = _msg_blob(msgs, n)
         st = np.empty((n,), dtype=np.uint8)
-        _check(self.lib.kyb_group_verify_batch(self.handle, _ptr(ps), _ptr(blob), _ptr(off), _ptr(ss), n, flavor, _ptr(st)), "kyb_group_verify_batch")
+        _check(self.lib.kyb_group_verify_batch(self.handle, _ptr(ps), _ptr(blob), _ptr(off), _ptr(ss), n, flavor, _ptr(st)), "kyb_group_verify_batch", self.lib)
         return st
