@@ -697,7 +697,7 @@ def protocol_phases(n=64, t=43):
         rounds = importlib.import_module("test_gpu_vss_round")
         out = {"n": n, "t": t, "unit": "ms per phase", "cpu_port": "the C restatement of the reference algorithm (oracle/) behind the same ABI, one thread"}
         out["repeats"] = "best of 3 runs per program and phase (host-side latencies: a busy host core shows at once)"
-        for prog in ("test_vss_round", "test_dkg_finish"):
+        for prog in ("test_vss_round", "test_dkg_finish", "test_dss_round"):
             gpu_bin, cpu_bin = rounds.build(prog), rounds.build(prog, cpu_port=True)
             lines, timing = rounds.run_program(gpu_bin, n, t)
             cpu_lines, cpu = rounds.run_program(cpu_bin, n, t, "eager")

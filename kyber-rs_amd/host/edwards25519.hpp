@@ -195,8 +195,18 @@ class Point {
   bool var_time = false; // point.rs:26 (never set; kept for layout parity)
   mutable uint64_t pend = 0;     // handle in the engine's arena (kyb_defer_*), 0 = none
   mutable bool have_ge = true;
+  // The 32 bytes marshal_binary() returns for this value, once they are known: a point that was unmarshalled from its canonical encoding, or
+  // has been marshalled before.  Protocol code marshals what it has just unmarshalled (every hash over received commitments or keys), asks
+  // has_small_order() of it (schnorr_sig.rs:79-95) and compares it (point.rs:227-241 compares ENCODINGS): with the bytes at hand none of these
+  // reaches the engine.  Part of the value: every operation that changes the point drops it.
+  mutable bool have_enc = false;
+  mutable uint8_t enc[32];
 
   Point() { std::memset(ge, 0, sizeof(ge)); }
+
+  // this object now holds the limbs `l` / is the recorded node `h`
+  void hold(const int32_t* l) { std::memcpy(ge, l, sizeof(ge)); have_ge = true; pend = 0; have_enc = false; }
+  void recorded(uint64_t h) { pend = h; have_ge = false; have_enc = false; }
 
   // the limbs, evaluated now if the point is still only recorded
   const int32_t* limbs() const {
@@ -225,7 +235,7 @@ class Point {
     return h;
   }
 
-  Point null() { std::memset(ge, 0, sizeof(ge)); ge[10] = 1; ge[20] = 1; have_ge = true; pend = 0; return *this; }        // point.rs:79-82
+  Point null() { std::memset(ge, 0, sizeof(ge)); ge[10] = 1; ge[20] = 1; have_ge = true; pend = 0; have_enc = false; return *this; }        // point.rs:79-82
   // 1 * B as the engine hands it out, asked for once per process (the reference copies the literal BASEEXT, constants.rs:70-87: the same point)
   static const int32_t* base_ext() {
     static const std::array<int32_t, 40> b = [] {
@@ -236,8 +246,8 @@ class Point {
     }();
     return b.data();
   }
-  Point base() { std::memcpy(ge, base_ext(), sizeof(ge)); have_ge = true; pend = 0; return *this; }   // point.rs:85-88
-  Point set(const Point& p) { std::memcpy(ge, p.ge, sizeof(ge)); pend = p.pend; have_ge = p.have_ge; return *this; }                // point.rs:94-97
+  Point base() { hold(base_ext()); return *this; }   // point.rs:85-88
+  Point set(const Point& p) { *this = p; return *this; }                // point.rs:94-97
   size_t embed_len() const { return (255 - 8 - 8) / 8; }                                        // point.rs:99-104
   Point pick(Stream& rand) { return embed(nullptr, 0, rand); }                                  // point.rs:90-92
 
@@ -250,7 +260,7 @@ class Point {
       rand.xor_key_stream(b, z, 32);
       if (data != nullptr) { b[0] = (uint8_t)dl; std::memcpy(b + 1, data, dl); }
       uint8_t ok = 0;
-      have_ge = true; pend = 0;                                // the rejection loop needs every answer at once: eager calls in either mode
+      have_ge = true; pend = 0; have_enc = false;              // the rejection loop needs every answer at once: eager calls in either mode
       detail::engine_must(kyb_decode_batch(b, 1, ge, &ok), "Point::embed decode");
       if (!ok) continue;
       if (data == nullptr) {
@@ -277,11 +287,11 @@ class Point {
   Point add(const Point& a, const Point& b) { return add_sub(a, b, 0); }                       // point.rs:179-188
   Point sub(const Point& a, const Point& b) { return add_sub(a, b, 1); }                       // point.rs:190-199
   Point neg(const Point& a) {                                                                  // point.rs:201-204, ge.rs:86-91... neg X and T
-    if (deferred()) { const uint64_t h = record("Point::neg", &a, nullptr, [&](uint64_t* o) { return kyb_defer_neg(a.handle(), o); }); pend = h; have_ge = false; return *this; }
+    if (deferred()) { const uint64_t h = record("Point::neg", &a, nullptr, [&](uint64_t* o) { return kyb_defer_neg(a.handle(), o); }); recorded(h); return *this; }
     const int32_t* l = a.limbs();
     int32_t out[40];
     for (int i = 0; i < 10; ++i) { out[i] = -l[i]; out[10 + i] = l[10 + i]; out[20 + i] = l[20 + i]; out[30 + i] = -l[30 + i]; }
-    std::memcpy(ge, out, sizeof(ge)); have_ge = true; pend = 0;
+    hold(out);
     return *this;
   }
   // point.rs:207-224: p == nullptr -> fixed base (ge_scalar_mult_base), else variable base.  Every in-tree caller passes the generator as
@@ -292,27 +302,30 @@ class Point {
     if (deferred()) {
       const uint64_t h = p == nullptr ? record("Point::mul (base)", nullptr, nullptr, [&](uint64_t* o) { return kyb_defer_mul_base(s.v.data(), o); })
                                       : record("Point::mul", p, nullptr, [&](uint64_t* o) { return kyb_defer_mul(s.v.data(), p->handle(), o); });
-      pend = h; have_ge = false;
+      recorded(h);
       return *this;
     }
     int32_t out[40];
     if (p == nullptr) detail::engine_must(kyb_mul_base_batch(s.v.data(), 1, nullptr, out), "Point::mul (base)");
     else detail::engine_must(kyb_mul_batch(s.v.data(), nullptr, p->limbs(), 1, nullptr, out, nullptr), "Point::mul");
-    std::memcpy(ge, out, sizeof(ge)); have_ge = true; pend = 0;
+    hold(out);
     return *this;
   }
   // Marshaling, point.rs:35-60
   std::vector<uint8_t> marshal_binary() const {
+    if (have_enc) return std::vector<uint8_t>(enc, enc + 32);
     std::vector<uint8_t> b(32);
     if (pend != 0) {                       // recorded (or registered as an operand): the arena evaluates what it depends on and caches the bytes
       const int rc = kyb_defer_get(pend, have_ge ? nullptr : ge, b.data());
       if (!(rc == KYB_E_STALE && forget_stale_handle())) {      // (a dropped node of a point that holds its limbs: marshal the limbs, below)
         detail::engine_must(rc, "Point::marshal_binary");
         have_ge = true;
+        std::memcpy(enc, b.data(), 32); have_enc = true;
         return b;
       }
     }
     detail::engine_must(kyb_encode_batch(ge, 1, b.data()), "Point::marshal_binary");
+    std::memcpy(enc, b.data(), 32); have_enc = true;
     return b;
   }
   void unmarshal_binary(const uint8_t* data, size_t n) {
@@ -320,12 +333,24 @@ class Point {
     int32_t out[40];
     if (n == 32) detail::engine_must(kyb_decode_batch(data, 1, out, &ok), "Point::unmarshal_binary");
     if (n != 32 || !ok) throw MarshallingError("invalid Ed25519 curve point");
-    std::memcpy(ge, out, sizeof(ge)); have_ge = true; pend = 0;
+    hold(out);
+    if (is_the_canonical_encoding(data)) { std::memcpy(enc, data, 32); have_enc = true; }
+  }
+  // are these 32 bytes, which decode, exactly what marshal_binary() yields for the point they decode to?  Not when y >= p (fe_from_bytes accepts
+  // it, fe_to_bytes reduces it: fe.rs:52-122) and not when x = 0 carries a sign bit (ge.rs:124-179 accepts it, the encoder writes sign 0).
+  static bool is_the_canonical_encoding(const uint8_t b[32]) {
+    uint8_t ff = 0xff, zero = 0;
+    for (int i = 1; i <= 30; ++i) { ff &= b[i]; zero |= b[i]; }
+    const uint8_t top = b[31] & 0x7f;
+    const bool y_ge_p = ff == 0xff && top == 0x7f && b[0] >= 0xed;
+    const bool y_is_one = zero == 0 && top == 0 && b[0] == 1, y_is_minus_one = ff == 0xff && top == 0x7f && b[0] == 0xec;
+    return !y_ge_p && !((b[31] & 0x80) != 0 && (y_is_one || y_is_minus_one));
   }
   size_t marshal_size() const { return 32; }
   // point.rs:227-241 compares the two encodings (two field inversions); the engine compares projectively, same answer
   bool operator==(const Point& o) const {
     uint8_t eq = 0;
+    if (have_enc && o.have_enc) return std::memcmp(enc, o.enc, 32) == 0;      // what the reference compares
     if (!have_ge || !o.have_ge) {
       int rc = kyb_defer_equal(handle(), o.handle(), &eq);
       if (rc == KYB_E_STALE && (forget_stale_handle() | o.forget_stale_handle())) rc = kyb_defer_equal(handle(), o.handle(), &eq);
@@ -345,9 +370,27 @@ class Point {
   // point.rs:286-313: the encoding against the five WEAK_KEYS below p (constants.rs:3744-3775) — on the engine, which marshals the limbs
   // and compares (kyb_point_checks_batch, bit 1): total on any limbs, as the reference's is
   bool has_small_order() const {
+    if (have_enc) return small_order_encoding(enc);
     uint8_t flags = 0;
     detail::engine_must(kyb_point_checks_batch(nullptr, limbs(), 1, &flags), "Point::has_small_order");
     return (flags & 2) != 0;
+  }
+  // the comparison of point.rs:286-313 itself, on bytes that ARE the point's encoding: sign bit masked, against the encodings of y = 0, 1, p - 1 and
+  // of the two order-8 classes (WEAK_KEYS below p, constants.rs:3744-3775; csrc/verify.h pt_has_small_order is the engine's form of it)
+  static bool small_order_encoding(const uint8_t e[32]) {
+    const uint32_t y8a[8] = KYB_W_ORDER8_Y0, y8b[8] = KYB_W_ORDER8_Y1, pw[8] = KYB_W_P;
+    uint32_t w[8];
+    std::memcpy(w, e, 32);
+    w[7] &= 0x7fffffffu;
+    uint32_t d0 = 0, d1 = 0, dm = 0, da = 0, db = 0;
+    for (int i = 0; i < 8; ++i) {
+      d0 |= w[i];
+      d1 |= w[i] ^ (i == 0 ? 1u : 0u);
+      dm |= w[i] ^ (i == 0 ? pw[0] - 1u : pw[i]);
+      da |= w[i] ^ y8a[i];
+      db |= w[i] ^ y8b[i];
+    }
+    return d0 == 0 || d1 == 0 || dm == 0 || da == 0 || db == 0;
   }
   // point.rs:315-337
   bool is_canonical(const uint8_t* b, size_t n) const {
@@ -391,10 +434,10 @@ class Point {
 
  private:
   Point add_sub(const Point& a, const Point& b, int subtract) {
-    if (deferred()) { const uint64_t h = record("Point::add", &a, &b, [&](uint64_t* o) { return kyb_defer_add(a.handle(), b.handle(), subtract, o); }); pend = h; have_ge = false; return *this; }
+    if (deferred()) { const uint64_t h = record("Point::add", &a, &b, [&](uint64_t* o) { return kyb_defer_add(a.handle(), b.handle(), subtract, o); }); recorded(h); return *this; }
     int32_t out[40];
     detail::engine_must(kyb_add_batch(a.limbs(), b.limbs(), 1, out, subtract), subtract ? "Point::sub" : "Point::add");
-    std::memcpy(ge, out, sizeof(ge)); have_ge = true; pend = 0;
+    hold(out);
     return *this;
   }
   static bool is_identity_encoding(const uint8_t e[32]) {

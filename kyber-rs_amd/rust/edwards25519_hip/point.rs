@@ -74,6 +74,9 @@ const MARSHAL_POINT_ID: [u8; 8] = *b"ed.point";
 const ORDER_LE: [u8; 32] = [0xed, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x58, 0xd6, 0x9c, 0xf7, 0xa2, 0xde, 0xf9, 0xde, 0x14, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x10];
 const COFACTOR_LE: [u8; 32] = [8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0];
 /// marshal_binary of the neutral element
+// y of the two classes of order-8 points, little-endian (csrc/consts.inc KYB_W_ORDER8_Y0 / _Y1; constants.rs:3744-3775 lists them among WEAK_KEYS)
+const ORDER8_Y0_LE: [u8; 32] = [0x26, 0xe8, 0x95, 0x8f, 0xc2, 0xb2, 0x27, 0xb0, 0x45, 0xc3, 0xf4, 0x89, 0xf2, 0xef, 0x98, 0xf0, 0xd5, 0xdf, 0xac, 0x05, 0xd3, 0xc6, 0x33, 0x39, 0xb1, 0x38, 0x02, 0x88, 0x6d, 0x53, 0xfc, 0x05];
+const ORDER8_Y1_LE: [u8; 32] = [0xc7, 0x17, 0x6a, 0x70, 0x3d, 0x4d, 0xd8, 0x4f, 0xba, 0x3c, 0x0b, 0x76, 0x0d, 0x10, 0x67, 0x0f, 0x2a, 0x20, 0x53, 0xfa, 0x2c, 0x39, 0xcc, 0xc6, 0x4e, 0xc7, 0xfd, 0x77, 0x92, 0xac, 0x03, 0x7a];
 const NEUTRAL_ENC: [u8; 32] = [1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0];
 
 fn invalid_point() -> MarshallingError {
@@ -90,6 +93,12 @@ pub struct Point {
     ge: Limbs,
     var_time: bool,
     pend: u64,
+    /// The 32 bytes `marshal_binary` returns for this value, when the point was unmarshalled from exactly those bytes.  Protocol code
+    /// marshals what it has just unmarshalled (every hash over received commitments and keys), asks `has_small_order` of it
+    /// (schnorr_sig.rs:79-95) and compares it (point.rs:227-241 compares ENCODINGS): with the bytes at hand none of these reaches the
+    /// engine.  Part of the value: every operation that changes the point drops it.  (`Point` is `Copy`, as in the reference, so a
+    /// `&self` marshal cannot store its result; the C++ mirror, host/edwards25519.hpp, also keeps the bytes of a first marshal.)
+    enc: Option<[u8; 32]>,
 }
 
 #[derive(Serialize, Deserialize)]
@@ -100,7 +109,7 @@ struct Plain {
 }
 impl From<Plain> for Point {
     fn from(p: Plain) -> Self {
-        Point { ge: p.ge, var_time: p.var_time, pend: 0 }
+        Point { ge: p.ge, var_time: p.var_time, pend: 0, enc: None }
     }
 }
 impl From<Point> for Plain {
@@ -112,7 +121,7 @@ impl From<Point> for Plain {
 impl Default for Point {
     /// all-zero limbs, like the derived default of the reference's element
     fn default() -> Self {
-        Point { ge: [[0; 10]; 4], var_time: false, pend: 0 }
+        Point { ge: [[0; 10]; 4], var_time: false, pend: 0, enc: None }
     }
 }
 
@@ -134,11 +143,11 @@ impl Point {
         Self::default()
     }
     fn from_limbs(ge: Limbs) -> Self {
-        Point { ge, var_time: false, pend: 0 }
+        Point { ge, var_time: false, pend: 0, enc: None }
     }
     /// a point that exists only as a recorded operation so far
     fn recorded(self, handle: u64) -> Self {
-        Point { ge: [[0; 10]; 4], pend: handle, ..self }
+        Point { ge: [[0; 10]; 4], pend: handle, enc: None, ..self }
     }
     /// the limbs: held, or evaluated now (with everything else recorded so far) and fetched from the arena
     fn limbs(&self) -> Limbs {
@@ -162,6 +171,7 @@ impl Point {
     }
     fn ext_mut(&mut self) -> *mut i32 {
         self.pend = 0;
+        self.enc = None;
         self.ge.as_mut_ptr() as *mut i32
     }
     /// Detach this point from the arena: its limbs are fetched (evaluating what it depends on) and it no longer names a handle.
@@ -175,6 +185,9 @@ impl Point {
     /// the 32 bytes of `marshal_binary`, from the engine (one field inversion on the GPU; for a recorded point: evaluation in batches,
     /// bytes cached in the arena)
     fn encoding(&self) -> [u8; 32] {
+        if let Some(bytes) = self.enc {
+            return bytes;
+        }
         ensure_init();
         let mut b = [0u8; 32];
         if self.pend != 0 {
@@ -210,7 +223,7 @@ impl Point {
         let (a, b) = (p1.limbs(), p2.limbs());
         let mut out: Limbs = [[0; 10]; 4];
         must(unsafe { ffi::kyb_add_batch(a.as_ptr() as *const i32, b.as_ptr() as *const i32, 1, out.as_mut_ptr() as *mut i32, subtract as c_int) }, "add");
-        Point { ge: out, pend: 0, ..self }
+        Point { ge: out, pend: 0, enc: None, ..self }
     }
 
     /// `mul` for a multiplier the caller KNOWS to be public (a share index, the cofactor): the engine may then skip its leading
@@ -382,6 +395,35 @@ pub fn verify_batch(pubs: &[[u8; 32]], msgs: &[&[u8]], sigs: &[[u8; 64]], eddsa_
     status
 }
 
+/// Are these 32 bytes, which decode, exactly what `marshal_binary` yields for the point they decode to?  Not when y >= p (`fe_from_bytes`
+/// accepts it, `fe_to_bytes` reduces it: fe.rs:52-122) and not when x = 0 carries a sign bit (ge.rs:124-179 accepts it, the encoder writes 0).
+fn is_the_canonical_encoding(b: &[u8]) -> bool {
+    let (mut ones, mut any) = (0xffu8, 0u8);
+    for byte in &b[1..31] {
+        ones &= byte;
+        any |= byte;
+    }
+    let top = b[31] & 0x7f;
+    let y_ge_p = ones == 0xff && top == 0x7f && b[0] >= 0xed;
+    let y_is_one = any == 0 && top == 0 && b[0] == 1;
+    let y_is_minus_one = ones == 0xff && top == 0x7f && b[0] == 0xec;
+    !y_ge_p && !(b[31] & 0x80 != 0 && (y_is_one || y_is_minus_one))
+}
+
+/// The comparison of point.rs:286-313 on bytes that ARE the point's encoding: sign bit masked, against y = 0, 1, p - 1 and the two classes of
+/// order-8 points (the WEAK_KEYS below p, constants.rs:3744-3775; csrc/verify.h `pt_has_small_order` is the engine's form of it).
+fn small_order_encoding(e: &[u8; 32]) -> bool {
+    let mut y = *e;
+    y[31] &= 0x7f;
+    let mut one = [0u8; 32];
+    one[0] = 1;
+    let mut minus_one = [0xffu8; 32];
+    minus_one[0] = 0xec;
+    minus_one[31] = 0x7f;
+    let matches = |w: &[u8; 32]| y.iter().zip(w).fold(0u8, |d, (a, b)| d | (a ^ b)) == 0;
+    matches(&[0u8; 32]) | matches(&one) | matches(&minus_one) | matches(&ORDER8_Y0_LE) | matches(&ORDER8_Y1_LE)
+}
+
 impl BinaryMarshaler for Point {
     fn marshal_binary(&self) -> Result<Vec<u8>, MarshallingError> {
         Ok(self.encoding().to_vec())
@@ -391,6 +433,7 @@ impl BinaryUnmarshaler for Point {
     fn unmarshal_binary(&mut self, data: &[u8]) -> Result<(), MarshallingError> {
         self.ge = Self::decode(data).ok_or_else(invalid_point)?;
         self.pend = 0;
+        self.enc = is_the_canonical_encoding(data).then(|| data.try_into().unwrap());
         Ok(())
     }
 }
@@ -422,12 +465,12 @@ impl group::Point for Point {
         let mut ge: Limbs = [[0; 10]; 4];
         ge[1][0] = 1;
         ge[2][0] = 1;
-        Point { ge, pend: 0, ..self }
+        Point { ge, pend: 0, enc: None, ..self }
     }
 
     /// 1 * B from the engine (the reference copies a literal; the same point)
     fn base(self) -> Self {
-        Point { ge: *base_ext(), pend: 0, ..self }
+        Point { ge: *base_ext(), pend: 0, enc: None, ..self }
     }
 
     /// `embed` without data (point.rs:90-92)
@@ -471,10 +514,10 @@ impl group::Point for Point {
                 "embed",
             );
             if keep_product && enc != NEUTRAL_ENC {
-                return Point { ge: product, pend: 0, ..self };
+                return Point { ge: product, pend: 0, enc: None, ..self };
             }
             if !keep_product && enc == NEUTRAL_ENC {
-                return Point { ge: limbs, pend: 0, ..self };
+                return Point { ge: limbs, pend: 0, enc: None, ..self };
             }
         }
     }
@@ -511,6 +554,7 @@ impl group::Point for Point {
         let l = a.limbs();
         self.ge = [flip(&l[0]), l[1], l[2], flip(&l[3])];
         self.pend = 0;
+        self.enc = None;
         *self
     }
 
@@ -548,6 +592,9 @@ impl group::Point for Point {
 impl PartialEq for Point {
     /// the reference compares the two encodings (two inversions); the engine compares projectively, same answer
     fn eq(&self, p2: &Self) -> bool {
+        if let (Some(a), Some(b)) = (self.enc, p2.enc) {
+            return a == b; // what the reference compares
+        }
         ensure_init();
         let mut e = 0u8;
         if self.pend != 0 || p2.pend != 0 {
@@ -588,6 +635,9 @@ impl UpperHex for Point {
 impl PointCanCheckCanonicalAndSmallOrder for Point {
     /// on the engine: marshals the limbs and compares with the weak keys (no `unmarshal`, hence total on any limbs)
     fn has_small_order(&self) -> bool {
+        if let Some(bytes) = self.enc {
+            return small_order_encoding(&bytes);
+        }
         ensure_init();
         let mut flags = 0u8;
         let l = self.limbs();

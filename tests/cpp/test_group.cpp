@@ -439,12 +439,54 @@ int main() {
     }
     CHECK(saw_small && saw_noncanonical, "checks_batch: both flags exercised");
   }
+  // the encoding a Point keeps once it is known (unmarshalled from its canonical bytes, or marshalled before): marshal_binary, has_small_order
+  // and == then answer from the bytes — the same answers the engine gives on the limbs; encodings that are NOT what marshal_binary yields
+  // (y >= p; x = 0 with a sign bit) are not kept; any operation on the point drops the bytes
+  {
+    std::vector<std::array<uint8_t, 32>> encs;
+    for (size_t i = 0; i < 3 && i < points.size(); ++i) { std::array<uint8_t, 32> e; auto b = points[i].marshal_binary(); std::memcpy(e.data(), b.data(), 32); encs.push_back(e); }
+    { std::array<uint8_t, 32> e{}; e[0] = 1; encs.push_back(e); }                                             // neutral element
+    { std::array<uint8_t, 32> e{}; encs.push_back(e); }                                                       // y = 0: order 4
+    { std::array<uint8_t, 32> e; e.fill(0xff); e[0] = 0xec; e[31] = 0x7f; encs.push_back(e); }              // y = p - 1: order 2
+    const size_t canonical = encs.size();
+    { std::array<uint8_t, 32> e{}; e[0] = 1; e[31] = 0x80; encs.push_back(e); }                              // x = 0 with a sign bit (ge.rs:124-179 accepts it)
+    { std::array<uint8_t, 32> e; e.fill(0xff); e[0] = 0xec; encs.push_back(e); }                             // y = p - 1, sign bit set
+    { std::array<uint8_t, 32> e; e.fill(0xff); e[0] = 0xed; e[31] = 0x7f; encs.push_back(e); }              // y = p      (= 0)
+    { std::array<uint8_t, 32> e; e.fill(0xff); e[0] = 0xee; e[31] = 0x7f; encs.push_back(e); }              // y = p + 1  (= 1)
+    for (size_t i = 0; i < encs.size(); ++i) {
+      Point q;
+      q.unmarshal_binary(encs[i].data(), 32);
+      CHECK(q.have_enc == (i < canonical), "the bytes are kept exactly when they are the canonical encoding");
+      uint8_t want[32], flags = 0;
+      CHECK(kyb_encode_batch(q.limbs(), 1, want) == KYB_OK && kyb_point_checks_batch(nullptr, q.limbs(), 1, &flags) == KYB_OK, "engine answers");
+      CHECK(q.has_small_order() == ((flags & 2) != 0), "has_small_order: bytes and engine agree");
+      const std::vector<uint8_t> m = q.marshal_binary();
+      CHECK(std::memcmp(m.data(), want, 32) == 0, "marshal_binary: bytes and engine agree");
+      CHECK((std::memcmp(m.data(), encs[i].data(), 32) == 0) == (i < canonical), "a non-canonical encoding is not what marshal_binary returns");
+      CHECK(q.have_enc && q.has_small_order() == ((flags & 2) != 0), "after a marshal the bytes are kept");
+      Point fresh;                                                     // the same point without bytes: == through the engine, then through the bytes
+      std::memcpy(fresh.ge, q.limbs(), sizeof(fresh.ge));
+      CHECK(!fresh.have_enc && q == fresh && fresh == q, "== with bytes on one side");
+      (void)fresh.marshal_binary();
+      CHECK(fresh.have_enc && q == fresh, "== with bytes on both sides");
+      Point moved = q;
+      CHECK(moved.have_enc, "a copy keeps the bytes");
+      moved = moved.add(moved, gen);
+      CHECK(!moved.have_enc && !(moved == q), "an operation drops them");
+      uint8_t want2[32];
+      CHECK(kyb_encode_batch(moved.limbs(), 1, want2) == KYB_OK && std::memcmp(moved.marshal_binary().data(), want2, 32) == 0, "marshal after the operation");
+      set_deferred(true);
+      Point rec = Point().sub(moved, gen);                             // recorded: no bytes until asked; then those of q
+      CHECK(!rec.have_enc && rec == q && std::memcmp(rec.marshal_binary().data(), want, 32) == 0 && rec.have_enc, "a recorded point gains its bytes when marshalled");
+      set_deferred(false);
+    }
+  }
   // a long-lived key used as a deferred operand keeps a CACHED handle; when the arena drops the node (kyb_defer_floor at the end of a round,
   // defer.max_nodes) the limbs the point still holds are registered again — no abort, same bytes (KYB_E_STALE)
   {
     Scalar k = Scalar().pick(rand), x = Scalar().pick(rand);
     Point key = Point().mul(k, nullptr);                               // eager: holds its limbs
-    const std::vector<uint8_t> key_bytes = key.marshal_binary();
+    const std::vector<uint8_t> key_bytes = Point(key).marshal_binary();      // (of a copy: `key` itself keeps no bytes, its marshal below must go to the arena)
     const Point eager = Point().add(Point().mul(x, &key), key);
     set_deferred(true);
     Point r1 = Point().add(Point().mul(x, &key), key);                 // key is registered as a leaf, its handle cached

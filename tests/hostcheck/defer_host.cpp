@@ -218,6 +218,47 @@ int main() {
     for (const Val& p : prod) CHECK(got_enc(p.h) == enc_of(p.ext), "every product of the chain");
     for (const Val& p : sums) CHECK(got_enc(p.h) == enc_of(p.ext), "every sum of the chain");
   }
+  // DSS::process_partial_sig (dss_sig.rs:266-273): two Horner chains whose results are NOT sinks — long_poly.eval(i) goes into a multiplication by a
+  // 253-bit scalar, random_poly.eval(i) into an addition with that product, and only the comparison asks.  Both chains are still one evaluation
+  // call; then one multiplication, one addition (the big multiplier is no share index: no chain there), and a sum fed by a chain result keeps it a leaf
+  for (int shape = 0; shape < 2; ++shape) {
+    const size_t t = 11;
+    std::vector<Val> lc(t), rc(t);
+    for (size_t j = 0; j < t; ++j) {
+      uint8_t s[32];
+      scalar_small(s, 600 + (uint32_t)j + 50 * shape); orc_mul_base(nullptr, lc[j].ext, s); CHECK(kyb_defer_input(lc[j].ext, &lc[j].h) == KYB_OK, "long commit");
+      scalar_small(s, 900 + (uint32_t)j + 50 * shape); orc_mul_base(nullptr, rc[j].ext, s); CHECK(kyb_defer_input(rc[j].ext, &rc[j].h) == KYB_OK, "random commit");
+    }
+    const uint32_t index = 37;
+    auto eval = [&](const std::vector<Val>& c) {
+      uint8_t x[32]; scalar_small(x, index + 1);
+      Val v; orc_null(v.ext); CHECK(kyb_defer_null(&v.h) == KYB_OK, "null");
+      for (size_t j = t; j-- > 0;) {
+        Val m, a;
+        orc_mul(nullptr, m.ext, x, v.ext); orc_add(a.ext, m.ext, c[j].ext, 0);
+        CHECK(kyb_defer_mul(x, v.h, &m.h) == KYB_OK && kyb_defer_add(m.h, c[j].h, 0, &a.h) == KYB_OK, "eval");
+        v = a;
+      }
+      return v;
+    };
+    uint64_t st0[8], st1[8];
+    kyb_defer_stats(st0, 8);
+    const long c0 = g_calls;
+    Val rand_share = eval(rc), long_share = eval(lc);
+    uint8_t hs[32]; for (int i = 0; i < 32; ++i) hs[i] = (uint8_t)(0x5b + 29 * i); hs[31] &= 0x0f;
+    Val right, right2;
+    orc_mul(nullptr, right.ext, hs, long_share.ext); CHECK(kyb_defer_mul(hs, long_share.h, &right.h) == KYB_OK, "hash * long_share");
+    orc_add(right2.ext, rand_share.ext, right.ext, 0); CHECK(kyb_defer_add(rand_share.h, right.h, 0, &right2.h) == KYB_OK, "rand_share + ...");
+    Val top = right2;
+    if (shape == 1) {      // two more terms on top: a sum chain whose innermost term is the chain result
+      for (int k = 0; k < 2; ++k) { Val nx; orc_add(nx.ext, top.ext, lc[k].ext, 0); CHECK(kyb_defer_add(top.h, lc[k].h, 0, &nx.h) == KYB_OK, "more terms"); top = nx; }
+    }
+    CHECK(got_enc(top.h) == enc_of(top.ext), "the value the comparison looks at");
+    kyb_defer_stats(st1, 8);
+    CHECK(st1[3] - st0[3] == 2, "both evaluations fused although neither is a sink");
+    CHECK(g_calls - c0 == (shape == 0 ? 4 : 3), "one evaluation call for both chains, one multiplication, then an addition and its marshal / one sum");
+    CHECK(got_enc(rand_share.h) == enc_of(rand_share.ext) && got_enc(long_share.h) == enc_of(long_share.ext) && got_enc(right.h) == enc_of(right.ext), "the results in between");
+  }
   // recover_commit: one batch of products, one sum
   {
     const size_t t = 9;

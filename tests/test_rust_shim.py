@@ -145,3 +145,39 @@ def test_the_call_site_check_catches_a_wrong_arity_and_a_missing_declaration(tmp
     bad = []
     chk.ffi_call_sites(bad)
     assert any("kyb_defer_get is called with 2 arguments" in b for b in bad) and any("kyb_defer_marker" in b for b in bad), bad
+
+
+def test_the_byte_constants_of_the_module_are_the_curve_s():
+    """point.rs spells a few 32-byte constants out (it cannot include csrc/consts.inc): the group order, the cofactor, the neutral element's
+    encoding and the y of the two classes of order-8 points that has_small_order() compares a kept encoding with — against Python integers and the
+    words tools/gen_constants.py derived from the curve definition"""
+    import struct
+    point = open(os.path.join(SHIM, "point.rs")).read()
+    def const(name):
+        m = re.search(r"const %s: \[u8; 32\] = \[([^\]]*)\];" % name, point)
+        assert m, name
+        return bytes(int(x, 0) for x in m.group(1).split(","))
+    consts = open(os.path.join(ROOT, "kyber-rs_amd", "csrc", "consts.inc")).read()
+    def words(name):
+        m = re.search(r"#define %s\s+\{([^}]*)\}" % name, consts)
+        return struct.pack("<8I", *[int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")])
+    P, L = 2**255 - 19, 2**252 + 27742317777372353535851937790883648493
+    assert int.from_bytes(const("ORDER_LE"), "little") == L and int.from_bytes(const("COFACTOR_LE"), "little") == 8
+    assert const("NEUTRAL_ENC") == (1).to_bytes(32, "little")
+    assert const("ORDER8_Y0_LE") == words("KYB_W_ORDER8_Y0") and const("ORDER8_Y1_LE") == words("KYB_W_ORDER8_Y1")
+    # and from the curve itself: a point of order 8 has y^2 = +-sqrt(-1)-ish roots of 4 P = (+-1, 0) ... checked the direct way: x^2 = (y^2 - 1) / (d y^2 + 1),
+    # doubling (x, y) three times gives the neutral element, twice does not
+    d = (-121665 * pow(121666, P - 2, P)) % P
+    def dbl(pt):
+        x, y = pt
+        den = d * x * x * y * y % P
+        return (2 * x * y * pow(1 + den, P - 2, P)) % P, ((y * y + x * x) * pow(1 - den, P - 2, P)) % P
+    for name in ("ORDER8_Y0_LE", "ORDER8_Y1_LE"):
+        y = int.from_bytes(const(name), "little")
+        x2 = (y * y - 1) * pow(d * y * y + 1, P - 2, P) % P
+        x = pow(x2, (P + 3) // 8, P)
+        if x * x % P != x2:
+            x = x * pow(2, (P - 1) // 4, P) % P
+        assert x * x % P == x2, name
+        p2 = dbl((x, y)); p4 = dbl(p2); p8 = dbl(p4)
+        assert p8 == (0, 1) and p4 != (0, 1), name
