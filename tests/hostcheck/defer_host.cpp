@@ -249,6 +249,9 @@ int main() {
     Val right, right2;
     orc_mul(nullptr, right.ext, hs, long_share.ext); CHECK(kyb_defer_mul(hs, long_share.h, &right.h) == KYB_OK, "hash * long_share");
     orc_add(right2.ext, rand_share.ext, right.ext, 0); CHECK(kyb_defer_add(rand_share.h, right.h, 0, &right2.h) == KYB_OK, "rand_share + ...");
+    // partial * B (dss_sig.rs:271): nothing waits for it, so it rides in the call that multiplies by the challenge — no call of its own
+    Val left; uint8_t ps[32]; for (int i = 0; i < 32; ++i) ps[i] = (uint8_t)(0xc3 + 7 * i + shape); ps[31] = shape ? 0x9e : 0x0e;      // (0x9e: above 2^255, the top-digit quirk)
+    orc_mul_base(nullptr, left.ext, ps); CHECK(kyb_defer_mul_base(ps, &left.h) == KYB_OK, "partial * B");
     Val top = right2;
     if (shape == 1) {      // two more terms on top: a sum chain whose innermost term is the chain result
       for (int k = 0; k < 2; ++k) { Val nx; orc_add(nx.ext, top.ext, lc[k].ext, 0); CHECK(kyb_defer_add(top.h, lc[k].h, 0, &nx.h) == KYB_OK, "more terms"); top = nx; }
@@ -258,6 +261,7 @@ int main() {
     CHECK(st1[3] - st0[3] == 2, "both evaluations fused although neither is a sink");
     CHECK(g_calls - c0 == (shape == 0 ? 4 : 3), "one evaluation call for both chains, one multiplication, then an addition and its marshal / one sum");
     CHECK(got_enc(rand_share.h) == enc_of(rand_share.ext) && got_enc(long_share.h) == enc_of(long_share.ext) && got_enc(right.h) == enc_of(right.ext), "the results in between");
+    CHECK(got_enc(left.h) == enc_of(left.ext) && g_calls - c0 == (shape == 0 ? 4 : 3), "the fixed-base product rode along (and everything was marshalled on the way)");
   }
   // recover_commit: one batch of products, one sum
   {
