@@ -685,7 +685,8 @@ def call_by_call_sequences(eng, orc, med, t=43):
 
 def protocol_phases(n=64, t=43):
     """Unmodified call-by-call protocol code, phase by phase, with the CPU beside it (round-4 review item 3): tests/cpp/test_vss_round.cpp (a Pedersen dealer
-    round: vss.rs:287-337, 361-386, 904-909) and tests/cpp/test_dkg_finish.cpp (dkg.rs:905-953, poly.rs:566-603) are compiled twice — against the engine
+    round: vss.rs:287-337, 361-386, 904-909), tests/cpp/test_dkg_finish.cpp (dkg.rs:905-953, poly.rs:566-603) and tests/cpp/test_dss_round.cpp (a DSS
+    signing round at one participant: dss_sig.rs:173-326) are compiled twice — against the engine
     (eager = every trait call a batch-of-1 engine call; deferred = calls recorded and evaluated in batches; batched = the same round written with the batch
     entry points) and against tests/cpp/cpu_port_abi.cpp, the oracle behind the same ABI: the IDENTICAL sequence on one host core (cpu_port_ms).  All four
     transcripts of a program are byte-identical (checked here; against the oracle item by item in tests/test_gpu_vss_round.py).  Milliseconds, one run each
