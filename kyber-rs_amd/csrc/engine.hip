@@ -164,6 +164,11 @@ std::mutex g_reg_mu;
 std::vector<Ctx*> g_all;               // every live context (default one included)
 Ctx* g_default = nullptr;              // created by kyb_init / kyb_init_no_table, destroyed by kyb_shutdown
 thread_local Ctx* tl_cur = nullptr;    // kyb_ctx_set_current; nullptr = the default context
+// the deferred evaluator (defer.inc) asks for projective limbs for the calls of a flush whose results only feed other operations and a projective
+// comparison — the option ext.projective for the calling thread's calls only, whatever the context's option says
+thread_local bool tl_defer_projective = false;
+inline bool ext_projective(const Ctx& g) { return g.opt_ext_projective != 0 || tl_defer_projective; }
+void defer_projective(bool on) { tl_defer_projective = on; }
 
 int fail(int code, const char* what, hipError_t e = hipSuccess) {
   char buf[320];
@@ -1035,7 +1040,7 @@ int launch_finish(Ctx& g, StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, 
   if (n <= coop_lim(g, g.opt_coop_decode_max)) {          // few points: one per wavefront
     ProfScope ps(g, st, KID_FINISH_COOP);
     LAUNCHCK(launch::finish_coop(st, r->proj, r->proj_items, nullptr, n, oenc, oext, src_mul, last ? take_done_flag(g, st, n) : launch::DoneFlag{},
-                                 g.opt_ext_projective != 0));
+                                 ext_projective(g)));
     return KYB_OK;
   }
   ProfScope ps(g, st, KID_FINISH);
@@ -1148,7 +1153,7 @@ int launch_lincomb(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t
       { ProfScope ps(g, st, KID_MUL_COOP);
         LAUNCHCK(launch::mul_coop(st, sc, pext, n, nullptr, nullptr, 0, nullptr, 0, 0, launch::DoneFlag{}, shared ? t : 0, 1, false, r->part)); }
       ProfScope ps(g, st, KID_FINISH_COOP);
-      LAUNCHCK(launch::sum_coop(st, r->part, nullptr, m, t, oenc, oext, g.opt_ext_projective != 0, take_done_flag(g, st, m)));
+      LAUNCHCK(launch::sum_coop(st, r->part, nullptr, m, t, oenc, oext, ext_projective(g), take_done_flag(g, st, m)));
       return KYB_OK;
     }
     ProfScope ps(g, st, KID_MUL_COOP);
@@ -1181,7 +1186,7 @@ int sum_locked(Ctx& g, StreamRes* r, const int32_t* pext, const uint8_t* penc, u
   if (penc == nullptr && small && !ext_item_major) {
     // short sums of few groups: one group per wavefront, one launch
     ProfScope ps(g, st, KID_FINISH_COOP);
-    LAUNCHCK(launch::sum_coop(st, nullptr, pext, m, t, oenc, oext, g.opt_ext_projective != 0, take_done_flag(g, st, m)));
+    LAUNCHCK(launch::sum_coop(st, nullptr, pext, m, t, oenc, oext, ext_projective(g), take_done_flag(g, st, m)));
     return KYB_OK;
   }
   { int rc = ensure_proj(g, r, n); if (rc) return rc; }
@@ -1278,7 +1283,7 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
     const int canon_skip = (skip_hint >= 4 && g.opt_ladder_skip_canonical != 0) ? 4 : 0;
     LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, short_scalars ? (skip_hint > 255 ? 255 : skip_hint) : canon_skip, nullptr, 0, 0, take_done_flag(g, st, n), 0,
                               (!short_scalars && 2 * n <= coop_lim(g, g.opt_coop_verify_max)) ? 4 : 1,   // very few items (measured: up to 256): four wavefronts share an item's scalar
-                              g.opt_ext_projective != 0));
+                              ext_projective(g)));
     return KYB_OK;
   }
 #ifdef KYB_CROSSCHECK
@@ -1358,7 +1363,7 @@ int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t*
     ProfScope ps(g, st, KID_MUL_BASE_COOP);
     LAUNCHCK(launch::mul_base_coop(st, sc, n, oenc, oext, coop_table(g), nullptr, 0, 0, nullptr, 0, take_done_flag(g, st, n),
                                    n <= 2 * coop_lim(g, g.opt_coop_verify_max) ? 4 : 1,      // few items (measured: up to 1,024): four wavefronts share an item's 43 windows
-                                   g.opt_ext_projective != 0));
+                                   ext_projective(g)));
     return KYB_OK;
   }
   if (use_split(g, n)) {
@@ -1791,11 +1796,11 @@ int poly_eval_locked(Ctx& g, StreamRes* r, const int32_t* commits, size_t t, con
       int rc = ensure_enc(g, r, 160 * n * (size_t)segs + 256); if (rc) return rc;
       ProfScope ps(g, st, KID_POLY_EVAL_COOP);
       LAUNCHCK(launch::poly_eval_seg(st, commits, (int)t, idx, n, per_poly, len, segs, reinterpret_cast<uint32_t*>(r->enc), oenc, oext, (last ? take_done_flag(g, st, n) : launch::DoneFlag{}),
-                                     g.opt_ext_projective != 0));
+                                     ext_projective(g)));
       return KYB_OK;
     }
     ProfScope ps(g, st, KID_POLY_EVAL_COOP);
-    LAUNCHCK(launch::poly_eval_coop(st, commits, (int)t, idx, n, nbits, per_poly, oenc, oext, (last ? take_done_flag(g, st, n) : launch::DoneFlag{}), g.opt_ext_projective != 0));
+    LAUNCHCK(launch::poly_eval_coop(st, commits, (int)t, idx, n, nbits, per_poly, oenc, oext, (last ? take_done_flag(g, st, n) : launch::DoneFlag{}), ext_projective(g)));
     return KYB_OK;
   }
   const bool split = use_split(g, n);

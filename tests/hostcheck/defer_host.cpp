@@ -53,6 +53,8 @@ thread_local std::string g_err;
 int fail(int code, const char* msg) { g_err = msg; return code; }
 std::atomic<long> g_calls{0}, g_items{0};
 }  // namespace
+std::atomic<long> g_projective_flushes{0};
+void defer_projective(bool on) { if (on) ++g_projective_flushes; }      // (engine.hip: projective limbs for the calling thread's calls)
 #define ENTER() Ctx* ctx_ = cur(); Ctx& g = *ctx_
 #define ENTER_HOST() ENTER()
 
@@ -262,6 +264,27 @@ int main() {
     CHECK(g_calls - c0 == (shape == 0 ? 4 : 3), "one evaluation call for both chains, one multiplication, then an addition and its marshal / one sum");
     CHECK(got_enc(rand_share.h) == enc_of(rand_share.ext) && got_enc(long_share.h) == enc_of(long_share.ext) && got_enc(right.h) == enc_of(right.ext), "the results in between");
     CHECK(got_enc(left.h) == enc_of(left.ext) && g_calls - c0 == (shape == 0 ? 4 : 3), "the fixed-base product rode along (and everything was marshalled on the way)");
+  }
+  // Point::eq on a sum: no bytes are asked of that flush (its kernels hand over projective limbs, the comparison is the projective one); on two
+  // kernel results: the encodings, as before
+  {
+    uint8_t s1[32], s2[32], s3[32];
+    scalar_small(s1, 1234567); scalar_small(s2, 7654321); scalar_small(s3, 1234567 + 7654321);
+    Val a, b, sum, direct;
+    orc_mul_base(nullptr, a.ext, s1); orc_mul_base(nullptr, b.ext, s2); orc_mul_base(nullptr, direct.ext, s3); orc_add(sum.ext, a.ext, b.ext, 0);
+    CHECK(kyb_defer_mul_base(s1, &a.h) == KYB_OK && kyb_defer_mul_base(s2, &b.h) == KYB_OK && kyb_defer_mul_base(s3, &direct.h) == KYB_OK, "products");
+    CHECK(kyb_defer_add(a.h, b.h, 0, &sum.h) == KYB_OK, "sum");
+    const long p0 = g_projective_flushes, c0 = g_calls;
+    uint8_t eq = 2;
+    CHECK(kyb_defer_equal(direct.h, sum.h, &eq) == KYB_OK && eq == 1, "s1 B + s2 B == (s1 + s2) B");
+    CHECK(g_projective_flushes - p0 == 1 && g_calls - c0 == 3, "a comparison with a sum: one projective flush — products, addition, comparison");
+    CHECK(kyb_defer_equal(a.h, sum.h, &eq) == KYB_OK && eq == 0, "and an unequal pair, from the values at hand");
+    CHECK(got_enc(sum.h) == enc_of(sum.ext) && got_enc(a.h) == enc_of(a.ext), "bytes asked for afterwards");
+    Val c, d;
+    scalar_small(s1, 99); orc_mul_base(nullptr, c.ext, s1); orc_mul_base(nullptr, d.ext, s1);
+    CHECK(kyb_defer_mul_base(s1, &c.h) == KYB_OK && kyb_defer_mul_base(s1, &d.h) == KYB_OK, "two kernel results");
+    const long p1 = g_projective_flushes, c1 = g_calls;
+    CHECK(kyb_defer_equal(c.h, d.h, &eq) == KYB_OK && eq == 1 && g_projective_flushes == p1 && g_calls - c1 == 1, "two kernel results: their encodings, one call");
   }
   // recover_commit: one batch of products, one sum
   {
