@@ -73,6 +73,7 @@ struct StreamRes {
   hipStream_t stream = nullptr;
   uint4* ws = nullptr; uint4* proj = nullptr; size_t proj_items = 0; uint8_t* enc = nullptr; size_t enc_bytes = 0;
   uint32_t* part = nullptr; size_t part_items = 0;      // extended quads of a small linear combination's products
+  uint32_t* pieces = nullptr;                           // k_mul_coop in four workgroups per item: their records and arrival counters (zero between launches)
   uint8_t* pub_enc = nullptr; size_t pub_enc_items = 0;    // kyb_verify_points_batch: marshal_binary of the callers' public-key points
   uint32_t* msm = nullptr; size_t msm_points = 0;        // kyb_lincomb_public_batch over shared points: window bases + tables of the points (227,040 B per point)
   uint32_t* top_or = nullptr; unsigned top_seq = 0;     // two alternating words behind the projective staging records (k_mont_prep / k_mul_ladder)
@@ -783,6 +784,8 @@ int check_messages(const uint8_t* msgs, const uint32_t* msg_off, size_t n, size_
 
 // ---- per-stream scratch slots ---------------------------------------------------------------------------
 constexpr size_t MSM_BASE_WORDS = 43 * 40, MSM_TAB_WORDS = 43 * 32 * 40;      // per point
+constexpr size_t COOP_PIECES_ITEMS = 1024;             // most items a launch of k_mul_coop may cut into pieces (the per-CU limit times any CU count in use stays below)
+constexpr size_t COOP_PIECES_BYTES = KYB_COOP_PIECES_WORDS(COOP_PIECES_ITEMS) * sizeof(uint32_t);
 inline size_t proj_alloc_bytes(size_t items) { return items * 8 * sizeof(uint4) + 256; }
 inline size_t msm_alloc_bytes(size_t points) { return points * (MSM_BASE_WORDS + MSM_TAB_WORDS) * sizeof(uint32_t); }
 void free_slot(Ctx& g, StreamRes* r) {
@@ -791,6 +794,7 @@ void free_slot(Ctx& g, StreamRes* r) {
   if (r->proj) wipe_free_dev(g, r->proj, proj_alloc_bytes(r->proj_items));
   if (r->enc) wipe_free_dev(g, r->enc, r->enc_bytes);
   if (r->part) wipe_free_dev(g, r->part, r->part_items * 160);
+  if (r->pieces) wipe_free_dev(g, r->pieces, COOP_PIECES_BYTES);
   if (r->msm) ctx_free(g, r->msm, msm_alloc_bytes(r->msm_points));
   if (r->pub_enc) ctx_free(g, r->pub_enc, 32 * r->pub_enc_items);
   if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); (void)hipEventDestroy(r->ev_fork); (void)hipEventDestroy(r->ev_join); if (r->ev_mid) (void)hipEventDestroy(r->ev_mid); }
@@ -859,6 +863,14 @@ int ensure_ws_part(Ctx& g, StreamRes* r, size_t items) {
   hipError_t e = ctx_malloc(g, reinterpret_cast<void**>(&r->part), want * 160);
   if (e != hipSuccess) return fail(KYB_E_NOMEM, "product staging allocation", e);
   r->part_items = want;
+  return KYB_OK;
+}
+// records and arrival counters of k_mul_coop's four workgroups per item: allocated once per slot, zero from then on (the kernel clears what it used)
+int ensure_pieces(Ctx& g, StreamRes* r) {
+  if (r->pieces) return KYB_OK;
+  hipError_t e = ctx_malloc(g, reinterpret_cast<void**>(&r->pieces), COOP_PIECES_BYTES);
+  if (e != hipSuccess) { r->pieces = nullptr; return fail(KYB_E_NOMEM, "scratch of the four-piece multiplication", e); }
+  HIPCK(hipMemsetAsync(r->pieces, 0, COOP_PIECES_BYTES, r->stream));
   return KYB_OK;
 }
 int ensure_msm(Ctx& g, StreamRes* r, size_t points) {
@@ -1281,9 +1293,12 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
     const bool short_scalars = skip_hint >= 192 && (multipliers_public || g.opt_mul_short_scalars != 0);
     // (canonical scalars, all below 2^252: the top wavefront's piece starts four bits lower, as the batch ladder does)
     const int canon_skip = (skip_hint >= 4 && g.opt_ladder_skip_canonical != 0) ? 4 : 0;
+    // very few items: four single-wavefront workgroups share an item's scalar — while the 4 n workgroups find compute units of their own, or nearly
+    // (measured on 256 CUs, tools/mul_coop_pieces_probe.py: 165 against 195 us up to 32 items, 191 / 199 at 128, 210 / 200 at 192)
+    const bool in_pieces = !short_scalars && 4 * n <= coop_lim(g, g.opt_coop_verify_max) && n <= COOP_PIECES_ITEMS;
+    if (in_pieces) { int rc = ensure_pieces(g, r); if (rc) return rc; }
     LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, short_scalars ? (skip_hint > 255 ? 255 : skip_hint) : canon_skip, nullptr, 0, 0, take_done_flag(g, st, n), 0,
-                              (!short_scalars && 2 * n <= coop_lim(g, g.opt_coop_verify_max)) ? 4 : 1,   // very few items (measured: up to 256): four wavefronts share an item's scalar
-                              ext_projective(g)));
+                              in_pieces ? 4 : 1, ext_projective(g), nullptr, in_pieces ? r->pieces : nullptr));
     return KYB_OK;
   }
 #ifdef KYB_CROSSCHECK

@@ -318,19 +318,25 @@ __device__ __forceinline__ void coop_ladder_run(const lane_consts& c, const uint
   SZ = bperm(I_sw, st.SZ);
 }
 
-// One item per workgroup of `waves` wavefronts (1 or 4).  With four the scalar is cut into 64-bit pieces k = sum_j k_j 2^(64 j):
-// wavefront j doubles P 64 j times (Edwards doublings, 0.3 us each), runs a 64-step ladder for k_j on that point and recovers the full
-// point; wavefront 0 adds the four results and encodes.  The dependent chain of a one-item call is 192 doublings + 64 ladder steps +
-// 3 additions instead of 256 ladder steps (a doubling is half a step).  Same instruction stream for every scalar.
-__global__ void __launch_bounds__(256)
+// One item per wavefront — or, for very few items, FOUR single-wavefront workgroups per item: the scalar is cut into pieces
+// k = sum_j k_j 2^(b_j); workgroup j doubles P b_j times (Edwards doublings, 0.3 us each), runs a ladder of the piece's length for k_j on
+// that point, recovers the full point and leaves it in device scratch; the workgroup that arrives LAST (one atomic counter per item) adds
+// the four in a fixed order and encodes.  Measured in place, a doubling costs 0.79 of a ladder step (0.444 / 0.560 us:
+// tools/mul_coop_pieces_probe.py, profiles/r05/mul_coop_pieces.log), so the chain of the top piece is hardly shorter than its doublings:
+// with pieces of 144 / 66 / 31 / 15 bits from the bottom the four chains — b_j doublings, then the piece's steps — are as long as 144 / 180 /
+// 197 / 205 steps (the optimum, 203 / 43 / 8 / 2 bits, is 203), where one wavefront alone walks 256 and the four 64-bit pieces of rounds
+// 3 - 4 needed 216: one item 139 us (projective limbs out) against 154 before and 167 on one wavefront.  Separate workgroups land on
+// separate compute units.  The cut is public (the workgroup's number), the instruction stream the same for every scalar; nobody waits for
+// anybody: every workgroup runs to its end.
+constexpr int KYB_COOP_CUT1 = 144, KYB_COOP_CUT2 = 210, KYB_COOP_CUT3 = 241;
+__global__ void __launch_bounds__(64)
 k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc, int32_t* __restrict__ out_ext,
-           int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, size_t pt_mod, int waves, int ext_proj, uint32_t* __restrict__ part,
-           kyb::launch::DoneFlag df) {
-  __shared__ uint32_t sh_part[3 * 40];
-  const size_t i = blockIdx.x;
+           int skip_bits, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, size_t pt_mod, int pieces, int ext_proj, uint32_t* __restrict__ part,
+           uint32_t* pieces_buf, kyb::launch::DoneFlag df) {
+  const size_t i = pieces == 1 ? (size_t)blockIdx.x : (size_t)blockIdx.x >> 2;      // (the four pieces of an item: consecutive workgroups, dealt to different XCDs)
   if (i >= n) return;
-  const int wave = (int)(threadIdx.x >> 6);
-  KYB_COOP_CONSTS(c, 4);
+  const int piece = pieces == 1 ? 0 : (int)(blockIdx.x & 3u);
+  KYB_COOP_CONSTS(c, 1);
   const size_t ip = pt_mod ? i % pt_mod : i;                             // shared operands: item i multiplies point i mod pt_mod
 
   // ---- operands: the scalar replicated on all lanes, the point as a quad (X, Y, Z, T) straight from its 40 reference limbs ----
@@ -340,7 +346,7 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
   sc_effective(neg, mag, a);
   const uint32_t word = c.active ? (uint32_t)pts_ext[40 * ip + 10 * c.row + c.k] : 0u;
   cq PQ = cnorm(c, c.active ? word + (c.p2 << 3) : 0u);                 // fe_from_ref10: signed limb + 16p, one carry pass
-  if (waves == 1) {
+  if (pieces == 1) {
     uint32_t p_flags;
     const cq M = coop_mont_prep(c, PQ, p_flags);                         // u = U / W, v = V / W: no inversion in front of the ladder
     cq SX, SZ;
@@ -357,27 +363,54 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
     if (c.lane == 0) signal_done(df);
     return;
   }
-  // ---- four wavefronts: piece `wave` of the scalar on 2^(64 wave) P ----
+  // ---- four workgroups per item: bits [lo, hi) of the scalar on 2^lo P ----
+  const int lo = piece == 0 ? 0 : (piece == 1 ? KYB_COOP_CUT1 : (piece == 2 ? KYB_COOP_CUT2 : KYB_COOP_CUT3));
+  const int hi = piece == 0 ? KYB_COOP_CUT1 : (piece == 1 ? KYB_COOP_CUT2 : (piece == 2 ? KYB_COOP_CUT3 : 256));
+  const int len = hi - lo;
 #pragma unroll 1
-  for (int d = 0; d < 64 * wave; ++d) PQ = coop_dbl(c, PQ);
+  for (int d = 0; d < lo; ++d) PQ = coop_dbl(c, PQ);
+  // the piece as a number of its own: (mag >> lo) mod 2^len.  Word and bit offsets are the workgroup's (public); the words are picked by selects
+  uint32_t pm[8];
+  {
+    const int ws = lo >> 5, bs = lo & 31;
+    KYB_UNROLL for (int q = 0; q < 8; ++q) {
+      uint32_t w0 = 0, w1 = 0;
+      KYB_UNROLL for (int k = 0; k < 8; ++k) { w0 = (q + ws == k) ? mag[k] : w0; w1 = (q + ws + 1 == k) ? mag[k] : w1; }
+      const uint32_t v = bs ? ((w0 >> bs) | (w1 << (32 - bs))) : w0;
+      const int keep = len - 32 * q;                                      // bits of this word that belong to the piece
+      pm[q] = keep >= 32 ? v : (keep <= 0 ? 0u : (v & ((1u << keep) - 1u)));
+    }
+  }
   uint32_t p_flags;
   const cq M = coop_mont_prep(c, PQ, p_flags);
   cq SX, SZ;
-  coop_ladder_run(c, mag, wave == 3 ? skip_bits : 0, M, SX, SZ, 2 * wave + 1, 2 * wave);
-  uint32_t lowbit = 0;
-  KYB_UNROLL for (int q = 0; q < 8; q += 2) lowbit = (2 * wave == q) ? (mag[q] & 1u) : lowbit;
-  const cq R = coop_mont_recover(c, M, SX, SZ, p_flags, lowbit, 0u);
-  // (X : Y : Z) -> extended (X Z : Y Z : Z^2 : X Y)
+  // leading bits of the 256-bit register known to be zero for the whole launch (skip_bits) shorten the piece they reach into
+  int known_zero = hi - (256 - skip_bits);
+  known_zero = known_zero < 0 ? 0 : (known_zero > len ? len : known_zero);
+  coop_ladder_run(c, pm, 256 - len + known_zero, M, SX, SZ);
+  const cq R = coop_mont_recover(c, M, SX, SZ, p_flags, pm[0] & 1u, 0u);
+  // (X : Y : Z) -> extended (X Z : Y Z : Z^2 : X Y), into this item's four records; then the arrival counter
   const cq zz = bperm(rowperm_idx(c, 2, 2, 2, 2), R), xy = bperm(rowperm_idx(c, 0, 1, 2, 0), R), yy = bperm(rowperm_idx(c, 1, 1, 1, 1), R);
   cq q = cmul4(c, xy, c.row == 3 ? yy : zz);
-  if (wave > 0 && c.active) sh_part[(wave - 1) * 40 + 10 * c.row + c.k] = q;
-  __syncthreads();
-  if (wave != 0) return;
+  uint32_t* mine = pieces_buf + (4 * i + (size_t)piece) * 40;
+  uint32_t* arrived = pieces_buf + 160 * n + i;                           // (behind the n * 4 records; zero between launches)
+  if (c.active) mine[10 * c.row + c.k] = q;
+  __threadfence();                                                         // release: the record before the count, device-wide (the others are on other XCDs)
+  uint32_t before = 0;
+  if (c.lane == 0) before = atomicAdd(arrived, 1u);
+  before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+  if (before != 3u) return;                                                // not the last: done
+  __threadfence();                                                         // acquire: the three other records
+  // the same sum whoever comes last: ((piece 0 + piece 1) + piece 2) + piece 3; the records held multiples of a secret — cleared here
+  const uint32_t* rec = pieces_buf + 4 * i * 40;
+  q = c.active ? __builtin_nontemporal_load(rec + 10 * c.row + c.k) : 0u;
 #pragma unroll 1
   for (int w = 1; w < 4; ++w) {
-    const cq o = c.active ? sh_part[(w - 1) * 40 + 10 * c.row + c.k] : 0u;
+    const cq o = c.active ? __builtin_nontemporal_load(rec + 40 * w + 10 * c.row + c.k) : 0u;
     q = coop_add(c, q, coop_to_cached(c, o));
   }
+  if (c.lane < 40u) { KYB_UNROLL for (int w = 0; w < 4; ++w) pieces_buf[(4 * i + (size_t)w) * 40 + c.lane] = 0u; }
+  if (c.lane == 0) *arrived = 0u;
   coop_finish(c, q, neg, out_enc, out_ext, i, proj, proj_stride, proj_offset, ext_proj != 0, true);
   if (c.lane == 0) signal_done(df);
 }
@@ -1050,9 +1083,10 @@ hipError_t poly_eval_seg(hipStream_t st, const int32_t* commits, int t, const ui
   return hipGetLastError();
 }
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
-                    uint4* proj, size_t proj_stride, size_t proj_offset, DoneFlag df, size_t pt_mod, int waves, bool ext_proj, uint32_t* part) {
-  hipLaunchKernelGGL(k_mul_coop, dim3((unsigned)n), dim3(64u * (unsigned)waves), 0, st, sc, pext, n, oenc, oext, skip_bits, proj, proj_stride, proj_offset, pt_mod,
-                     waves, ext_proj ? 1 : 0, part, df);
+                    uint4* proj, size_t proj_stride, size_t proj_offset, DoneFlag df, size_t pt_mod, int pieces, bool ext_proj, uint32_t* part, uint32_t* pieces_buf) {
+  if (pieces != 1 && (pieces != 4 || pieces_buf == nullptr || part != nullptr)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_mul_coop, dim3((unsigned)(n * (size_t)pieces)), dim3(64u), 0, st, sc, pext, n, oenc, oext, skip_bits, proj, proj_stride, proj_offset, pt_mod,
+                     pieces, ext_proj ? 1 : 0, part, pieces_buf, df);
   return hipGetLastError();
 }
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* table_coop,

@@ -108,8 +108,11 @@ hipError_t poly_eval_seg(hipStream_t st, const int32_t* commits, int t, const ui
                          uint32_t* part, uint8_t* oenc, int32_t* oext, DoneFlag df = DoneFlag{}, bool ext_proj = false);
 hipError_t mul_coop(hipStream_t st, const uint8_t* sc, const int32_t* pext, size_t n, uint8_t* oenc, int32_t* oext, int skip_bits,
                     uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, DoneFlag df = DoneFlag{}, size_t pt_mod = 0,
-                    int waves = 1, bool ext_proj = false, uint32_t* part = nullptr);      // waves: 1, or 4 wavefronts per item (64-bit pieces of the scalar);
-                    // ext_proj: option ext.projective; part != nullptr (waves == 1): the product goes there as an extended quad (40 words) for sum_coop
+                    int pieces = 1, bool ext_proj = false, uint32_t* part = nullptr, uint32_t* pieces_buf = nullptr);
+                    // pieces: 1, or 4 single-wavefront workgroups per item (the scalar in four pieces, the last to arrive adds them): then pieces_buf =
+                    // KYB_COOP_PIECES_WORDS(n) words of device scratch, ZERO between launches (the kernel leaves it so);
+                    // ext_proj: option ext.projective; part != nullptr (pieces == 1): the product goes there as an extended quad (40 words) for sum_coop
+#define KYB_COOP_PIECES_WORDS(n) ((size_t)(n) * 161)      /* four 40-word records and one arrival counter per item */
 // out[g] = sum of t points per group, from extended quads (part) or reference limbs (pts_ext)
 hipError_t sum_coop(hipStream_t st, const uint32_t* part, const int32_t* pts_ext, size_t m, size_t t, uint8_t* oenc, int32_t* oext, bool ext_proj,
                     DoneFlag df = DoneFlag{});
