@@ -273,13 +273,14 @@ __device__ __forceinline__ cq coop_dbl(const lane_consts& c, cq h) {
   const cq Q = csq4(c, r3 ? xpy : a);                                             // (XX, YY, ZZ, (X+Y)^2)
   const cq xx = bperm(rowperm_idx(c, 0, 0, 0, 0), Q), yy = bperm(rowperm_idx(c, 1, 1, 1, 1), Q);
   const cq zz = bperm(rowperm_idx(c, 2, 2, 2, 2), Q), aa = bperm(rowperm_idx(c, 3, 3, 3, 3), Q);
-  // the four combinations side by side (no carry pass waits for another): 4p - (yy + xx) >= 0 limb-wise; T3 stays lazy (<= 5T, a
-  // second operand: columns stay below 2^63)
-  const cq ypx = cadd(yy, xx);
-  const cq Y3 = cnorm(c, ypx), Z3 = cnorm(c, csub(c, yy, xx));
-  const cq X3 = cnorm(c, cadd(aa, (c.p2 << 1) - ypx));
+  // every row picks its first operand among the raw combinations and ONE carry pass makes it tight (a lone wavefront pays per instruction, not
+  // per dependency: three passes side by side cost three times one); the second operands stay lazy: Y3 <= 2T, Z3 <= 3T, T3 <= 5T (columns
+  // stay below 2^63).  4p - (yy + xx) >= 0 limb-wise.
+  const cq Y3 = cadd(yy, xx);
+  const cq Z3 = csub(c, yy, xx);
+  const cq X3 = cadd(aa, (c.p2 << 1) - Y3);
   const cq T3 = csub(c, cadd(cadd(zz, zz), xx), yy);
-  return cmul4(c, (r0 || r3) ? X3 : (r1 ? Y3 : Z3), (r0 || r2) ? T3 : (r1 ? Z3 : Y3));      // (X3 T3, Y3 Z3, Z3 T3, X3 Y3)
+  return cmul4(c, cnorm(c, (r0 || r3) ? X3 : (r1 ? Y3 : Z3)), (r0 || r2) ? T3 : (r1 ? Z3 : Y3));      // (X3 T3, Y3 Z3, Z3 T3, X3 Y3)
 }
 
 // The whole ladder: UWQ = the base point's u as U1 (row 0) / W1 (row 2), tight; |scalar| = mag (or its words w_hi .. w_lo taken as a
