@@ -286,6 +286,35 @@ int main() {
     const long p1 = g_projective_flushes, c1 = g_calls;
     CHECK(kyb_defer_equal(c.h, d.h, &eq) == KYB_OK && eq == 1 && g_projective_flushes == p1 && g_calls - c1 == 1, "two kernel results: their encodings, one call");
   }
+  // Rabin's verify_deal (vss/rabin/vss.rs: fi G + gi H == commit_poly.eval(i)): a fixed-base product riding with the variable-base one, their sum,
+  // one Horner chain, one comparison whose left operand is a plain sum (so: nothing marshalled, projective comparison) — four engine calls
+  {
+    const size_t t = 9;
+    uint8_t hs[32]; scalar_small(hs, 424242);
+    Val H; orc_mul_base(nullptr, H.ext, hs); CHECK(kyb_defer_input(H.ext, &H.h) == KYB_OK, "H");
+    // commitments c_j = f_j G + g_j H, share (f(i), g(i)) at index i
+    const uint32_t index = 5;
+    std::vector<Val> commits(t);
+    uint64_t fi = 0, gi = 0, xp = 1;
+    for (size_t j = 0; j < t; ++j) {
+      const uint32_t fj = 1000 + 7 * (uint32_t)j, gj = 2000 + 11 * (uint32_t)j;
+      uint8_t a[32], b[32]; scalar_small(a, fj); scalar_small(b, gj);
+      int32_t fg[40], gh[40];
+      orc_mul_base(nullptr, fg, a); orc_mul(nullptr, gh, b, H.ext); orc_add(commits[j].ext, fg, gh, 0);
+      CHECK(kyb_defer_input(commits[j].ext, &commits[j].h) == KYB_OK, "commitment");
+      fi += fj * xp; gi += gj * xp; xp *= (index + 1);          // (index + 1)^8 * 2100 < 2^32: no reduction needed
+    }
+    uint8_t fs[32] = {0}, gs[32] = {0}; memcpy(fs, &fi, 8); memcpy(gs, &gi, 8);
+    const long c0 = g_calls, p0 = g_projective_flushes;
+    uint64_t fig, gih, ci;
+    CHECK(kyb_defer_mul_base(fs, &fig) == KYB_OK && kyb_defer_mul(gs, H.h, &gih) == KYB_OK && kyb_defer_add(fig, gih, 0, &ci) == KYB_OK, "fi G + gi H");
+    uint8_t x[32]; scalar_small(x, index + 1);
+    uint64_t v; CHECK(kyb_defer_null(&v) == KYB_OK, "null");
+    for (size_t j = t; j-- > 0;) { uint64_t m, a; CHECK(kyb_defer_mul(x, v, &m) == KYB_OK && kyb_defer_add(m, commits[j].h, 0, &a) == KYB_OK, "eval"); v = a; }
+    uint8_t eq = 2;
+    CHECK(kyb_defer_equal(ci, v, &eq) == KYB_OK && eq == 1, "the deal verifies");
+    CHECK(g_calls - c0 == 4 && g_projective_flushes - p0 == 1, "products in one call, the chain in one, the sum, the comparison");
+  }
   // recover_commit: one batch of products, one sum
   {
     const size_t t = 9;
