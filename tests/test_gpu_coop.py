@@ -80,6 +80,50 @@ def test_coop_variable_base_matches_oracle(coop_engine, oracle):
     assert np.array_equal(eng.mul(s, pts_ext=b), oracle.mul_batch(s, b, nthreads=8))
 
 
+def test_variable_base_in_four_pieces_around_the_cuts(engine, oracle):
+    """k_mul_coop with an item's scalar cut at bits 144 / 210 / 241 and every piece on a workgroup of its own (4 n <= coop.verify_max_items): scalars
+    whose pieces are zero, one, all ones, and that straddle a cut — on ordinary points, the neutral element, small-order points and projective sums —
+    against the oracle and against the one-wavefront form; the arrival counters and records in device scratch must be left clean (call after call, sizes
+    going up and down)."""
+    import kyber_rs_amd
+    cuts = (144, 210, 241)
+    vals = [0, 1, 2, 8, synth.L, synth.L - 1, synth.L + 1, 8 * synth.L, (1 << 255) - 19, (1 << 256) - 1, 1 << 255, (1 << 252) + 1]
+    for c in cuts:
+        vals += [1 << c, (1 << c) - 1, (1 << c) + 1, 1 << (c - 1), ((1 << 256) - 1) ^ ((1 << c) - 1), (1 << c) | 1, 3 << (c - 1)]
+    vals += [(1 << 144) | (1 << 241), ((1 << 210) - 1) ^ ((1 << 144) - 1), ((1 << 241) - 1) ^ ((1 << 210) - 1), 0xf << 252, (1 << 253) - 1]
+    sc = np.frombuffer(b"".join((v % (1 << 256)).to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(-1, 32)
+    n = len(sc)
+    assert 4 * n <= engine.get_option("coop.verify_max_items")           # the whole set travels in pieces
+    ordinary = oracle.mul_base_ext_batch(synth.scalars(n, 811, b"point"))
+    sums = np.stack([oracle.add(x, y) for x, y in zip(ordinary, np.roll(ordinary, 3, axis=0))])      # Z != 1
+    weak = [oracle.decode(k)[0] for k in oracle.weak_keys() if oracle.decode(k)[1]]
+    special = np.stack([oracle.null()] + weak)
+    keep = engine.get_option("coop.verify_max_items")
+    for pts in (ordinary, sums, np.stack([special[i % len(special)] for i in range(n)])):
+        want = oracle.mul_batch(sc, pts, nthreads=8)
+        got = engine.mul(sc, pts_ext=pts)
+        assert np.array_equal(got, want)
+        engine.set_option("coop.verify_max_items", 0)                     # one wavefront per item
+        try:
+            assert np.array_equal(engine.mul(sc, pts_ext=pts), want)
+        finally:
+            engine.set_option("coop.verify_max_items", keep)
+    # sizes up and down through the hand-over (128 | 129) and back to one item: nothing of an earlier call may be left in the scratch
+    for m in (1, 128, 3, 129, 2, 64, 1):
+        s, p = np.resize(sc, (m, 32)), np.resize(ordinary, (m, 40))
+        assert np.array_equal(engine.mul(s, pts_ext=p), oracle.mul_batch(s, p, nthreads=8)), m
+    # projective limbs out: the same point whichever workgroup comes last (the four are added in a fixed order)
+    eng = kyber_rs_amd.Engine(0, private=True)
+    try:
+        eng.set_option("ext.projective", 1)
+        first = eng.mul(sc, pts_ext=ordinary, ext_only=True)
+        for _ in range(5):
+            assert np.array_equal(eng.mul(sc, pts_ext=ordinary, ext_only=True), first)
+        assert np.array_equal(eng.encode(first), oracle.mul_batch(sc, ordinary, nthreads=8))
+    finally:
+        eng.close()
+
+
 def test_coop_decode_sign_verify_match_oracle(coop_xengine, oracle):
     coop_engine = coop_xengine
     """the small-batch forms of unmarshal_binary (cooperative square-root chain), Schnorr signing and both verification
