@@ -58,6 +58,12 @@
  *   kyb_xxx_batch      host pointers; H2D copy, kernel, D2H copy, synchronous.
  *   kyb_xxx_batch_dev  device pointers (HBM-resident batches); asynchronous on `stream`
  *                      (a hipStream_t passed as void*, NULL = the engine's own stream).
+ *                      ORDERING IS THE CALLER'S: the kernels are ordered with whatever else is queued on `stream` and with nothing
+ *                      else.  The engine's own stream is created hipStreamNonBlocking: it does NOT wait for the device's null stream
+ *                      (nor the null stream for it), so a caller that passes NULL must have FINISHED producing the operands
+ *                      (hipStreamSynchronize / an event it waited for) before the call, and must kyb_sync(NULL) before it reads
+ *                      the results or overwrites / frees any operand.  A caller whose producers and consumers run on a stream
+ *                      passes THAT stream; for the null stream, whose handle is also NULL, pass KYB_STREAM_LEGACY.
  *
  * There is NO CPU implementation behind this ABI: without a usable gfx950 device kyb_init fails
  * with KYB_E_NO_DEVICE and every other call returns KYB_E_NOT_INIT.
@@ -71,6 +77,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* `stream` argument of the _dev calls and kyb_sync: the device's null (legacy default) stream, = hipStreamLegacy */
+#define KYB_STREAM_LEGACY ((void*)1)
 
 #define KYB_OK 0
 #define KYB_E_NOT_INIT (-1)
@@ -164,8 +173,9 @@ int kyb_group_verify_batch(kyb_group* g, const uint8_t* pubs, const uint8_t* msg
                            size_t n, int flavor, uint8_t* status);
 /* Device-resident shards: argument r of every array is rank r's pointer / item count, the memory on rank r's GPU (16-byte aligned,
  * as for the kyb_*_dev calls).  The launches are asynchronous on each context's own stream — one calling thread queues the work of
- * all GPUs — and kyb_group_sync waits for everything queued on every rank.  Arrays that are NULL as a whole are absent for all
- * ranks (out_ext, ok; exactly one of pts_enc / pts_ext). */
+ * all GPUs — and kyb_group_sync waits for everything queued on every rank.  Those streams are non-blocking (ordered with no other
+ * stream of the process): the caller has FINISHED producing the shards before the call and reads results after kyb_group_sync.
+ * Arrays that are NULL as a whole are absent for all ranks (out_ext, ok; exactly one of pts_enc / pts_ext). */
 int kyb_group_mul_base_batch_dev(kyb_group* g, const uint8_t* const* scalars, const size_t* n, uint8_t* const* out_enc, int32_t* const* out_ext);
 int kyb_group_mul_batch_dev(kyb_group* g, const uint8_t* const* scalars, const uint8_t* const* pts_enc, const int32_t* const* pts_ext,
                             const size_t* n, uint8_t* const* out_enc, int32_t* const* out_ext, uint8_t* const* ok);

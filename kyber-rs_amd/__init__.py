@@ -73,6 +73,19 @@ class KyberHipError(RuntimeError):
     pass
 
 
+STREAM_ENGINE = 0     # C ABI: NULL = the context's own non-blocking stream
+STREAM_LEGACY = 1     # C ABI: KYB_STREAM_LEGACY = the device's null stream (hipStreamLegacy)
+
+
+def _torch_current_stream(device_index):
+    """handle of torch's current stream on that device as the C ABI names it, or None when torch is not in the process / has no GPU"""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is None or device_index is None or not torch.cuda.is_available():
+        return None
+    return int(torch.cuda.current_stream(device_index).cuda_stream) or STREAM_LEGACY
+
+
 _lib = None
 _xlib = None
 
@@ -414,8 +427,16 @@ class Engine:
         _check(self.lib.kyb_profile_read(ids, ms, cap, ctypes.byref(cnt)), "kyb_profile_read")
         return [(self.lib.kyb_kernel_name(ids[i]).decode(), float(ms[i])) for i in range(cnt.value)]
 
-    def sync(self, stream: int = 0) -> None:
-        _check(self.lib.kyb_sync(ctypes.c_void_p(stream)), "kyb_sync")
+    def sync(self, stream: Optional[int] = None) -> None:
+        """wait for the work queued by this engine: stream=None = both the engine's own stream and the stream the _dev methods
+        launch on by default (torch's current stream of the engine's device); an explicit handle = that stream (0: the engine's own)"""
+        if stream is not None:
+            _check(self.lib.kyb_sync(ctypes.c_void_p(stream)), "kyb_sync")
+            return
+        _check(self.lib.kyb_sync(None), "kyb_sync")
+        cur = _torch_current_stream(self.device)
+        if cur is not None:
+            _check(self.lib.kyb_sync(ctypes.c_void_p(cur)), "kyb_sync")
 
     def shutdown(self) -> None:
         self.lib.kyb_shutdown()
@@ -531,14 +552,14 @@ class Engine:
         _check(self.lib.kyb_verify_points_batch(_ptr(px), _ptr(blob), _ptr(off), _ptr(ss), n, flavor, _ptr(st)), "kyb_verify_points_batch")
         return st
 
-    def verify_points_dev(self, pubs_ext, msgs, msg_off, sigs, status, flavor: int = 0, stream: int = 0) -> None:
+    def verify_points_dev(self, pubs_ext, msgs, msg_off, sigs, status, flavor: int = 0, stream: Optional[int] = None) -> None:
         n = pubs_ext.numel() // 40
-        _check(self.lib.kyb_verify_points_batch_dev(self._dp(pubs_ext), self._dp(msgs), self._dp(msg_off), self._dp(sigs), n, flavor, self._dp(status), ctypes.c_void_p(stream)),
+        _check(self.lib.kyb_verify_points_batch_dev(self._dp(pubs_ext), self._dp(msgs), self._dp(msg_off), self._dp(sigs), n, flavor, self._dp(status), self._st(stream, pubs_ext)),
                "kyb_verify_points_batch_dev")
 
-    def verify_dev(self, pubs, msgs, msg_off, sigs, status, flavor: int = 0, stream: int = 0) -> None:
+    def verify_dev(self, pubs, msgs, msg_off, sigs, status, flavor: int = 0, stream: Optional[int] = None) -> None:
         n = pubs.numel() // 32
-        _check(self.lib.kyb_verify_batch_dev(self._dp(pubs), self._dp(msgs), self._dp(msg_off), self._dp(sigs), n, flavor, self._dp(status), ctypes.c_void_p(stream)), "kyb_verify_batch_dev")
+        _check(self.lib.kyb_verify_batch_dev(self._dp(pubs), self._dp(msgs), self._dp(msg_off), self._dp(sigs), n, flavor, self._dp(status), self._st(stream, pubs)), "kyb_verify_batch_dev")
 
     def pubpoly_eval(self, commits_ext, indices, want_ext: bool = False, ext_only: bool = False):
         """PubPoly::eval of one polynomial (t x 40 limbs) at every index of `indices` (x = index + 1)"""
@@ -768,54 +789,69 @@ class Engine:
         _check(self.lib.kyb_base_table_import(_ptr(t)), "kyb_base_table_import")
 
     # ---- device-pointer API (torch tensors resident in HBM; asynchronous on `stream`) -------------
+    # stream=None (the default): the kernels are queued on torch's CURRENT stream of the tensors' device — the stream on which torch
+    # produced the operands and will consume the results, so the call is ordered with both like any torch operation (when that is the
+    # device's null stream, whose handle 0 means "the engine's own stream" in the C ABI, it is named as KYB_STREAM_LEGACY).
+    # An explicit handle is passed through: 0 = the engine's own NON-BLOCKING stream, which is ordered with nothing — the caller then
+    # synchronises its producers before the call and the engine (sync()) before it reads results or reuses the buffers.
     @staticmethod
     def _dp(t):
         return None if t is None else ctypes.c_void_p(t.data_ptr())
 
-    def mul_base_dev(self, scalars, out_enc=None, out_ext=None, stream: int = 0) -> None:
-        n = scalars.numel() // 32
-        _check(self.lib.kyb_mul_base_batch_dev(self._dp(scalars), n, self._dp(out_enc), self._dp(out_ext), ctypes.c_void_p(stream)), "kyb_mul_base_batch_dev")
+    @staticmethod
+    def _st(stream, t):
+        if stream is not None:
+            return ctypes.c_void_p(stream)
+        dev = getattr(t, "device", None)
+        cur = _torch_current_stream(dev.index if getattr(dev, "type", None) == "cuda" else None) if dev is not None else None
+        if cur is None:
+            raise KyberHipError("a _dev call needs torch device tensors (to launch on torch's current stream) or an explicit stream handle")
+        return ctypes.c_void_p(cur)
 
-    def mul_dev(self, scalars, pts_ext=None, pts_enc=None, out_enc=None, out_ext=None, ok=None, stream: int = 0) -> None:
+    def mul_base_dev(self, scalars, out_enc=None, out_ext=None, stream: Optional[int] = None) -> None:
         n = scalars.numel() // 32
-        _check(self.lib.kyb_mul_batch_dev(self._dp(scalars), self._dp(pts_enc), self._dp(pts_ext), n, self._dp(out_enc), self._dp(out_ext), self._dp(ok), ctypes.c_void_p(stream)), "kyb_mul_batch_dev")
+        _check(self.lib.kyb_mul_base_batch_dev(self._dp(scalars), n, self._dp(out_enc), self._dp(out_ext), self._st(stream, scalars)), "kyb_mul_base_batch_dev")
 
-    def lincomb_dev(self, scalars, m: int, t: int, pts_ext=None, pts_enc=None, shared: bool = False, out_enc=None, out_ext=None, ok=None, stream: int = 0) -> None:
+    def mul_dev(self, scalars, pts_ext=None, pts_enc=None, out_enc=None, out_ext=None, ok=None, stream: Optional[int] = None) -> None:
+        n = scalars.numel() // 32
+        _check(self.lib.kyb_mul_batch_dev(self._dp(scalars), self._dp(pts_enc), self._dp(pts_ext), n, self._dp(out_enc), self._dp(out_ext), self._dp(ok), self._st(stream, scalars)), "kyb_mul_batch_dev")
+
+    def lincomb_dev(self, scalars, m: int, t: int, pts_ext=None, pts_enc=None, shared: bool = False, out_enc=None, out_ext=None, ok=None, stream: Optional[int] = None) -> None:
         _check(self.lib.kyb_lincomb_batch_dev(self._dp(scalars), self._dp(pts_enc), self._dp(pts_ext), int(shared), m, t,
-                                              self._dp(out_enc), self._dp(out_ext), self._dp(ok), ctypes.c_void_p(stream)), "kyb_lincomb_batch_dev")
+                                              self._dp(out_enc), self._dp(out_ext), self._dp(ok), self._st(stream, scalars)), "kyb_lincomb_batch_dev")
 
-    def add_dev(self, a_ext, b_ext, out_ext, subtract: bool = False, stream: int = 0) -> None:
+    def add_dev(self, a_ext, b_ext, out_ext, subtract: bool = False, stream: Optional[int] = None) -> None:
         n = a_ext.numel() // 40
-        _check(self.lib.kyb_add_batch_dev(self._dp(a_ext), self._dp(b_ext), n, self._dp(out_ext), int(subtract), ctypes.c_void_p(stream)), "kyb_add_batch_dev")
+        _check(self.lib.kyb_add_batch_dev(self._dp(a_ext), self._dp(b_ext), n, self._dp(out_ext), int(subtract), self._st(stream, a_ext)), "kyb_add_batch_dev")
 
-    def equal_dev(self, a_ext, b_ext, eq, stream: int = 0) -> None:
+    def equal_dev(self, a_ext, b_ext, eq, stream: Optional[int] = None) -> None:
         n = a_ext.numel() // 40
-        _check(self.lib.kyb_equal_batch_dev(self._dp(a_ext), self._dp(b_ext), n, self._dp(eq), ctypes.c_void_p(stream)), "kyb_equal_batch_dev")
+        _check(self.lib.kyb_equal_batch_dev(self._dp(a_ext), self._dp(b_ext), n, self._dp(eq), self._st(stream, a_ext)), "kyb_equal_batch_dev")
 
-    def point_checks_dev(self, flags, enc=None, pts_ext=None, stream: int = 0) -> None:
+    def point_checks_dev(self, flags, enc=None, pts_ext=None, stream: Optional[int] = None) -> None:
         n = enc.numel() // 32 if enc is not None else pts_ext.numel() // 40
-        _check(self.lib.kyb_point_checks_batch_dev(self._dp(enc), self._dp(pts_ext), n, self._dp(flags), ctypes.c_void_p(stream)), "kyb_point_checks_batch_dev")
+        _check(self.lib.kyb_point_checks_batch_dev(self._dp(enc), self._dp(pts_ext), n, self._dp(flags), self._st(stream, flags)), "kyb_point_checks_batch_dev")
 
-    def encode_dev(self, pts_ext, out_enc, stream: int = 0) -> None:
+    def encode_dev(self, pts_ext, out_enc, stream: Optional[int] = None) -> None:
         n = pts_ext.numel() // 40
-        _check(self.lib.kyb_encode_batch_dev(self._dp(pts_ext), n, self._dp(out_enc), ctypes.c_void_p(stream)), "kyb_encode_batch_dev")
+        _check(self.lib.kyb_encode_batch_dev(self._dp(pts_ext), n, self._dp(out_enc), self._st(stream, pts_ext)), "kyb_encode_batch_dev")
 
-    def decode_dev(self, enc, out_ext, ok=None, stream: int = 0) -> None:
+    def decode_dev(self, enc, out_ext, ok=None, stream: Optional[int] = None) -> None:
         n = enc.numel() // 32
-        _check(self.lib.kyb_decode_batch_dev(self._dp(enc), n, self._dp(out_ext), self._dp(ok), ctypes.c_void_p(stream)), "kyb_decode_batch_dev")
+        _check(self.lib.kyb_decode_batch_dev(self._dp(enc), n, self._dp(out_ext), self._dp(ok), self._st(stream, enc)), "kyb_decode_batch_dev")
 
-    def sign_dev(self, x, k, msgs, msg_off, sig, stream: int = 0, pubs=None) -> None:
+    def sign_dev(self, x, k, msgs, msg_off, sig, stream: Optional[int] = None, pubs=None) -> None:
         n = x.numel() // 32
         if pubs is not None:
-            _check(self.lib.kyb_schnorr_sign_keyed_batch_dev(self._dp(x), self._dp(pubs), self._dp(k), self._dp(msgs), self._dp(msg_off), n, self._dp(sig), ctypes.c_void_p(stream)), "kyb_schnorr_sign_keyed_batch_dev")
+            _check(self.lib.kyb_schnorr_sign_keyed_batch_dev(self._dp(x), self._dp(pubs), self._dp(k), self._dp(msgs), self._dp(msg_off), n, self._dp(sig), self._st(stream, x)), "kyb_schnorr_sign_keyed_batch_dev")
             return
-        _check(self.lib.kyb_schnorr_sign_batch_dev(self._dp(x), self._dp(k), self._dp(msgs), self._dp(msg_off), n, self._dp(sig), ctypes.c_void_p(stream)), "kyb_schnorr_sign_batch_dev")
+        _check(self.lib.kyb_schnorr_sign_batch_dev(self._dp(x), self._dp(k), self._dp(msgs), self._dp(msg_off), n, self._dp(sig), self._st(stream, x)), "kyb_schnorr_sign_batch_dev")
 
-    def base_table_export_dev(self, dst, stream: int = 0) -> None:
-        _check(self.lib.kyb_base_table_export_dev(self._dp(dst), ctypes.c_void_p(stream)), "kyb_base_table_export_dev")
+    def base_table_export_dev(self, dst, stream: Optional[int] = None) -> None:
+        _check(self.lib.kyb_base_table_export_dev(self._dp(dst), self._st(stream, dst)), "kyb_base_table_export_dev")
 
-    def base_table_import_dev(self, src, stream: int = 0) -> None:
-        _check(self.lib.kyb_base_table_import_dev(self._dp(src), ctypes.c_void_p(stream)), "kyb_base_table_import_dev")
+    def base_table_import_dev(self, src, stream: Optional[int] = None) -> None:
+        _check(self.lib.kyb_base_table_import_dev(self._dp(src), self._st(stream, src)), "kyb_base_table_import_dev")
 
 
 class Group:
@@ -852,13 +888,32 @@ class Group:
             return None
         return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
+    @staticmethod
+    def _producers_done(*tensor_lists) -> None:
+        """The group's calls run on every rank's OWN non-blocking stream, which is ordered with no torch stream: whatever torch has queued on
+        the current stream of the shards' devices (the kernels that wrote the operands, a zero_() of an output) is waited for on the host
+        before the shards are handed over.  (sync() is the other half: results are read after it.)"""
+        import sys
+        torch = sys.modules.get("torch")
+        if torch is None:
+            return
+        seen = set()
+        for lst in tensor_lists:
+            for t in lst or ():
+                dev = getattr(t, "device", None)
+                if dev is not None and dev.type == "cuda" and dev.index not in seen:
+                    seen.add(dev.index)
+                    torch.cuda.current_stream(dev).synchronize()
+
     def mul_dev(self, scalars, pts_ext=None, pts_enc=None, out_enc=None, out_ext=None, ok=None) -> None:
         """kyb_group_mul_batch_dev: device-resident shards, asynchronous on every rank's own stream (sync() waits)"""
+        self._producers_done(scalars, pts_ext, pts_enc, out_enc, out_ext, ok)
         n = (ctypes.c_size_t * self.size)(*[t.numel() // 32 for t in scalars])
         _check(self.lib.kyb_group_mul_batch_dev(self.handle, self._ptr_array(scalars), self._ptr_array(pts_enc), self._ptr_array(pts_ext), n,
                                                 self._ptr_array(out_enc), self._ptr_array(out_ext), self._ptr_array(ok)), "kyb_group_mul_batch_dev", self.lib)
 
     def mul_base_dev(self, scalars, out_enc=None, out_ext=None) -> None:
+        self._producers_done(scalars, out_enc, out_ext)
         n = (ctypes.c_size_t * self.size)(*[t.numel() // 32 for t in scalars])
         _check(self.lib.kyb_group_mul_base_batch_dev(self.handle, self._ptr_array(scalars), n, self._ptr_array(out_enc), self._ptr_array(out_ext)),
                "kyb_group_mul_base_batch_dev", self.lib)

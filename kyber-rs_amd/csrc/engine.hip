@@ -236,13 +236,17 @@ struct ProfScope {
 };
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-inline hipStream_t pick(Ctx& g, void* s) { return s ? reinterpret_cast<hipStream_t>(s) : g.stream; }
+// NULL = the context's own (non-blocking) stream; KYB_STREAM_LEGACY = the device's null stream, whatever value the runtime gives that name
+inline hipStream_t pick(Ctx& g, void* s) { return !s ? g.stream : s == KYB_STREAM_LEGACY ? hipStreamLegacy : reinterpret_cast<hipStream_t>(s); }
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // device buffers that held caller data (possibly private keys and nonces) are cleared before they go back to the runtime
+// (callers have waited for the buffer's last user; the fill runs on the engine's own stream and is waited for there — a plain hipMemset
+// would go through the device's null stream and stall every blocking stream of the process behind it)
 void wipe_free_dev(Ctx& g, void* p, size_t bytes) {
   if (!p) return;
-  (void)hipMemset(p, 0, bytes);
+  if (g.stream && hipMemsetAsync(p, 0, bytes, g.stream) == hipSuccess) (void)hipStreamSynchronize(g.stream);
+  else (void)hipMemset(p, 0, bytes);           // context being torn down before its stream existed
   ctx_free(g, p, bytes);
 }
 
@@ -870,7 +874,12 @@ int ensure_pieces(Ctx& g, StreamRes* r) {
   if (r->pieces) return KYB_OK;
   hipError_t e = ctx_malloc(g, reinterpret_cast<void**>(&r->pieces), COOP_PIECES_BYTES);
   if (e != hipSuccess) { r->pieces = nullptr; return fail(KYB_E_NOMEM, "scratch of the four-piece multiplication", e); }
-  HIPCK(hipMemsetAsync(r->pieces, 0, COOP_PIECES_BYTES, r->stream));
+  e = hipMemsetAsync(r->pieces, 0, COOP_PIECES_BYTES, r->stream);
+  if (e != hipSuccess) {       // never leave a registered buffer whose arrival counters are not zero: no workgroup would ever be the last to arrive
+    ctx_free(g, r->pieces, COOP_PIECES_BYTES);
+    r->pieces = nullptr;
+    return fail(KYB_E_HIP, "hipMemsetAsync (scratch of the four-piece multiplication)", e);
+  }
   return KYB_OK;
 }
 int ensure_msm(Ctx& g, StreamRes* r, size_t points) {

@@ -4,6 +4,8 @@ inputs — bit-exact 32-byte encodings / 64-byte signatures (integer work: no to
 Sizes: oracle-checked cases finish in seconds; BASELINE.json's full sizes (2^20 / 2^18) are covered by
 size-independent properties (fixed-base == variable-base on B, DH commutativity, decode(encode) round
 trip, sign == golden) plus an oracle-checked random sample."""
+import contextlib
+import ctypes
 import gzip
 import hashlib
 import json
@@ -1046,9 +1048,14 @@ def test_cfg5_whole_2_24_on_one_gpu(engine, oracle):
     bext = torch.from_numpy(oracle.base()).to(dev).repeat(n, 1)
     assert bext.numel() * 4 > 2**31
     enc_var = torch.empty_like(enc_fixed)
-    engine.mul_dev(s, pts_ext=bext, out_enc=enc_var)
+    engine.mul_dev(s, pts_ext=bext, out_enc=enc_var)          # (default stream: torch's current one — ordered behind the `.repeat` that writes bext)
     engine.sync()
-    assert torch.equal(enc_fixed, enc_var)
+    bad = (enc_fixed != enc_var).any(dim=1)
+    if bool(bad.any()):                                       # say WHICH side is wrong before failing
+        i = int(torch.nonzero(bad)[0].item())
+        want = bytes(oracle.mul_base_batch(s[i:i + 1].cpu().numpy())[0])
+        pytest.fail(f"{int(bad.sum())} of {n} items differ, first at {i} (scalar top byte {int(s[i, 31])}): fixed base "
+                    f"{'==' if bytes(enc_fixed[i].cpu().numpy()) == want else '!='} oracle, variable base {'==' if bytes(enc_var[i].cpu().numpy()) == want else '!='} oracle")
     # 2^16 random sample compared element-wise, SHA-256 over all outputs stable across a repeat run
     idx = torch.cat([torch.randint(0, n, (1 << 16,), generator=torch.Generator().manual_seed(1)), torch.tensor([0, n - 1, (1 << 23) - 1, 1 << 23, (1 << 24) - 1025])])
     threads = min(16, len(os.sched_getaffinity(0)))
@@ -1060,6 +1067,50 @@ def test_cfg5_whole_2_24_on_one_gpu(engine, oracle):
     assert hashlib.sha256(enc_fixed.cpu().numpy().tobytes()).hexdigest() == digest
     del bext, enc_var, enc_fixed, s
     torch.cuda.empty_cache()
+
+
+def test_dev_calls_are_ordered_with_torchs_current_stream(engine, oracle):
+    """Round 5's red run: the binding's _dev methods used to launch on the engine's own NON-BLOCKING stream, which waits for nothing torch has
+    queued — operands still being written by null-stream kernels were read early (tools/repro_stream_race.py, profiles/r06/stream_race.log).
+    Now the default is torch's current stream.  Here the operands are written BEHIND a few milliseconds of unrelated work on that stream and the
+    engine is called at once: on the null stream, and inside `with torch.cuda.stream(...)`; results are also consumed by torch with no
+    synchronisation in between."""
+    import torch
+    import kyber_rs_amd
+    dev = torch.device("cuda:0")
+    n = 1 << 15
+    s_np = synth.scalars(n, 661)
+    p_np = np.tile(rand_points_ext(oracle, 64, 662), (n // 64, 1))
+    want_var = oracle.mul_batch(s_np, p_np, nthreads=8)
+    want_fix = oracle.mul_base_batch(s_np, nthreads=8)
+    s_src, p_src = torch.from_numpy(s_np).to(dev), torch.from_numpy(p_np).to(dev)
+    junk = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    for stream in (None, side):
+        with torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext():
+            s = torch.zeros_like(s_src); p = torch.zeros_like(p_src)
+            out_v = torch.zeros((n, 32), dtype=torch.uint8, device=dev); out_f = torch.zeros_like(out_v)
+            for _ in range(8):
+                junk.random_()                                # the current stream is busy for a while ...
+            s.copy_(s_src); p.copy_(p_src)                    # ... the operands are written behind that ...
+            engine.mul_dev(s, pts_ext=p, out_enc=out_v)       # ... and the engine is called without any wait
+            engine.mul_base_dev(s, out_enc=out_f)
+            got_v, got_f = out_v.clone(), out_f.clone()       # consumed by torch on the same stream, again without a wait
+            out_v.zero_(); out_f.zero_()
+        torch.cuda.synchronize()
+        assert np.array_equal(got_v.cpu().numpy(), want_var), stream
+        assert np.array_equal(got_f.cpu().numpy(), want_fix), stream
+    # the explicit handles of the C ABI: KYB_STREAM_LEGACY is the null stream; 0 is the engine's own stream, which the CALLER orders
+    s.copy_(s_src)
+    engine.mul_base_dev(s, out_enc=out_f, stream=kyber_rs_amd.STREAM_LEGACY)
+    assert np.array_equal(out_f.cpu().numpy(), want_fix)
+    out_f.zero_()
+    torch.cuda.synchronize()
+    engine.mul_base_dev(s, out_enc=out_f, stream=kyber_rs_amd.STREAM_ENGINE)
+    engine.sync(kyber_rs_amd.STREAM_ENGINE)
+    assert np.array_equal(out_f.cpu().numpy(), want_fix)
+    engine.stream_release(side.cuda_stream)
 
 
 def test_structured_fuzz_against_oracle(engine, oracle):
