@@ -78,7 +78,7 @@
 extern "C" {
 #endif
 
-/* `stream` argument of the _dev calls and kyb_sync: the device's null (legacy default) stream, = hipStreamLegacy */
+/* `stream` argument of the _dev calls, kyb_sync and kyb_stream_release: the device's null (legacy default) stream */
 #define KYB_STREAM_LEGACY ((void*)1)
 
 #define KYB_OK 0
@@ -567,16 +567,25 @@ const char* kyb_kernel_name(int kernel_id);
  *     kyb_shutdown), which switches the stamps off by itself. */
 int kyb_diag_mad_peak(double min_ms, double* mads_per_s, double* clock_ghz, double* simd_cycles_per_mad, double* kernel_ms);
 int kyb_diag_wave_stamps(void* dev_buf);
-/* Test hooks for the error paths and the "secrets" convention above (tests/test_gpu_fault_injection.py):
+/* kyb_get_option diag.dev_kib / diag.host_kib (read-only): KiB of device / page-locked memory the context's lazily grown buffers hold now. */
+
+/* ---- test hooks: exported by the CROSS-CHECK build only -------------------------------------------------------------------------------
+ * libkyber_ed25519_hip_crosscheck.so (csrc/Makefile CROSSCHECK=1, compiled with -DKYB_CROSSCHECK) is the product's sources plus the
+ * alternative kernels the tests compare it with, the options that select them, and the hooks below.  The PRODUCT library exports none of
+ * them and knows none of these options: nothing in a process that loaded it can make its launches or allocations fail, or read the buffers
+ * secrets pass through.  (tests/test_gpu_fault_injection.py, tests/test_gpu_coop.py)
  *   options diag.fail_alloc_after = k / diag.fail_launch_after = k (kyb_set_option; 0 = off): the k-th buffer allocation / kernel launch this
  *     context attempts from now on fails without being made — KYB_E_NOMEM naming the buffer / KYB_E_HIP naming the launch — and the counter
  *     is spent.  A failed call leaves the context usable: the next call gives the ordinary results.
- *   kyb_get_option diag.dev_kib / diag.host_kib: KiB of device / page-locked memory the context's lazily grown buffers hold now.
  *   kyb_diag_scratch_read(which, dst, cap, bytes): copies up to cap bytes of one of the context's buffers to dst and stores the buffer's
  *     size in *bytes (0 = not allocated).  which: 0, 1 page-locked zero-copy / bounce buffers; 2 device staging of host-pointer calls;
- *     3 page-locked landing area of large pageable results; 4, 5, 6 the engine stream's scratch (projective records, encodings, products of
- *     small linear combinations).  Waits for the device first.  Never needed by a caller of the engine. */
+ *     3 page-locked landing area of large pageable results; 4, 5, 6, 7 the engine stream's scratch (projective records, encodings, products of
+ *     small linear combinations, pieces of the four-workgroup variable-base product).  Waits for the device first.
+ *   kyb_diag_coop(op, a, b, out): one cooperative one-item-per-wavefront primitive on caller-supplied operands (64 words each). */
+#ifdef KYB_CROSSCHECK
 int kyb_diag_scratch_read(int which, uint8_t* dst, size_t cap, size_t* bytes);
+int kyb_diag_coop(int op, const uint32_t* a, const uint32_t* b, uint32_t* out);
+#endif
 
 #ifdef __cplusplus
 }

@@ -53,8 +53,10 @@ ABI_SYMBOLS = [
     "kyb_defer_flush", "kyb_defer_mark", "kyb_defer_floor", "kyb_defer_stats",
     "kyb_host_alloc", "kyb_host_free",
     "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
-    "kyb_diag_mad_peak", "kyb_diag_wave_stamps", "kyb_diag_scratch_read",
+    "kyb_diag_mad_peak", "kyb_diag_wave_stamps",
 ]
+# declared inside `#ifdef KYB_CROSSCHECK` of the header: test hooks only the cross-check build exports
+CROSSCHECK_ONLY_SYMBOLS = ["kyb_diag_scratch_read", "kyb_diag_coop"]
 
 
 def kernel_sources_id() -> str:
@@ -157,7 +159,9 @@ def load_library(crosscheck: bool = False) -> ctypes.CDLL:
     dp = ctypes.POINTER(ctypes.c_double)
     lib.kyb_diag_mad_peak.argtypes = [ctypes.c_double, dp, dp, dp, dp]
     lib.kyb_diag_wave_stamps.argtypes = [vp]
-    lib.kyb_diag_scratch_read.argtypes = [ctypes.c_int, vp, sz, ctypes.POINTER(ctypes.c_size_t)]
+    if crosscheck:
+        lib.kyb_diag_scratch_read.argtypes = [ctypes.c_int, vp, sz, ctypes.POINTER(ctypes.c_size_t)]
+        lib.kyb_diag_coop.argtypes = [ctypes.c_int, vp, vp, vp]
     lib.kyb_add_batch.argtypes = [vp, vp, sz, vp, i32]
     lib.kyb_add_batch_dev.argtypes = [vp, vp, sz, vp, i32, vp]
     lib.kyb_encode_batch.argtypes = [vp, sz, vp]
@@ -403,7 +407,7 @@ class Engine:
         return {"mads_per_s": r.value, "clock_ghz": c.value, "simd_cycles_per_mad": y.value, "kernel_ms": k.value}
 
     def scratch_read(self, which: int) -> bytes:
-        """kyb_diag_scratch_read: the present contents of one of the context's buffers (test hook for the secret-hygiene checks)"""
+        """kyb_diag_scratch_read: the present contents of one of the context's buffers (test hook for the secret-hygiene checks; cross-check build only)"""
         size = ctypes.c_size_t(0)
         _check(self.lib.kyb_diag_scratch_read(which, None, 0, ctypes.byref(size)), "kyb_diag_scratch_read")
         if size.value == 0:

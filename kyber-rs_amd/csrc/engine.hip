@@ -182,10 +182,15 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 // a kernel launch of an entry point (`g` = its context in scope): the injected failure is reported without the launch being made
 #define LAUNCHCK(x) do { if (diag_trip(g.diag_fail_launch)) return fail(KYB_E_HIP, "injected launch failure (diag.fail_launch_after) at " #x); \
                          hipError_t e_ = (x); if (e_ != hipSuccess) return fail(KYB_E_HIP, #x, e_); } while (0)
+// (fault injection exists in the CROSS-CHECK build only — the tests' library; in the product nothing can make a launch or an allocation fail on request)
+#ifdef KYB_CROSSCHECK
 inline bool diag_trip(std::atomic<int>& c) {
   if (c.load(std::memory_order_relaxed) <= 0) return false;
   return c.fetch_sub(1, std::memory_order_relaxed) == 1;
 }
+#else
+inline constexpr bool diag_trip(std::atomic<int>&) { return false; }
+#endif
 // every buffer a context grows on demand comes from these four: one place for the injected failure and for the byte accounting the leak tests read
 inline hipError_t ctx_malloc(Ctx& g, void** p, size_t bytes) {
   if (diag_trip(g.diag_fail_alloc)) { *p = nullptr; return hipErrorOutOfMemory; }
@@ -236,8 +241,10 @@ struct ProfScope {
 };
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-// NULL = the context's own (non-blocking) stream; KYB_STREAM_LEGACY = the device's null stream, whatever value the runtime gives that name
-inline hipStream_t pick(Ctx& g, void* s) { return !s ? g.stream : s == KYB_STREAM_LEGACY ? hipStreamLegacy : reinterpret_cast<hipStream_t>(s); }
+// NULL = the context's own (non-blocking) stream; KYB_STREAM_LEGACY = the device's null stream, which the runtime knows as the null handle
+// (the name hipStreamLegacy is avoided: hipStreamWaitEvent on it crashed inside the ROCm 7.2 runtime, profiles/r06/README.md)
+inline hipStream_t caller_stream(void* s) { return s == KYB_STREAM_LEGACY ? hipStream_t(nullptr) : reinterpret_cast<hipStream_t>(s); }
+inline hipStream_t pick(Ctx& g, void* s) { return !s ? g.stream : caller_stream(s); }
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // device buffers that held caller data (possibly private keys and nonces) are cleared before they go back to the runtime

@@ -101,60 +101,41 @@ KYB_HD uint32_t kyb_x2(uint32_t a, const char* what) {
 // per column (v_lshl_add_u64, half rate).  Writing the column's mads as one asm statement keeps the
 // running sum — carry of the previous column included — as the addend chain (no extra add), and costs
 // one asm-boundary pad per column instead of one per mad (the per-mad barrier variant lost to its
-// s_nops, profiles/r01/ab_chain_barrier.log).  -DKYB_NO_ASM_COLUMNS restores the plain C++ columns.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(KYB_NO_ASM_COLUMNS)
+// s_nops, profiles/r01/ab_chain_barrier.log).  (The host build of tests/hostcheck/ takes the plain C++ columns.)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define KYB_ASM_COLUMNS 1
 // The carry-out of v_mad_u64_u32 is never used (the sums stay below 2^64 by the bound calculus); it goes to VCC.  In a PURE multiply-add
 // stream the form that writes an SGPR pair instead issues 7 % faster (profiles/r02/valu_rates_selfconsistent_mi355x.jsonl: 30.4 against
-// 28.2 T mad/s); in these kernels, where a third of the instructions are not multiply-adds, it makes no difference
-// (-DKYB_MAD_CARRY_SGPR, same-box A/B profiles/r03/ab_carry_sgpr.log: 8.642 against 8.638 ms per 2^20 variable-base mults), so VCC stays.
-#if !defined(KYB_MAD_CARRY_SGPR)
-#define KYB_CARRY "vcc"
-#define KYB_CARRY_OUT
-#define KYB_CARRY_CLOBBER : "vcc"
-#define KYB_CARRY_DECL
-#else
-#define KYB_CARRY "%[cy]"
-#define KYB_CARRY_OUT , [cy] "=&s"(kyb_cy)
-#define KYB_CARRY_CLOBBER
-#define KYB_CARRY_DECL uint64_t kyb_cy;
-#endif
+// 28.2 T mad/s); in these kernels, where a third of the instructions are not multiply-adds, it made no difference
+// (profiles/r03/ab_carry_sgpr.log: 8.642 against 8.638 ms per 2^20 variable-base mults), so VCC it is.
 // operands by name: %[acc]; the column's factors %[a1].. / %[b1]..
-#define KYB_M1(i) "v_mad_u64_u32 %[acc], " KYB_CARRY ", %[a" #i "], %[b" #i "], %[acc]\n\t"
-#if defined(KYB_EXPERIMENT_EXTRA_NOPS)      // what does an s_nop cost?  (tools/ab_kernels.py, profiles/r02/ab_extra_nops.log)
-#define KYB_COL_TAIL "s_nop 0\n\t"
-#else
-#define KYB_COL_TAIL
-#endif
+#define KYB_M1(i) "v_mad_u64_u32 %[acc], vcc, %[a" #i "], %[b" #i "], %[acc]\n\t"
 __device__ __forceinline__ uint64_t kyb_col10(uint64_t acc, const uint32_t* A, const uint32_t* B) {
-  KYB_CARRY_DECL
-  asm(KYB_M1(1) KYB_M1(2) KYB_M1(3) KYB_M1(4) KYB_M1(5) KYB_M1(6) KYB_M1(7) KYB_M1(8) KYB_M1(9) KYB_M1(10) KYB_COL_TAIL
-      : [acc] "+v"(acc) KYB_CARRY_OUT
+  asm(KYB_M1(1) KYB_M1(2) KYB_M1(3) KYB_M1(4) KYB_M1(5) KYB_M1(6) KYB_M1(7) KYB_M1(8) KYB_M1(9) KYB_M1(10)
+      : [acc] "+v"(acc)
       : [a1] "v"(A[0]), [a2] "v"(A[1]), [a3] "v"(A[2]), [a4] "v"(A[3]), [a5] "v"(A[4]), [a6] "v"(A[5]), [a7] "v"(A[6]), [a8] "v"(A[7]), [a9] "v"(A[8]), [a10] "v"(A[9]),
         [b1] "v"(B[0]), [b2] "v"(B[1]), [b3] "v"(B[2]), [b4] "v"(B[3]), [b5] "v"(B[4]), [b6] "v"(B[5]), [b7] "v"(B[6]), [b8] "v"(B[7]), [b9] "v"(B[8]), [b10] "v"(B[9])
-      KYB_CARRY_CLOBBER);
+      : "vcc");
   return acc;
 }
-#define KYB_M0(i) "v_mad_u64_u32 %[acc], " KYB_CARRY ", %[a" #i "], %[b" #i "], 0\n\t"
+#define KYB_M0(i) "v_mad_u64_u32 %[acc], vcc, %[a" #i "], %[b" #i "], 0\n\t"
 // first column of a product: the accumulator starts at the literal 0 (no v_mov_b64 to clear a register pair)
 __device__ __forceinline__ uint64_t kyb_col10z(const uint32_t* A, const uint32_t* B) {
   uint64_t acc;
-  KYB_CARRY_DECL
-  asm(KYB_M0(1) KYB_M1(2) KYB_M1(3) KYB_M1(4) KYB_M1(5) KYB_M1(6) KYB_M1(7) KYB_M1(8) KYB_M1(9) KYB_M1(10) KYB_COL_TAIL
-      : [acc] "=&v"(acc) KYB_CARRY_OUT
+  asm(KYB_M0(1) KYB_M1(2) KYB_M1(3) KYB_M1(4) KYB_M1(5) KYB_M1(6) KYB_M1(7) KYB_M1(8) KYB_M1(9) KYB_M1(10)
+      : [acc] "=&v"(acc)
       : [a1] "v"(A[0]), [a2] "v"(A[1]), [a3] "v"(A[2]), [a4] "v"(A[3]), [a5] "v"(A[4]), [a6] "v"(A[5]), [a7] "v"(A[6]), [a8] "v"(A[7]), [a9] "v"(A[8]), [a10] "v"(A[9]),
         [b1] "v"(B[0]), [b2] "v"(B[1]), [b3] "v"(B[2]), [b4] "v"(B[3]), [b5] "v"(B[4]), [b6] "v"(B[5]), [b7] "v"(B[6]), [b8] "v"(B[7]), [b9] "v"(B[8]), [b10] "v"(B[9])
-      KYB_CARRY_CLOBBER);
+      : "vcc");
   return acc;
 }
 __device__ __forceinline__ uint64_t kyb_col6z(const uint32_t* A, const uint32_t* B) {
   uint64_t acc;
-  KYB_CARRY_DECL
   asm(KYB_M0(1) KYB_M1(2) KYB_M1(3) KYB_M1(4) KYB_M1(5) KYB_M1(6)
-      : [acc] "=&v"(acc) KYB_CARRY_OUT
+      : [acc] "=&v"(acc)
       : [a1] "v"(A[0]), [a2] "v"(A[1]), [a3] "v"(A[2]), [a4] "v"(A[3]), [a5] "v"(A[4]), [a6] "v"(A[5]),
         [b1] "v"(B[0]), [b2] "v"(B[1]), [b3] "v"(B[2]), [b4] "v"(B[3]), [b5] "v"(B[4]), [b6] "v"(B[5])
-      KYB_CARRY_CLOBBER);
+      : "vcc");
   return acc;
 }
 // 2*a as v_add_u32 a, a: LLVM canonicalises x + x into v_lshlrev_b32, which issues at 4.4 cycles per wave-instruction on
@@ -169,21 +150,19 @@ __device__ __forceinline__ void kyb_dbl3(uint32_t& o0, uint32_t& o1, uint32_t& o
   asm("v_add_u32 %0, %3, %3\n\tv_add_u32 %1, %4, %4\n\tv_add_u32 %2, %5, %5" : "=&v"(o0), "=&v"(o1), "=&v"(o2) : "v"(a0), "v"(a1), "v"(a2));
 }
 __device__ __forceinline__ uint64_t kyb_col6(uint64_t acc, const uint32_t* A, const uint32_t* B) {
-  KYB_CARRY_DECL
   asm(KYB_M1(1) KYB_M1(2) KYB_M1(3) KYB_M1(4) KYB_M1(5) KYB_M1(6)
-      : [acc] "+v"(acc) KYB_CARRY_OUT
+      : [acc] "+v"(acc)
       : [a1] "v"(A[0]), [a2] "v"(A[1]), [a3] "v"(A[2]), [a4] "v"(A[3]), [a5] "v"(A[4]), [a6] "v"(A[5]),
         [b1] "v"(B[0]), [b2] "v"(B[1]), [b3] "v"(B[2]), [b4] "v"(B[3]), [b5] "v"(B[4]), [b6] "v"(B[5])
-      KYB_CARRY_CLOBBER);
+      : "vcc");
   return acc;
 }
 __device__ __forceinline__ uint64_t kyb_col5(uint64_t acc, const uint32_t* A, const uint32_t* B) {
-  KYB_CARRY_DECL
   asm(KYB_M1(1) KYB_M1(2) KYB_M1(3) KYB_M1(4) KYB_M1(5)
-      : [acc] "+v"(acc) KYB_CARRY_OUT
+      : [acc] "+v"(acc)
       : [a1] "v"(A[0]), [a2] "v"(A[1]), [a3] "v"(A[2]), [a4] "v"(A[3]), [a5] "v"(A[4]),
         [b1] "v"(B[0]), [b2] "v"(B[1]), [b3] "v"(B[2]), [b4] "v"(B[3]), [b5] "v"(B[4])
-      KYB_CARRY_CLOBBER);
+      : "vcc");
   return acc;
 }
 #endif

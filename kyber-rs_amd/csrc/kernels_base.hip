@@ -71,12 +71,7 @@ k_mul_base64(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ sc
     else if (i0 + t < n_a) load_words8(a, scalars + 32 * i0, t);                               // the one chunk that straddles the two arrays
     else load_words8(a, scalars_b, (size_t)(i0 + t - n_a));
     ge_p3 h;
-#if !defined(KYB_BASE64_PIPELINE_768)      // the pipelined form is an A/B leftover (profiles/r03/ab_base_pipeline.log: no gain)
     ge_scalarmult_base64(h, a, tbl);
-#else
-    if (BLOCK == 768) ge_scalarmult_base64_pipelined(h, a, tbl);      // 168 registers: room for the next window's rows under the current one's arithmetic
-    else ge_scalarmult_base64(h, a, tbl);
-#endif
     uint32_t tl = threadIdx.x & 63u;
     asm volatile("" : "+v"(tl));         // the lane's store address is formed here, after the loop (not hoisted out of the chunk loop and spilled)
     if (SPLIT) { if (tl < cnt) store_proj(proj + (proj_offset + i0), proj_stride, tl, h.X, h.Y, h.Z); }

@@ -972,6 +972,7 @@ k_verify_coop(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs
   }
 }
 
+#ifdef KYB_CROSSCHECK      // the cross-check build only
 // Test hook (tests/test_gpu_coop.py, against the lane-level model tools/coop_model.py): one wavefront applies ONE
 // cooperative primitive to caller-supplied quads.  op: 0 cmul4(A, B), 1 cnorm(A), 2 cinv(A), 3 mixed addition h = A, entry = B,
 // 4 table entry (window, idx, negate) = (B[0], B[1], B[2]) of the radix-64 image, 5 csub(A, B), 6 one ladder step S = A,
@@ -1023,16 +1024,19 @@ k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restri
   }
   out[c.lane] = r;
 }
+#endif
 
 namespace kyb { namespace launch {
 hipError_t msm_bases_coop(hipStream_t st, const int32_t* pts_ext, size_t t, uint32_t* bases) {
   hipLaunchKernelGGL(k_msm_bases_coop, dim3((unsigned)t), dim3(64), 0, st, pts_ext, t, bases);
   return hipGetLastError();
 }
+#ifdef KYB_CROSSCHECK
 hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* table_coop) {
   hipLaunchKernelGGL(k_coop_selftest, dim3(1), dim3(64), 0, st, op, A, B, out, table_coop);
   return hipGetLastError();
 }
+#endif
 hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul, DoneFlag df,
                        bool ext_proj) {
   hipLaunchKernelGGL(k_finish_coop, dim3((unsigned)n), dim3(64), 0, st, proj, stride, pts_ext, n, oenc, oext, src_mul, ext_proj ? 1 : 0, df);

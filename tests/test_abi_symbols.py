@@ -9,15 +9,41 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
+def header_symbols(crosscheck_only=False):
+    """what the header declares outside (default) / inside its `#ifdef KYB_CROSSCHECK` block (the test hooks of the cross-check build)"""
     txt = open(os.path.join(ROOT, "include", "kyber_ed25519.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(kyb_[a-z0-9_]+)\s*\(", txt)))
+    guarded = "".join(re.findall(r"#ifdef KYB_CROSSCHECK(.*?)#endif", txt, flags=re.S))
+    if not crosscheck_only:
+        txt = re.sub(r"#ifdef KYB_CROSSCHECK.*?#endif", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(kyb_[a-z0-9_]+)\s*\(", guarded if crosscheck_only else txt)))
 
 
 def test_header_and_python_binding_agree():
     import kyber_rs_amd
     assert header_symbols() == sorted(kyber_rs_amd.ABI_SYMBOLS)
+    assert header_symbols(crosscheck_only=True) == sorted(kyber_rs_amd.CROSSCHECK_ONLY_SYMBOLS)
+
+
+def test_test_hooks_are_not_in_the_product_library():
+    """round-5 review item 5: fault injection and the scratch reader shipped in the product.  Now the product exports exactly the two
+    benchmark diagnostics (the chip's multiply-add rate and the in-kernel clock stamps, which bench.py's roofline needs); the fault
+    injection counters, kyb_diag_scratch_read and kyb_diag_coop exist in the cross-check build only."""
+    import subprocess
+    libdir = os.path.join(ROOT, "kyber-rs_amd")
+
+    def exported(lib):
+        out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(libdir, lib)], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("kyb_")}
+    prod = exported("libkyber_ed25519_hip.so")
+    assert sorted(n for n in prod if n.startswith("kyb_diag")) == ["kyb_diag_mad_peak", "kyb_diag_wave_stamps"]
+    assert prod == set(header_symbols()), sorted(prod ^ set(header_symbols()))
+    strings = subprocess.run(["strings", "-n", "8", os.path.join(libdir, "libkyber_ed25519_hip.so")], capture_output=True, text=True).stdout
+    assert "diag.fail_alloc_after" not in strings and "diag.fail_launch_after" not in strings and "injected launch failure" not in strings
+    assert "k_coop_selftest" not in strings
+    if os.path.exists(os.path.join(libdir, "libkyber_ed25519_hip_crosscheck.so")):
+        cross = exported("libkyber_ed25519_hip_crosscheck.so")
+        assert cross == prod | set(header_symbols(crosscheck_only=True)), sorted(cross ^ (prod | set(header_symbols(crosscheck_only=True))))
 
 
 def test_library_exports_every_declared_symbol():
@@ -99,7 +125,7 @@ def test_the_product_library_has_one_kernel_per_regime_and_no_variant_selectors(
     assert kept == {"device.cus", "coop.max_items", "coop.base_max_items", "coop.decode_max_items", "coop.verify_max_items", "coop.ladder_max_items",
                     "coop.ladder_enc_max_items", "coop.share_by_load", "ladder.pair_max_items", "ladder.skip_canonical", "mul.short_scalars", "ext.projective",
                     "host.in_place", "host.zero_copy_kib", "host.pipe_chunks", "host.copy_threads", "defer.fuse", "defer.max_nodes",
-                    "diag.fail_alloc_after", "diag.fail_launch_after", "diag.dev_kib", "diag.host_kib"}, sorted(kept)
+                    "diag.dev_kib", "diag.host_kib"}, sorted(kept)
     libdir = os.path.join(ROOT, "kyber-rs_amd")
     names = {}
     for lib in ("libkyber_ed25519_hip.so", "libkyber_ed25519_hip_crosscheck.so"):

@@ -427,17 +427,18 @@ def test_coop_and_batch_kernels_agree_at_the_threshold(engine, oracle):
         engine.set_option("coop.base_max_items", old[1])
 
 
-def test_coop_primitives_match_the_lane_model(engine):
+def test_coop_primitives_match_the_lane_model(xengine):
     """every cooperative primitive (cmul4, cnorm, csub, cinv, table entry, mixed addition, ladder step, layout round
-    trip) run by one wavefront through the library's test hook == the lane-level numpy model tools/coop_model.py"""
+    trip) run by one wavefront through the test hook of the cross-check build (the same device code as the product's; the product
+    library does not export the hook) == the lane-level numpy model tools/coop_model.py"""
+    engine = xengine
     import ctypes
     import random
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
     import coop_model as M
     import kyber_rs_amd
-    lib = kyber_rs_amd.load_library()
-    lib.kyb_diag_coop.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib = kyber_rs_amd.load_library(crosscheck=True)
     engine.device_info()                       # makes the fixture's context current on this thread
 
     def run(op, A, B=None):

@@ -7,9 +7,8 @@ import numpy as np
 import kyber_rs_amd
 import coop_model as M
 
-eng = kyber_rs_amd.Engine(0)
-lib = kyber_rs_amd.load_library()
-lib.kyb_diag_coop.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+eng = kyber_rs_amd.Engine(0, crosscheck=True)          # the hook lives in the cross-check build only
+lib = kyber_rs_amd.load_library(crosscheck=True)
 eng.device_info()
 c = M.lane_consts()
 A = np.ascontiguousarray(M.quad_from_ints(c, [3, 5, 7, 11]), dtype=np.uint32)

@@ -46,8 +46,11 @@ def trial(engine, oracle, base_row, s, enc_fixed, arm: str, slow_gib: int, check
     bext = torch.zeros((n, 40), dtype=torch.int32, device=dev)          # what the ladder sees if it runs too early: X = Y = Z = T = 0
     enc_var = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    junk = slow_null_stream_work(dev, slow_gib) if arm != "engine_stream_as_r05" else None
-    if arm == "engine_stream_as_r05":
+    junk = slow_null_stream_work(dev, slow_gib) if slow_gib else None
+    if arm == "engine_stream_ordered_by_caller":
+        bext.copy_(base_row.expand(n, 40))
+        torch.cuda.synchronize()                                         # what the C ABI asks of a caller that passes NULL
+    elif arm == "engine_stream_as_r05":
         engine.mul_base_dev(s, out_enc=enc_var, stream=0)                # as in the round-5 test: the fixed-base kernel holds every CU ...
         bext = base_row.repeat(n, 1)                                     # ... while its line queues a fresh 2.68 GB null-stream write
     else:
@@ -97,9 +100,18 @@ def main():
 
     ok = True
     t0 = time.time()
-    forced = trial(engine, oracle, base_row, s, enc_fixed, "engine_stream_forced", args.slow_gib, True)
-    print(json.dumps({"arm": "engine_stream_forced", **forced, "s": round(time.time() - t0, 1)}), flush=True)
-    ok &= forced["mismatching_items"] > 0 and forced["fixed_base_equals_oracle_on_sample"]
+    # the engine stream's scratch grows on its first 2^24-item call, and growing frees device memory — hipFree waits for the whole device,
+    # null stream included, which would hide the race in the first trial: grow it now, with operands that are complete
+    warm = trial(engine, oracle, base_row, s, enc_fixed, "engine_stream_ordered_by_caller", 0, False)
+    print(json.dumps({"arm": "engine_stream_ordered_by_caller (operands synchronised first)", **warm, "s": round(time.time() - t0, 1)}), flush=True)
+    ok &= warm["mismatching_items"] == 0
+    forced_fails = 0
+    for i in range(3):
+        forced = trial(engine, oracle, base_row, s, enc_fixed, "engine_stream_forced", args.slow_gib, True)
+        print(json.dumps({"arm": "engine_stream_forced", "trial": i, **forced, "s": round(time.time() - t0, 1)}), flush=True)
+        forced_fails += forced["mismatching_items"] > 0
+        ok &= forced["fixed_base_equals_oracle_on_sample"]
+    ok &= forced_fails == 3
 
     fails = 0
     for i in range(args.trials):
