@@ -88,7 +88,7 @@ extern "C" {
 #define KYB_E_HIP (-4)
 #define KYB_E_NOMEM (-5)
 #define KYB_E_TRANSPORT (-6)  /* kyb_group_create_ex(KYB_GROUP_REQUIRE_RCCL): the RCCL broadcast of the table image could not be done */
-#define KYB_E_STALE (-7)      /* deferred points: the handle names a node the arena has dropped (kyb_defer_floor, defer.max_nodes) */
+#define KYB_E_STALE (-7)      /* deferred points: the handle names a node the arena no longer has (see "Lifetime" at kyb_defer_*) */
 
 /* table image exchanged between GPUs at init — the role of constants.rs:89 BASE (which holds the 32 even
  * radix-16 positions only); affine (y+x, y-x, 2dxy), canonical limbs:
@@ -415,22 +415,36 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *     inversions) and cached: the marshal_binary calls that follow cost no engine call.
  * Results: the same group elements, hence the same 32 bytes, as the eager calls; the limbs are one valid representation of the point
  * (as everywhere in this ABI).  Option defer.fuse = 0 switches the chain recognition off (level-by-level batches only).
- * Lifetime: the reference's Point is Copy, so copies of a handle may live anywhere and nodes are not reference-counted.  Evaluated nodes
- * stay in the arena until kyb_defer_floor(mark) drops everything recorded before `mark` (= an earlier kyb_defer_mark(); e.g. at the end
- * of a protocol round) or until more than defer.max_nodes (default 2^18; a node is 40 bytes, plus 224 where it holds a scalar or a value: at most 69 MB per arena) exist, when the oldest are dropped; a
- * dropped handle is refused with KYB_E_STALE ("stale handle"), never answered wrongly (a binding whose point still holds its limbs registers them again: host/edwards25519.hpp).  Secret scalars are kept until their node is
- * evaluated and cleared then; a node's limbs and bytes — a recorded Diffie-Hellman exchange leaves the shared point there — are cleared when the
- * node is dropped (floor, defer.max_nodes, the end of the arena): call kyb_defer_floor when a round's secrets are done with.  A handle carries the number of the arena it came from (upper 24 bits), so handles of
- * two contexts never collide and a point recorded through one context may be read, compared or used as an operand through another (the reference's
- * Point is Send: a worker thread may hand its points to the thread that marshals them) — the evaluation then runs on the reader's context.  The arena
- * of a released context stays readable as an orphan until sixteen younger orphans exist.
+ * Lifetime: the reference's Point is Copy, so copies of a handle may live anywhere — in protocol state for the life of a node (dkg.rs:41,170;
+ * dss_sig.rs:44) — and nodes are not reference-counted.  The arena therefore keeps two things:
+ *   the WINDOW   the youngest defer.max_nodes nodes (default 2^18) with their graph: 40 bytes a node, plus 224 where it holds a scalar or a
+ *                value — at most 69 MB.  When it is full it moves on by a quarter: first everything still pending is evaluated (one flush),
+ *                then the oldest quarter leaves;
+ *   KEPT VALUES  a node that leaves the window WITH a value leaves its 160 bytes of limbs (and its 32 bytes, if it has them) in a table keyed
+ *                by its handle: the handle keeps working — asked for, it answers from the table; used as an operand, it comes back into the
+ *                window as a leaf.  The table is bounded by defer.keep_mib (default 256 MiB = 1.29 million values of 208 bytes, plus about a
+ *                third for its index); when full, the values nobody has touched since they were last looked over go first (second-chance
+ *                order), so a distributed public key that is marshalled or multiplied every round stays.
+ * A handle is refused with KYB_E_STALE ("stale handle"), never answered wrongly, only when (1) kyb_defer_floor(mark) dropped it — everything
+ * recorded before `mark` (= an earlier kyb_defer_mark()), values included: the host's own statement that a round is over; (2) its node never
+ * had a value when the window left it — the inner steps of a chain that was evaluated as ONE call, which exist as locals that the reference's
+ * loops overwrite (poly.rs:457-469, 566-603); (3) its value was pushed out of the table: untouched while defer.keep_mib of younger values
+ * arrived (at 64 participants a Pedersen dealer round leaves about 200 values: tens of thousands of rounds).  A binding whose point still
+ * holds its limbs registers them again (host/edwards25519.hpp).  Secret scalars are kept until their node is evaluated and cleared then; a
+ * node's limbs and bytes — a recorded Diffie-Hellman exchange leaves the shared point there — are cleared when they leave the window without
+ * being kept, when they leave the table, and at the end of the arena: call kyb_defer_floor when a round's secrets are done with.
+ * A handle carries the number of the arena it came from (upper 24 bits), so handles of two contexts never collide and a point recorded
+ * through one context may be read, compared or used as an operand through another (the reference's Point is Send: a worker thread may hand
+ * its points to the thread that marshals them) — the evaluation then runs on the reader's context.  The arena of a released context stays
+ * readable as an orphan until sixteen younger orphans exist.
  *   kyb_defer_input   a point the caller holds (40 limbs) as a leaf          kyb_defer_null / _base   the neutral element / B
  *   kyb_defer_mul_base / _mul / _add (subtract != 0: a - b) / _neg            Point::mul(s, None) / mul(s, Some(p)) / add / sub / neg
  *   kyb_defer_get(p, out_ext, out_enc)   evaluates p — and everything else recorded so far: who asks for one result will ask for the others —
  *                                        and returns its limbs and / or marshal_binary; either pointer may be NULL
  *   kyb_defer_equal(a, b, eq)            Point::eq;   kyb_defer_flush()   evaluates everything recorded
  *   kyb_defer_stats(out, cap)            nodes recorded, flushes, engine calls made by flushes, Horner chains fused, sums fused,
- *                                        marshal cache hits, nodes held now, nodes dropped by defer.max_nodes (for tests and benchmarks) */
+ *                                        marshal cache hits, nodes in the window now, nodes that left the window, values kept now, values
+ *                                        pushed out of the table, answers from the table, operands taken back in (for tests and benchmarks) */
 int kyb_defer_input(const int32_t* ext, uint64_t* out);
 int kyb_defer_null(uint64_t* out);
 int kyb_defer_base(uint64_t* out);
@@ -500,7 +514,9 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     point accepts such points, kyb_encode_batch pays the inversion when an encoding is wanted
  *   defer.fuse        1 (default): a flush of deferred points (kyb_defer_*) evaluates Horner chains and chains of additions as ONE call each; 0:
  *                     level by level only.  Same results.
- *   defer.max_nodes   nodes the deferred-point arena keeps before it drops the oldest (default 2^18 = at most 69 MB, at least 16); a dropped handle is refused
+ *   defer.max_nodes   the window of the deferred-point arena: the youngest nodes, kept with their graph (default 2^18 = at most 69 MB, at least 16)
+ *   defer.keep_mib    MiB of values that evaluated nodes leave behind when the window moves past them (default 256; 0: none — a handle older
+ *                     than the window is then refused with KYB_E_STALE)
  *   host.in_place     1 (default): a host-pointer call small enough for host.zero_copy_kib (and of at least 64 KiB) whose array lies in memory
  *                     kyb_host_alloc handed out on this context's device (16-byte aligned start) has its kernels read / write that array where it
  *                     lies instead of a copy in the context's buffer (an 8,192-item multiplication: 0.03-0.05 ms less); other page-locked

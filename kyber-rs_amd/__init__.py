@@ -762,9 +762,10 @@ class Engine:
         _check(self.lib.kyb_defer_floor(mark), "kyb_defer_floor")
 
     def defer_stats(self) -> dict:
-        v = (ctypes.c_uint64 * 8)()
-        _check(self.lib.kyb_defer_stats(v, 8), "kyb_defer_stats")
-        return dict(zip(("nodes", "flushes", "engine_calls", "horner_fused", "sums_fused", "marshal_cache_hits", "nodes_held", "nodes_dropped"), (int(x) for x in v)))
+        v = (ctypes.c_uint64 * 12)()
+        _check(self.lib.kyb_defer_stats(v, 12), "kyb_defer_stats")
+        return dict(zip(("nodes", "flushes", "engine_calls", "horner_fused", "sums_fused", "marshal_cache_hits", "nodes_held", "nodes_dropped",
+                         "values_kept", "values_pushed_out", "kept_hits", "operands_readmitted"), (int(x) for x in v)))
 
     def point_checks(self, enc=None, pts_ext=None) -> np.ndarray:
         """kyb_point_checks_batch: flags per point, bit 0 = is_canonical (the reference's expression), bit 1 = has_small_order (point.rs:286-337)"""

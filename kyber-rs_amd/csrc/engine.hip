@@ -137,7 +137,8 @@ struct Ctx {
   std::atomic<int> opt_ladder_y_only{2};         // two-lane ladder from wire encodings: ladder on y while the decode looks for x — 2: as workgroups of the same launch, 1: on a side stream (0: decode first)
   std::atomic<DeferArena*> defer{nullptr};       // recorded, not yet evaluated point operations of this context's callers (kyb_defer_*; made on first use)
   std::atomic<int> opt_defer_fuse{1};            // flushes recognise Horner chains and chains of additions (defer.inc)
-  std::atomic<int> opt_defer_max_nodes{1 << 18}; // nodes kept for late readers of a handle before the oldest are dropped (40 B each + 224 B where a value is held: at most 69 MB)
+  std::atomic<int> opt_defer_max_nodes{1 << 18}; // the arena's WINDOW: the youngest nodes, with their graph (40 B each + 224 B where a value is held: at most 69 MB); older nodes leave their values in ...
+  std::atomic<int> opt_defer_keep_mib{256};      // ... the table of kept values (208 B per evaluated node, bounded by this many MiB; least recently touched go first; 0: values leave with their nodes)
   bool stamps_on = false;                        // this context set the device's wave-stamp slots (kyb_diag_wave_stamps): cleared again when it is released
   std::atomic<int> opt_coop_share{1};             // divide the small-batch thresholds by the number of host-pointer calls in flight in this process (coop_lim)
   std::atomic<int> opt_host_inplace{1};           // zero-copy host-pointer calls use page-locked CALLER arrays (kyb_host_alloc) where they lie instead of copying them into the context's buffer

@@ -7,14 +7,17 @@
 //   Marshaling    src/encoding/encodings.rs:12-27      point.rs:35-51, scalar.rs:91-112
 //   canonical / small-order checks  point.rs:286-337, scalar.rs:54-75
 //   Curve::new_key_and_seed_with_input  curve.rs:74-87
-// Every Point operation that does curve arithmetic is a batch-of-1 call into the GPU engine (the
-// trait is per-element and synchronous); throughput callers use the *_batch statics.
-// With set_deferred(true) (per thread) the same methods RECORD their operation in the engine's arena
-// instead (kyb_defer_*, include/kyber_ed25519.h "deferred points") and a Point holds a handle until
+// The trait is per-element and synchronous and a batch-of-1 engine call costs more than
+// the CPU needs for the operation, so BY DEFAULT mul / add / sub / neg RECORD their operation in the
+// engine's arena (kyb_defer_*, include/kyber_ed25519.h "deferred points") and a Point holds a handle until
 // somebody needs its bytes or limbs — marshal_binary, ==, data, hex, the batch helpers — which is
 // when the engine evaluates the recorded graph in batches (one call for the t multiplications of
-// PriPoly::commit, one for the whole Horner chain of PubPoly::eval, ...).  Protocol code written
-// against the trait, call by call, runs unchanged in either mode and yields the same bytes.
+// PriPoly::commit, one for the whole Horner chain of PubPoly::eval, ...).  Handles stay valid for as long
+// as protocol state holds them (the arena keeps the values of evaluated nodes; "Lifetime" in the header).
+// set_deferred(false) per thread / KYBER_HIP_EAGER=1 in the environment: every Point operation that does
+// curve arithmetic is a batch-of-1 call into the GPU engine instead.  Protocol code written against the
+// trait, call by call, runs unchanged in either mode and yields the same bytes; throughput callers use
+// the *_batch statics.
 // Scalar arithmetic stays on the host (microseconds) and shares sc25519.h with
 // the device sign kernel.  `mul`/`add`/... are infallible in the reference: an engine failure aborts.
 #pragma once
@@ -54,7 +57,8 @@ namespace group {
 namespace edwards25519 {
 
 namespace detail {
-inline bool& deferred_flag() { static thread_local bool on = false; return on; }
+// (on unless KYBER_HIP_EAGER is set in the environment: the mode a maintainer gets by default is the fast one)
+inline bool& deferred_flag() { static thread_local bool on = std::getenv("KYBER_HIP_EAGER") == nullptr; return on; }
 inline void engine_must(int rc, const char* what) {
   if (rc != KYB_OK) {  // the trait has no error channel (group.rs:139): abort like a Rust panic
     std::fprintf(stderr, "kyber-ed25519-hip: %s failed (%d): %s\n", what, rc, kyb_last_error());
@@ -67,7 +71,8 @@ static const uint8_t L_BYTES[32] = {0xed, 0xd3, 0xf5, 0x5c, 0x1a, 0x63, 0x12, 0x
                                     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x10};
 }  // namespace detail
 
-// deferred evaluation of this thread's Point operations (off by default): see the header of this file
+// deferred evaluation of this thread's Point operations — ON by default; set_deferred(false) / KYBER_HIP_EAGER=1: every trait call is its own
+// engine call (three times SLOWER than a CPU core on protocol code: bench.py protocol_phases).  See the header of this file.
 inline void set_deferred(bool on) { detail::deferred_flag() = on; }
 inline bool deferred() { return detail::deferred_flag(); }
 

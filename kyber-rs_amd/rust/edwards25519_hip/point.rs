@@ -8,16 +8,21 @@
 //! `embed`, the length byte of `data`, the byte comparison of `is_canonical`, the formatters (they print the bytes the engine marshals).
 //! tools/check_rust_shim.py checks, method by method, that this file reaches the same `kyb_*` entry points as the C++ mirror
 //! `host/edwards25519.hpp`, which the GPU tests drive.
-//! DEFERRED MODE (`set_deferred(true)` per thread, or KYBER_HIP_DEFERRED in the environment): `mul` / `add` / `sub` / `neg` RECORD their
-//! operation in the engine's arena (`kyb_defer_*`) and return a `Point` that holds only a handle; the engine evaluates what was recorded,
-//! in batches, when somebody needs bytes or limbs (`marshal_binary`, `eq`, `hash`, `data`, serde, the batch helpers).  Unmodified protocol
-//! code then gets one engine call for the t multiplications of `PriPoly::commit` and one for the whole Horner chain of `PubPoly::eval`
-//! (tests/cpp/test_vss_round.cpp is the same logic in C++, timed).  This is the mode to run protocol code in: an eager `add` of one pair
-//! is a round trip to the GPU (27 us; the CPU needs 0.3 us), a recorded one costs a fraction of a microsecond and is evaluated as part
-//! of a sum.  `Point` stays `Copy` and `Send`: handles are plain numbers that name the arena (the recording thread's context) they came
-//! from, so a point recorded on one thread can be marshalled or multiplied on another.  The arena keeps evaluated nodes until
-//! `defer_floor(mark)` or until `defer.max_nodes` of them exist; a point that must outlive that (a long-term key, a distributed public
-//! key) is detached with `materialize()`, which fetches its limbs — after that it depends on nothing.
+//! DEFERRED MODE — the DEFAULT (`set_deferred(false)` per thread or KYBER_HIP_EAGER in the environment switch it off): `mul` / `add` /
+//! `sub` / `neg` RECORD their operation in the engine's arena (`kyb_defer_*`) and return a `Point` that holds only a handle; the engine
+//! evaluates what was recorded, in batches, when somebody needs bytes or limbs (`marshal_binary`, `eq`, `hash`, `data`, serde, the batch
+//! helpers).  Unmodified protocol code then gets one engine call for the t multiplications of `PriPoly::commit` and one for the whole
+//! Horner chain of `PubPoly::eval` (tests/cpp/test_vss_round.cpp is the same logic in C++, timed).  Eager mode exists for comparison: an
+//! eager `add` of one pair is a round trip to the GPU (27 us; the CPU needs 0.3 us), a recorded one costs a fraction of a microsecond and
+//! is evaluated as part of a sum.  `Point` stays `Copy` and `Send`: handles are plain numbers that name the arena (the recording thread's
+//! context) they came from, so a point recorded on one thread can be marshalled or multiplied on another.
+//! LIFETIME.  A `Copy` point cannot remember what it fetched, and copies of a handle sit in protocol state for the life of a node
+//! (dkg.rs:41,170; dss_sig.rs:44), so the ARENA remembers: a node that has been evaluated leaves its value behind when the arena's window
+//! (the youngest 2^18 nodes) moves past it, and its handle keeps answering — and keeps working as an operand — from that table (bounded by
+//! `defer.keep_mib`, 256 MiB = 1.3 million values; least recently touched first).  Unmodified protocol code needs neither of the two
+//! manual controls: `defer_floor(mark)` (end of a round: everything older is dropped, values included — a statement that nothing older is
+//! wanted) and `materialize()` (detach one point from the arena for good).  tests/cpp/test_long_running.cpp runs a handle-only client of
+//! this shape through the C ABI for hundreds of rounds past the window.
 //! Which reference method each one stands for: INTEGRATION.md §3.
 use core::fmt::{Debug, Display, Formatter, LowerHex, UpperHex};
 
@@ -36,7 +41,7 @@ use super::ffi::{self, ensure_init, must};
 type Limbs = [[i32; 10]; 4];
 
 thread_local! {
-    static DEFERRED: std::cell::Cell<bool> = std::cell::Cell::new(std::env::var_os("KYBER_HIP_DEFERRED").is_some());
+    static DEFERRED: std::cell::Cell<bool> = std::cell::Cell::new(std::env::var_os("KYBER_HIP_EAGER").is_none());
 }
 /// Record this thread's `mul` / `add` / `sub` / `neg` in the engine's arena instead of running them one by one (module docs).
 pub fn set_deferred(on: bool) {
@@ -175,7 +180,7 @@ impl Point {
         self.ge.as_mut_ptr() as *mut i32
     }
     /// Detach this point from the arena: its limbs are fetched (evaluating what it depends on) and it no longer names a handle.
-    /// For points that outlive a protocol round — the arena drops old nodes (`defer_floor`, `defer.max_nodes`), limbs are forever.
+    /// Never needed for correctness (module docs, LIFETIME); for a host that calls `defer_floor` and wants one point to survive it.
     pub fn materialize(&mut self) -> Self {
         self.ge = self.limbs();
         self.pend = 0;
@@ -478,9 +483,10 @@ impl group::Point for Point {
         self.embed(None, rand)
     }
 
+    /// point.rs:94-97 copies the element; here the value is limbs, handle AND the bytes it was unmarshalled from (`var_time` stays the
+    /// receiver's, as in the reference, whose `set` assigns `ge` only)
     fn set(&mut self, p: &Self) -> Self {
-        self.ge = p.ge;
-        self.pend = p.pend;
+        *self = Point { var_time: self.var_time, ..*p };
         *self
     }
 

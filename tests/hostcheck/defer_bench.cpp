@@ -29,6 +29,7 @@ struct Ctx {
   std::atomic<DeferArena*> defer{nullptr};
   std::atomic<int> opt_defer_fuse{1};
   std::atomic<int> opt_defer_max_nodes{1 << 18};
+  std::atomic<int> opt_defer_keep_mib{256};
 };
 Ctx g_ctx;
 Ctx* cur() { return &g_ctx; }

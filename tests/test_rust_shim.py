@@ -126,6 +126,25 @@ def test_the_symbol_comparison_with_the_cpp_mirror_catches_a_second_code_path():
         assert bad and any(what in b for b in bad), (what, bad)
 
 
+def test_a_writer_of_one_value_field_writes_all_three():
+    """round-5 advice: `Point::set` copied `ge` and `pend` and kept the RECEIVER's `enc` — after `p.unmarshal_binary(a); p.set(&q)` the point
+    held q's limbs with a's bytes, and marshal_binary / eq / has_small_order answered for a.  tools/check_rust_shim.py part 5 on the module as it
+    is (clean) and on that very slip (caught); the C++ mirror's `set` is `*this = p`."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_rust_shim as chk
+    bad = []
+    assert chk.value_fields_move_together(bad) >= 10 and not bad, bad
+    text = open(os.path.join(SHIM, "point.rs")).read()
+    start = text.index("fn set(&mut self, p: &Self) -> Self {")
+    end = text.index("}\n", text.index("*self\n", start)) + 2
+    doctored = text[:start] + "fn set(&mut self, p: &Self) -> Self {\n        self.ge = p.ge;\n        self.pend = p.pend;\n        *self\n    }\n" + text[end:]
+    bad = []
+    chk.value_fields_move_together(bad, doctored)
+    assert len(bad) == 1 and "fn set" in bad[0] and "enc" in bad[0], bad
+    cpp = open(os.path.join(ROOT, "kyber-rs_amd", "host", "edwards25519.hpp")).read()
+    assert "Point set(const Point& p) { *this = p; return *this; }" in cpp
+
+
 def test_the_call_site_check_catches_a_wrong_arity_and_a_missing_declaration(tmp_path, monkeypatch):
     """tools/check_rust_shim.py part 4 on a doctored copy of the module: one argument dropped from a call, one call of an undeclared entry point"""
     import shutil

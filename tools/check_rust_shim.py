@@ -21,6 +21,8 @@ container only — the GPU box has no /root/reference and the test that calls th
    header), pointer parameters get pointer-shaped arguments, and the brackets of every file balance — the little a text check can do for
    source no compiler has seen.
 
+5. A Point's value is `ge`, `pend` and `enc` together: every writer of one writes all three (value_fields_move_together).
+
   python tools/check_rust_shim.py [--reference /root/reference] [--markdown]
 """
 import argparse
@@ -270,6 +272,30 @@ def ffi_call_sites(bad):
     return calls, len(decl)
 
 
+def value_fields_move_together(bad, rust_text=None):
+    """5. A Point's VALUE is three fields — the limbs `ge`, the handle `pend`, the bytes it was unmarshalled from `enc` — and a writer of one
+    that forgets another leaves a point whose marshal_binary / eq / has_small_order answer for some OTHER point (round-5 advice: `set` copied
+    `ge` and `pend` and kept the receiver's `enc`).  Every fn of point.rs that assigns `self.ge`, `self.pend` or `self.enc` field by field must
+    assign all three; whole-value writes (`*self = ...`, a `Point { .. }` literal) are fine by construction, and a struct literal that names
+    one of the three must name all three or spread (`..`) from a point it means to copy."""
+    text = rust_text if rust_text is not None else open(os.path.join(SHIM, "point.rs")).read()
+    checked = 0
+    for name, body in rust_fn_texts(text).items():
+        wrote = {f for f in ("ge", "pend", "enc") if re.search(r"\bself\.%s\s*=[^=]" % f, body)}
+        if wrote:
+            checked += 1
+            if wrote != {"ge", "pend", "enc"} and name not in ("materialize", "ext_mut"):       # (materialize keeps the bytes on purpose: same point, now with limbs; ext_mut hands `ge` to the engine call that writes it)
+                bad.append(f"point.rs: fn {name} assigns self.{{{', '.join(sorted(wrote))}}} but not self.{{{', '.join(sorted({'ge', 'pend', 'enc'} - wrote))}}}")
+        for lit in re.finditer(r"\bPoint\s*\{([^{}]*)\}", body):
+            fields = {f for f in ("ge", "pend", "enc") if re.search(r"(?:^|[,{\s])%s\s*(?::|,|$)" % f, lit.group(1).strip())}
+            spread = re.search(r"\.\.\s*\*?\w", lit.group(1))
+            if fields and fields != {"ge", "pend", "enc"} and not (spread and not re.search(r"\.\.\s*\*?self\b", lit.group(1))):
+                # spreading from `self` keeps the RECEIVER's other fields: then all three must be named
+                bad.append(f"point.rs: fn {name} builds Point {{ {', '.join(sorted(fields))}, ..self }} without {sorted({'ge', 'pend', 'enc'} - fields)}")
+            checked += 1
+    return checked
+
+
 def similarity(shim_text, ref_text):
     a, b = strip(shim_text), strip(ref_text)
     if len(a) < 8:                        # a three-line mod.rs shares `mod point;` with anybody's
@@ -290,6 +316,7 @@ def main():
     print(f"one code path: {len(surface)} trait methods compared with the C++ mirror, symbol set by symbol set")
     calls, declared = ffi_call_sites(bad)
     print(f"ffi call sites: {calls} calls of {declared} declared entry points checked for arity and pointer shape")
+    print(f"value fields: {value_fields_move_together(bad)} writers of a Point's ge / pend / enc checked for writing all three")
     if not os.path.isdir(ref_dir):
         for b in bad:
             print("MISMATCH:", b)
