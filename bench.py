@@ -712,11 +712,14 @@ def protocol_phases(n=64, t=43):
             same = lines["E"] == lines["D"] == cpu_lines["E"] and (not lines["B"] or lines["B"] == lines["E"])
             phases = {}
             for ph, ms in cpu["eager_ms"].items():
-                phases[ph] = {"cpu_port_ms": ms, "eager_ms": timing["eager_ms"][ph], "deferred_ms": timing["deferred_ms"][ph]}
+                # default_ms: what a caller gets who never chooses a mode — the program reports which mode its binding starts in
+                # (host/edwards25519.hpp: deferred unless KYBER_HIP_EAGER is set; the Rust module the same)
+                dflt = timing.get("default_mode", "eager")
+                phases[ph] = {"cpu_port_ms": ms, "eager_ms": timing["eager_ms"][ph], "deferred_ms": timing["deferred_ms"][ph], "default_ms": timing[dflt + "_ms"][ph]}
                 if "batched_ms" in timing:
                     phases[ph]["batched_ms"] = timing["batched_ms"][ph]
                 phases[ph]["deferred_vs_cpu"] = round(ms / timing["deferred_ms"][ph], 2)
-            out[prog] = {"phases": phases, "transcripts_identical": same, "deferred_stats": timing["deferred_stats"]}
+            out[prog] = {"phases": phases, "transcripts_identical": same, "deferred_stats": timing["deferred_stats"], "default_mode": timing.get("default_mode", "eager")}
         return out
     except Exception as e:      # a missing g++ on the bench box must not cost the bench line
         return {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -3,7 +3,8 @@
 // sequences on one host core — the "cpu_port_ms" column beside the engine's eager and deferred columns (round-4 review: the CPU figure for a
 // dealer round was a sum of per-operation estimates, never run).  The C port follows the reference's algorithm and limb schedule (radix 2^25.5,
 // signed radix-16 windows), so its timings stand for the reference's CPU path as far as anything in this image can.
-// TEST INFRASTRUCTURE: lives under tests/, is never linked into the product, and refuses the deferred entry points (the CPU runs eagerly).
+// TEST INFRASTRUCTURE: lives under tests/, is never linked into the product, and refuses the deferred entry points (the CPU runs eagerly) —
+// unless built with -DKYB_CPU_PORT_DEFER, which puts the product's own evaluator (csrc/defer.inc) on top of these entry points (end of this file).
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -77,6 +78,7 @@ int kyb_verify_points_batch(const int32_t* pubs_ext, const uint8_t* msgs, const 
   for (size_t i = 0; i < n; ++i) { uint8_t pub[32]; orc_encode(pub, pubs_ext + 40 * i); status[i] = (uint8_t)orc_verify(flavor, pub, msgs + off[i], off[i + 1] - off[i], sigs + 64 * i, 64); }
   return KYB_OK;
 }
+#ifndef KYB_CPU_PORT_DEFER
 // the CPU port runs eagerly: nothing is recorded
 int kyb_defer_input(const int32_t*, uint64_t*) { return refuse("cpu port: no deferred mode"); }
 int kyb_defer_null(uint64_t*) { return refuse("cpu port: no deferred mode"); }
@@ -92,3 +94,69 @@ uint64_t kyb_defer_mark(void) { return 0; }
 int kyb_defer_floor(uint64_t) { return KYB_OK; }
 int kyb_defer_stats(uint64_t* out, int cap) { for (int i = 0; i < cap; ++i) out[i] = 0; return KYB_OK; }
 }
+#else
+// -DKYB_CPU_PORT_DEFER: the PRODUCT's deferred-point evaluator (kyber-rs_amd/csrc/defer.inc: arena, window, kept values, chain recognition) compiled
+// for the CPU on top of the entry points above — so that the C++ mirror's DEFAULT mode (deferred) and the long-running programs run in the CPU suite:
+// host logic of the product under test, the curve arithmetic behind it answered by the oracle.  The two batch calls only the evaluator makes:
+void orc_pubpoly_eval(uint8_t out_enc[32], const int32_t* commits_ext, size_t t, uint32_t index);
+void orc_null(int32_t out[40]);
+int kyb_pubpoly_eval_multi_batch(const int32_t* commits, size_t t, size_t m, const uint32_t* idx, size_t k, uint8_t* enc, int32_t* ext) {
+  for (size_t gi = 0; gi < m; ++gi)
+    for (size_t j = 0; j < k; ++j) {
+      uint8_t e[32];
+      orc_pubpoly_eval(e, commits + 40 * t * gi, t, idx[gi * k + j]);
+      if (enc) memcpy(enc + 32 * (gi * k + j), e, 32);
+      if (ext && !orc_decode(ext + 40 * (gi * k + j), e)) return refuse("oracle produced an encoding that does not decode");
+    }
+  return KYB_OK;
+}
+int kyb_sum_batch(const int32_t* pts, size_t m, size_t t, uint8_t* enc, int32_t* ext) {
+  for (size_t gi = 0; gi < m; ++gi) {
+    int32_t acc[40];
+    orc_null(acc);
+    for (size_t j = 0; j < t; ++j) orc_add(acc, acc, pts + 40 * (gi * t + j), 0);
+    if (enc) orc_encode(enc + 32 * gi, acc);
+    if (ext) memcpy(ext + 40 * gi, acc, 160);
+  }
+  return KYB_OK;
+}
+}
+#include <algorithm>
+#include <atomic>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+struct DeferArena;
+void defer_release(DeferArena* a);
+namespace {
+struct Ctx {      // the little of the engine's context that defer.inc refers to
+  bool ready = true;
+  int device = 0;
+  std::mutex launch_mu;
+  std::atomic<DeferArena*> defer{nullptr};
+  std::atomic<int> opt_defer_fuse{1};
+  std::atomic<int> opt_defer_max_nodes{1 << 18};
+  std::atomic<int> opt_defer_keep_mib{256};
+};
+Ctx g_ctx;
+Ctx* cur() { return &g_ctx; }
+thread_local std::string g_fail_text;
+int fail(int code, const char* msg) { g_fail_text = msg; g_msg = g_fail_text.c_str(); return code; }
+}  // namespace
+void defer_projective(bool) {}      // (the engine hands projective limbs to a flush that serves a comparison; the oracle's limbs are what they are)
+#define ENTER() Ctx* ctx_ = cur(); Ctx& g = *ctx_; (void)g
+#define ENTER_HOST() ENTER()
+#include "../../kyber-rs_amd/csrc/defer.inc"
+extern "C" {
+int kyb_set_option(const char* key, int value) {
+  if (!strcmp(key, "defer.max_nodes")) { g_ctx.opt_defer_max_nodes = value; return KYB_OK; }
+  if (!strcmp(key, "defer.keep_mib")) { g_ctx.opt_defer_keep_mib = value; return KYB_OK; }
+  if (!strcmp(key, "defer.fuse")) { g_ctx.opt_defer_fuse = value; return KYB_OK; }
+  return refuse("cpu port: unknown option");
+}
+}
+#endif

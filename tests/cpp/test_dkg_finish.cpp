@@ -113,6 +113,7 @@ static void finish_once(size_t n, size_t t, bool deferred_mode, Transcript& tr, 
 }
 
 int main(int argc, char** argv) {
+  const bool default_deferred = deferred();      // the mode a caller gets who never calls set_deferred: what the "default_mode" of the TIMING line reports
   const size_t n = argc > 1 ? (size_t)atol(argv[1]) : 64, t = argc > 2 ? (size_t)atol(argv[2]) : 43;
   // mode "eager": only the call-by-call run — what the build against tests/cpp/cpu_port_abi.cpp (the oracle behind the same ABI) is started with to
   // time the identical sequence on one host core (the cpu_port_ms column)
@@ -128,16 +129,16 @@ int main(int argc, char** argv) {
   finish_once(n, t, false, eager, te, se);
   for (const std::string& ln : eager.lines) std::printf("E %s\n", ln.c_str());
   if (eager_only) {
-    std::printf("TIMING {\"n\": %zu, \"t\": %zu, \"eager_ms\": {\"dist_key_share\": %.3f, \"recover_commit\": %.3f}, \"point_additions\": %zu}\n", n, t, te.dist_key, te.recover, (n - 1) * t + t);
+    std::printf("TIMING {\"default_mode\": \"%s\", \"n\": %zu, \"t\": %zu, \"eager_ms\": {\"dist_key_share\": %.3f, \"recover_commit\": %.3f}, \"point_additions\": %zu}\n", default_deferred ? "deferred" : "eager", n, t, te.dist_key, te.recover, (n - 1) * t + t);
     kyb_shutdown();
     return 0;
   }
   finish_once(n, t, true, lazy, tl, sl);
   for (const std::string& ln : lazy.lines) std::printf("D %s\n", ln.c_str());
-  std::printf("TIMING {\"n\": %zu, \"t\": %zu, \"eager_ms\": {\"dist_key_share\": %.3f, \"recover_commit\": %.3f}, \"deferred_ms\": {\"dist_key_share\": %.3f, \"of_which_recording\": %.3f, \"recover_commit\": %.3f}, "
+  std::printf("TIMING {\"default_mode\": \"%s\", \"n\": %zu, \"t\": %zu, \"eager_ms\": {\"dist_key_share\": %.3f, \"recover_commit\": %.3f}, \"deferred_ms\": {\"dist_key_share\": %.3f, \"of_which_recording\": %.3f, \"recover_commit\": %.3f}, "
               "\"point_additions\": %zu, \"deferred_stats\": {\"nodes\": %llu, \"flushes\": %llu, \"engine_calls\": %llu, \"horner_fused\": %llu, \"sums_fused\": %llu, \"marshal_cache_hits\": %llu}, "
               "\"eager_stats_nodes\": %llu}\n",
-              n, t, te.dist_key, te.recover, tl.dist_key, tl.dist_key_recorded, tl.recover, (n - 1) * t + t,
+              default_deferred ? "deferred" : "eager", n, t, te.dist_key, te.recover, tl.dist_key, tl.dist_key_recorded, tl.recover, (n - 1) * t + t,
               (unsigned long long)sl[0], (unsigned long long)sl[1], (unsigned long long)sl[2], (unsigned long long)sl[3], (unsigned long long)sl[4], (unsigned long long)sl[5],
               (unsigned long long)se[0]);
   kyb_shutdown();

@@ -425,6 +425,7 @@ static void round_batched(size_t n, size_t t, Transcript& tr, Timing& tm) {
 #endif
 
 int main(int argc, char** argv) {
+  const bool default_deferred = deferred();      // the mode a caller gets who never calls set_deferred: what the "default_mode" of the TIMING line reports
   const size_t n = argc > 1 ? (size_t)atol(argv[1]) : 64, t = argc > 2 ? (size_t)atol(argv[2]) : 43;
   const bool eager_only = argc > 3 && std::string(argv[3]) == "eager";
   if (n < 2 || t < 1 || t > n) { std::printf("need 2 <= n, 1 <= t <= n\n"); return 2; }
@@ -444,8 +445,8 @@ int main(int argc, char** argv) {
   for (const std::string& ln : eager.lines) std::printf("E %s\n", ln.c_str());
   const double e_all = te.new_dss + te.partial_sig + te.process;
   if (eager_only) {
-    std::printf("TIMING {\"n\": %zu, \"t\": %zu, \"eager_ms\": {\"new_dss\": %.3f, \"partial_sig\": %.3f, \"process_partial_sigs\": %.3f, \"round\": %.3f}}\n",
-                n, t, te.new_dss, te.partial_sig, te.process, e_all);
+    std::printf("TIMING {\"default_mode\": \"%s\", \"n\": %zu, \"t\": %zu, \"eager_ms\": {\"new_dss\": %.3f, \"partial_sig\": %.3f, \"process_partial_sigs\": %.3f, \"round\": %.3f}}\n",
+                default_deferred ? "deferred" : "eager", n, t, te.new_dss, te.partial_sig, te.process, e_all);
     kyb_shutdown();
     return 0;
   }
@@ -457,12 +458,12 @@ int main(int argc, char** argv) {
   for (const std::string& ln : batched.lines) std::printf("B %s\n", ln.c_str());
 #endif
   const double l_all = tl.new_dss + tl.partial_sig + tl.process, b_all = tb.new_dss + tb.partial_sig + tb.process;
-  std::printf("TIMING {\"n\": %zu, \"t\": %zu, \"eager_ms\": {\"new_dss\": %.3f, \"partial_sig\": %.3f, \"process_partial_sigs\": %.3f, \"round\": %.3f}, "
+  std::printf("TIMING {\"default_mode\": \"%s\", \"n\": %zu, \"t\": %zu, \"eager_ms\": {\"new_dss\": %.3f, \"partial_sig\": %.3f, \"process_partial_sigs\": %.3f, \"round\": %.3f}, "
               "\"deferred_ms\": {\"new_dss\": %.3f, \"partial_sig\": %.3f, \"process_partial_sigs\": %.3f, \"round\": %.3f}, "
               "\"batched_ms\": {\"new_dss\": %.3f, \"partial_sig\": %.3f, \"process_partial_sigs\": %.3f, \"round\": %.3f}, \"speedup\": %.2f, "
               "\"deferred_stats\": {\"nodes\": %llu, \"flushes\": %llu, \"engine_calls\": %llu, \"horner_fused\": %llu, \"sums_fused\": %llu, \"marshal_cache_hits\": %llu}, "
               "\"eager_stats_nodes\": %llu}\n",
-              n, t, te.new_dss, te.partial_sig, te.process, e_all, tl.new_dss, tl.partial_sig, tl.process, l_all,
+              default_deferred ? "deferred" : "eager", n, t, te.new_dss, te.partial_sig, te.process, e_all, tl.new_dss, tl.partial_sig, tl.process, l_all,
               tb.new_dss, tb.partial_sig, tb.process, b_all, e_all / l_all,
               (unsigned long long)sl[0], (unsigned long long)sl[1], (unsigned long long)sl[2], (unsigned long long)sl[3], (unsigned long long)sl[4], (unsigned long long)sl[5],
               (unsigned long long)se[0]);

@@ -46,6 +46,9 @@ static void test_embed(Curve& g, Stream& rand, std::vector<Point>& points, const
 
 int main() {
   if (kyb_init(0) != KYB_OK) { std::printf("kyb_init failed: %s\n", kyb_last_error()); return 2; }
+  // everything below runs in the mode a caller gets who never chooses one: deferred, unless KYBER_HIP_EAGER is set (tests/test_gpu_cpp_group.py runs both)
+  const bool default_mode = deferred();
+  std::printf("MODE %s\n", default_mode ? "deferred" : "eager");
   Curve g;
   XorShiftStream rand;
   std::vector<Point> points;
@@ -478,13 +481,14 @@ int main() {
       set_deferred(true);
       Point rec = Point().sub(moved, gen);                             // recorded: no bytes until asked; then those of q
       CHECK(!rec.have_enc && rec == q && std::memcmp(rec.marshal_binary().data(), want, 32) == 0 && rec.have_enc, "a recorded point gains its bytes when marshalled");
-      set_deferred(false);
+      set_deferred(default_mode);
     }
   }
   // a long-lived key used as a deferred operand keeps a CACHED handle; when the arena drops the node (kyb_defer_floor at the end of a round,
   // defer.max_nodes) the limbs the point still holds are registered again — no abort, same bytes (KYB_E_STALE)
   {
     Scalar k = Scalar().pick(rand), x = Scalar().pick(rand);
+    set_deferred(false);
     Point key = Point().mul(k, nullptr);                               // eager: holds its limbs
     const std::vector<uint8_t> key_bytes = Point(key).marshal_binary();      // (of a copy: `key` itself keeps no bytes, its marshal below must go to the arena)
     const Point eager = Point().add(Point().mul(x, &key), key);
@@ -505,7 +509,7 @@ int main() {
     CHECK(key == Point().mul(k, nullptr), "== with a stale cached handle on one side");
     CHECK(Point().neg(key).marshal_binary() == Point().sub(Point().null(), key).marshal_binary(), "neg of a point with a stale handle");
     CHECK(kyb_defer_floor(0) == KYB_OK, "the mark of a thread that recorded nothing");
-    set_deferred(false);
+    set_deferred(default_mode);
   }
   for (const Point& p : points) std::printf("POINT %s\n", p.hex().c_str());
   std::printf("S1 %s\nS2 %s\n", s1.hex().c_str(), s2.hex().c_str());

@@ -249,6 +249,7 @@ static void round_batched(size_t n, size_t t, Transcript& tr, Timing& tm) {
 #endif
 
 int main(int argc, char** argv) {
+  const bool default_deferred = deferred();      // the mode a caller gets who never calls set_deferred: what the "default_mode" of the TIMING line reports
   const size_t n = argc > 1 ? (size_t)atol(argv[1]) : 64, t = argc > 2 ? (size_t)atol(argv[2]) : 43;
   const bool eager_only = argc > 3 && std::string(argv[3]) == "eager";
   if (kyb_init(0) != KYB_OK) { std::printf("kyb_init failed: %s\n", kyb_last_error()); return 2; }
@@ -267,8 +268,8 @@ int main(int argc, char** argv) {
   for (const std::string& ln : eager.lines) std::printf("E %s\n", ln.c_str());
   const double e_all = te.dealer_setup + te.encrypted_deals + te.verify_deals;
   if (eager_only) {
-    std::printf("TIMING {\"n\": %zu, \"t\": %zu, \"eager_ms\": {\"new_dealer\": %.3f, \"encrypted_deals\": %.3f, \"verify_deals\": %.3f, \"round\": %.3f}}\n",
-                n, t, te.dealer_setup, te.encrypted_deals, te.verify_deals, e_all);
+    std::printf("TIMING {\"default_mode\": \"%s\", \"n\": %zu, \"t\": %zu, \"eager_ms\": {\"new_dealer\": %.3f, \"encrypted_deals\": %.3f, \"verify_deals\": %.3f, \"round\": %.3f}}\n",
+                default_deferred ? "deferred" : "eager", n, t, te.dealer_setup, te.encrypted_deals, te.verify_deals, e_all);
     kyb_shutdown();
     return 0;
   }
@@ -280,12 +281,12 @@ int main(int argc, char** argv) {
   for (const std::string& ln : batched.lines) std::printf("B %s\n", ln.c_str());
 #endif
   const double l_all = tl.dealer_setup + tl.encrypted_deals + tl.verify_deals, b_all = tb.dealer_setup + tb.encrypted_deals + tb.verify_deals;
-  std::printf("TIMING {\"n\": %zu, \"t\": %zu, \"eager_ms\": {\"new_dealer\": %.3f, \"encrypted_deals\": %.3f, \"verify_deals\": %.3f, \"round\": %.3f}, "
+  std::printf("TIMING {\"default_mode\": \"%s\", \"n\": %zu, \"t\": %zu, \"eager_ms\": {\"new_dealer\": %.3f, \"encrypted_deals\": %.3f, \"verify_deals\": %.3f, \"round\": %.3f}, "
               "\"deferred_ms\": {\"new_dealer\": %.3f, \"encrypted_deals\": %.3f, \"verify_deals\": %.3f, \"round\": %.3f}, "
               "\"batched_ms\": {\"new_dealer\": %.3f, \"encrypted_deals\": %.3f, \"verify_deals\": %.3f, \"round\": %.3f}, \"speedup\": %.2f, "
               "\"deferred_stats\": {\"nodes\": %llu, \"flushes\": %llu, \"engine_calls\": %llu, \"horner_fused\": %llu, \"sums_fused\": %llu, \"marshal_cache_hits\": %llu}, "
               "\"eager_stats_nodes\": %llu}\n",
-              n, t, te.dealer_setup, te.encrypted_deals, te.verify_deals, e_all, tl.dealer_setup, tl.encrypted_deals, tl.verify_deals, l_all,
+              default_deferred ? "deferred" : "eager", n, t, te.dealer_setup, te.encrypted_deals, te.verify_deals, e_all, tl.dealer_setup, tl.encrypted_deals, tl.verify_deals, l_all,
               tb.dealer_setup, tb.encrypted_deals, tb.verify_deals, b_all, e_all / l_all,
               (unsigned long long)sl[0], (unsigned long long)sl[1], (unsigned long long)sl[2], (unsigned long long)sl[3], (unsigned long long)sl[4], (unsigned long long)sl[5],
               (unsigned long long)se[0]);

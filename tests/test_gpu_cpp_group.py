@@ -11,16 +11,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_reference_group_test_through_cpp_mirror(oracle):
+@pytest.mark.parametrize("mode", ["deferred", "eager"])
+def test_reference_group_test_through_cpp_mirror(oracle, mode):
+    """mode "deferred": the binding's DEFAULT (nothing set) — the reference's test_group identities on recorded points, evaluated in batches;
+    "eager": KYBER_HIP_EAGER=1, every trait call its own engine call.  Same points either way."""
     src = os.path.join(ROOT, "tests", "cpp", "test_group.cpp")
     out = os.path.join(ROOT, "tests", "cpp", "_build", "test_group")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     libdir = os.path.join(ROOT, "kyber-rs_amd")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-o", out, src,
                            "-L", libdir, "-lkyber_ed25519_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
-    r = subprocess.run([out], capture_output=True, text=True, timeout=300)
+    env = {k: v for k, v in os.environ.items() if k != "KYBER_HIP_EAGER"}
+    if mode == "eager":
+        env["KYBER_HIP_EAGER"] = "1"
+    r = subprocess.run([out], capture_output=True, text=True, timeout=300, env=env)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and r.stdout.strip().endswith("OK")
+    assert f"MODE {mode}" in r.stdout.splitlines()
     pts = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("POINT ")]
     s1 = bytes.fromhex([ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("S1 ")][0])
     s2 = bytes.fromhex([ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("S2 ")][0])

@@ -13,16 +13,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build(prog, cpu_port=False):
+def build(prog, cpu_port=False, cpu_defer=False):
     """tests/cpp/<prog>.cpp against the engine — or, cpu_port, against tests/cpp/cpu_port_abi.cpp: the oracle behind the same entry points, so that the
-    very same call-by-call sequence runs on one host core (the CPU column of the per-phase tables; test infrastructure, nothing of it ships)"""
+    very same call-by-call sequence runs on one host core (the CPU column of the per-phase tables; test infrastructure, nothing of it ships).
+    cpu_defer: that CPU port with the PRODUCT's deferred-point evaluator (csrc/defer.inc) compiled on top of it — the bindings' default mode on the CPU."""
     src = os.path.join(ROOT, "tests", "cpp", prog + ".cpp")
-    out = os.path.join(ROOT, "tests", "cpp", "_build", prog + ("_cpu_port" if cpu_port else ""))
+    out = os.path.join(ROOT, "tests", "cpp", "_build", prog + ("_cpu_defer" if cpu_defer else "_cpu_port" if cpu_port else ""))
     os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-o", out, src]
-    if cpu_port:
+    if cpu_port or cpu_defer:
         orc = os.path.join(ROOT, "oracle", "_build")
         cmd += ["-DKYB_CPU_PORT", os.path.join(ROOT, "tests", "cpp", "cpu_port_abi.cpp"), "-L", orc, "-loracle", f"-Wl,-rpath,{orc}"]
+        if cpu_defer:
+            cmd += ["-DKYB_CPU_PORT_DEFER", "-Wno-subobject-linkage", "-lpthread"]
     else:
         libdir = os.path.join(ROOT, "kyber-rs_amd")
         cmd += ["-L", libdir, "-lkyber_ed25519_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
@@ -89,6 +92,21 @@ def test_pedersen_dealer_round_call_by_call_eager_and_deferred(oracle):
     assert st["marshal_cache_hits"] >= t                             # session_id's marshals of the commitments
     assert timing["speedup"] >= 5.0, timing
     assert timing["deferred_ms"]["verify_deals"] * 10 <= timing["eager_ms"]["verify_deals"], timing
+
+
+def test_the_fast_mode_is_the_default_of_the_binding():
+    """round-5 review item 3: deferred mode was opt-in and the default (eager) drop-in is three times slower than a CPU core on every protocol
+    program.  Now a caller who never chooses gets the deferred mode — the programs report the mode their binding starts in — and KYBER_HIP_EAGER
+    in the environment is the way back."""
+    out = build("test_vss_round")
+    for env, want in ((dict(os.environ), "deferred"), (dict(os.environ, KYBER_HIP_EAGER="1"), "eager")):
+        env.pop("KYBER_HIP_EAGER", None) if want == "deferred" else None
+        r = subprocess.run([out, "3", "2", "all"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+        timing = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("TIMING ")][0][7:])
+        assert timing["default_mode"] == want
+    rust = open(os.path.join(ROOT, "kyber-rs_amd", "rust", "edwards25519_hip", "point.rs")).read()
+    assert 'Cell::new(std::env::var_os("KYBER_HIP_EAGER").is_none())' in rust
 
 
 def test_small_round_with_odd_shapes(oracle):

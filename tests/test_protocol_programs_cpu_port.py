@@ -27,3 +27,20 @@ def test_end_of_a_dkg_on_the_cpu_port(oracle):
             total = sum(coeffs[d * t + j] for d in range(n)) % L
             assert by["DISTCOMMIT"][j] == oracle.mul_base(total.to_bytes(32, "little")).hex(), (n, t, j)
         assert by["RECOVERED"] == [oracle.mul_base(coeffs[0].to_bytes(32, "little")).hex()]
+
+
+def test_the_three_programs_in_the_bindings_default_mode_on_the_cpu(oracle):
+    """The C++ mirror in its DEFAULT (deferred) mode over the product's own evaluator (csrc/defer.inc compiled for the CPU on top of the CPU port): a
+    dealer round, the end of a DKG and a DSS round recorded and evaluated in batches give, byte for byte, the transcript of the call-by-call run —
+    and the chains are recognised (Horner per verifier, one sum per coefficient)."""
+    for prog, n, t in (("test_vss_round", 6, 4), ("test_dkg_finish", 5, 3), ("test_dss_round", 6, 4), ("test_vss_round", 3, 2)):
+        lines, timing = run_program(build(prog, cpu_defer=True), n, t, "all")
+        assert timing["default_mode"] == "deferred"
+        assert lines["E"] == lines["D"] and len(lines["E"]) > 10, prog
+        st = timing["deferred_stats"]
+        assert timing["eager_stats_nodes"] == 0 and st["nodes"] > 0 and st["engine_calls"] < st["nodes"]
+        if prog == "test_vss_round":
+            _check_against_oracle(lines["D"], n, t, oracle)
+            assert st["horner_fused"] == n + 1
+        if prog == "test_dkg_finish":
+            assert st["sums_fused"] == t + 1
