@@ -597,10 +597,14 @@ int kyb_diag_wave_stamps(void* dev_buf);
  *     size in *bytes (0 = not allocated).  which: 0, 1 page-locked zero-copy / bounce buffers; 2 device staging of host-pointer calls;
  *     3 page-locked landing area of large pageable results; 4, 5, 6, 7 the engine stream's scratch (projective records, encodings, products of
  *     small linear combinations, pieces of the four-workgroup variable-base product).  Waits for the device first.
- *   kyb_diag_coop(op, a, b, out): one cooperative one-item-per-wavefront primitive on caller-supplied operands (64 words each). */
+ *   kyb_diag_coop(op, a, b, out): one cooperative one-item-per-wavefront primitive on caller-supplied operands (64 words each).
+ *   kyb_diag_phase_stamps(dev_buf): dev_buf = 32 x uint64 of zeroed device memory (NULL = off): the one-item kernels write the constant
+ *     100 MHz clock into fixed slots at their phase boundaries (start, scalar multiplication done, partial results combined, inversion
+ *     begin / end, stored) — where the time of a one-item call goes (tools/one_item_stamps.py). */
 #ifdef KYB_CROSSCHECK
 int kyb_diag_scratch_read(int which, uint8_t* dst, size_t cap, size_t* bytes);
 int kyb_diag_coop(int op, const uint32_t* a, const uint32_t* b, uint32_t* out);
+int kyb_diag_phase_stamps(void* dev_buf);
 #endif
 
 #ifdef __cplusplus

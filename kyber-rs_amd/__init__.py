@@ -56,7 +56,7 @@ ABI_SYMBOLS = [
     "kyb_diag_mad_peak", "kyb_diag_wave_stamps",
 ]
 # declared inside `#ifdef KYB_CROSSCHECK` of the header: test hooks only the cross-check build exports
-CROSSCHECK_ONLY_SYMBOLS = ["kyb_diag_scratch_read", "kyb_diag_coop"]
+CROSSCHECK_ONLY_SYMBOLS = ["kyb_diag_scratch_read", "kyb_diag_coop", "kyb_diag_phase_stamps"]
 
 
 def kernel_sources_id() -> str:
@@ -162,6 +162,7 @@ def load_library(crosscheck: bool = False) -> ctypes.CDLL:
     if crosscheck:
         lib.kyb_diag_scratch_read.argtypes = [ctypes.c_int, vp, sz, ctypes.POINTER(ctypes.c_size_t)]
         lib.kyb_diag_coop.argtypes = [ctypes.c_int, vp, vp, vp]
+        lib.kyb_diag_phase_stamps.argtypes = [vp]
     lib.kyb_add_batch.argtypes = [vp, vp, sz, vp, i32]
     lib.kyb_add_batch_dev.argtypes = [vp, vp, sz, vp, i32, vp]
     lib.kyb_encode_batch.argtypes = [vp, sz, vp]

@@ -36,6 +36,23 @@ using namespace kyb::coop;
 
 namespace {
 
+// Phase stamps of the one-item kernels (CROSS-CHECK build only; tools/one_item_stamps.py, profiles/r06/one_item_stamps.log): while a buffer is
+// set (kyb_diag_phase_stamps), lane 0 of the named wavefront of workgroup 0..3 writes the constant 100 MHz clock into its slot at the phase
+// boundaries below — where the time of a one-item call goes, measured inside the kernel.  The product build compiles none of it.
+#ifdef KYB_CROSSCHECK
+static __device__ uint64_t* kyb_phase_buf = nullptr;
+__device__ __forceinline__ void phase_stamp(int slot, bool mine) {
+  uint64_t* b = *reinterpret_cast<uint64_t* const volatile*>(&kyb_phase_buf);
+  if (b == nullptr) return;
+  uint64_t rt;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt) :: "memory");
+  if (mine && (threadIdx.x & 63u) == 0) b[slot] = rt;
+}
+#define KYB_PHASE(slot, mine) phase_stamp((slot), (mine))
+#else
+#define KYB_PHASE(slot, mine) ((void)0)
+#endif
+
 // affine (x, y) of the point (X : Y : Z) in rows 0..2 of a tight quad, in every lane; Z^-1 cooperative (0 when Z = 0: the reference's 0^(p-2))
 __device__ __forceinline__ void coop_affine(const lane_consts& c, cq q, fe& x, fe& y) {
   const cq inv = cinv(c, q);
@@ -77,7 +94,7 @@ __device__ __forceinline__ void coop_finish(const lane_consts& c, cq q, uint32_t
   }
   fe x, y;
   if (z_is_one) { fe_from_quad_row(c, x, q, 0); fe_from_quad_row(c, y, q, 1); }      // (wave-uniform: see k_finish_coop)
-  else coop_affine(c, q, x, y);
+  else { KYB_PHASE(30, blockIdx.x < 4); coop_affine(c, q, x, y); KYB_PHASE(31, blockIdx.x < 4); }      // (slots 30 / 31: the inversion of whichever workgroup finished last)
   if (out_enc != nullptr) {
     uint32_t w[8];
     fe_to_words(w, y);
@@ -339,6 +356,7 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
   const int piece = pieces == 1 ? 0 : (int)(blockIdx.x & 3u);
   KYB_COOP_CONSTS(c, 1);
   const size_t ip = pt_mod ? i % pt_mod : i;                             // shared operands: item i multiplies point i mod pt_mod
+  KYB_PHASE(0 + piece, blockIdx.x < 4);                                   // slots 0..3: a piece's wavefront starts
 
   // ---- operands: the scalar replicated on all lanes, the point as a quad (X, Y, Z, T) straight from its 40 reference limbs ----
   uint32_t a[8];
@@ -370,6 +388,7 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
   const int len = hi - lo;
 #pragma unroll 1
   for (int d = 0; d < lo; ++d) PQ = coop_dbl(c, PQ);
+  KYB_PHASE(4 + piece, blockIdx.x < 4);                                   // slots 4..7: its doublings are done
   // the piece as a number of its own: (mag >> lo) mod 2^len.  Word and bit offsets are the workgroup's (public); the words are picked by selects
   uint32_t pm[8];
   {
@@ -396,6 +415,7 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
   uint32_t* mine = pieces_buf + (4 * i + (size_t)piece) * 40;
   uint32_t* arrived = pieces_buf + 160 * n + i;                           // (behind the n * 4 records; zero between launches)
   if (c.active) mine[10 * c.row + c.k] = q;
+  KYB_PHASE(8 + piece, blockIdx.x < 4);                                   // slots 8..11: ladder, recovery and record are done
   __threadfence();                                                         // release: the record before the count, device-wide (the others are on other XCDs)
   uint32_t before = 0;
   if (c.lane == 0) before = atomicAdd(arrived, 1u);
@@ -412,7 +432,9 @@ k_mul_coop(const uint8_t* __restrict__ scalars, const int32_t* __restrict__ pts_
   }
   if (c.lane < 40u) { KYB_UNROLL for (int w = 0; w < 4; ++w) pieces_buf[(4 * i + (size_t)w) * 40 + c.lane] = 0u; }
   if (c.lane == 0) *arrived = 0u;
+  KYB_PHASE(12, blockIdx.x < 4);                                          // slot 12: the four pieces are added
   coop_finish(c, q, neg, out_enc, out_ext, i, proj, proj_stride, proj_offset, ext_proj != 0, true);
+  KYB_PHASE(13, blockIdx.x < 4);                                          // slot 13: encoded and stored
   if (c.lane == 0) signal_done(df);
 }
 
@@ -648,7 +670,9 @@ k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__
   uint32_t neg;
   const int per = (KYB_BASE64_POS + waves - 1) / waves;
   const int lo = wave * per, hi = (wave + 1) * per < KYB_BASE64_POS ? (wave + 1) * per : KYB_BASE64_POS;
+  KYB_PHASE(16, blockIdx.x == 0 && wave == 0);                            // slot 16: wavefront 0 starts (operands loaded)
   cq h = coop_base_mul(c, a, table_coop, neg, lo, hi);
+  KYB_PHASE(17, blockIdx.x == 0 && wave == 0);                            // slot 17: its share of the 43 windows is added up
   if (waves > 1) {
     if (wave > 0 && c.active) sh_part[(wave - 1) * 40 + 10 * c.row + c.k] = h;
     __syncthreads();
@@ -659,7 +683,9 @@ k_mul_base_coop(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__
       h = coop_add(c, h, coop_to_cached(c, o));
     }
   }
+  KYB_PHASE(18, blockIdx.x == 0);                                         // slot 18: the partial sums of the other wavefronts are in
   coop_finish(c, h, neg, out_enc, out_ext, i, proj, proj_stride, proj_offset, ext_proj != 0, true);
+  KYB_PHASE(19, blockIdx.x == 0);                                         // slot 19: encoded and stored
   if (c.lane == 0) signal_done(df);
 }
 
@@ -1032,6 +1058,7 @@ hipError_t msm_bases_coop(hipStream_t st, const int32_t* pts_ext, size_t t, uint
   return hipGetLastError();
 }
 #ifdef KYB_CROSSCHECK
+hipError_t diag_phase_stamps(uint64_t* buf) { return hipMemcpyToSymbol(HIP_SYMBOL(kyb_phase_buf), &buf, sizeof(buf)); }
 hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* table_coop) {
   hipLaunchKernelGGL(k_coop_selftest, dim3(1), dim3(64), 0, st, op, A, B, out, table_coop);
   return hipGetLastError();

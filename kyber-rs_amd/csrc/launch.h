@@ -124,6 +124,7 @@ hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* o
                          uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, const uint8_t* sc_b = nullptr, size_t n_b = 0,
                          DoneFlag df = DoneFlag{}, int waves = 1, bool ext_proj = false);      // waves: 1, or 4 wavefronts per item sharing the 43 windows
 hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32_t* B, uint32_t* out, const uint32_t* table_coop);
+hipError_t diag_phase_stamps(uint64_t* buf);      // (cross-check build only, like coop_selftest)
 
 // ---- kernels_verify.hip ----
 hipError_t verify_prep_pts(hipStream_t st, const uint8_t* pub_enc, const int32_t* pubs_ext, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n,

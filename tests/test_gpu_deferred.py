@@ -170,21 +170,38 @@ def test_random_graphs_match_the_eager_calls(eng, oracle):
         for h, want in nodes:
             enc, ext = eng.defer_get(h, want_ext=True)
             assert enc == oracle.encode(want) and oracle.encode(ext) == enc
-    # stale handles
+    # a small window: the value of an evaluated node outlives it (the table of kept values) — handles stay good, as answers and as operands;
+    # with the table switched off a handle older than the window is refused, never answered wrongly; the host's floor drops values and all
     eng.set_option("defer.max_nodes", 64)
     try:
         first = eng.defer_mul_base(_le(5))
         for i in range(200):
             eng.defer_mul_base(_le(i))
+        st = eng.defer_stats()
+        assert st["nodes_dropped"] > 0 and st["values_kept"] > 0 and st["nodes_held"] <= 64
+        assert eng.defer_get(first) == oracle.mul_base(_le(5))                                        # answered from the table
+        again = eng.defer_mul(_le(3), first)                                                          # ... and taken back in as an operand
+        assert eng.defer_get(again) == oracle.mul_base(_le(15))
+        assert eng.defer_equal(first, eng.defer_mul_base(_le(5))) and not eng.defer_equal(first, again)
+        st2 = eng.defer_stats()
+        assert st2["kept_hits"] > st["kept_hits"] and st2["operands_readmitted"] > st["operands_readmitted"]
+        eng.set_option("defer.keep_mib", 0)
+        lost = eng.defer_mul_base(_le(9))
+        for i in range(200):
+            eng.defer_mul_base(_le(i))
         with pytest.raises(kyber_rs_amd.KyberHipError, match="stale"):
-            eng.defer_get(first)
-        assert eng.defer_stats()["nodes_dropped"] > 0
+            eng.defer_get(lost)
+        eng.set_option("defer.keep_mib", 256)
         m = eng.defer_mark()
         keep = eng.defer_mul_base(_le(7))
         eng.defer_floor(m)
-        assert eng.defer_stats()["nodes_held"] == 1 and eng.defer_get(keep) == oracle.mul_base(_le(7))
+        st3 = eng.defer_stats()
+        assert st3["nodes_held"] == 1 and st3["values_kept"] == 0 and eng.defer_get(keep) == oracle.mul_base(_le(7))
+        with pytest.raises(kyber_rs_amd.KyberHipError, match="stale"):
+            eng.defer_get(first)                                                                      # the floor is the host's word that nothing older is wanted
     finally:
         eng.set_option("defer.max_nodes", 1 << 18)
+        eng.set_option("defer.keep_mib", 256)
 
 
 def test_threads_recording_into_one_arena(eng, oracle):
