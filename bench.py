@@ -79,7 +79,7 @@ WORKLOAD_TEXT = {"mul": "2^20 variable-base scalar-mults, random scalars+points,
 PEAK_MAD_NOMINAL = 1024 * 64 / 4 * 2.4e9
 HBM_PEAK_GBS = 8000.0
 DEFAULT_N = {"mul": 1 << 20, "mul_enc": 1 << 20, "mul_base": 1 << 20, "sign": 1 << 18, "verify": 1 << 20}
-PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")
 OPTION_KEYS = ("device.cus", "coop.max_items", "coop.base_max_items", "coop.ladder_max_items", "ladder.skip_canonical", "ladder.pair_max_items")      # (kernel variants are not options of the product library)
 
 
@@ -428,7 +428,7 @@ def roofline(w, eng, steps, peak, clock, cus):
          "avg_launch_ms": round(dom_ms, 4), "launches_timed": len(per_kernel[dom]),
          "executed_achieved": round(exec_rate / 1e12, 3), "executed_frac": round(exec_rate / pk, 4), "executed_frac_nominal": round(exec_rate / PEAK_MAD_NOMINAL, 4),
          "frac_vs_reference_algorithm": round(alg_rate / pk, 4),
-         "traffic": traffic, "traffic_source": traffic_source}
+         "traffic": traffic, "traffic_measured_in_this_run": False, "traffic_replayed_from_profiles": traffic is not None, "traffic_source": traffic_source}
     if clock is not None:
         simd_cycles = dom_ms * 1e-3 * clock["ghz"] * 1e9
         wave_mads_per_simd = executed * items_per_launch / 64.0 / (cus * 4)

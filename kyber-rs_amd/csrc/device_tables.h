@@ -159,11 +159,7 @@ struct tbl_lds64 {
     uint32_t lane = threadIdx.x & 63u;
     if (once) asm volatile("" : "+v"(lane));     // a fetch outside the window loop: recompute the lane terms there instead of keeping them live across it
     const uint32_t mine = lane & (uint32_t)(E - 1);
-#ifdef KYB_AB_REQUESTER_NEG
-    const uint32_t s = 0u;                                             // A/B: every lane holds the POSITIVE entry; the requester negates
-#else
     const uint32_t s = SIGNED ? (lane >> 5) & 1u : 0u;                 // this lane holds the negated entry
-#endif
     const uint32_t* pa = win + (s ? 8 * E : 0);                        // plane A (ypx 0..7) or B (ymx 0..7)
     const uint32_t* pb = win + (s ? 0 : 8 * E);
     const uint32_t* qa = win + (s ? 18 * E : 16 * E);                  // plane a (ypx 8, 9) or b
@@ -182,31 +178,6 @@ struct tbl_lds64 {
     const uint2 wc = *reinterpret_cast<const uint2*>(win + 28 * E + mine * 2);
     own[8] = wa.x; own[9] = wa.y; own[18] = wb.x; own[19] = wb.y; own[28] = wc.x; own[29] = wc.y;
   }
-#ifdef KYB_AB_REQUESTER_NEG
-  // A/B (profiles/r06/ab_base_requester_neg.log): the source lane is (own half | idx) — 32 sources in 32 banks per lane group, no bank
-  // conflict whatever the digits — and the REQUESTING lane swaps ypx / ymx and negates xy2d for a negative digit
-  template <bool SIGNED>
-  __device__ __forceinline__ void permute(ge_precomp& c, uint32_t own[30], uint32_t src_lane) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t neg = SIGNED ? (src_lane >> 5) & 1u : 0u;
-    const int src = SIGNED ? (int)(((lane & ~31u) | (src_lane & 31u)) << 2) : (int)(((lane & ~63u) | src_lane) << 2);
-    uint32_t f[30];
-#pragma unroll
-    for (int i = 0; i < 30; ++i) f[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)own[i]);
-    if (SIGNED) {
-      const uint32_t p2[10] = KYB_FE_2P;
-      const uint32_t m = 0u - neg;
-#pragma unroll
-      for (int i = 0; i < 10; ++i) {
-        const uint32_t a = f[i], b = f[10 + i];
-        f[i] = neg ? b : a; f[10 + i] = neg ? a : b;
-        f[20 + i] = (f[20 + i] ^ m) + (m & (p2[i] + 1u));
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { c.ypx.v[i] = f[i]; c.ymx.v[i] = f[10 + i]; c.xy2d.v[i] = f[20 + i]; }
-  }
-#else
   template <bool SIGNED>
   __device__ __forceinline__ void permute(ge_precomp& c, uint32_t own[30], uint32_t src_lane) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -223,7 +194,6 @@ struct tbl_lds64 {
 #pragma unroll
     for (int i = 0; i < 10; ++i) { c.ypx.v[i] = f[i]; c.ymx.v[i] = f[10 + i]; c.xy2d.v[i] = f[20 + i]; }
   }
-#endif
   template <int E, bool SIGNED>
   __device__ __forceinline__ void fetch(ge_precomp& c, const uint32_t* win, uint32_t src_lane, bool once = false) {
     uint32_t own[30];
