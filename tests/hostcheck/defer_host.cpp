@@ -408,6 +408,33 @@ int main() {
     uint8_t eq = 0; uint64_t again;
     CHECK(kyb_defer_input(key_ext, &again) == KYB_OK && kyb_defer_equal(key, again, &eq) == KYB_OK && eq == 1, "kept == young");
     CHECK(kyb_defer_equal(old_commits[0].h, old_commits[1].h, &eq) == KYB_OK && eq == 0 && kyb_defer_equal(old_commits[2].h, old_commits[2].h, &eq) == KYB_OK && eq == 1, "kept == kept");
+    // an inner step of a fused chain, asked for BY NAME when its operands are already behind the window: evaluated from their kept values
+    {
+      std::vector<Held> cs(4);
+      for (auto& c : cs) { uint8_t sc[32]; rnd(sc); orc_mul_base(nullptr, c.ext, sc); CHECK(kyb_defer_mul_base(sc, &c.h) == KYB_OK, "coefficient"); }
+      for (uint32_t i = 0; i < 100; ++i) { uint8_t sc[32]; uint64_t h; scalar_small(sc, 700000 + i); CHECK(kyb_defer_mul_base(sc, &h) == KYB_OK, "filler"); }
+      uint8_t x[32]; scalar_small(x, 3);
+      uint64_t v, inner = 0; int32_t want[40], inner_want[40];
+      CHECK(kyb_defer_null(&v) == KYB_OK, "null"); orc_null(want);
+      for (int j = 4; j-- > 0;) {
+        uint64_t m, a;
+        CHECK(kyb_defer_mul(x, v, &m) == KYB_OK && kyb_defer_add(m, cs[(size_t)j].h, 0, &a) == KYB_OK, "horner");
+        v = a;
+        int32_t prod[40]; orc_mul(nullptr, prod, x, want); orc_add(want, prod, cs[(size_t)j].ext, 0);
+        if (j == 2) { inner = a; memcpy(inner_want, want, 160); }
+      }
+      uint64_t sth[12]; kyb_defer_stats(sth, 12);
+      CHECK(got_enc(v) == enc_of(want), "the chain's end");
+      uint64_t sti[12]; kyb_defer_stats(sti, 12);
+      CHECK(sti[3] == sth[3] + 1, "evaluated as ONE chain: its inner steps have no value");
+      for (uint32_t i = 0; i < 150; ++i) { uint8_t sc[32]; uint64_t h; scalar_small(sc, 800000 + i); CHECK(kyb_defer_mul_base(sc, &h) == KYB_OK, "filler"); }
+      uint64_t stj[12]; kyb_defer_stats(stj, 12);
+      uint8_t e32[32];
+      CHECK((cs[3].h & 0xffffffffffull) < (kyb_defer_mark() & 0xffffffffffull) - stj[6], "the coefficients are behind the window");
+      CHECK((inner & 0xffffffffffull) >= (kyb_defer_mark() & 0xffffffffffull) - stj[6], "the inner step is still inside it");
+      CHECK(got_enc(inner) == enc_of(inner_want), "an inner step asked for by name: its operands come from the kept values");
+      (void)e32;
+    }
     // the table is bounded: at 1 MiB (5,041 values) the untouched go, what is touched every so often stays
     g_ctx.opt_defer_keep_mib = 1;
     for (uint32_t i = 0; i < 12000; ++i) {
