@@ -121,51 +121,78 @@ static std::string enc_of(const int32_t* ext) { uint8_t e[32]; orc_encode(e, ext
 static std::string got_enc(uint64_t h) { uint8_t e[32]; if (kyb_defer_get(h, nullptr, e) != KYB_OK) return "error: " + g_err; return std::string((const char*)e, 32); }
 static void scalar_small(uint8_t s[32], uint32_t x) { memset(s, 0, 32); memcpy(s, &x, 4); }
 
-static void random_graphs(unsigned seed, int steps) {
+// small_window: the graphs run through a window of 48 nodes with the table of kept values on — every path of the eviction logic under random
+// shapes (operands behind the window, operands about to leave it, chains cut by the window's edge, flushes forced by it).  A handle may then be
+// REFUSED (KYB_E_STALE) — the test keeps handles of leaves and of inner steps of fused chains, which leave no value behind — but every answer
+// that is given must be right, and a refused handle is dropped from the pool.
+static long g_stale_seen = 0, g_answers = 0;
+static void random_graphs(unsigned seed, int steps, bool small_window = false) {
   std::mt19937_64 rng(seed);
   std::vector<Val> nodes;
   auto rnd_scalar = [&](uint8_t s[32]) { for (int i = 0; i < 32; ++i) s[i] = (uint8_t)rng(); if (rng() % 3 == 0) { memset(s + 1, 0, 31); } if (rng() % 4) s[31] &= 0x0f; };
-  for (int i = 0; i < 5; ++i) { Val v; uint8_t s[32]; rnd_scalar(s); orc_mul_base(nullptr, v.ext, s); CHECK(kyb_defer_input(v.ext, &v.h) == KYB_OK, "input"); nodes.push_back(v); }
-  { Val v; orc_null(v.ext); CHECK(kyb_defer_null(&v.h) == KYB_OK, "null"); nodes.push_back(v); }
-  { Val v; orc_base(v.ext); CHECK(kyb_defer_base(&v.h) == KYB_OK, "base"); nodes.push_back(v); }
+  // rc of a recording / asking call: KYB_OK, or (small window only) a stale operand — which is then forgotten
+  auto fine = [&](int rc, std::initializer_list<uint64_t> used) {
+    if (rc == KYB_OK) return true;
+    if (small_window && rc == KYB_E_STALE && g_err.find("stale") != std::string::npos) {
+      ++g_stale_seen;
+      // forget the handles that can no longer be used: those of `used` the arena refuses when asked directly
+      for (uint64_t h : used) { uint8_t e[32]; if (kyb_defer_get(h, nullptr, e) == KYB_E_STALE) nodes.erase(std::remove_if(nodes.begin(), nodes.end(), [&](const Val& v) { return v.h == h; }), nodes.end()); }
+      return false;
+    }
+    CHECK(false, "a deferred call failed");
+    return false;
+  };
+  auto seed_leaves = [&] {
+    for (int i = 0; i < 5; ++i) { Val v; uint8_t s[32]; rnd_scalar(s); orc_mul_base(nullptr, v.ext, s); CHECK(kyb_defer_input(v.ext, &v.h) == KYB_OK, "input"); nodes.push_back(v); }
+    { Val v; orc_null(v.ext); CHECK(kyb_defer_null(&v.h) == KYB_OK, "null"); nodes.push_back(v); }
+    { Val v; orc_base(v.ext); CHECK(kyb_defer_base(&v.h) == KYB_OK, "base"); nodes.push_back(v); }
+  };
+  seed_leaves();
   for (int st = 0; st < steps; ++st) {
+    if (nodes.size() < 4) seed_leaves();
     const Val a = nodes[rng() % nodes.size()], b = nodes[rng() % nodes.size()];
     uint8_t s[32]; rnd_scalar(s);
     Val v;
     switch (rng() % 7) {
-      case 0: orc_mul_base(nullptr, v.ext, s); CHECK(kyb_defer_mul_base(s, &v.h) == KYB_OK, "mul_base"); nodes.push_back(v); break;
-      case 1: orc_mul(nullptr, v.ext, s, a.ext); CHECK(kyb_defer_mul(s, a.h, &v.h) == KYB_OK, "mul"); nodes.push_back(v); break;
-      case 2: orc_add(v.ext, a.ext, b.ext, 0); CHECK(kyb_defer_add(a.h, b.h, 0, &v.h) == KYB_OK, "add"); nodes.push_back(v); break;
-      case 3: orc_add(v.ext, a.ext, b.ext, 1); CHECK(kyb_defer_add(a.h, b.h, 1, &v.h) == KYB_OK, "sub"); nodes.push_back(v); break;
-      case 4: orc_neg(v.ext, a.ext); CHECK(kyb_defer_neg(a.h, &v.h) == KYB_OK, "neg"); nodes.push_back(v); break;
+      case 0: orc_mul_base(nullptr, v.ext, s); if (fine(kyb_defer_mul_base(s, &v.h), {})) nodes.push_back(v); break;
+      case 1: orc_mul(nullptr, v.ext, s, a.ext); if (fine(kyb_defer_mul(s, a.h, &v.h), {a.h})) nodes.push_back(v); break;
+      case 2: orc_add(v.ext, a.ext, b.ext, 0); if (fine(kyb_defer_add(a.h, b.h, 0, &v.h), {a.h, b.h})) nodes.push_back(v); break;
+      case 3: orc_add(v.ext, a.ext, b.ext, 1); if (fine(kyb_defer_add(a.h, b.h, 1, &v.h), {a.h, b.h})) nodes.push_back(v); break;
+      case 4: orc_neg(v.ext, a.ext); if (fine(kyb_defer_neg(a.h, &v.h), {a.h})) nodes.push_back(v); break;
       case 5: {      // a short Horner chain with a small multiplier on top of a
         uint8_t x[32]; scalar_small(x, (uint32_t)(1 + rng() % 9));
         Val cur = a;
         const int len = 1 + (int)(rng() % 5);
-        for (int k = 0; k < len; ++k) {
+        bool whole = true;
+        for (int k = 0; k < len && whole; ++k) {
+          if (nodes.empty()) { whole = false; break; }
           const Val c = nodes[rng() % nodes.size()];
           Val m, s2;
-          orc_mul(nullptr, m.ext, x, cur.ext); CHECK(kyb_defer_mul(x, cur.h, &m.h) == KYB_OK, "chain mul");
-          orc_add(s2.ext, m.ext, c.ext, 0); CHECK((rng() & 1 ? kyb_defer_add(m.h, c.h, 0, &s2.h) : kyb_defer_add(c.h, m.h, 0, &s2.h)) == KYB_OK, "chain add");
+          orc_mul(nullptr, m.ext, x, cur.ext);
+          if (!fine(kyb_defer_mul(x, cur.h, &m.h), {cur.h})) { whole = false; break; }
+          orc_add(s2.ext, m.ext, c.ext, 0);
+          if (!fine(rng() & 1 ? kyb_defer_add(m.h, c.h, 0, &s2.h) : kyb_defer_add(c.h, m.h, 0, &s2.h), {m.h, c.h})) { whole = false; break; }
           if (rng() % 4 == 0) nodes.push_back(s2);          // sometimes an inner node is kept and asked for later
           if (rng() % 5 == 0) nodes.push_back(m);           // ... and so is an inner PRODUCT (`m = x v; s = m + c; ...; m.marshal_binary()`)
-          if (rng() % 16 == 0) CHECK(got_enc(m.h) == enc_of(m.ext), "inner product asked for while its chain is pending");
+          if (rng() % 16 == 0) { uint8_t e[32]; if (fine(kyb_defer_get(m.h, nullptr, e), {m.h})) { ++g_answers; CHECK(std::string((const char*)e, 32) == enc_of(m.ext), "inner product asked for while its chain is pending"); } }
           cur = s2;
         }
-        nodes.push_back(cur);
+        if (whole) nodes.push_back(cur);
         break;
       }
       default: {
         const int k = (int)(rng() % 3);
-        if (k == 0) CHECK(got_enc(a.h) == enc_of(a.ext), "get");
-        else if (k == 1) { uint8_t eq = 2; CHECK(kyb_defer_equal(a.h, b.h, &eq) == KYB_OK && (eq != 0) == (enc_of(a.ext) == enc_of(b.ext)), "equal"); }
+        if (k == 0) { uint8_t e[32]; if (fine(kyb_defer_get(a.h, nullptr, e), {a.h})) { ++g_answers; CHECK(std::string((const char*)e, 32) == enc_of(a.ext), "get"); } }
+        else if (k == 1) { uint8_t eq = 2; if (fine(kyb_defer_equal(a.h, b.h, &eq), {a.h, b.h})) { ++g_answers; CHECK((eq != 0) == (enc_of(a.ext) == enc_of(b.ext)), "equal"); } }
         else CHECK(kyb_defer_flush() == KYB_OK, "flush");
       }
     }
   }
-  for (const Val& v : nodes) {
+  const std::vector<Val> at_end = nodes;
+  for (const Val& v : at_end) {
     int32_t ext[40]; uint8_t e[32];
-    CHECK(kyb_defer_get(v.h, ext, e) == KYB_OK, "final get");
+    if (!fine(kyb_defer_get(v.h, ext, e), {v.h})) continue;
+    ++g_answers;
     CHECK(std::string((const char*)e, 32) == enc_of(v.ext) && enc_of(ext) == enc_of(v.ext), "final value");
   }
 }
@@ -176,6 +203,16 @@ int main() {
     g_ctx.opt_defer_fuse = seed % 4 != 0;
     random_graphs(seed, 220);
   }
+  // the same random graphs through a window of 48 nodes (it moves by 12 at a time): kept values, operands taken back in, forced flushes
+  g_ctx.opt_defer_max_nodes = 48;
+  for (unsigned seed = 101; seed <= 124; ++seed) {
+    g_ctx.opt_defer_fuse = seed % 4 != 0;
+    random_graphs(seed, 400, true);
+  }
+  std::printf("small window: %ld answers checked, %ld calls refused as stale\n", g_answers, g_stale_seen);
+  CHECK(g_answers > 3000 && g_stale_seen * 4 < g_answers, "through a small window most handles stay good, and every answer given is right");
+  CHECK(kyb_defer_floor(kyb_defer_mark()) == KYB_OK, "floor");
+  g_ctx.opt_defer_max_nodes = 1 << 18;
   g_ctx.opt_defer_fuse = 1;
   // PubPoly::eval: one call; six chains: still one call
   {
