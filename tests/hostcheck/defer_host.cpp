@@ -211,6 +211,16 @@ int main() {
   }
   std::printf("small window: %ld answers checked, %ld calls refused as stale\n", g_answers, g_stale_seen);
   CHECK(g_answers > 3000 && g_stale_seen * 4 < g_answers, "through a small window most handles stay good, and every answer given is right");
+  // ... and with a table of 40 values behind it (second-chance eviction at every step): more handles are refused, no answer is wrong
+  {
+    const long a0 = g_answers, s0 = g_stale_seen;
+    g_ctx.opt_defer_keep_mib = -40;
+    for (unsigned seed = 201; seed <= 216; ++seed) { g_ctx.opt_defer_fuse = seed % 4 != 0; random_graphs(seed, 400, true); }
+    g_ctx.opt_defer_keep_mib = 256;
+    uint64_t st[12]; kyb_defer_stats(st, 12);
+    std::printf("small window, 40 kept values: %ld answers checked, %ld calls refused as stale, %llu values pushed out\n", g_answers - a0, g_stale_seen - s0, (unsigned long long)st[9]);
+    CHECK(g_answers - a0 > 800 && st[9] > 500 && st[8] <= 40, "a tiny table: bounded, evicting, never wrong");
+  }
   CHECK(kyb_defer_floor(kyb_defer_mark()) == KYB_OK, "floor");
   g_ctx.opt_defer_max_nodes = 1 << 18;
   g_ctx.opt_defer_fuse = 1;
