@@ -429,7 +429,8 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  * recorded before `mark` (= an earlier kyb_defer_mark()), values included: the host's own statement that a round is over; (2) its node never
  * had a value when the window left it — the inner steps of a chain that was evaluated as ONE call, which exist as locals that the reference's
  * loops overwrite (poly.rs:457-469, 566-603); (3) its value was pushed out of the table: untouched while defer.keep_mib of younger values
- * arrived (at 64 participants a Pedersen dealer round leaves about 200 values: tens of thousands of rounds).  A binding whose point still
+ * arrived (at 64 participants a Pedersen dealer round leaves 300 to 750 values: the table holds the last 1,700 to 4,600 rounds, what is
+ * touched stays longer).  A binding whose point still
  * holds its limbs registers them again (host/edwards25519.hpp).  Secret scalars are kept until their node is evaluated and cleared then; a
  * node's limbs and bytes — a recorded Diffie-Hellman exchange leaves the shared point there — are cleared when they leave the window without
  * being kept, when they leave the table, and at the end of the arena: call kyb_defer_floor when a round's secrets are done with.
