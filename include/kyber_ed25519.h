@@ -439,6 +439,10 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  * its points to the thread that marshals them) — the evaluation then runs on the reader's context.  The arena of a released context stays
  * readable as an orphan until sixteen younger orphans exist.
  *   kyb_defer_input   a point the caller holds (40 limbs) as a leaf          kyb_defer_null / _base   the neutral element / B
+ *   kyb_defer_input_enc   the same, with the 32 bytes marshal_binary yields for it when the caller knows them (NULL: unknown) — a point that was
+ *                     unmarshalled from its canonical encoding: the leaf has its bytes from the start, so comparing it with an evaluated point
+ *                     (the search of the own key among the participants' keys, dss_sig.rs:180-190) is 32 bytes against 32 bytes, no engine call.
+ *                     The bytes are taken on trust: they must be what kyb_encode_batch would return for these limbs.
  *   kyb_defer_mul_base / _mul / _add (subtract != 0: a - b) / _neg            Point::mul(s, None) / mul(s, Some(p)) / add / sub / neg
  *   kyb_defer_get(p, out_ext, out_enc)   evaluates p — and everything else recorded so far: who asks for one result will ask for the others —
  *                                        and returns its limbs and / or marshal_binary; either pointer may be NULL
@@ -447,6 +451,7 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  *                                        marshal cache hits, nodes in the window now, nodes that left the window, values kept now, values
  *                                        pushed out of the table, answers from the table, operands taken back in (for tests and benchmarks) */
 int kyb_defer_input(const int32_t* ext, uint64_t* out);
+int kyb_defer_input_enc(const int32_t* ext, const uint8_t* enc, uint64_t* out);
 int kyb_defer_null(uint64_t* out);
 int kyb_defer_base(uint64_t* out);
 int kyb_defer_mul_base(const uint8_t* scalar, uint64_t* out);

@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "kyb_sum_batch", "kyb_sum_batch_dev",
     "kyb_pubpoly_eval_multi_enc_batch", "kyb_pubpoly_eval_multi_enc_batch_dev", "kyb_sum_enc_batch", "kyb_sum_enc_batch_dev",
     "kyb_dkg_verify_round_enc", "kyb_dkg_verify_round_enc_dev",
-    "kyb_defer_input", "kyb_defer_null", "kyb_defer_base", "kyb_defer_mul_base", "kyb_defer_mul", "kyb_defer_add", "kyb_defer_neg", "kyb_defer_get", "kyb_defer_equal",
+    "kyb_defer_input", "kyb_defer_input_enc", "kyb_defer_null", "kyb_defer_base", "kyb_defer_mul_base", "kyb_defer_mul", "kyb_defer_add", "kyb_defer_neg", "kyb_defer_get", "kyb_defer_equal",
     "kyb_defer_flush", "kyb_defer_mark", "kyb_defer_floor", "kyb_defer_stats",
     "kyb_host_alloc", "kyb_host_free",
     "kyb_set_option", "kyb_get_option", "kyb_profile_begin", "kyb_profile_read", "kyb_kernel_name",
@@ -197,6 +197,7 @@ def load_library(crosscheck: bool = False) -> ctypes.CDLL:
     lib.kyb_equal_batch_dev.argtypes = [vp, vp, sz, vp, vp]
     u64, pu64 = ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)
     lib.kyb_defer_input.argtypes = [vp, pu64]
+    lib.kyb_defer_input_enc.argtypes = [vp, vp, pu64]
     lib.kyb_defer_null.argtypes = [pu64]
     lib.kyb_defer_base.argtypes = [pu64]
     lib.kyb_defer_mul_base.argtypes = [vp, pu64]

@@ -222,7 +222,7 @@ class Point {
   // handle only as a cache (the marshal_binary that follows is then a hit in the arena): when the arena has dropped the node meanwhile
   // (kyb_defer_floor, defer.max_nodes -> KYB_E_STALE) the limbs are registered again instead of aborting — record() / marshal / == below.
   uint64_t handle() const {
-    if (pend == 0) detail::engine_must(kyb_defer_input(ge, &pend), "Point: kyb_defer_input");
+    if (pend == 0) detail::engine_must(kyb_defer_input_enc(ge, have_enc ? enc : nullptr, &pend), "Point: kyb_defer_input_enc");      // (with its bytes, when it has them)
     return pend;
   }
   bool forget_stale_handle() const { if (have_ge && pend != 0) { pend = 0; return true; } return false; }

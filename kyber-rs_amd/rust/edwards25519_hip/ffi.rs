@@ -73,6 +73,7 @@ extern "C" {
     pub fn kyb_pripoly_eval_batch(coeffs: *const u8, m: size_t, t: size_t, indices: *const u32, k: size_t, out_shares: *mut u8) -> c_int;
     // deferred points: operations recorded in the context's arena, evaluated in batches when a result is asked for
     pub fn kyb_defer_input(ext: *const i32, out: *mut u64) -> c_int;
+    pub fn kyb_defer_input_enc(ext: *const i32, enc: *const u8, out: *mut u64) -> c_int;
     pub fn kyb_defer_mul_base(scalar: *const u8, out: *mut u64) -> c_int;
     pub fn kyb_defer_mul(scalar: *const u8, p: u64, out: *mut u64) -> c_int;
     pub fn kyb_defer_add(a: u64, b: u64, subtract: c_int, out: *mut u64) -> c_int;

@@ -171,7 +171,9 @@ impl Point {
         }
         ensure_init();
         let mut h = 0u64;
-        must(unsafe { ffi::kyb_defer_input(self.ge.as_ptr() as *const i32, &mut h) }, "defer_input");
+        // (with the bytes it was unmarshalled from, when it has them: comparing it with an evaluated point is then a byte comparison in the arena)
+        let bytes = self.enc.as_ref().map_or(std::ptr::null(), |e| e.as_ptr());
+        must(unsafe { ffi::kyb_defer_input_enc(self.ge.as_ptr() as *const i32, bytes, &mut h) }, "defer_input");
         h
     }
     fn ext_mut(&mut self) -> *mut i32 {

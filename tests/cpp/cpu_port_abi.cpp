@@ -81,6 +81,7 @@ int kyb_verify_points_batch(const int32_t* pubs_ext, const uint8_t* msgs, const 
 #ifndef KYB_CPU_PORT_DEFER
 // the CPU port runs eagerly: nothing is recorded
 int kyb_defer_input(const int32_t*, uint64_t*) { return refuse("cpu port: no deferred mode"); }
+int kyb_defer_input_enc(const int32_t*, const uint8_t*, uint64_t*) { return refuse("cpu port: no deferred mode"); }
 int kyb_defer_null(uint64_t*) { return refuse("cpu port: no deferred mode"); }
 int kyb_defer_base(uint64_t*) { return refuse("cpu port: no deferred mode"); }
 int kyb_defer_mul_base(const uint8_t*, uint64_t*) { return refuse("cpu port: no deferred mode"); }

@@ -379,6 +379,31 @@ int main() {
     }
     CHECK(got_enc(acc) == enc_of(want) && g_calls - c0 == 2, "sum chain: two engine calls");
   }
+  // a leaf handed over WITH its bytes (a point unmarshalled from its canonical encoding): comparing it with evaluated points costs no engine call
+  // — the search of the own key among the participants' keys (dss_sig.rs:180-190) — and its marshal is a cache hit
+  {
+    const size_t n = 12;
+    std::vector<Val> keys(n);
+    std::vector<std::string> key_enc(n);
+    for (size_t j = 0; j < n; ++j) {
+      uint8_t sc[32]; scalar_small(sc, 60000 + (uint32_t)j);
+      uint8_t e[32]; orc_mul_base(e, keys[j].ext, sc); key_enc[j] = std::string((const char*)e, 32);
+      CHECK(kyb_defer_input_enc(keys[j].ext, e, &keys[j].h) == KYB_OK, "leaf with bytes");
+    }
+    uint8_t sc[32]; scalar_small(sc, 60000 + 7);
+    uint64_t own; CHECK(kyb_defer_mul_base(sc, &own) == KYB_OK, "own key");
+    uint8_t eq = 0;
+    CHECK(kyb_defer_equal(keys[0].h, own, &eq) == KYB_OK && eq == 0, "first comparison evaluates the own key (with its bytes)");
+    const long c0 = g_calls;
+    size_t found = n;
+    for (size_t j = 0; j < n; ++j) { CHECK(kyb_defer_equal(keys[j].h, own, &eq) == KYB_OK, "search"); if (eq) { found = j; break; } }
+    CHECK(found == 7 && g_calls == c0, "the search itself: byte comparisons, not one engine call");
+    CHECK(got_enc(keys[3].h) == key_enc[3] && g_calls == c0, "the marshal of such a leaf is a hit");
+    uint64_t again; CHECK(kyb_defer_input(keys[5].ext, &again) == KYB_OK && again == keys[5].h, "the same limbs without bytes: the same leaf");
+    Val plain; uint8_t e2[32]; scalar_small(sc, 61000); orc_mul_base(e2, plain.ext, sc);
+    CHECK(kyb_defer_input(plain.ext, &plain.h) == KYB_OK && kyb_defer_input_enc(plain.ext, e2, &again) == KYB_OK && again == plain.h, "bytes that arrive later are taken");
+    CHECK(kyb_defer_equal(plain.h, own, &eq) == KYB_OK && eq == 0 && g_calls == c0, "... and used");
+  }
   // a small window and NO table of kept values (defer.keep_mib = 0): old handles become stale, never wrong; floor / mark
   {
     g_ctx.opt_defer_max_nodes = 32;
