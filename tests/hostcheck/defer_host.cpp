@@ -569,8 +569,9 @@ int main() {
     g_ctx.opt_defer_max_nodes = 1 << 18;
     (void)mark0;
   }
-  // four threads on the one arena
-  {
+  // four threads on the one arena — with the default window, then through a window of 64 nodes (their handles are answered from the kept values)
+  for (int small = 0; small < 2; ++small) {
+    g_ctx.opt_defer_max_nodes = small ? 64 : 1 << 18;
     std::vector<std::thread> th;
     std::atomic<int> bad{0};
     for (int i = 0; i < 4; ++i)
@@ -582,7 +583,8 @@ int main() {
         }
       });
     for (auto& t : th) t.join();
-    CHECK(bad == 0, "threads");
+    CHECK(bad == 0, small ? "threads through a small window" : "threads");
+    g_ctx.opt_defer_max_nodes = 1 << 18;
   }
   // a handle names its arena: a point recorded through one context is read, and used as an operand, through another — also after the first context is gone
   {

@@ -204,6 +204,109 @@ def test_random_graphs_match_the_eager_calls(eng, oracle):
         eng.set_option("defer.keep_mib", 256)
 
 
+def test_random_graphs_through_a_small_window_on_the_engine(eng, oracle):
+    """the random graphs again, on the real kernels, through a window of 64 nodes (it moves by 16 after a flush of everything pending): values
+    kept behind the window — also those a projective flush left with Z != 1 and no bytes —, operands taken back in as leaves, Horner steps cut by
+    the window's edge.  A handle may be refused (leaves and never-evaluated inner steps leave nothing behind) — then it is dropped from the pool —
+    but whatever is answered equals the oracle's eager evaluation, and no flush fails."""
+    import kyber_rs_amd
+    rng = np.random.default_rng(4646)
+    pts = oracle.mul_base_ext_batch(synth.scalars(6, 4747))
+    eng.set_option("defer.max_nodes", 64)
+    answers = refused = 0
+    try:
+        for trial in range(8):
+            eng.set_option("defer.fuse", 0 if trial % 4 == 3 else 1)
+            nodes = []
+
+            def leaves():
+                for p in pts:
+                    nodes.append((eng.defer_input(p), p))
+                nodes.append((eng.defer_null(), oracle.null()))
+                nodes.append((eng.defer_base(), oracle.base()))
+
+            def attempt(fn, used):
+                """fn() -> result, or None when an operand was refused as stale (it is then forgotten)"""
+                nonlocal refused
+                try:
+                    return fn()
+                except kyber_rs_amd.KyberHipError as e:
+                    assert "stale" in str(e), e
+                    refused += 1
+                    for h in used:
+                        try:
+                            eng.defer_get(h)
+                        except kyber_rs_amd.KyberHipError:
+                            nodes[:] = [nd for nd in nodes if nd[0] != h]
+                    return None
+
+            leaves()
+            for step in range(260):
+                if len(nodes) < 4:
+                    leaves()
+                op = rng.integers(0, 7)
+                a = nodes[rng.integers(0, len(nodes))]
+                b = nodes[rng.integers(0, len(nodes))]
+                sc = [synth.scalars(1, 5000 * trial + step)[0].tobytes(), _le(int(rng.integers(1, 9))), synth.raw256(1, 5000 * trial + step)[0].tobytes()][rng.integers(0, 3)]
+                if op == 0:
+                    h = attempt(lambda: eng.defer_mul_base(sc), ())
+                    if h is not None:
+                        nodes.append((h, oracle.mul_base_ext(sc)))
+                elif op == 1:
+                    h = attempt(lambda: eng.defer_mul(sc, a[0]), (a[0],))
+                    if h is not None:
+                        nodes.append((h, oracle.mul_ext(sc, a[1])))
+                elif op in (2, 3):
+                    h = attempt(lambda: eng.defer_add(a[0], b[0], subtract=(op == 3)), (a[0], b[0]))
+                    if h is not None:
+                        nodes.append((h, oracle.add(a[1], b[1], sub=(op == 3))))
+                elif op == 4:                      # a short Horner chain with a share index on top of a
+                    x = _le(int(rng.integers(1, 9)))
+                    cur = a
+                    for _ in range(int(rng.integers(2, 6))):
+                        c = nodes[rng.integers(0, len(nodes))]
+                        m = attempt(lambda: eng.defer_mul(x, cur[0]), (cur[0],))
+                        if m is None:
+                            cur = None
+                            break
+                        mv = oracle.mul_ext(x, cur[1])
+                        sm = attempt(lambda: eng.defer_add(m, c[0]), (m, c[0]))
+                        if sm is None:
+                            cur = None
+                            break
+                        cur = (sm, oracle.add(mv, c[1]))
+                        if rng.integers(0, 4) == 0:
+                            nodes.append(cur)          # an inner step is kept and used later
+                    if cur is not None:
+                        nodes.append(cur)
+                else:
+                    k = rng.integers(0, 3)
+                    if k == 0:
+                        got = attempt(lambda: eng.defer_get(a[0]), (a[0],))
+                        if got is not None:
+                            answers += 1
+                            assert got == oracle.encode(a[1])
+                    elif k == 1:
+                        got = attempt(lambda: eng.defer_equal(a[0], b[0]), (a[0], b[0]))
+                        if got is not None:
+                            answers += 1
+                            assert got == (oracle.encode(a[1]) == oracle.encode(b[1]))
+                    else:
+                        eng.defer_flush()              # never fails: nothing pending can have lost an operand
+            for h, want in list(nodes):
+                got = attempt(lambda: eng.defer_get(h, want_ext=True), (h,))
+                if got is not None:
+                    answers += 1
+                    assert got[0] == oracle.encode(want) and oracle.encode(got[1]) == got[0]
+        st = eng.defer_stats()
+        print(f"small window on the engine: {answers} answers checked, {refused} calls refused as stale; {st}")
+        assert answers > 600 and refused * 3 < answers and st["kept_hits"] > 0 and st["operands_readmitted"] > 0
+    finally:
+        eng.set_option("defer.max_nodes", 1 << 18)
+        eng.set_option("defer.fuse", 1)
+        eng.defer_floor(eng.defer_mark())
+
+
 def test_threads_recording_into_one_arena(eng, oracle):
     """four host threads record and ask on ONE context at the same time (the arena has its own lock; a flush evaluates everybody's nodes): every
     thread gets its own results right"""
