@@ -220,7 +220,8 @@ class Point {
   }
   // this point as an operand of a recorded operation: its handle, or a leaf made of its limbs.  A point that HOLDS its limbs keeps the
   // handle only as a cache (the marshal_binary that follows is then a hit in the arena): when the arena has dropped the node meanwhile
-  // (kyb_defer_floor, defer.max_nodes -> KYB_E_STALE) the limbs are registered again instead of aborting — record() / marshal / == below.
+  // (a leaf leaves no value behind when the arena's window moves on, and kyb_defer_floor drops everything older than its mark -> KYB_E_STALE) the
+  // limbs are registered again instead of aborting — record() / marshal / == below.
   uint64_t handle() const {
     if (pend == 0) detail::engine_must(kyb_defer_input_enc(ge, have_enc ? enc : nullptr, &pend), "Point: kyb_defer_input_enc");      // (with its bytes, when it has them)
     return pend;

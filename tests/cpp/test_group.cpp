@@ -485,7 +485,7 @@ int main() {
     }
   }
   // a long-lived key used as a deferred operand keeps a CACHED handle; when the arena drops the node (kyb_defer_floor at the end of a round,
-  // defer.max_nodes) the limbs the point still holds are registered again — no abort, same bytes (KYB_E_STALE)
+  // the window moving past a leaf) the limbs the point still holds are registered again — no abort, same bytes (KYB_E_STALE)
   {
     Scalar k = Scalar().pick(rand), x = Scalar().pick(rand);
     set_deferred(false);
