@@ -433,7 +433,8 @@ int kyb_equal_batch_dev(const int32_t* a_ext, const int32_t* b_ext, size_t n, ui
  * touched stays longer).  A binding whose point still
  * holds its limbs registers them again (host/edwards25519.hpp).  Secret scalars are kept until their node is evaluated and cleared then; a
  * node's limbs and bytes — a recorded Diffie-Hellman exchange leaves the shared point there — are cleared when they leave the window without
- * being kept, when they leave the table, and at the end of the arena: call kyb_defer_floor when a round's secrets are done with.
+ * being kept, when they leave the table, and at the end of the arena (the evaluator's own staging arrays as they are released): call
+ * kyb_defer_floor when a round's secrets are done with.
  * A handle carries the number of the arena it came from (upper 24 bits), so handles of two contexts never collide and a point recorded
  * through one context may be read, compared or used as an operand through another (the reference's Point is Send: a worker thread may hand
  * its points to the thread that marshals them) — the evaluation then runs on the reader's context.  The arena of a released context stays
