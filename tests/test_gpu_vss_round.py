@@ -13,14 +13,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build(prog, cpu_port=False, cpu_defer=False):
+def build(prog, cpu_port=False, cpu_defer=False, sanitize=False):
     """tests/cpp/<prog>.cpp against the engine — or, cpu_port, against tests/cpp/cpu_port_abi.cpp: the oracle behind the same entry points, so that the
     very same call-by-call sequence runs on one host core (the CPU column of the per-phase tables; test infrastructure, nothing of it ships).
     cpu_defer: that CPU port with the PRODUCT's deferred-point evaluator (csrc/defer.inc) compiled on top of it — the bindings' default mode on the CPU."""
     src = os.path.join(ROOT, "tests", "cpp", prog + ".cpp")
-    out = os.path.join(ROOT, "tests", "cpp", "_build", prog + ("_cpu_defer" if cpu_defer else "_cpu_port" if cpu_port else ""))
+    out = os.path.join(ROOT, "tests", "cpp", "_build", prog + ("_cpu_defer" if cpu_defer else "_cpu_port" if cpu_port else "") + ("_asan" if sanitize else ""))
     os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-o", out, src]
+    if sanitize:      # (CPU builds only: AddressSanitizer + UBSan over the C++ mirror and the product's defer.inc)
+        cmd[1:2] = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
     if cpu_port or cpu_defer:
         orc = os.path.join(ROOT, "oracle", "_build")
         cmd += ["-DKYB_CPU_PORT", os.path.join(ROOT, "tests", "cpp", "cpu_port_abi.cpp"), "-L", orc, "-loracle", f"-Wl,-rpath,{orc}"]

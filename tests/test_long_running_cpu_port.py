@@ -10,7 +10,8 @@ from test_gpu_vss_round import build
 
 
 def _run(args, timeout=600):
-    return subprocess.run([build("test_long_running", cpu_defer=True)] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
+    # (under AddressSanitizer + UBSan: the C++ mirror and the product's defer.inc — window moves, kept values, leaves taken back in)
+    return subprocess.run([build("test_long_running", cpu_defer=True, sanitize=True)] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout)
 
 
 def test_three_hundred_rounds_through_a_small_window(oracle):
