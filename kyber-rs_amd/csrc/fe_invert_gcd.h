@@ -110,13 +110,7 @@ KYB_HD void fe_invert_gcd(fe& h, const fe& z) {
   fe_from_words(h, o);
 }
 
-// the inversion the kernels use: -DKYB_INVERT_FERMAT restores the exponentiation (same results; A/B in profiles/r03/ab_invert_gcd.log)
-KYB_HD void fe_inv(fe& h, const fe& z) {
-#if defined(KYB_INVERT_FERMAT)
-  fe_invert(h, z);
-#else
-  fe_invert_gcd(h, z);
-#endif
-}
+// the inversion the kernels use (the exponentiation fe_invert gives the same results: A/B in profiles/r03/ab_invert_gcd.log)
+KYB_HD void fe_inv(fe& h, const fe& z) { fe_invert_gcd(h, z); }
 
 }  // namespace kyb

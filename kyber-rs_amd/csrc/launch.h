@@ -24,10 +24,7 @@ namespace kyb {
 
 constexpr int KYB_BLOCK = 256;      // threads per workgroup of every one-item-per-lane kernel
 constexpr int KYB_BLOCK32 = 1024;   // radix-32 fixed-base kernel
-#ifndef KYB_FINISH_K
-#define KYB_FINISH_K 8
-#endif
-constexpr int FINISH_K = KYB_FINISH_K;         // items per shared field inversion (k_finish, k_mont_prep, k_encode_batched); -DKYB_FINISH_K=.. for A/B builds
+constexpr int FINISH_K = 8;                    // items per shared field inversion (k_finish, k_mont_prep, k_encode_batched)
 
 // The short kernels either side of the ladder (k_mont_prep, k_finish: one wavefront per 512 items, a 265-multiplication inversion chain
 // each) raise their wavefronts' issue priority.  Alone on the chip it changes nothing.  In the pipelined host-pointer path they share

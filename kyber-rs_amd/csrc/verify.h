@@ -17,10 +17,6 @@
 #include "sc25519.h"
 #include "sha512.h"
 
-// kernels.hip may route the point decodes through an out-of-line copy of ge_decode
-#ifndef KYB_GE_DECODE
-#define KYB_GE_DECODE ge_decode
-#endif
 
 namespace kyb {
 
@@ -142,7 +138,7 @@ KYB_HD uint32_t verify_prep_a_point_with(uint32_t h[8], ge_p3& A, const ge_p3& P
   sc_reduce512(h, dig);
   return s_ok | (a_can << 1) | (a_dec << 2) | (a_small << 3);
 }
-struct ge_decode_fn { KYB_HD uint32_t operator()(ge_p3& P, const uint32_t w[8]) const { return KYB_GE_DECODE(P, w); } };
+struct ge_decode_fn { KYB_HD uint32_t operator()(ge_p3& P, const uint32_t w[8]) const { return ge_decode(P, w); } };
 KYB_HD uint32_t verify_prep_a(uint32_t h[8], ge_p3& A, const uint32_t pub[8], const uint32_t sig[16], const uint8_t* msg, uint32_t msg_len) {
   return verify_prep_a_with(h, A, pub, sig, msg, msg_len, ge_decode_fn());
 }

@@ -321,6 +321,9 @@ class Point {
   std::vector<uint8_t> marshal_binary() const {
     if (have_enc) return std::vector<uint8_t>(enc, enc + 32);
     std::vector<uint8_t> b(32);
+    // (deferred mode: a point that holds limbs without bytes is marshalled THROUGH the arena, as the leaf its limbs are — the bytes stay with the
+    //  leaf, so marshalling the same value again costs no engine call even for a binding whose point cannot remember them: the Rust type is Copy)
+    if (pend == 0 && deferred()) (void)handle();
     if (pend != 0) {                       // recorded (or registered as an operand): the arena evaluates what it depends on and caches the bytes
       const int rc = kyb_defer_get(pend, have_ge ? nullptr : ge, b.data());
       if (!(rc == KYB_E_STALE && forget_stale_handle())) {      // (a dropped node of a point that holds its limbs: marshal the limbs, below)

@@ -197,8 +197,10 @@ impl Point {
         }
         ensure_init();
         let mut b = [0u8; 32];
-        if self.pend != 0 {
-            must(unsafe { ffi::kyb_defer_get(self.pend, std::ptr::null_mut(), b.as_mut_ptr()) }, "defer_get");
+        if self.pend != 0 || deferred() {
+            // (a point that holds limbs goes through the arena as the leaf its limbs are: the bytes stay with the leaf, so marshalling the
+            //  same value again — protocol state is marshalled in every round — costs no engine call although `&self` cannot remember them)
+            must(unsafe { ffi::kyb_defer_get(self.handle(), std::ptr::null_mut(), b.as_mut_ptr()) }, "defer_get");
         } else {
             must(unsafe { ffi::kyb_encode_batch(self.ge.as_ptr() as *const i32, 1, b.as_mut_ptr()) }, "encode");
         }
