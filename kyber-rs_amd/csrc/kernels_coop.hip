@@ -53,10 +53,124 @@ __device__ __forceinline__ void phase_stamp(int slot, bool mine) {
 #define KYB_PHASE(slot, mine) ((void)0)
 #endif
 
-// affine (x, y) of the point (X : Y : Z) in rows 0..2 of a tight quad, in every lane; Z^-1 cooperative (0 when Z = 0: the reference's 0^(p-2))
+// ---- ONE field inversion by a whole wavefront (round 6) ----------------------------------------------------------------------------------
+// The one-item kernels end in Z^-1, and a lone wavefront issues one instruction per ~5.3 cycles on whichever unit: the 254 cooperative squarings +
+// 11 products of cinv (coop25519.h) are ~12,000 instructions, 30.6 us of a 41 us one-item fixed-base multiplication
+// (profiles/r06/one_item_stamps.log).  Here: Bernstein-Yang safegcd (fe_invert_gcd.h: 20 batches of 30 divsteps, 2x2 matrix per batch) laid out over
+// the lanes —
+//   * the 30 divsteps of a batch in THREE lane roles (lane & 3 = 0: (f, g) low words, 1: (u, q), 2: (v, r)): the three updates of a divstep are one
+//     vector instruction each, the decision bits uniform (g's low bit read from lane 0, zeta in scalar registers): 14 instructions per divstep
+//     where one lane needs ~22;
+//   * the nine 30-bit limbs of d, e, f, g in lanes 0..8 of every 16-lane row: the matrix step is two multiply-adds per lane and quantity, the
+//     division by 2^30 a limb shift by DPP with two short carry passes (limbs stay LOOSELY normalised, in [-1, 2^30 + 1]: the products have the
+//     room, the low 30 bits the next divsteps look at are exact, and an exact carry chain runs once at the end);
+// ~10,600 instructions: fixed base + encoding 55.4 -> 49.7 us, encode of a projective point 46.4 -> 40.2, variable base 164.3 -> 159.6, signing
+// 92.8 -> 90.3 (profiles/r06/ab_coop_inv_gcd.log).  Same result as cinv / fe_invert bit for bit (the inverse is unique; 0 -> 0).  Constant time:
+// 600 divsteps whatever the input, every selection a mask, no table, no branch (tools/ct_check.py covers the kernels that use it).
+// tools/gcd_lanes_model.py is the limb-exact model (every intermediate in the width used here, against x^(p-2)); the cross-check build runs it
+// beside cinv on the device (k_coop_selftest op 9, tests/test_gpu_coop.py).
+// ---- the nine 30-bit limbs of d, e, f, g in lanes 0..8 of every 16-lane row (lanes 9..15 hold 0) ---------------------------------------------
+// One 64-bit column value per lane -> the number divided by 2^30, limb k again in lane k: x_k = lo_k + mid_k 2^30 + top_k 2^60, so the new limb k is
+// lo_(k+1) + mid_k + top_(k-1); two short carry passes leave limbs 0..7 in [-1, 2^30 + 1] (LOOSELY normalised: the next products have the room, the
+// low 30 bits the divsteps look at are exact) and everything above in the signed limb 8.
+struct gcd_lane_consts { uint32_t k; uint32_t mk30, cmask, live; int32_t mod; };
+__device__ __forceinline__ int32_t gcd_shr1(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, KYB_DPP_ROW_SHR(1), 0xf, 0xf, true); }      // lane k reads lane k-1
+__device__ __forceinline__ int32_t gcd_shl1(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, KYB_DPP_ROW_SHL(1), 0xf, 0xf, true); }      // lane k reads lane k+1
+__device__ __forceinline__ int32_t gcd_lane_div30(const gcd_lane_consts& L, int64_t x) {
+  const int32_t lo = (int32_t)((uint32_t)x & KYB_GCD_M30);
+  const int32_t mid = (int32_t)((uint32_t)(x >> 30) & L.mk30);           // lane 8: everything above bit 30 (|x_8| < 2^48), signed
+  const int32_t top = (int32_t)(x >> 60);                                // -4 .. 3  (lane 8's goes to lane 9, which is cleared)
+  const int32_t t1 = gcd_shl1(lo) + gcd_shr1(top);                       // [-4, 2^30 + 2]
+  const int32_t c1 = (t1 >> 30) & (int32_t)L.cmask;                      // (no carry out of lane 8)
+  const int32_t r1 = (int32_t)((uint32_t)t1 & L.mk30);
+  const int32_t t2 = r1 + mid;                                           // lanes 0..7: [0, 2^31 - 2]
+  const int32_t c2 = (int32_t)(((uint32_t)t2 >> 30) & L.cmask);
+  const int32_t r2 = (int32_t)((uint32_t)t2 & L.mk30);
+  return (r2 + gcd_shr1(c1 + c2)) & (int32_t)L.live;
+}
+// 30 divsteps on the low words in three lane roles, the matrix as uniform values (gcd_divsteps_30 of fe_invert_gcd.h is the one-lane form)
+__device__ __forceinline__ int32_t gcd_divsteps_30_roles(int32_t zeta, uint32_t f0, uint32_t g0, int32_t& mu, int32_t& mv, int32_t& mq, int32_t& mr) {
+  const uint32_t role = threadIdx.x & 3u;
+  uint32_t F = role == 0 ? f0 : (role == 1 ? 1u : 0u);
+  uint32_t G = role == 0 ? g0 : (role == 1 ? 0u : 1u);
+  const uint32_t shG = role == 0 ? 1u : 0u, shF = role == 0 ? 0u : 1u;
+#pragma unroll
+  for (int i = 0; i < 30; ++i) {
+    const uint32_t g_lo = (uint32_t)__builtin_amdgcn_readlane((int)G, 0);
+    const uint32_t c2 = 0u - (g_lo & 1u);
+    uint32_t c1 = (uint32_t)(zeta >> 31);
+    const uint32_t x = (F ^ c1) - c1;
+    G += x & c2;
+    c1 &= c2;
+    zeta = (int32_t)((uint32_t)zeta ^ c1) - 1;
+    F += G & c1;
+    G >>= shG; F <<= shF;
+  }
+  mu = __builtin_amdgcn_readlane((int)F, 1); mv = __builtin_amdgcn_readlane((int)F, 2);
+  mq = __builtin_amdgcn_readlane((int)G, 1); mr = __builtin_amdgcn_readlane((int)G, 2);
+  return zeta;
+}
+__device__ __forceinline__ void gcd_carry_chain(int32_t r[9]) { KYB_UNROLL for (int i = 0; i < 8; ++i) { r[i + 1] += r[i] >> 30; r[i] &= KYB_GCD_M30; } }
+__device__ __forceinline__ void fe_invert_gcd_wave(fe& h, const fe& z) {
+  uint32_t w[8];
+  fe_to_words(w, z);
+  int32_t g0[9];
+  g0[0] = (int32_t)(w[0] & KYB_GCD_M30);
+  KYB_UNROLL for (int i = 1; i < 8; ++i) g0[i] = (int32_t)(((w[i - 1] >> (32 - 2 * i)) | (w[i] << (2 * i))) & KYB_GCD_M30);
+  g0[8] = (int32_t)(w[7] >> 16);
+  const int32_t modv[9] = KYB_GCD_MOD;
+  gcd_lane_consts L;
+  L.k = threadIdx.x & 15u;
+  L.mk30 = L.k < 8u ? KYB_GCD_M30 : 0xffffffffu;
+  L.cmask = L.k < 8u ? 0xffffffffu : 0u;
+  L.live = L.k <= 8u ? 0xffffffffu : 0u;
+  int32_t Gv = 0, Fv = 0;
+  KYB_UNROLL for (int i = 0; i < 9; ++i) { Gv = L.k == (uint32_t)i ? g0[i] : Gv; Fv = L.k == (uint32_t)i ? modv[i] : Fv; }
+  L.mod = Fv;
+  int32_t D = 0, E = L.k == 0u ? 1 : 0;
+  int32_t zeta = -1;
+#pragma unroll 1
+  for (int it = 0; it < 20; ++it) {
+    int32_t u, v, q, r;
+    zeta = gcd_divsteps_30_roles(zeta, (uint32_t)__builtin_amdgcn_readlane(Fv, 0), (uint32_t)__builtin_amdgcn_readlane(Gv, 0), u, v, q, r);
+    // (d, e) <- (u d + v e + md p, q d + r e + me p) / 2^30: md, me clear the low 30 bits (gcd_update_de)
+    const int64_t bd = (int64_t)u * D + (int64_t)v * E, be = (int64_t)q * D + (int64_t)r * E;
+    const int32_t sd = __builtin_amdgcn_readlane(D, 8) >> 31, se = __builtin_amdgcn_readlane(E, 8) >> 31;
+    int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+    md -= (int32_t)((KYB_GCD_MODINV30 * (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)bd, 0) + (uint32_t)md) & KYB_GCD_M30);
+    me -= (int32_t)((KYB_GCD_MODINV30 * (uint32_t)__builtin_amdgcn_readlane((int32_t)(uint32_t)be, 0) + (uint32_t)me) & KYB_GCD_M30);
+    const int32_t nD = gcd_lane_div30(L, bd + (int64_t)L.mod * md);
+    const int32_t nE = gcd_lane_div30(L, be + (int64_t)L.mod * me);
+    // (f, g) <- (u f + v g, q f + r g) / 2^30, exact
+    const int32_t nF = gcd_lane_div30(L, (int64_t)u * Fv + (int64_t)v * Gv);
+    const int32_t nG = gcd_lane_div30(L, (int64_t)q * Fv + (int64_t)r * Gv);
+    D = nD; E = nE; Fv = nF; Gv = nG;
+  }
+  int32_t d[9], f[9];
+  KYB_UNROLL for (int i = 0; i < 9; ++i) { d[i] = __builtin_amdgcn_readlane(D, i); f[i] = __builtin_amdgcn_readlane(Fv, i); }
+  gcd_carry_chain(f);                                                    // f = +-1 (+-p for z = 0): its sign from EXACT limbs
+  // d (|d| < 2p up to the loose limbs' epsilon; anything below 8p is handled) -> sign(f) d + 8p in (0, 16p) -> a field element:
+  // 8p = 2^258 - 152 in 30-bit limbs; what lies above bit 255 folds back as 19 (bit 255) and 38 (bits 256..258)
+  const int32_t neg = f[8] >> 31;
+  KYB_UNROLL for (int i = 0; i < 9; ++i) d[i] = (d[i] ^ neg) - neg;
+  const int32_t p8[9] = {0x3fffff68, 0x3fffffff, 0x3fffffff, 0x3fffffff, 0x3fffffff, 0x3fffffff, 0x3fffffff, 0x3fffffff, 0x3ffff};
+  KYB_UNROLL for (int i = 0; i < 9; ++i) d[i] += p8[i];
+  gcd_carry_chain(d);
+  const uint32_t above = (uint32_t)d[8] >> 16;                           // bits 256.. : 0..7
+  d[8] &= 0xffff;
+  uint32_t o[8];
+  KYB_UNROLL for (int i = 0; i < 8; ++i) o[i] = ((uint32_t)d[i] >> (2 * i)) | ((uint32_t)d[i + 1] << (30 - 2 * i));
+  fe_from_words(h, o);                                                   // (ignores bit 255)
+  h.v[0] += 19u * (o[7] >> 31) + 38u * above;                            // <= 285 above the mask: tight
+}
+// affine (x, y) of the point (X : Y : Z) in rows 0..2 of a tight quad, in every lane; Z^-1 by the whole wavefront (0 when Z = 0: the reference's 0^(p-2))
 __device__ __forceinline__ void coop_affine(const lane_consts& c, cq q, fe& x, fe& y) {
-  const cq inv = cinv(c, q);
-  const cq zi = bperm(rowperm_idx(c, 2, 2, 2, 2), inv);
+  fe Z, zinv;
+  fe_from_quad_row(c, Z, q, 2);
+  fe_invert_gcd_wave(zinv, Z);
+  uint32_t v = 0;
+  KYB_UNROLL for (int j = 0; j < 10; ++j) v = (c.k == (uint32_t)j) ? zinv.v[j] : v;
+  const cq zi = c.active ? v : 0u;                                   // Z^-1 in every row
   const cq xy = cmul4(c, q, zi);                                     // rows 0, 1 = x, y
   fe_from_quad_row(c, x, xy, 0);
   fe_from_quad_row(c, y, xy, 1);
@@ -1002,7 +1116,8 @@ k_verify_coop(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs
 // Test hook (tests/test_gpu_coop.py, against the lane-level model tools/coop_model.py): one wavefront applies ONE
 // cooperative primitive to caller-supplied quads.  op: 0 cmul4(A, B), 1 cnorm(A), 2 cinv(A), 3 mixed addition h = A, entry = B,
 // 4 table entry (window, idx, negate) = (B[0], B[1], B[2]) of the radix-64 image, 5 csub(A, B), 6 one ladder step S = A,
-// U1 / W1 in rows 0 / 2 of B, swap / bit in B lanes 16 / 17 (returns S'), 7 quad -> fe -> quad round trip of every row, 8 csq4(A).
+// U1 / W1 in rows 0 / 2 of B, swap / bit in B lanes 16 / 17 (returns S'), 7 quad -> fe -> quad round trip of every row, 8 csq4(A),
+// 9 fe_invert_gcd_wave(row 0 of A) in every row.
 __global__ void __launch_bounds__(64)
 k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restrict__ B, uint32_t* __restrict__ out, const uint32_t* __restrict__ table_coop) {
   KYB_COOP_CONSTS(c, 1);
@@ -1011,6 +1126,14 @@ k_coop_selftest(int op, const uint32_t* __restrict__ A, const uint32_t* __restri
   if (op == 0) r = cmul4(c, a, b);
   else if (op == 1) r = cnorm(c, a);
   else if (op == 2) r = cinv(c, a);
+  else if (op == 9) {                                                 // the wavefront's safegcd inversion of row 0, result in every row
+    fe Z, zi;
+    fe_from_quad_row(c, Z, a, 0);
+    fe_invert_gcd_wave(zi, Z);
+    uint32_t v = 0;
+    KYB_UNROLL for (int j = 0; j < 10; ++j) v = (c.k == (uint32_t)j) ? zi.v[j] : v;
+    r = c.active ? v : 0u;
+  }
   else if (op == 5) r = csub(c, a, b);
   else if (op == 8) r = csq4(c, a);
   else if (op == 4) {

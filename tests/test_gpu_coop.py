@@ -427,6 +427,35 @@ def test_coop_and_batch_kernels_agree_at_the_threshold(engine, oracle):
         engine.set_option("coop.base_max_items", old[1])
 
 
+def test_the_wavefront_inversion_matches_the_exponentiation_and_python(xengine):
+    """csrc/kernels_coop.hip fe_invert_gcd_wave (safegcd over the lanes; what every one-item kernel ends in since round 6) through the test hook of the
+    cross-check build (op 9), against the cooperative exponentiation it replaced (op 2, cinv) and against Python's pow(z, p - 2, p): edge values
+    (0 -> 0, 1, p - 1, values around 2^255, small and huge) and random ones; tools/gcd_lanes_model.py is the limb-exact model of the same code."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import coop_model as M
+    import kyber_rs_amd
+    lib = kyber_rs_amd.load_library(crosscheck=True)
+    xengine.device_info()
+    c = M.lane_consts()
+    P = 2**255 - 19
+    rng = random.Random(606)
+    vals = [0, 1, 2, 3, 19, P - 1, P - 2, (P - 1) // 2, 2**254, 2**255 - 20, 2**30, 2**30 - 1, 2**240, 2**252 + 27742317777372353535851937790883648493]
+    vals += [rng.randrange(P) for _ in range(150)] + [rng.randrange(2**64) for _ in range(20)] + [P - rng.randrange(2**64) for _ in range(20)]
+    for z in vals:
+        A = np.ascontiguousarray(M.quad_from_ints(c, [z, z, z, z]), dtype=np.uint32)
+        B = np.zeros(64, np.uint32)
+        got = {}
+        for op in (9, 2):
+            out = np.zeros(64, np.uint32)
+            assert lib.kyb_diag_coop(op, A.ctypes.data, B.ctypes.data, out.ctypes.data) == 0
+            got[op] = [v % P for v in M.ints_from_quad(out.astype(np.uint64))]
+        want = pow(z, P - 2, P)
+        assert got[9] == [want] * 4, (hex(z), got[9][0], want)
+        assert got[2] == [want] * 4, hex(z)
+
+
 def test_coop_primitives_match_the_lane_model(xengine):
     """every cooperative primitive (cmul4, cnorm, csub, cinv, table entry, mixed addition, ladder step, layout round
     trip) run by one wavefront through the test hook of the cross-check build (the same device code as the product's; the product
