@@ -59,7 +59,7 @@ __device__ __forceinline__ void phase_stamp(int slot, bool mine) {
 // (profiles/r06/one_item_stamps.log).  Here: Bernstein-Yang safegcd (fe_invert_gcd.h: 20 batches of 30 divsteps, 2x2 matrix per batch) laid out over
 // the lanes —
 //   * the 30 divsteps of a batch in THREE lane roles (lane & 3 = 0: (f, g) low words, 1: (u, q), 2: (v, r)): the three updates of a divstep are one
-//     vector instruction each, the decision bits uniform (g's low bit read from lane 0, zeta in scalar registers): 14 instructions per divstep
+//     vector instruction each, the decision bits uniform (g's low bit read from lane 0, zeta in scalar registers): 13 instructions per divstep
 //     where one lane needs ~22;
 //   * the nine 30-bit limbs of d, e, f, g in lanes 0..8 of every 16-lane row: the matrix step is two multiply-adds per lane and quantity, the
 //     division by 2^30 a limb shift by DPP with two short carry passes (limbs stay LOOSELY normalised, in [-1, 2^30 + 1]: the products have the
@@ -102,6 +102,7 @@ __device__ __forceinline__ int32_t gcd_divsteps_30_roles(int32_t zeta, uint32_t 
     const uint32_t x = (F ^ c1) - c1;
     G += x & c2;
     c1 &= c2;
+    asm volatile("" : "+s"(c1));                                     // the combined mask stays a scalar operand (else c2 is copied into a vector register: 14 -> 13 instructions)
     zeta = (int32_t)((uint32_t)zeta ^ c1) - 1;
     F += G & c1;
     G >>= shG; F <<= shF;
