@@ -489,7 +489,7 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     the number here: the hand-over sizes below — kept as wavefronts per compute unit — and the persistent grids follow it.
  *   coop.max_items    batches of at most this many items take the one-item-per-wavefront kernels (variable base, verification,
  *                     polynomial evaluation; default 24 per compute unit = 6144 on an MI355X, 0 = never); coop.base_max_items the same for the
- *                     fixed base and signing (13 per compute unit = 3328), coop.decode_max_items for a bare decode (4 per compute unit = 1024),
+ *                     fixed base and signing (18 per compute unit = 4608), coop.decode_max_items for a bare decode (4 per compute unit = 1024),
  *                     coop.verify_max_items for the kernels that give ONE item several wavefronts (verification in one launch, signing in one
  *                     launch, the fixed base with four wavefronts per item: item counts up to 2 per compute unit = 512; the variable base with
  *                     an item's scalar in four pieces on four workgroups: up to a quarter of that, 128).  Setting one of them sets an absolute
@@ -502,7 +502,7 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     projective, so that no inversion runs in front (default 128 x compute units = one wavefront per SIMD: 32768 on an MI355X, 0 = never): up to there the
  *                     call time is one lane's chain of 255 steps, and the two-lane form takes 0.49 instead of 0.79 ms.  Same results.  These
  *                     launches always walk 256 bits (minus publicly known zeros): ladder.skip_canonical does not apply to them.
- *   coop.ladder_max_items  variable base and linear combinations leave the one-item-per-wavefront kernels above this many items (default 11 per compute unit = 2816;
+ *   coop.ladder_max_items  variable base and linear combinations leave the one-item-per-wavefront kernels above this many items (default 14 per compute unit = 3584;
  *                     verification with the keys given as points at 7/8 of it) even when coop.max_items would still allow them: from there the
  *                     two-lane ladder is faster.
  *   coop.ladder_enc_max_items  the same for calls from BYTES — kyb_mul_batch with pts_enc (full-length multipliers), kyb_verify_batch: default 8 per compute unit = 2048

@@ -263,13 +263,15 @@ void wipe_free_dev(Ctx& g, void* p, size_t bytes) {
 // as per-CU figures, multiplied by the CUs the context works with: the device's, or what the host declares with option device.cus (a CU-masked
 // stream, a partitioned device whose streams see fewer CUs than the property says; profiles/r05/coop_crossover_cu_mask.log).  An explicit
 // kyb_set_option of one of the thresholds still sets an absolute item count.
-constexpr int COOP_MAX_PER_CU = 24, COOP_BASE_MAX_PER_CU = 13, COOP_LADDER_MAX_PER_CU = 11, COOP_LADDER_ENC_MAX_PER_CU = 8, COOP_DECODE_MAX_PER_CU = 4,
+// (round 6: the one-item-per-wavefront point operations move rows with permlane swaps instead of ds_bpermute and end in a cheaper inversion — they
+//  stay ahead of the batch kernels for longer: fixed base 13 -> 18, variable base 11 -> 14 wavefronts per CU; profiles/r06/coop_crossover.log)
+constexpr int COOP_MAX_PER_CU = 24, COOP_BASE_MAX_PER_CU = 18, COOP_LADDER_MAX_PER_CU = 14, COOP_LADDER_ENC_MAX_PER_CU = 8, COOP_DECODE_MAX_PER_CU = 4,
               COOP_VERIFY_MAX_PER_CU = 2, LADDER_PAIR_MAX_PER_CU = 128;      // (128: two lanes per item up to one wavefront per SIMD = 4 SIMDs x 64 lanes / 2)
 void apply_cu_count(Ctx& g, int cus) {
   g.cus = cus;
   g.opt_coop_max = COOP_MAX_PER_CU * cus;                       // 6,144 on 256 CUs
-  g.opt_coop_base_max = COOP_BASE_MAX_PER_CU * cus;             // 3,328
-  g.opt_coop_ladder_max = COOP_LADDER_MAX_PER_CU * cus;         // 2,816
+  g.opt_coop_base_max = COOP_BASE_MAX_PER_CU * cus;             // 4,608
+  g.opt_coop_ladder_max = COOP_LADDER_MAX_PER_CU * cus;         // 3,584
   g.opt_coop_ladder_enc_max = COOP_LADDER_ENC_MAX_PER_CU * cus; // 2,048
   g.opt_coop_decode_max = COOP_DECODE_MAX_PER_CU * cus;         // 1,024
   g.opt_coop_verify_max = COOP_VERIFY_MAX_PER_CU * cus;         // 512

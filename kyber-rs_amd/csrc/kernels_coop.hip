@@ -267,22 +267,34 @@ __device__ __forceinline__ ladder_state coop_ladder_step(const lane_consts& c, c
   // level 1: (aa, bb, da, cb) = (sa^2, sb^2, d*a, b*c) with (sa, sb) = swap ? (c, d) : (a, b)
   const int sx = (0 - (int)swap) & li.x128;
   const cq L1 = cmul4(c, bperm(li.I_F1 ^ sx, AB), bperm(li.I_G1 ^ sx, ABraw));
+  // (row moves by permlane swaps, as in coop_dbl — with several wavefronts per SIMD the LDS crossbar was the bottleneck: 2,048 items 334 -> 299 us,
+  //  profiles/r06/ab_permlane_rows.log; only level 1's operands keep the ds_bpermute, whose lane index carries the conditional swap)
+  const bool rlo = c.row < 2;
   // level 2: (s, t', x2', a24*e) = ((da+cb)^2, (da-cb)^2, aa*bb, e*a24),  e = aa - bb
-  const cq W = bperm(li.I_2200, L1), Z = bperm(li.I_3311, L1);                    // (da, da, aa, aa), (cb, cb, bb, bb)
+  const auto l16 = __builtin_amdgcn_permlane16_swap(L1, L1, false, false);         // (aa, aa, da, da), (bb, bb, cb, cb)
+  const auto le = __builtin_amdgcn_permlane32_swap(l16[0], l16[0], false, false);  // aa x 4, da x 4
+  const auto lo = __builtin_amdgcn_permlane32_swap(l16[1], l16[1], false, false);  // bb x 4, cb x 4
+  const cq W = rlo ? le[1] : le[0], Z = rlo ? lo[1] : lo[0];                       // (da, da, aa, aa), (cb, cb, bb, bb)
+  const cq A1 = le[0];                                                             // aa in every row
   const cq F2raw = rodd ? csub(c, W, Z) : (r2 ? W : cadd(W, Z));                   // (da+cb, da-cb, aa, e), <= 3T
   const cq F2 = cnorm(c, F2raw);
-  const cq E1 = bperm(li.I_3333, F2), A1 = bperm(li.I_0000, L1);                   // e, aa in every row
+  const auto f16 = __builtin_amdgcn_permlane16_swap(F2, F2, false, false);         // [1] = (F2.1, F2.1, e, e)
+  const auto fo = __builtin_amdgcn_permlane32_swap(f16[1], f16[1], false, false);  // [1] = e x 4
+  const cq E1 = fo[1];
   const cq L2 = cmul4(c, F2, r3 ? A24Q : (r2 ? Z : F2raw));
   // level 3: (z3', z2', x3') = (t' * U1, (a24*e + aa) * e, s * W1)
-  const cq T3 = bperm(li.I_1300, L2);                                              // (t', a24*e, s, s)
-  const cq X2 = bperm(li.I_2222, L2);                                              // x2' in every row
+  const auto m16 = __builtin_amdgcn_permlane16_swap(L2, L2, false, false);         // (s, s, x2', x2'), (t', t', a24e, a24e)
+  const auto me = __builtin_amdgcn_permlane32_swap(m16[0], m16[0], false, false);  // s x 4, x2' x 4
+  const auto mo = __builtin_amdgcn_permlane32_swap(m16[1], m16[1], false, false);  // t' x 4, a24e x 4
+  const cq T3 = c.row == 0 ? mo[0] : (r1 ? mo[1] : me[0]);                         // (t', a24*e, s, s)
+  const cq X2 = me[1];                                                             // x2' in every row
   const cq F3 = r1 ? cnorm(c, cadd(T3, A1)) : T3;                                  // row 3: * 0
   const cq L3 = cmul4(c, F3, r1 ? E1 : UWQ);
   // new state: SX = (x2', x2', x3', x3') = (L2 row 2 twice, L3 row 2 twice), SZ = (z2', z2', z3', z3') = (L3 rows 1, 1, 0, 0)
-  // (all cross-lane reads are issued by EVERY lane before the select: `cond ? bperm() : bperm()` would run each under a
-  // partial EXEC mask, and a ds_bpermute that reads a disabled lane gets 0)
-  const cq x3n = bperm(li.I_2222, L3), zn = bperm(li.I_1100, L3);
-  return ladder_state{c.row < 2 ? X2 : x3n, zn};
+  const auto n16 = __builtin_amdgcn_permlane16_swap(L3, L3, false, false);         // (z3', z3', x3', x3'), (z2', z2', ., .)
+  const auto ne = __builtin_amdgcn_permlane32_swap(n16[0], n16[0], false, false);  // z3' x 4, x3' x 4
+  const auto no = __builtin_amdgcn_permlane32_swap(n16[1], n16[1], false, false);  // z2' x 4
+  return ladder_state{rlo ? X2 : ne[1], rlo ? no[0] : ne[0]};
 }
 
 // Head of k_mul_coop in quads (mont_prep_proj, ge_ladder.h): PQ = (X, Y, Z, T) -> M = (U, V, W, 0), the projective Montgomery
@@ -370,6 +382,22 @@ __device__ __forceinline__ cq coop_mont_recover(const lane_consts& c, cq M, cq S
   return csel((uint32_t)r0 & negate, nres, RES);
 }
 
+// ---- row moves without the LDS crossbar (gfx950 v_permlane16_swap / v_permlane32_swap; tools/microbench/permlane_probe.hip) -------------------
+//   swap16(A, B) = ((A0, B0, A2, B2), (A1, B1, A3, B3)),   swap32(A, B) = ((A0, A1, B0, B1), (A2, A3, B2, B3))
+struct cq2 { cq a, b; };
+__device__ __forceinline__ cq2 swap16(cq x, cq y) { const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false); return cq2{r[0], r[1]}; }
+__device__ __forceinline__ cq2 swap32(cq x, cq y) { const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false); return cq2{r[0], r[1]}; }
+// the tail shared by the two additions: from (A, B, C, .) and D in rows 2, 3 of `dd` to the operands of the second level
+//   Q1 = (A, A, D, D), Q2 = (B, B, C, C);  SUM = (Y3, Y3, Z3, Z3), DIF = (X3, X3, T3, T3);  returns (X3 T3, Z3 Y3, Z3 T3, X3 Y3)
+__device__ __forceinline__ cq coop_add_tail(const lane_consts& c, cq LA, cq dd) {
+  const bool r0 = c.row == 0, r2 = c.row == 2, r3 = c.row == 3, rlo = c.row < 2;
+  const cq2 l16 = swap16(LA, LA);                                       // (A, A, C, C), (B, B, ., .)
+  const cq Q1 = rlo ? l16.a : dd, Q2 = rlo ? l16.b : l16.a;
+  const cq SUM = cadd(Q1, Q2), DIF = csub(c, Q1, Q2);
+  const cq2 sm = swap32(SUM, SUM), df = swap32(DIF, DIF);               // Y3 x 4, Z3 x 4;  X3 x 4, T3 x 4
+  return cmul4(c, cnorm(c, (r0 || r3) ? df.a : sm.b), (r0 || r2) ? df.b : sm.a);
+}
+
 // ---- general point arithmetic in quads: PubPoly::eval for small batches (share/poly.rs:457-469) ----------------------------------
 // (X : Y : Z : T) -> the cached form (Y+X, Y-X, 2d T, Z) the addition below takes as its second operand.  One multiplication level.
 __device__ __forceinline__ cq coop_to_cached(const lane_consts& c, cq P) {
@@ -378,33 +406,37 @@ __device__ __forceinline__ cq coop_to_cached(const lane_consts& c, cq P) {
   uint32_t d2k = 0;
   KYB_UNROLL for (int j = 0; j < 10; ++j) d2k = (c.k == (uint32_t)j) ? d2v[j] : d2k;
   const cq ONE0 = (c.k == 0 && c.active) ? 1u : 0u;
-  const cq a = bperm(rowperm_idx(c, 1, 1, 3, 2), P), b = bperm(rowperm_idx(c, 0, 0, 0, 0), P);      // (Y, Y, T, Z), X
+  const cq2 p16 = swap16(P, P);                                         // (X, X, Z, Z), (Y, Y, T, T)
+  const cq a = c.row == 3 ? p16.a : p16.b, b = swap32(p16.a, p16.a).a;  // (Y, Y, T, Z), X
   const cq F = cnorm(c, r0 ? cadd(a, b) : (r1 ? csub(c, a, b) : a));
   return cmul4(c, F, r2 ? (c.active ? d2k : 0u) : ONE0);
 }
 // h + E for extended h and cached E: ge_add followed by ge_p1p1_to_p3 (ge25519.h).  Two multiplication levels.
 __device__ __forceinline__ cq coop_add(const lane_consts& c, cq h, cq E) {
   const bool r0 = c.row == 0, r1 = c.row == 1, r2 = c.row == 2, r3 = c.row == 3;
-  const int I0 = rowperm_idx(c, 0, 0, 0, 0), I2 = rowperm_idx(c, 2, 2, 2, 2);
-  const cq U = bperm(rowperm_idx(c, 1, 1, 3, 2), h), V = bperm(I0, h);          // (Y, Y, T, Z), X
+  const cq2 h16 = swap16(h, h);                                                   // (X, X, Z, Z), (Y, Y, T, T)
+  const cq U = r3 ? h16.a : h16.b, V = swap32(h16.a, h16.a).a;                    // (Y, Y, T, Z), X
   const cq FA = cnorm(c, r0 ? cadd(U, V) : (r1 ? csub(c, U, V) : U));
   const cq LA = cmul4(c, FA, E);                                                  // (A, B, C, ZZ)
-  const cq H2 = cadd(LA, LA);
-  const cq qa = bperm(I0, LA), qd = bperm(rowperm_idx(c, 3, 3, 3, 3), H2);       // every lane issues both reads, then selects
-  const cq Q1 = (c.row < 2) ? qa : qd;                                            // (A, A, D, D), D = 2 ZZ
-  const cq Q2 = bperm(rowperm_idx(c, 1, 1, 2, 2), LA);                            // (B, B, C, C)
-  const cq SUM = cadd(Q1, Q2), DIF = csub(c, Q1, Q2);                             // (Y3, Y3, Z3, Z3), (X3, X3, T3, T3)
-  const cq x3 = bperm(I0, DIF), z3 = bperm(I2, SUM), t3 = bperm(I2, DIF), y3 = bperm(I0, SUM);
-  return cmul4(c, cnorm(c, (r0 || r3) ? x3 : z3), (r0 || r2) ? t3 : y3);          // (X3 T3, Z3 Y3, Z3 T3, X3 Y3)
+  const cq2 z16 = swap16(LA, LA);                                                 // .b = (B, B, ZZ, ZZ)
+  return coop_add_tail(c, LA, cadd(z16.b, z16.b));                                // D = 2 ZZ
 }
 // 2 h: ge_p2_dbl followed by ge_p1p1_to_p3.  One squaring level, one multiplication level.
 __device__ __forceinline__ cq coop_dbl(const lane_consts& c, cq h) {
   const bool r0 = c.row == 0, r1 = c.row == 1, r2 = c.row == 2, r3 = c.row == 3;
-  const cq a = bperm(rowperm_idx(c, 0, 1, 2, 0), h), b = bperm(rowperm_idx(c, 1, 1, 1, 1), h);
-  const cq xpy = cnorm(c, cadd(a, b));
-  const cq Q = csq4(c, r3 ? xpy : a);                                             // (XX, YY, ZZ, (X+Y)^2)
-  const cq xx = bperm(rowperm_idx(c, 0, 0, 0, 0), Q), yy = bperm(rowperm_idx(c, 1, 1, 1, 1), Q);
-  const cq zz = bperm(rowperm_idx(c, 2, 2, 2, 2), Q), aa = bperm(rowperm_idx(c, 3, 3, 3, 3), Q);
+  // Row moves by v_permlane16_swap / v_permlane32_swap (gfx950; semantics probed on the device: tools/microbench/permlane_probe.hip) —
+  //   swap16(A, B) = ((A0, B0, A2, B2), (A1, B1, A3, B3)),   swap32(A, B) = ((A0, A1, B0, B1), (A2, A3, B2, B3))
+  // — instead of ds_bpermute round trips through the LDS crossbar: a lone wavefront waits out every one of those (round 6: a doubling 0.43 ->
+  // 0.375 us, the 241 doublings of a one-item product 104 -> 91 us; profiles/r06/ab_permlane_rows.log)
+  const auto h16 = __builtin_amdgcn_permlane16_swap(h, h, false, false);            // (X, X, Z, Z), (Y, Y, T, T)
+  const cq s = h16[0] + h16[1];                                                   // (X + Y, X + Y, ., .)
+  const auto s32 = __builtin_amdgcn_permlane32_swap(s, s, false, false);            // X + Y in every row
+  const cq xpy = cnorm(c, s32[0]);
+  const cq Q = csq4(c, r3 ? xpy : h);                                             // (XX, YY, ZZ, (X+Y)^2)
+  const auto q16 = __builtin_amdgcn_permlane16_swap(Q, Q, false, false);            // (Q0, Q0, Q2, Q2), (Q1, Q1, Q3, Q3)
+  const auto qe = __builtin_amdgcn_permlane32_swap(q16[0], q16[0], false, false);   // Q0 x 4, Q2 x 4
+  const auto qo = __builtin_amdgcn_permlane32_swap(q16[1], q16[1], false, false);   // Q1 x 4, Q3 x 4
+  const cq xx = qe[0], zz = qe[1], yy = qo[0], aa = qo[1];
   // every row picks its first operand among the raw combinations and ONE carry pass makes it tight (a lone wavefront pays per instruction, not
   // per dependency: three passes side by side cost three times one); the second operands stay lazy: Y3 <= 2T, Z3 <= 3T, T3 <= 5T (columns
   // stay below 2^63).  4p - (yy + xx) >= 0 limb-wise.
@@ -585,20 +617,13 @@ __device__ __forceinline__ madd_idx madd_idx_init(const lane_consts& c) {
 __device__ __forceinline__ cq coop_madd(const lane_consts& c, const madd_idx& mi, cq h, cq E) {
   const bool r0 = c.row == 0, r1 = c.row == 1, r2 = c.row == 2, r3 = c.row == 3;
   // a = Y + X, b = Y - X; A = a ypx, B = b ymx, C = xy2d T
-  const cq U = bperm(mi.I_1133, h), V = bperm(mi.I_0000, h);         // (Y, Y, T, T), (X, X, X, X)
+  (void)mi;
+  const cq2 h16 = swap16(h, h);                                        // (X, X, Z, Z), (Y, Y, T, T)
+  const cq U = h16.b, V = swap32(h16.a, h16.a).a;                      // (Y, Y, T, T), (X, X, X, X)
   const cq FA = cnorm(c, r0 ? cadd(U, V) : (r1 ? csub(c, U, V) : (r2 ? U : 0u)));
   const cq LA = cmul4(c, FA, E);                                       // (A, B, C, 0)
   // X3 = A - B, Y3 = A + B, Z3 = D + C, T3 = D - C with D = 2Z
-  const cq H2 = cadd(h, h);
-  const cq qa = bperm(mi.I_0000, LA), qd = bperm(mi.I_2222, H2);       // every lane issues both reads, then selects
-  const cq Q1 = (c.row < 2) ? qa : qd;                                 // (A, A, D, D)
-  const cq Q2 = bperm(mi.I_1122, LA);                                  // (B, B, C, C)
-  const cq SUM = cadd(Q1, Q2), DIF = csub(c, Q1, Q2);                  // (Y3, Y3, Z3, Z3), (X3, X3, T3, T3)
-  // (X3 T3, Z3 Y3, Z3 T3, X3 Y3)
-  const cq x3 = bperm(mi.I_0000, DIF), z3 = bperm(mi.I_2222, SUM), t3 = bperm(mi.I_2222, DIF), y3 = bperm(mi.I_0000, SUM);
-  const cq FB = cnorm(c, (r0 || r3) ? x3 : z3);                        // (X3, Z3, Z3, X3)
-  const cq GB = (r0 || r2) ? t3 : y3;                                  // (T3, Y3, T3, Y3)
-  return cmul4(c, FB, GB);
+  return coop_add_tail(c, LA, cadd(h16.a, h16.a));                     // rows 2, 3 of (X, X, Z, Z) doubled: D
 }
 
 // sum_{j < count} x^j C_{first + j} by Horner (x >= 1 public and wave-uniform: the instruction stream follows its bits), every

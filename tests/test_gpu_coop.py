@@ -361,7 +361,7 @@ def test_every_routing_boundary_with_default_options(oracle, cus):
         n_cu = cus or hw
         opt = {k: eng.get_option(k) for k in ("coop.max_items", "coop.base_max_items", "coop.ladder_max_items", "coop.ladder_enc_max_items", "coop.decode_max_items",
                                               "coop.verify_max_items", "ladder.pair_max_items")}
-        assert opt == {"coop.max_items": 24 * n_cu, "coop.base_max_items": 13 * n_cu, "coop.ladder_max_items": 11 * n_cu, "coop.ladder_enc_max_items": 8 * n_cu,
+        assert opt == {"coop.max_items": 24 * n_cu, "coop.base_max_items": 18 * n_cu, "coop.ladder_max_items": 14 * n_cu, "coop.ladder_enc_max_items": 8 * n_cu,
                        "coop.decode_max_items": 4 * n_cu, "coop.verify_max_items": 2 * n_cu, "ladder.pair_max_items": 128 * n_cu}, opt      # no absolute item count among the defaults
         # every size the routing of engine.hip compares a batch with, from these options (x/2, x/4, 2x, 7x/8: the derived comparisons there)
         marks = set()
@@ -391,11 +391,11 @@ def test_every_routing_boundary_with_default_options(oracle, cus):
             assert np.array_equal(eng.schnorr_sign(x[:n], k[:n], msgs[:n]), want_sig[:n]), n
             assert np.array_equal(eng.verify(pubs[:n], msgs[:n], bad[:n], 1), want_st[:n]), n
         # the kernel families really change with the declared CU count: 1,000 variable-base items are a one-item-per-wavefront launch on 256 CUs
-        # (11 per CU = 2,816) and a two-lane ladder launch on 64 (704)
+        # (14 per CU = 3,584) and a two-lane ladder launch on 64 (896)
         eng.profile_begin(16)
         eng.mul(s[:1000], pts_ext=pts[:1000])
         names = [nm for nm, _ in eng.profile_read(16)]
-        assert ("k_mul_coop" in names) == (1000 <= 11 * n_cu) and ("k_mul_ladder_pair" in names) == (1000 > 11 * n_cu), (n_cu, names)
+        assert ("k_mul_coop" in names) == (1000 <= 14 * n_cu) and ("k_mul_ladder_pair" in names) == (1000 > 14 * n_cu), (n_cu, names)
         if cus:
             eng.set_option("device.cus", 0)
             assert eng.get_option("coop.max_items") == 24 * hw

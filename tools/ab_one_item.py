@@ -35,6 +35,10 @@ def child():
         "encode_projective": (lambda i: eng.encode(proj[i:i + 1]), lambda i: enc[i:i + 1]),
         "verify": (lambda i: eng.verify(enc[i:i + 1], msgs[i:i + 1], sig[i:i + 1], 1), lambda i: np.zeros(1, np.uint8)),
         "mul_base_64_items": (lambda i: eng.mul_base(np.tile(s, (8, 1))), lambda i: np.tile(enc, (8, 1))),
+        "mul_base_2048_items": (lambda i: eng.mul_base(np.tile(s, (256, 1))), lambda i: np.tile(enc, (256, 1))),
+        "mul_256_items": (lambda i: eng.mul(np.tile(k, (32, 1)), pts_ext=np.tile(ext, (32, 1))), lambda i: np.tile(want_mul, (32, 1))),
+        "mul_2048_items": (lambda i: eng.mul(np.tile(k, (256, 1)), pts_ext=np.tile(ext, (256, 1))), lambda i: np.tile(want_mul, (256, 1))),
+        "mul_2816_items": (lambda i: eng.mul(np.tile(k, (352, 1)), pts_ext=np.tile(ext, (352, 1))), lambda i: np.tile(want_mul, (352, 1))),
     }
     out = {}
     for name, (fn, want) in ops.items():

@@ -32,7 +32,7 @@ orc = oracle_lib.Oracle()
 KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "kats.json")))
 weak = [orc.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
 L = synth.L
-SIZES = [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 512, 513, 700, 1023, 1024, 1025, 1536, 1537, 1664, 1665, 2048, 2049, 2816, 2817, 3328, 3329, 4096, 4097, 6144, 6145]
+SIZES = [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 512, 513, 700, 1023, 1024, 1025, 1536, 1537, 1664, 1665, 2048, 2049, 2304, 2305, 2816, 2817, 3328, 3329, 3584, 3585, 4096, 4097, 4608, 4609, 6144, 6145]
 NMAX = max(SIZES)
 POOL_S = synth.raw256(NMAX, 1000 + seed)
 POOL_S[::3] = synth.scalars(len(POOL_S[::3]), 2000 + seed)
@@ -68,7 +68,7 @@ COMMITS = POOL_P[:200].copy()
 def set_random_options():
     o = {"ext.projective": int(rng.integers(0, 2)),
          "coop.verify_max_items": int(rng.choice([512, 512, 0, 4096])), "ladder.pair_max_items": int(rng.choice([32768, 32768, 0, 1 << 20])),
-         "coop.ladder_max_items": int(rng.choice([2816, 2816, 1 << 20, 700])), "coop.ladder_enc_max_items": int(rng.choice([2048, 2048, 1 << 20, 700]))}
+         "coop.ladder_max_items": int(rng.choice([3584, 2816, 1 << 20, 700])), "coop.ladder_enc_max_items": int(rng.choice([2048, 2048, 1 << 20, 700]))}
     variants = {"poly.segments": int(rng.choice([0, 0, 1, 2, 5, 32])), "poly.batch_segments": int(rng.choice([0, 0, 1, 1, 2, 3, 16, 200])),
                 "verify.by_encoding": int(rng.integers(0, 2)), "verify.overlap": int(rng.integers(0, 2)), "ladder.y_only": int(rng.integers(0, 3)), "finish.four": int(rng.integers(0, 2))}
     if CROSSCHECK:          # (drawn in either mode: the same seed walks the same cases on both libraries)
@@ -77,7 +77,7 @@ def set_random_options():
         o["coop.max_items"], o["coop.base_max_items"] = 0, 0
         o["coop.verify_max_items"] = int(rng.choice([0, 0, 512]))
     else:
-        o["coop.max_items"], o["coop.base_max_items"] = 6144, 3328
+        o["coop.max_items"], o["coop.base_max_items"] = 6144, 4608
     for k_, v in o.items():
         eng.set_option(k_, v)
     return o
