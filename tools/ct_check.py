@@ -182,6 +182,12 @@ class Insn:
         elif op.startswith("ds_"):                  # LDS atomics and the like
             self.kind = "ldsrmw"
             self.dst, self.addr, self.src = self.R(0), self.R(1), allregs(2)
+        elif op.startswith(("v_permlane16_swap", "v_permlane32_swap")):
+            # gfx950: rows (or halves) of the two registers are exchanged in place — a fixed pattern, no lane-select operand: both registers are
+            # written and each takes data from both (the row moves of the one-item-per-wavefront kernels since round 6)
+            self.kind = "rowswap"
+            self.dst = self.R(0) + self.R(1)
+            self.src = self.R(0) + self.R(1)
         elif op.startswith("v_cmpx"):
             self.dst, self.src = ["exec_lo", "exec_hi"] + self.R(0), allregs(1) + ["exec_lo", "exec_hi"]
         elif op.startswith("v_cmp"):
@@ -443,7 +449,7 @@ def analyse(name, body, secret_offsets, karg_sgpr):
                     work.append(j)
     # sinks
     viol = []
-    counts = {"instructions": n, "branches": 0, "memory_accesses": 0, "lane_moves": 0, "secret_loads": 0, "unreached": sum(1 for s_ in IN if s_ is None)}
+    counts = {"instructions": n, "branches": 0, "memory_accesses": 0, "lane_moves": 0, "row_swaps": 0, "secret_loads": 0, "unreached": sum(1 for s_ in IN if s_ is None)}
     for ins in insns:
         st = IN[ins.idx]
         if st is None:
@@ -468,6 +474,8 @@ def analyse(name, body, secret_offsets, karg_sgpr):
                 counts["secret_loads"] += 1
         if ins.kind == "lanemove":
             counts["lane_moves"] += 1
+        if ins.kind == "rowswap":
+            counts["row_swaps"] += 1
         if ins.kind == "movrel" and "m0" in T:
             viol.append((ins.idx, "register index (M0) depends on a secret", ins.text))
     return {"kernel": name, "counts": counts, "violations": viol, "kernarg_base": karg}
