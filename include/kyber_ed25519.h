@@ -492,7 +492,7 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     fixed base and signing (18 per compute unit = 4608), coop.decode_max_items for a bare decode (4 per compute unit = 1024),
  *                     coop.verify_max_items for the kernels that give ONE item several wavefronts (verification in one launch, signing in one
  *                     launch, the fixed base with four wavefronts per item: item counts up to 2 per compute unit = 512; the variable base with
- *                     an item's scalar in four pieces on four workgroups: up to a quarter of that, 128).  Setting one of them sets an absolute
+ *                     an item's scalar in four pieces on four workgroups: up to half of that, 256).  Setting one of them sets an absolute
  *                     item count (until device.cus is set again).  Same results either way.
  *   coop.share_by_load  1 (default): the coop.* and ladder.pair_max_items thresholds are divided by the number of synchronous host-pointer
  *                     calls this process has in flight on the same GPU (each on its own context): kernels that spend 64 or 2 lanes on an item are for a chip

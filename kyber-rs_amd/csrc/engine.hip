@@ -1313,8 +1313,9 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
     // (canonical scalars, all below 2^252: the top wavefront's piece starts four bits lower, as the batch ladder does)
     const int canon_skip = (skip_hint >= 4 && g.opt_ladder_skip_canonical != 0) ? 4 : 0;
     // very few items: four single-wavefront workgroups share an item's scalar — while the 4 n workgroups find compute units of their own, or nearly
-    // (measured on 256 CUs, tools/mul_coop_pieces_probe.py: 165 against 195 us up to 32 items, 191 / 199 at 128, 210 / 200 at 192)
-    const bool in_pieces = !short_scalars && 4 * n <= coop_lim(g, g.opt_coop_verify_max) && n <= COOP_PIECES_ITEMS;
+    // (measured on 256 CUs, tools/mul_coop_pieces_probe.py, with the row moves on permlane swaps: 142 against 182 us up to 16 items, 164 / 188 at 128,
+    // 184 / 192 at 256, 216 / 195 at 384 — profiles/r06/coop_pieces_crossover.log; round 5, rows through the LDS crossbar: 191 / 199 at 128, 210 / 200 at 192)
+    const bool in_pieces = !short_scalars && 2 * n <= coop_lim(g, g.opt_coop_verify_max) && n <= COOP_PIECES_ITEMS;
     if (in_pieces) { int rc = ensure_pieces(g, r); if (rc) return rc; }
     LAUNCHCK(launch::mul_coop(st, sc, pext, n, oenc, oext, short_scalars ? (skip_hint > 255 ? 255 : skip_hint) : canon_skip, nullptr, 0, 0, take_done_flag(g, st, n), 0,
                               in_pieces ? 4 : 1, ext_projective(g), nullptr, in_pieces ? r->pieces : nullptr));

@@ -108,8 +108,8 @@ def test_variable_base_in_four_pieces_around_the_cuts(engine, oracle):
             assert np.array_equal(engine.mul(sc, pts_ext=pts), want)
         finally:
             engine.set_option("coop.verify_max_items", keep)
-    # sizes up and down through the hand-over (128 | 129) and back to one item: nothing of an earlier call may be left in the scratch
-    for m in (1, 128, 3, 129, 2, 64, 1):
+    # sizes up and down through the hand-over (256 | 257 on 256 compute units) and back to one item: nothing of an earlier call may be left in the scratch
+    for m in (1, 128, 3, 256, 2, 257, 129, 64, 1):
         s, p = np.resize(sc, (m, 32)), np.resize(ordinary, (m, 40))
         assert np.array_equal(engine.mul(s, pts_ext=p), oracle.mul_batch(s, p, nthreads=8)), m
     # projective limbs out: the same point whichever workgroup comes last (the four are added in a fixed order)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One variable-base multiplication of FEW items (kyb_mul_batch, host pointers): k_mul_coop with an item's scalar cut into four pieces, each on a
 single-wavefront workgroup of its own (kernels_coop.hip), against one wavefront per item — the figures behind the cut (144 / 66 / 31 / 15 bits) and
-behind the hand-over 4 n <= coop.verify_max_items.  The option is a hand-over size, not a kernel selector: both sides give the same bytes.
+behind the hand-over 2 n <= coop.verify_max_items.  The option is a hand-over size, not a kernel selector: both sides give the same bytes.
 
   python tools/mul_coop_pieces_probe.py        (GPU)"""
 import os, sys, time
@@ -22,7 +22,7 @@ def med(fn, n=100):
 
 keep = eng.get_option("coop.verify_max_items")
 print("items, four workgroups per item [us], one wavefront per item [us]   (32-byte encodings out)")
-for n in (1, 4, 16, 32, 64, 96, 128, 192, 256, 384):
+for n in (1, 4, 16, 32, 64, 96, 128, 192, 256, 384, 512, 768, 1024):
     s = rng.integers(0, 256, (n, 32), dtype=np.uint8); s[:, 31] &= 0x0f
     P = eng.mul_base(rng.integers(0, 256, (n, 32), dtype=np.uint8), ext_only=True)
     eng.set_option("coop.verify_max_items", 4 * n)
