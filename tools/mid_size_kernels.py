@@ -29,7 +29,8 @@ eng.mul_base_dev(s, out_enc=pubs, out_ext=ext)
 eng.sign_dev(s, k, msgs, off, sig)
 eng.sync()
 for n in (4096, 8192, 16384, 32768, 65536):
-    for what, fn in (("mul", lambda: eng.mul_dev(s[:n], pts_ext=ext[:n], out_enc=out[:n])), ("mul_enc", lambda: eng.mul_dev(s[:n], pts_enc=pubs[:n], out_enc=out[:n])),
+    for what, fn in (("mul_base", lambda: eng.mul_base_dev(s[:n], out_enc=out[:n])), ("sign", lambda: eng.sign_dev(s[:n], k[:n], msgs, off[: n + 1], sig[:n])),
+                     ("mul", lambda: eng.mul_dev(s[:n], pts_ext=ext[:n], out_enc=out[:n])), ("mul_enc", lambda: eng.mul_dev(s[:n], pts_enc=pubs[:n], out_enc=out[:n])),
                      ("verify", lambda: eng.verify_dev(pubs[:n], msgs, off[: n + 1], sig[:n], status[:n], 1))):
         for _ in range(3):
             fn()
