@@ -489,7 +489,8 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     the number here: the hand-over sizes below — kept as wavefronts per compute unit — and the persistent grids follow it.
  *   coop.max_items    batches of at most this many items take the one-item-per-wavefront kernels (variable base, verification,
  *                     polynomial evaluation; default 24 per compute unit = 6144 on an MI355X, 0 = never); coop.base_max_items the same for the
- *                     fixed base and signing (18 per compute unit = 4608), coop.decode_max_items for a bare decode (4 per compute unit = 1024),
+ *                     fixed base and signing (18 per compute unit = 4608), coop.decode_max_items for a bare decode (4 per compute unit = 1024; a bare encode — and the closing inversion of any
+ *                     small result — up to twice that),
  *                     coop.verify_max_items for the kernels that give ONE item several wavefronts (verification in one launch, signing in one
  *                     launch, the fixed base with four wavefronts per item: item counts up to 2 per compute unit = 512; the variable base with
  *                     an item's scalar in four pieces on four workgroups: up to half of that, 256).  Setting one of them sets an absolute

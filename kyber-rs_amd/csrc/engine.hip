@@ -308,6 +308,10 @@ inline int host_load(const Ctx& g) {
   return load < 1 ? 1 : (load > 64 ? 64 : load);
 }
 inline size_t coop_lim(const Ctx& g, int opt) { return opt <= 0 ? 0 : (size_t)opt / (size_t)host_load(g); }
+// the closing inversion one point per wavefront (k_finish_coop) up to TWICE coop.decode_max_items: that inversion is safegcd over the lanes since round 6,
+// no chain of squarings through LDS as the decode's square root still is (tools/finish_crossover.py, profiles/r06/finish_crossover.log: 42 against 52 us at
+// 2,048 points, level at 3,072)
+inline size_t finish_coop_lim(const Ctx& g) { return 2 * coop_lim(g, g.opt_coop_decode_max); }
 // the two-lane ladder spends 2 lanes on an item, not 64: it stays worth its 12 % of extra work until the calls in flight fill the chip
 // several times over (16 threads x 4,096 items: 5.7e7 items/s with it, 4.2e7 without)
 inline bool finish_four(const Ctx& g, size_t n) { return g.opt_finish_four != 0 && n <= (size_t)64 * 4 * (size_t)g.cus; }      // launches of at most a wavefront per SIMD share an inversion between 4 items (finish.four)
@@ -1068,7 +1072,7 @@ int do_init(int device, bool build_table) {
 // ---- launch sequences ------------------------------------------------------------------------------------
 // last: nothing is queued behind this launch in its call (it may carry the completion flag)
 int launch_finish(Ctx& g, StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, hipStream_t st, size_t src_mul = 1, bool last = false) {
-  if (n <= coop_lim(g, g.opt_coop_decode_max)) {          // few points: one per wavefront
+  if (n <= finish_coop_lim(g)) {          // few points: one per wavefront
     ProfScope ps(g, st, KID_FINISH_COOP);
     LAUNCHCK(launch::finish_coop(st, r->proj, r->proj_items, nullptr, n, oenc, oext, src_mul, last ? take_done_flag(g, st, n) : launch::DoneFlag{},
                                  ext_projective(g)));
@@ -1411,7 +1415,7 @@ int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t*
 // marshal_binary of n extended points: one shared inversion per FINISH_K points
 int launch_encode(Ctx& g, const int32_t* pext, size_t n, uint8_t* oenc, hipStream_t st) {
   if (n == 0) return KYB_OK;
-  if (n <= coop_lim(g, g.opt_coop_decode_max)) {
+  if (n <= finish_coop_lim(g)) {
     ProfScope ps(g, st, KID_FINISH_COOP);
     LAUNCHCK(launch::finish_coop(st, nullptr, 0, pext, n, oenc, nullptr, 1, take_done_flag(g, st, n)));
     return KYB_OK;
@@ -1434,7 +1438,7 @@ int launch_point_checks(Ctx& g, const uint8_t* enc, const int32_t* pext, size_t 
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
   { int rc = ensure_enc(g, r, 32 * n + 256); if (rc) return rc; }
-  if (n <= coop_lim(g, g.opt_coop_decode_max)) {
+  if (n <= finish_coop_lim(g)) {
     ProfScope ps(g, st, KID_FINISH_COOP);
     LAUNCHCK(launch::finish_coop(st, nullptr, 0, pext, n, r->enc, nullptr, 1, launch::DoneFlag{}));      // not the call's last kernel: no completion flag
   } else {
@@ -1581,7 +1585,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   SlotUse use(r, st);
   if (pubs_ext != nullptr) {
     int rc = ensure_pub_enc(g, r, n); if (rc) return rc;
-    if (n <= coop_lim(g, g.opt_coop_decode_max)) {
+    if (n <= finish_coop_lim(g)) {
       ProfScope ps(g, st, KID_FINISH_COOP);
       LAUNCHCK(launch::finish_coop(st, nullptr, 0, pubs_ext, n, r->pub_enc, nullptr, 1));          // (not the call's last kernel: no completion flag)
     } else {
