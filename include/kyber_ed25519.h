@@ -489,8 +489,7 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     the number here: the hand-over sizes below — kept as wavefronts per compute unit — and the persistent grids follow it.
  *   coop.max_items    batches of at most this many items take the one-item-per-wavefront kernels (variable base, verification,
  *                     polynomial evaluation; default 24 per compute unit = 6144 on an MI355X, 0 = never); coop.base_max_items the same for the
- *                     fixed base and signing (18 per compute unit = 4608), coop.decode_max_items for a bare decode (4 per compute unit = 1024; a bare encode — and the closing inversion of any
- *                     small result — up to twice that),
+ *                     fixed base and signing (18 per compute unit = 4608), coop.decode_max_items for a bare decode or encode (4 per compute unit = 1024),
  *                     coop.verify_max_items for the kernels that give ONE item several wavefronts (verification in one launch, signing in one
  *                     launch, the fixed base with four wavefronts per item: item counts up to 2 per compute unit = 512; the variable base with
  *                     an item's scalar in four pieces on four workgroups: up to half of that, 256).  Setting one of them sets an absolute
@@ -561,8 +560,9 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     further workgroups of the SAME launch take the square root of the decode (a verification: of the key and of R, and its hash
  *                     moves into the ladder's workgroups); a short kernel joins them.  1: the decode as a kernel of its own on a side stream.
  *                     0: decode first, then the ladder.  Same results.
- *   finish.four       1 (default): the batched encode shares one field inversion between 4 instead of 8 items when a launch leaves at most one
- *                     wavefront per SIMD (shorter dependent chain; full batches keep 8).  Same results.
+ *   finish.four       what closes a launch that does not fill the chip (full batches share one field inversion between 8 items of a lane): 2 (default)
+ *                     up to 64 x 8 x CUs results (two wavefronts per SIMD) take one inversion per WAVEFRONT, spread over its lanes, Montgomery's trick
+ *                     across the 64 lanes; 1 up to 64 x 4 x CUs results take one inversion per 4 items of a lane; 0 per 8 throughout.  Same results.
  *   verify.overlap    1 (default): small verification batches run s*B on a side stream next to the ladder (and, with ladder.y_only, the decode of A)
  *   verify.by_encoding 1 (default): large batches test the equation as enc(s*B - h*A) == R bytes and decode R only on a mismatch
  * Options belong to the calling thread's context. */

@@ -133,7 +133,7 @@ struct Ctx {
   std::atomic<int> opt_coop_max{0};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: the chunk unit is 1/this of the batch (plan_chunks)
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
-  std::atomic<int> opt_finish_four{1};           // k_finish with 4 instead of 8 items per shared inversion for launches of at most one wavefront per SIMD
+  std::atomic<int> opt_finish_four{2};           // k_finish with 4 instead of 8 items per shared inversion for launches of at most one wavefront per SIMD
   std::atomic<int> opt_ladder_y_only{2};         // two-lane ladder from wire encodings: ladder on y while the decode looks for x — 2: as workgroups of the same launch, 1: on a side stream (0: decode first)
   std::atomic<DeferArena*> defer{nullptr};       // recorded, not yet evaluated point operations of this context's callers (kyb_defer_*; made on first use)
   std::atomic<int> opt_defer_fuse{1};            // flushes recognise Horner chains and chains of additions (defer.inc)
@@ -308,13 +308,15 @@ inline int host_load(const Ctx& g) {
   return load < 1 ? 1 : (load > 64 ? 64 : load);
 }
 inline size_t coop_lim(const Ctx& g, int opt) { return opt <= 0 ? 0 : (size_t)opt / (size_t)host_load(g); }
-// the closing inversion one point per wavefront (k_finish_coop) up to TWICE coop.decode_max_items: that inversion is safegcd over the lanes since round 6,
-// no chain of squarings through LDS as the decode's square root still is (tools/finish_crossover.py, profiles/r06/finish_crossover.log: 42 against 52 us at
-// 2,048 points, level at 3,072)
-inline size_t finish_coop_lim(const Ctx& g) { return 2 * coop_lim(g, g.opt_coop_decode_max); }
+// the closing inversion one point per wavefront (k_finish_coop) up to coop.decode_max_items; above, one point per lane and one inversion per wavefront
+// (k_finish_wave) — tools/finish_crossover.py, profiles/r06/finish_crossover.log: 35.4 us flat against 33 / 35 / 42 us at 256 / 1,024 / 2,048 points
+inline size_t finish_coop_lim(const Ctx& g) { return coop_lim(g, g.opt_coop_decode_max); }
 // the two-lane ladder spends 2 lanes on an item, not 64: it stays worth its 12 % of extra work until the calls in flight fill the chip
 // several times over (16 threads x 4,096 items: 5.7e7 items/s with it, 4.2e7 without)
 inline bool finish_four(const Ctx& g, size_t n) { return g.opt_finish_four != 0 && n <= (size_t)64 * 4 * (size_t)g.cus; }      // launches of at most a wavefront per SIMD share an inversion between 4 items (finish.four)
+// ... and with finish.four = 2 (default) launches of up to TWO wavefronts of finish lanes per SIMD close with ONE inversion per wavefront, spread over its lanes
+// (k_finish_wave, kernels_coop.hip; profiles/r06/finish_crossover.log: 35 against 52 us up to 2^16 points, 48 / 64 at 2^17, 70 / 67 at 196,608)
+inline bool finish_wave(const Ctx& g, size_t n) { return g.opt_finish_four == 2 && n <= (size_t)64 * 8 * (size_t)g.cus; }
 inline size_t pair_lim(const Ctx& g, int opt) { const int l = host_load(g) / 4; return opt <= 0 ? 0 : (size_t)opt / (size_t)(l < 1 ? 1 : l); }
 
 int ensure_pin(Ctx& g, int lane, size_t bytes) {
@@ -1080,7 +1082,8 @@ int launch_finish(Ctx& g, StreamRes* r, size_t n, uint8_t* oenc, int32_t* oext, 
   }
   ProfScope ps(g, st, KID_FINISH);
   // up to a wavefront per SIMD of finish lanes the kernel is one lane's chain: four items per inversion shorten it (k_finish4)
-  LAUNCHCK(launch::finish(st, r->proj, r->proj_items, n, oenc, oext, src_mul, finish_four(g, n)));
+  if (finish_wave(g, n)) LAUNCHCK(launch::finish_wave(st, r->proj, r->proj_items, nullptr, n, oenc, oext, src_mul));
+  else LAUNCHCK(launch::finish(st, r->proj, r->proj_items, n, oenc, oext, src_mul, finish_four(g, n)));
   return KYB_OK;
 }
 
@@ -1422,7 +1425,8 @@ int launch_encode(Ctx& g, const int32_t* pext, size_t n, uint8_t* oenc, hipStrea
   }
   if (g.opt_encode_batched == 1) {
     ProfScope ps(g, st, KID_ENCODE);
-    LAUNCHCK(launch::encode_batched(st, pext, n, oenc, finish_four(g, n)));
+    if (finish_wave(g, n)) LAUNCHCK(launch::finish_wave(st, nullptr, 0, pext, n, oenc, nullptr, 1));
+    else LAUNCHCK(launch::encode_batched(st, pext, n, oenc, finish_four(g, n)));
   } else {
     LAUNCHCK(launch::encode(st, pext, n, oenc));
   }
@@ -1443,7 +1447,8 @@ int launch_point_checks(Ctx& g, const uint8_t* enc, const int32_t* pext, size_t 
     LAUNCHCK(launch::finish_coop(st, nullptr, 0, pext, n, r->enc, nullptr, 1, launch::DoneFlag{}));      // not the call's last kernel: no completion flag
   } else {
     ProfScope ps(g, st, KID_ENCODE);
-    LAUNCHCK(launch::encode_batched(st, pext, n, r->enc, finish_four(g, n)));
+    if (finish_wave(g, n)) LAUNCHCK(launch::finish_wave(st, nullptr, 0, pext, n, r->enc, nullptr, 1));
+    else LAUNCHCK(launch::encode_batched(st, pext, n, r->enc, finish_four(g, n)));
   }
   LAUNCHCK(launch::point_checks(st, r->enc, n, flags));
   return KYB_OK;
@@ -1590,7 +1595,8 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
       LAUNCHCK(launch::finish_coop(st, nullptr, 0, pubs_ext, n, r->pub_enc, nullptr, 1));          // (not the call's last kernel: no completion flag)
     } else {
       ProfScope ps(g, st, KID_ENCODE);
-      LAUNCHCK(launch::encode_batched(st, pubs_ext, n, r->pub_enc, finish_four(g, n)));
+      if (finish_wave(g, n)) LAUNCHCK(launch::finish_wave(st, nullptr, 0, pubs_ext, n, r->pub_enc, nullptr, 1));
+      else LAUNCHCK(launch::encode_batched(st, pubs_ext, n, r->pub_enc, finish_four(g, n)));
     }
     pubs = r->pub_enc;
   }

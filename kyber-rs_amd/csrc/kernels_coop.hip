@@ -8,6 +8,7 @@
 //                     line of a limb's 32 entries is touched whatever the digit), 43 cooperative mixed additions, cooperative inversion.
 //   k_sum_coop        short sums of points (kyb_sum_batch, the tail of a linear combination), one group per wavefront
 //   k_finish_coop     marshal_binary / the finish of a projective staging record, one point per wavefront (cooperative inversion)
+//   k_finish_wave     the same for mid-size batches: one point per lane, one cooperative inversion per wavefront (Montgomery's trick across the lanes)
 //   k_decode_coop     unmarshal_binary          ge.rs:124-179   ge_decode replicated on all lanes, its square-root chain
 //                     (252 of ~270 dependent multiplications) cooperative
 //   k_verify_prep_coop / k_verify_prep_r_coop   the two front halves of a verification (verify.h) with that decode
@@ -859,6 +860,65 @@ k_finish_coop(const uint4* __restrict__ proj, size_t stride, const int32_t* __re
   if (c.lane == 0) signal_done(df);
 }
 
+// k_finish / k_encode_batched for a MID-SIZE batch (above the one-point-per-wavefront sizes, up to a wavefront per SIMD): one point per LANE, ONE
+// inversion per WAVEFRONT, and that one spread over its lanes (fe_invert_gcd_wave).  The batch forms of csrc/kernels_misc.hip share an inversion
+// between 4 (8) points of one lane — a lane's 600 divsteps are the whole kernel, 52 us however few the points (profiles/r06/finish_crossover.log);
+// here the 64 lanes multiply their Z's together in a butterfly (level j: lane l takes the sub-product of lane l ^ 2^j and multiplies it on — after six
+// levels every lane holds the product of all 64, each having kept the six sub-products it received), the wavefront inverts that once, and every
+// lane peels its own 1/Z off by multiplying the six kept sub-products back on: 1/P_j = 1/P_{j+1} * Q_j.  12 products + one cooperative inversion
+// per 64 points instead of 9 + a one-lane inversion per 4.  The lanes' products agree mod p, not limb by limb: the inversion starts from the
+// canonical words (fe_to_words) and everything stored is canonical, so the bytes and limbs are those of the other forms.  A zero Z (invalid
+// extended input only) counts as 1 in the product and gets the reference's own 0^(p-2) = 0, as in finish_body.  Source: projective staging
+// record i * src_mul, or the 40 reference limbs of point i.
+__device__ __forceinline__ void fe_of_lane_xor(fe& h, const fe& f, int mask) {
+  KYB_UNROLL for (int k = 0; k < 10; ++k) h.v[k] = (uint32_t)__shfl_xor((int)f.v[k], mask);
+}
+__global__ void __launch_bounds__(64)
+k_finish_wave(const uint4* __restrict__ proj, size_t stride, const int32_t* __restrict__ pts_ext, size_t n, uint8_t* __restrict__ out_enc,
+              int32_t* __restrict__ out_ext, size_t src_mul) {
+  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  const bool live = i < n;
+  const size_t ii = live ? i : n - 1;                                     // dead lanes of the last wavefront redo its last point (nothing stored)
+  fe X, Y, Z, one, zero;
+  fe_one(one); fe_zero(zero);
+  if (pts_ext != nullptr) {
+    ge_p3 P;
+    load_ext(P, pts_ext, ii);
+    fe_copy(X, P.X); fe_copy(Y, P.Y); fe_copy(Z, P.Z);
+  } else {
+    load_proj_z(Z, proj, stride, ii * src_mul);
+    load_proj_xy(X, Y, proj, stride, ii * src_mul);
+  }
+  const uint32_t z_zero = 1u - fe_is_nonzero(Z);
+  fe P, Q0, Q1, Q2, Q3, Q4, Q5;
+  fe_copy(P, Z);
+  fe_cmov(P, one, z_zero);
+  fe_of_lane_xor(Q0, P, 1);  fe_mul(P, P, Q0);
+  fe_of_lane_xor(Q1, P, 2);  fe_mul(P, P, Q1);
+  fe_of_lane_xor(Q2, P, 4);  fe_mul(P, P, Q2);
+  fe_of_lane_xor(Q3, P, 8);  fe_mul(P, P, Q3);
+  fe_of_lane_xor(Q4, P, 16); fe_mul(P, P, Q4);
+  fe_of_lane_xor(Q5, P, 32); fe_mul(P, P, Q5);
+  fe I;
+  fe_invert_gcd_wave(I, P);                                               // (wave-uniform input: the canonical words of the 64 lanes' products are the same)
+  fe_mul(I, I, Q5); fe_mul(I, I, Q4); fe_mul(I, I, Q3); fe_mul(I, I, Q2); fe_mul(I, I, Q1); fe_mul(I, I, Q0);
+  fe_cmov(I, zero, z_zero);                                               // Z == 0: the reference's 0^(p-2) = 0
+  fe x, y;
+  fe_mul(x, X, I);
+  fe_mul(y, Y, I);
+  if (out_enc != nullptr) {
+    uint32_t w[8];
+    fe_to_words(w, y);
+    w[7] ^= fe_is_negative(x) << 31;
+    if (live) store_words8(out_enc, i, w);
+  }
+  if (out_ext != nullptr) {
+    fe tt;
+    fe_mul(tt, x, y);
+    if (live) store_ext(out_ext, i, x, y, one, tt);
+  }
+}
+
 // out[g] = sum_j P[g t + j] for short sums (kyb_sum_batch, the tail of kyb_lincomb_batch), one group per wavefront: t - 1 cooperative
 // additions, then the finish.  Source: extended quads in `part` (k_mul_coop's products) or the 40 reference limbs per point.
 __global__ void __launch_bounds__(64)
@@ -1216,6 +1276,10 @@ hipError_t coop_selftest(hipStream_t st, int op, const uint32_t* A, const uint32
 hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul, DoneFlag df,
                        bool ext_proj) {
   hipLaunchKernelGGL(k_finish_coop, dim3((unsigned)n), dim3(64), 0, st, proj, stride, pts_ext, n, oenc, oext, src_mul, ext_proj ? 1 : 0, df);
+  return hipGetLastError();
+}
+hipError_t finish_wave(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul) {
+  hipLaunchKernelGGL(k_finish_wave, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, proj, stride, pts_ext, n, oenc, oext, src_mul);
   return hipGetLastError();
 }
 hipError_t sum_coop(hipStream_t st, const uint32_t* part, const int32_t* pts_ext, size_t m, size_t t, uint8_t* oenc, int32_t* oext, bool ext_proj, DoneFlag df) {

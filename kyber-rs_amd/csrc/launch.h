@@ -116,6 +116,8 @@ hipError_t sum_coop(hipStream_t st, const uint32_t* part, const int32_t* pts_ext
 // proj != nullptr: projective staging record i * src_mul, else the 40 reference limbs of point i
 hipError_t finish_coop(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul,
                        DoneFlag df = DoneFlag{}, bool ext_proj = false);
+// the same, one point per lane and one cooperative inversion per wavefront (mid-size batches)
+hipError_t finish_wave(hipStream_t st, const uint4* proj, size_t stride, const int32_t* pts_ext, size_t n, uint8_t* oenc, int32_t* oext, size_t src_mul);
 // sc_b != nullptr: n_b more scalars follow the first n in the same launch (their results behind the first n)
 hipError_t mul_base_coop(hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint32_t* table_coop,
                          uint4* proj = nullptr, size_t proj_stride = 0, size_t proj_offset = 0, const uint8_t* sc_b = nullptr, size_t n_b = 0,

@@ -242,6 +242,53 @@ def test_encode_batched_matches_per_item_encode(xengine, oracle):
         assert [bytes(a[i]) for i in idx] == [oracle.encode(pts[i]) for i in idx]
 
 
+def test_one_inversion_per_wavefront_matches_the_per_lane_forms(xengine, oracle):
+    engine = xengine          # finish.four is a selector of the cross-check build (tests/conftest.py); the product runs its default, 2
+    """what closes a mid-size launch (engine.hip finish_wave / finish_four): one inversion per WAVEFRONT with Montgomery's trick across the 64
+    lanes (k_finish_wave, finish.four = 2, the default) == one per 4 points of a lane (1) == one per 8 (0) == the oracle: marshal_binary of
+    projective points, and the end of fixed-base, variable-base and signing calls (encodings and affine limbs); sizes whose last wavefront has
+    1, 63 and 64 live lanes; Z = 0 garbage in the first, a middle and the last lane of a wavefront gets the reference's 0^(p-2) = 0 and leaves
+    the other 63 points of its wavefront alone"""
+    assert engine.get_option("finish.four") == 2
+    dm = engine.get_option("coop.decode_max_items")
+    base = oracle.mul_base_ext_batch(synth.scalars(300, 910, b"point"))
+    proj300 = np.stack([oracle.add(a_, b_) for a_, b_ in zip(base, np.roll(base, 1, axis=0))])        # Z != 1
+    want300 = np.stack([np.frombuffer(oracle.encode(e), dtype=np.uint8) for e in proj300])
+    try:
+        for n in (dm + 1, dm + 63, dm + 64, 4099, 20000, 64 * 8 * engine.get_option("device.cus") - 3):
+            reps = (n + 299) // 300
+            pts, want = np.tile(proj300, (reps, 1))[:n].copy(), np.tile(want300, (reps, 1))[:n].copy()
+            for bad in (0, 64 + 37, n - 1, n - 64):
+                pts[bad, 20:30] = 0                              # Z = 0
+                want[bad] = 0                                    # (x, y) = (0, 0): the all-zero encoding
+            got = {}
+            for four in (2, 1, 0):
+                engine.set_option("finish.four", four)
+                got[four] = engine.encode(pts)
+            assert np.array_equal(got[2], got[1]) and np.array_equal(got[2], got[0]), n
+            assert np.array_equal(got[2], want), n
+        # the end of whole calls: above every one-item-per-wavefront size, below a wavefront per SIMD
+        n = max(engine.get_option("coop.base_max_items"), engine.get_option("coop.ladder_max_items")) + 77
+        s, k = synth.raw256(n, 911), synth.scalars(n, 912, b"k")
+        x = s.copy(); x[:, 31] &= 0x7f
+        p = np.tile(proj300, ((n + 299) // 300, 1))[:n].copy()
+        msgs = synth.messages(n, 913)
+        res = {}
+        for four in (2, 1):
+            engine.set_option("finish.four", four)
+            res[four] = (engine.mul_base(s, want_ext=True), engine.mul(s, pts_ext=p, want_ext=True), engine.schnorr_sign(x, k, msgs))
+        for a_, b_ in zip(res[2], res[1]):
+            if isinstance(a_, tuple):
+                assert np.array_equal(a_[0], b_[0]) and np.array_equal(a_[1], b_[1])
+            else:
+                assert np.array_equal(a_, b_)
+        assert np.array_equal(res[2][0][0], oracle.mul_base_batch(s, nthreads=8))
+        assert np.array_equal(res[2][1][0], oracle.mul_batch(s, p, nthreads=8))
+        assert np.array_equal(res[2][2], oracle.schnorr_sign_batch(x, k, msgs, nthreads=8))
+    finally:
+        engine.set_option("finish.four", 2)
+
+
 def test_group_device_resident_shards_and_pool_reuse(oracle):
     """kyb_group_mul(_base)_batch_dev: per-rank device pointers, launches queued on every rank's own stream by ONE thread, kyb_group_sync;
     and the group's persistent worker threads serve many sharded host-pointer calls in a row (nothing is spawned per call)."""

@@ -390,15 +390,15 @@ def test_every_routing_boundary_with_default_options(oracle, cus):
                 assert np.array_equal(eng.mul(s[:n], pts_enc=enc[:n]), want_mul[:n]), n
             assert np.array_equal(eng.schnorr_sign(x[:n], k[:n], msgs[:n]), want_sig[:n]), n
             assert np.array_equal(eng.verify(pubs[:n], msgs[:n], bad[:n], 1), want_st[:n]), n
-        # marshal_binary of PROJECTIVE points around its own hand-over (twice coop.decode_max_items: engine.hip finish_coop_lim): one point per wavefront
-        # with the inversion over its lanes | one lane per point, an inversion shared by four
+        # marshal_binary of PROJECTIVE points around its hand-over (coop.decode_max_items): one point per wavefront with the inversion over its lanes |
+        # one point per lane and one inversion per wavefront (k_finish_wave; a last wavefront of 1, 63 and 64 live lanes)
         dm = opt["coop.decode_max_items"]
-        proj = np.stack([oracle.add(a_, b_) for a_, b_ in zip(pts[: 2 * dm + 1], np.roll(pts[: 2 * dm + 1], 1, axis=0))])
+        proj = np.stack([oracle.add(a_, b_) for a_, b_ in zip(pts[: dm + 130], np.roll(pts[: dm + 130], 1, axis=0))])
         want_enc = np.stack([np.frombuffer(oracle.encode(e), dtype=np.uint8) for e in proj])
-        for n in (dm, dm + 1, 2 * dm - 1, 2 * dm, 2 * dm + 1):
+        for n in (dm - 1, dm, dm + 1, dm + 63, dm + 64, dm + 65, dm + 128):
             assert np.array_equal(eng.encode(proj[:n]), want_enc[:n]), n
         eng.profile_begin(4)
-        eng.encode(proj[: 2 * dm]); eng.encode(proj[: 2 * dm + 1])
+        eng.encode(proj[:dm]); eng.encode(proj[: dm + 1])
         assert [nm for nm, _ in eng.profile_read(4)] == ["k_finish_coop", "k_encode_batched"]
         eng.profile_begin(0)
         # the kernel families really change with the declared CU count: 1,000 variable-base items are a one-item-per-wavefront launch on 256 CUs

@@ -59,6 +59,7 @@ SECRET_ARGS = {
     "_Z18k_pripoly_eval_sum": ("kernels_verify", {0: "partial values of secret polynomials"}),
     "_Z8k_finishPK": ("kernels_misc", {0: "projective results (a DH shared secret before its encoding)"}),
     "_Z9k_finish4PK": ("kernels_misc", {0: "projective results (a DH shared secret before its encoding)"}),
+    "_Z13k_finish_wavePK": ("kernels_coop", {0: "projective results (a DH shared secret before its encoding)", 16: "the same as extended limbs"}),
 }
 # the windowed-table kernels (mul.algo = 0, radix-16 / -32 fixed base) are selectable cross-checks, not default paths; the public-input
 # kernels (verification, decoding, polynomial evaluation at public indices) have nothing to hide

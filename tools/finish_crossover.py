@@ -13,11 +13,11 @@ import torch
 import kyber_rs_amd
 import synth
 
-eng = kyber_rs_amd.Engine(0)
-N = 16384
-sc = synth.scalars(N, 5)
+eng = kyber_rs_amd.Engine(0, crosscheck=True)      # finish.four is a selector of the cross-check build (same kernels)
+N = 196608
+sc = synth.scalars(16000, 5)
 eng.set_option("ext.projective", 1)       # projective limbs (small-batch calls asked for limbs only): Z != 1, the encoder has to invert
-host_ext = np.concatenate([eng.mul_base(sc[i:i + 2000], ext_only=True) for i in range(0, N, 2000)])
+host_ext = np.tile(np.concatenate([eng.mul_base(sc[i:i + 2000], ext_only=True) for i in range(0, 16000, 2000)]), (N // 16000 + 1, 1))[:N].copy()
 eng.set_option("ext.projective", 0)
 assert all(list(e[20:30]) != [1] + [0] * 9 for e in host_ext[::97])
 ext = torch.from_numpy(host_ext).to("cuda:0")
@@ -38,14 +38,21 @@ def kernel_us(fn, reps=30):
 
 
 keep = eng.get_option("coop.decode_max_items")
-print("points, one per wavefront [us], one per lane [us]   (device-resident, HIP events around the call)")
-for n in (256, 512, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 16384):
-    eng.set_option("coop.decode_max_items", n)
-    a = kernel_us(lambda: eng.encode_dev(ext[:n], out[:n])); ea = out[:n].cpu().numpy().copy()
+print("points, one per wavefront [us], one per lane and an inversion per wavefront (finish.four = 2) [us], per 4 points of a lane (finish.four = 1) [us]   (device-resident, HIP events around the call)")
+for n in (256, 512, 1024, 1536, 2048, 3072, 4096, 8192, 16384, 65536, 131072, 196608):
+    if n <= 16384:
+        eng.set_option("coop.decode_max_items", n)
+        a = kernel_us(lambda: eng.encode_dev(ext[:n], out[:n])); ea = out[:n].cpu().numpy().copy()
+    else:
+        a, ea = float("nan"), None                           # (far beyond its range)
     eng.set_option("coop.decode_max_items", 0)
+    eng.set_option("finish.four", 2)
+    w = kernel_us(lambda: eng.encode_dev(ext[:n], out[:n])); ew = out[:n].cpu().numpy().copy()
+    eng.set_option("finish.four", 1)
     b = kernel_us(lambda: eng.encode_dev(ext[:n], out[:n])); eb = out[:n].cpu().numpy().copy()
-    assert np.array_equal(ea, eb)
-    print("%6d, %.1f, %.1f" % (n, a, b), flush=True)
+    eng.set_option("finish.four", 2)
+    assert (ea is None or np.array_equal(ea, eb)) and np.array_equal(ew, eb)
+    print("%6d, %.1f, %.1f, %.1f" % (n, a, w, b), flush=True)
 # unmarshal_binary alone (the square root is still a chain of cooperative squarings through LDS): its hand-over is coop.decode_max_items itself
 enc = out.clone()
 eng.set_option("coop.decode_max_items", 0)
