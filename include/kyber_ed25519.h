@@ -489,7 +489,8 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     the number here: the hand-over sizes below — kept as wavefronts per compute unit — and the persistent grids follow it.
  *   coop.max_items    batches of at most this many items take the one-item-per-wavefront kernels (variable base, verification,
  *                     polynomial evaluation; default 24 per compute unit = 6144 on an MI355X, 0 = never); coop.base_max_items the same for the
- *                     fixed base and signing (18 per compute unit = 4608), coop.decode_max_items for a bare decode or encode (4 per compute unit = 1024),
+ *                     fixed base, signing, short sums (18 per compute unit = 4608; a fixed-base multiplication itself — signing: two per signature — leaves them at
+ *                     5 per compute unit = 1280 for its mid-size kernel, mul_base.quarters), coop.decode_max_items for a bare decode or encode (4 per compute unit = 1024),
  *                     coop.verify_max_items for the kernels that give ONE item several wavefronts (verification in one launch, signing in one
  *                     launch, the fixed base with four wavefronts per item: item counts up to 2 per compute unit = 512; the variable base with
  *                     an item's scalar in four pieces on four workgroups: up to half of that, 256).  Setting one of them sets an absolute
@@ -560,6 +561,8 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     further workgroups of the SAME launch take the square root of the decode (a verification: of the key and of R, and its hash
  *                     moves into the ladder's workgroups); a short kernel joins them.  1: the decode as a kernel of its own on a side stream.
  *                     0: decode first, then the ladder.  Same results.
+ *   mul_base.quarters 1 (default): a fixed-base launch above the one-item-per-wavefront sizes and up to 128 items per compute unit gives every 64 items a
+ *                     workgroup of four wavefronts, each adding a quarter of the 43 windows; 0: one lane per item throughout.  Same results.
  *   finish.four       what closes a launch that does not fill the chip (full batches share one field inversion between 8 items of a lane): 2 (default)
  *                     up to 64 x 8 x CUs results (two wavefronts per SIMD) take one inversion per WAVEFRONT, spread over its lanes, Montgomery's trick
  *                     across the 64 lanes; 1 up to 64 x 4 x CUs results take one inversion per 4 items of a lane; 0 per 8 throughout.  Same results.

@@ -133,6 +133,7 @@ struct Ctx {
   std::atomic<int> opt_coop_max{0};           // variable base: batches of at most this many items take the one-item-per-wavefront kernel (0 = never; crossover measured between 6144 and 8192, profiles/r02/coop_crossover.log)
   std::atomic<int> opt_pipe_chunks{PIPE_CHUNKS_DEFAULT};      // host-pointer batches of 2^16 items or more: the chunk unit is 1/this of the batch (plan_chunks)
   std::atomic<int> opt_ext_projective{0};        // 1: small-batch multiplications asked for extended limbs ONLY return them projective (Z != 1, no inversion)
+  std::atomic<int> opt_base_quarters{1};         // mid-size fixed-base launches give an item four wavefronts, a quarter of the 43 windows each (k_mul_base64_quarters); 0 = never
   std::atomic<int> opt_finish_four{2};           // k_finish with 4 instead of 8 items per shared inversion for launches of at most one wavefront per SIMD
   std::atomic<int> opt_ladder_y_only{2};         // two-lane ladder from wire encodings: ladder on y while the decode looks for x — 2: as workgroups of the same launch, 1: on a side stream (0: decode first)
   std::atomic<DeferArena*> defer{nullptr};       // recorded, not yet evaluated point operations of this context's callers (kyb_defer_*; made on first use)
@@ -313,6 +314,18 @@ inline size_t coop_lim(const Ctx& g, int opt) { return opt <= 0 ? 0 : (size_t)op
 inline size_t finish_coop_lim(const Ctx& g) { return coop_lim(g, g.opt_coop_decode_max); }
 // the two-lane ladder spends 2 lanes on an item, not 64: it stays worth its 12 % of extra work until the calls in flight fill the chip
 // several times over (16 threads x 4,096 items: 5.7e7 items/s with it, 4.2e7 without)
+// Fixed base above the one-item-per-wavefront sizes and up to 128 items per CU (two rounds of 64-item workgroups): k_mul_base64 would be ONE lane's chain of 43
+// additions (105 us flat) on a mostly idle chip; four wavefronts per 64 items take a quarter of the windows each (tools/mid_size_kernels.py,
+// profiles/r06/base_quarters.log)
+inline bool base_quarters(const Ctx& g, size_t n) { return g.opt_base_quarters != 0 && g.opt_base_radix == 64 && n <= (size_t)128 * (size_t)g.cus; }
+// ... and with that form behind them the one-item-per-wavefront kernels hand a FIXED-BASE multiplication (and signing, two per signature) over at 5 wavefronts
+// per CU instead of coop.base_max_items (tools/base_quarters_probe.py, profiles/r06/base_quarters.log: 70 against 99 us at 1,024 items, 98 / 86 at 1,536,
+// 183 / 93 at 4,096); the other users of coop.base_max_items (short sums, small verifications) keep it
+constexpr int COOP_BASE_TO_QUARTERS_PER_CU = 5;
+inline size_t base_coop_lim(const Ctx& g) {
+  const size_t lim = coop_lim(g, g.opt_coop_base_max), q = coop_lim(g, COOP_BASE_TO_QUARTERS_PER_CU * g.cus);
+  return (g.opt_base_quarters != 0 && g.opt_base_radix == 64 && q < lim) ? q : lim;
+}
 inline bool finish_four(const Ctx& g, size_t n) { return g.opt_finish_four != 0 && n <= (size_t)64 * 4 * (size_t)g.cus; }      // launches of at most a wavefront per SIMD share an inversion between 4 items (finish.four)
 // ... and with finish.four = 2 (default) launches of up to TWO wavefronts of finish lanes per SIMD close with ONE inversion per wavefront, spread over its lanes
 // (k_finish_wave, kernels_coop.hip; profiles/r06/finish_crossover.log: 35 against 52 us up to 2^16 points, 48 / 64 at 2^17, 70 / 67 at 196,608)
@@ -1371,6 +1384,11 @@ int launch_base(Ctx& g, bool split, const uint8_t* sc, size_t n, uint8_t* oenc, 
     const size_t nchunks64 = (n + block - 1) / block;                   // workgroups' worth of items (the kernel deals them out per wavefront)
     const int grid64 = (int)(nchunks64 < (size_t)g.cus ? nchunks64 : (size_t)g.cus);
     ProfScope ps(g, st, KID_MUL_BASE);
+    if (split && offset == 0 && base_quarters(g, n) && r->proj_items >= 4 * n) {      // (the callers that want this form ask ensure_proj for 4 n records)
+      const size_t groups = (n + 63) / 64;
+      LAUNCHCK(launch::mul_base64_quarters((int)(groups < (size_t)g.cus ? groups : (size_t)g.cus), st, sc, sc_b, n_a, n, img64, r->proj, r->proj_items, offset));
+      return KYB_OK;
+    }
     LAUNCHCK(launch::mul_base64(split, block, grid64, st, sc, sc_b, n_a, n, oenc, oext, img64, r->proj, r->proj_items, offset));
     return KYB_OK;
   }
@@ -1401,7 +1419,7 @@ int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t*
   StreamRes* r = nullptr;
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
-  if (n <= coop_lim(g, g.opt_coop_base_max)) {
+  if (n <= base_coop_lim(g)) {
     ProfScope ps(g, st, KID_MUL_BASE_COOP);
     LAUNCHCK(launch::mul_base_coop(st, sc, n, oenc, oext, coop_table(g), nullptr, 0, 0, nullptr, 0, take_done_flag(g, st, n),
                                    n <= 2 * coop_lim(g, g.opt_coop_verify_max) ? 4 : 1,      // few items (measured: up to 1,024): four wavefronts share an item's 43 windows
@@ -1409,7 +1427,7 @@ int launch_mul_base(Ctx& g, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t*
     return KYB_OK;
   }
   if (use_split(g, n)) {
-    int rc = ensure_proj(g, r, n); if (rc) return rc;
+    int rc = ensure_proj(g, r, base_quarters(g, n) ? 4 * n : n); if (rc) return rc;
     rc = launch_base(g, true, sc, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
     return launch_finish(g, r, n, oenc, oext, st, 1, true);
   }
@@ -1458,7 +1476,7 @@ int launch_point_checks(Ctx& g, const uint8_t* enc, const int32_t* pext, size_t 
 // pub_out != nullptr: receives enc(x*B).
 int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const uint8_t* pub_in, const uint8_t* msgs, const uint32_t* off, size_t n,
                 uint8_t* sig, uint8_t* pub_out, hipStream_t st) {
-  if (n <= coop_lim(g, g.opt_coop_verify_max) && 2 * n <= coop_lim(g, g.opt_coop_base_max)) {
+  if (n <= coop_lim(g, g.opt_coop_verify_max) && 4 * n <= 3 * base_coop_lim(g)) {
     // few signatures: one launch, two wavefronts each (kernels_coop.hip)
     ProfScope ps(g, st, KID_SIGN_COOP);
     LAUNCHCK(launch::sign_coop(st, x, k, pub_in, msgs, off, n, sig, pub_out, coop_table(g), take_done_flag(g, st, n)));
@@ -1467,11 +1485,11 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
   if (pub_in != nullptr) {
     // R = k*B only
     int rc = ensure_enc(g, r, 32 * n); if (rc) return rc;
-    if (n <= coop_lim(g, g.opt_coop_base_max)) {
+    if (n <= base_coop_lim(g)) {
       ProfScope ps(g, st, KID_MUL_BASE_COOP);
       LAUNCHCK(launch::mul_base_coop(st, k, n, r->enc, nullptr, coop_table(g)));
     } else if (use_split(g, n)) {
-      rc = ensure_proj(g, r, n); if (rc) return rc;
+      rc = ensure_proj(g, r, base_quarters(g, n) ? 4 * n : n); if (rc) return rc;
       rc = launch_base(g, true, k, n, nullptr, nullptr, r, 0, st); if (rc) return rc;
       rc = launch_finish(g, r, n, r->enc, nullptr, st); if (rc) return rc;
     } else {
@@ -1485,7 +1503,7 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
     if (pub_out != nullptr && pub_out != pub_in) HIPCK(hipMemcpyAsync(pub_out, pub_in, 32 * n, hipMemcpyDeviceToDevice, st));
     return KYB_OK;
   }
-  if (2 * n <= coop_lim(g, g.opt_coop_base_max)) {
+  if (4 * n <= 3 * base_coop_lim(g)) {      // (signing crosses a little later than a bare multiplication: 118 / 122 us at 768 signatures, 123 / 124 at 1,024, 150 / 130 at 1,536)
     // small batch: the 2n fixed-base multiplications as 2n wavefronts of the cooperative kernel, encodings straight out
     int rc = ensure_enc(g, r, 64 * n); if (rc) return rc;
     {
@@ -1501,7 +1519,7 @@ int sign_locked(Ctx& g, StreamRes* r, const uint8_t* x, const uint8_t* k, const 
   }
   if (use_split(g, 2 * n)) {
     // R = k*B -> proj[0, n), A = x*B -> proj[n, 2n); one batched finish; then hash + scalar arithmetic
-    int rc = ensure_proj(g, r, 2 * n); if (rc) return rc;
+    int rc = ensure_proj(g, r, base_quarters(g, 2 * n) ? 8 * n : 2 * n); if (rc) return rc;
     rc = ensure_enc(g, r, 64 * n); if (rc) return rc;
     rc = launch_base(g, true, k, n, nullptr, nullptr, r, 0, st, x, n); if (rc) return rc;
     rc = launch_finish(g, r, 2 * n, r->enc, nullptr, st); if (rc) return rc;

@@ -383,6 +383,39 @@ KYB_HD void ge_scalarmult_base64(ge_p3& h, const uint32_t a[8], Tbl& tbl) {
   fe_cmov(h.X, nx, dg.neg);
   fe_cmov(h.T, nt, dg.neg);
 }
+// Windows [p0, p1) of the same sum: the radix-64 form has no doublings, so the 43 additions split freely — four lanes (wavefronts) take a quarter
+// of the windows each and the four partial points are added up (k_mul_base64_quarters, kernels_base.hip).  The sign of the whole scalar goes onto
+// every part.
+template <class Tbl>
+KYB_HD void ge_scalarmult_base64_part(ge_p3& h, const uint32_t a[8], Tbl& tbl, int p0, int p1) {
+  sc_digits64 dg;
+  sc_recode64(dg, a);
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+  for (int pos = 0; pos < p0; ++pos) {            // (uniform trip count: the part is the wavefront's number)
+    KYB_UNROLL for (int i = 0; i < 7; ++i) dg.w[i] = (dg.w[i] >> 6) | (dg.w[i + 1] << 26);
+    dg.w[7] >>= 6;
+  }
+  ge_p3_0(h);
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+  for (int pos = p0; pos < p1; ++pos) {
+    uint32_t mag, neg;
+    sc_next_digit64(mag, neg, dg, pos == KYB_BASE64_POS - 1);
+    ge_precomp c;
+    if (pos < KYB_BASE64_POS - 1) tbl.select(c, pos, mag, neg); else tbl.select_top(c, mag);
+    ge_p1p1 t;
+    ge_madd_lazy_t(t, h, c);
+    ge_p1p1_to_p3_lazy_t(h, t);
+  }
+  fe nx, nt;
+  fe_neg(nx, h.X); fe_reduce_weak(nx, nx);
+  fe_neg(nt, h.T); fe_reduce_weak(nt, nt);
+  fe_cmov(h.X, nx, dg.neg);
+  fe_cmov(h.T, nt, dg.neg);
+}
 struct tbl_base64_words {
   const uint32_t* w;
   KYB_HD void scan(ge_precomp& c, int pos, uint32_t idx, int entries) {

@@ -2,6 +2,7 @@
 //   k_base_table / 32 / 64   build the LDS table images on the GPU at init (role of constants.rs:89 BASE)
 //   k_table_checksum         checksum embedded in / checked against an image that travelled between GPUs
 //   k_mul_base64             Point::mul(s, None)  ge.rs:442-486   42x32+16 affine table = the whole LDS (163,200 B), batches
+//   k_mul_base64_quarters    the same for mid-size batches: the four wavefronts of a workgroup take a quarter of an item's 43 windows each
 #include <hip/hip_runtime.h>
 #include "launch.h"
 #include "ge_scalarmult.h"
@@ -80,6 +81,60 @@ k_mul_base64(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ sc
   KYB_STAMP_END();
 }
 
+// The same for MID-SIZE batches (above the one-item-per-wavefront sizes, up to 128 items per CU): k_mul_base64 is then one lane's chain of 43
+// additions with a wavefront per SIMD at most and most of the chip idle (105 us whatever the size).  The radix-64 sum has no doublings, so here
+// the FOUR WAVEFRONTS of a 256-thread workgroup share 64 items: wavefront w adds windows [11 w, 11 w + 11) (the last one 33..42) for all of them,
+// the partial points meet through the staging records (the table is the whole LDS) and two additions — wavefronts 0 and 1 side by side, then
+// wavefront 0 — leave the sum in the item's own record, where k_finish* expects it.  Staging: part q of item i in record offset + q n + i
+// (q = 1, 2, 3: the caller provides 4 n records), the result in record offset + i.  Same group element as k_mul_base64, hence the same bytes.
+__device__ __forceinline__ void add_staged_part(ge_p3& h, const uint4* proj, size_t stride, size_t rec) {
+  ge_p2 b;
+  load_proj_xy(b.X, b.Y, proj, stride, rec); load_proj_z(b.Z, proj, stride, rec);
+  ge_p3 B;
+  ge_p2_to_p3(B, b);
+  ge_cached c;
+  ge_p3_to_cached(c, B);
+  ge_p1p1 t;
+  ge_add(t, h, c);
+  ge_p1p1_to_p3(h, t);
+}
+__global__ void __launch_bounds__(256, 1)
+k_mul_base64_quarters(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ scalars_b, size_t n_a, size_t n,
+                      const uint4* __restrict__ table_image, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
+  __shared__ uint4 lds_tbl[KYB_BASE64_TABLE_WORDS / 4];
+  for (int k = threadIdx.x; k < KYB_BASE64_TABLE_WORDS / 4; k += 256) lds_tbl[k] = table_image[k];
+  __syncthreads();
+  tbl_lds64 tbl{reinterpret_cast<const uint32_t*>(lds_tbl)};
+  const size_t ngroups = (n + 63) / 64;
+  const int part = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform, and the compiler knows it
+  const uint32_t lane = threadIdx.x & 63u;
+  for (size_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {          // (uniform per workgroup: every wavefront reaches every barrier)
+    const size_t i0 = grp * 64;
+    const uint32_t cnt = (uint32_t)((n - i0 < (size_t)64) ? n - i0 : (size_t)64);
+    const bool live = lane < cnt;
+    const uint32_t t = live ? lane : 0u;                                     // dead lanes redo the group's first item
+    uint32_t a[8];
+    if (scalars_b == nullptr || i0 + 64 <= n_a) load_words8(a, scalars + 32 * i0, t);
+    else if (i0 >= n_a) load_words8(a, scalars_b + 32 * (i0 - n_a), t);
+    else if (i0 + t < n_a) load_words8(a, scalars + 32 * i0, t);             // the one group that straddles the two arrays
+    else load_words8(a, scalars_b, (size_t)(i0 + t - n_a));
+    ge_p3 h;
+    ge_scalarmult_base64_part(h, a, tbl, 11 * part, part == 3 ? KYB_BASE64_POS : 11 * part + 11);
+    const size_t rec = proj_offset + i0 + t;
+    if (part >= 2 && live) store_proj(proj, proj_stride, rec + (size_t)part * n, h.X, h.Y, h.Z);
+    __threadfence_block();
+    __syncthreads();
+    if (part < 2) add_staged_part(h, proj, proj_stride, rec + (size_t)(part + 2) * n);      // 0 + 2 | 1 + 3
+    if (part == 1 && live) store_proj(proj, proj_stride, rec + n, h.X, h.Y, h.Z);
+    __threadfence_block();
+    __syncthreads();
+    if (part == 0) {
+      add_staged_part(h, proj, proj_stride, rec + n);
+      if (live) store_proj(proj, proj_stride, rec, h.X, h.Y, h.Z);
+    }
+  }
+}
+
 // ---- table image checksum ---------------------------------------------------------------------------
 // 64-bit position-weighted sum of the image's words, the two padding words of radix-16 entry (0, 0) excluded: that is
 // where the checksum itself travels (KYB_BT_IDX(0, 0, 30 / 31); no kernel reads those words as data).  A wrong or
@@ -137,6 +192,11 @@ hipError_t mul_base64(bool split, int block, int grid, hipStream_t st, const uin
   }
   if (block == 256) KYB_L(true, 256); else KYB_L(true, 1024);
 #undef KYB_L
+  return hipGetLastError();
+}
+hipError_t mul_base64_quarters(int grid, hipStream_t st, const uint8_t* sc, const uint8_t* sc_b, size_t n_a, size_t n, const uint4* img64, uint4* proj, size_t stride,
+                               size_t offset) {
+  hipLaunchKernelGGL(k_mul_base64_quarters, dim3(grid), dim3(256), 0, st, sc, sc_b, n_a, n, img64, proj, stride, offset);
   return hipGetLastError();
 }
 hipError_t diag_stamps_base(uint64_t* buf) { return kyb_set_stamp_slot(buf); }

@@ -106,7 +106,7 @@ def test_every_engine_option_is_documented_in_the_header():
 
 
 VARIANT_OPTIONS = ("mul.select", "mul_base.select", "mul.algo", "mul.ladder_waves", "mul_base.radix", "mul_base.block", "mul_base.block64", "mul_base.small_chunks",
-                   "finish.batched", "finish.min_items", "encode.batched", "finish.four", "ladder.y_only", "verify.by_encoding", "verify.overlap", "mul.grid_per_cu",
+                   "finish.batched", "finish.min_items", "encode.batched", "finish.four", "mul_base.quarters", "ladder.y_only", "verify.by_encoding", "verify.overlap", "mul.grid_per_cu",
                    "poly.segments", "poly.batch_segments")
 
 

@@ -108,8 +108,8 @@ def test_host_calls_in_flight_share_the_chip(engine, oracle):
     bad = sig.copy(); bad[::5, 3] ^= 1
     want_st = engine.verify(want_base, msgs, bad, 1)
     engine.profile_begin(8)
-    assert np.array_equal(engine.mul_base(s), want_base)
-    assert [nm for nm, _ in engine.profile_read(8)][0] == "k_mul_base_coop"      # alone: 3,000 items take the latency kernels
+    assert np.array_equal(engine.mul(k, pts_ext=pts), want_mul)
+    assert [nm for nm, _ in engine.profile_read(8)][0] == "k_mul_coop"           # alone: 3,000 items take the latency kernels
     engine.profile_begin(0)
     for share in (1, 0):
         engines = [kyber_rs_amd.Engine(0, private=True) for _ in range(6)]
@@ -268,7 +268,7 @@ def test_one_inversion_per_wavefront_matches_the_per_lane_forms(xengine, oracle)
             assert np.array_equal(got[2], got[1]) and np.array_equal(got[2], got[0]), n
             assert np.array_equal(got[2], want), n
         # the end of whole calls: above every one-item-per-wavefront size, below a wavefront per SIMD
-        n = max(engine.get_option("coop.base_max_items"), engine.get_option("coop.ladder_max_items")) + 77
+        n = engine.get_option("coop.ladder_max_items") + 77
         s, k = synth.raw256(n, 911), synth.scalars(n, 912, b"k")
         x = s.copy(); x[:, 31] &= 0x7f
         p = np.tile(proj300, ((n + 299) // 300, 1))[:n].copy()
@@ -287,6 +287,42 @@ def test_one_inversion_per_wavefront_matches_the_per_lane_forms(xengine, oracle)
         assert np.array_equal(res[2][2], oracle.schnorr_sign_batch(x, k, msgs, nthreads=8))
     finally:
         engine.set_option("finish.four", 2)
+
+
+def test_fixed_base_in_quarters_matches_one_lane_per_item(xengine, oracle):
+    engine = xengine          # mul_base.quarters is a selector of the cross-check build (tests/conftest.py); the product runs its default, 1
+    """mid-size fixed-base launches (engine.hip base_quarters): four wavefronts per 64 items, a quarter of the 43 windows each, the partial points
+    added through the staging records (k_mul_base64_quarters) == one lane per item (k_mul_base64) == the oracle — sizes from the first above the
+    one-item-per-wavefront kernels to the last that takes this form and one beyond, ragged last groups, the scalars whose digits sit at the
+    window cuts (0, 1, L - 1, L, 2^66 - 1, 2^132, 2^198 +- 1, the a[31] quirk values), signing (two scalar arrays in one launch, the seam inside a group)
+    and limbs out"""
+    assert engine.get_option("mul_base.quarters") == 1
+    cus = engine.get_option("device.cus")
+    lo = 5 * cus                                        # (engine.hip COOP_BASE_TO_QUARTERS_PER_CU: the last size of the one-item-per-wavefront kernel)
+    L = (1 << 252) + 27742317777372353535851937790883648493
+    special = [0, 1, 2, 63, 64, L - 1, L, L + 1, (1 << 66) - 1, 1 << 66, 1 << 132, (1 << 198) - 1, (1 << 198) + 1, (1 << 255) - 19, (1 << 255), (1 << 256) - 1,
+               0x7f << 248, 0x80 << 248, 0x8f << 248, 0x90 << 248, (0xff << 248) | 12345]
+    try:
+        for n in (lo + 1, lo + 64, 8192 + 37, 128 * cus, 128 * cus + 1):
+            s = synth.raw256(n, 920 + n % 7)
+            for j, v in enumerate(special):
+                s[(j * 131) % n] = np.frombuffer(int(v).to_bytes(32, "little"), dtype=np.uint8)
+            want = oracle.mul_base_batch(s, nthreads=8)
+            engine.set_option("mul_base.quarters", 1)
+            enc1, ext1 = engine.mul_base(s, want_ext=True)
+            engine.set_option("mul_base.quarters", 0)
+            enc0, ext0 = engine.mul_base(s, want_ext=True)
+            assert np.array_equal(enc1, want) and np.array_equal(enc0, want), n
+            assert np.array_equal(ext1, ext0), n
+        n = lo // 2 + 45                                   # 2 n items in the launch, the seam between nonces and keys inside a group
+        x, k, msgs = synth.raw256(n, 925), synth.scalars(n, 926, b"k"), synth.messages(n, 927)
+        x[:, 31] &= 0x7f
+        want_sig = oracle.schnorr_sign_batch(x, k, msgs, nthreads=8)
+        for q in (1, 0):
+            engine.set_option("mul_base.quarters", q)
+            assert np.array_equal(engine.schnorr_sign(x, k, msgs), want_sig), q
+    finally:
+        engine.set_option("mul_base.quarters", 1)
 
 
 def test_group_device_resident_shards_and_pool_reuse(oracle):

@@ -313,12 +313,13 @@ def test_projective_extended_results_on_request(oracle):
     eng = kyber_rs_amd.Engine(0, private=True)
     try:
         eng.set_option("ext.projective", 1)
-        for n in (1, 5, 300, 700, 2000):                                   # four wavefronts per item / one
+        small = 5 * eng.get_option("device.cus")                           # (engine.hip COOP_BASE_TO_QUARTERS_PER_CU: above it the fixed base is a batch kernel, affine limbs)
+        for n in (1, 5, 300, 700, small, 2000):                            # four wavefronts per item / one / the mid-size form
             s, k = synth.raw256(n, 51), synth.scalars(n, 52)
             want_b = oracle.mul_base_batch(s, nthreads=8)
             eb = eng.mul_base(s, ext_only=True)
             assert [oracle.encode(e) for e in eb[:40]] == [bytes(w) for w in want_b[:40]]
-            assert any(list(e[20:30]) != [1] + [0] * 9 for e in eb[:8])   # really projective
+            assert any(list(e[20:30]) != [1] + [0] * 9 for e in eb[:8]) == (n <= small)   # really projective where the option applies
             assert np.array_equal(eng.encode(eb), want_b)
             em = eng.mul(k, pts_ext=eb, ext_only=True)                     # projective points in, projective points out
             want_m = oracle.mul_batch(k, oracle.mul_base_ext_batch(s), nthreads=8)
@@ -367,7 +368,7 @@ def test_every_routing_boundary_with_default_options(oracle, cus):
         marks = set()
         for v in opt.values():
             marks |= {v, v // 2, v // 4, 2 * v, 7 * v // 8}
-        marks |= {4 * n_cu}
+        marks |= {4 * n_cu, 5 * n_cu, 15 * n_cu // 4, 128 * n_cu}      # (5: fixed base hands over to its four-wavefronts-per-64-items form, signing at 3/4 of it; 128: that form's last size)
         sizes = sorted({n for m in marks for n in (m - 1, m, m + 1) if 1 <= n <= 24 * n_cu + 1 and n <= 6200})
         nmax = max(sizes)
         s = synth.raw256(nmax, 31); s[::7] = synth.scalars(len(s[::7]), 32)

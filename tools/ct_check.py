@@ -49,6 +49,7 @@ SECRET_ARGS = {
     "_Z12k_mul_base64ILb1ELi1024E": ("kernels_base", {0: "scalars", 8: "scalars_b"}),
     "_Z12k_mul_base64ILb1ELi768E": ("kernels_base", {0: "scalars", 8: "scalars_b"}),
     "_Z12k_mul_base64ILb1ELi256E": ("kernels_base", {0: "scalars", 8: "scalars_b"}),
+    "_Z21k_mul_base64_quarters": ("kernels_base", {0: "scalars", 8: "scalars_b"}),
     "_Z10k_mul_coopPKhPKim": ("kernels_coop", {0: "scalars"}),
     "_Z14k_mul_enc_coopPKhS0_m": ("kernels_coop", {0: "scalars"}),
     "_Z15k_mul_base_coopPKhS0_mm": ("kernels_coop", {0: "scalars", 8: "scalars_b"}),

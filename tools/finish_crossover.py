@@ -17,7 +17,7 @@ eng = kyber_rs_amd.Engine(0, crosscheck=True)      # finish.four is a selector o
 N = 196608
 sc = synth.scalars(16000, 5)
 eng.set_option("ext.projective", 1)       # projective limbs (small-batch calls asked for limbs only): Z != 1, the encoder has to invert
-host_ext = np.tile(np.concatenate([eng.mul_base(sc[i:i + 2000], ext_only=True) for i in range(0, 16000, 2000)]), (N // 16000 + 1, 1))[:N].copy()
+host_ext = np.tile(np.concatenate([eng.mul_base(sc[i:i + 1000], ext_only=True) for i in range(0, 16000, 1000)]), (N // 16000 + 1, 1))[:N].copy()
 eng.set_option("ext.projective", 0)
 assert all(list(e[20:30]) != [1] + [0] * 9 for e in host_ext[::97])
 ext = torch.from_numpy(host_ext).to("cuda:0")

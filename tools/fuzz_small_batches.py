@@ -70,7 +70,7 @@ def set_random_options():
          "coop.verify_max_items": int(rng.choice([512, 512, 0, 4096])), "ladder.pair_max_items": int(rng.choice([32768, 32768, 0, 1 << 20])),
          "coop.ladder_max_items": int(rng.choice([3584, 2816, 1 << 20, 700])), "coop.ladder_enc_max_items": int(rng.choice([2048, 2048, 1 << 20, 700]))}
     variants = {"poly.segments": int(rng.choice([0, 0, 1, 2, 5, 32])), "poly.batch_segments": int(rng.choice([0, 0, 1, 1, 2, 3, 16, 200])),
-                "verify.by_encoding": int(rng.integers(0, 2)), "verify.overlap": int(rng.integers(0, 2)), "ladder.y_only": int(rng.integers(0, 3)), "finish.four": int(rng.integers(0, 3))}
+                "verify.by_encoding": int(rng.integers(0, 2)), "verify.overlap": int(rng.integers(0, 2)), "ladder.y_only": int(rng.integers(0, 3)), "finish.four": int(rng.integers(0, 3)), "mul_base.quarters": int(rng.integers(0, 2))}
     if CROSSCHECK:          # (drawn in either mode: the same seed walks the same cases on both libraries)
         o.update(variants)
     if rng.integers(0, 4) == 0:              # the batch kernels of DKG-sized calls at these sizes (two-lane ladder, ladder.y_only, finish.four)
