@@ -317,7 +317,11 @@ inline size_t finish_coop_lim(const Ctx& g) { return coop_lim(g, g.opt_coop_deco
 // Fixed base above the one-item-per-wavefront sizes and up to 128 items per CU (two rounds of 64-item workgroups): k_mul_base64 would be ONE lane's chain of 43
 // additions (105 us flat) on a mostly idle chip; four wavefronts per 64 items take a quarter of the windows each (tools/mid_size_kernels.py,
 // profiles/r06/base_quarters.log)
-inline bool base_quarters(const Ctx& g, size_t n) { return g.opt_base_quarters != 0 && g.opt_base_radix == 64 && n <= (size_t)128 * (size_t)g.cus; }
+// (a launch in this form occupies four times the compute units of the one-lane form — each workgroup owns a CU's LDS: with several host-pointer calls in flight the
+//  size limit is divided by their number, like the other latency-oriented hand-overs)
+inline bool base_quarters(const Ctx& g, size_t n) {
+  return g.opt_base_quarters != 0 && g.opt_base_radix == 64 && n * (size_t)host_load(g) <= (size_t)128 * (size_t)g.cus;
+}
 // ... and with that form behind them the one-item-per-wavefront kernels hand a FIXED-BASE multiplication (and signing, two per signature) over at 5 wavefronts
 // per CU instead of coop.base_max_items (tools/base_quarters_probe.py, profiles/r06/base_quarters.log: 70 against 99 us at 1,024 items, 98 / 86 at 1,536,
 // 183 / 93 at 4,096); the other users of coop.base_max_items (short sums, small verifications) keep it

@@ -39,9 +39,13 @@ for nt, opts in VARIANTS:
     if shared:
         engines = engines * nt
         print(f"# {nt} threads sharing ONE context (mean_call_ms = time a call is served, queueing included)", flush=True)
-    for e in engines:
-        for k_, v_ in opts.items():
-            e.set_option(k_, v_)
+    try:
+        for e in engines:
+            for k_, v_ in opts.items():
+                e.set_option(k_, v_)
+    except kyber_rs_amd.KyberHipError as err:          # a selector of the cross-check build (verify.overlap since round 5): nothing to compare in the product
+        print(f"# {nt} threads with {opts}: skipped ({err})", flush=True)
+        continue
     if opts:
         print(f"# {nt} threads with {opts}", flush=True)
     for op in ("mul_base", "mul", "sign", "verify"):
