@@ -503,9 +503,12 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     projective, so that no inversion runs in front (default 128 x compute units = one wavefront per SIMD: 32768 on an MI355X, 0 = never): up to there the
  *                     call time is one lane's chain of 255 steps, and the two-lane form takes 0.49 instead of 0.79 ms.  Same results.  These
  *                     launches always walk 256 bits (minus publicly known zeros): ladder.skip_canonical does not apply to them.
+ *   ladder.quad_max_items  ... and of at most this many items FOUR lanes, a ladder step three products deep instead of five (variable base from points; default
+ *                     64 x compute units = one wavefront per SIMD: 16384, 0 = never): 0.34 instead of 0.43 ms.  Same results.
  *   coop.ladder_max_items  variable base and linear combinations leave the one-item-per-wavefront kernels above this many items (default 14 per compute unit = 3584;
  *                     verification with the keys given as points at 7/8 of it) even when coop.max_items would still allow them: from there the
- *                     two-lane ladder is faster.
+ *                     two-lane ladder is faster (a plain multiplication of points by full-size scalars already leaves at 9 per compute unit = 2304 while
+ *                     ladder.quad_max_items is set: its four-lane ladder is).
  *   coop.ladder_enc_max_items  the same for calls from BYTES — kyb_mul_batch with pts_enc (full-length multipliers), kyb_verify_batch: default 8 per compute unit = 2048
  *                     (two wavefronts per SIMD); above it the role-split launches of ladder.y_only = 2 are faster.
  *   ladder.skip_canonical  1 (default): the batch ladder starts four bits lower when no scalar of the launch reaches 2^252 — true of a scalar

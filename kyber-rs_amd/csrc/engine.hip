@@ -144,6 +144,7 @@ struct Ctx {
   std::atomic<int> opt_coop_share{1};             // divide the small-batch thresholds by the number of host-pointer calls in flight in this process (coop_lim)
   std::atomic<int> opt_host_inplace{1};           // zero-copy host-pointer calls use page-locked CALLER arrays (kyb_host_alloc) where they lie instead of copying them into the context's buffer
   std::atomic<int> opt_zero_copy_kib{4096};         // host-pointer calls whose arrays fit this many KiB run their kernels on the context's page-locked buffer (no hipMemcpy); 512 in round 2, 4 MiB wins up to 16,384 items (profiles/r03/mid_size_host_calls.log)
+  std::atomic<int> opt_ladder_quad_max{0};    // ... and of at most this many items FOUR lanes (k_mul_ladder_quad: one wavefront per SIMD up to here); 0 = never
   std::atomic<int> opt_ladder_pair_max{0};    // ladder launches of at most this many items give each item two lanes (k_mul_ladder_pair: one wavefront per SIMD up to here); 0 = never
   std::atomic<int> opt_coop_ladder_max{0};     // variable base from points, linear combinations: above this the two-lane batch ladder is faster than one item per wavefront (3072 until the batch path lost its in-kernel decode wait: profiles/r04/coop_vs_fused.log)
   std::atomic<int> opt_coop_ladder_enc_max{0};  // the same for calls from BYTES (multiplication from encodings, verification from key bytes): the role-split launches of ladder.y_only = 2 take over at two wavefronts per SIMD
@@ -267,7 +268,7 @@ void wipe_free_dev(Ctx& g, void* p, size_t bytes) {
 // (round 6: the one-item-per-wavefront point operations move rows with permlane swaps instead of ds_bpermute and end in a cheaper inversion — they
 //  stay ahead of the batch kernels for longer: fixed base 13 -> 18, variable base 11 -> 14 wavefronts per CU; profiles/r06/coop_crossover.log)
 constexpr int COOP_MAX_PER_CU = 24, COOP_BASE_MAX_PER_CU = 18, COOP_LADDER_MAX_PER_CU = 14, COOP_LADDER_ENC_MAX_PER_CU = 8, COOP_DECODE_MAX_PER_CU = 4,
-              COOP_VERIFY_MAX_PER_CU = 2, LADDER_PAIR_MAX_PER_CU = 128;      // (128: two lanes per item up to one wavefront per SIMD = 4 SIMDs x 64 lanes / 2)
+              COOP_VERIFY_MAX_PER_CU = 2, LADDER_PAIR_MAX_PER_CU = 128, LADDER_QUAD_MAX_PER_CU = 64;      // (128: two lanes per item up to one wavefront per SIMD = 4 SIMDs x 64 lanes / 2)
 void apply_cu_count(Ctx& g, int cus) {
   g.cus = cus;
   g.opt_coop_max = COOP_MAX_PER_CU * cus;                       // 6,144 on 256 CUs
@@ -277,6 +278,7 @@ void apply_cu_count(Ctx& g, int cus) {
   g.opt_coop_decode_max = COOP_DECODE_MAX_PER_CU * cus;         // 1,024
   g.opt_coop_verify_max = COOP_VERIFY_MAX_PER_CU * cus;         // 512
   g.opt_ladder_pair_max = LADDER_PAIR_MAX_PER_CU * cus;         // 32,768
+  g.opt_ladder_quad_max = LADDER_QUAD_MAX_PER_CU * cus;         // 16,384
   g.grid_mul = cus * 2;
 }
 
@@ -335,6 +337,14 @@ inline bool finish_four(const Ctx& g, size_t n) { return g.opt_finish_four != 0 
 // (k_finish_wave, kernels_coop.hip; profiles/r06/finish_crossover.log: 35 against 52 us up to 2^16 points, 48 / 64 at 2^17, 70 / 67 at 196,608)
 inline bool finish_wave(const Ctx& g, size_t n) { return g.opt_finish_four == 2 && n <= (size_t)64 * 8 * (size_t)g.cus; }
 inline size_t pair_lim(const Ctx& g, int opt) { const int l = host_load(g) / 4; return opt <= 0 ? 0 : (size_t)opt / (size_t)(l < 1 ? 1 : l); }
+// A variable-base multiplication by FULL-SIZE scalars from points leaves the one-item-per-wavefront kernel at 9 wavefronts per CU when the four-lane ladder
+// is there to take it (tools/ladder_quad_probe.py, profiles/r06/ladder_quad.log: 277 / 337 us at 2,048 items, 341 / 338 at 2,304, 450 / 334 at 3,584); the other
+// users of coop.ladder_max_items (short public multipliers, linear combinations, verification: their batch forms are the two-lane ladder's) keep it
+constexpr int COOP_LADDER_TO_QUAD_PER_CU = 9;
+inline size_t ladder_coop_lim(const Ctx& g) {
+  const size_t lim = coop_lim(g, g.opt_coop_ladder_max), q = coop_lim(g, COOP_LADDER_TO_QUAD_PER_CU * g.cus);
+  return (pair_lim(g, g.opt_ladder_quad_max) > q && pair_lim(g, g.opt_ladder_pair_max) > q && q < lim) ? q : lim;
+}
 
 int ensure_pin(Ctx& g, int lane, size_t bytes) {
   if (bytes <= g.pin_bytes[lane]) return KYB_OK;
@@ -1143,6 +1153,12 @@ int launch_ladder_core(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int
   } else if (ok != nullptr) {
     HIPCK(hipMemsetAsync(ok, 1, np, st));          // extended operands are taken as they are (k_mul does the same)
   }
+  if (n <= pair_lim(g, g.opt_ladder_quad_max) && n <= pair_lim(g, g.opt_ladder_pair_max)) {      // (ladder.pair_max_items = 0 keeps every item on one lane)
+    // fewer items still (a wavefront per SIMD at FOUR lanes per item): a step is three products deep instead of five (ge_ladder_quad.h)
+    ProfScope ps(g, st, KID_MUL_LADDER_PAIR);
+    LAUNCHCK(launch::mul_ladder_quad(st, sc, n, pext, npts, r->proj, r->proj_items, skip_bits));
+    return KYB_OK;
+  }
   if (n <= pair_lim(g, g.opt_ladder_pair_max)) {
     // more SIMDs than wavefronts: two lanes per item shorten the dependent chain and keep the base point projective — no k_mont_prep,
     // no inversion in front (ge_ladder_pair.h).  Without the prep there is no launch-wide canonical test: 256 - skip_bits steps.
@@ -1316,7 +1332,8 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
   StreamRes* r = nullptr;
   { int rc = res_for(g, st, &r); if (rc) return rc; }
   SlotUse use(r, st);
-  if (n <= coop_lim(g, g.opt_coop_max) && n <= coop_lim(g, penc != nullptr && skip_hint < 192 ? g.opt_coop_ladder_enc_max : g.opt_coop_ladder_max) && g.opt_mul_algo == 1) {
+  const size_t coop_to = penc != nullptr && skip_hint < 192 ? coop_lim(g, g.opt_coop_ladder_enc_max) : (penc == nullptr && skip_hint < 192 ? ladder_coop_lim(g) : coop_lim(g, g.opt_coop_ladder_max));
+  if (n <= coop_lim(g, g.opt_coop_max) && n <= coop_to && g.opt_mul_algo == 1) {
     // small batch: one item per wavefront, the whole multiplication in one launch (kernels_coop.hip)
     if (penc != nullptr && 4 * n <= coop_lim(g, g.opt_coop_max)) {
       // from the wire encoding, two wavefronts per item: the ladder starts on y while the decode is still looking for x

@@ -12,6 +12,7 @@
 #include "ge_scalarmult.h"
 #include "ge_ladder.h"
 #include "ge_ladder_pair.h"
+#include "ge_ladder_quad.h"
 #include "schnorr.h"
 #include "verify.h"
 #include "device_batch_invert.h"
@@ -152,6 +153,23 @@ k_mul_ladder_pair(const uint8_t* __restrict__ scalars, size_t n, const int32_t* 
   ge_p2 r;
   ge_scalarmult_ladder_pair(r, a, P, skip_bits, odd);
   if (odd == 0u) store_proj(proj, stride, i, r.X, r.Y, r.Z);
+}
+
+// Four lanes per item (ge_ladder_quad.h): lanes 4i .. 4i+3 walk the ladder of item i three products deep per step, all four recover the point, lane 4i
+// stores it.  For launches of at most a wavefront per SIMD (ladder.quad_max_items).
+__global__ void __launch_bounds__(KYB_BLOCK, 1)
+k_mul_ladder_quad(const uint8_t* __restrict__ scalars, size_t n, const int32_t* __restrict__ pts_ext, size_t pts_mod, uint4* __restrict__ proj, size_t stride, int skip_bits) {
+  const size_t lane = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
+  const size_t i = lane >> 2;
+  const uint32_t q = threadIdx.x & 3u;
+  if (i >= n) return;                                  // (n is a whole number of quads: the four lanes of an item leave together)
+  uint32_t a[8];
+  load_words8(a, scalars, i);
+  ge_p3 P;
+  load_ext(P, pts_ext, pts_mod ? i % pts_mod : i);
+  ge_p2 r;
+  ge_scalarmult_ladder_quad(r, a, P, skip_bits, q);
+  if (q == 0u) store_proj(proj, stride, i, r.X, r.Y, r.Z);
 }
 
 // The same launch with the R half of a verification as further workgroups (keys given as POINTS: nothing to decode on the A side, but R's square
@@ -421,6 +439,10 @@ hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, ui
 }
 hipError_t mul_ladder_pair(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, size_t pts_mod, uint4* proj, size_t stride, int skip_bits) {
   hipLaunchKernelGGL(k_mul_ladder_pair, dim3(blocks_for(2 * n)), dim3(KYB_BLOCK), 0, st, sc, n, pext, pts_mod, proj, stride, skip_bits);
+  return hipGetLastError();
+}
+hipError_t mul_ladder_quad(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, size_t pts_mod, uint4* proj, size_t stride, int skip_bits) {
+  hipLaunchKernelGGL(k_mul_ladder_quad, dim3(blocks_for(4 * n)), dim3(KYB_BLOCK), 0, st, sc, n, pext, pts_mod, proj, stride, skip_bits);
   return hipGetLastError();
 }
 hipError_t mul_ladder_pair_r(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, uint4* proj, size_t stride, int skip_bits, const uint8_t* sigs, uint8_t* flags_r, size_t r_offset) {

@@ -65,6 +65,8 @@ hipError_t mont_prep(hipStream_t st, const int32_t* pext, size_t n, uint4* proj,
 hipError_t mul_ladder(int waves, hipStream_t st, const uint8_t* sc, size_t n, uint4* proj, size_t stride, size_t img_offset, size_t img_mod, int skip_bits,
                       const uint32_t* top_or = nullptr, uint32_t* zero_next = nullptr);
 hipError_t mul_ladder_pair(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, size_t pts_mod, uint4* proj, size_t stride, int skip_bits);
+// the same with FOUR lanes per item (ge_ladder_quad.h): three products deep per step
+hipError_t mul_ladder_quad(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, size_t pts_mod, uint4* proj, size_t stride, int skip_bits);
 // the same from wire encodings: the ladder on (1 + y : 1 - y) leaves its x-only state (160 bytes per item) while the decode runs elsewhere;
 // ladder_recover turns state + decoded point into the projective result (ge_ladder_pair.h)
 // k_mul_ladder_pair with the R half of a verification (k_verify_prep_r: flags_r, record r_offset + i) as further workgroups of the launch

@@ -123,7 +123,7 @@ def test_the_product_library_has_one_kernel_per_regime_and_no_variant_selectors(
         assert f'"{key}"' in src and f'"{key}"' not in product, key
     kept = set(re.findall(r'strcmp\(key, "([a-z_0-9.]+)"\)', product))
     assert kept == {"device.cus", "coop.max_items", "coop.base_max_items", "coop.decode_max_items", "coop.verify_max_items", "coop.ladder_max_items",
-                    "coop.ladder_enc_max_items", "coop.share_by_load", "ladder.pair_max_items", "ladder.skip_canonical", "mul.short_scalars", "ext.projective",
+                    "coop.ladder_enc_max_items", "coop.share_by_load", "ladder.pair_max_items", "ladder.quad_max_items", "ladder.skip_canonical", "mul.short_scalars", "ext.projective",
                     "host.in_place", "host.zero_copy_kib", "host.pipe_chunks", "host.copy_threads", "defer.fuse", "defer.max_nodes", "defer.keep_mib",
                     "diag.dev_kib", "diag.host_kib"}, sorted(kept)
     libdir = os.path.join(ROOT, "kyber-rs_amd")

@@ -494,10 +494,11 @@ def test_ladder_path_matches_oracle(xengine, oracle, waves):
 
 def test_two_lane_ladder_matches_one_lane_and_oracle(xengine, oracle):
     engine = xengine          # variant kernels / selectors: the cross-check build (tests/conftest.py)
-    """k_mul_ladder_pair (two lanes per item, ge_ladder_pair.h; launches of at most ladder.pair_max_items items) == k_mul_ladder == the oracle:
+    """k_mul_ladder_pair (two lanes per item, ge_ladder_pair.h; launches of at most ladder.pair_max_items items) == k_mul_ladder_quad (four lanes,
+    ge_ladder_quad.h; variable base from points, at most ladder.quad_max_items items) == k_mul_ladder == the oracle:
     quirk vectors, mixed-order points, scalars around multiples of L, canonical-only batches (252 steps) and batches with one unreduced
     scalar (256), invalid encodings, ragged and odd sizes, shared operands (linear combinations) and the h*A of a verification"""
-    saved = {k: engine.get_option(k) for k in ("coop.max_items", "coop.base_max_items", "coop.verify_max_items", "ladder.pair_max_items")}
+    saved = {k: engine.get_option(k) for k in ("coop.max_items", "coop.base_max_items", "coop.verify_max_items", "ladder.pair_max_items", "ladder.quad_max_items")}
     try:
         for k in ("coop.max_items", "coop.base_max_items", "coop.verify_max_items"):
             engine.set_option(k, 0)                                       # small batches reach the ladder kernels
@@ -531,8 +532,9 @@ def test_two_lane_ladder_matches_one_lane_and_oracle(xengine, oracle):
         lsc = synth.scalars(40 * 9, 617).reshape(40, 9, 32)
         lp = pts[:9]
         results = {}
-        for pair_max in (0, 1 << 20):
-            engine.set_option("ladder.pair_max_items", pair_max)
+        for pair_max in (0, 1 << 20, 1 << 21):                           # one lane | two lanes | four lanes where that kernel applies (points given as limbs), two elsewhere
+            engine.set_option("ladder.pair_max_items", min(pair_max, 1 << 20))
+            engine.set_option("ladder.quad_max_items", (1 << 20) if pair_max == 1 << 21 else 0)
             got, ok = engine.mul(sc, pts_enc=pe, want_ok=True)
             assert ok.all() and [bytes(r).hex() for r in got] == [v["out"] for v in q], pair_max
             g1, gext = engine.mul(s, pts_ext=pts, want_ext=True)
@@ -552,6 +554,14 @@ def test_two_lane_ladder_matches_one_lane_and_oracle(xengine, oracle):
             results[pair_max] = (g1, gext, lc_shared, lc_own)
         for a_, b_ in zip(results[0], results[1 << 20]):
             assert np.array_equal(a_, b_)                                 # limbs included: the same field operations on the same values
+        for a_, b_ in zip(results[0], results[1 << 21]):
+            assert np.array_equal(a_, b_)
+        engine.set_option("ladder.quad_max_items", 1 << 20)
+        engine.profile_begin(4)
+        engine.mul(s[:100], pts_ext=pts[:100])
+        assert "k_mul_ladder_pair" in [nm for nm, _ in engine.profile_read(4)]      # (the four-lane launch is profiled under the two-lane ladder's name)
+        engine.profile_begin(0)
+        engine.set_option("ladder.quad_max_items", 0)
         # from wire encodings the two-lane ladder runs on the y of the encoding while a side stream decodes x (ladder.y_only, round 4): the same
         # bytes with the option off (decode first), on the quirk points, on encodings that do not decode, on y = +-1 (x = 0) and on non-canonical y
         engine.set_option("ladder.pair_max_items", 1 << 20)

@@ -42,6 +42,7 @@ SECRET_ARGS = {
     "_Z12k_mul_ladderILi3E": ("kernels_ladder", {0: "scalars"}),
     "_Z12k_mul_ladderILi2E": ("kernels_ladder", {0: "scalars"}),
     "_Z17k_mul_ladder_pair": ("kernels_ladder", {0: "scalars"}),
+    "_Z17k_mul_ladder_quad": ("kernels_ladder", {0: "scalars"}),
     "_Z19k_mul_ladder_pair_y": ("kernels_ladder", {0: "scalars"}),
     "_Z23k_mul_ladder_pair_y_dec": ("kernels_ladder", {0: "scalars"}),      # the role of a workgroup depends on blockIdx only
     "_Z16k_ladder_recover": ("kernels_ladder", {0: "scalars", 24: "x-only state the ladder left (a function of the scalar)"}),
