@@ -340,6 +340,8 @@ inline size_t pair_lim(const Ctx& g, int opt) { const int l = host_load(g) / 4; 
 // A variable-base multiplication by FULL-SIZE scalars from points leaves the one-item-per-wavefront kernel at 9 wavefronts per CU when the four-lane ladder
 // is there to take it (tools/ladder_quad_probe.py, profiles/r06/ladder_quad.log: 277 / 337 us at 2,048 items, 341 / 338 at 2,304, 450 / 334 at 3,584); the other
 // users of coop.ladder_max_items (short public multipliers, linear combinations, verification: their batch forms are the two-lane ladder's) keep it
+// lanes per item of a ladder launch below ladder.pair_max_items: four up to ladder.quad_max_items (a wavefront per SIMD), else two
+inline int ladder_lanes(const Ctx& g, size_t n) { return (n <= pair_lim(g, g.opt_ladder_quad_max) && n <= pair_lim(g, g.opt_ladder_pair_max)) ? 4 : 2; }
 constexpr int COOP_LADDER_TO_QUAD_PER_CU = 9;
 inline size_t ladder_coop_lim(const Ctx& g) {
   const size_t lim = coop_lim(g, g.opt_coop_ladder_max), q = coop_lim(g, COOP_LADDER_TO_QUAD_PER_CU * g.cus);
@@ -1131,7 +1133,7 @@ int launch_ladder_core(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int
     int32_t* tmp = reinterpret_cast<int32_t*>(r->enc);
     uint4* state = reinterpret_cast<uint4*>(r->part);
     if (g.opt_ladder_y_only == 2) {      // one launch: ladder workgroups first, decoding workgroups behind them (on CUs of their own)
-      { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::mul_ladder_pair_y_dec(st, sc, n, penc, state, skip_bits, tmp, ok)); }
+      { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::mul_ladder_pair_y_dec(st, sc, n, penc, state, skip_bits, tmp, ok, ladder_lanes(g, n))); }
       { ProfScope ps(g, st, KID_LADDER_RECOVER); LAUNCHCK(launch::ladder_recover(st, sc, n, tmp, state, r->proj, r->proj_items)); }
       return KYB_OK;
     }
@@ -1139,7 +1141,7 @@ int launch_ladder_core(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int
     HIPCK(hipStreamWaitEvent(r->aux, r->ev_fork, 0));
     { ProfScope ps(g, r->aux, KID_DECODE); LAUNCHCK(launch::decode_or_identity(r->aux, penc, n, tmp, ok)); }
     HIPCK(hipEventRecord(r->ev_join, r->aux));
-    { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::mul_ladder_pair_y(st, sc, n, penc, state, skip_bits)); }
+    { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::mul_ladder_pair_y(st, sc, n, penc, state, skip_bits, ladder_lanes(g, n))); }
     HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
     { ProfScope ps(g, st, KID_LADDER_RECOVER); LAUNCHCK(launch::ladder_recover(st, sc, n, tmp, state, r->proj, r->proj_items)); }
     return KYB_OK;
@@ -1698,7 +1700,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
       { ProfScope ps(g, side, KID_VERIFY_PREP_R); LAUNCHCK(launch::sig_scalars(side, sigs, n, sbuf)); }
       rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side); if (rc) return rc;
       HIPCK(hipEventRecord(r->ev_join, side));
-      { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::verify_ladder_y(st, pubs, sigs, msgs, off, n, flags_a, flags_r, a_ok, hbuf, state, a_ext, r->proj, r->proj_items)); }
+      { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::verify_ladder_y(st, pubs, sigs, msgs, off, n, flags_a, flags_r, a_ok, hbuf, state, a_ext, r->proj, r->proj_items, ladder_lanes(g, n))); }
       HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
       ProfScope ps(g, st, KID_VERIFY_FINAL);
       LAUNCHCK(launch::verify_recover_final(st, hbuf, n, a_ext, state, r->proj, r->proj_items, flags_a, a_ok, flags_r, flavor, status, take_done_flag(g, st, n)));
@@ -1711,7 +1713,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     HIPCK(hipStreamWaitEvent(side, r->ev_fork, 0));
     rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side); if (rc) return rc;
     HIPCK(hipEventRecord(r->ev_join, side));
-    { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::mul_ladder_pair_y(st, hbuf, n, pubs, state, 3)); }      // h < L < 2^253
+    { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::mul_ladder_pair_y(st, hbuf, n, pubs, state, 3, ladder_lanes(g, n))); }      // h < L < 2^253
     HIPCK(hipStreamWaitEvent(st, r->ev_mid, 0));
     { ProfScope ps(g, st, KID_LADDER_RECOVER); LAUNCHCK(launch::ladder_recover(st, hbuf, n, a_ext, state, r->proj, r->proj_items, flags_a, flags_r)); }
     HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
@@ -1744,7 +1746,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     LAUNCHCK(launch::mul_coop(st, hbuf, a_ext, n, nullptr, nullptr, 3, r->proj, r->proj_items, 0));      // h < L < 2^253
   } else if (r_role) {
     ProfScope ps(g, st, KID_MUL_LADDER_PAIR);
-    LAUNCHCK(launch::mul_ladder_pair_r(st, hbuf, n, a_ext, r->proj, r->proj_items, 3, sigs, flags_r, 2 * n));      // h < L < 2^253
+    LAUNCHCK(launch::mul_ladder_pair_r(st, hbuf, n, a_ext, r->proj, r->proj_items, 3, sigs, flags_r, 2 * n, ladder_lanes(g, n)));      // h < L < 2^253
   }
 #ifdef KYB_CROSSCHECK
   else if (g.opt_mul_algo != 1) {

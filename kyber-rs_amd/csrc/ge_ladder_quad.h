@@ -92,4 +92,30 @@ __device__ __forceinline__ void ge_scalarmult_ladder_quad(ge_p2& out, const uint
   mont_recover_to_edwards_proj(out, m, x2, z2, x3, z3, mag[0] & 1u, neg);
 }
 
+// ... and from the WIRE encoding (ge_ladder_pair.h, "from the WIRE encoding"): the ladder on (1 + y : 1 - y); all four lanes return the x-only state
+__device__ __forceinline__ void mont_ladder_quad_from_y(fe& x2, fe& z2, fe& x3, fe& z3, const uint32_t a[8], const uint32_t enc_words[8], int skip, uint32_t q) {
+  uint32_t neg, mag[8];
+  sc_effective(neg, mag, a);
+  fe y, one, U1, W1, st;
+  fe_from_words(y, enc_words);            // bit 255 ignored, y >= p accepted (fe_from_bytes)
+  fe_one(one);
+  fe_add(U1, one, y);                     // 1 + y
+  fe_sub(W1, one, y);                     // 1 - y  (3T)
+  fe_reduce_weak(U1, U1);
+  fe_reduce_weak(W1, W1);                 // tight: operands of the ladder's last product and its first additions
+  mont_ladder_quad(st, U1, W1, mag, skip, q);
+  fe_quad<KYB_QP_L0>(x3, st); fe_quad<KYB_QP_L1>(z3, st);
+  fe_quad<KYB_QP_L2>(x2, st); fe_quad<KYB_QP_L3>(z2, st);
+}
+
+// LG = 1: two lanes per item, LG = 2: four — one spelling for the kernels that exist in both forms (sub = the lane's number within its item)
+template <int LG>
+__device__ __forceinline__ void ge_scalarmult_ladder_lanes(ge_p2& out, const uint32_t a[8], const ge_p3& P, int skip, uint32_t sub) {
+  if constexpr (LG == 1) ge_scalarmult_ladder_pair(out, a, P, skip, sub); else ge_scalarmult_ladder_quad(out, a, P, skip, sub);
+}
+template <int LG>
+__device__ __forceinline__ void mont_ladder_lanes_from_y(fe& x2, fe& z2, fe& x3, fe& z3, const uint32_t a[8], const uint32_t enc_words[8], int skip, uint32_t sub) {
+  if constexpr (LG == 1) mont_ladder_pair_from_y(x2, z2, x3, z3, a, enc_words, skip, sub); else mont_ladder_quad_from_y(x2, z2, x3, z3, a, enc_words, skip, sub);
+}
+
 }  // namespace kyb

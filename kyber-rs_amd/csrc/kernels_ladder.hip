@@ -175,22 +175,23 @@ k_mul_ladder_quad(const uint8_t* __restrict__ scalars, size_t n, const int32_t* 
 // The same launch with the R half of a verification as further workgroups (keys given as POINTS: nothing to decode on the A side, but R's square
 // root would otherwise be paid at the end, inside the encode-and-compare tail): workgroups [0, ladder_blocks) are k_mul_ladder_pair, the ones behind
 // them k_verify_prep_r — checks and decode of R into record r_offset + i — on CUs of their own (ladder.y_only = 2).
+template <int LG>      // (two or four lanes per item: ge_ladder_quad.h)
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
 k_mul_ladder_pair_r(const uint8_t* __restrict__ scalars, size_t n, const int32_t* __restrict__ pts_ext, uint4* __restrict__ proj, size_t stride, int skip_bits,
                     unsigned ladder_blocks, const uint8_t* __restrict__ sigs, uint8_t* __restrict__ flags_r, size_t r_offset) {
   if (blockIdx.x < ladder_blocks) {
     __builtin_amdgcn_s_setprio(3);         // s*B shares these CUs from the side stream; the ladder is the critical path
     const size_t lane = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
-    const size_t i = lane >> 1;
-    const uint32_t odd = threadIdx.x & 1u;
+    const size_t i = lane >> LG;
+    const uint32_t sub = threadIdx.x & ((1u << LG) - 1u);
     if (i >= n) return;
     uint32_t a[8];
     load_words8(a, scalars, i);
     ge_p3 P;
     load_ext(P, pts_ext, i);
     ge_p2 r;
-    ge_scalarmult_ladder_pair(r, a, P, skip_bits, odd);
-    if (odd == 0u) store_proj(proj, stride, i, r.X, r.Y, r.Z);
+    ge_scalarmult_ladder_lanes<LG>(r, a, P, skip_bits, sub);
+    if (sub == 0u) store_proj(proj, stride, i, r.X, r.Y, r.Z);
     return;
   }
   const size_t i = (size_t)(blockIdx.x - ladder_blocks) * KYB_BLOCK + threadIdx.x;
@@ -221,40 +222,42 @@ __device__ __forceinline__ void load_state(fe& a, fe& b, fe& c, fe& d, const uin
 #pragma unroll
   for (int k = 0; k < 10; ++k) { a.v[k] = f[k]; b.v[k] = f[10 + k]; c.v[k] = f[20 + k]; d.v[k] = f[30 + k]; }
 }
+template <int LG>
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
 k_mul_ladder_pair_y(const uint8_t* __restrict__ scalars, size_t n, const uint8_t* __restrict__ pts_enc, uint4* __restrict__ state, int skip_bits) {
   // the decode kernel runs beside this one and its workgroups land on the same CUs (both grids start at CU 0): the ladder is the critical path, so its
   // wavefronts win the issue arbitration and the decode takes the slots a lone ladder wavefront leaves empty anyway (profiles/r04/mid_size_kernels.log)
   __builtin_amdgcn_s_setprio(3);
   const size_t lane = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
-  const size_t i = lane >> 1;
-  const uint32_t odd = threadIdx.x & 1u;
+  const size_t i = lane >> LG;
+  const uint32_t sub = threadIdx.x & ((1u << LG) - 1u);
   if (i >= n) return;
   uint32_t a[8], w[8];
   load_words8(a, scalars, i);
   load_words8(w, pts_enc, i);
   fe x2, z2, x3, z3;
-  mont_ladder_pair_from_y(x2, z2, x3, z3, a, w, skip_bits, odd);
-  if (odd == 0u) store_state(state, i, x2, z2, x3, z3);
+  mont_ladder_lanes_from_y<LG>(x2, z2, x3, z3, a, w, skip_bits, sub);
+  if (sub == 0u) store_state(state, i, x2, z2, x3, z3);
 }
 // The two kernels above and k_decode_or_identity as ONE launch (ladder.y_only = 2): workgroups [0, ladder_blocks) walk the ladder, two lanes per item;
 // the workgroups behind them decode the same encodings, one lane per item.  Workgroups of one launch are dealt out to the CUs in order, so the decoding
 // ones land on CUs of their own instead of on the SIMDs the ladder occupies — which is where a second kernel on a side stream puts them (both grids start
 // at the same CU; profiles/r04/side_cu_mask_probe.log) — and no stream has to be forked and joined.  The role depends on blockIdx only.
+template <int LG>
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
 k_mul_ladder_pair_y_dec(const uint8_t* __restrict__ scalars, size_t n, const uint8_t* __restrict__ pts_enc, uint4* __restrict__ state, int skip_bits,
                         unsigned ladder_blocks, int32_t* __restrict__ out_ext, uint8_t* __restrict__ ok_out) {
   if (blockIdx.x < ladder_blocks) {
     const size_t lane = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
-    const size_t i = lane >> 1;
-    const uint32_t odd = threadIdx.x & 1u;
+    const size_t i = lane >> LG;
+    const uint32_t sub = threadIdx.x & ((1u << LG) - 1u);
     if (i >= n) return;
     uint32_t a[8], w[8];
     load_words8(a, scalars, i);
     load_words8(w, pts_enc, i);
     fe x2, z2, x3, z3;
-    mont_ladder_pair_from_y(x2, z2, x3, z3, a, w, skip_bits, odd);
-    if (odd == 0u) store_state(state, i, x2, z2, x3, z3);
+    mont_ladder_lanes_from_y<LG>(x2, z2, x3, z3, a, w, skip_bits, sub);
+    if (sub == 0u) store_state(state, i, x2, z2, x3, z3);
     return;
   }
   const size_t i = (size_t)(blockIdx.x - ladder_blocks) * KYB_BLOCK + threadIdx.x;
@@ -295,6 +298,7 @@ k_ladder_recover(const uint8_t* __restrict__ scalars, size_t n, const int32_t* _
 // The decoding workgroups are dealt to CUs the ladder does not occupy (up to 128 items per CU in total), so neither square root is on the critical
 // path and R arrives decoded: the equation is checked projectively by k_verify_recover_final, without the field inversion k_verify_final_enc
 // pays to compare encodings.  s*B runs beside this launch on the side stream (k_sig_scalars gathers its scalars first).
+template <int LG>
 __global__ void __launch_bounds__(KYB_BLOCK, 2)
 k_verify_ladder_y(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ msgs, const uint32_t* __restrict__ msg_off, size_t n,
                   uint8_t* __restrict__ flags_a, uint8_t* __restrict__ flags_r, uint8_t* __restrict__ a_ok, uint8_t* __restrict__ hbuf, uint4* __restrict__ state,
@@ -302,8 +306,8 @@ k_verify_ladder_y(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ 
   if (blockIdx.x < ladder_blocks) {
     __builtin_amdgcn_s_setprio(3);         // s*B shares these CUs from the side stream; the ladder is the critical path
     const size_t lane = (size_t)blockIdx.x * KYB_BLOCK + threadIdx.x;
-    const size_t i = lane >> 1;
-    const uint32_t odd = threadIdx.x & 1u;
+    const size_t i = lane >> LG;
+    const uint32_t sub = threadIdx.x & ((1u << LG) - 1u);
     if (i >= n) return;
     uint32_t pub[8], ra[16], h[8];
     load_words8(pub, pubs, i);
@@ -321,10 +325,10 @@ k_verify_ladder_y(const uint8_t* __restrict__ pubs, const uint8_t* __restrict__ 
     uint32_t dig[16];
     sha512_final(dig, c);
     sc_reduce512(h, dig);
-    if (odd == 0u) { flags_a[i] = (uint8_t)fl; store_words8(hbuf, i, h); }
+    if (sub == 0u) { flags_a[i] = (uint8_t)fl; store_words8(hbuf, i, h); }
     fe x2, z2, x3, z3;
-    mont_ladder_pair_from_y(x2, z2, x3, z3, h, pub, 3, odd);      // h < L < 2^253
-    if (odd == 0u) store_state(state, i, x2, z2, x3, z3);
+    mont_ladder_lanes_from_y<LG>(x2, z2, x3, z3, h, pub, 3, sub);      // h < L < 2^253
+    if (sub == 0u) store_state(state, i, x2, z2, x3, z3);
     return;
   }
   const unsigned b = blockIdx.x - ladder_blocks;
@@ -445,18 +449,22 @@ hipError_t mul_ladder_quad(hipStream_t st, const uint8_t* sc, size_t n, const in
   hipLaunchKernelGGL(k_mul_ladder_quad, dim3(blocks_for(4 * n)), dim3(KYB_BLOCK), 0, st, sc, n, pext, pts_mod, proj, stride, skip_bits);
   return hipGetLastError();
 }
-hipError_t mul_ladder_pair_r(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, uint4* proj, size_t stride, int skip_bits, const uint8_t* sigs, uint8_t* flags_r, size_t r_offset) {
-  const unsigned lb = blocks_for(2 * n);
-  hipLaunchKernelGGL(k_mul_ladder_pair_r, dim3(lb + blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, pext, proj, stride, skip_bits, lb, sigs, flags_r, r_offset);
+hipError_t mul_ladder_pair_r(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, uint4* proj, size_t stride, int skip_bits, const uint8_t* sigs, uint8_t* flags_r, size_t r_offset,
+                             int lanes) {
+  const unsigned lb = blocks_for((size_t)lanes * n);
+  if (lanes == 4) hipLaunchKernelGGL(k_mul_ladder_pair_r<2>, dim3(lb + blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, pext, proj, stride, skip_bits, lb, sigs, flags_r, r_offset);
+  else hipLaunchKernelGGL(k_mul_ladder_pair_r<1>, dim3(lb + blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, pext, proj, stride, skip_bits, lb, sigs, flags_r, r_offset);
   return hipGetLastError();
 }
-hipError_t mul_ladder_pair_y(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits) {
-  hipLaunchKernelGGL(k_mul_ladder_pair_y, dim3(blocks_for(2 * n)), dim3(KYB_BLOCK), 0, st, sc, n, penc, state, skip_bits);
+hipError_t mul_ladder_pair_y(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits, int lanes) {
+  if (lanes == 4) hipLaunchKernelGGL(k_mul_ladder_pair_y<2>, dim3(blocks_for(4 * n)), dim3(KYB_BLOCK), 0, st, sc, n, penc, state, skip_bits);
+  else hipLaunchKernelGGL(k_mul_ladder_pair_y<1>, dim3(blocks_for(2 * n)), dim3(KYB_BLOCK), 0, st, sc, n, penc, state, skip_bits);
   return hipGetLastError();
 }
-hipError_t mul_ladder_pair_y_dec(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits, int32_t* out_ext, uint8_t* ok) {
-  const unsigned lb = blocks_for(2 * n);
-  hipLaunchKernelGGL(k_mul_ladder_pair_y_dec, dim3(lb + blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, penc, state, skip_bits, lb, out_ext, ok);
+hipError_t mul_ladder_pair_y_dec(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits, int32_t* out_ext, uint8_t* ok, int lanes) {
+  const unsigned lb = blocks_for((size_t)lanes * n);
+  if (lanes == 4) hipLaunchKernelGGL(k_mul_ladder_pair_y_dec<2>, dim3(lb + blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, penc, state, skip_bits, lb, out_ext, ok);
+  else hipLaunchKernelGGL(k_mul_ladder_pair_y_dec<1>, dim3(lb + blocks_for(n)), dim3(KYB_BLOCK), 0, st, sc, n, penc, state, skip_bits, lb, out_ext, ok);
   return hipGetLastError();
 }
 hipError_t ladder_recover(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, const uint4* state, uint4* proj, size_t stride, uint8_t* flags, const uint8_t* dec_ok) {
@@ -464,9 +472,10 @@ hipError_t ladder_recover(hipStream_t st, const uint8_t* sc, size_t n, const int
   return hipGetLastError();
 }
 hipError_t verify_ladder_y(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* flags_a, uint8_t* flags_r,
-                           uint8_t* a_ok, uint8_t* hbuf, uint4* state, int32_t* a_ext, uint4* proj, size_t stride) {
-  const unsigned lb = blocks_for(2 * n), ib = blocks_for(n);
-  hipLaunchKernelGGL(k_verify_ladder_y, dim3(lb + 2 * ib), dim3(KYB_BLOCK), 0, st, pubs, sigs, msgs, off, n, flags_a, flags_r, a_ok, hbuf, state, a_ext, proj, stride, lb, ib);
+                           uint8_t* a_ok, uint8_t* hbuf, uint4* state, int32_t* a_ext, uint4* proj, size_t stride, int lanes) {
+  const unsigned lb = blocks_for((size_t)lanes * n), ib = blocks_for(n);
+  if (lanes == 4) hipLaunchKernelGGL(k_verify_ladder_y<2>, dim3(lb + 2 * ib), dim3(KYB_BLOCK), 0, st, pubs, sigs, msgs, off, n, flags_a, flags_r, a_ok, hbuf, state, a_ext, proj, stride, lb, ib);
+  else hipLaunchKernelGGL(k_verify_ladder_y<1>, dim3(lb + 2 * ib), dim3(KYB_BLOCK), 0, st, pubs, sigs, msgs, off, n, flags_a, flags_r, a_ok, hbuf, state, a_ext, proj, stride, lb, ib);
   return hipGetLastError();
 }
 hipError_t sig_scalars(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* sbuf) {

@@ -70,17 +70,18 @@ hipError_t mul_ladder_quad(hipStream_t st, const uint8_t* sc, size_t n, const in
 // the same from wire encodings: the ladder on (1 + y : 1 - y) leaves its x-only state (160 bytes per item) while the decode runs elsewhere;
 // ladder_recover turns state + decoded point into the projective result (ge_ladder_pair.h)
 // k_mul_ladder_pair with the R half of a verification (k_verify_prep_r: flags_r, record r_offset + i) as further workgroups of the launch
-hipError_t mul_ladder_pair_r(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, uint4* proj, size_t stride, int skip_bits, const uint8_t* sigs, uint8_t* flags_r, size_t r_offset);
-hipError_t mul_ladder_pair_y(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits);
+hipError_t mul_ladder_pair_r(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, uint4* proj, size_t stride, int skip_bits, const uint8_t* sigs, uint8_t* flags_r, size_t r_offset,
+                             int lanes = 2);      // lanes: 2, or 4 lanes per item (ge_ladder_quad.h)
+hipError_t mul_ladder_pair_y(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits, int lanes = 2);
 // ladder and decode as one launch: the first workgroups walk the ladder, the ones behind them decode (out_ext / ok as decode_or_identity)
-hipError_t mul_ladder_pair_y_dec(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits, int32_t* out_ext, uint8_t* ok);
+hipError_t mul_ladder_pair_y_dec(hipStream_t st, const uint8_t* sc, size_t n, const uint8_t* penc, uint4* state, int skip_bits, int32_t* out_ext, uint8_t* ok, int lanes = 2);
 hipError_t ladder_recover(hipStream_t st, const uint8_t* sc, size_t n, const int32_t* pext, const uint4* state, uint4* proj, size_t stride,
                           uint8_t* flags = nullptr, const uint8_t* dec_ok = nullptr);       // flags != nullptr: flags[i] |= dec_ok[i] << 2 (verification)
 // verification, the A half without the decode: flags (bits 0, 1, 3), h, s from the bytes alone (kernels_verify.hip)
 hipError_t verify_hash(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* flags_a, uint8_t* hbuf, uint8_t* sbuf);
 // ladder.y_only = 2, verification (kernels_ladder.hip): hash + ladder on A's y, decode of A, decode of R as workgroup roles of one launch; the join checks the equation
 hipError_t verify_ladder_y(hipStream_t st, const uint8_t* pubs, const uint8_t* sigs, const uint8_t* msgs, const uint32_t* off, size_t n, uint8_t* flags_a, uint8_t* flags_r,
-                           uint8_t* a_ok, uint8_t* hbuf, uint4* state, int32_t* a_ext, uint4* proj, size_t stride);
+                           uint8_t* a_ok, uint8_t* hbuf, uint4* state, int32_t* a_ext, uint4* proj, size_t stride, int lanes = 2);
 hipError_t sig_scalars(hipStream_t st, const uint8_t* sigs, size_t n, uint8_t* sbuf);
 hipError_t pair_sum(hipStream_t st, uint4* proj, size_t stride, size_t m, size_t gstride, size_t len, size_t half);
 hipError_t ext_to_proj(hipStream_t st, const int32_t* pext, size_t n, uint4* proj, size_t stride, size_t rows = 0, size_t cols = 0);      // rows != 0: transposed, as decode_to_proj

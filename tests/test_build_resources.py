@@ -46,10 +46,12 @@ DEFAULT_PATH = [
     ("_Z12k_mul_ladderILi3E", 168),                       # variable base, mul.ladder_waves = 3 (default)
     ("_Z12k_mul_ladderILi2E", 256),
     ("_Z17k_mul_ladder_pair", 256),                       # two lanes per item, batches of at most one wavefront per SIMD
-    ("_Z19k_mul_ladder_pair_y", 256), ("_Z16k_ladder_recover", 256),      # the same from wire encodings: ladder on y, recovery after the decode
-    ("_Z23k_mul_ladder_pair_y_dec", 256),                 # ... with the decode as further workgroups of the same launch (ladder.y_only = 2)
-    ("_Z19k_mul_ladder_pair_r", 256),                      # ... or decode R beside a ladder from points (verification with the keys given as points)
-    ("_Z17k_verify_ladder_y", 256), ("_Z22k_verify_recover_final", 256), ("_Z13k_sig_scalars", 512),      # a DKG-sized verification in two launches
+    ("_Z17k_mul_ladder_quad", 256),                       # four lanes per item (ge_ladder_quad.h), the same bound
+    ("_Z19k_mul_ladder_pair_yILi1EE", 256), ("_Z19k_mul_ladder_pair_yILi2EE", 256), ("_Z16k_ladder_recover", 256),      # the same from wire encodings (two | four lanes per item): ladder on y, recovery after the decode
+    ("_Z23k_mul_ladder_pair_y_decILi1EE", 256), ("_Z23k_mul_ladder_pair_y_decILi2EE", 256),      # ... with the decode as further workgroups of the same launch (ladder.y_only = 2)
+    ("_Z19k_mul_ladder_pair_rILi1EE", 256), ("_Z19k_mul_ladder_pair_rILi2EE", 256),      # ... or decode R beside a ladder from points (verification with the keys given as points)
+    ("_Z17k_verify_ladder_yILi1EE", 256), ("_Z17k_verify_ladder_yILi2EE", 256), ("_Z22k_verify_recover_final", 256), ("_Z13k_sig_scalars", 512),      # a DKG-sized verification in two launches
+    ("_Z13k_finish_wavePK", 512), ("_Z21k_mul_base64_quarters", 512),      # the two mid-size kernels of round 6 (one wavefront per SIMD)
     ("_Z12k_mul_base64ILb1ELi1024E", 128),                # fixed base, full batches: 4 waves/SIMD, the table owns the LDS
     ("_Z12k_mul_base64ILb1ELi256E", 512),                 # fixed base, batches that do not fill the chip: 1 wave/SIMD
     ("_Z11k_mont_prepPKim", 256), ("_Z8k_finishPK", 256), ("_Z9k_finish4PK", 256), ("_Z16k_encode_batchedPKimPh", 256), ("_Z17k_encode_batched4PKimPh", 256),

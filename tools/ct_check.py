@@ -43,8 +43,10 @@ SECRET_ARGS = {
     "_Z12k_mul_ladderILi2E": ("kernels_ladder", {0: "scalars"}),
     "_Z17k_mul_ladder_pair": ("kernels_ladder", {0: "scalars"}),
     "_Z17k_mul_ladder_quad": ("kernels_ladder", {0: "scalars"}),
-    "_Z19k_mul_ladder_pair_y": ("kernels_ladder", {0: "scalars"}),
-    "_Z23k_mul_ladder_pair_y_dec": ("kernels_ladder", {0: "scalars"}),      # the role of a workgroup depends on blockIdx only
+    "_Z19k_mul_ladder_pair_yILi1EE": ("kernels_ladder", {0: "scalars"}),
+    "_Z19k_mul_ladder_pair_yILi2EE": ("kernels_ladder", {0: "scalars"}),      # (four lanes per item)
+    "_Z23k_mul_ladder_pair_y_decILi1EE": ("kernels_ladder", {0: "scalars"}),      # the role of a workgroup depends on blockIdx only
+    "_Z23k_mul_ladder_pair_y_decILi2EE": ("kernels_ladder", {0: "scalars"}),
     "_Z16k_ladder_recover": ("kernels_ladder", {0: "scalars", 24: "x-only state the ladder left (a function of the scalar)"}),
     "_Z11k_mont_prepPKim": ("kernels_ladder", {32: "scalars (top bits, canonical test)"}),
     "_Z12k_mul_base64ILb1ELi1024E": ("kernels_base", {0: "scalars", 8: "scalars_b"}),
