@@ -1389,8 +1389,10 @@ int launch_mul(Ctx& g, const uint8_t* sc, const uint8_t* penc, const int32_t* pe
 // fixed-base multiplication of n scalars; split leaves the points in r->proj at [offset, offset + n)
 // sc_b != nullptr: a second array of n_b scalars follows the first in the same launch (radix-64 kernel), their
 // results land behind the first n
+// parts_at: where the mid-size form (base_quarters) may put its 3 n partial points; NO_PARTS: behind the results when offset == 0, else that form is not used
+constexpr size_t NO_PARTS = ~(size_t)0;
 int launch_base(Ctx& g, bool split, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, StreamRes* r, size_t offset, hipStream_t st,
-                const uint8_t* sc_b = nullptr, size_t n_b = 0) {
+                const uint8_t* sc_b = nullptr, size_t n_b = 0, size_t parts_at = NO_PARTS) {
   const int radix = g.opt_base_radix, finish_min = g.opt_finish_min;
   if (sc_b != nullptr && !(radix == 64 && n + n_b >= (size_t)finish_min)) {
     int rc = launch_base(g, split, sc, n, oenc, oext, r, offset, st); if (rc) return rc;
@@ -1407,9 +1409,10 @@ int launch_base(Ctx& g, bool split, const uint8_t* sc, size_t n, uint8_t* oenc, 
     const size_t nchunks64 = (n + block - 1) / block;                   // workgroups' worth of items (the kernel deals them out per wavefront)
     const int grid64 = (int)(nchunks64 < (size_t)g.cus ? nchunks64 : (size_t)g.cus);
     ProfScope ps(g, st, KID_MUL_BASE);
-    if (split && offset == 0 && base_quarters(g, n) && r->proj_items >= 4 * n) {      // (the callers that want this form ask ensure_proj for 4 n records)
+    const size_t parts = parts_at != NO_PARTS ? parts_at : n;
+    if (split && (offset == 0 || parts_at != NO_PARTS) && base_quarters(g, n) && r->proj_items >= parts + 3 * n) {      // (the callers that want this form ask ensure_proj for the room)
       const size_t groups = (n + 63) / 64;
-      LAUNCHCK(launch::mul_base64_quarters((int)(groups < (size_t)g.cus ? groups : (size_t)g.cus), st, sc, sc_b, n_a, n, img64, r->proj, r->proj_items, offset));
+      LAUNCHCK(launch::mul_base64_quarters((int)(groups < (size_t)g.cus ? groups : (size_t)g.cus), st, sc, sc_b, n_a, n, img64, r->proj, r->proj_items, offset, parts));
       return KYB_OK;
     }
     LAUNCHCK(launch::mul_base64(split, block, grid64, st, sc, sc_b, n_a, n, oenc, oext, img64, r->proj, r->proj_items, offset));
@@ -1647,7 +1650,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     LAUNCHCK(launch::verify_coop(st, pubs, sigs, msgs, off, n, flavor, coop_table(g), status, take_done_flag(g, st, n)));
     return KYB_OK;
   }
-  int rc = ensure_proj(g, r, 3 * n); if (rc) return rc;
+  int rc = ensure_proj(g, r, base_quarters(g, n) ? 6 * n : 3 * n); if (rc) return rc;      // (h A | s B | R, and room for the partial points of s B's mid-size form)
   const size_t o_h = 0, o_s = up256(32 * n), o_a = o_s + up256(32 * n), o_fa = o_a + up256(160 * n), o_fr = o_fa + up256(n), o_ok = o_fr + up256(n);
   rc = ensure_enc(g, r, o_ok + up256(n)); if (rc) return rc;
   uint8_t* hbuf = r->enc + o_h; uint8_t* sbuf = r->enc + o_s; int32_t* a_ext = reinterpret_cast<int32_t*>(r->enc + o_a);
@@ -1698,7 +1701,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
       // k_verify_ladder_y); the side stream gathers s and multiplies s*B beside the first one.  R arrives decoded, so no inversion at the end.
       uint8_t* a_ok = r->enc + o_ok;
       { ProfScope ps(g, side, KID_VERIFY_PREP_R); LAUNCHCK(launch::sig_scalars(side, sigs, n, sbuf)); }
-      rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side); if (rc) return rc;
+      rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side, nullptr, 0, 3 * n); if (rc) return rc;
       HIPCK(hipEventRecord(r->ev_join, side));
       { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::verify_ladder_y(st, pubs, sigs, msgs, off, n, flags_a, flags_r, a_ok, hbuf, state, a_ext, r->proj, r->proj_items, ladder_lanes(g, n))); }
       HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
@@ -1711,7 +1714,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     { ProfScope ps(g, st, KID_VERIFY_PREP); LAUNCHCK(launch::verify_hash(st, pubs, sigs, msgs, off, n, flags_a, hbuf, sbuf)); }
     HIPCK(hipEventRecord(r->ev_fork, st));                 // s*B reads sbuf
     HIPCK(hipStreamWaitEvent(side, r->ev_fork, 0));
-    rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side); if (rc) return rc;
+    rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side, nullptr, 0, 3 * n); if (rc) return rc;
     HIPCK(hipEventRecord(r->ev_join, side));
     { ProfScope ps(g, st, KID_MUL_LADDER_PAIR); LAUNCHCK(launch::mul_ladder_pair_y(st, hbuf, n, pubs, state, 3, ladder_lanes(g, n))); }      // h < L < 2^253
     HIPCK(hipStreamWaitEvent(st, r->ev_mid, 0));
@@ -1738,7 +1741,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
     HIPCK(hipEventRecord(r->ev_fork, st));                 // s*B reads sbuf, which the A-half kernel has just been asked to write
     HIPCK(hipStreamWaitEvent(side, r->ev_fork, 0));
     if (coop) { ProfScope ps(g, side, KID_MUL_BASE_COOP); LAUNCHCK(launch::mul_base_coop(side, sbuf, n, nullptr, nullptr, coop_table(g), r->proj, r->proj_items, n)); }
-    else { rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side); if (rc) return rc; }
+    else { rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, side, nullptr, 0, 3 * n); if (rc) return rc; }
     HIPCK(hipEventRecord(r->ev_join, side));
   }
   if (coop) {
@@ -1762,7 +1765,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   }
   if (fork) HIPCK(hipStreamWaitEvent(st, r->ev_join, 0));
   else if (coop) { ProfScope ps(g, st, KID_MUL_BASE_COOP); LAUNCHCK(launch::mul_base_coop(st, sbuf, n, nullptr, nullptr, coop_table(g), r->proj, r->proj_items, n)); }
-  else { rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, st); if (rc) return rc; }
+  else { rc = launch_base(g, true, sbuf, n, nullptr, nullptr, r, n, st, nullptr, 0, 3 * n); if (rc) return rc; }
   {
     ProfScope ps(g, st, KID_VERIFY_FINAL);
     if (by_enc) LAUNCHCK(launch::verify_tail_enc(st, r->proj, r->proj_items, n, sigs, flags_a, flavor, status, take_done_flag(g, st, n), finish_four(g, n)));

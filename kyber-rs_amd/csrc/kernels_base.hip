@@ -100,7 +100,7 @@ __device__ __forceinline__ void add_staged_part(ge_p3& h, const uint4* proj, siz
 }
 __global__ void __launch_bounds__(256, 1)
 k_mul_base64_quarters(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ scalars_b, size_t n_a, size_t n,
-                      const uint4* __restrict__ table_image, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset) {
+                      const uint4* __restrict__ table_image, uint4* __restrict__ proj, size_t proj_stride, size_t proj_offset, size_t parts_offset) {
   __shared__ uint4 lds_tbl[KYB_BASE64_TABLE_WORDS / 4];
   for (int k = threadIdx.x; k < KYB_BASE64_TABLE_WORDS / 4; k += 256) lds_tbl[k] = table_image[k];
   __syncthreads();
@@ -120,16 +120,16 @@ k_mul_base64_quarters(const uint8_t* __restrict__ scalars, const uint8_t* __rest
     else load_words8(a, scalars_b, (size_t)(i0 + t - n_a));
     ge_p3 h;
     ge_scalarmult_base64_part(h, a, tbl, 11 * part, part == 3 ? KYB_BASE64_POS : 11 * part + 11);
-    const size_t rec = proj_offset + i0 + t;
-    if (part >= 2 && live) store_proj(proj, proj_stride, rec + (size_t)part * n, h.X, h.Y, h.Z);
+    const size_t rec = proj_offset + i0 + t, prec = parts_offset + i0 + t;      // part q = 1, 2, 3 of the item: record prec + (q - 1) n
+    if (part >= 2 && live) store_proj(proj, proj_stride, prec + (size_t)(part - 1) * n, h.X, h.Y, h.Z);
     __threadfence_block();
     __syncthreads();
-    if (part < 2) add_staged_part(h, proj, proj_stride, rec + (size_t)(part + 2) * n);      // 0 + 2 | 1 + 3
-    if (part == 1 && live) store_proj(proj, proj_stride, rec + n, h.X, h.Y, h.Z);
+    if (part < 2) add_staged_part(h, proj, proj_stride, prec + (size_t)(part + 1) * n);      // 0 + 2 | 1 + 3
+    if (part == 1 && live) store_proj(proj, proj_stride, prec, h.X, h.Y, h.Z);
     __threadfence_block();
     __syncthreads();
     if (part == 0) {
-      add_staged_part(h, proj, proj_stride, rec + n);
+      add_staged_part(h, proj, proj_stride, prec);
       if (live) store_proj(proj, proj_stride, rec, h.X, h.Y, h.Z);
     }
   }
@@ -195,8 +195,8 @@ hipError_t mul_base64(bool split, int block, int grid, hipStream_t st, const uin
   return hipGetLastError();
 }
 hipError_t mul_base64_quarters(int grid, hipStream_t st, const uint8_t* sc, const uint8_t* sc_b, size_t n_a, size_t n, const uint4* img64, uint4* proj, size_t stride,
-                               size_t offset) {
-  hipLaunchKernelGGL(k_mul_base64_quarters, dim3(grid), dim3(256), 0, st, sc, sc_b, n_a, n, img64, proj, stride, offset);
+                               size_t offset, size_t parts_offset) {
+  hipLaunchKernelGGL(k_mul_base64_quarters, dim3(grid), dim3(256), 0, st, sc, sc_b, n_a, n, img64, proj, stride, offset, parts_offset);
   return hipGetLastError();
 }
 hipError_t diag_stamps_base(uint64_t* buf) { return kyb_set_stamp_slot(buf); }

@@ -45,9 +45,10 @@ hipError_t table_checksum(const uint32_t* table, uint64_t* out_dev, hipStream_t 
 hipError_t build_coop_table(const uint32_t* image64, uint32_t* table_coop, hipStream_t st);      // entry-major copy of the radix-64 table for kernels_coop.hip
 hipError_t mul_base64(bool split, int block, int grid, hipStream_t st, const uint8_t* sc, const uint8_t* sc_b, size_t n_a, size_t n,
                       uint8_t* oenc, int32_t* oext, const uint4* img64, uint4* proj, size_t stride, size_t offset);
-// mid-size batches: four wavefronts per 64 items, a quarter of the windows each; needs 4 n staging records from `offset` on, the sums land in [offset, offset + n)
+// mid-size batches: four wavefronts per 64 items, a quarter of the windows each; the sums land in records [offset, offset + n), three partial points per item pass
+// through records [parts_offset, parts_offset + 3 n)
 hipError_t mul_base64_quarters(int grid, hipStream_t st, const uint8_t* sc, const uint8_t* sc_b, size_t n_a, size_t n, const uint4* img64, uint4* proj, size_t stride,
-                               size_t offset);
+                               size_t offset, size_t parts_offset);
 hipError_t mul_base32(bool split, int grid, hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext, const uint4* img32,
                       uint4* proj, size_t stride, size_t offset);
 hipError_t mul_base16(int mode, int block, bool split, int grid, hipStream_t st, const uint8_t* sc, size_t n, uint8_t* oenc, int32_t* oext,
