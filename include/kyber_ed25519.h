@@ -509,8 +509,8 @@ int kyb_point_checks_batch_dev(const uint8_t* enc, const int32_t* pts_ext, size_
  *                     verification with the keys given as points at 7/8 of it) even when coop.max_items would still allow them: from there the
  *                     two-lane ladder is faster (a plain multiplication of points by full-size scalars already leaves at 9 per compute unit = 2304 while
  *                     ladder.quad_max_items is set: its four-lane ladder is).
- *   coop.ladder_enc_max_items  the same for calls from BYTES — kyb_mul_batch with pts_enc (full-length multipliers), kyb_verify_batch: default 8 per compute unit = 2048
- *                     (two wavefronts per SIMD); above it the role-split launches of ladder.y_only = 2 are faster.
+ *   coop.ladder_enc_max_items  the same for calls from BYTES — kyb_mul_batch with pts_enc (full-length multipliers), kyb_verify_batch (at 5/6 of it): default 6 per compute unit = 1536;
+ *                     above it the role-split launches of ladder.y_only = 2 are faster.
  *   ladder.skip_canonical  1 (default): the batch ladder starts four bits lower when no scalar of the launch reaches 2^252 — true of a scalar
  *                     reduced mod L (L = 2^252 + 2.8e37) except for 2^-127 of them, so the test (an OR over the batch, taken on the way by the
  *                     kernel that prepares the points) says nothing about a canonical secret; one unreduced scalar anywhere and the launch

@@ -267,14 +267,14 @@ void wipe_free_dev(Ctx& g, void* p, size_t bytes) {
 // kyb_set_option of one of the thresholds still sets an absolute item count.
 // (round 6: the one-item-per-wavefront point operations move rows with permlane swaps instead of ds_bpermute and end in a cheaper inversion — they
 //  stay ahead of the batch kernels for longer: fixed base 13 -> 18, variable base 11 -> 14 wavefronts per CU; profiles/r06/coop_crossover.log)
-constexpr int COOP_MAX_PER_CU = 24, COOP_BASE_MAX_PER_CU = 18, COOP_LADDER_MAX_PER_CU = 14, COOP_LADDER_ENC_MAX_PER_CU = 8, COOP_DECODE_MAX_PER_CU = 4,
+constexpr int COOP_MAX_PER_CU = 24, COOP_BASE_MAX_PER_CU = 18, COOP_LADDER_MAX_PER_CU = 14, COOP_LADDER_ENC_MAX_PER_CU = 6, COOP_DECODE_MAX_PER_CU = 4,
               COOP_VERIFY_MAX_PER_CU = 2, LADDER_PAIR_MAX_PER_CU = 128, LADDER_QUAD_MAX_PER_CU = 64;      // (128: two lanes per item up to one wavefront per SIMD = 4 SIMDs x 64 lanes / 2)
 void apply_cu_count(Ctx& g, int cus) {
   g.cus = cus;
   g.opt_coop_max = COOP_MAX_PER_CU * cus;                       // 6,144 on 256 CUs
   g.opt_coop_base_max = COOP_BASE_MAX_PER_CU * cus;             // 4,608
   g.opt_coop_ladder_max = COOP_LADDER_MAX_PER_CU * cus;         // 3,584
-  g.opt_coop_ladder_enc_max = COOP_LADDER_ENC_MAX_PER_CU * cus; // 2,048
+  g.opt_coop_ladder_enc_max = COOP_LADDER_ENC_MAX_PER_CU * cus; // 1,536 (2,048 until the batch forms behind it got four lanes per item: 289 / 346 us at 1,536 items, 459 / 344 at 2,048)
   g.opt_coop_decode_max = COOP_DECODE_MAX_PER_CU * cus;         // 1,024
   g.opt_coop_verify_max = COOP_VERIFY_MAX_PER_CU * cus;         // 512
   g.opt_ladder_pair_max = LADDER_PAIR_MAX_PER_CU * cus;         // 32,768
@@ -1660,7 +1660,7 @@ int launch_verify(Ctx& g, const uint8_t* pubs, const uint8_t* msgs, const uint32
   const size_t fork_max = g.opt_ladder_y_only != 0 && pair_lim(g, g.opt_ladder_pair_max) > (size_t)64 * (size_t)g.cus ? pair_lim(g, g.opt_ladder_pair_max) : (size_t)64 * (size_t)g.cus;
   const bool fork = g.opt_verify_overlap && n <= fork_max && host_load(g) < 4;      // with several calls in flight the other calls fill the idle SIMDs; a side stream only adds queue traffic
   const bool coop = g.opt_mul_algo == 1 && n <= coop_lim(g, g.opt_coop_max) && n <= coop_lim(g, g.opt_coop_base_max) &&
-                    (pubs_ext == nullptr ? n <= coop_lim(g, g.opt_coop_ladder_enc_max) : 8 * n <= 7 * coop_lim(g, g.opt_coop_ladder_max));     // small batch: one item per wavefront
+                    (pubs_ext == nullptr ? 6 * n <= 5 * coop_lim(g, g.opt_coop_ladder_enc_max) : 8 * n <= 7 * coop_lim(g, g.opt_coop_ladder_max));      // (from bytes: 260 / 350 us at 1,024 signatures, 380 / 352 at 1,536)     // small batch: one item per wavefront
   hipStream_t side = st;
   if (fork) {
     rc = ensure_aux(g, r); if (rc) return rc;

@@ -362,13 +362,13 @@ def test_every_routing_boundary_with_default_options(oracle, cus):
         n_cu = cus or hw
         opt = {k: eng.get_option(k) for k in ("coop.max_items", "coop.base_max_items", "coop.ladder_max_items", "coop.ladder_enc_max_items", "coop.decode_max_items",
                                               "coop.verify_max_items", "ladder.pair_max_items", "ladder.quad_max_items")}
-        assert opt == {"coop.max_items": 24 * n_cu, "coop.base_max_items": 18 * n_cu, "coop.ladder_max_items": 14 * n_cu, "coop.ladder_enc_max_items": 8 * n_cu,
+        assert opt == {"coop.max_items": 24 * n_cu, "coop.base_max_items": 18 * n_cu, "coop.ladder_max_items": 14 * n_cu, "coop.ladder_enc_max_items": 6 * n_cu,
                        "coop.decode_max_items": 4 * n_cu, "coop.verify_max_items": 2 * n_cu, "ladder.pair_max_items": 128 * n_cu, "ladder.quad_max_items": 64 * n_cu}, opt      # no absolute item count among the defaults
         # every size the routing of engine.hip compares a batch with, from these options (x/2, x/4, 2x, 7x/8: the derived comparisons there)
         marks = set()
         for v in opt.values():
             marks |= {v, v // 2, v // 4, 2 * v, 7 * v // 8}
-        marks |= {4 * n_cu, 5 * n_cu, 15 * n_cu // 4, 9 * n_cu, 128 * n_cu}      # (5: fixed base hands over to its four-wavefronts-per-64-items form, signing at 3/4 of it; 128: that form's last size)
+        marks |= {4 * n_cu, 5 * n_cu, 15 * n_cu // 4, 9 * n_cu, 128 * n_cu, 8 * n_cu}      # (5: fixed base hands over to its four-wavefronts-per-64-items form, signing at 3/4 of it; 128: that form's last size)
         sizes = sorted({n for m in marks for n in (m - 1, m, m + 1) if 1 <= n <= 24 * n_cu + 1 and n <= 6200})
         nmax = max(sizes)
         s = synth.raw256(nmax, 31); s[::7] = synth.scalars(len(s[::7]), 32)
