@@ -274,6 +274,55 @@ void hd_mul_ladder_proj(uint8_t out[32], const uint8_t scalar[32], const int32_t
   ge_encode(w, r.X, r.Y, r.Z);
   memcpy(out, w, 32);
 }
+// The four-lane ladder (ge_ladder_quad.h is device code: DPP lane moves) as a HOST MODEL of the same data flow — the four lanes of an item are the
+// four elements of an array, quad_perm is indexing, the per-lane selections are those of mont_ladder_quad line by line — so that the formulas and
+// the limb BOUNDS of every operation of that kernel run under the overflow-checked host build (kyb_add32 / kyb_sub32 / the column checks of fe_mul).
+void hd_mul_ladder_quad_model(uint8_t out[32], const uint8_t scalar[32], const int32_t pt[40], int skip) {
+  uint32_t a[8], w[8], neg, mag[8];
+  load_words(a, scalar);
+  ge_p3 P;
+  fe_from_ref10(P.X, pt); fe_from_ref10(P.Y, pt + 10); fe_from_ref10(P.Z, pt + 20); fe_from_ref10(P.T, pt + 30);
+  sc_effective(neg, mag, a);
+  mont_point_proj m;
+  mont_prep_proj(m, P);
+  fe one, zero, st[4], U[4];
+  uint32_t U19[4][10];
+  fe_one(one); fe_zero(zero);
+  fe_copy(st[0], m.U); fe_copy(st[1], m.W); fe_copy(st[2], one); fe_copy(st[3], zero);      // x3 | z3 | x2 | z2
+  fe_copy(U[0], m.W); fe_copy(U[1], m.U); fe_copy(U[2], one); fe_copy(U[3], one);
+  for (int q = 0; q < 4; ++q) fe_x19(U19[q], U[q]);
+  uint32_t swap = 0;
+  for (int i = 255 - skip; i >= 0; --i) {
+    const uint32_t bit = (mag[i >> 5] >> (i & 31)) & 1u;
+    swap ^= bit;
+    fe sd[4], X[4], F[4], G[4], r1[4], Y1[4], Y2[4], T[4], g[4], r2[4];
+    for (int q = 0; q < 4; ++q) { const fe& p = st[q ^ 1]; if (q & 1) fe_sub(sd[q], p, st[q]); else fe_add(sd[q], p, st[q]); }      // c | d | a | b
+    const int cross[4] = {2, 3, 1, 0};
+    for (int q = 0; q < 4; ++q) fe_copy(X[q], sd[cross[q]]);
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t hi = (uint32_t)(q >> 1);
+      fe_select(F[q], X[q], sd[q], hi | swap);
+      fe_select(G[q], F[q], X[q], hi);
+    }
+    swap = bit;
+    for (int q = 0; q < 4; ++q) fe_mul(r1[q], F[q], G[q]);      // aa | bb | da | cb
+    for (int q = 0; q < 4; ++q) { fe_copy(Y1[q], r1[q < 2 ? 2 : 0]); fe_copy(Y2[q], r1[q < 2 ? 3 : 1]); }
+    for (int q = 0; q < 4; ++q) { if (q & 1) fe_sub(T[q], Y1[q], Y2[q]); else fe_add(T[q], Y1[q], Y2[q]); }
+    for (int q = 0; q < 4; ++q) { fe_mul_small(g[q], T[q], q == 3 ? 121665u : 0u); fe_addw(g[q], g[q], Y1[q]); }
+    for (int q = 0; q < 4; ++q) {
+      fe_select(F[q], T[q], Y1[q], (uint32_t)(q == 2));
+      fe_select(G[q], T[q], g[q], (uint32_t)(q == 3));
+      fe_select(G[q], G[q], Y2[q], (uint32_t)(q == 2));
+    }
+    for (int q = 0; q < 4; ++q) fe_mul(r2[q], F[q], G[q]);
+    for (int q = 0; q < 4; ++q) fe_mul_g19<true>(st[q], r2[q], U[q], U19[q]);
+  }
+  if (swap) { fe t; fe_copy(t, st[0]); fe_copy(st[0], st[2]); fe_copy(st[2], t); fe_copy(t, st[1]); fe_copy(st[1], st[3]); fe_copy(st[3], t); }
+  ge_p2 r;
+  mont_recover_to_edwards_proj(r, m, st[2], st[3], st[0], st[1], mag[0] & 1u, neg);
+  ge_encode(w, r.X, r.Y, r.Z);
+  memcpy(out, w, 32);
+}
 // the flow of kyb_lincomb_batch for one group: t ladder multiplications, the halving passes of k_pair_sum, encode
 void hd_lincomb(uint8_t out[32], const uint8_t* scalars, const int32_t* pts, int t) {
   std::vector<ge_p2> v((size_t)t);
@@ -378,6 +427,33 @@ void hd_mul_base64(uint8_t out[32], const uint8_t scalar[32]) {
   ge_p3 h;
   ge_scalarmult_base64(h, a, tbl);
   ge_encode(w, h.X, h.Y, h.Z);
+  memcpy(out, w, 32);
+}
+// the same as k_mul_base64_quarters forms it (kernels_base.hip): four partial sums over a quarter of the windows each, added up as that kernel adds them
+// (a staged part comes back as X, Y, Z only)
+void hd_mul_base64_quarters(uint8_t out[32], const uint8_t scalar[32]) {
+  uint8_t whole[32];
+  hd_mul_base64(whole, scalar);          // (builds the table)
+  uint32_t a[8], w[8];
+  load_words(a, scalar);
+  tbl_base64_words tbl{g_base64_table.data()};
+  ge_p3 part[4];
+  for (int q = 0; q < 4; ++q) ge_scalarmult_base64_part(part[q], a, tbl, 11 * q, q == 3 ? KYB_BASE64_POS : 11 * q + 11);
+  auto add_staged = [](ge_p3& h, const ge_p3& other) {
+    ge_p2 b;
+    fe_copy(b.X, other.X); fe_copy(b.Y, other.Y); fe_copy(b.Z, other.Z);
+    ge_p3 B;
+    ge_p2_to_p3(B, b);
+    ge_cached c;
+    ge_p3_to_cached(c, B);
+    ge_p1p1 t;
+    ge_add(t, h, c);
+    ge_p1p1_to_p3(h, t);
+  };
+  add_staged(part[0], part[2]);
+  add_staged(part[1], part[3]);
+  add_staged(part[0], part[1]);
+  ge_encode(w, part[0].X, part[0].Y, part[0].Z);
   memcpy(out, w, 32);
 }
 void hd_eddsa_sign(uint8_t sig[64], const uint8_t seed[32], const uint8_t* msg, uint32_t n) {

@@ -399,6 +399,8 @@ def test_ladder_path_matches_oracle(hd, oracle):
         assert o.raw.hex() == q["out"], q
         o = B(32); hd.hd_mul_ladder_proj(o, bytes.fromhex(q["scalar"]), p32(ext), 0)      # projective-base variant (small-batch kernel)
         assert o.raw.hex() == q["out"], q
+        o = B(32); hd.hd_mul_ladder_quad_model(o, bytes.fromhex(q["scalar"]), p32(ext), 0)
+        assert o.raw.hex() == q["out"], q
     weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
     for i in range(120):
         s = bytes(rnd.getrandbits(8) for _ in range(32))
@@ -413,6 +415,8 @@ def test_ladder_path_matches_oracle(hd, oracle):
             pz = oracle.add(oracle.add(pt, weak[0]), weak[0], sub=True)                     # the same point with Z != 1
             o = B(32); hd.hd_mul_ladder_proj(o, s, p32(pz), 0)
             assert o.raw == oracle.mul(s, pt), (i, s.hex())
+            o = B(32); hd.hd_mul_ladder_quad_model(o, s, p32(pz), 0)                         # the four-lane ladder's data flow (ge_ladder_quad.h), lanes as array elements
+            assert o.raw == oracle.mul(s, pt), (i, s.hex())
     # verification multiplies by h < L < 2^253: the ladder may start three bits lower
     for v in [0, 1, 2, M.L - 1, M.L - 2, 2**252, 2**252 - 1, 2**252 + 12345] + [rnd.randrange(M.L) for _ in range(40)]:
         s = v.to_bytes(32, "little")
@@ -420,6 +424,8 @@ def test_ladder_path_matches_oracle(hd, oracle):
         o = B(32); hd.hd_mul_ladder_skip(o, s, p32(pt), 3)
         assert o.raw == oracle.mul(s, pt), v
         o = B(32); hd.hd_mul_ladder_proj(o, s, p32(pt), 3)
+        assert o.raw == oracle.mul(s, pt), v
+        o = B(32); hd.hd_mul_ladder_quad_model(o, s, p32(pt), 3)
         assert o.raw == oracle.mul(s, pt), v
     assert hd.hd_overflows() == base
 
@@ -461,6 +467,9 @@ def test_fixed_base_radix64_matches_oracle(hd, oracle):
     for s in cases:
         o = B(32); hd.hd_mul_base64(o, s)
         assert o.raw == oracle.mul_base(s), s.hex()
+        # ... and in four quarters of the windows added up, as the mid-size kernel forms it (k_mul_base64_quarters)
+        o4 = B(32); hd.hd_mul_base64_quarters(o4, s)
+        assert o4.raw == o.raw, s.hex()
     assert hd.hd_overflows() == base
 
 
