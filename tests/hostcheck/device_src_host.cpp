@@ -323,6 +323,37 @@ void hd_mul_ladder_quad_model(uint8_t out[32], const uint8_t scalar[32], const i
   ge_encode(w, r.X, r.Y, r.Z);
   memcpy(out, w, 32);
 }
+// k_finish_wave (kernels_coop.hip) as a HOST MODEL: the 64 lanes of a wavefront are 64 array elements — the butterfly product of the Z's (lane l takes the
+// sub-product of lane l ^ 2^j at level j and keeps it), ONE inversion of what every lane then holds, the six kept sub-products multiplied back on;
+// a zero Z counts as 1 and gets 0 as its inverse.  enc: 64 x 32 bytes out, pts: 64 x 40 reference limbs in.
+void hd_finish_wave_model(uint8_t* enc, const int32_t* pts) {
+  fe X[64], Y[64], P[64], Q[6][64], I[64], one, zero;
+  uint32_t z_zero[64];
+  fe_one(one); fe_zero(zero);
+  for (int l = 0; l < 64; ++l) {
+    fe Z;
+    fe_from_ref10(X[l], pts + 40 * l); fe_from_ref10(Y[l], pts + 40 * l + 10); fe_from_ref10(Z, pts + 40 * l + 20);
+    z_zero[l] = 1u - fe_is_nonzero(Z);
+    fe_copy(P[l], Z);
+    fe_cmov(P[l], one, z_zero[l]);
+  }
+  for (int j = 0; j < 6; ++j) {
+    for (int l = 0; l < 64; ++l) fe_copy(Q[j][l], P[l ^ (1 << j)]);
+    for (int l = 0; l < 64; ++l) fe_mul(P[l], P[l], Q[j][l]);
+  }
+  for (int l = 0; l < 64; ++l) {
+    fe_inv(I[l], P[l]);                                  // (the kernel inverts once, from the canonical words every lane agrees on)
+    for (int j = 5; j >= 0; --j) fe_mul(I[l], I[l], Q[j][l]);
+    fe_cmov(I[l], zero, z_zero[l]);
+    fe x, y;
+    fe_mul(x, X[l], I[l]);
+    fe_mul(y, Y[l], I[l]);
+    uint32_t w[8];
+    fe_to_words(w, y);
+    w[7] ^= fe_is_negative(x) << 31;
+    memcpy(enc + 32 * l, w, 32);
+  }
+}
 // the flow of kyb_lincomb_batch for one group: t ladder multiplications, the halving passes of k_pair_sum, encode
 void hd_lincomb(uint8_t out[32], const uint8_t* scalars, const int32_t* pts, int t) {
   std::vector<ge_p2> v((size_t)t);

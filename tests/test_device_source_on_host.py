@@ -430,6 +430,32 @@ def test_ladder_path_matches_oracle(hd, oracle):
     assert hd.hd_overflows() == base
 
 
+def test_one_inversion_per_wavefront_model(hd, oracle):
+    """k_finish_wave's Montgomery trick across the 64 lanes of a wavefront (butterfly product, one inversion, six kept sub-products multiplied back on)
+    as a host model through the overflow-checked build: 64 projective points — sums, the neutral element, small-order points, Z = 0 garbage in three
+    lanes — encode as the oracle encodes them one by one; the garbage gets the reference's (0, 0) and disturbs nobody"""
+    import numpy as np
+    base = hd.hd_overflows()
+    rnd = random.Random(66)
+    weak = [oracle.decode(bytes.fromhex(h))[0] for h in KATS["weak_keys"]]
+    pts = []
+    for l in range(64):
+        p = oracle.mul_base_ext(bytes(rnd.getrandbits(8) for _ in range(32)))
+        q = oracle.mul_base_ext(bytes(rnd.getrandbits(8) for _ in range(32)))
+        pts.append(oracle.add(p, q))                                   # Z != 1
+    pts[3], pts[17], pts[40] = oracle.null(), weak[1], oracle.add(pts[40], weak[2])
+    want = [oracle.encode(p) for p in pts]
+    arr = np.stack(pts).astype(np.int32)
+    for bad in (0, 31, 63):
+        arr[bad, 20:30] = 0                                            # Z = 0
+        want[bad] = bytes(32)
+    out = B(64 * 32)
+    hd.hd_finish_wave_model(out, arr.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    for l in range(64):
+        assert out.raw[32 * l: 32 * l + 32] == want[l], l
+    assert hd.hd_overflows() == base
+
+
 def test_fixed_base_radix32_matches_oracle(hd, oracle):
     """52-window signed radix-32 fixed-base multiplication (sc_effective + sc_recode32) == the
     reference's 64-window routine, quirk scalars included"""
