@@ -187,6 +187,17 @@ void hd_sha512(uint8_t out[64], const uint8_t* msg, uint32_t n) {
   sha512_final(d, c);
   memcpy(out, d, 64);
 }
+// the same message absorbed in two calls cut anywhere: the second starts at a block position that is not a multiple of 8 (head bytes one by one, then
+// eight per step, then the tail)
+void hd_sha512_split(uint8_t out[64], const uint8_t* msg, uint32_t n, uint32_t cut) {
+  sha512_ctx c;
+  sha512_init(c);
+  sha512_bytes(c, msg, cut);
+  sha512_bytes(c, msg + cut, n - cut);
+  uint32_t d[16];
+  sha512_final(d, c);
+  memcpy(out, d, 64);
+}
 void hd_schnorr_sign(uint8_t sig[64], const uint8_t x[32], const uint8_t k[32], const uint8_t* msg, uint32_t n) {
   ensure_table();
   uint32_t wx[8], wk[8], s[16];

@@ -208,6 +208,9 @@ def test_scalar_mod_l_and_sha512(hd):
         m = bytes(rnd.getrandbits(8) for _ in range(n)); o = B(64)
         hd.hd_sha512(o, m, n)
         assert o.raw == hashlib.sha512(m).digest()
+        for cut in sorted({c for c in (0, 1, 3, 7, 8, 9, 63, 64, 65, 120, 127, 128, 131, n // 2, n - 1, n) if 0 <= c <= n}):      # sha512_bytes from any block position
+            o = B(64); hd.hd_sha512_split(o, m, n, cut)
+            assert o.raw == hashlib.sha512(m).digest(), (n, cut)
 
 
 def test_sign_golden_lines(hd, oracle):
